@@ -1,0 +1,257 @@
+/*
+ * surge_replay.h — C ABI of the MI355X-native aggregate-replay engine.
+ *
+ * This is the drop-in boundary for ONE hot path of UltimateSoftware/surge: the
+ * per-aggregate event fold that reconstructs the aggregate state store.  The
+ * reference is 100 % JVM and has no FFI; the entry points below are what a JNI
+ * shim binds so that the engine can sit behind the
+ * reference's own seams.  Citations are into /root/reference (read-only):
+ *
+ *   R2  the fold                events.foldLeft(state)(handleEvent)
+ *       modules/command-engine/scaladsl/src/main/scala/surge/scaladsl/command/CommandModels.scala:20,26
+ *   S1  persistence plugin      SurgeKafkaStreamsPersistencePlugin.createSupplier
+ *       modules/common/src/main/scala/surge/kafka/streams/SurgeKafkaStreamsPersistencePlugin.scala:12-15
+ *   S2  state read seam         AggregateStateStoreKafkaStreams.getAggregateBytes
+ *       modules/common/src/main/scala/surge/kafka/streams/AggregateStateStoreKafkaStreams.scala:83-85
+ *   R12 store-side recovery     SurgeStateStoreConsumer.ktableIndexingTopology
+ *       modules/common/src/main/scala/surge/kafka/streams/SurgeStateStoreConsumer.scala:57-76
+ *   R15 shard map               KafkaPartitionProvider.partitionForKey
+ *       modules/common/src/main/scala/surge/kafka/KafkaPartitioner.scala:8,38-42
+ *
+ * Conventions
+ *   - plain C, no exceptions across the boundary; every function returns an
+ *     int32 status (0 = OK, negative = error class, see SURGE_E_*).
+ *   - surge_replay_last_error(h) returns a NUL-terminated message owned by the
+ *     handle (or by the calling thread when h == NULL).
+ *   - all buffers are caller-allocated.  "host" buffers are ordinary process
+ *     memory (JNI passes DirectByteBuffer addresses); "_device" entry points
+ *     take HIP device pointers (the Python host passes torch tensor pointers).
+ *   - one handle per GPU; mutation of a handle is NOT thread-safe, reads
+ *     (surge_replay_get after a snapshot) are.
+ *   - There is NO CPU fallback inside this library: without a usable HIP device
+ *     surge_replay_create fails with SURGE_E_DEVICE.
+ */
+#ifndef SURGE_REPLAY_H
+#define SURGE_REPLAY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SURGE_REPLAY_ABI_VERSION 1u
+
+/* ---- status codes --------------------------------------------------------- */
+#define SURGE_OK             0
+#define SURGE_E_INVALID     (-1) /* bad argument (NULL, negative size, non-monotone seg_off ...) */
+#define SURGE_E_STATE       (-2) /* call order (fold before load, get before fold ...)           */
+#define SURGE_E_DEVICE      (-3) /* HIP runtime error / no device                               */
+#define SURGE_E_NOMEM       (-4) /* host or device allocation failed                            */
+#define SURGE_E_UNSUPPORTED (-5) /* schema / algorithm not supported by this build              */
+#define SURGE_E_RANGE       (-6) /* aggregate index out of range                                */
+
+/* ---- fixed-width layouts (little-endian) ----------------------------------
+ *
+ * The reference has no fixed-width format (states are JSON); these
+ * layouts are the engine's restatement of the reference fixtures' fields:
+ *   count/version  <- Counter  State(aggregateId, count:Int, version:Int)
+ *       modules/command-engine/scaladsl/src/test/scala/surge/scaladsl/TestBoundedContext.scala:15
+ *   balance        <- BankAccount(..., balance: Double)
+ *       modules/surge-docs/src/test/scala/docs/command/BankAccountCommandModel.scala:19
+ * Aggregate-id strings never cross this boundary: callers keep a key table and
+ * address aggregates by dense index.
+ */
+typedef struct surge_event16 {
+  int32_t type;        /* index into surge_replay_schema.desc; out of range => poison */
+  int32_t seq;         /* sequenceNumber of the event (TestBoundedContext.scala:51)  */
+  union {
+    struct { int32_t arg; int32_t pad; } i; /* integer payload (incrementBy / decrementBy) */
+    double value;                           /* f64 payload (balance / newBalance)          */
+    uint64_t raw;
+  } p;
+} surge_event16;
+
+#define SURGE_STATE_PRESENT  1u /* flags bit0: Some(...) vs None                       */
+#define SURGE_STATE_POISONED 2u /* flags bit1: an event "threw"; state frozen before it */
+
+typedef struct surge_state64 {
+  int32_t  count;       /*  0 */
+  int32_t  version;     /*  4 */
+  int64_t  sum64;       /*  8 */
+  double   balance;     /* 16  (moved bit-exactly, never computed on)                  */
+  int32_t  min_arg;     /* 24 */
+  int32_t  max_arg;     /* 28 */
+  uint32_t event_count; /* 32 */
+  uint32_t flags;       /* 36  SURGE_STATE_*                                           */
+  uint8_t  reserved[24];/* 40  always zero                                             */
+} surge_state64;
+/* Canonical encoding of None: all 64 bytes zero except possibly SURGE_STATE_POISONED. */
+
+/* ---- event algebra -------------------------------------
+ * handleEvent is arbitrary JVM code (CommandModels.scala:14) and cannot run on
+ * a GPU.  A plugin declares, beside its handleEvent, one 32-bit descriptor per
+ * event type; the descriptor is the kernel-able restatement of that case of
+ * handleEvent.  Presence classes are literal readings of the fixtures:
+ *   MATERIALIZE  agg.getOrElse(State(id,0,0)) then update, always Some
+ *                (TestBoundedContext.scala:78,88)
+ *   REQUIRE      aggregate.map(_.copy(...)): dropped when None
+ *                (BankAccountCommandModel.scala:84)
+ *   CREATE       Some(<built only from the event>): overwrites
+ *                (BankAccountCommandModel.scala:83)
+ *   DELETE       handleEvent returns None => tombstone (SurgeModel.scala:62)
+ */
+#define SURGE_CLS_MATERIALIZE 0u
+#define SURGE_CLS_REQUIRE     1u
+#define SURGE_CLS_CREATE      2u
+#define SURGE_CLS_DELETE      3u
+#define SURGE_CLS_MASK        3u
+#define SURGE_D_POISON        (1u << 2)  /* handleEvent throws (TestBoundedContext.scala:86) */
+#define SURGE_D_COUNT_ADD     (1u << 4)  /* count += arg  (32-bit wrap, JVM Int)             */
+#define SURGE_D_COUNT_SUB     (2u << 4)  /* count -= arg                                     */
+#define SURGE_D_COUNT_SET     (3u << 4)  /* count  = arg                                     */
+#define SURGE_D_COUNT_MASK    (3u << 4)
+#define SURGE_D_VERSION_SET   (1u << 6)  /* version = seq                                    */
+#define SURGE_D_SUM_ADD       (1u << 8)  /* sum64 += (int64)arg                              */
+#define SURGE_D_SUM_SUB       (2u << 8)  /* sum64 -= (int64)arg                              */
+#define SURGE_D_SUM_MASK      (3u << 8)
+#define SURGE_D_BALANCE_SET   (1u << 10) /* balance = value (bit copy)                       */
+#define SURGE_D_MIN_ARG       (1u << 11) /* min_arg = min(min_arg, arg)                      */
+#define SURGE_D_MAX_ARG       (1u << 12) /* max_arg = max(max_arg, arg)                      */
+#define SURGE_D_EVCOUNT_INC   (1u << 13) /* event_count += 1                                 */
+
+#define SURGE_MAX_EVENT_TYPES 16
+
+typedef struct surge_replay_schema {
+  uint32_t abi_version;              /* SURGE_REPLAY_ABI_VERSION                    */
+  uint32_t state_size;               /* must be 64                                  */
+  uint32_t event_size;               /* must be 16                                  */
+  uint32_t n_types;                  /* 1..SURGE_MAX_EVENT_TYPES                    */
+  uint32_t desc[SURGE_MAX_EVENT_TYPES];
+  surge_state64 default_state;       /* fields an absent aggregate materialises to;
+                                        flags/reserved ignored                      */
+} surge_replay_schema;
+
+/* Built-in event types of the reference fixtures' algebra (default schema). */
+#define SURGE_EVT_NOOP        0 /* NoOpEvent            TestBoundedContext.scala:63,85    */
+#define SURGE_EVT_INC         1 /* CountIncremented     TestBoundedContext.scala:55,81-82 */
+#define SURGE_EVT_DEC         2 /* CountDecremented     TestBoundedContext.scala:59,83-84 */
+#define SURGE_EVT_CREATE      3 /* BankAccountCreated   BankAccountCommandModel.scala:39,83 */
+#define SURGE_EVT_SET_BALANCE 4 /* BankAccountUpdated   BankAccountCommandModel.scala:46,84 */
+#define SURGE_EVT_DELETE      5 /* handleEvent => None  SurgeModel.scala:62 (tombstone)  */
+#define SURGE_EVT_THROW       6 /* ExceptionThrowingEvent TestBoundedContext.scala:67,86 */
+
+/* ---- fold algorithms -------------------------------------------------------- */
+#define SURGE_ALGO_AUTO  0 /* FIXED when every segment has the same length L, L % 16 == 0; else FLAT */
+#define SURGE_ALGO_FIXED 1 /* K1: fixed fan-in, segment heads computed arithmetically              */
+#define SURGE_ALGO_FLAT  2 /* K2: load-balanced flat segmented scan over the CSR                  */
+
+typedef struct surge_replay_stats_t {
+  int64_t n_aggregates;
+  int64_t n_events;
+  int64_t algorithmic_bytes;   /* 16*E + 8*(A+1) + 64*A*(1+r)                  */
+  double  last_fold_kernel_ms; /* HIP-event time of the dominant fold kernel, last launch */
+  double  last_fold_total_ms;  /* HIP-event time of the whole fold (plan + fold + fill)    */
+  double  h2d_ms;              /* last load_csr / append_fold host->device copy           */
+  int32_t last_algo;           /* SURGE_ALGO_* actually run                               */
+  int32_t n_tasks;             /* wave tasks of the last fold                             */
+  int64_t n_folds;             /* folds since create                                      */
+  int64_t n_poisoned;          /* aggregates flagged POISONED by the last snapshot, -1 if unknown */
+} surge_replay_stats_t;
+
+typedef struct surge_replay_handle surge_replay_handle;
+
+/* ---- lifecycle -------------------------------------------------------------- */
+
+/* Fills *out with the built-in algebra (Counter + BankAccount fixtures). */
+int32_t surge_replay_default_schema(surge_replay_schema* out);
+
+/* Binds a schema to one GPU.  Replaces: constructing the KTable store behind
+ * SurgeKafkaStreamsPersistencePlugin.createSupplier (…PersistencePlugin.scala:13). */
+int32_t surge_replay_create(const surge_replay_schema* schema, int32_t device_id,
+                            surge_replay_handle** out);
+int32_t surge_replay_destroy(surge_replay_handle* h);
+const char* surge_replay_last_error(const surge_replay_handle* h);
+
+/* Launch all work of this handle on the given hipStream_t (NULL = default stream). */
+int32_t surge_replay_set_stream(surge_replay_handle* h, void* hip_stream);
+int32_t surge_replay_synchronize(surge_replay_handle* h);
+
+/* ---- load -------------------------------------------------------------------
+ * One shard's CSR-packed event log.  Events of aggregate a are
+ * events[seg_off[a] .. seg_off[a+1]) in publish (Kafka offset) order — what one
+ * partition of the events topic holds for keys "<id>:<seq>" under
+ * PartitionStringUpToColon (KafkaPartitioner.scala:38-42).
+ * init_state (nullable, n_agg x 64 B) is a prior snapshot to fold onto.
+ * Replaces: the Kafka Streams restore consumer feeding RocksDB
+ * (SurgeStateStoreConsumer.scala:57-76).
+ */
+int32_t surge_replay_load_csr(surge_replay_handle* h, const int64_t* seg_off, int64_t n_agg,
+                              const void* events, int64_t n_events, const void* init_state);
+
+/* Zero-copy variant: all pointers are device pointers that stay valid until the
+ * next load/bind or destroy.  d_state_out (nullable) receives the n_agg x 64 B
+ * result; when NULL the handle allocates it. */
+int32_t surge_replay_bind_device_csr(surge_replay_handle* h, const int64_t* d_seg_off,
+                                     int64_t n_agg, const void* d_events, int64_t n_events,
+                                     const void* d_init_state, void* d_state_out);
+
+/* ---- fold (R2) ----------------------------------------------------------------
+ * state[a] = events[seg_off[a]..seg_off[a+1]).foldLeft(init[a])(handleEvent)
+ * (CommandModels.scala:26).  Result stays device-resident.  Asynchronous on the
+ * handle's stream. */
+int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo);
+
+/* Streaming micro-batch (K3): for every group g,
+ *   state[group_agg[g]] = events[group_off[g]..group_off[g+1]).foldLeft(state[group_agg[g]])(handleEvent)
+ * Groups are order-preserving and each aggregate appears at most once per batch.
+ * Replaces: PersistentActor.doApplyEvent -> callEventHandler for many aggregates
+ * at once (PersistentActor.scala:245-272).  Host buffers. */
+int32_t surge_replay_append_fold(surge_replay_handle* h, const int64_t* group_agg,
+                                 const int64_t* group_off, int64_t n_groups,
+                                 const void* events, int64_t n_events);
+int32_t surge_replay_append_fold_device(surge_replay_handle* h, const int64_t* d_group_agg,
+                                        const int64_t* d_group_off, int64_t n_groups,
+                                        const void* d_events, int64_t n_events);
+
+/* ---- read (S2) ------------------------------------------------------------------
+ * Point read of the recovered state; serves
+ * AggregateStateStoreKafkaStreams.getAggregateBytes (…KafkaStreams.scala:83-85)
+ * after the plugin's writeState re-attaches the aggregate id.  *present_out = 0
+ * means None (KTable miss / tombstone).  Thread-safe once surge_replay_snapshot
+ * has published a host mirror for the current fold epoch. */
+int32_t surge_replay_get(surge_replay_handle* h, int64_t agg_idx, void* state64_out,
+                         uint8_t* present_out);
+
+/* Bulk device->host copy of all states (+ presence bytes, nullable); also
+ * publishes the host mirror used by surge_replay_get. */
+int32_t surge_replay_snapshot(surge_replay_handle* h, void* states_out, uint8_t* present_out);
+
+/* Device pointer of the resident n_agg x 64 B state array (for the host layer's
+ * RCCL all-gather of the final snapshot). */
+int32_t surge_replay_device_state(surge_replay_handle* h, void** d_states, int64_t* n_agg);
+
+/* ---- shard map (R15) --------------------------------------------------------------
+ * part_out[i] = abs(MurmurHash3.stringHash(str_i.takeWhile(_ != ':')) % n_partitions)
+ * (KafkaPartitioner.scala:8,38-42) for n strings given as UTF-16 code units
+ * utf16[str_off[i] .. str_off[i+1]).  CPU (host buffers) and GPU (K4, device
+ * buffers) variants give identical results. */
+int32_t surge_replay_partition_hash(const uint16_t* utf16, const int64_t* str_off, int64_t n,
+                                    int32_t n_partitions, int32_t* part_out);
+int32_t surge_replay_partition_hash_device(surge_replay_handle* h, const uint16_t* d_utf16,
+                                           const int64_t* d_str_off, int64_t n,
+                                           int32_t n_partitions, int32_t* d_part_out);
+
+/* ---- measurement --------------------------------------------------------------- */
+int32_t surge_replay_stats(surge_replay_handle* h, surge_replay_stats_t* out);
+
+/* HBM read-stream ceiling probe: reads n_bytes (multiple of 16) from d_src with
+ * 16 B/lane loads and returns the HIP-event time of one launch.  Used by
+ * bench.py to report the achievable streaming ceiling beside the 8 TB/s spec. */
+int32_t surge_replay_stream_probe(surge_replay_handle* h, const void* d_src, int64_t n_bytes,
+                                  double* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SURGE_REPLAY_H */

@@ -1,0 +1,364 @@
+/*
+ * surge_fold_oracle.c — CPU restatement of the reference's aggregate fold.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under surge_amd/ may include, link or call
+ * this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg use it, and only as the checker / reported baseline.
+ *
+ * PARITY STATUS: the reference is JVM-only and cannot be built or run in this
+ * image (no JVM, sbt or jars), and it ships no golden files.  The
+ * fold below is pinned against the explicit expected values in the reference's
+ * own specs (tests/test_oracle_kat.py, SURVEY §8c KAT 1-7).  Two third-party
+ * behaviours are "parity unpinned" (no reference test fixes their bytes):
+ *   - scala.util.hashing.MurmurHash3.stringHash (scala-library 2.13.8) used by
+ *     KafkaPartitioner.scala:8 — restated from the published algorithm;
+ *   - play-json 2.9.2 number/text formatting used by TestBoundedContext.scala:127-133.
+ *
+ * Everything here is written as a literal, sequential, one-event-at-a-time
+ * reading of the Scala code it cites — deliberately NOT the transformer-monoid
+ * formulation the GPU kernels use, so that agreement between the two means
+ * something.
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <stdio.h>
+#include <pthread.h>
+
+#include "../include/surge_replay.h"
+
+/* Option[State]: `present` is Some/None; `poisoned` models "handleEvent threw". */
+typedef struct {
+  int present;
+  int poisoned;
+  int32_t count, version;
+  int64_t sum64;
+  uint64_t balance_bits;
+  int32_t min_arg, max_arg;
+  uint32_t event_count;
+} opt_state;
+
+static void from_state64(const surge_state64* s, opt_state* o) {
+  uint64_t bits;
+  memcpy(&bits, &s->balance, 8);
+  o->present = (s->flags & SURGE_STATE_PRESENT) != 0;
+  o->poisoned = (s->flags & SURGE_STATE_POISONED) != 0;
+  o->count = s->count;
+  o->version = s->version;
+  o->sum64 = s->sum64;
+  o->balance_bits = bits;
+  o->min_arg = s->min_arg;
+  o->max_arg = s->max_arg;
+  o->event_count = s->event_count;
+}
+
+static void to_state64(const opt_state* o, surge_state64* s) {
+  memset(s, 0, sizeof(*s));
+  if (o->present) {
+    s->count = o->count;
+    s->version = o->version;
+    s->sum64 = o->sum64;
+    memcpy(&s->balance, &o->balance_bits, 8);
+    s->min_arg = o->min_arg;
+    s->max_arg = o->max_arg;
+    s->event_count = o->event_count;
+    s->flags |= SURGE_STATE_PRESENT;
+  }
+  if (o->poisoned) s->flags |= SURGE_STATE_POISONED;
+}
+
+/* `agg.getOrElse(State(evt.aggregateId, 0, 0))` — TestBoundedContext.scala:78 */
+static void materialise_default(const surge_replay_schema* sc, opt_state* o) {
+  opt_state d;
+  from_state64(&sc->default_state, &d);
+  o->present = 1;
+  o->count = d.count;
+  o->version = d.version;
+  o->sum64 = d.sum64;
+  o->balance_bits = d.balance_bits;
+  o->min_arg = d.min_arg;
+  o->max_arg = d.max_arg;
+  o->event_count = d.event_count;
+}
+
+/* The field updates of one case of handleEvent, applied to a Some(current).
+ * JVM Int arithmetic wraps mod 2^32 (TestBoundedContext.scala:82,84): do the
+ * adds in uint32 so C has no signed-overflow UB. */
+static void update_fields(uint32_t d, const surge_event16* ev, opt_state* o) {
+  switch (d & SURGE_D_COUNT_MASK) {
+    case SURGE_D_COUNT_ADD: o->count = (int32_t)((uint32_t)o->count + (uint32_t)ev->p.i.arg); break;
+    case SURGE_D_COUNT_SUB: o->count = (int32_t)((uint32_t)o->count - (uint32_t)ev->p.i.arg); break;
+    case SURGE_D_COUNT_SET: o->count = ev->p.i.arg; break;
+    default: break;
+  }
+  if (d & SURGE_D_VERSION_SET) o->version = ev->seq;
+  switch (d & SURGE_D_SUM_MASK) {
+    case SURGE_D_SUM_ADD: o->sum64 = (int64_t)((uint64_t)o->sum64 + (uint64_t)(int64_t)ev->p.i.arg); break;
+    case SURGE_D_SUM_SUB: o->sum64 = (int64_t)((uint64_t)o->sum64 - (uint64_t)(int64_t)ev->p.i.arg); break;
+    default: break;
+  }
+  if (d & SURGE_D_BALANCE_SET) o->balance_bits = ev->p.raw;
+  if ((d & SURGE_D_MIN_ARG) && ev->p.i.arg < o->min_arg) o->min_arg = ev->p.i.arg;
+  if ((d & SURGE_D_MAX_ARG) && ev->p.i.arg > o->max_arg) o->max_arg = ev->p.i.arg;
+  if (d & SURGE_D_EVCOUNT_INC) o->event_count += 1u;
+}
+
+/*
+ * handleEvent(aggregate: Option[Agg], event: Evt): Option[Agg]
+ * — CommandModels.scala:14, as declared by the schema's descriptor for the
+ * event's type.  Returns nonzero when the event "throws".
+ *
+ *   MATERIALIZE  TestBoundedContext.scala:77-89
+ *   REQUIRE      BankAccountCommandModel.scala:84
+ *   CREATE       BankAccountCommandModel.scala:83
+ *   DELETE       Option[Agg] = None (tombstone, SurgeModel.scala:62)
+ *   throw        TestBoundedContext.scala:86 ; caller keeps the old state
+ *                (PersistentActor.scala:260-263)
+ */
+static int handle_event(const surge_replay_schema* sc, opt_state* agg, const surge_event16* ev) {
+  uint32_t d;
+  if (ev->type < 0 || (uint32_t)ev->type >= sc->n_types) return 1; /* no such case: MatchError */
+  d = sc->desc[ev->type];
+  if (d & SURGE_D_POISON) return 1;
+  switch (d & SURGE_CLS_MASK) {
+    case SURGE_CLS_DELETE:
+      agg->present = 0;
+      return 0;
+    case SURGE_CLS_REQUIRE:
+      if (!agg->present) return 0; /* aggregate.map(...) on None */
+      update_fields(d, ev, agg);
+      return 0;
+    case SURGE_CLS_CREATE:
+      materialise_default(sc, agg); /* Some(<built only from the event>) */
+      update_fields(d, ev, agg);
+      return 0;
+    default: /* SURGE_CLS_MATERIALIZE */
+      if (!agg->present) materialise_default(sc, agg);
+      update_fields(d, ev, agg);
+      return 0;
+  }
+}
+
+/* One step, exposed for the known-answer tests. */
+int32_t oracle_handle_event(const surge_replay_schema* sc, const surge_state64* in,
+                            const surge_event16* ev, surge_state64* out) {
+  opt_state o;
+  from_state64(in, &o);
+  if (!o.poisoned && handle_event(sc, &o, ev)) o.poisoned = 1;
+  to_state64(&o, out);
+  return 0;
+}
+
+/*
+ * events.foldLeft(state)((stateAccum, evt) => handleEvent(stateAccum, evt))
+ * — CommandModels.scala:26 — for aggregates [a0, a1).  Replay semantics for a
+ * throwing event (the reference defines none for replay; PersistentActor.scala:
+ * 260-263 keeps the pre-event state): stop at the first throwing event, keep the
+ * state before it, flag the aggregate POISONED.
+ */
+static void fold_range(const surge_replay_schema* sc, const int64_t* seg_off, int64_t a0, int64_t a1,
+                       const surge_event16* events, const surge_state64* init, surge_state64* out) {
+  int64_t a, e;
+  for (a = a0; a < a1; ++a) {
+    opt_state acc;
+    if (init) {
+      from_state64(&init[a], &acc);
+    } else {
+      memset(&acc, 0, sizeof(acc)); /* None */
+    }
+    for (e = seg_off[a]; e < seg_off[a + 1] && !acc.poisoned; ++e) {
+      if (handle_event(sc, &acc, &events[e])) acc.poisoned = 1;
+    }
+    to_state64(&acc, &out[a]);
+  }
+}
+
+int32_t oracle_fold_csr(const surge_replay_schema* sc, const int64_t* seg_off, int64_t n_agg,
+                        const void* events, const void* init_state, void* out_states) {
+  if (!sc || !seg_off || n_agg < 0 || !out_states) return -1;
+  fold_range(sc, seg_off, 0, n_agg, (const surge_event16*)events, (const surge_state64*)init_state,
+             (surge_state64*)out_states);
+  return 0;
+}
+
+/* Same fold with aggregates split over host threads (baseline B2). */
+typedef struct {
+  const surge_replay_schema* sc;
+  const int64_t* seg_off;
+  int64_t a0, a1;
+  const surge_event16* events;
+  const surge_state64* init;
+  surge_state64* out;
+} fold_job;
+
+static void* fold_thread(void* p) {
+  fold_job* j = (fold_job*)p;
+  fold_range(j->sc, j->seg_off, j->a0, j->a1, j->events, j->init, j->out);
+  return NULL;
+}
+
+int32_t oracle_fold_csr_mt(const surge_replay_schema* sc, const int64_t* seg_off, int64_t n_agg,
+                           const void* events, const void* init_state, void* out_states,
+                           int32_t n_threads) {
+  enum { MAXT = 256 };
+  pthread_t th[MAXT];
+  fold_job jobs[MAXT];
+  int t, started = 0;
+  int64_t total, target, a;
+  if (!sc || !seg_off || n_agg < 0 || !out_states) return -1;
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > MAXT) n_threads = MAXT;
+  total = seg_off[n_agg];
+  a = 0;
+  for (t = 0; t < n_threads; ++t) {
+    int64_t a_end;
+    /* split by events, not aggregates, so Zipf logs balance */
+    target = (t + 1 == n_threads) ? total : (total / n_threads) * (t + 1);
+    a_end = a;
+    if (t + 1 == n_threads) {
+      a_end = n_agg;
+    } else {
+      while (a_end < n_agg && seg_off[a_end] < target) ++a_end;
+    }
+    jobs[t].sc = sc;
+    jobs[t].seg_off = seg_off;
+    jobs[t].a0 = a;
+    jobs[t].a1 = a_end;
+    jobs[t].events = (const surge_event16*)events;
+    jobs[t].init = (const surge_state64*)init_state;
+    jobs[t].out = (surge_state64*)out_states;
+    a = a_end;
+  }
+  for (t = 0; t < n_threads; ++t) {
+    if (pthread_create(&th[t], NULL, fold_thread, &jobs[t]) != 0) break;
+    ++started;
+  }
+  for (t = started; t < n_threads; ++t) fold_thread(&jobs[t]); /* degraded: run inline */
+  for (t = 0; t < started; ++t) pthread_join(th[t], NULL);
+  return 0;
+}
+
+/* ---------------------------------------------------------------------------
+ * scala.util.hashing.MurmurHash3.stringHash(str)  [scala-library 2.13.8, not
+ * vendored under /root/reference; call site KafkaPartitioner.scala:8].
+ * Published algorithm: seed 0xf7ca7fd2; UTF-16 code units consumed in pairs
+ * data = (c[i] << 16) + c[i+1]; odd tail through mixLast; finalizeHash(h, len).
+ * PARITY UNPINNED: no reference test fixes a value of this function.
+ * ------------------------------------------------------------------------- */
+static uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+static uint32_t mm3_mix_last(uint32_t hash, uint32_t data) {
+  uint32_t k = data;
+  k *= 0xcc9e2d51u;
+  k = rotl32(k, 15);
+  k *= 0x1b873593u;
+  return hash ^ k;
+}
+
+static uint32_t mm3_mix(uint32_t hash, uint32_t data) {
+  uint32_t h = mm3_mix_last(hash, data);
+  h = rotl32(h, 13);
+  return h * 5u + 0xe6546b64u;
+}
+
+static uint32_t mm3_finalize(uint32_t hash, uint32_t length) {
+  uint32_t h = hash ^ length;
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+
+int32_t oracle_murmur3_string_hash(const uint16_t* s, int64_t len) {
+  uint32_t h = 0xf7ca7fd2u;
+  int64_t i = 0;
+  while (i + 1 < len) {
+    uint32_t data = ((uint32_t)s[i] << 16) + (uint32_t)s[i + 1];
+    h = mm3_mix(h, data);
+    i += 2;
+  }
+  if (i < len) h = mm3_mix_last(h, (uint32_t)s[i]);
+  return (int32_t)mm3_finalize(h, (uint32_t)len);
+}
+
+/* math.abs(MurmurHash3.stringHash(partitionByString) % numberOfPartitions)
+ * — KafkaPartitioner.scala:8 ; partitionBy = str.takeWhile(_ != ':') — :39-41.
+ * JVM `%` truncates toward zero, like C99. */
+int32_t oracle_partition_for_key(const uint16_t* s, int64_t len, int32_t n_partitions) {
+  int64_t n = 0;
+  int32_t h, r;
+  while (n < len && s[n] != (uint16_t)':') ++n;
+  h = oracle_murmur3_string_hash(s, n);
+  r = h % n_partitions;
+  return r < 0 ? -r : r;
+}
+
+int32_t oracle_partition_hash_batch(const uint16_t* utf16, const int64_t* str_off, int64_t n,
+                                    int32_t n_partitions, int32_t* part_out) {
+  int64_t i;
+  if (n_partitions <= 0) return -1;
+  for (i = 0; i < n; ++i)
+    part_out[i] = oracle_partition_for_key(utf16 + str_off[i], str_off[i + 1] - str_off[i], n_partitions);
+  return 0;
+}
+
+/* ---------------------------------------------------------------------------
+ * Json.toJson(agg).toString().getBytes() for State(aggregateId, count, version)
+ * — TestBoundedContext.scala:15-16,127-129.  play-json's Json.format macro
+ * emits fields in declaration order, compact: {"aggregateId":"…","count":4,"version":4}
+ * (the shape asserted by AggregateStateStoreKafkaStreamsSpec.scala:64-85).
+ * String escaping follows Jackson's default (\" \\ \b \f \n \r \t, other
+ * controls as \u00XX, non-ASCII passed through as UTF-8).
+ * Returns the number of bytes written (excluding NUL), or -1 if cap is too small.
+ * ------------------------------------------------------------------------- */
+static int64_t put(char* out, int64_t cap, int64_t pos, const char* s, int64_t n) {
+  if (pos < 0 || pos + n >= cap) return -1;
+  memcpy(out + pos, s, (size_t)n);
+  return pos + n;
+}
+
+static int64_t put_json_string(char* out, int64_t cap, int64_t pos, const char* utf8) {
+  const unsigned char* p = (const unsigned char*)utf8;
+  char buf[8];
+  pos = put(out, cap, pos, "\"", 1);
+  for (; *p && pos >= 0; ++p) {
+    switch (*p) {
+      case '"': pos = put(out, cap, pos, "\\\"", 2); break;
+      case '\\': pos = put(out, cap, pos, "\\\\", 2); break;
+      case '\b': pos = put(out, cap, pos, "\\b", 2); break;
+      case '\f': pos = put(out, cap, pos, "\\f", 2); break;
+      case '\n': pos = put(out, cap, pos, "\\n", 2); break;
+      case '\r': pos = put(out, cap, pos, "\\r", 2); break;
+      case '\t': pos = put(out, cap, pos, "\\t", 2); break;
+      default:
+        if (*p < 0x20) {
+          snprintf(buf, sizeof(buf), "\\u%04X", (unsigned)*p);
+          pos = put(out, cap, pos, buf, 6);
+        } else {
+          pos = put(out, cap, pos, (const char*)p, 1);
+        }
+    }
+  }
+  if (pos >= 0) pos = put(out, cap, pos, "\"", 1);
+  return pos;
+}
+
+int64_t oracle_counter_state_json(const char* aggregate_id_utf8, int32_t count, int32_t version,
+                                  char* out, int64_t cap) {
+  char num[32];
+  int64_t pos = 0;
+  int n;
+  pos = put(out, cap, pos, "{\"aggregateId\":", 15);
+  if (pos >= 0) pos = put_json_string(out, cap, pos, aggregate_id_utf8);
+  if (pos >= 0) pos = put(out, cap, pos, ",\"count\":", 9);
+  n = snprintf(num, sizeof(num), "%d", count);
+  if (pos >= 0) pos = put(out, cap, pos, num, n);
+  if (pos >= 0) pos = put(out, cap, pos, ",\"version\":", 11);
+  n = snprintf(num, sizeof(num), "%d", version);
+  if (pos >= 0) pos = put(out, cap, pos, num, n);
+  if (pos >= 0) pos = put(out, cap, pos, "}", 1);
+  if (pos >= 0) out[pos] = 0;
+  return pos;
+}

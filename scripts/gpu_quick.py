@@ -1,0 +1,68 @@
+"""Quick GPU iteration script (not a test): parity on small logs + a first perf number."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from surge_amd import synth, schema
+from surge_amd.replay import ReplayEngine
+from oracle import oracle
+
+def check(name, so, ev, init=None, algo=0):
+    eng = ReplayEngine()
+    eng.load_csr(so, ev, init)
+    eng.fold(algo)
+    got = eng.snapshot()
+    exp = oracle.fold_csr(so, ev, init)
+    ok = got.tobytes() == exp.tobytes()
+    st = eng.stats()
+    print(f"{name}: ok={ok} algo={st.last_algo} tasks={st.n_tasks} kernel_ms={st.last_fold_kernel_ms:.3f}")
+    if not ok:
+        bad = np.nonzero(got != exp)[0]
+        print("  mismatches:", len(bad), "first:", bad[:5])
+        for b in bad[:3]:
+            print("   agg", b, "len", so[b+1]-so[b], "\n    got", got[b], "\n    exp", exp[b])
+    eng.close()
+    return ok
+
+allok = True
+allok &= check("fixed 1000x100 (flat, L%16!=0)", *synth.fixed_log(1000, 100, 1, synth.C1_MIX, True))
+allok &= check("fixed 4096x256", *synth.fixed_log(4096, 256, 2))
+allok &= check("fixed 4096x256 flat", *synth.fixed_log(4096, 256, 2), algo=2)
+allok &= check("fixed 333x48", *synth.fixed_log(333, 48, 5, synth.STRESS_MIX))
+allok &= check("fixed 100x4096 stress", *synth.fixed_log(100, 4096, 6, synth.STRESS_MIX))
+allok &= check("zipf 20000", *synth.zipf_log(20000, 3))
+allok &= check("zipf 20000 stress", *synth.zipf_log(20000, 4, mix=synth.STRESS_MIX))
+rng = np.random.default_rng(0)
+lens = rng.integers(0, 5, size=50000)
+allok &= check("ragged with empties", *synth.csr_log(lens, 7, synth.STRESS_MIX))
+lens = rng.integers(0, 3, size=3000) * rng.integers(0, 2000, size=3000)
+so, ev = synth.csr_log(lens, 8, synth.STRESS_MIX)
+init = oracle.fold_csr(*synth.csr_log(rng.integers(0, 4, size=3000), 9, synth.STRESS_MIX))
+allok &= check("init + empties + long", so, ev, init)
+print("ALL OK" if allok else "FAILURES")
+
+# perf: C2
+dev = torch.device("cuda:0")
+for (A, L) in [(1_000_000, 256)]:
+    so, ev = synth.fixed_log_device(A, L, 2, dev)
+    out = torch.empty((A, 64), dtype=torch.uint8, device=dev)
+    eng = ReplayEngine()
+    eng.load_csr(so, ev, None, out)
+    for algo in (1, 2):
+        for _ in range(3):
+            eng.fold(algo)
+        eng.synchronize()
+        t = time.time()
+        for _ in range(10):
+            eng.fold(algo)
+        eng.synchronize()
+        dt = (time.time() - t) / 10
+        st = eng.stats()
+        print(f"C2 algo={algo}: wall {dt*1e3:.3f} ms/fold, kernel {st.last_fold_kernel_ms:.3f} ms, "
+              f"{A*L/dt/1e9:.1f} Gev/s, {st.algorithmic_bytes/st.last_fold_kernel_ms/1e6:.1f} GB/s alg")
+    ms = min(eng.stream_probe_ms(ev) for _ in range(5))
+    print(f"stream probe: {ev.numel()*8/ms/1e6:.1f} GB/s")
+    # parity on a slice vs oracle
+    got = out[:2000].cpu().numpy().view(schema.STATE_DTYPE).reshape(-1)
+    exp = oracle.fold_csr(so[:2001].cpu().numpy(), synth.to_event_records(ev[:2000*L]))
+    print("C2 slice parity:", got.tobytes() == exp.tobytes())
+    eng.close()

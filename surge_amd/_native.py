@@ -1,0 +1,142 @@
+"""Builds and loads ``libsurge_replay.so`` (the C-ABI of ``include/surge_replay.h``) through ctypes.
+
+There is no Python/CPU fallback for the fold: if the library cannot be built or loaded this
+module raises, and every ``ReplayEngine`` call would fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+from typing import List, Optional
+
+from .schema import CSchema, CStats
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
+LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
+SOURCES = ("fold_kernels.hip", "engine.hip")
+HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(INCLUDE, "surge_replay.h"))
+
+#: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
+EXPORTS = (
+    "surge_replay_default_schema",
+    "surge_replay_create",
+    "surge_replay_destroy",
+    "surge_replay_last_error",
+    "surge_replay_set_stream",
+    "surge_replay_synchronize",
+    "surge_replay_load_csr",
+    "surge_replay_bind_device_csr",
+    "surge_replay_fold",
+    "surge_replay_append_fold",
+    "surge_replay_append_fold_device",
+    "surge_replay_get",
+    "surge_replay_snapshot",
+    "surge_replay_device_state",
+    "surge_replay_partition_hash",
+    "surge_replay_partition_hash_device",
+    "surge_replay_stats",
+    "surge_replay_stream_probe",
+)
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise NativeLibraryError("hipcc not found; cannot build libsurge_replay.so")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps: List[str] = [os.path.join(CSRC, s) for s in SOURCES] + list(HEADERS)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (the .so travels with the repo snapshot)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [
+        _hipcc(),
+        "--offload-arch=gfx950",
+        "-O3",
+        "-std=c++17",
+        "-fPIC",
+        "-shared",
+        "-ffp-contract=off",
+        "-Wall",
+        "-I" + INCLUDE,
+    ]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    tmp = LIB_PATH + ".tmp"
+    cmd += ["-o", tmp]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise NativeLibraryError("hipcc failed:\n" + proc.stdout + proc.stderr)
+    if verbose and (proc.stdout or proc.stderr):
+        print(proc.stdout + proc.stderr)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load the library (building it first when the sources are newer).
+
+    ``torch`` is imported first on purpose: its bundled ``libamdhip64.so`` has the same soname as
+    the system one, and loading it first makes the library share torch's HIP runtime so device
+    pointers and streams interoperate.
+    """
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        import torch  # noqa: F401  (side effect: loads torch's HIP runtime)
+    except Exception:  # pragma: no cover - torch is optional for pure C hosts
+        pass
+    if needs_build():
+        build()
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    sig = {
+        "surge_replay_default_schema": ([ctypes.POINTER(CSchema)], i32),
+        "surge_replay_create": ([ctypes.POINTER(CSchema), i32, ctypes.POINTER(vp)], i32),
+        "surge_replay_destroy": ([vp], i32),
+        "surge_replay_last_error": ([vp], ctypes.c_char_p),
+        "surge_replay_set_stream": ([vp, vp], i32),
+        "surge_replay_synchronize": ([vp], i32),
+        "surge_replay_load_csr": ([vp, vp, i64, vp, i64, vp], i32),
+        "surge_replay_bind_device_csr": ([vp, vp, i64, vp, i64, vp, vp], i32),
+        "surge_replay_fold": ([vp, i32], i32),
+        "surge_replay_append_fold": ([vp, vp, vp, i64, vp, i64], i32),
+        "surge_replay_append_fold_device": ([vp, vp, vp, i64, vp, i64], i32),
+        "surge_replay_get": ([vp, i64, vp, ctypes.POINTER(ctypes.c_uint8)], i32),
+        "surge_replay_snapshot": ([vp, vp, vp], i32),
+        "surge_replay_device_state": ([vp, ctypes.POINTER(vp), ctypes.POINTER(i64)], i32),
+        "surge_replay_partition_hash": ([vp, vp, i64, i32, vp], i32),
+        "surge_replay_partition_hash_device": ([vp, vp, vp, i64, i32, vp], i32),
+        "surge_replay_stats": ([vp, ctypes.POINTER(CStats)], i32),
+        "surge_replay_stream_probe": ([vp, vp, i64, ctypes.POINTER(ctypes.c_double)], i32),
+    }
+    for name in EXPORTS:
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.argtypes, fn.restype = sig[name]
+    _lib = L
+    return L

@@ -1,0 +1,605 @@
+// engine.hip — host side of libsurge_replay.so: handle, device memory, launch sequencing and
+// the extern "C" boundary declared in include/surge_replay.h.  No torch types, no CPU fold:
+// if HIP is unusable every entry point reports SURGE_E_DEVICE.
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "replay_internal.h"
+
+using namespace surge;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct DevBuf {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&ptr, bytes ? bytes : 16);
+    if (e == hipSuccess) cap = bytes ? bytes : 16;
+    return e;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+  }
+};
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+}  // namespace
+
+struct surge_replay_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  surge_replay_schema schema{};
+  std::string err;
+
+  // the bound log (owned copies or borrowed device pointers)
+  DevBuf own_seg_off, own_events, own_init, own_state;
+  const int64_t* d_seg_off = nullptr;
+  const uint4* d_events = nullptr;
+  const uint4* d_init = nullptr;
+  uint4* d_state = nullptr;
+  int64_t n_agg = 0, n_events = 0;
+  bool bound = false;
+
+  // analysis of the bound CSR (computed at load/bind time)
+  CsrAnalysis an{};
+  DevBuf d_analysis, nz_off, nz_map, block_counts;
+  int64_t n_nz = 0;
+
+  // per-fold scratch
+  DevBuf plan, batch_group_agg, batch_group_off, batch_events, poison_count;
+
+  hipEvent_t ev_total0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_total1 = nullptr, ev_h0 = nullptr,
+             ev_h1 = nullptr;
+  bool timing_valid = false, h2d_valid = false;
+  surge_replay_stats_t st{};
+
+  // host mirror for point reads (S2)
+  std::mutex mu;
+  std::vector<uint8_t> mirror;
+  std::atomic<int64_t> fold_epoch{0};
+  int64_t mirror_epoch = -1;
+};
+
+namespace {
+
+int32_t fail(surge_replay_handle* h, int32_t code, const std::string& msg) {
+  if (h) h->err = msg;
+  g_last_error = msg;
+  return code;
+}
+
+int32_t fail_hip(surge_replay_handle* h, hipError_t e, const char* what) {
+  std::string m = std::string(what) + ": " + hipGetErrorString(e);
+  const int32_t code = (e == hipErrorOutOfMemory) ? SURGE_E_NOMEM : SURGE_E_DEVICE;
+  return fail(h, code, m);
+}
+
+#define HIPCHK(h, call)                                   \
+  do {                                                    \
+    hipError_t e_ = (call);                               \
+    if (e_ != hipSuccess) return fail_hip(h, e_, #call); \
+  } while (0)
+
+void fill_params(const surge_replay_handle* h, FoldParams& p) {
+  std::memset(&p, 0, sizeof(p));
+  for (int i = 0; i < 17; ++i) p.desc[i] = SURGE_D_POISON;
+  for (uint32_t i = 0; i < h->schema.n_types; ++i) p.desc[i] = h->schema.desc[i];
+  const surge_state64& d = h->schema.default_state;
+  p.d_count = d.count;
+  p.d_version = d.version;
+  p.d_sum = d.sum64;
+  std::memcpy(&p.d_balance, &d.balance, 8);
+  p.d_min = d.min_arg;
+  p.d_max = d.max_arg;
+  p.d_evcount = d.event_count;
+}
+
+// Wave-task size in events: a multiple of one tile, at most kMaxTaskTiles tiles, small enough that
+// short logs still spread over the chip.
+int64_t choose_task_events(int64_t n_events) {
+  int64_t tiles = (n_events / kTargetTasks + kTileEvents - 1) / kTileEvents;
+  if (tiles < 1) tiles = 1;
+  if (tiles > kMaxTaskTiles) tiles = kMaxTaskTiles;
+  return tiles * kTileEvents;
+}
+
+int32_t validate_schema(const surge_replay_schema* s) {
+  if (!s) return fail(nullptr, SURGE_E_INVALID, "schema is NULL");
+  if (s->abi_version != SURGE_REPLAY_ABI_VERSION) return fail(nullptr, SURGE_E_UNSUPPORTED, "schema.abi_version mismatch");
+  if (s->state_size != 64 || s->event_size != 16)
+    return fail(nullptr, SURGE_E_UNSUPPORTED, "only 64-byte states and 16-byte events are supported");
+  if (s->n_types < 1 || s->n_types > SURGE_MAX_EVENT_TYPES) return fail(nullptr, SURGE_E_INVALID, "schema.n_types out of range");
+  const uint32_t known = SURGE_CLS_MASK | SURGE_D_POISON | SURGE_D_COUNT_MASK | SURGE_D_VERSION_SET | SURGE_D_SUM_MASK |
+                         SURGE_D_BALANCE_SET | SURGE_D_MIN_ARG | SURGE_D_MAX_ARG | SURGE_D_EVCOUNT_INC;
+  for (uint32_t i = 0; i < s->n_types; ++i) {
+    if (s->desc[i] & ~known) return fail(nullptr, SURGE_E_UNSUPPORTED, "schema descriptor uses unknown bits");
+    if ((s->desc[i] & SURGE_D_SUM_MASK) == SURGE_D_SUM_MASK) return fail(nullptr, SURGE_E_UNSUPPORTED, "invalid sum64 op");
+  }
+  return SURGE_OK;
+}
+
+// Analyse the bound CSR once: monotone? empty segments? uniform length?  Synchronous (load time).
+int32_t analyze_bound(surge_replay_handle* h) {
+  HIPCHK(h, h->d_analysis.reserve(sizeof(CsrAnalysis)));
+  h->n_nz = h->n_agg;
+  std::memset(&h->an, 0, sizeof(h->an));
+  if (h->n_agg == 0) return SURGE_OK;
+  HIPCHK(h, launch_analyze_csr(h->d_seg_off, h->n_agg, (CsrAnalysis*)h->d_analysis.ptr, h->stream));
+  HIPCHK(h, hipMemcpyAsync(&h->an, h->d_analysis.ptr, sizeof(CsrAnalysis), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->an.bad) return fail(h, SURGE_E_INVALID, "seg_off is not monotone non-decreasing");
+  if (h->an.first < 0 || h->an.last > h->n_events)
+    return fail(h, SURGE_E_INVALID, "seg_off range exceeds the events buffer");
+  if (h->an.n_empty > 0) {
+    // kernel-facing CSR without empty segments (+ rank -> aggregate map)
+    const int64_t nb = (h->n_agg + 1023) / 1024;
+    h->n_nz = h->n_agg - h->an.n_empty;
+    HIPCHK(h, h->block_counts.reserve((size_t)(nb + 1) * 8));
+    HIPCHK(h, h->nz_off.reserve((size_t)(h->n_nz + 1) * 8));
+    HIPCHK(h, h->nz_map.reserve((size_t)(h->n_nz > 0 ? h->n_nz : 1) * 8));
+    HIPCHK(h, launch_compact_nonempty(h->d_seg_off, h->n_agg, (int64_t*)h->block_counts.ptr, (int64_t*)h->nz_off.ptr,
+                                      (int64_t*)h->nz_map.ptr, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return SURGE_OK;
+}
+
+int64_t algorithmic_bytes(int64_t n_events, int64_t n_agg, bool has_init) {
+  return 16 * n_events + 8 * (n_agg + 1) + 64 * n_agg * (has_init ? 2 : 1);
+}
+
+// plan + flat fold over an arbitrary kernel-facing CSR
+int32_t run_flat(surge_replay_handle* h, FoldParams& p, const int64_t* off, int64_t n_seg, int64_t span_events) {
+  const int64_t task_events = choose_task_events(span_events);
+  const int64_t n_tasks = (span_events + task_events - 1) / task_events;
+  HIPCHK(h, h->plan.reserve((size_t)(n_tasks + 1) * 8));
+  HIPCHK(h, launch_plan(off, n_seg, task_events, n_tasks, (int64_t*)h->plan.ptr, h->stream));
+  p.seg_off = off;
+  p.plan = (const int64_t*)h->plan.ptr;
+  p.n_seg = n_seg;
+  HIPCHK(h, hipEventRecord(h->ev_k0, h->stream));
+  HIPCHK(h, launch_fold_flat(p, n_tasks, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_k1, h->stream));
+  h->st.n_tasks = (int32_t)n_tasks;
+  return SURGE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t surge_replay_default_schema(surge_replay_schema* out) {
+  if (!out) return fail(nullptr, SURGE_E_INVALID, "out is NULL");
+  std::memset(out, 0, sizeof(*out));
+  out->abi_version = SURGE_REPLAY_ABI_VERSION;
+  out->state_size = 64;
+  out->event_size = 16;
+  out->n_types = 7;
+  const uint32_t extras = SURGE_D_MIN_ARG | SURGE_D_MAX_ARG | SURGE_D_EVCOUNT_INC;
+  out->desc[SURGE_EVT_NOOP] = SURGE_CLS_MATERIALIZE;
+  out->desc[SURGE_EVT_INC] = SURGE_CLS_MATERIALIZE | SURGE_D_COUNT_ADD | SURGE_D_VERSION_SET | SURGE_D_SUM_ADD | extras;
+  out->desc[SURGE_EVT_DEC] = SURGE_CLS_MATERIALIZE | SURGE_D_COUNT_SUB | SURGE_D_VERSION_SET | SURGE_D_SUM_SUB | extras;
+  out->desc[SURGE_EVT_CREATE] = SURGE_CLS_CREATE | SURGE_D_BALANCE_SET | SURGE_D_EVCOUNT_INC;
+  out->desc[SURGE_EVT_SET_BALANCE] = SURGE_CLS_REQUIRE | SURGE_D_BALANCE_SET | SURGE_D_EVCOUNT_INC;
+  out->desc[SURGE_EVT_DELETE] = SURGE_CLS_DELETE;
+  out->desc[SURGE_EVT_THROW] = SURGE_D_POISON;
+  out->default_state.min_arg = 0x7fffffff;
+  out->default_state.max_arg = (int32_t)0x80000000;
+  out->default_state.flags = SURGE_STATE_PRESENT;
+  return SURGE_OK;
+}
+
+int32_t surge_replay_create(const surge_replay_schema* schema, int32_t device_id, surge_replay_handle** out) {
+  if (!out) return fail(nullptr, SURGE_E_INVALID, "out is NULL");
+  *out = nullptr;
+  const int32_t v = validate_schema(schema);
+  if (v != SURGE_OK) return v;
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess || n_dev <= 0)
+    return fail(nullptr, SURGE_E_DEVICE, "no usable HIP device (this library has no CPU fallback)");
+  if (device_id < 0 || device_id >= n_dev) return fail(nullptr, SURGE_E_INVALID, "device_id out of range");
+  surge_replay_handle* h = new (std::nothrow) surge_replay_handle();
+  if (!h) return fail(nullptr, SURGE_E_NOMEM, "out of host memory");
+  h->device = device_id;
+  h->schema = *schema;
+  DeviceGuard g(device_id);
+  if (!g.ok) {
+    delete h;
+    return fail(nullptr, SURGE_E_DEVICE, "hipSetDevice failed");
+  }
+  hipEvent_t* evs[] = {&h->ev_total0, &h->ev_k0, &h->ev_k1, &h->ev_total1, &h->ev_h0, &h->ev_h1};
+  for (hipEvent_t* ev : evs) {
+    e = hipEventCreate(ev);
+    if (e != hipSuccess) {
+      const int32_t rc = fail_hip(nullptr, e, "hipEventCreate");
+      surge_replay_destroy(h);
+      return rc;
+    }
+  }
+  h->st.n_poisoned = -1;
+  *out = h;
+  return SURGE_OK;
+}
+
+int32_t surge_replay_destroy(surge_replay_handle* h) {
+  if (!h) return SURGE_OK;
+  DeviceGuard g(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  DevBuf* bufs[] = {&h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
+                    &h->nz_map, &h->block_counts, &h->plan, &h->batch_group_agg, &h->batch_group_off,
+                    &h->batch_events, &h->poison_count};
+  for (DevBuf* b : bufs) b->release();
+  hipEvent_t evs[] = {h->ev_total0, h->ev_k0, h->ev_k1, h->ev_total1, h->ev_h0, h->ev_h1};
+  for (hipEvent_t ev : evs)
+    if (ev) (void)hipEventDestroy(ev);
+  delete h;
+  return SURGE_OK;
+}
+
+const char* surge_replay_last_error(const surge_replay_handle* h) {
+  return h ? h->err.c_str() : g_last_error.c_str();
+}
+
+int32_t surge_replay_set_stream(surge_replay_handle* h, void* hip_stream) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  h->stream = (hipStream_t)hip_stream;
+  return SURGE_OK;
+}
+
+int32_t surge_replay_synchronize(surge_replay_handle* h) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  DeviceGuard g(h->device);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SURGE_OK;
+}
+
+int32_t surge_replay_bind_device_csr(surge_replay_handle* h, const int64_t* d_seg_off, int64_t n_agg,
+                                     const void* d_events, int64_t n_events, const void* d_init_state,
+                                     void* d_state_out) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (n_agg < 0 || n_events < 0) return fail(h, SURGE_E_INVALID, "negative size");
+  if (!d_seg_off) return fail(h, SURGE_E_INVALID, "seg_off is NULL");
+  if (n_events > 0 && !d_events) return fail(h, SURGE_E_INVALID, "events is NULL");
+  if (((uintptr_t)d_events & 15) || ((uintptr_t)d_init_state & 15) || ((uintptr_t)d_state_out & 15) ||
+      ((uintptr_t)d_seg_off & 7))
+    return fail(h, SURGE_E_INVALID, "device buffers must be 16-byte aligned (seg_off: 8)");
+  DeviceGuard g(h->device);
+  h->bound = false;
+  h->d_seg_off = d_seg_off;
+  h->d_events = (const uint4*)d_events;
+  h->d_init = (const uint4*)d_init_state;
+  h->n_agg = n_agg;
+  h->n_events = n_events;
+  if (d_state_out) {
+    h->d_state = (uint4*)d_state_out;
+  } else {
+    HIPCHK(h, h->own_state.reserve((size_t)n_agg * 64));
+    h->d_state = (uint4*)h->own_state.ptr;
+  }
+  const int32_t rc = analyze_bound(h);
+  if (rc != SURGE_OK) return rc;
+  h->bound = true;
+  h->st.n_aggregates = n_agg;
+  h->st.n_events = h->an.last - h->an.first;
+  h->st.algorithmic_bytes = algorithmic_bytes(h->st.n_events, n_agg, d_init_state != nullptr);
+  h->fold_epoch.fetch_add(1);
+  return SURGE_OK;
+}
+
+int32_t surge_replay_load_csr(surge_replay_handle* h, const int64_t* seg_off, int64_t n_agg, const void* events,
+                              int64_t n_events, const void* init_state) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (n_agg < 0 || n_events < 0) return fail(h, SURGE_E_INVALID, "negative size");
+  if (!seg_off) return fail(h, SURGE_E_INVALID, "seg_off is NULL");
+  if (n_events > 0 && !events) return fail(h, SURGE_E_INVALID, "events is NULL");
+  // cheap host-side validation before touching the device
+  for (int64_t a = 0; a < n_agg; ++a)
+    if (seg_off[a + 1] < seg_off[a]) return fail(h, SURGE_E_INVALID, "seg_off is not monotone non-decreasing");
+  if (seg_off[0] < 0 || seg_off[n_agg] > n_events) return fail(h, SURGE_E_INVALID, "seg_off range exceeds the events buffer");
+  DeviceGuard g(h->device);
+  h->bound = false;
+  HIPCHK(h, h->own_seg_off.reserve((size_t)(n_agg + 1) * 8));
+  HIPCHK(h, h->own_events.reserve((size_t)n_events * 16));
+  if (init_state) HIPCHK(h, h->own_init.reserve((size_t)n_agg * 64));
+  HIPCHK(h, hipEventRecord(h->ev_h0, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->own_seg_off.ptr, seg_off, (size_t)(n_agg + 1) * 8, hipMemcpyHostToDevice, h->stream));
+  if (n_events > 0)
+    HIPCHK(h, hipMemcpyAsync(h->own_events.ptr, events, (size_t)n_events * 16, hipMemcpyHostToDevice, h->stream));
+  if (init_state && n_agg > 0)
+    HIPCHK(h, hipMemcpyAsync(h->own_init.ptr, init_state, (size_t)n_agg * 64, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_h1, h->stream));
+  h->h2d_valid = true;
+  return surge_replay_bind_device_csr(h, (const int64_t*)h->own_seg_off.ptr, n_agg, h->own_events.ptr, n_events,
+                                      init_state ? h->own_init.ptr : nullptr, nullptr);
+}
+
+int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->bound) return fail(h, SURGE_E_STATE, "fold before load_csr/bind_device_csr");
+  if (algo != SURGE_ALGO_AUTO && algo != SURGE_ALGO_FIXED && algo != SURGE_ALGO_FLAT)
+    return fail(h, SURGE_E_INVALID, "unknown algo");
+  DeviceGuard g(h->device);
+  const int64_t span = h->an.last - h->an.first;
+  const bool uniform = h->n_agg > 0 && !h->an.nonuniform && h->an.n_empty == 0 && h->an.len0 > 0 &&
+                       (h->an.len0 % kLaneEvents) == 0 && h->an.len0 < (1ll << 31) && h->an.first == 0;
+  if (algo == SURGE_ALGO_FIXED && !uniform)
+    return fail(h, SURGE_E_UNSUPPORTED, "ALGO_FIXED needs equal segment lengths that are a multiple of 16");
+  const int32_t use = (algo == SURGE_ALGO_AUTO) ? (uniform ? SURGE_ALGO_FIXED : SURGE_ALGO_FLAT) : algo;
+
+  FoldParams p;
+  fill_params(h, p);
+  p.events = h->d_events;
+  p.n_events = h->n_events;
+  p.init = h->d_init;
+  p.out = h->d_state;
+
+  HIPCHK(h, hipEventRecord(h->ev_total0, h->stream));
+  h->st.n_tasks = 0;
+  if (h->n_agg > 0 && span > 0) {
+    if (use == SURGE_ALGO_FIXED) {
+      const int64_t L = h->an.len0;
+      const int64_t task_events = choose_task_events(span);
+      int64_t G = task_events / L;
+      if (G < 1) G = 1;
+      const int64_t n_tasks = (h->n_agg + G - 1) / G;
+      p.n_seg = h->n_agg;
+      p.fixed_len = L;
+      p.segs_per_task = G;
+      HIPCHK(h, hipEventRecord(h->ev_k0, h->stream));
+      HIPCHK(h, launch_fold_fixed(p, n_tasks, h->stream));
+      HIPCHK(h, hipEventRecord(h->ev_k1, h->stream));
+      h->st.n_tasks = (int32_t)n_tasks;
+    } else if (h->an.n_empty > 0) {
+      p.out_map = (const int64_t*)h->nz_map.ptr;
+      const int32_t rc = run_flat(h, p, (const int64_t*)h->nz_off.ptr, h->n_nz, span);
+      if (rc != SURGE_OK) return rc;
+    } else {
+      const int32_t rc = run_flat(h, p, h->d_seg_off, h->n_agg, span);
+      if (rc != SURGE_OK) return rc;
+    }
+  } else {
+    HIPCHK(h, hipEventRecord(h->ev_k0, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_k1, h->stream));
+  }
+  if (h->an.n_empty > 0 || span == 0)
+    HIPCHK(h, launch_fill_empty(h->d_seg_off, h->n_agg, h->d_init, h->d_state, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_total1, h->stream));
+  h->timing_valid = true;
+  h->st.last_algo = use;
+  h->st.n_folds += 1;
+  h->st.n_poisoned = -1;
+  h->fold_epoch.fetch_add(1);
+  return SURGE_OK;
+}
+
+int32_t surge_replay_append_fold_device(surge_replay_handle* h, const int64_t* d_group_agg, const int64_t* d_group_off,
+                                        int64_t n_groups, const void* d_events, int64_t n_events) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->bound) return fail(h, SURGE_E_STATE, "append_fold before load_csr/bind_device_csr");
+  if (n_groups < 0 || n_events < 0) return fail(h, SURGE_E_INVALID, "negative size");
+  if (n_groups == 0 || n_events == 0) return SURGE_OK;
+  if (!d_group_agg || !d_group_off || !d_events) return fail(h, SURGE_E_INVALID, "NULL batch buffer");
+  if ((uintptr_t)d_events & 15) return fail(h, SURGE_E_INVALID, "events must be 16-byte aligned");
+  DeviceGuard g(h->device);
+  FoldParams p;
+  fill_params(h, p);
+  p.events = (const uint4*)d_events;
+  p.n_events = n_events;
+  p.init = h->d_state;  // fold onto the resident state, in place
+  p.out = h->d_state;
+  p.out_map = d_group_agg;
+  HIPCHK(h, hipEventRecord(h->ev_total0, h->stream));
+  const int32_t rc = run_flat(h, p, d_group_off, n_groups, n_events);
+  if (rc != SURGE_OK) return rc;
+  HIPCHK(h, hipEventRecord(h->ev_total1, h->stream));
+  h->timing_valid = true;
+  h->st.last_algo = SURGE_ALGO_FLAT;
+  h->st.n_folds += 1;
+  h->st.n_poisoned = -1;
+  h->fold_epoch.fetch_add(1);
+  return SURGE_OK;
+}
+
+int32_t surge_replay_append_fold(surge_replay_handle* h, const int64_t* group_agg, const int64_t* group_off,
+                                 int64_t n_groups, const void* events, int64_t n_events) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->bound) return fail(h, SURGE_E_STATE, "append_fold before load_csr/bind_device_csr");
+  if (n_groups < 0 || n_events < 0) return fail(h, SURGE_E_INVALID, "negative size");
+  if (n_groups == 0 || n_events == 0) return SURGE_OK;
+  if (!group_agg || !group_off || !events) return fail(h, SURGE_E_INVALID, "NULL batch buffer");
+  if (group_off[0] != 0 || group_off[n_groups] != n_events)
+    return fail(h, SURGE_E_INVALID, "group_off must span [0, n_events]");
+  for (int64_t gidx = 0; gidx < n_groups; ++gidx) {
+    if (group_off[gidx + 1] <= group_off[gidx]) return fail(h, SURGE_E_INVALID, "batch groups must be non-empty and ordered");
+    if (group_agg[gidx] < 0 || group_agg[gidx] >= h->n_agg) return fail(h, SURGE_E_RANGE, "group_agg out of range");
+  }
+  DeviceGuard g(h->device);
+  HIPCHK(h, h->batch_group_agg.reserve((size_t)n_groups * 8));
+  HIPCHK(h, h->batch_group_off.reserve((size_t)(n_groups + 1) * 8));
+  HIPCHK(h, h->batch_events.reserve((size_t)n_events * 16));
+  HIPCHK(h, hipEventRecord(h->ev_h0, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->batch_group_agg.ptr, group_agg, (size_t)n_groups * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->batch_group_off.ptr, group_off, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->batch_events.ptr, events, (size_t)n_events * 16, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_h1, h->stream));
+  h->h2d_valid = true;
+  return surge_replay_append_fold_device(h, (const int64_t*)h->batch_group_agg.ptr, (const int64_t*)h->batch_group_off.ptr,
+                                         n_groups, h->batch_events.ptr, n_events);
+}
+
+int32_t surge_replay_snapshot(surge_replay_handle* h, void* states_out, uint8_t* present_out) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->bound) return fail(h, SURGE_E_STATE, "snapshot before load_csr/bind_device_csr");
+  if (h->st.n_folds == 0) return fail(h, SURGE_E_STATE, "snapshot before fold");
+  DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  const int64_t epoch = h->fold_epoch.load();
+  const size_t bytes = (size_t)h->n_agg * 64;
+  try {
+    h->mirror.resize(bytes);
+  } catch (const std::bad_alloc&) {
+    return fail(h, SURGE_E_NOMEM, "out of host memory for the snapshot mirror");
+  }
+  if (bytes) {
+    HIPCHK(h, hipMemcpyAsync(h->mirror.data(), h->d_state, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  h->mirror_epoch = epoch;
+  int64_t poisoned = 0;
+  for (int64_t a = 0; a < h->n_agg; ++a) {
+    uint32_t fl;
+    std::memcpy(&fl, h->mirror.data() + a * 64 + 36, 4);
+    if (present_out) present_out[a] = (uint8_t)(fl & SURGE_STATE_PRESENT);
+    poisoned += (fl & SURGE_STATE_POISONED) ? 1 : 0;
+  }
+  h->st.n_poisoned = poisoned;
+  if (states_out && bytes) std::memcpy(states_out, h->mirror.data(), bytes);
+  return SURGE_OK;
+}
+
+int32_t surge_replay_get(surge_replay_handle* h, int64_t agg_idx, void* state64_out, uint8_t* present_out) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!state64_out) return fail(h, SURGE_E_INVALID, "state64_out is NULL");
+  if (!h->bound || h->st.n_folds == 0) return fail(h, SURGE_E_STATE, "get before fold");
+  if (agg_idx < 0 || agg_idx >= h->n_agg) return fail(h, SURGE_E_RANGE, "aggregate index out of range");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->mirror_epoch == h->fold_epoch.load()) {
+    std::memcpy(state64_out, h->mirror.data() + agg_idx * 64, 64);
+  } else {
+    DeviceGuard g(h->device);
+    HIPCHK(h, hipMemcpyAsync(state64_out, h->d_state + agg_idx * 4, 64, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  if (present_out) {
+    uint32_t fl;
+    std::memcpy(&fl, (const uint8_t*)state64_out + 36, 4);
+    *present_out = (uint8_t)(fl & SURGE_STATE_PRESENT);
+  }
+  return SURGE_OK;
+}
+
+int32_t surge_replay_device_state(surge_replay_handle* h, void** d_states, int64_t* n_agg) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->bound) return fail(h, SURGE_E_STATE, "device_state before load_csr/bind_device_csr");
+  if (d_states) *d_states = h->d_state;
+  if (n_agg) *n_agg = h->n_agg;
+  return SURGE_OK;
+}
+
+/* CPU variant of the shard map (R15).  This is product code (host-side routing needs it without a
+ * GPU round trip), written independently of oracle/. */
+static inline uint32_t rotl32_host(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+int32_t surge_replay_partition_hash(const uint16_t* utf16, const int64_t* str_off, int64_t n, int32_t n_partitions,
+                                    int32_t* part_out) {
+  if (n < 0 || n_partitions <= 0) return fail(nullptr, SURGE_E_INVALID, "bad n or n_partitions");
+  if (n == 0) return SURGE_OK;
+  if (!str_off || !part_out) return fail(nullptr, SURGE_E_INVALID, "NULL buffer");
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t b = str_off[i], e = str_off[i + 1];
+    if (e < b) return fail(nullptr, SURGE_E_INVALID, "str_off is not monotone");
+    int64_t len = 0;
+    while (b + len < e && utf16[b + len] != (uint16_t)':') ++len;
+    uint32_t hsh = 0xf7ca7fd2u;
+    int64_t k = 0;
+    for (; k + 1 < len; k += 2) {
+      uint32_t d = ((uint32_t)utf16[b + k] << 16) + (uint32_t)utf16[b + k + 1];
+      d *= 0xcc9e2d51u; d = rotl32_host(d, 15); d *= 0x1b873593u;
+      hsh ^= d; hsh = rotl32_host(hsh, 13); hsh = hsh * 5u + 0xe6546b64u;
+    }
+    if (k < len) {
+      uint32_t d = (uint32_t)utf16[b + k];
+      d *= 0xcc9e2d51u; d = rotl32_host(d, 15); d *= 0x1b873593u;
+      hsh ^= d;
+    }
+    hsh ^= (uint32_t)len;
+    hsh ^= hsh >> 16; hsh *= 0x85ebca6bu; hsh ^= hsh >> 13; hsh *= 0xc2b2ae35u; hsh ^= hsh >> 16;
+    const int32_t r = (int32_t)hsh % n_partitions;
+    part_out[i] = r < 0 ? -r : r;
+  }
+  return SURGE_OK;
+}
+
+int32_t surge_replay_partition_hash_device(surge_replay_handle* h, const uint16_t* d_utf16, const int64_t* d_str_off,
+                                           int64_t n, int32_t n_partitions, int32_t* d_part_out) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (n < 0 || n_partitions <= 0) return fail(h, SURGE_E_INVALID, "bad n or n_partitions");
+  if (n == 0) return SURGE_OK;
+  if (!d_str_off || !d_part_out) return fail(h, SURGE_E_INVALID, "NULL buffer");
+  DeviceGuard g(h->device);
+  HIPCHK(h, launch_partition_hash(d_utf16, d_str_off, n, n_partitions, d_part_out, h->stream));
+  return SURGE_OK;
+}
+
+int32_t surge_replay_stats(surge_replay_handle* h, surge_replay_stats_t* out) {
+  if (!h || !out) return fail(h, SURGE_E_INVALID, "NULL argument");
+  DeviceGuard g(h->device);
+  if (h->timing_valid) {
+    HIPCHK(h, hipEventSynchronize(h->ev_total1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev_k0, h->ev_k1));
+    h->st.last_fold_kernel_ms = ms;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev_total0, h->ev_total1));
+    h->st.last_fold_total_ms = ms;
+  }
+  if (h->h2d_valid) {
+    HIPCHK(h, hipEventSynchronize(h->ev_h1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev_h0, h->ev_h1));
+    h->st.h2d_ms = ms;
+  }
+  if (h->bound && h->st.n_folds > 0 && h->st.n_poisoned < 0) {
+    HIPCHK(h, h->poison_count.reserve(8));
+    HIPCHK(h, launch_count_poisoned(h->d_state, h->n_agg, (unsigned long long*)h->poison_count.ptr, h->stream));
+    unsigned long long c = 0;
+    HIPCHK(h, hipMemcpyAsync(&c, h->poison_count.ptr, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->st.n_poisoned = (int64_t)c;
+  }
+  *out = h->st;
+  return SURGE_OK;
+}
+
+int32_t surge_replay_stream_probe(surge_replay_handle* h, const void* d_src, int64_t n_bytes, double* ms_out) {
+  if (!h || !d_src || !ms_out) return fail(h, SURGE_E_INVALID, "NULL argument");
+  if (n_bytes < 16 || (n_bytes & 15) || ((uintptr_t)d_src & 15)) return fail(h, SURGE_E_INVALID, "n_bytes/pointer must be 16-byte multiples");
+  DeviceGuard g(h->device);
+  HIPCHK(h, h->poison_count.reserve(8));
+  HIPCHK(h, hipEventRecord(h->ev_h0, h->stream));
+  HIPCHK(h, launch_stream_probe((const uint4*)d_src, n_bytes / 16, (uint32_t*)h->poison_count.ptr, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_h1, h->stream));
+  HIPCHK(h, hipEventSynchronize(h->ev_h1));
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev_h0, h->ev_h1));
+  *ms_out = ms;
+  h->h2d_valid = false;  // ev_h0/ev_h1 were reused
+  return SURGE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// replay_internal.h — shared between the HIP kernels and the host engine.
+// Not part of the C ABI (that is include/surge_replay.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/surge_replay.h"
+
+namespace surge {
+
+// Tile geometry of the flat fold: one wave = 64 lanes x 16 contiguous events
+// = 1024 events = 16 KiB, staged through LDS with direct global->LDS loads.
+constexpr int kWave = 64;
+constexpr int kLaneEvents = 16;
+constexpr int kTileEvents = kWave * kLaneEvents;          // 1024
+constexpr int kTileBytes = kTileEvents * 16;              // 16384
+constexpr int kHeadWords = kTileEvents / 32;              // 32 dwords = 128 B head bitmask
+constexpr int kFoldLdsBytes = kTileBytes + kHeadWords * 4 + 17 * 4 + 60;  // + desc table, padded to 16 B multiple
+constexpr int kMaxTaskTiles = 16;                         // a wave task streams <= ~256 KiB contiguous
+constexpr int kTargetTasks = 16384;                       // enough tasks to fill 256 CUs x 8 waves twice
+
+struct FoldParams {
+  const uint4* events;      // 16 B records
+  int64_t n_events;         // length of the events buffer (loads are clamped to it)
+  const int64_t* seg_off;   // kernel-facing CSR offsets, strictly increasing (FLAT); unused for FIXED
+  const int64_t* plan;      // FLAT: n_tasks+1 segment indices; task k owns segments [plan[k], plan[k+1])
+  const int64_t* out_map;   // nullable: segment rank -> aggregate index (compacted CSR / micro-batch groups)
+  const uint4* init;        // nullable: prior snapshot, 64 B per aggregate
+  uint4* out;               // 64 B per aggregate
+  int64_t n_seg;            // kernel-facing segment count
+  int64_t fixed_len;        // FIXED: events per segment (multiple of 16)
+  int64_t segs_per_task;    // FIXED: segments per wave task
+  uint32_t desc[17];        // descriptor per type; [16] (and unused slots) = POISON
+  int32_t d_count, d_version;
+  int64_t d_sum;
+  uint64_t d_balance;
+  int32_t d_min, d_max;
+  uint32_t d_evcount;
+};
+
+struct CsrAnalysis {
+  int32_t bad;              // a negative segment length was seen
+  int32_t nonuniform;       // lengths differ
+  int64_t n_empty;
+  int64_t len0;             // length of segment 0
+  int64_t max_len;
+  int64_t first, last;      // seg_off[0], seg_off[n]
+};
+
+// Launch wrappers (fold_kernels.hip).  All asynchronous on `stream`.
+hipError_t launch_fold_fixed(const FoldParams& p, int64_t n_tasks, hipStream_t stream);
+hipError_t launch_fold_flat(const FoldParams& p, int64_t n_tasks, hipStream_t stream);
+hipError_t launch_plan(const int64_t* off, int64_t n_seg, int64_t task_events, int64_t n_tasks,
+                       int64_t* plan, hipStream_t stream);
+hipError_t launch_analyze_csr(const int64_t* off, int64_t n_seg, CsrAnalysis* d_result, hipStream_t stream);
+hipError_t launch_fill_empty(const int64_t* off, int64_t n_seg, const uint4* init, uint4* out,
+                             hipStream_t stream);
+// Stable compaction of non-empty segments: nz_off[n_nz+1], nz_map[n_nz].  d_block_counts is scratch of
+// ceil(n_seg/1024)+1 int64.
+hipError_t launch_compact_nonempty(const int64_t* off, int64_t n_seg, int64_t* d_block_counts,
+                                   int64_t* nz_off, int64_t* nz_map, hipStream_t stream);
+hipError_t launch_partition_hash(const uint16_t* utf16, const int64_t* str_off, int64_t n,
+                                 int32_t n_partitions, int32_t* part_out, hipStream_t stream);
+hipError_t launch_stream_probe(const uint4* src, int64_t n_vec, uint32_t* sink, hipStream_t stream);
+hipError_t launch_count_poisoned(const uint4* states, int64_t n, unsigned long long* d_count,
+                                 hipStream_t stream);
+
+}  // namespace surge

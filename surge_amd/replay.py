@@ -1,0 +1,233 @@
+"""``ReplayEngine`` — thin Python host over the C ABI (``include/surge_replay.h``).
+
+What it replaces in the reference: Kafka Streams restoring the aggregate KTable
+(``modules/common/src/main/scala/surge/kafka/streams/SurgeStateStoreConsumer.scala:57-76``)
+followed by one ``readState`` per actor start; here the state store is rebuilt by folding the
+events topic on the GPU —
+``events.foldLeft(state)(handleEvent)`` (``.../scaladsl/command/CommandModels.scala:26``).
+
+Host (numpy) buffers go through ``surge_replay_load_csr``; device buffers (torch tensors on
+``cuda``) are bound zero-copy.  PyTorch is only plumbing here: device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+
+from . import _native
+from .schema import (
+    ALGO_AUTO,
+    DEFAULT_ALGEBRA,
+    EVENT_DTYPE,
+    STATE_DTYPE,
+    CSchema,
+    CStats,
+    EventAlgebra,
+)
+
+_STATUS = {0: "OK", -1: "INVALID", -2: "STATE", -3: "DEVICE", -4: "NOMEM", -5: "UNSUPPORTED", -6: "RANGE"}
+
+
+class ReplayError(RuntimeError):
+    """A C-ABI call returned a negative status (maps to a failed ``Future`` on the JVM side)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"surge_replay status {status} ({_STATUS.get(status, '?')}): {message}")
+        self.status = status
+
+
+def _np_ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _dev_ptr(t, nbytes_min: int = 0):
+    if t is None:
+        return None
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError("device buffers must be contiguous CUDA/HIP tensors")
+    if t.numel() * t.element_size() < nbytes_min:
+        raise ValueError("device buffer too small")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def default_schema_from_library() -> CSchema:
+    s = CSchema()
+    rc = _native.load().surge_replay_default_schema(ctypes.byref(s))
+    if rc != 0:
+        raise ReplayError(rc, "surge_replay_default_schema")
+    return s
+
+
+class ReplayEngine:
+    """One handle = one GPU = one shard of the event log."""
+
+    def __init__(self, algebra: EventAlgebra = DEFAULT_ALGEBRA, device: int = 0):
+        self._lib = _native.load()
+        self._h = ctypes.c_void_p()
+        self.algebra = algebra
+        self.device = device
+        sc = algebra.to_c()
+        rc = self._lib.surge_replay_create(ctypes.byref(sc), device, ctypes.byref(self._h))
+        if rc != 0:
+            msg = self._lib.surge_replay_last_error(None)
+            raise ReplayError(rc, msg.decode() if msg else "surge_replay_create failed")
+        self.n_agg = 0
+        self._keep = []  # tensors bound zero-copy must outlive the binding
+
+    # -- lifecycle -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.surge_replay_destroy(self._h)
+            self._h = ctypes.c_void_p()
+            self._keep = []
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self._lib.surge_replay_last_error(self._h)
+            raise ReplayError(rc, msg.decode() if msg else "")
+
+    def use_stream(self, stream) -> None:
+        """Launch on a ``torch.cuda.Stream`` (or ``None`` for the default stream)."""
+        ptr = None if stream is None else ctypes.c_void_p(stream.cuda_stream)
+        self._check(self._lib.surge_replay_set_stream(self._h, ptr))
+
+    def synchronize(self) -> None:
+        self._check(self._lib.surge_replay_synchronize(self._h))
+
+    # -- load ---------------------------------------------------------------------------------
+    def load_csr(self, seg_off, events, init_state=None, state_out=None) -> None:
+        """Bind one shard's CSR log.  numpy arrays are copied H2D; CUDA tensors are bound in place."""
+        if _is_torch(events) or _is_torch(seg_off):
+            import torch
+
+            if seg_off.dtype != torch.int64:
+                raise ValueError("seg_off must be int64")
+            n_agg = seg_off.numel() - 1
+            n_events = (events.numel() * events.element_size()) // 16
+            self._keep = [seg_off, events, init_state, state_out]
+            self._check(
+                self._lib.surge_replay_bind_device_csr(
+                    self._h,
+                    _dev_ptr(seg_off),
+                    n_agg,
+                    _dev_ptr(events),
+                    n_events,
+                    _dev_ptr(init_state, n_agg * 64),
+                    _dev_ptr(state_out, n_agg * 64),
+                )
+            )
+        else:
+            seg_off = np.ascontiguousarray(seg_off, dtype=np.int64)
+            events = np.ascontiguousarray(events, dtype=EVENT_DTYPE)
+            n_agg = seg_off.shape[0] - 1
+            if n_agg < 0:
+                raise ValueError("seg_off needs at least one entry")
+            if init_state is not None:
+                init_state = np.ascontiguousarray(init_state, dtype=STATE_DTYPE)
+                if init_state.shape[0] != n_agg:
+                    raise ValueError("init_state must have one entry per aggregate")
+            self._keep = []
+            self._check(
+                self._lib.surge_replay_load_csr(
+                    self._h, _np_ptr(seg_off), n_agg, _np_ptr(events), events.shape[0], _np_ptr(init_state)
+                )
+            )
+        self.n_agg = n_agg
+
+    # -- fold ------------------------------------------------------------------------------------
+    def fold(self, algo: int = ALGO_AUTO) -> None:
+        self._check(self._lib.surge_replay_fold(self._h, algo))
+
+    def append_fold(self, group_agg, group_off, events) -> None:
+        """Micro-batch re-fold onto the resident state (K3); see ``surge_replay_append_fold``."""
+        if _is_torch(events):
+            n_groups = group_agg.numel()
+            n_events = (events.numel() * events.element_size()) // 16
+            self._check(
+                self._lib.surge_replay_append_fold_device(
+                    self._h, _dev_ptr(group_agg), _dev_ptr(group_off), n_groups, _dev_ptr(events), n_events
+                )
+            )
+            self._keep_batch = [group_agg, group_off, events]
+        else:
+            group_agg = np.ascontiguousarray(group_agg, dtype=np.int64)
+            group_off = np.ascontiguousarray(group_off, dtype=np.int64)
+            events = np.ascontiguousarray(events, dtype=EVENT_DTYPE)
+            if group_off.shape[0] != group_agg.shape[0] + 1:
+                raise ValueError("group_off needs n_groups + 1 entries")
+            self._check(
+                self._lib.surge_replay_append_fold(
+                    self._h, _np_ptr(group_agg), _np_ptr(group_off), group_agg.shape[0], _np_ptr(events), events.shape[0]
+                )
+            )
+
+    # -- read --------------------------------------------------------------------------------------
+    def snapshot(self) -> np.ndarray:
+        out = np.zeros(self.n_agg, dtype=STATE_DTYPE)
+        self._check(self._lib.surge_replay_snapshot(self._h, _np_ptr(out), None))
+        return out
+
+    def get(self, agg_idx: int) -> Optional[np.ndarray]:
+        """Fixed-width state of one aggregate, or ``None`` when it is absent (KTable miss)."""
+        out = np.zeros(1, dtype=STATE_DTYPE)
+        present = ctypes.c_uint8(0)
+        self._check(self._lib.surge_replay_get(self._h, int(agg_idx), _np_ptr(out), ctypes.byref(present)))
+        return out[0] if present.value else None
+
+    def get_raw(self, agg_idx: int) -> np.ndarray:
+        out = np.zeros(1, dtype=STATE_DTYPE)
+        self._check(self._lib.surge_replay_get(self._h, int(agg_idx), _np_ptr(out), None))
+        return out[0]
+
+    def device_state(self):
+        """The resident ``n_agg x 64`` byte state array as a ``torch.uint8`` view (no copy)."""
+        import torch
+
+        ptr = ctypes.c_void_p()
+        n = ctypes.c_int64()
+        self._check(self._lib.surge_replay_device_state(self._h, ctypes.byref(ptr), ctypes.byref(n)))
+        for t in self._keep:
+            if t is not None and _is_torch(t) and t.data_ptr() == ptr.value:
+                return t.view(torch.uint8).reshape(-1)[: n.value * 64].view(n.value, 64)
+        # handle-owned buffer: wrap through the CUDA array interface
+        iface = {"shape": (n.value, 64), "typestr": "|u1", "data": (ptr.value or 0, False), "version": 3}
+        holder = type("_DevView", (), {"__cuda_array_interface__": iface})()
+        return torch.as_tensor(holder, device=f"cuda:{self.device}")
+
+    # -- measurement ----------------------------------------------------------------------------------
+    def stats(self) -> CStats:
+        st = CStats()
+        self._check(self._lib.surge_replay_stats(self._h, ctypes.byref(st)))
+        return st
+
+    def stream_probe_ms(self, tensor) -> float:
+        ms = ctypes.c_double(0.0)
+        nbytes = (tensor.numel() * tensor.element_size()) // 16 * 16
+        self._check(self._lib.surge_replay_stream_probe(self._h, _dev_ptr(tensor), nbytes, ctypes.byref(ms)))
+        return ms.value
+
+    def partition_hash_device(self, d_utf16, d_str_off, n_partitions: int, d_out) -> None:
+        n = d_str_off.numel() - 1
+        self._check(
+            self._lib.surge_replay_partition_hash_device(
+                self._h, _dev_ptr(d_utf16), _dev_ptr(d_str_off), n, n_partitions, _dev_ptr(d_out)
+            )
+        )
