@@ -156,7 +156,9 @@ typedef struct surge_replay_stats_t {
   int32_t last_algo;           /* SURGE_ALGO_* actually run                               */
   int32_t n_tasks;             /* wave tasks of the last fold                             */
   int64_t n_folds;             /* folds since create                                      */
-  int64_t n_poisoned;          /* aggregates flagged POISONED by the last snapshot, -1 if unknown */
+  int64_t n_poisoned;          /* aggregates flagged POISONED after the last fold                */
+  double  sum_fold_kernel_ms;  /* sum of the dominant kernel's HIP-event times since stats_reset  */
+  int64_t timed_folds;         /* number of folds in that sum (at most 256 are kept)              */
 } surge_replay_stats_t;
 
 typedef struct surge_replay_handle surge_replay_handle;
@@ -242,8 +244,13 @@ int32_t surge_replay_partition_hash_device(surge_replay_handle* h, const uint16_
                                            const int64_t* d_str_off, int64_t n,
                                            int32_t n_partitions, int32_t* d_part_out);
 
+/* Redirect the fold's output to another device buffer (n_agg x 64 B, 16-byte aligned) without
+ * re-analysing the bound log; lets a host double-buffer snapshots under an overlapped all-gather. */
+int32_t surge_replay_set_state_out(surge_replay_handle* h, void* d_state_out);
+
 /* ---- measurement --------------------------------------------------------------- */
 int32_t surge_replay_stats(surge_replay_handle* h, surge_replay_stats_t* out);
+int32_t surge_replay_stats_reset(surge_replay_handle* h);
 
 /* HBM read-stream ceiling probe: reads n_bytes (multiple of 16) from d_src with
  * 16 B/lane loads and returns the HIP-event time of one launch.  Used by

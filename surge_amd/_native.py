@@ -38,7 +38,9 @@ EXPORTS = (
     "surge_replay_device_state",
     "surge_replay_partition_hash",
     "surge_replay_partition_hash_device",
+    "surge_replay_set_state_out",
     "surge_replay_stats",
+    "surge_replay_stats_reset",
     "surge_replay_stream_probe",
 )
 
@@ -129,7 +131,9 @@ def load() -> ctypes.CDLL:
         "surge_replay_device_state": ([vp, ctypes.POINTER(vp), ctypes.POINTER(i64)], i32),
         "surge_replay_partition_hash": ([vp, vp, i64, i32, vp], i32),
         "surge_replay_partition_hash_device": ([vp, vp, vp, i64, i32, vp], i32),
+        "surge_replay_set_state_out": ([vp, vp], i32),
         "surge_replay_stats": ([vp, ctypes.POINTER(CStats)], i32),
+        "surge_replay_stats_reset": ([vp], i32),
         "surge_replay_stream_probe": ([vp, vp, i64, ctypes.POINTER(ctypes.c_double)], i32),
     }
     for name in EXPORTS:

@@ -77,6 +77,9 @@ struct surge_replay_handle {
              ev_h1 = nullptr;
   bool timing_valid = false, h2d_valid = false;
   surge_replay_stats_t st{};
+  // one HIP-event pair per fold since the last stats_reset (kernel time of the dominant kernel)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> fold_events;
+  size_t folds_since_reset = 0;
 
   // host mirror for point reads (S2)
   std::mutex mu;
@@ -173,6 +176,30 @@ int64_t algorithmic_bytes(int64_t n_events, int64_t n_agg, bool has_init) {
   return 16 * n_events + 8 * (n_agg + 1) + 64 * n_agg * (has_init ? 2 : 1);
 }
 
+constexpr size_t kMaxTimedFolds = 256;
+
+// Event pair bracketing the dominant kernel of this fold; pairs are kept per fold (up to
+// kMaxTimedFolds since the last stats_reset) so a benchmark can average them without syncing per step.
+int32_t next_fold_events(surge_replay_handle* h, hipEvent_t* e0, hipEvent_t* e1) {
+  size_t i = h->folds_since_reset < kMaxTimedFolds ? h->folds_since_reset : kMaxTimedFolds - 1;
+  while (h->fold_events.size() <= i) {
+    hipEvent_t a = nullptr, b = nullptr;
+    HIPCHK(h, hipEventCreate(&a));
+    hipError_t e = hipEventCreate(&b);
+    if (e != hipSuccess) {
+      (void)hipEventDestroy(a);
+      return fail_hip(h, e, "hipEventCreate");
+    }
+    h->fold_events.emplace_back(a, b);
+  }
+  *e0 = h->fold_events[i].first;
+  *e1 = h->fold_events[i].second;
+  h->ev_k0 = *e0;
+  h->ev_k1 = *e1;
+  h->folds_since_reset += 1;
+  return SURGE_OK;
+}
+
 // plan + flat fold over an arbitrary kernel-facing CSR
 int32_t run_flat(surge_replay_handle* h, FoldParams& p, const int64_t* off, int64_t n_seg, int64_t span_events) {
   const int64_t task_events = choose_task_events(span_events);
@@ -182,9 +209,12 @@ int32_t run_flat(surge_replay_handle* h, FoldParams& p, const int64_t* off, int6
   p.seg_off = off;
   p.plan = (const int64_t*)h->plan.ptr;
   p.n_seg = n_seg;
-  HIPCHK(h, hipEventRecord(h->ev_k0, h->stream));
+  hipEvent_t e0, e1;
+  const int32_t rc = next_fold_events(h, &e0, &e1);
+  if (rc != SURGE_OK) return rc;
+  HIPCHK(h, hipEventRecord(e0, h->stream));
   HIPCHK(h, launch_fold_flat(p, n_tasks, h->stream));
-  HIPCHK(h, hipEventRecord(h->ev_k1, h->stream));
+  HIPCHK(h, hipEventRecord(e1, h->stream));
   h->st.n_tasks = (int32_t)n_tasks;
   return SURGE_OK;
 }
@@ -233,7 +263,7 @@ int32_t surge_replay_create(const surge_replay_schema* schema, int32_t device_id
     delete h;
     return fail(nullptr, SURGE_E_DEVICE, "hipSetDevice failed");
   }
-  hipEvent_t* evs[] = {&h->ev_total0, &h->ev_k0, &h->ev_k1, &h->ev_total1, &h->ev_h0, &h->ev_h1};
+  hipEvent_t* evs[] = {&h->ev_total0, &h->ev_total1, &h->ev_h0, &h->ev_h1};
   for (hipEvent_t* ev : evs) {
     e = hipEventCreate(ev);
     if (e != hipSuccess) {
@@ -255,9 +285,13 @@ int32_t surge_replay_destroy(surge_replay_handle* h) {
                     &h->nz_map, &h->block_counts, &h->plan, &h->batch_group_agg, &h->batch_group_off,
                     &h->batch_events, &h->poison_count};
   for (DevBuf* b : bufs) b->release();
-  hipEvent_t evs[] = {h->ev_total0, h->ev_k0, h->ev_k1, h->ev_total1, h->ev_h0, h->ev_h1};
+  hipEvent_t evs[] = {h->ev_total0, h->ev_total1, h->ev_h0, h->ev_h1};
   for (hipEvent_t ev : evs)
     if (ev) (void)hipEventDestroy(ev);
+  for (auto& pr : h->fold_events) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
   delete h;
   return SURGE_OK;
 }
@@ -371,9 +405,12 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       p.n_seg = h->n_agg;
       p.fixed_len = L;
       p.segs_per_task = G;
-      HIPCHK(h, hipEventRecord(h->ev_k0, h->stream));
+      hipEvent_t e0, e1;
+      const int32_t rc = next_fold_events(h, &e0, &e1);
+      if (rc != SURGE_OK) return rc;
+      HIPCHK(h, hipEventRecord(e0, h->stream));
       HIPCHK(h, launch_fold_fixed(p, n_tasks, h->stream));
-      HIPCHK(h, hipEventRecord(h->ev_k1, h->stream));
+      HIPCHK(h, hipEventRecord(e1, h->stream));
       h->st.n_tasks = (int32_t)n_tasks;
     } else if (h->an.n_empty > 0) {
       p.out_map = (const int64_t*)h->nz_map.ptr;
@@ -384,8 +421,11 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       if (rc != SURGE_OK) return rc;
     }
   } else {
-    HIPCHK(h, hipEventRecord(h->ev_k0, h->stream));
-    HIPCHK(h, hipEventRecord(h->ev_k1, h->stream));
+    hipEvent_t e0, e1;
+    const int32_t rc = next_fold_events(h, &e0, &e1);
+    if (rc != SURGE_OK) return rc;
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    HIPCHK(h, hipEventRecord(e1, h->stream));
   }
   if (h->an.n_empty > 0 || span == 0)
     HIPCHK(h, launch_fill_empty(h->d_seg_off, h->n_agg, h->d_init, h->d_state, h->stream));
@@ -567,6 +607,14 @@ int32_t surge_replay_stats(surge_replay_handle* h, surge_replay_stats_t* out) {
     h->st.last_fold_kernel_ms = ms;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev_total0, h->ev_total1));
     h->st.last_fold_total_ms = ms;
+    const size_t n = h->folds_since_reset < kMaxTimedFolds ? h->folds_since_reset : kMaxTimedFolds;
+    double sum = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+      HIPCHK(h, hipEventElapsedTime(&ms, h->fold_events[i].first, h->fold_events[i].second));
+      sum += ms;
+    }
+    h->st.sum_fold_kernel_ms = sum;
+    h->st.timed_folds = (int64_t)n;
   }
   if (h->h2d_valid) {
     HIPCHK(h, hipEventSynchronize(h->ev_h1));
@@ -583,6 +631,26 @@ int32_t surge_replay_stats(surge_replay_handle* h, surge_replay_stats_t* out) {
     h->st.n_poisoned = (int64_t)c;
   }
   *out = h->st;
+  return SURGE_OK;
+}
+
+int32_t surge_replay_stats_reset(surge_replay_handle* h) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  DeviceGuard g(h->device);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->folds_since_reset = 0;
+  h->timing_valid = false;
+  h->st.sum_fold_kernel_ms = 0.0;
+  h->st.timed_folds = 0;
+  return SURGE_OK;
+}
+
+int32_t surge_replay_set_state_out(surge_replay_handle* h, void* d_state_out) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->bound) return fail(h, SURGE_E_STATE, "set_state_out before load_csr/bind_device_csr");
+  if (!d_state_out || ((uintptr_t)d_state_out & 15)) return fail(h, SURGE_E_INVALID, "state buffer must be non-NULL and 16-byte aligned");
+  h->d_state = (uint4*)d_state_out;
+  h->fold_epoch.fetch_add(1);
   return SURGE_OK;
 }
 

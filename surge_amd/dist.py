@@ -1,0 +1,164 @@
+"""Multi-GPU layout: one process per GPU, aggregates sharded by the reference's own shard map.
+
+The path shards naturally — aggregates are independent (one writer per aggregate,
+``modules/surge-docs/src/main/paradox/overview.md:37-39``):
+
+    partition = abs(MurmurHash3.stringHash(aggregateId.takeWhile(_ != ':')) % numPartitions)
+        — modules/common/src/main/scala/surge/kafka/KafkaPartitioner.scala:8,38-42
+    gpu       = partition % world_size          (the reference assigns partitions to nodes through the
+                                                 Kafka Streams consumer group, PartitionAssignments.scala:51-63)
+
+Each rank folds its shard with no communication.  The single exchange step is the all-gather of the
+final snapshot (``A_r x 64`` bytes per rank, counts differ per rank, so shards are padded to the
+max count) over RCCL/xGMI — ``torch.distributed`` with backend ``nccl`` on GPUs, ``gloo`` in the CPU
+tests.  The gather runs on a side stream so it overlaps the next replay's fold.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+ID_PREFIX = "acct-"
+ID_DIGITS = 8
+
+
+def aggregate_id(i: int) -> str:
+    """Synthetic aggregate ids of the sharded configs: ``acct-%08d``."""
+    return f"{ID_PREFIX}{i:0{ID_DIGITS}d}"
+
+
+def shard_of_partition(partition, world_size: int):
+    return partition % world_size
+
+
+def id_table_utf16(ids, xp_device=None):
+    """UTF-16 code units of ``acct-%08d`` for integer ids (numpy array or torch tensor) + offsets."""
+    width = len(ID_PREFIX) + ID_DIGITS
+    if type(ids).__module__.startswith("torch"):
+        import torch
+
+        n = ids.numel()
+        out = torch.empty((n, width), dtype=torch.int16, device=ids.device)
+        for k, ch in enumerate(ID_PREFIX):
+            out[:, k] = ord(ch)
+        for k in range(ID_DIGITS):
+            out[:, len(ID_PREFIX) + k] = ((ids // (10 ** (ID_DIGITS - 1 - k))) % 10 + 48).to(torch.int16)
+        off = torch.arange(n + 1, dtype=torch.int64, device=ids.device) * width
+        return out.reshape(-1), off
+    ids = np.asarray(ids, dtype=np.int64)
+    n = ids.shape[0]
+    out = np.empty((n, width), dtype=np.uint16)
+    for k, ch in enumerate(ID_PREFIX):
+        out[:, k] = ord(ch)
+    for k in range(ID_DIGITS):
+        out[:, len(ID_PREFIX) + k] = (ids // (10 ** (ID_DIGITS - 1 - k))) % 10 + 48
+    return out.reshape(-1), np.arange(n + 1, dtype=np.int64) * width
+
+
+def partitions_of_ids(ids, n_partitions: int, engine=None):
+    """``partitionForKey`` of ``acct-%08d`` ids.  CUDA tensors go through kernel K4 (needs ``engine``),
+    host arrays through the C ABI's CPU entry point."""
+    if type(ids).__module__.startswith("torch") and ids.is_cuda:
+        import torch
+
+        if engine is None:
+            raise ValueError("device ids need a ReplayEngine to launch the hash kernel on")
+        utf16, off = id_table_utf16(ids)
+        out = torch.empty(ids.numel(), dtype=torch.int32, device=ids.device)
+        engine.partition_hash_device(utf16, off, n_partitions, out)
+        engine.synchronize()
+        return out
+    import ctypes
+
+    from . import _native
+
+    host = ids.numpy() if type(ids).__module__.startswith("torch") else np.asarray(ids, dtype=np.int64)
+    utf16, off = id_table_utf16(host)
+    out = np.zeros(host.shape[0], dtype=np.int32)
+    if host.shape[0]:
+        rc = _native.load().surge_replay_partition_hash(
+            utf16.ctypes.data_as(ctypes.c_void_p), off.ctypes.data_as(ctypes.c_void_p), host.shape[0], n_partitions,
+            out.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f"surge_replay_partition_hash failed: {rc}")
+    return out
+
+
+def local_aggregate_ids(n_global: int, n_partitions: int, rank: int, world_size: int, device="cpu", engine=None):
+    """Global indices (ascending) of the aggregates rank ``rank`` owns."""
+    if str(device).startswith("cuda"):
+        import torch
+
+        ids = torch.arange(n_global, dtype=torch.int64, device=device)
+        part = partitions_of_ids(ids, n_partitions, engine).to(torch.int64)
+        return ids[shard_of_partition(part, world_size) == rank]
+    ids = np.arange(n_global, dtype=np.int64)
+    part = partitions_of_ids(ids, n_partitions).astype(np.int64)
+    return ids[shard_of_partition(part, world_size) == rank]
+
+
+class SnapshotGather:
+    """All-gather of the per-rank final snapshots, overlapped with the next fold.
+
+    ``launch(local_states, ready_event)`` enqueues the collective on a side stream after
+    ``ready_event``; ``result(slot)`` is ``[world, max_count, 64]`` (rows beyond a rank's count are
+    padding).  Two output slots alternate so a gather can still be in flight while the next fold
+    writes the other snapshot buffer.
+    """
+
+    def __init__(self, n_local: int, device, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.dist, self.torch = dist, torch
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = torch.device(device)
+        counts = torch.tensor([n_local], dtype=torch.int64, device=self.device)
+        all_counts = [torch.zeros_like(counts) for _ in range(self.world)]
+        dist.all_gather(all_counts, counts, group=group)
+        self.counts = [int(c.item()) for c in all_counts]
+        self.max_count = max(self.counts)
+        self.n_local = n_local
+        self.out = [torch.zeros((self.world, self.max_count, 64), dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.cuda = self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.done = [None, None]
+
+    def make_local_buffers(self):
+        """Two snapshot buffers padded to ``max_count`` rows (the fold writes the first ``n_local``)."""
+        return [self.torch.zeros((self.max_count, 64), dtype=self.torch.uint8, device=self.device) for _ in range(2)]
+
+    def launch(self, slot: int, local_padded, ready_event=None) -> None:
+        if self.cuda:
+            with self.torch.cuda.stream(self.stream):
+                if ready_event is not None:
+                    self.stream.wait_event(ready_event)
+                self.dist.all_gather_into_tensor(self.out[slot].view(-1), local_padded.view(-1), group=self.group)
+                ev = self.torch.cuda.Event()
+                ev.record(self.stream)
+                self.done[slot] = ev
+        else:
+            parts = [self.out[slot][r] for r in range(self.world)]
+            self.dist.all_gather(parts, local_padded, group=self.group)
+
+    def wait(self, slot: int, stream=None) -> None:
+        """Make ``stream`` (default: current) wait for slot ``slot``'s gather."""
+        if self.cuda and self.done[slot] is not None:
+            (stream or self.torch.cuda.current_stream(self.device)).wait_event(self.done[slot])
+
+    def result(self, slot: int):
+        return self.out[slot]
+
+    def assemble(self, slot: int, owner_ids: List) -> "np.ndarray":
+        """Host-side reassembly into global aggregate order (for checks): ``owner_ids[r]`` are the
+        global indices rank r owns."""
+        flat = self.out[slot].cpu().numpy()
+        n_global = sum(len(o) for o in owner_ids)
+        res = np.zeros((n_global, 64), dtype=np.uint8)
+        for r, ids in enumerate(owner_ids):
+            ids = np.asarray(ids.cpu() if hasattr(ids, "cpu") else ids)
+            res[ids] = flat[r, : len(ids)]
+        return res

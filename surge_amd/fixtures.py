@@ -1,0 +1,424 @@
+"""The reference's own sample models, restated on the host mirror (used by tests and examples).
+
+* Counter — ``modules/command-engine/scaladsl/src/test/scala/surge/scaladsl/TestBoundedContext.scala``
+  (State :15, commands :18-39, events :49-69, handleEvent :77-89, processCommand :91-106,
+  formats :122-134).
+* BankAccount — ``modules/surge-docs/src/test/scala/docs/command/BankAccountCommandModel.scala``
+  (aggregate :19, commands :23-28, events :32-48, processCommand :53-79, handleEvent :81-86).
+
+``handle_event`` below is the literal case analysis of the Scala code (JVM ``Int`` wrap included);
+the ``event_algebra`` beside it is what the GPU replays.  The two are checked against each other
+in ``tests/test_host_models.py``.
+"""
+from __future__ import annotations
+
+import json
+import uuid
+from dataclasses import dataclass, replace
+from typing import Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from .command import ReplayableCommandModel, SurgeCommandBusinessLogic
+from .core import (
+    KafkaTopic,
+    SerializedAggregate,
+    SerializedMessage,
+    SurgeAggregateFormatting,
+    SurgeEventReadFormatting,
+    SurgeEventWriteFormatting,
+)
+from .schema import (
+    CLS_CREATE,
+    CLS_MATERIALIZE,
+    CLS_REQUIRE,
+    D_BALANCE_SET,
+    D_COUNT_ADD,
+    D_COUNT_SUB,
+    D_POISON,
+    D_VERSION_SET,
+    STATE_DTYPE,
+    STATE_PRESENT,
+    EventAlgebra,
+)
+
+
+def _i32(x: int) -> int:
+    """JVM ``Int`` arithmetic: wrap to 32-bit two's complement."""
+    x &= 0xFFFFFFFF
+    return x - (1 << 32) if x & 0x80000000 else x
+
+
+# ======================================================================================
+# Counter (TestBoundedContext)
+# ======================================================================================
+@dataclass(frozen=True)
+class State:
+    aggregateId: str
+    count: int
+    version: int
+
+
+@dataclass(frozen=True)
+class Increment:
+    aggregateId: str
+
+
+@dataclass(frozen=True)
+class Decrement:
+    aggregateId: str
+
+
+@dataclass(frozen=True)
+class DoNothing:
+    aggregateId: str
+
+
+@dataclass(frozen=True)
+class CreateNoOpEvent:
+    aggregateId: str
+
+
+@dataclass(frozen=True)
+class FailCommandProcessing:
+    aggregateId: str
+    withError: Exception
+
+
+@dataclass(frozen=True)
+class CreateExceptionThrowingEvent:
+    aggregateId: str
+    throwable: Exception
+
+
+@dataclass(frozen=True)
+class CountIncremented:
+    aggregateId: str
+    incrementBy: int
+    sequenceNumber: int
+    eventName = "countIncremented"
+
+
+@dataclass(frozen=True)
+class CountDecremented:
+    aggregateId: str
+    decrementBy: int
+    sequenceNumber: int
+    eventName = "countDecremented"
+
+
+@dataclass(frozen=True)
+class NoOpEvent:
+    aggregateId: str
+    sequenceNumber: int
+    eventName = "no-op"
+
+
+@dataclass(frozen=True)
+class ExceptionThrowingEvent:
+    aggregateId: str
+    sequenceNumber: int
+    throwable: Exception
+    eventName = "exception-throwing"
+
+
+CounterEvent = Union[CountIncremented, CountDecremented, NoOpEvent, ExceptionThrowingEvent]
+
+#: event type codes of the Counter model's own (4-type) algebra
+CT_NOOP, CT_INC, CT_DEC, CT_THROW = 0, 1, 2, 3
+
+COUNTER_ALGEBRA = EventAlgebra(
+    desc=(
+        CLS_MATERIALIZE,                                   # NoOpEvent           :85
+        CLS_MATERIALIZE | D_COUNT_ADD | D_VERSION_SET,     # CountIncremented    :81-82
+        CLS_MATERIALIZE | D_COUNT_SUB | D_VERSION_SET,     # CountDecremented    :83-84
+        D_POISON,                                          # ExceptionThrowingEvent :86
+    ),
+    names=("no-op", "countIncremented", "countDecremented", "exception-throwing"),
+)
+
+
+class CounterCommandModel(ReplayableCommandModel[State, object, CounterEvent]):
+    # TestBoundedContext.scala:77-89
+    def handle_event(self, agg: Optional[State], evt: CounterEvent) -> Optional[State]:
+        current = agg if agg is not None else State(evt.aggregateId, 0, 0)
+        if isinstance(evt, CountIncremented):
+            new_state = replace(current, count=_i32(current.count + evt.incrementBy), version=evt.sequenceNumber)
+        elif isinstance(evt, CountDecremented):
+            new_state = replace(current, count=_i32(current.count - evt.decrementBy), version=evt.sequenceNumber)
+        elif isinstance(evt, NoOpEvent):
+            new_state = current
+        elif isinstance(evt, ExceptionThrowingEvent):
+            raise evt.throwable
+        else:
+            raise TypeError(f"MatchError: {evt!r}")
+        return new_state
+
+    # TestBoundedContext.scala:91-106
+    def process_command(self, agg: Optional[State], cmd) -> Sequence[CounterEvent]:
+        new_sequence_number = (agg.version if agg is not None else 0) + 1
+        if isinstance(cmd, Increment):
+            return [CountIncremented(cmd.aggregateId, 1, new_sequence_number)]
+        if isinstance(cmd, Decrement):
+            return [CountDecremented(cmd.aggregateId, 1, new_sequence_number)]
+        if isinstance(cmd, CreateNoOpEvent):
+            return [NoOpEvent(cmd.aggregateId, new_sequence_number)]
+        if isinstance(cmd, DoNothing):
+            return []
+        if isinstance(cmd, FailCommandProcessing):
+            raise cmd.withError
+        if isinstance(cmd, CreateExceptionThrowingEvent):
+            return [ExceptionThrowingEvent(cmd.aggregateId, new_sequence_number, cmd.throwable)]
+        raise RuntimeError("Received unexpected message in command handler! This should not happen and indicates a bad test")
+
+    # ---- additive: the replay declaration -------------------------------------------------
+    def event_algebra(self) -> EventAlgebra:
+        return COUNTER_ALGEBRA
+
+    def encode_event(self, event: CounterEvent):
+        if isinstance(event, CountIncremented):
+            return CT_INC, event.sequenceNumber, event.incrementBy, None
+        if isinstance(event, CountDecremented):
+            return CT_DEC, event.sequenceNumber, event.decrementBy, None
+        if isinstance(event, NoOpEvent):
+            return CT_NOOP, event.sequenceNumber, 0, None
+        if isinstance(event, ExceptionThrowingEvent):
+            return CT_THROW, event.sequenceNumber, 0, None
+        raise TypeError(f"not a Counter event: {event!r}")
+
+    def aggregate_id_of(self, event: CounterEvent) -> str:
+        return event.aggregateId
+
+    def state_from_fixed(self, aggregate_id: str, fixed) -> State:
+        return State(aggregate_id, int(fixed["count"]), int(fixed["version"]))
+
+    def state_to_fixed(self, aggregate: State) -> np.ndarray:
+        s = np.zeros(1, dtype=STATE_DTYPE)
+        a = self.event_algebra()
+        s["min_arg"], s["max_arg"] = a.default_min_arg, a.default_max_arg
+        s["count"], s["version"], s["flags"] = aggregate.count, aggregate.version, STATE_PRESENT
+        return s
+
+
+class CounterAggregateFormat(SurgeAggregateFormatting[State]):
+    """``Json.toJson(agg).toString().getBytes()`` / ``Json.parse(bytes).asOpt[State]`` (:126-134).
+
+    play-json's ``Json.format`` macro writes the case-class fields in declaration order, compact.
+    """
+
+    def write_state(self, agg: State) -> SerializedAggregate:
+        text = json.dumps(
+            {"aggregateId": agg.aggregateId, "count": agg.count, "version": agg.version},
+            separators=(",", ":"),
+            ensure_ascii=False,
+        )
+        return SerializedAggregate(text.encode("utf-8"))
+
+    def read_state(self, data: bytes) -> Optional[State]:
+        try:
+            o = json.loads(data)
+            return State(str(o["aggregateId"]), int(o["count"]), int(o["version"]))
+        except Exception:
+            return None  # asOpt
+
+
+class CounterEventFormat(SurgeEventWriteFormatting[CounterEvent], SurgeEventReadFormatting[CounterEvent]):
+    """Key ``"<aggregateId>:<sequenceNumber>"`` + JSON value (:122-124).  ``read_event`` is additive."""
+
+    def write_event(self, evt: CounterEvent) -> SerializedMessage:
+        body = {"aggregateId": evt.aggregateId}
+        if isinstance(evt, CountIncremented):
+            body["incrementBy"] = evt.incrementBy
+        elif isinstance(evt, CountDecremented):
+            body["decrementBy"] = evt.decrementBy
+        body["sequenceNumber"] = evt.sequenceNumber
+        body["_type"] = evt.eventName  # discriminator of the sealed-trait Format (:48)
+        return SerializedMessage(
+            f"{evt.aggregateId}:{evt.sequenceNumber}", json.dumps(body, separators=(",", ":")).encode("utf-8")
+        )
+
+    def read_event(self, msg: SerializedMessage) -> CounterEvent:
+        o = json.loads(msg.value)
+        t = o.get("_type")
+        if t == "countIncremented":
+            return CountIncremented(o["aggregateId"], int(o["incrementBy"]), int(o["sequenceNumber"]))
+        if t == "countDecremented":
+            return CountDecremented(o["aggregateId"], int(o["decrementBy"]), int(o["sequenceNumber"]))
+        if t == "no-op":
+            return NoOpEvent(o["aggregateId"], int(o["sequenceNumber"]))
+        raise ValueError(f"unreadable event {msg.key}")
+
+
+class CounterBusinessLogic(SurgeCommandBusinessLogic[State, object, CounterEvent]):
+    """``TestBoundedContext.businessLogic`` (:136-155)."""
+
+    aggregate_name = "CounterAggregate"
+    state_topic = KafkaTopic("testStateTopic")
+    events_topic = KafkaTopic("testEventsTopic")
+
+    def __init__(self):
+        self._model = CounterCommandModel()
+        self._agg_format = CounterAggregateFormat()
+        self._evt_format = CounterEventFormat()
+
+    def command_model(self):
+        return self._model
+
+    def aggregate_read_formatting(self):
+        return self._agg_format
+
+    def aggregate_write_formatting(self):
+        return self._agg_format
+
+    def event_write_formatting(self):
+        return self._evt_format
+
+
+# ======================================================================================
+# BankAccount (surge-docs sample)
+# ======================================================================================
+@dataclass(frozen=True)
+class BankAccount:
+    accountNumber: uuid.UUID
+    accountOwner: str
+    securityCode: str
+    balance: float
+
+
+@dataclass(frozen=True)
+class CreateAccount:
+    accountNumber: uuid.UUID
+    accountOwner: str
+    securityCode: str
+    initialBalance: float
+
+
+@dataclass(frozen=True)
+class CreditAccount:
+    accountNumber: uuid.UUID
+    amount: float
+
+
+@dataclass(frozen=True)
+class DebitAccount:
+    accountNumber: uuid.UUID
+    amount: float
+
+
+@dataclass(frozen=True)
+class BankAccountCreated:
+    accountNumber: uuid.UUID
+    accountOwner: str
+    securityCode: str
+    balance: float
+
+
+@dataclass(frozen=True)
+class BankAccountUpdated:
+    accountNumber: uuid.UUID
+    newBalance: float
+
+
+class AccountDoesNotExistException(Exception):
+    pass
+
+
+class InsufficientFundsException(Exception):
+    pass
+
+
+BA_CREATED, BA_UPDATED = 0, 1
+BANK_ACCOUNT_ALGEBRA = EventAlgebra(
+    desc=(
+        CLS_CREATE | D_BALANCE_SET,    # BankAccountCreated :83
+        CLS_REQUIRE | D_BALANCE_SET,   # BankAccountUpdated :84
+    ),
+    names=("BankAccountCreated", "BankAccountUpdated"),
+)
+
+
+class BankAccountCommandModel(ReplayableCommandModel[BankAccount, object, object]):
+    """The non-numeric fields (owner, security code) ride in a host-side side table keyed by the
+    account number: they are set once by ``BankAccountCreated`` and never folded."""
+
+    def __init__(self):
+        self.static_fields = {}
+
+    # BankAccountCommandModel.scala:53-79
+    def process_command(self, aggregate: Optional[BankAccount], command):
+        if isinstance(command, CreateAccount):
+            if aggregate is not None:
+                return []
+            return [BankAccountCreated(command.accountNumber, command.accountOwner, command.securityCode, command.initialBalance)]
+        if isinstance(command, CreditAccount):
+            if aggregate is None:
+                raise AccountDoesNotExistException(command.accountNumber)
+            return [BankAccountUpdated(aggregate.accountNumber, aggregate.balance + command.amount)]
+        if isinstance(command, DebitAccount):
+            if aggregate is None:
+                raise AccountDoesNotExistException(command.accountNumber)
+            if aggregate.balance >= command.amount:
+                return [BankAccountUpdated(aggregate.accountNumber, aggregate.balance - command.amount)]
+            raise InsufficientFundsException(aggregate.accountNumber)
+        raise TypeError(f"MatchError: {command!r}")
+
+    # BankAccountCommandModel.scala:81-86
+    def handle_event(self, aggregate: Optional[BankAccount], event) -> Optional[BankAccount]:
+        if isinstance(event, BankAccountCreated):
+            return BankAccount(event.accountNumber, event.accountOwner, event.securityCode, event.balance)
+        if isinstance(event, BankAccountUpdated):
+            return None if aggregate is None else replace(aggregate, balance=event.newBalance)
+        raise TypeError(f"MatchError: {event!r}")
+
+    def event_algebra(self) -> EventAlgebra:
+        return BANK_ACCOUNT_ALGEBRA
+
+    def encode_event(self, event):
+        if isinstance(event, BankAccountCreated):
+            self.static_fields[str(event.accountNumber)] = (event.accountOwner, event.securityCode)
+            return BA_CREATED, 0, None, event.balance
+        if isinstance(event, BankAccountUpdated):
+            return BA_UPDATED, 0, None, event.newBalance
+        raise TypeError(f"not a BankAccount event: {event!r}")
+
+    def aggregate_id_of(self, event) -> str:
+        return str(event.accountNumber)
+
+    def state_from_fixed(self, aggregate_id: str, fixed) -> BankAccount:
+        owner, code = self.static_fields.get(aggregate_id, ("", ""))
+        return BankAccount(uuid.UUID(aggregate_id), owner, code, float(fixed["balance"]))
+
+    def state_to_fixed(self, aggregate: BankAccount) -> np.ndarray:
+        s = np.zeros(1, dtype=STATE_DTYPE)
+        a = self.event_algebra()
+        s["min_arg"], s["max_arg"] = a.default_min_arg, a.default_max_arg
+        s["balance"], s["flags"] = aggregate.balance, STATE_PRESENT
+        self.static_fields[str(aggregate.accountNumber)] = (aggregate.accountOwner, aggregate.securityCode)
+        return s
+
+
+class BankAccountFormat(SurgeAggregateFormatting[BankAccount]):
+    """``BankAccountSurgeModel`` formats (``.../docs/command/BankAccountSurgeModel.scala:22-32``).
+
+    play-json's text for ``Double`` is parity-unpinned: compare parsed values.
+    """
+
+    def write_state(self, agg: BankAccount) -> SerializedAggregate:
+        text = json.dumps(
+            {
+                "accountNumber": str(agg.accountNumber),
+                "accountOwner": agg.accountOwner,
+                "securityCode": agg.securityCode,
+                "balance": agg.balance,
+            },
+            separators=(",", ":"),
+            ensure_ascii=False,
+        )
+        return SerializedAggregate(text.encode("utf-8"), {"aggregate_id": str(agg.accountNumber)})
+
+    def read_state(self, data: bytes) -> Optional[BankAccount]:
+        try:
+            o = json.loads(data)
+            return BankAccount(uuid.UUID(o["accountNumber"]), o["accountOwner"], o["securityCode"], float(o["balance"]))
+        except Exception:
+            return None

@@ -212,7 +212,17 @@ class ReplayEngine:
         holder = type("_DevView", (), {"__cuda_array_interface__": iface})()
         return torch.as_tensor(holder, device=f"cuda:{self.device}")
 
+    def set_state_out(self, tensor) -> None:
+        """Redirect the next folds' output to ``tensor`` (``n_agg x 64`` bytes on the device)."""
+        self._check(self._lib.surge_replay_set_state_out(self._h, _dev_ptr(tensor, self.n_agg * 64)))
+        self._keep.append(tensor)
+        if len(self._keep) > 8:
+            del self._keep[4]
+
     # -- measurement ----------------------------------------------------------------------------------
+    def stats_reset(self) -> None:
+        self._check(self._lib.surge_replay_stats_reset(self._h))
+
     def stats(self) -> CStats:
         st = CStats()
         self._check(self._lib.surge_replay_stats(self._h, ctypes.byref(st)))

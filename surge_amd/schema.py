@@ -115,6 +115,8 @@ class CStats(ctypes.Structure):
         ("n_tasks", ctypes.c_int32),
         ("n_folds", ctypes.c_int64),
         ("n_poisoned", ctypes.c_int64),
+        ("sum_fold_kernel_ms", ctypes.c_double),
+        ("timed_folds", ctypes.c_int64),
     ]
 
 

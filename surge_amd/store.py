@@ -1,0 +1,173 @@
+"""GPU-backed aggregate state store behind the reference's read seams.
+
+* S2 ``getAggregateBytes(aggregateId): Future[Option[Array[Byte]]]`` —
+  ``modules/common/src/main/scala/surge/kafka/streams/AggregateStateStoreKafkaStreams.scala:83-85``,
+  called once per actor start by ``KTableInitializationSupport.fetchState``
+  (``modules/command-engine/core/src/main/scala/surge/internal/persistence/KTableInitializationSupport.scala:63-74``).
+* S1 ``SurgeKafkaStreamsPersistencePlugin.createSupplier(storeName)`` —
+  ``.../streams/SurgeKafkaStreamsPersistencePlugin.scala:12-15``: the key/value store the KTable
+  topology writes state-topic records into (last value per key wins, ``null`` deletes —
+  ``SurgeStateStoreConsumer.scala:69``).
+
+The reference rebuilds this store by replaying the compacted *state* topic into RocksDB; here the
+same bytes are produced by folding the *events* topic on the GPU (equal by the reference's own
+invariant: events and snapshot are published in one transaction).  The serialized
+format stays the plugin's: the engine hands a fixed-width state to ``writeState``.
+"""
+from __future__ import annotations
+
+import bisect
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .command import ReplayableCommandModel, SurgeCommandBusinessLogic
+from .log import EventLog, KeyTable, pack_batch, pack_events
+from .replay import ReplayEngine
+from .schema import ALGO_AUTO, STATE_DTYPE, STATE_POISONED, STATE_PRESENT
+
+
+class AggregateInitializationException(RuntimeError):
+    """Mirror of the error an actor gets when its state cannot be initialised
+    (``PersistentActor.scala:328-333``); raised for aggregates whose replay hit a throwing event."""
+
+
+class GpuReplayStateStore:
+    """Recover aggregate state by GPU replay and serve it through ``get_aggregate_bytes``."""
+
+    def __init__(self, business_logic: SurgeCommandBusinessLogic, device: int = 0):
+        model = business_logic.command_model()
+        if not isinstance(model, ReplayableCommandModel):
+            raise TypeError("GPU replay needs a ReplayableCommandModel (event algebra + fixed-width codecs)")
+        self.business_logic = business_logic
+        self.model = model
+        self.engine = ReplayEngine(model.event_algebra(), device)
+        self.keys = KeyTable()
+        self.store_name = f"{business_logic.aggregate_name}AggregateStateStore"  # SurgeStateStoreConsumer.scala:110
+        self._restored = False
+
+    def close(self):
+        self.engine.close()
+
+    # -- recovery ---------------------------------------------------------------------------
+    def restore(self, events_in_offset_order: Sequence, prior: Optional[Dict[str, object]] = None,
+                capacity: int = 0, algo: int = ALGO_AUTO) -> None:
+        """Fold the whole events topic.  ``prior`` (id -> aggregate) is an earlier snapshot to fold onto."""
+        if prior:
+            for k in prior:
+                self.keys.intern(k)
+        log = pack_events(self.model, events_in_offset_order, self.keys, capacity)
+        init = None
+        if prior:
+            init = np.zeros(log.n_aggregates, dtype=STATE_DTYPE)
+            for k, agg in prior.items():
+                init[self.keys.index[k]] = self.model.state_to_fixed(agg)[0]
+        self.restore_log(log, init, algo)
+
+    def restore_log(self, log: EventLog, init_state: Optional[np.ndarray] = None, algo: int = ALGO_AUTO) -> None:
+        self.keys = log.keys
+        self.engine.load_csr(log.seg_off, log.events, init_state)
+        self.engine.fold(algo)
+        self.engine.snapshot()  # publishes the host mirror that serves point reads
+        self._restored = True
+
+    def apply_events(self, events_in_offset_order: Sequence) -> None:
+        """Streaming micro-batch (config C5): fold new events onto the resident state."""
+        if not self._restored:
+            raise RuntimeError("restore() first")
+        group_agg, group_off, ev = pack_batch(self.model, events_in_offset_order, self.keys, self.engine.n_agg)
+        self.engine.append_fold(group_agg, group_off, ev)
+        self.engine.snapshot()
+
+    # -- S2 ---------------------------------------------------------------------------------
+    def get_aggregate_bytes(self, aggregate_id: str) -> Optional[bytes]:
+        """``None`` = no such aggregate (KTable miss) or tombstone; else ``writeState(state).value``."""
+        agg = self.get_aggregate(aggregate_id)
+        if agg is None:
+            return None
+        return self.business_logic.aggregate_write_formatting().write_state(agg).value
+
+    def get_aggregate(self, aggregate_id: str):
+        idx = self.keys.get(aggregate_id)
+        if idx is None or idx >= self.engine.n_agg:
+            return None
+        raw = self.engine.get_raw(idx)
+        if int(raw["flags"]) & STATE_POISONED:
+            raise AggregateInitializationException(
+                f"replay of aggregate {aggregate_id!r} hit an event whose handler throws; state is frozen before it"
+            )
+        if not int(raw["flags"]) & STATE_PRESENT:
+            return None
+        return self.model.state_from_fixed(aggregate_id, raw)
+
+
+class GpuReplayKeyValueStore:
+    """The store a ``GpuReplayPersistencePlugin.create_supplier`` hands to the KTable topology.
+
+    Reads fall through to the GPU-recovered snapshot; ``put`` overlays later state-topic records
+    (last write wins, ``None`` is a tombstone).  Read API and semantics follow
+    ``KafkaStreamsKeyValueStore`` (``.../streams/KafkaStreamsKeyValueStore.scala:24-54``,
+    pinned by ``KafkaStreamsKeyValueStoreSpec.scala:37-91``).
+    """
+
+    _TOMBSTONE = object()
+
+    def __init__(self, name: str, recovered: Optional[GpuReplayStateStore] = None):
+        self.name = name
+        self.recovered = recovered
+        self._overlay: Dict[str, object] = {}
+
+    def put(self, key: str, value: Optional[bytes]) -> None:
+        self._overlay[key] = self._TOMBSTONE if value is None else bytes(value)
+
+    def delete(self, key: str) -> None:
+        self.put(key, None)
+
+    def get(self, key: str) -> Optional[bytes]:
+        if key in self._overlay:
+            v = self._overlay[key]
+            return None if v is self._TOMBSTONE else v
+        if self.recovered is not None:
+            return self.recovered.get_aggregate_bytes(key)
+        return None
+
+    def _all_keys(self) -> List[str]:
+        ks = set(self._overlay)
+        if self.recovered is not None:
+            ks.update(self.recovered.keys.keys)
+        return sorted(ks)
+
+    def all(self) -> Iterator[Tuple[str, bytes]]:
+        for k in self._all_keys():
+            v = self.get(k)
+            if v is not None:
+                yield k, v
+
+    def all_values(self) -> List[bytes]:
+        return [v for _, v in self.all()]
+
+    def range(self, from_key: str, to_key: str) -> Iterator[Tuple[str, bytes]]:
+        ks = self._all_keys()
+        for k in ks[bisect.bisect_left(ks, from_key): bisect.bisect_right(ks, to_key)]:
+            v = self.get(k)
+            if v is not None:
+                yield k, v
+
+    def approximate_num_entries(self) -> int:
+        return sum(1 for _ in self.all())
+
+
+class GpuReplayPersistencePlugin:
+    """``SurgeKafkaStreamsPersistencePlugin`` (…PersistencePlugin.scala:12-15) for the GPU store.
+
+    ``enable_logging`` is False: the store is rebuilt from the events topic, so it needs no
+    changelog (the reference then builds the topology un-optimised, SurgeStateStoreConsumer.scala:63-75).
+    """
+
+    enable_logging = False
+
+    def __init__(self, recovered: Optional[GpuReplayStateStore] = None):
+        self.recovered = recovered
+
+    def create_supplier(self, store_name: str) -> GpuReplayKeyValueStore:
+        return GpuReplayKeyValueStore(store_name, self.recovered)

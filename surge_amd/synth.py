@@ -232,3 +232,24 @@ def to_event_records(words) -> np.ndarray:
     if _is_torch(words):
         words = words.detach().cpu().numpy()
     return np.ascontiguousarray(words).view(EVENT_DTYPE).reshape(-1)
+
+
+def fixed_log_for_aggregates_device(agg_ids, events_per_agg: int, seed: int, mix: TypeMix = C2_MIX,
+                                    chunk_aggs: int = 1 << 17):
+    """Shard of the global fixed-fan-in log: the events of the listed global aggregate indices
+    (int64 tensor, any device), in list order.  Returns ``(seg_off, events[n, 2])``."""
+    import torch
+
+    device = agg_ids.device
+    n_agg = agg_ids.numel()
+    L = events_per_agg
+    events = torch.empty((n_agg * L, 2), dtype=torch.int64, device=device)
+    pos1 = torch.arange(L, dtype=torch.int64, device=device)
+    for s in range(0, n_agg, chunk_aggs):
+        e = min(n_agg, s + chunk_aggs)
+        agg = agg_ids[s:e].repeat_interleave(L)
+        pos = pos1.repeat(e - s)
+        idx = agg * L + pos
+        events[s * L: e * L] = event_words(idx, agg, pos, seed, mix)
+    seg_off = torch.arange(n_agg + 1, dtype=torch.int64, device=device) * L
+    return seg_off, events

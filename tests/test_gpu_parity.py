@@ -1,0 +1,260 @@
+"""-m gpu: the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs.
+
+Bit-exact is the bar: all state fields are integers or bit-copied f64 payloads.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from golden_util import NAMES, load_golden
+from oracle import oracle
+from surge_amd import schema as S
+from surge_amd import synth
+from surge_amd.fixtures import BANK_ACCOUNT_ALGEBRA, COUNTER_ALGEBRA
+from surge_amd.replay import ReplayEngine, ReplayError
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_fold(seg_off, events, init=None, algebra=S.DEFAULT_ALGEBRA, algo=S.ALGO_AUTO):
+    with ReplayEngine(algebra) as eng:
+        eng.load_csr(seg_off, events, init)
+        eng.fold(algo)
+        out = eng.snapshot()
+        st = eng.stats()
+    return out, st
+
+
+def assert_same(got, exp, seg_off):
+    if got.tobytes() != exp.tobytes():
+        bad = np.nonzero(got != exp)[0]
+        a = bad[0]
+        raise AssertionError(
+            f"{bad.size} aggregates differ; first {a} (len {seg_off[a + 1] - seg_off[a]}):\n got {got[a]}\n exp {exp[a]}"
+        )
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_golden_vectors(name):
+    seg_off, events, init, expected = load_golden(name)
+    got, _ = gpu_fold(seg_off, events, init)
+    assert_same(got, expected, seg_off)
+
+
+@pytest.mark.parametrize(
+    "n_agg,length,mix",
+    [(1000, 100, synth.C1_MIX), (4096, 256, synth.C2_MIX), (333, 48, synth.STRESS_MIX), (100, 4096, synth.STRESS_MIX),
+     (7, 16, synth.STRESS_MIX), (1, 1024, synth.C2_MIX), (5000, 1, synth.STRESS_MIX), (64, 1040, synth.C2_MIX)],
+)
+def test_fixed_fan_in(n_agg, length, mix):
+    so, ev = synth.fixed_log(n_agg, length, seed=n_agg + length, mix=mix)
+    exp = oracle.fold_csr(so, ev)
+    got, st = gpu_fold(so, ev)
+    assert_same(got, exp, so)
+    assert st.last_algo == (S.ALGO_FIXED if length % 16 == 0 else S.ALGO_FLAT)
+    got_flat, st = gpu_fold(so, ev, algo=S.ALGO_FLAT)
+    assert st.last_algo == S.ALGO_FLAT
+    assert_same(got_flat, exp, so)
+
+
+@pytest.mark.parametrize("seed,mix", [(3, synth.C2_MIX), (4, synth.STRESS_MIX)])
+def test_zipf_csr(seed, mix):
+    so, ev = synth.zipf_log(20000, seed, mix=mix)
+    got, st = gpu_fold(so, ev)
+    assert st.last_algo == S.ALGO_FLAT
+    assert_same(got, oracle.fold_csr(so, ev), so)
+
+
+def test_ragged_with_empty_segments_and_prior_snapshot():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 3, size=3000) * rng.integers(0, 2000, size=3000)
+    so, ev = synth.csr_log(lens, 8, synth.STRESS_MIX)
+    prior = oracle.fold_csr(*synth.csr_log(rng.integers(0, 4, size=3000), 9, synth.STRESS_MIX))
+    got, _ = gpu_fold(so, ev, prior)
+    assert_same(got, oracle.fold_csr(so, ev, prior), so)
+    # empties at both ends and in runs
+    lens = np.concatenate([np.zeros(70, np.int64), rng.integers(1, 50, 500), np.zeros(200, np.int64),
+                           rng.integers(1, 3000, 30), np.zeros(65, np.int64)])
+    so, ev = synth.csr_log(lens, 10, synth.STRESS_MIX)
+    got, _ = gpu_fold(so, ev)
+    assert_same(got, oracle.fold_csr(so, ev), so)
+
+
+def test_empty_log_and_all_empty_segments():
+    so = np.zeros(1, dtype=np.int64)
+    ev = S.make_events([], [], [])
+    got, _ = gpu_fold(so, ev)
+    assert got.shape[0] == 0
+    so = np.zeros(11, dtype=np.int64)
+    prior = oracle.fold_csr(*synth.fixed_log(10, 3, 1))
+    got, _ = gpu_fold(so, ev, prior)
+    assert got.tobytes() == prior.tobytes()
+    got, _ = gpu_fold(so, ev)
+    assert got.tobytes() == S.empty_states(10).tobytes()
+
+
+def test_single_aggregate_longer_than_many_tasks():
+    so, ev = synth.fixed_log(1, 300_000 // 16 * 16, seed=12, mix=synth.C2_MIX)
+    got, _ = gpu_fold(so, ev)
+    assert_same(got, oracle.fold_csr(so, ev), so)
+    lens = np.array([5, 70_001, 3, 0, 2_000_003, 1], dtype=np.int64)
+    so, ev = synth.csr_log(lens, 13)
+    got, _ = gpu_fold(so, ev)
+    assert_same(got, oracle.fold_csr(so, ev), so)
+
+
+def test_segment_boundaries_on_every_tile_alignment():
+    # heads at tile starts/ends, lane-chunk starts/ends, and one before/after them
+    for shift in (0, 1, 15, 16, 17, 1023, 1024, 1025):
+        lens = np.array([shift or 1, 1024, 16, 1, 1023 - 16, 2048, 15, 17, 1], dtype=np.int64)
+        so, ev = synth.csr_log(lens, 20 + shift, synth.STRESS_MIX)
+        got, _ = gpu_fold(so, ev)
+        assert_same(got, oracle.fold_csr(so, ev), so)
+
+
+def test_every_aggregate_poisoned_or_deleted():
+    n = 3000
+    ev = S.make_events(np.tile([S.EVT_INC, S.EVT_THROW, S.EVT_INC], n), np.tile([1, 2, 3], n), np.tile([4, 0, 9], n))
+    so = np.arange(n + 1, dtype=np.int64) * 3
+    got, st = gpu_fold(so, ev)
+    assert_same(got, oracle.fold_csr(so, ev), so)
+    assert st.n_poisoned == n and (got["count"] == 4).all()
+    ev["type"][1::3] = S.EVT_DELETE
+    got, st = gpu_fold(so, ev)
+    assert_same(got, oracle.fold_csr(so, ev), so)
+    assert st.n_poisoned == 0 and (got["count"] == 9).all() and (got["event_count"] == 1).all()
+
+
+def test_int32_and_int64_wrap_match_the_jvm():
+    n = 40000
+    ev = S.make_events(np.full(n, S.EVT_INC), np.arange(1, n + 1), np.full(n, S.INT32_MAX))
+    so = np.array([0, n], dtype=np.int64)
+    got, _ = gpu_fold(so, ev)
+    assert_same(got, oracle.fold_csr(so, ev), so)
+    assert got[0]["count"] == np.int64(n * S.INT32_MAX).astype(np.int32)  # wrapped
+    assert got[0]["sum64"] == n * S.INT32_MAX
+
+
+def test_custom_algebras_counter_and_bank_account():
+    rng = np.random.default_rng(3)
+    lens = rng.integers(0, 300, size=2000)
+    so = np.zeros(lens.size + 1, np.int64)
+    np.cumsum(lens, out=so[1:])
+    n = int(so[-1])
+    ev = S.make_events(rng.integers(0, 4, n), rng.integers(0, 1 << 30, n), rng.integers(-(1 << 31), 1 << 31, n))
+    ev["type"][rng.random(n) < 0.97] %= 3  # few throwing events
+    got, _ = gpu_fold(so, ev, algebra=COUNTER_ALGEBRA)
+    assert_same(got, oracle.fold_csr(so, ev, None, COUNTER_ALGEBRA), so)
+    ev = S.make_events(rng.integers(0, 2, n), np.zeros(n), values=rng.standard_normal(n))
+    got, _ = gpu_fold(so, ev, algebra=BANK_ACCOUNT_ALGEBRA)
+    assert_same(got, oracle.fold_csr(so, ev, None, BANK_ACCOUNT_ALGEBRA), so)
+
+
+def test_count_set_op_and_nan_payload_bits():
+    alg = S.EventAlgebra(desc=(S.CLS_MATERIALIZE | S.D_COUNT_SET | S.D_EVCOUNT_INC, S.CLS_MATERIALIZE | S.D_COUNT_ADD,
+                               S.CLS_REQUIRE | S.D_BALANCE_SET, S.CLS_CREATE))
+    rng = np.random.default_rng(5)
+    n = 50000
+    so = np.arange(0, n + 1, 50, dtype=np.int64)
+    ev = S.make_events(rng.integers(0, 4, n), np.arange(n), rng.integers(-100, 100, n))
+    nan_bits = np.uint64(0x7FF8DEADBEEF0001)  # a NaN payload must be moved bit-exactly, never canonicalised
+    ev["raw"][ev["type"] == 2] = nan_bits
+    got, _ = gpu_fold(so, ev, algebra=alg)
+    exp = oracle.fold_csr(so, ev, None, alg)
+    assert_same(got, exp, so)
+    assert (got.view(np.uint8).reshape(-1, 64)[:, 16:24].view(np.uint64) == nan_bits).any()
+
+
+def test_micro_batch_append_fold_matches_full_refold():
+    # K3: fold(prev snapshot, new events) == fold over the concatenated log (associativity of the monoid)
+    rng = np.random.default_rng(7)
+    n_agg = 5000
+    so, ev = synth.zipf_log(n_agg, 30, max_len=256, mix=synth.STRESS_MIX)
+    with ReplayEngine() as eng:
+        eng.load_csr(so, ev)
+        eng.fold()
+        state = oracle.fold_csr(so, ev)
+        for batch in range(4):
+            m = 20000
+            agg_idx = rng.integers(0, n_agg, m)
+            be = synth.to_event_records(synth.event_words(np.arange(m, dtype=np.int64) + batch * m, agg_idx,
+                                                           np.arange(m, dtype=np.int64), 31, synth.STRESS_MIX))
+            from surge_amd.log import batch_groups
+
+            group_agg, group_off, sorted_ev = batch_groups(agg_idx, be)
+            eng.append_fold(group_agg, group_off, sorted_ev)
+            # oracle: fold each group onto the previous state
+            full_off = np.zeros(n_agg + 1, np.int64)
+            np.cumsum(np.bincount(agg_idx, minlength=n_agg), out=full_off[1:])
+            state = oracle.fold_csr(full_off, sorted_ev, state)
+            got = eng.snapshot()
+            assert_same(got, state, full_off)
+
+
+def test_get_point_reads_and_errors():
+    so, ev = synth.fixed_log(100, 32, 4)
+    with ReplayEngine() as eng:
+        with pytest.raises(ReplayError) as ei:
+            eng.fold()
+        assert ei.value.status == -2  # SURGE_E_STATE
+        eng.load_csr(so, ev)
+        eng.fold()
+        exp = oracle.fold_csr(so, ev)
+        for a in (0, 17, 99):  # served by a device read (no snapshot yet)
+            assert eng.get_raw(a).tobytes() == exp[a].tobytes()
+        eng.snapshot()
+        for a in (0, 17, 99):  # served by the host mirror
+            assert eng.get_raw(a).tobytes() == exp[a].tobytes()
+        with pytest.raises(ReplayError) as ei:
+            eng.get_raw(100)
+        assert ei.value.status == -6  # SURGE_E_RANGE
+        bad = so.copy()
+        bad[5] = bad[6] + 1
+        with pytest.raises(ReplayError) as ei:
+            eng.load_csr(bad, ev)
+        assert ei.value.status == -1 and "monotone" in str(ei.value)
+        with pytest.raises(ReplayError):
+            eng.fold(S.ALGO_FIXED + 7)
+    so, ev = synth.fixed_log(10, 20, 4)
+    with ReplayEngine() as eng:
+        eng.load_csr(so, ev)
+        with pytest.raises(ReplayError) as ei:
+            eng.fold(S.ALGO_FIXED)  # 20 % 16 != 0
+        assert ei.value.status == -5
+
+
+def test_device_resident_binding_and_idempotence():
+    import torch
+
+    dev = torch.device("cuda:0")
+    so, ev = synth.fixed_log_device(20000, 256, 2, dev)
+    out = torch.empty((20000, 64), dtype=torch.uint8, device=dev)
+    with ReplayEngine() as eng:
+        eng.load_csr(so, ev, None, out)
+        eng.fold()
+        eng.synchronize()
+        first = out.clone()
+        eng.fold()  # replay is a pure function of the log
+        eng.synchronize()
+        assert torch.equal(first, out)
+        view = eng.device_state()
+        assert view.data_ptr() == out.data_ptr()
+    exp = oracle.fold_csr(so.cpu().numpy(), synth.to_event_records(ev))
+    assert out.cpu().numpy().tobytes() == exp.tobytes()
+
+
+def test_partition_hash_kernel_matches_cpu_entry_point_and_oracle():
+    import torch
+
+    from surge_amd.kafka import partition_for_keys, utf16_table
+
+    keys = [f"acct-{i:08d}:{i % 13}" for i in range(20000)] + ["", ":", "a", "ab:c", "ünï-✓", "x" * 301]
+    data, off = utf16_table(keys)
+    cpu = partition_for_keys(keys, 64)
+    with ReplayEngine() as eng:
+        d_out = torch.zeros(len(keys), dtype=torch.int32, device="cuda:0")
+        eng.partition_hash_device(torch.from_numpy(data.view(np.int16)).cuda(), torch.from_numpy(off).cuda(), 64, d_out)
+        eng.synchronize()
+    assert (d_out.cpu().numpy() == cpu).all()
+    assert (oracle.partition_hash_batch(data, off, 64) == cpu).all()

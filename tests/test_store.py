@@ -1,0 +1,151 @@
+"""The state-store seams (S1/S2) over the GPU replay, written after the reference's own store specs."""
+import json
+import uuid
+
+import pytest
+
+from surge_amd.fixtures import (
+    BankAccountCommandModel, BankAccountCreated, BankAccountUpdated, BankAccountFormat, CounterBusinessLogic,
+    CountDecremented, CountIncremented, ExceptionThrowingEvent, NoOpEvent, State,
+)
+from surge_amd.log import KeyTable, batch_groups, group_by_aggregate, pack_events
+from surge_amd.store import GpuReplayKeyValueStore, GpuReplayPersistencePlugin
+
+
+# ---- CPU-only parts ----------------------------------------------------------------------------------
+def test_ktable_semantics_last_write_wins_and_tombstones():
+    # AggregateStateStoreKafkaStreamsSpec.scala:64-85 — pipe 4 keys, read back byte-equal; re-pipe key1 => overwritten
+    store = GpuReplayPersistencePlugin().create_supplier("CounterAggregateAggregateStateStore")
+    fmt = CounterBusinessLogic().aggregate_write_formatting()
+    recs = {f"stateKey{i}": fmt.write_state(State(f"stateKey{i}", i, i)).value for i in range(1, 5)}
+    for k, v in recs.items():
+        store.put(k, v)
+    for k, v in recs.items():
+        assert store.get(k) == v
+    updated = fmt.write_state(State("stateKey1", 3, 3)).value
+    store.put("stateKey1", updated)
+    assert store.get("stateKey1") == updated
+    store.put("stateKey2", None)  # `null` value = tombstone (SurgeModel.scala:62)
+    assert store.get("stateKey2") is None
+    assert store.get("never-seen") is None
+
+
+def test_key_value_store_read_api():
+    # KafkaStreamsKeyValueStoreSpec.scala:37-91 — get / all / allValues / range("J","M") inclusive / approximateNumEntries
+    store = GpuReplayKeyValueStore("s")
+    for k in ["Alice", "Jane", "Kate", "Mike", "Zed"]:
+        store.put(k, k.lower().encode())
+    assert store.get("Jane") == b"jane" and store.get("Bob") is None
+    assert [k for k, _ in store.range("J", "Mike")] == ["Jane", "Kate", "Mike"]
+    assert [k for k, _ in store.range("J", "M")] == ["Jane", "Kate"]
+    assert store.approximate_num_entries() == 5 and len(store.all_values()) == 5
+    assert GpuReplayPersistencePlugin.enable_logging is False
+
+
+def test_pack_events_orders_by_arrival_not_by_sequence_number():
+    model = CounterBusinessLogic().command_model()
+    # a NoOp consumes a sequence number without storing it, so "<id>:<seq>" keys can repeat
+    events = [
+        CountIncremented("a", 1, 1), CountIncremented("b", 5, 1), NoOpEvent("a", 2), CountDecremented("a", 3, 2),
+        CountIncremented("b", 5, 2),
+    ]
+    log = pack_events(model, events, capacity=4)
+    assert log.keys.keys == ["a", "b"] and log.n_aggregates == 4
+    assert list(log.seg_off) == [0, 3, 5, 5, 5]
+    assert list(log.events["seq"]) == [1, 2, 2, 1, 2]
+
+
+def test_batch_groups_are_unique_and_order_preserving():
+    import numpy as np
+
+    from surge_amd import schema as S
+
+    agg = np.array([5, 2, 5, 9, 2, 5])
+    ev = S.make_events([1] * 6, [10, 20, 11, 30, 21, 12], [0] * 6)
+    group_agg, group_off, sorted_ev = batch_groups(agg, ev)
+    assert list(group_agg) == [2, 5, 9] and list(group_off) == [0, 2, 5, 6]
+    assert list(sorted_ev["seq"]) == [20, 21, 10, 11, 12, 30]
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_get_aggregate_bytes_equals_write_state_of_the_host_fold():
+    from surge_amd.store import AggregateInitializationException, GpuReplayStateStore
+
+    bl = CounterBusinessLogic()
+    model = bl.command_model()
+    events = []
+    for i in range(300):
+        aid = f"agg-{i % 37}"
+        events.append(CountIncremented(aid, i, i + 1) if i % 3 else CountDecremented(aid, 2, i + 1))
+    events.insert(40, ExceptionThrowingEvent("agg-5", 41, RuntimeError("failed")))
+    store = GpuReplayStateStore(bl)
+    try:
+        store.restore(events, capacity=64)
+        for aid in {e.aggregateId for e in events}:
+            if aid == "agg-5":
+                with pytest.raises(AggregateInitializationException):
+                    store.get_aggregate_bytes(aid)
+                continue
+            state = None
+            for e in events:
+                if e.aggregateId == aid:
+                    state = model.handle_event(state, e)
+            # drop-in: bytes == writeState(fold(...)).value (SURVEY §7 "serialized state format stays drop-in")
+            assert store.get_aggregate_bytes(aid) == bl.aggregate_write_formatting().write_state(state).value
+            assert bl.aggregate_read_formatting().read_state(store.get_aggregate_bytes(aid)) == state
+        assert store.get_aggregate_bytes("no-such-aggregate") is None  # KTable miss
+        # the plugin's store serves recovered state, later state-topic records override it
+        kv = GpuReplayPersistencePlugin(store).create_supplier(store.store_name)
+        assert kv.get("agg-1") == store.get_aggregate_bytes("agg-1")
+        kv.put("agg-1", b"newer")
+        assert kv.get("agg-1") == b"newer"
+        # streaming micro-batch with a brand-new aggregate id
+        more = [CountIncremented("agg-1", 10, 1000), CountIncremented("agg-new", 7, 1)]
+        before = bl.aggregate_read_formatting().read_state(store.get_aggregate_bytes("agg-1"))
+        store.apply_events(more)
+        after = bl.aggregate_read_formatting().read_state(store.get_aggregate_bytes("agg-1"))
+        assert (after.count, after.version) == (before.count + 10, 1000)
+        assert bl.aggregate_read_formatting().read_state(store.get_aggregate_bytes("agg-new")) == State("agg-new", 7, 1)
+    finally:
+        store.close()
+
+
+@pytest.mark.gpu
+def test_bank_account_recovery_with_prior_snapshot():
+    from surge_amd.command import SurgeCommandBusinessLogic
+    from surge_amd.store import GpuReplayStateStore
+
+    class BL(SurgeCommandBusinessLogic):
+        aggregate_name = "BankAccount"
+
+        def __init__(self):
+            self.m, self.f = BankAccountCommandModel(), BankAccountFormat()
+
+        def command_model(self):
+            return self.m
+
+        def aggregate_read_formatting(self):
+            return self.f
+
+        def aggregate_write_formatting(self):
+            return self.f
+
+    bl = BL()
+    a, b, c = (uuid.UUID(int=i) for i in (1, 2, 3))
+    prior = {str(c): bl.m.handle_event(None, BankAccountCreated(c, "Carol", "9", 5.0))}
+    events = [
+        BankAccountUpdated(b, 50.0),  # before Created: dropped (aggregate.map on None)
+        BankAccountCreated(a, "Jane Doe", "1234", 1000.0),
+        BankAccountUpdated(a, 1100.0),  # BankAccountCommandEngineSpec.scala:44-68
+        BankAccountUpdated(c, 7.5),
+    ]
+    store = GpuReplayStateStore(bl)
+    try:
+        store.restore(events, prior=prior)
+        got = json.loads(store.get_aggregate_bytes(str(a)))
+        assert got == {"accountNumber": str(a), "accountOwner": "Jane Doe", "securityCode": "1234", "balance": 1100.0}
+        assert store.get_aggregate_bytes(str(b)) is None
+        assert json.loads(store.get_aggregate_bytes(str(c)))["balance"] == 7.5
+    finally:
+        store.close()
