@@ -110,8 +110,36 @@ int32_t fail_hip(surge_replay_handle* h, hipError_t e, const char* what) {
 
 void fill_params(const surge_replay_handle* h, FoldParams& p) {
   std::memset(&p, 0, sizeof(p));
-  for (int i = 0; i < 17; ++i) p.desc[i] = SURGE_D_POISON;
-  for (uint32_t i = 0; i < h->schema.n_types; ++i) p.desc[i] = h->schema.desc[i];
+  for (int i = 0; i < kTableEntries; ++i) {
+    const uint32_t d = ((uint32_t)i < h->schema.n_types && i < SURGE_MAX_EVENT_TYPES) ? h->schema.desc[i] : SURGE_D_POISON;
+    uint32_t* w = p.table[i];
+    const uint32_t cop = d & SURGE_D_COUNT_MASK, sop = d & SURGE_D_SUM_MASK, cls = d & SURGE_CLS_MASK;
+    if (d & SURGE_D_POISON) {
+      w[TW_POISON] = ~0u;  // everything else stays zero: a throwing event has no effect on the fields
+      w[TW_FLAGS] = 1u;
+      continue;
+    }
+    if (cls == SURGE_CLS_DELETE) {
+      w[TW_DELETE] = ~0u;  // a tombstone has no field ops
+      w[TW_NOT_REQUIRE] = ~0u;
+      w[TW_FLAGS] = 2u;
+      continue;
+    }
+    w[TW_CNT_NZ] = (cop == SURGE_D_COUNT_ADD || cop == SURGE_D_COUNT_SUB) ? ~0u : 0u;
+    w[TW_CNT_NEG] = (cop == SURGE_D_COUNT_SUB) ? ~0u : 0u;
+    w[TW_CNT_SET] = (cop == SURGE_D_COUNT_SET) ? ~0u : 0u;
+    w[TW_VER_SET] = (d & SURGE_D_VERSION_SET) ? ~0u : 0u;
+    w[TW_SUM_NZ] = (sop == SURGE_D_SUM_ADD || sop == SURGE_D_SUM_SUB) ? ~0u : 0u;
+    w[TW_SUM_NEG] = (sop == SURGE_D_SUM_SUB) ? ~0u : 0u;
+    w[TW_BAL_SET] = (d & SURGE_D_BALANCE_SET) ? ~0u : 0u;
+    w[TW_EVC] = (d & SURGE_D_EVCOUNT_INC) ? 1u : 0u;
+    w[TW_MATERIALIZES] = (cls == SURGE_CLS_MATERIALIZE || cls == SURGE_CLS_CREATE) ? ~0u : 0u;
+    w[TW_NOT_REQUIRE] = (cls != SURGE_CLS_REQUIRE) ? ~0u : 0u;
+    w[TW_CREATE] = (cls == SURGE_CLS_CREATE) ? ~0u : 0u;
+    w[TW_MIN] = (d & SURGE_D_MIN_ARG) ? ~0u : 0u;
+    w[TW_MAX] = (d & SURGE_D_MAX_ARG) ? ~0u : 0u;
+    w[TW_FLAGS] = w[TW_MATERIALIZES] ? 4u : 0u;
+  }
   const surge_state64& d = h->schema.default_state;
   p.d_count = d.count;
   p.d_version = d.version;

@@ -12,17 +12,22 @@
 //     (64 lanes x 16 consecutive events); the source lane permutation rotates each lane's
 //     16 events inside its own 256 B LDS row so that the later ds_read_b128 of
 //     "event j of lane l" is bank-conflict free.
-//   * foldLeft is sequential, the GPU is not: each lane folds its 16 consecutive events into
-//     a *state transformer*  f : Option[State] -> Option[State]  kept as two accumulators
-//     (z = f(None), t = f restricted to Some(x), per field "relative" or "absolute").  These
-//     transformers form a monoid under composition, so a wave-level segmented scan
-//     (segment heads = aggregate boundaries) yields every aggregate's final state while
-//     preserving the strict left-to-right event order.  Integer adds wrap mod 2^32 / 2^64
-//     exactly like JVM Int/Long, min/max/set are exact, f64 payloads are only moved — so the
-//     result is bit-identical to the sequential fold under any association.
-//   * A wave task is a contiguous range of WHOLE segments (~256 KiB of events) chosen by a
-//     tiny plan kernel from the CSR offsets, so waves never exchange carries through memory:
-//     the running state of a segment that spans tiles is carried in scalar registers.
+//   * foldLeft is sequential, the GPU is not: each lane folds its 16 consecutive events into a
+//     *state transformer* (per field either "relative to the incoming state": a delta for
+//     count/sum64/event_count, a clamp for min/max, unchanged for version/balance — or "absolute"),
+//     and transformers compose associatively, so a wave-level segmented scan (segment heads =
+//     aggregate boundaries) yields every aggregate's final state in strict event order.  Integer
+//     adds wrap mod 2^32 / 2^64 exactly like JVM Int/Long, min/max/set are exact, f64 payloads are
+//     only moved — the result is bit-identical to the sequential fold under any association.
+//   * The only thing a transformer cannot be relative to is PRESENCE (Some/None decides whether a
+//     REQUIRE-class event applies and whether MATERIALIZE resets to defaults).  So presence (and the
+//     sticky "an event threw" flag) is resolved first: a cheap pre-pass tracks three booleans per
+//     lane, four wave ballots turn them into each lane's incoming (present, poisoned) with a couple
+//     of bit scans, and the main walk then runs ONE evaluation path per lane with mask arithmetic
+//     from a pre-expanded per-type op table (no per-event decode, no divergent branches).
+//   * A wave task is a contiguous range of WHOLE segments (~256 KiB of events) chosen by a tiny
+//     plan kernel from the CSR offsets, so waves never exchange carries through memory: the
+//     running state of a segment that spans tiles is carried in scalar registers.
 //   * No MFMA: this is an HBM-bound fold (16 B in per event, 64 B out per aggregate).
 #include "replay_internal.h"
 
@@ -37,16 +42,12 @@ constexpr uint32_t FL_POISONED = 2u;
 constexpr uint32_t FL_HEAD = 16u;
 constexpr uint32_t SM_COUNT = 1u << 8;
 constexpr uint32_t SM_VERSION = 1u << 9;
-constexpr uint32_t SM_SUM = 1u << 10;
 constexpr uint32_t SM_BAL = 1u << 11;
-constexpr uint32_t SM_MIN = 1u << 12;
-constexpr uint32_t SM_MAX = 1u << 13;
-constexpr uint32_t SM_N = 1u << 14;
-constexpr uint32_t SM_ALL = 0x7Fu << 8;
+constexpr uint32_t SM_ALL = 0x7Fu << 8;  // count, version, sum, balance, min, max, event_count
 
-// One evaluation path of a transformer.  With fl & SM_x the field x holds an absolute value,
-// otherwise a value relative to the (unknown) incoming state: a delta for count/sum/n, a clamp
-// for min/max, "unchanged" for version/balance.
+// A lane's transformer.  With fl & SM_x the field x holds an absolute value, otherwise a value
+// relative to the incoming state.  sum64/min/max/event_count only become absolute through a
+// reset (SM_ALL); count/version/balance also through their SET ops.
 struct Acc {
   int32_t count, version;
   int64_t sum;
@@ -55,72 +56,100 @@ struct Acc {
   uint32_t n, fl;
 };
 
-// z: result when the incoming aggregate is None (always absolute: z.fl has SM_ALL).
-// t: result when the incoming aggregate is Some(x).  FL_HEAD lives in t.fl.
-struct Part {
-  Acc z, t;
-};
-
-__device__ __forceinline__ Acc acc_none() {
+__device__ __forceinline__ Acc acc_none() {  // the aggregate is None (absolute)
   Acc a;
   a.count = 0; a.version = 0; a.sum = 0; a.bal = 0; a.mn = 0x7fffffff; a.mx = (int32_t)0x80000000; a.n = 0;
   a.fl = SM_ALL;
   return a;
 }
 
-__device__ __forceinline__ Acc acc_identity() {
+__device__ __forceinline__ Acc acc_identity() {  // "whatever came in", present
   Acc a = acc_none();
   a.fl = FL_PRESENT;
   return a;
 }
 
-// One case of handleEvent (see surge_replay.h for the descriptor semantics and the reference
-// lines each presence class restates).
-__device__ __forceinline__ void apply_event(Acc& a, uint32_t d, int32_t seq, uint64_t raw, bool valid,
-                                            const FoldParams& p) {
-  const bool live = valid && !(a.fl & FL_POISONED);
-  const bool poison = live && (d & SURGE_D_POISON);
-  const bool go = live && !poison;
-  const uint32_t cls = d & SURGE_CLS_MASK;
-  const bool present = (a.fl & FL_PRESENT) != 0;
-  const bool del = go && cls == SURGE_CLS_DELETE;
-  const bool app = go && cls != SURGE_CLS_DELETE && (present || cls != SURGE_CLS_REQUIRE);
-  const bool rst = app && (cls == SURGE_CLS_CREATE || !present);
-  if (poison) a.fl |= FL_POISONED;
-  if (del) a.fl = (a.fl & ~FL_PRESENT) | SM_ALL;
-  if (rst) {
-    a.count = p.d_count; a.version = p.d_version; a.sum = p.d_sum; a.bal = p.d_balance;
-    a.mn = p.d_min; a.mx = p.d_max; a.n = p.d_evcount;
-    a.fl |= FL_PRESENT | SM_ALL;
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
+__device__ __forceinline__ uint32_t andn(uint32_t x, uint32_t m) { return bfi(m, 0u, x); }  // x & ~m in one v_bfi
+
+// One case of handleEvent applied to one evaluation path, as pure VALU mask arithmetic: every
+// "condition" is an all-ones / all-zero dword (table words q0..q3, see TW_* in replay_internal.h),
+// selects are v_bfi_b32, nothing touches the scalar unit.  frozenM: events are being ignored
+// (the aggregate is poisoned).  validM: this event exists (tail of the last tile).
+__device__ __forceinline__ void apply_event(Acc& a, uint32_t& frozenM, const uint4 q0, const uint4 q1, const uint4 q2,
+                                            const uint4 q3, uint32_t seq, uint32_t raw_lo, uint32_t raw_hi,
+                                            uint32_t validM, const FoldParams& p) {
+  const uint32_t liveM = andn(validM, frozenM);
+  const uint32_t ispM = liveM & q2.x;                                   // throws
+  const uint32_t goM = andn(liveM, q2.x);
+  const uint32_t presentM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 0, 1);
+  const uint32_t delM = goM & q2.y;
+  const uint32_t appM = andn(goM, q2.y) & (presentM | q2.w);            // REQUIRE-class events skip None
+  const uint32_t rstM = appM & bfi(presentM, q3.x, ~0u);                // CREATE, or materialising from None
+  frozenM |= ispM;
+
+  uint32_t fl = a.fl | (ispM & FL_POISONED);
+  fl = andn(fl, delM & FL_PRESENT) | (delM & SM_ALL);
+  fl |= rstM & (FL_PRESENT | SM_ALL);
+
+  uint32_t count = bfi(rstM, (uint32_t)p.d_count, (uint32_t)a.count);
+  uint32_t version = bfi(rstM, (uint32_t)p.d_version, (uint32_t)a.version);
+  uint32_t sum_lo = bfi(rstM, (uint32_t)p.d_sum, (uint32_t)a.sum);
+  uint32_t sum_hi = bfi(rstM, (uint32_t)((uint64_t)p.d_sum >> 32), (uint32_t)((uint64_t)a.sum >> 32));
+  uint32_t bal_lo = bfi(rstM, (uint32_t)p.d_balance, (uint32_t)a.bal);
+  uint32_t bal_hi = bfi(rstM, (uint32_t)(p.d_balance >> 32), (uint32_t)(a.bal >> 32));
+  uint32_t mn = bfi(rstM, (uint32_t)p.d_min, (uint32_t)a.mn);
+  uint32_t mx = bfi(rstM, (uint32_t)p.d_max, (uint32_t)a.mx);
+  uint32_t n = bfi(rstM, p.d_evcount, a.n);
+
+  const uint32_t arg = raw_lo;
+  // count: += / -= arg (JVM Int wrap) or := arg
+  count += ((arg ^ q0.y) - q0.y) & (q0.x & appM);
+  const uint32_t msetM = q0.z & appM;
+  count = bfi(msetM, arg, count);
+  const uint32_t mverM = q0.w & appM;
+  version = bfi(mverM, seq, version);
+  // sum64: += / -= (long) arg   (negate in 64 bits: -(long)Int.MinValue is +2^31)
+  {
+    const uint64_t x = (uint64_t)(int64_t)(int32_t)arg;
+    const uint64_t ng = ((uint64_t)q1.y << 32) | q1.y;
+    const uint32_t m = q1.x & appM;
+    const uint64_t d = ((x ^ ng) - ng) & (((uint64_t)m << 32) | m);
+    const uint64_t sum = (((uint64_t)sum_hi << 32) | sum_lo) + d;
+    sum_lo = (uint32_t)sum;
+    sum_hi = (uint32_t)(sum >> 32);
   }
-  if (app) {
-    const int32_t arg = (int32_t)(uint32_t)raw;
-    const uint32_t cop = d & SURGE_D_COUNT_MASK;
-    if (cop == SURGE_D_COUNT_ADD) a.count = (int32_t)((uint32_t)a.count + (uint32_t)arg);
-    if (cop == SURGE_D_COUNT_SUB) a.count = (int32_t)((uint32_t)a.count - (uint32_t)arg);
-    if (cop == SURGE_D_COUNT_SET) { a.count = arg; a.fl |= SM_COUNT; }
-    if (d & SURGE_D_VERSION_SET) { a.version = seq; a.fl |= SM_VERSION; }
-    const uint32_t sop = d & SURGE_D_SUM_MASK;
-    if (sop == SURGE_D_SUM_ADD) a.sum = (int64_t)((uint64_t)a.sum + (uint64_t)(int64_t)arg);
-    if (sop == SURGE_D_SUM_SUB) a.sum = (int64_t)((uint64_t)a.sum - (uint64_t)(int64_t)arg);
-    if (d & SURGE_D_BALANCE_SET) { a.bal = raw; a.fl |= SM_BAL; }
-    if (d & SURGE_D_MIN_ARG) a.mn = min(a.mn, arg);
-    if (d & SURGE_D_MAX_ARG) a.mx = max(a.mx, arg);
-    if (d & SURGE_D_EVCOUNT_INC) a.n += 1u;
-  }
+  // balance := value (bit copy)
+  const uint32_t mbalM = q1.z & appM;
+  bal_lo = bfi(mbalM, raw_lo, bal_lo);
+  bal_hi = bfi(mbalM, raw_hi, bal_hi);
+  mn = (uint32_t)min((int32_t)mn, (int32_t)bfi(q3.y & appM, arg, 0x7fffffffu));
+  mx = (uint32_t)max((int32_t)mx, (int32_t)bfi(q3.z & appM, arg, 0x80000000u));
+  n += q1.w & appM;
+  fl |= (msetM & SM_COUNT) | (mverM & SM_VERSION) | (mbalM & SM_BAL);
+
+  a.count = (int32_t)count; a.version = (int32_t)version;
+  a.sum = (int64_t)(((uint64_t)sum_hi << 32) | sum_lo);
+  a.bal = ((uint64_t)bal_hi << 32) | bal_lo;
+  a.mn = (int32_t)mn; a.mx = (int32_t)mx; a.n = n; a.fl = fl;
 }
 
-// g after f on the Some-path: absolute fields of g win, relative ones combine with f's.
+// g after f.  Absolute fields of g win, relative ones combine with f's.  A poisoned f is only ever
+// followed (inside its segment) by lanes that ignored their events, i.e. by identity transformers,
+// so the fields need no special case; the presence bit then has to come from f.
 __device__ __forceinline__ Acc seq_acc(const Acc& f, const Acc& g) {
   Acc r;
+  const bool all = (g.fl & SM_ALL) == SM_ALL;  // sum/min/max/n become absolute only through a reset
   r.count = (g.fl & SM_COUNT) ? g.count : (int32_t)((uint32_t)f.count + (uint32_t)g.count);
   r.version = (g.fl & SM_VERSION) ? g.version : f.version;
-  r.sum = (g.fl & SM_SUM) ? g.sum : (int64_t)((uint64_t)f.sum + (uint64_t)g.sum);
+  r.sum = all ? g.sum : (int64_t)((uint64_t)f.sum + (uint64_t)g.sum);
   r.bal = (g.fl & SM_BAL) ? g.bal : f.bal;
-  r.mn = (g.fl & SM_MIN) ? g.mn : min(f.mn, g.mn);
-  r.mx = (g.fl & SM_MAX) ? g.mx : max(f.mx, g.mx);
-  r.n = (g.fl & SM_N) ? g.n : f.n + g.n;
-  r.fl = (g.fl & (FL_PRESENT | FL_POISONED)) | ((f.fl | g.fl) & SM_ALL);
+  r.mn = all ? g.mn : min(f.mn, g.mn);
+  r.mx = all ? g.mx : max(f.mx, g.mx);
+  r.n = all ? g.n : f.n + g.n;
+  const uint32_t present = (f.fl & FL_POISONED) ? (f.fl & FL_PRESENT) : (g.fl & FL_PRESENT);
+  r.fl = present | ((f.fl | g.fl) & (FL_POISONED | SM_ALL)) | (f.fl & FL_HEAD);
   return r;
 }
 
@@ -129,21 +158,6 @@ __device__ __forceinline__ Acc select_acc(bool c, const Acc& a, const Acc& b) {
   r.count = c ? a.count : b.count; r.version = c ? a.version : b.version;
   r.sum = c ? a.sum : b.sum; r.bal = c ? a.bal : b.bal;
   r.mn = c ? a.mn : b.mn; r.mx = c ? a.mx : b.mx; r.n = c ? a.n : b.n; r.fl = c ? a.fl : b.fl;
-  return r;
-}
-
-// Segmented composition: f is the earlier (left) element.
-__device__ __forceinline__ Part combine(const Part& f, const Part& g) {
-  const bool g_head = (g.t.fl & FL_HEAD) != 0;
-  const bool f_poisoned = (f.t.fl & FL_POISONED) != 0;  // z and t are poisoned together
-  const uint32_t f_head = f.t.fl & FL_HEAD;
-  Acc cz = select_acc((f.z.fl & FL_PRESENT) != 0, seq_acc(f.z, g.t), g.z);
-  Acc ct = select_acc((f.t.fl & FL_PRESENT) != 0, seq_acc(f.t, g.t), g.z);
-  ct.fl |= f_head;
-  const bool keep_f = f_poisoned && !g_head;
-  Part r;
-  r.z = select_acc(g_head, g.z, select_acc(keep_f, f.z, cz));
-  r.t = select_acc(g_head, g.t, select_acc(keep_f, f.t, ct));
   return r;
 }
 
@@ -216,7 +230,7 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_ev = smem;
   uint32_t* lds_hb = (uint32_t*)(smem + kTileBytes);
-  uint32_t* lds_desc = (uint32_t*)(smem + kTileBytes + kHeadWords * 4);
+  uint32_t* lds_tab = (uint32_t*)(smem + kTileBytes + kHeadWords * 4);
 
   const int lane = threadIdx.x;
   const int64_t task = blockIdx.x;
@@ -237,7 +251,11 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
   }
   if (E1 <= E0) return;
 
-  if (lane < 17) lds_desc[lane] = p.desc[lane];
+  {
+    const uint32_t* src = &p.table[0][0];
+    for (int i = lane; i < kTableEntries * kTableWords; i += kWave)
+      lds_tab[(i / kTableWords) * kTableStride + (i % kTableWords)] = src[i];
+  }
   if (MODE == MODE_FLAT && lane < kHeadWords) lds_hb[lane] = 0u;
 
   const int n_tiles = (int)((E1 - E0 + kTileEvents - 1) / kTileEvents);
@@ -263,11 +281,11 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
   if (MODE == MODE_FLAT) mark_heads(E0);
 
   // The running segment that enters the next tile; starts as "nothing" (a head, None).
-  Part carry;
-  carry.z = acc_none();
-  carry.t = acc_none();
-  carry.t.fl |= FL_HEAD;
+  Acc carry = acc_none();
+  carry.fl |= FL_HEAD;
   int64_t c = S0 - 1;  // FLAT: index of the segment open when the tile starts
+
+  const uint64_t below = (1ull << lane) - 1ull;
 
   for (int tile = 0; tile < n_tiles; ++tile) {
     const int64_t te0 = E0 + (int64_t)tile * kTileEvents;
@@ -300,81 +318,138 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
       hb = (r == 0u && te0 + lane * kLaneEvents < E1) ? 1u : 0u;
       seg_open = S0 - 1 + (int64_t)q + (r != 0u ? 1 : 0);
     }
-    uint32_t desc[kLaneEvents];
-#pragma unroll
-    for (int j = 0; j < kLaneEvents; ++j) {
-      const uint32_t ty = ev[j].x;
-      desc[j] = lds_desc[ty < 16u ? ty : 16u];
-    }
-    // all my LDS reads are done: the buffer can take the next tile
+    // all my reads of the event buffer are done: it can take the next tile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (MODE == MODE_FLAT && lane < kHeadWords) lds_hb[lane] = 0u;
     if (tile + 1 < n_tiles) issue_tile_loads(p, te0 + kTileEvents, lds_ev, lane);
 
-    // ---- per-lane sequential walk over 16 consecutive events -------------------------------
     int64_t rem = E1 - (te0 + (int64_t)lane * kLaneEvents);
     const int nvalid = rem >= kLaneEvents ? kLaneEvents : (rem > 0 ? (int)rem : 0);
-    Acc z = acc_none();
-    Acc t = acc_identity();
-    Acc lead_z = z;
+
+    // ---- pass A: presence / poison only -----------------------------------------------------
+    // pzM / ptM: is the aggregate Some after my events if it was None / Some before them;
+    // poiM: did one of my (not ignored) events throw.  After a head all three are concrete.
+    uint32_t pzM = 0u, ptM = ~0u, poiM = 0u;
+    bool has_head = false;
+    uint32_t tyc[kLaneEvents];  // clamped type -> LDS dword offset of the table entry
+    {
+      uint32_t fw[kLaneEvents];
+#pragma unroll
+      for (int j = 0; j < kLaneEvents; ++j) {
+        const uint32_t ty = ev[j].x;
+        tyc[j] = (ty < 16u ? ty : 16u) * kTableStride;
+        fw[j] = lds_tab[tyc[j] + TW_FLAGS];
+      }
+      int64_t sg = seg_open;
+#pragma unroll
+      for (int j = 0; j < kLaneEvents; ++j) {
+        if ((MODE == MODE_FLAT || j == 0) && ((hb >> j) & 1u)) {
+          has_head = true;
+          sg += 1;
+          uint32_t ifl = 0u;
+          if (p.init) {
+            const int64_t ii = p.out_map ? p.out_map[sg] : sg;
+            ifl = ((const uint32_t*)(p.init + ii * 4 + 2))[1];
+          }
+          pzM = ptM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)ifl, 0, 1);
+          poiM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)ifl, 1, 1);
+        }
+        const uint32_t poisonM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)fw[j], 0, 1);
+        const uint32_t deleteM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)fw[j], 1, 1);
+        const uint32_t matM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)fw[j], 2, 1);
+        const uint32_t validM = (uint32_t)((int32_t)(j - nvalid) >> 31);
+        const uint32_t liveM = andn(validM, poiM);
+        const uint32_t goM = andn(liveM, poisonM);
+        const uint32_t mM = goM & matM, dlM = goM & deleteM;
+        pzM = andn(pzM | mM, dlM);
+        ptM = andn(ptM | mM, dlM);
+        poiM |= liveM & poisonM;
+      }
+    }
+    // incoming (present, poisoned) of every lane from four ballots
+    bool b_in, q_in;
+    {
+      const uint64_t Cm = __ballot(has_head || (pzM == ptM));  // my chunk forces presence to a constant
+      const uint64_t Vm = __ballot(pzM != 0u);
+      const uint64_t Hm = __ballot(has_head);
+      const uint64_t Qm = __ballot(poiM != 0u);
+      const uint64_t x = Cm & below;
+      b_in = x ? (((Vm >> (63 - __clzll((long long)x))) & 1ull) != 0) : ((carry.fl & FL_PRESENT) != 0);
+      const uint64_t h = Hm & below;
+      bool base = (carry.fl & FL_POISONED) != 0;
+      uint64_t range = below;
+      if (h) {
+        const int hp = 63 - __clzll((long long)h);
+        base = ((Qm >> hp) & 1ull) != 0;
+        range = below & ~((2ull << hp) - 1ull);
+      }
+      q_in = base || ((Qm & ~Hm & range) != 0ull);
+    }
+
+    // ---- pass B: one evaluation path per lane ----------------------------------------------------
+    Acc a = (b_in || q_in) ? acc_identity() : acc_none();
+    uint32_t frozenM = q_in ? ~0u : 0u;
+    Acc lead = a;
     bool seen = false;
     const int64_t lead_seg = seg_open;
+    uint4 tq0, tq1, tq2, tq3;  // op-table entry of the current event (prefetched one event ahead)
+    {
+      const uint4* te = (const uint4*)(lds_tab + tyc[0]);
+      tq0 = te[0]; tq1 = te[1]; tq2 = te[2]; tq3 = te[3];
+    }
 #pragma unroll
     for (int j = 0; j < kLaneEvents; ++j) {
-      if ((hb >> j) & 1u) {
+      uint4 nq0 = tq0, nq1 = tq1, nq2 = tq2, nq3 = tq3;
+      if (j + 1 < kLaneEvents) {
+        const uint4* te = (const uint4*)(lds_tab + tyc[j + 1]);
+        nq0 = te[0]; nq1 = te[1]; nq2 = te[2]; nq3 = te[3];
+      }
+      if ((MODE == MODE_FLAT || j == 0) && ((hb >> j) & 1u)) {
         if (!seen) {
-          lead_z = z;
+          lead = a;
           seen = true;
         } else {
           const int64_t oi = p.out_map ? p.out_map[seg_open] : seg_open;
-          store_state(p.out, oi, z);
+          store_state(p.out, oi, a);
         }
         seg_open += 1;
         if (p.init) {
           const int64_t ii = p.out_map ? p.out_map[seg_open] : seg_open;
-          z = load_state(p.init, ii);
+          a = load_state(p.init, ii);
         } else {
-          z = acc_none();
+          a = acc_none();
         }
+        frozenM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 1, 1);
       }
-      const bool valid = j < nvalid;
-      const uint64_t raw = ((uint64_t)ev[j].w << 32) | ev[j].z;
-      apply_event(z, desc[j], (int32_t)ev[j].y, raw, valid, p);
-      if (!seen) apply_event(t, desc[j], (int32_t)ev[j].y, raw, valid, p);
+      const uint32_t validM = (uint32_t)((int32_t)(j - nvalid) >> 31);
+      apply_event(a, frozenM, tq0, tq1, tq2, tq3, ev[j].y, ev[j].z, ev[j].w, validM, p);
+      tq0 = nq0; tq1 = nq1; tq2 = nq2; tq3 = nq3;
+      __builtin_amdgcn_sched_barrier(0);  // keep the table prefetch one event deep (bounds VGPR pressure)
     }
 
-    // ---- wave-level segmented scan of the lane transformers --------------------------------
-    Part lead;           // my leading partial (events before my first head), if I saw a head
-    lead.z = lead_z;
-    lead.t = t;
-    Part el;
-    el.z = z;
-    el.t = seen ? z : t;
-    if (seen) el.t.fl |= FL_HEAD;
+    // ---- wave-level segmented scan of the lane transformers --------------------------------------
+    Acc el = a;
+    if (seen) el.fl |= FL_HEAD;
     {
-      const Part seeded = combine(carry, el);
-      if (lane == 0) el = seeded;
+      const Acc seeded = seq_acc(carry, el);
+      if (lane == 0 && !seen) el = seeded;
     }
 #pragma unroll
     for (int d = 1; d < kWave; d <<= 1) {
-      Part o;
-      o.z = shfl_up_acc(el.z, d);
-      o.t = shfl_up_acc(el.t, d);
-      const Part cmb = combine(o, el);
-      if (lane >= d) el = cmb;
+      const Acc o = shfl_up_acc(el, d);
+      const Acc cmb = seq_acc(o, el);
+      const bool keep = (el.fl & FL_HEAD) || lane < d;
+      el = select_acc(keep, el, cmb);
     }
-    Part prefix;
-    prefix.z = shfl_up_acc(el.z, 1);
-    prefix.t = shfl_up_acc(el.t, 1);
+    Acc prefix = shfl_up_acc(el, 1);
     if (lane == 0) prefix = carry;
 
     if (seen && lead_seg >= S0) {
-      const Part fin = combine(prefix, lead);
+      const Acc fin = seq_acc(prefix, lead);
       const int64_t oi = p.out_map ? p.out_map[lead_seg] : lead_seg;
-      store_state(p.out, oi, fin.z);
+      store_state(p.out, oi, fin);
     }
-    carry.z = readlane_acc(el.z, 63);
-    carry.t = readlane_acc(el.t, 63);
+    carry = readlane_acc(el, 63);
 
     if (MODE == MODE_FLAT) {
       c += heads_in_tile;
@@ -384,7 +459,7 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
 
   if (lane == 0) {
     const int64_t oi = p.out_map ? p.out_map[S1 - 1] : (S1 - 1);
-    store_state(p.out, oi, carry.z);
+    store_state(p.out, oi, carry);
   }
 }
 

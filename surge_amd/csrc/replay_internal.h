@@ -16,7 +16,32 @@ constexpr int kLaneEvents = 16;
 constexpr int kTileEvents = kWave * kLaneEvents;          // 1024
 constexpr int kTileBytes = kTileEvents * 16;              // 16384
 constexpr int kHeadWords = kTileEvents / 32;              // 32 dwords = 128 B head bitmask
-constexpr int kFoldLdsBytes = kTileBytes + kHeadWords * 4 + 17 * 4 + 60;  // + desc table, padded to 16 B multiple
+constexpr int kTableEntries = 17;                         // 16 event types + the "unknown type" (poison) entry
+constexpr int kTableWords = 16;                           // 64 B of pre-expanded masks per event type
+constexpr int kTableStride = 20;                          // dwords between entries in LDS (80 B: conflict-free b128 reads)
+constexpr int kFoldLdsBytes = kTileBytes + kHeadWords * 4 + kTableEntries * kTableStride * 4;  // 17872 (16 B multiple)
+
+// Per-type op table, pre-expanded on the host from the ABI descriptor so the kernel applies an event
+// with VALU mask arithmetic only (no per-event decode, no compares, no branches).  Every word is an
+// all-ones / all-zero mask except TW_EVC (0 or 1).
+enum {
+  TW_CNT_NZ = 0,   // count += / -= arg
+  TW_CNT_NEG = 1,  // ... negated (SUB)
+  TW_CNT_SET = 2,  // count := arg
+  TW_VER_SET = 3,  // version := seq
+  TW_SUM_NZ = 4,   // sum64 += / -= (long) arg
+  TW_SUM_NEG = 5,
+  TW_BAL_SET = 6,  // balance := value
+  TW_EVC = 7,      // event_count += this (0 / 1)
+  TW_POISON = 8,   // handleEvent throws
+  TW_DELETE = 9,   // result is None
+  TW_MATERIALIZES = 10,  // class MATERIALIZE or CREATE: result is always Some
+  TW_NOT_REQUIRE = 11,   // applies to None as well
+  TW_CREATE = 12,  // resets to defaults even when Some
+  TW_MIN = 13,
+  TW_MAX = 14,
+  TW_FLAGS = 15,   // compact copy for the presence pre-pass: bit0 poison, bit1 delete, bit2 materializes
+};
 constexpr int kMaxTaskTiles = 16;                         // a wave task streams <= ~256 KiB contiguous
 constexpr int kTargetTasks = 16384;                       // enough tasks to fill 256 CUs x 8 waves twice
 
@@ -31,7 +56,7 @@ struct FoldParams {
   int64_t n_seg;            // kernel-facing segment count
   int64_t fixed_len;        // FIXED: events per segment (multiple of 16)
   int64_t segs_per_task;    // FIXED: segments per wave task
-  uint32_t desc[17];        // descriptor per type; [16] (and unused slots) = POISON
+  uint32_t table[kTableEntries][kTableWords];  // see TF_* above; unused slots and [16] = poison
   int32_t d_count, d_version;
   int64_t d_sum;
   uint64_t d_balance;
