@@ -60,6 +60,10 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the replay engine has no CPU fallback")
+    # rehearsal of the N > 1 control flow on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL
+    rehearsal = os.environ.get("SURGE_BENCH_SINGLE_GPU_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -68,7 +72,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     A, L = args.aggregates, args.events_per_aggregate
     eng = ReplayEngine(device=local_rank)
@@ -115,6 +122,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def reduce_(t, op):
+        if dist is None:
+            return t
+        if rehearsal:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            return h.to(dev)
+        dist.all_reduce(t, op=op)
+        return t
+
     for i in range(args.warmup):
         step(i)
     sync_all()
@@ -129,8 +146,8 @@ def main():
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     totals = torch.tensor([n_events_local, n_local], dtype=torch.int64, device=dev)
     if dist is not None:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+        elapsed = reduce_(elapsed, dist.ReduceOp.MAX)
+        totals = reduce_(totals, dist.ReduceOp.SUM)
     elapsed_s = float(elapsed.item())
     total_events, total_aggs = int(totals[0].item()), int(totals[1].item())
 
@@ -151,6 +168,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu_baseline = run_cpu_baseline(args, seg_off, events, bufs[(args.warmup + args.steps - 1) & 1], L)
         ms_per_step = elapsed_s / args.steps * 1e3
+        if world > 1:
+            # the gathered snapshot must contain this rank's own shard, bit for bit
+            last = (args.warmup + args.steps - 1) & 1
+            torch.cuda.synchronize(dev)
+            own = gather.result(last)[rank, :n_local]
+            assert torch.equal(own, bufs[last][:n_local]), "all-gathered snapshot does not contain the local shard"
         result = {
             "metric": "events/sec replayed",
             "value": total_events * args.steps / elapsed_s,

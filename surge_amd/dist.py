@@ -124,6 +124,8 @@ class SnapshotGather:
         self.n_local = n_local
         self.out = [torch.zeros((self.world, self.max_count, 64), dtype=torch.uint8, device=self.device) for _ in range(2)]
         self.cuda = self.device.type == "cuda"
+        # gloo cannot all-gather device tensors: stage through the host (debug / single-GPU rehearsal only)
+        self.stage_host = self.cuda and dist.get_backend(group) == "gloo"
         self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
         self.done = [None, None]
 
@@ -132,7 +134,14 @@ class SnapshotGather:
         return [self.torch.zeros((self.max_count, 64), dtype=self.torch.uint8, device=self.device) for _ in range(2)]
 
     def launch(self, slot: int, local_padded, ready_event=None) -> None:
-        if self.cuda:
+        if self.stage_host:
+            if ready_event is not None:
+                ready_event.synchronize()
+            host = local_padded.cpu()
+            parts = [self.torch.zeros_like(host) for _ in range(self.world)]
+            self.dist.all_gather(parts, host, group=self.group)
+            self.out[slot].copy_(self.torch.stack(parts))
+        elif self.cuda:
             with self.torch.cuda.stream(self.stream):
                 if ready_event is not None:
                     self.stream.wait_event(ready_event)
