@@ -117,12 +117,16 @@ void fill_params(const surge_replay_handle* h, FoldParams& p) {
     if (d & SURGE_D_POISON) {
       w[TW_POISON] = ~0u;  // everything else stays zero: a throwing event has no effect on the fields
       w[TW_FLAGS] = 1u;
+      if (i == kTableEntries - 1) {  // [17]: the null event that pads the last tile — identity on every state
+        w[TW_POISON] = 0u;
+        w[TW_FLAGS] = 0u;
+      }
       continue;
     }
     if (cls == SURGE_CLS_DELETE) {
       w[TW_DELETE] = ~0u;  // a tombstone has no field ops
       w[TW_NOT_REQUIRE] = ~0u;
-      w[TW_FLAGS] = 2u;
+      w[TW_FLAGS] = 1u << 16;
       continue;
     }
     w[TW_CNT_NZ] = (cop == SURGE_D_COUNT_ADD || cop == SURGE_D_COUNT_SUB) ? ~0u : 0u;
@@ -138,7 +142,7 @@ void fill_params(const surge_replay_handle* h, FoldParams& p) {
     w[TW_CREATE] = (cls == SURGE_CLS_CREATE) ? ~0u : 0u;
     w[TW_MIN] = (d & SURGE_D_MIN_ARG) ? ~0u : 0u;
     w[TW_MAX] = (d & SURGE_D_MAX_ARG) ? ~0u : 0u;
-    w[TW_FLAGS] = w[TW_MATERIALIZES] ? 4u : 0u;
+    w[TW_FLAGS] = 0u;  // bit0 poison, bit16 delete; materializes goes in its own accumulator (TW_MATERIALIZES & 1)
   }
   const surge_state64& d = h->schema.default_state;
   p.d_count = d.count;

@@ -77,12 +77,11 @@ __device__ __forceinline__ uint32_t andn(uint32_t x, uint32_t m) { return bfi(m,
 // "condition" is an all-ones / all-zero dword (table words q0..q3, see TW_* in replay_internal.h),
 // selects are v_bfi_b32, nothing touches the scalar unit.  frozenM: events are being ignored
 // (the aggregate is poisoned).  validM: this event exists (tail of the last tile).
-__device__ __forceinline__ void apply_event(Acc& a, uint32_t& frozenM, const uint4 q0, const uint4 q1, const uint4 q2,
-                                            const uint4 q3, uint32_t seq, uint32_t raw_lo, uint32_t raw_hi,
-                                            uint32_t validM, const FoldParams& p) {
-  const uint32_t liveM = andn(validM, frozenM);
-  const uint32_t ispM = liveM & q2.x;                                   // throws
-  const uint32_t goM = andn(liveM, q2.x);
+__device__ __forceinline__ void apply_event(Acc& a, uint32_t& frozenM, uint32_t& corr, const uint4 q0, const uint4 q1,
+                                            const uint4 q2, const uint4 q3, uint32_t seq, uint32_t raw_lo,
+                                            uint32_t raw_hi, const FoldParams& p) {
+  const uint32_t ispM = andn(q2.x, frozenM);                            // throws (and is not ignored)
+  const uint32_t goM = ~(frozenM | q2.x);
   const uint32_t presentM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 0, 1);
   const uint32_t delM = goM & q2.y;
   const uint32_t appM = andn(goM, q2.y) & (presentM | q2.w);            // REQUIRE-class events skip None
@@ -102,6 +101,7 @@ __device__ __forceinline__ void apply_event(Acc& a, uint32_t& frozenM, const uin
   uint32_t mn = bfi(rstM, (uint32_t)p.d_min, (uint32_t)a.mn);
   uint32_t mx = bfi(rstM, (uint32_t)p.d_max, (uint32_t)a.mx);
   uint32_t n = bfi(rstM, p.d_evcount, a.n);
+  corr = andn(corr, rstM);
 
   const uint32_t arg = raw_lo;
   // count: += / -= arg (JVM Int wrap) or := arg
@@ -110,15 +110,15 @@ __device__ __forceinline__ void apply_event(Acc& a, uint32_t& frozenM, const uin
   count = bfi(msetM, arg, count);
   const uint32_t mverM = q0.w & appM;
   version = bfi(mverM, seq, version);
-  // sum64: += / -= (long) arg   (negate in 64 bits: -(long)Int.MinValue is +2^31)
+  // sum64 += / -= (long) arg.  -(long)x == (long)~x + 1 exactly (also for Int.MinValue), so add the
+  // sign-extended complement now and count the "+1"s in corr (folded into the sum when the walk ends).
   {
-    const uint64_t x = (uint64_t)(int64_t)(int32_t)arg;
-    const uint64_t ng = ((uint64_t)q1.y << 32) | q1.y;
     const uint32_t m = q1.x & appM;
-    const uint64_t d = ((x ^ ng) - ng) & (((uint64_t)m << 32) | m);
-    const uint64_t sum = (((uint64_t)sum_hi << 32) | sum_lo) + d;
+    const uint32_t x = (arg ^ q1.y) & m;
+    const uint64_t sum = (((uint64_t)sum_hi << 32) | sum_lo) + (uint64_t)(int64_t)(int32_t)x;
     sum_lo = (uint32_t)sum;
     sum_hi = (uint32_t)(sum >> 32);
+    corr -= q1.y & m;
   }
   // balance := value (bit copy)
   const uint32_t mbalM = q1.z & appM;
@@ -209,17 +209,32 @@ __device__ __forceinline__ Acc load_state(const uint4* in, int64_t idx) {
 
 // Direct global->LDS load of one 16 KiB tile.  Instruction q writes LDS bytes [q*1024, q*1024+1024)
 // linearly by lane (that is what the hardware does); WHICH event a lane fetches is ours to choose:
-// LDS slot (q*64 + m) belongs to chunk-lane l = 4q + (m >> 4) and holds its event j = ((m & 15) - l) & 15.
-// Every instruction still covers one contiguous, fully used 1 KiB of the log.
-__device__ __forceinline__ void issue_tile_loads(const FoldParams& p, int64_t te0, char* lds, int lane) {
-  const int64_t last = p.n_events - 1;
+// LDS slot (q*64 + m) belongs to chunk-lane l = 4q + (m >> 4) and holds its event j = (m & 15) ^ (l & 15),
+// an XOR swizzle inside the lane's own 256 B row, so the later ds_read_b128 of "event j of lane l" is
+// bank-conflict free.  Every instruction still covers one contiguous, fully used 1 KiB of the log.
+// voff[k] is the lane's byte offset inside the 1 KiB piece for q & 3 == k (it only depends on q & 3).
+__device__ __forceinline__ void tile_lane_offsets(int lane, uint32_t voff[4]) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int l = 4 * q + (lane >> 4);
-    const int j = ((lane & 15) - l) & 15;
-    int64_t e = te0 + l * 16 + j;
-    e = e < last ? e : last;
-    __builtin_amdgcn_global_load_lds((gptr_t)(p.events + e), (lptr_t)(lds + q * 1024), 16, 0, 0);
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t j = (uint32_t)(lane & 15) ^ (uint32_t)(4 * k + (lane >> 4));
+    voff[k] = (16u * (uint32_t)(lane >> 4) + j) * 16u;
+  }
+}
+
+__device__ __forceinline__ void issue_tile_loads(const FoldParams& p, int64_t te0, char* lds, const uint32_t voff[4]) {
+  const char* base = (const char*)(p.events + te0);  // wave-uniform
+  if (te0 + kTileEvents <= p.n_events) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + q * 1024 + voff[q & 3]), (lptr_t)(lds + q * 1024), 16, 0, 0);
+  } else {  // the last tile of the buffer: clamp so nothing is read past the end
+    const int64_t last = (p.n_events - 1 - te0) * 16;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      int64_t off = (int64_t)(q * 1024 + voff[q & 3]);
+      off = off < last ? off : last;
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(lds + q * 1024), 16, 0, 0);
+    }
   }
 }
 
@@ -259,7 +274,10 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
   if (MODE == MODE_FLAT && lane < kHeadWords) lds_hb[lane] = 0u;
 
   const int n_tiles = (int)((E1 - E0 + kTileEvents - 1) / kTileEvents);
-  issue_tile_loads(p, E0, lds_ev, lane);
+  uint32_t voff[4];
+  tile_lane_offsets(lane, voff);
+  const uint32_t ev_row = (uint32_t)lane * 256u + (uint32_t)(lane & 15) * 16u;  // my LDS row, pre-swizzled
+  issue_tile_loads(p, E0, lds_ev, voff);
 
   // FLAT: head marking.  next_s = first segment whose start has not been marked yet.
   int64_t next_s = S0;
@@ -294,8 +312,7 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint4 ev[kLaneEvents];
 #pragma unroll
-    for (int j = 0; j < kLaneEvents; ++j)
-      ev[j] = *(const uint4*)(lds_ev + lane * 256 + ((j + lane) & 15) * 16);
+    for (int j = 0; j < kLaneEvents; ++j) ev[j] = *(const uint4*)(lds_ev + (ev_row ^ (uint32_t)(j * 16)));
 
     uint32_t hb;          // bit j: my event j starts a new segment
     int64_t seg_open;     // segment open when my chunk starts (before a head at j = 0)
@@ -321,58 +338,59 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
     // all my reads of the event buffer are done: it can take the next tile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (MODE == MODE_FLAT && lane < kHeadWords) lds_hb[lane] = 0u;
-    if (tile + 1 < n_tiles) issue_tile_loads(p, te0 + kTileEvents, lds_ev, lane);
+    if (tile + 1 < n_tiles) issue_tile_loads(p, te0 + kTileEvents, lds_ev, voff);
 
-    int64_t rem = E1 - (te0 + (int64_t)lane * kLaneEvents);
-    const int nvalid = rem >= kLaneEvents ? kLaneEvents : (rem > 0 ? (int)rem : 0);
+    // LDS dword offset of each event's op-table entry.  Events past the end of the task (last tile
+    // only) become the null event [17], an identity on every state, so nothing below needs a validity mask.
+    uint32_t tyc[kLaneEvents];
+    if (te0 + kTileEvents <= E1) {
+#pragma unroll
+      for (int j = 0; j < kLaneEvents; ++j) tyc[j] = (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride;
+    } else {
+      const int64_t rem = E1 - (te0 + (int64_t)lane * kLaneEvents);
+#pragma unroll
+      for (int j = 0; j < kLaneEvents; ++j)
+        tyc[j] = ((int64_t)j < rem ? (ev[j].x < 16u ? ev[j].x : 16u) : 17u) * kTableStride;
+    }
 
-    // ---- pass A: presence / poison only -----------------------------------------------------
-    // pzM / ptM: is the aggregate Some after my events if it was None / Some before them;
-    // poiM: did one of my (not ignored) events throw.  After a head all three are concrete.
-    uint32_t pzM = 0u, ptM = ~0u, poiM = 0u;
-    bool has_head = false;
-    uint32_t tyc[kLaneEvents];  // clamped type -> LDS dword offset of the table entry
+    // ---- pass A: presence / poison only, bit-parallel ---------------------------------------------
+    // Three 16-bit masks over my events: P throws, D deletes, M materialises.  The piece that matters to
+    // later lanes is the one after my LAST head (or my whole chunk): events before its first throwing
+    // event are live; the last live M|D event, if any, forces presence to a constant.
+    bool has_head, c_const, c_val, poi;
     {
-      uint32_t fw[kLaneEvents];
+      uint32_t PD = 0u, Mb = 0u;
 #pragma unroll
       for (int j = 0; j < kLaneEvents; ++j) {
-        const uint32_t ty = ev[j].x;
-        tyc[j] = (ty < 16u ? ty : 16u) * kTableStride;
-        fw[j] = lds_tab[tyc[j] + TW_FLAGS];
+        PD |= lds_tab[tyc[j] + TW_FLAGS] << j;                 // bit j: throws ; bit 16+j: deletes
+        Mb |= lds_tab[tyc[j] + TW_MATERIALIZES] & (1u << j);
       }
-      int64_t sg = seg_open;
-#pragma unroll
-      for (int j = 0; j < kLaneEvents; ++j) {
-        if ((MODE == MODE_FLAT || j == 0) && ((hb >> j) & 1u)) {
-          has_head = true;
-          sg += 1;
-          uint32_t ifl = 0u;
-          if (p.init) {
-            const int64_t ii = p.out_map ? p.out_map[sg] : sg;
-            ifl = ((const uint32_t*)(p.init + ii * 4 + 2))[1];
-          }
-          pzM = ptM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)ifl, 0, 1);
-          poiM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)ifl, 1, 1);
-        }
-        const uint32_t poisonM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)fw[j], 0, 1);
-        const uint32_t deleteM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)fw[j], 1, 1);
-        const uint32_t matM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)fw[j], 2, 1);
-        const uint32_t validM = (uint32_t)((int32_t)(j - nvalid) >> 31);
-        const uint32_t liveM = andn(validM, poiM);
-        const uint32_t goM = andn(liveM, poisonM);
-        const uint32_t mM = goM & matM, dlM = goM & deleteM;
-        pzM = andn(pzM | mM, dlM);
-        ptM = andn(ptM | mM, dlM);
-        poiM |= liveM & poisonM;
+      has_head = hb != 0u;
+      const uint32_t lo = has_head ? (31u - (uint32_t)__clz((int)hb)) : 0u;
+      uint32_t ifl = 0u;
+      if (has_head && p.init) {
+        const int64_t sg = seg_open + __popc(hb);
+        const int64_t ii = p.out_map ? p.out_map[sg] : sg;
+        ifl = ((const uint32_t*)(p.init + ii * 4 + 2))[1];
       }
+      const bool ib = (ifl & FL_PRESENT) != 0u, iq = (ifl & FL_POISONED) != 0u;
+      const uint32_t range = 0xffffu & ~((1u << lo) - 1u);
+      const uint32_t Pm = PD & range;
+      uint32_t live = Pm ? (range & ((1u << __builtin_ctz(Pm)) - 1u)) : range;
+      live = iq ? 0u : live;
+      const uint32_t dec = (Mb | (PD >> 16)) & live;
+      const uint32_t top = dec ? (31u - (uint32_t)__clz((int)dec)) : 0u;
+      c_const = has_head || dec != 0u;
+      c_val = dec ? (((Mb >> top) & 1u) != 0u) : ib;
+      poi = Pm != 0u || iq;
     }
     // incoming (present, poisoned) of every lane from four ballots
     bool b_in, q_in;
     {
-      const uint64_t Cm = __ballot(has_head || (pzM == ptM));  // my chunk forces presence to a constant
-      const uint64_t Vm = __ballot(pzM != 0u);
+      const uint64_t Cm = __ballot(c_const);  // my chunk forces presence to a constant ...
+      const uint64_t Vm = __ballot(c_val);    // ... this one
       const uint64_t Hm = __ballot(has_head);
-      const uint64_t Qm = __ballot(poiM != 0u);
+      const uint64_t Qm = __ballot(poi);
       const uint64_t x = Cm & below;
       b_in = x ? (((Vm >> (63 - __clzll((long long)x))) & 1ull) != 0) : ((carry.fl & FL_PRESENT) != 0);
       const uint64_t h = Hm & below;
@@ -389,6 +407,7 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
     // ---- pass B: one evaluation path per lane ----------------------------------------------------
     Acc a = (b_in || q_in) ? acc_identity() : acc_none();
     uint32_t frozenM = q_in ? ~0u : 0u;
+    uint32_t corr = 0u;  // pending "+1"s of the sum64 complement trick
     Acc lead = a;
     bool seen = false;
     const int64_t lead_seg = seg_open;
@@ -405,6 +424,8 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
         nq0 = te[0]; nq1 = te[1]; nq2 = te[2]; nq3 = te[3];
       }
       if ((MODE == MODE_FLAT || j == 0) && ((hb >> j) & 1u)) {
+        a.sum = (int64_t)((uint64_t)a.sum + corr);
+        corr = 0u;
         if (!seen) {
           lead = a;
           seen = true;
@@ -421,11 +442,11 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
         }
         frozenM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 1, 1);
       }
-      const uint32_t validM = (uint32_t)((int32_t)(j - nvalid) >> 31);
-      apply_event(a, frozenM, tq0, tq1, tq2, tq3, ev[j].y, ev[j].z, ev[j].w, validM, p);
+      apply_event(a, frozenM, corr, tq0, tq1, tq2, tq3, ev[j].y, ev[j].z, ev[j].w, p);
       tq0 = nq0; tq1 = nq1; tq2 = nq2; tq3 = nq3;
       __builtin_amdgcn_sched_barrier(0);  // keep the table prefetch one event deep (bounds VGPR pressure)
     }
+    a.sum = (int64_t)((uint64_t)a.sum + corr);
 
     // ---- wave-level segmented scan of the lane transformers --------------------------------------
     Acc el = a;

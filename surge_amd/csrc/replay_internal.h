@@ -16,10 +16,10 @@ constexpr int kLaneEvents = 16;
 constexpr int kTileEvents = kWave * kLaneEvents;          // 1024
 constexpr int kTileBytes = kTileEvents * 16;              // 16384
 constexpr int kHeadWords = kTileEvents / 32;              // 32 dwords = 128 B head bitmask
-constexpr int kTableEntries = 17;                         // 16 event types + the "unknown type" (poison) entry
+constexpr int kTableEntries = 18;                         // 16 event types + [16] unknown type (poison) + [17] null (padding) event
 constexpr int kTableWords = 16;                           // 64 B of pre-expanded masks per event type
 constexpr int kTableStride = 20;                          // dwords between entries in LDS (80 B: conflict-free b128 reads)
-constexpr int kFoldLdsBytes = kTileBytes + kHeadWords * 4 + kTableEntries * kTableStride * 4;  // 17872 (16 B multiple)
+constexpr int kFoldLdsBytes = kTileBytes + kHeadWords * 4 + kTableEntries * kTableStride * 4;  // 17952 (16 B multiple)
 
 // Per-type op table, pre-expanded on the host from the ABI descriptor so the kernel applies an event
 // with VALU mask arithmetic only (no per-event decode, no compares, no branches).  Every word is an
@@ -40,7 +40,7 @@ enum {
   TW_CREATE = 12,  // resets to defaults even when Some
   TW_MIN = 13,
   TW_MAX = 14,
-  TW_FLAGS = 15,   // compact copy for the presence pre-pass: bit0 poison, bit1 delete, bit2 materializes
+  TW_FLAGS = 15,   // presence pre-pass: bit0 poison, bit16 delete, bit1 materializes (OR-ed in at << j)
 };
 constexpr int kMaxTaskTiles = 16;                         // a wave task streams <= ~256 KiB contiguous
 constexpr int kTargetTasks = 16384;                       // enough tasks to fill 256 CUs x 8 waves twice
