@@ -691,12 +691,17 @@ int32_t surge_replay_stream_probe(surge_replay_handle* h, const void* d_src, int
   if (n_bytes < 16 || (n_bytes & 15) || ((uintptr_t)d_src & 15)) return fail(h, SURGE_E_INVALID, "n_bytes/pointer must be 16-byte multiples");
   DeviceGuard g(h->device);
   HIPCHK(h, h->poison_count.reserve(8));
-  HIPCHK(h, hipEventRecord(h->ev_h0, h->stream));
-  HIPCHK(h, launch_stream_probe((const uint4*)d_src, n_bytes / 16, (uint32_t*)h->poison_count.ptr, h->stream));
-  HIPCHK(h, hipEventRecord(h->ev_h1, h->stream));
-  HIPCHK(h, hipEventSynchronize(h->ev_h1));
-  float ms = 0.f;
-  HIPCHK(h, hipEventElapsedTime(&ms, h->ev_h0, h->ev_h1));
+  float best = 0.f;
+  for (int variant = 0; variant < 2; ++variant) {  // plain and non-temporal 16 B/lane loads: report the faster
+    HIPCHK(h, hipEventRecord(h->ev_h0, h->stream));
+    HIPCHK(h, launch_stream_probe((const uint4*)d_src, n_bytes / 16, (uint32_t*)h->poison_count.ptr, variant == 1, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_h1, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev_h1));
+    float t = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&t, h->ev_h0, h->ev_h1));
+    if (variant == 0 || t < best) best = t;
+  }
+  const float ms = best;
   *ms_out = ms;
   h->h2d_valid = false;  // ev_h0/ev_h1 were reused
   return SURGE_OK;

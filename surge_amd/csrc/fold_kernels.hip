@@ -37,6 +37,13 @@ namespace {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Cache policy of the event-stream loads: the log is read exactly once, so mark it non-temporal
+// (aux bit 1 = nt on gfx950 global_load_lds).
+#ifndef SURGE_LOAD_AUX
+#define SURGE_LOAD_AUX 2
+#endif
+constexpr int kLoadAux = SURGE_LOAD_AUX;
+
 constexpr uint32_t FL_PRESENT = 1u;
 constexpr uint32_t FL_POISONED = 2u;
 constexpr uint32_t FL_HEAD = 16u;
@@ -226,14 +233,14 @@ __device__ __forceinline__ void issue_tile_loads(const FoldParams& p, int64_t te
   if (te0 + kTileEvents <= p.n_events) {
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + q * 1024 + voff[q & 3]), (lptr_t)(lds + q * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + q * 1024 + voff[q & 3]), (lptr_t)(lds + q * 1024), 16, 0, kLoadAux);
   } else {  // the last tile of the buffer: clamp so nothing is read past the end
     const int64_t last = (p.n_events - 1 - te0) * 16;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       int64_t off = (int64_t)(q * 1024 + voff[q & 3]);
       off = off < last ? off : last;
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(lds + q * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(lds + q * 1024), 16, 0, kLoadAux);
     }
   }
 }
@@ -635,17 +642,27 @@ __global__ void partition_hash_kernel(const uint16_t* __restrict__ utf16, const 
 }
 
 // ---- HBM read-stream ceiling probe -------------------------------------------------------------
+template <bool NT>
 __global__ void __launch_bounds__(256) stream_probe_kernel(const uint4* __restrict__ src, int64_t n_vec,
                                                            uint32_t* __restrict__ sink) {
   uint32_t acc = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  auto ld = [&](int64_t k) -> uint4 {
+    if (NT) {
+      uint4 v;
+      v.x = __builtin_nontemporal_load(&src[k].x); v.y = __builtin_nontemporal_load(&src[k].y);
+      v.z = __builtin_nontemporal_load(&src[k].z); v.w = __builtin_nontemporal_load(&src[k].w);
+      return v;
+    }
+    return src[k];
+  };
   for (; i + 3 * stride < n_vec; i += 4 * stride) {
-    const uint4 a = src[i], b = src[i + stride], c2 = src[i + 2 * stride], d = src[i + 3 * stride];
+    const uint4 a = ld(i), b = ld(i + stride), c2 = ld(i + 2 * stride), d = ld(i + 3 * stride);
     acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c2.x ^ c2.y ^ c2.z ^ c2.w ^ d.x ^ d.y ^ d.z ^ d.w;
   }
   for (; i < n_vec; i += stride) {
-    const uint4 a = src[i];
+    const uint4 a = ld(i);
     acc ^= a.x ^ a.y ^ a.z ^ a.w;
   }
   if (acc == 0x9e3779b9u) sink[0] = acc;  // practically never; keeps the loads alive
@@ -716,8 +733,11 @@ hipError_t launch_partition_hash(const uint16_t* utf16, const int64_t* str_off, 
   return hipGetLastError();
 }
 
-hipError_t launch_stream_probe(const uint4* src, int64_t n_vec, uint32_t* sink, hipStream_t stream) {
-  hipLaunchKernelGGL(stream_probe_kernel, dim3(256 * 8), dim3(256), 0, stream, src, n_vec, sink);
+hipError_t launch_stream_probe(const uint4* src, int64_t n_vec, uint32_t* sink, bool nontemporal, hipStream_t stream) {
+  if (nontemporal)
+    hipLaunchKernelGGL(stream_probe_kernel<true>, dim3(256 * 8), dim3(256), 0, stream, src, n_vec, sink);
+  else
+    hipLaunchKernelGGL(stream_probe_kernel<false>, dim3(256 * 8), dim3(256), 0, stream, src, n_vec, sink);
   return hipGetLastError();
 }
 
