@@ -142,9 +142,11 @@ typedef struct surge_replay_schema {
 #define SURGE_EVT_THROW       6 /* ExceptionThrowingEvent TestBoundedContext.scala:67,86 */
 
 /* ---- fold algorithms -------------------------------------------------------- */
-#define SURGE_ALGO_AUTO  0 /* FIXED when every segment has the same length L, L % 16 == 0; else FLAT */
-#define SURGE_ALGO_FIXED 1 /* K1: fixed fan-in, segment heads computed arithmetically              */
-#define SURGE_ALGO_FLAT  2 /* K2: load-balanced flat segmented scan over the CSR                  */
+#define SURGE_ALGO_AUTO  0 /* uniform segment length L (L % 16 == 0): ROWS when there are enough aggregates
+                              to fill the chip, else FIXED; otherwise FLAT                             */
+#define SURGE_ALGO_FIXED 1 /* K1b: flat fold with segment heads computed arithmetically (uniform L)   */
+#define SURGE_ALGO_FLAT  2 /* K2: load-balanced flat segmented scan over the CSR                      */
+#define SURGE_ALGO_ROWS  3 /* K1: uniform L, one lane per aggregate, no cross-lane scan               */
 
 typedef struct surge_replay_stats_t {
   int64_t n_aggregates;

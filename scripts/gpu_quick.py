@@ -27,6 +27,11 @@ allok = True
 allok &= check("fixed 1000x100 (flat, L%16!=0)", *synth.fixed_log(1000, 100, 1, synth.C1_MIX, True))
 allok &= check("fixed 4096x256", *synth.fixed_log(4096, 256, 2))
 allok &= check("fixed 4096x256 flat", *synth.fixed_log(4096, 256, 2), algo=2)
+allok &= check("fixed 4096x256 rows", *synth.fixed_log(4096, 256, 2), algo=3)
+allok &= check("fixed 4133x48 rows stress", *synth.fixed_log(4133, 48, 5, synth.STRESS_MIX), algo=3)
+allok &= check("fixed 70x4096 rows stress", *synth.fixed_log(70, 4096, 6, synth.STRESS_MIX), algo=3)
+so_, ev_ = synth.fixed_log(1000, 32, 15, synth.STRESS_MIX)
+allok &= check("rows with init", so_, ev_, oracle.fold_csr(*synth.fixed_log(1000, 3, 16, synth.STRESS_MIX)), algo=3)
 allok &= check("fixed 333x48", *synth.fixed_log(333, 48, 5, synth.STRESS_MIX))
 allok &= check("fixed 100x4096 stress", *synth.fixed_log(100, 4096, 6, synth.STRESS_MIX))
 allok &= check("zipf 20000", *synth.zipf_log(20000, 3))
@@ -47,7 +52,7 @@ for (A, L) in [(1_000_000, 256)]:
     out = torch.empty((A, 64), dtype=torch.uint8, device=dev)
     eng = ReplayEngine()
     eng.load_csr(so, ev, None, out)
-    for algo in (1, 2):
+    for algo in (3, 1, 2):
         for _ in range(3):
             eng.fold(algo)
         eng.synchronize()

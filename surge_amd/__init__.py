@@ -8,6 +8,7 @@ from .schema import (  # noqa: F401
     ALGO_AUTO,
     ALGO_FIXED,
     ALGO_FLAT,
+    ALGO_ROWS,
     DEFAULT_ALGEBRA,
     EVENT_DTYPE,
     STATE_DTYPE,
@@ -18,6 +19,7 @@ __all__ = [
     "ALGO_AUTO",
     "ALGO_FIXED",
     "ALGO_FLAT",
+    "ALGO_ROWS",
     "DEFAULT_ALGEBRA",
     "EVENT_DTYPE",
     "STATE_DTYPE",

@@ -408,15 +408,19 @@ int32_t surge_replay_load_csr(surge_replay_handle* h, const int64_t* seg_off, in
 int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
   if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
   if (!h->bound) return fail(h, SURGE_E_STATE, "fold before load_csr/bind_device_csr");
-  if (algo != SURGE_ALGO_AUTO && algo != SURGE_ALGO_FIXED && algo != SURGE_ALGO_FLAT)
+  if (algo != SURGE_ALGO_AUTO && algo != SURGE_ALGO_FIXED && algo != SURGE_ALGO_FLAT && algo != SURGE_ALGO_ROWS)
     return fail(h, SURGE_E_INVALID, "unknown algo");
   DeviceGuard g(h->device);
   const int64_t span = h->an.last - h->an.first;
   const bool uniform = h->n_agg > 0 && !h->an.nonuniform && h->an.n_empty == 0 && h->an.len0 > 0 &&
                        (h->an.len0 % kLaneEvents) == 0 && h->an.len0 < (1ll << 31) && h->an.first == 0;
-  if (algo == SURGE_ALGO_FIXED && !uniform)
-    return fail(h, SURGE_E_UNSUPPORTED, "ALGO_FIXED needs equal segment lengths that are a multiple of 16");
-  const int32_t use = (algo == SURGE_ALGO_AUTO) ? (uniform ? SURGE_ALGO_FIXED : SURGE_ALGO_FLAT) : algo;
+  if ((algo == SURGE_ALGO_FIXED || algo == SURGE_ALGO_ROWS) && !uniform)
+    return fail(h, SURGE_E_UNSUPPORTED, "ALGO_FIXED / ALGO_ROWS need equal segment lengths that are a multiple of 16");
+  const bool rows_ok = uniform && h->an.len0 <= (1 << 24);
+  if (algo == SURGE_ALGO_ROWS && !rows_ok) return fail(h, SURGE_E_UNSUPPORTED, "ALGO_ROWS needs L <= 2^24");
+  // one lane per aggregate only pays when 64-aggregate groups alone can fill the chip
+  const bool rows_auto = rows_ok && h->n_agg / kWave >= 2048;
+  const int32_t use = (algo == SURGE_ALGO_AUTO) ? (uniform ? (rows_auto ? SURGE_ALGO_ROWS : SURGE_ALGO_FIXED) : SURGE_ALGO_FLAT) : algo;
 
   FoldParams p;
   fill_params(h, p);
@@ -428,7 +432,26 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
   HIPCHK(h, hipEventRecord(h->ev_total0, h->stream));
   h->st.n_tasks = 0;
   if (h->n_agg > 0 && span > 0) {
-    if (use == SURGE_ALGO_FIXED) {
+    if (use == SURGE_ALGO_ROWS) {
+      const int64_t L = h->an.len0;
+      // a task = G groups of 64 aggregates, about kMaxTaskTiles tiles (one tile = 64 rows x 16 events)
+      int64_t G = (int64_t)kMaxTaskTiles * kLaneEvents / L;
+      if (G < 1) G = 1;
+      const int64_t groups = (h->n_agg + kWave - 1) / kWave;
+      if (groups / G < kTargetTasks / 4) G = 1;
+      const int64_t per_task = G * kWave;
+      const int64_t n_tasks = (h->n_agg + per_task - 1) / per_task;
+      p.n_seg = h->n_agg;
+      p.fixed_len = L;
+      p.segs_per_task = per_task;
+      hipEvent_t e0, e1;
+      const int32_t rc = next_fold_events(h, &e0, &e1);
+      if (rc != SURGE_OK) return rc;
+      HIPCHK(h, hipEventRecord(e0, h->stream));
+      HIPCHK(h, launch_fold_rows(p, n_tasks, h->stream));
+      HIPCHK(h, hipEventRecord(e1, h->stream));
+      h->st.n_tasks = (int32_t)n_tasks;
+    } else if (use == SURGE_ALGO_FIXED) {
       const int64_t L = h->an.len0;
       const int64_t task_events = choose_task_events(span);
       int64_t G = task_events / L;

@@ -76,6 +76,7 @@ struct CsrAnalysis {
 // Launch wrappers (fold_kernels.hip).  All asynchronous on `stream`.
 hipError_t launch_fold_fixed(const FoldParams& p, int64_t n_tasks, hipStream_t stream);
 hipError_t launch_fold_flat(const FoldParams& p, int64_t n_tasks, hipStream_t stream);
+hipError_t launch_fold_rows(const FoldParams& p, int64_t n_tasks, hipStream_t stream);
 hipError_t launch_plan(const int64_t* off, int64_t n_seg, int64_t task_events, int64_t n_tasks,
                        int64_t* plan, hipStream_t stream);
 hipError_t launch_analyze_csr(const int64_t* off, int64_t n_seg, CsrAnalysis* d_result, hipStream_t stream);

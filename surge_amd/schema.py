@@ -55,6 +55,7 @@ EVT_THROW = 6
 ALGO_AUTO = 0
 ALGO_FIXED = 1
 ALGO_FLAT = 2
+ALGO_ROWS = 3
 
 INT32_MAX = 2**31 - 1
 INT32_MIN = -(2**31)
