@@ -52,8 +52,15 @@ int main() {
   uint4* d; uint32_t* sink;
   hipMalloc(&d, bytes); hipMalloc(&sink, 4);
   hipMemset(d, 1, bytes);
+  const bool random_fill = true;
+  if (random_fill) {
+    std::vector<uint64_t> h(bytes / 8);
+    uint64_t x = 88172645463325252ull;
+    for (auto& v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = x; }
+    hipMemcpy(d, h.data(), bytes, hipMemcpyHostToDevice);
+  }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int lds_kb : {16, 32}) {
+  for (int lds_kb : {16, 18, 32}) {
     for (int rows = 0; rows < 2; ++rows) {
       for (int apt : {64, 128, 256}) {
         float best = 1e9;

@@ -3,6 +3,7 @@
 // if HIP is unusable every entry point reports SURGE_E_DEVICE.
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -154,13 +155,24 @@ void fill_params(const surge_replay_handle* h, FoldParams& p) {
   p.d_evcount = d.event_count;
 }
 
-// Wave-task size in events: a multiple of one tile, at most kMaxTaskTiles tiles, small enough that
-// short logs still spread over the chip.
-int64_t choose_task_events(int64_t n_events) {
-  int64_t tiles = (n_events / kTargetTasks + kTileEvents - 1) / kTileEvents;
+// Wave-task size in events: a multiple of one tile (64 * lane_events events), about kTaskBytes of
+// events at most, small enough that short logs still spread over the chip.
+int64_t choose_task_events(int64_t n_events, int lane_events) {
+  const int64_t tile = (int64_t)kWave * lane_events;
+  const int64_t max_tiles = kTaskBytes / (tile * 16);
+  int64_t tiles = (n_events / kTargetTasks + tile - 1) / tile;
   if (tiles < 1) tiles = 1;
-  if (tiles > kMaxTaskTiles) tiles = kMaxTaskTiles;
-  return tiles * kTileEvents;
+  if (tiles > max_tiles) tiles = max_tiles;
+  return tiles * tile;
+}
+
+// Events per lane per tile for each kernel (8 -> 8 KiB tiles and twice the resident waves, 16 -> 16 KiB
+// tiles and half the per-tile scan overhead).  Tunable through the environment for experiments.
+int env_lane_events(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  if (!v) return dflt;
+  const int x = std::atoi(v);
+  return (x == 8 || x == 16) ? x : dflt;
 }
 
 int32_t validate_schema(const surge_replay_schema* s) {
@@ -234,7 +246,8 @@ int32_t next_fold_events(surge_replay_handle* h, hipEvent_t* e0, hipEvent_t* e1)
 
 // plan + flat fold over an arbitrary kernel-facing CSR
 int32_t run_flat(surge_replay_handle* h, FoldParams& p, const int64_t* off, int64_t n_seg, int64_t span_events) {
-  const int64_t task_events = choose_task_events(span_events);
+  const int le = env_lane_events("SURGE_REPLAY_LE_FLAT", 16);
+  const int64_t task_events = choose_task_events(span_events, le);
   const int64_t n_tasks = (span_events + task_events - 1) / task_events;
   HIPCHK(h, h->plan.reserve((size_t)(n_tasks + 1) * 8));
   HIPCHK(h, launch_plan(off, n_seg, task_events, n_tasks, (int64_t*)h->plan.ptr, h->stream));
@@ -245,7 +258,7 @@ int32_t run_flat(surge_replay_handle* h, FoldParams& p, const int64_t* off, int6
   const int32_t rc = next_fold_events(h, &e0, &e1);
   if (rc != SURGE_OK) return rc;
   HIPCHK(h, hipEventRecord(e0, h->stream));
-  HIPCHK(h, launch_fold_flat(p, n_tasks, h->stream));
+  HIPCHK(h, launch_fold_flat(p, n_tasks, le, h->stream));
   HIPCHK(h, hipEventRecord(e1, h->stream));
   h->st.n_tasks = (int32_t)n_tasks;
   return SURGE_OK;
@@ -413,7 +426,7 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
   DeviceGuard g(h->device);
   const int64_t span = h->an.last - h->an.first;
   const bool uniform = h->n_agg > 0 && !h->an.nonuniform && h->an.n_empty == 0 && h->an.len0 > 0 &&
-                       (h->an.len0 % kLaneEvents) == 0 && h->an.len0 < (1ll << 31) && h->an.first == 0;
+                       (h->an.len0 % 16) == 0 && h->an.len0 < (1ll << 31) && h->an.first == 0;
   if ((algo == SURGE_ALGO_FIXED || algo == SURGE_ALGO_ROWS) && !uniform)
     return fail(h, SURGE_E_UNSUPPORTED, "ALGO_FIXED / ALGO_ROWS need equal segment lengths that are a multiple of 16");
   const bool rows_ok = uniform && h->an.len0 <= (1 << 24);
@@ -433,9 +446,10 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
   h->st.n_tasks = 0;
   if (h->n_agg > 0 && span > 0) {
     if (use == SURGE_ALGO_ROWS) {
+      const int le = env_lane_events("SURGE_REPLAY_LE_ROWS", 8);
       const int64_t L = h->an.len0;
-      // a task = G groups of 64 aggregates, about kMaxTaskTiles tiles (one tile = 64 rows x 16 events)
-      int64_t G = (int64_t)kMaxTaskTiles * kLaneEvents / L;
+      // a task = G groups of 64 aggregates, about kTaskBytes of events
+      int64_t G = kTaskBytes / (kWave * L * 16);
       if (G < 1) G = 1;
       const int64_t groups = (h->n_agg + kWave - 1) / kWave;
       if (groups / G < kTargetTasks / 4) G = 1;
@@ -448,12 +462,13 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       const int32_t rc = next_fold_events(h, &e0, &e1);
       if (rc != SURGE_OK) return rc;
       HIPCHK(h, hipEventRecord(e0, h->stream));
-      HIPCHK(h, launch_fold_rows(p, n_tasks, h->stream));
+      HIPCHK(h, launch_fold_rows(p, n_tasks, le, h->stream));
       HIPCHK(h, hipEventRecord(e1, h->stream));
       h->st.n_tasks = (int32_t)n_tasks;
     } else if (use == SURGE_ALGO_FIXED) {
+      const int le = env_lane_events("SURGE_REPLAY_LE_FIXED", 16);
       const int64_t L = h->an.len0;
-      const int64_t task_events = choose_task_events(span);
+      const int64_t task_events = choose_task_events(span, le);
       int64_t G = task_events / L;
       if (G < 1) G = 1;
       const int64_t n_tasks = (h->n_agg + G - 1) / G;
@@ -464,7 +479,7 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       const int32_t rc = next_fold_events(h, &e0, &e1);
       if (rc != SURGE_OK) return rc;
       HIPCHK(h, hipEventRecord(e0, h->stream));
-      HIPCHK(h, launch_fold_fixed(p, n_tasks, h->stream));
+      HIPCHK(h, launch_fold_fixed(p, n_tasks, le, h->stream));
       HIPCHK(h, hipEventRecord(e1, h->stream));
       h->st.n_tasks = (int32_t)n_tasks;
     } else if (h->an.n_empty > 0) {

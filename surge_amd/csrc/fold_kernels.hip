@@ -214,45 +214,96 @@ __device__ __forceinline__ Acc load_state(const uint4* in, int64_t idx) {
   return a;
 }
 
-// Direct global->LDS load of one 16 KiB tile.  Instruction q writes LDS bytes [q*1024, q*1024+1024)
-// linearly by lane (that is what the hardware does); WHICH event a lane fetches is ours to choose:
-// LDS slot (q*64 + m) belongs to chunk-lane l = 4q + (m >> 4) and holds its event j = (m & 15) ^ (l & 15),
-// an XOR swizzle inside the lane's own 256 B row, so the later ds_read_b128 of "event j of lane l" is
-// bank-conflict free.  Every instruction still covers one contiguous, fully used 1 KiB of the log.
-// voff[k] is the lane's byte offset inside the 1 KiB piece for q & 3 == k (it only depends on q & 3).
-__device__ __forceinline__ void tile_lane_offsets(int lane, uint32_t voff[4]) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint32_t j = (uint32_t)(lane & 15) ^ (uint32_t)(4 * k + (lane >> 4));
-    voff[k] = (16u * (uint32_t)(lane >> 4) + j) * 16u;
+// ---- tile geometry ---------------------------------------------------------------------------------
+// One wave = 64 lanes x LE consecutive events per tile (LE = 16: 16 KiB tiles, LE = 8: 8 KiB tiles and
+// twice the resident waves).  A tile is fetched by direct global->LDS loads; instruction q writes LDS
+// bytes [q*1024, q*1024+1024) linearly by lane (that is what the hardware does); WHICH event a lane
+// fetches is ours to choose: LDS slot (q*64 + m) belongs to chunk-lane l = (64/LE) q + m / LE and holds
+// its event j = (m % LE) ^ key(l), an XOR swizzle inside the lane's own LE*16-byte row that makes the
+// later ds_read_b128 of "event j of lane l" bank-conflict free.  Every instruction still covers one
+// contiguous, fully used 1 KiB of the log.  The lane offset inside a 1 KiB piece only depends on
+// q mod kClasses, so it is computed once per wave.
+template <int LE>
+struct Geo {
+  static constexpr int kTile = kWave * LE;
+  static constexpr int kTileBytes = kTile * 16;
+  static constexpr int kRowBytes = LE * 16;
+  static constexpr int kLoads = kTileBytes / 1024;
+  static constexpr int kRowsPerLoad = kWave / LE;
+  static constexpr int kHeadWords = kTile / 32;
+  static constexpr int kClasses = LE == 16 ? 4 : 2;
+  static constexpr int kLdsBytes = kTileBytes + kHeadWords * 4 + kTableEntries * kTableStride * 4;
+  static constexpr uint32_t kLaneMask = (1u << LE) - 1u;
+  __device__ static __forceinline__ uint32_t key(int l) { return LE == 16 ? (uint32_t)(l & 15) : (uint32_t)((l >> 1) & 7); }
+  // my pre-swizzled LDS row: event j lives at (row ^ (j * 16))
+  __device__ static __forceinline__ uint32_t ev_row(int lane) { return (uint32_t)lane * kRowBytes + key(lane) * 16u; }
+  // event index j that load-lane m of an instruction of class k fetches, and its chunk-lane within the instruction
+  __device__ static __forceinline__ uint32_t load_j(int m, int k) {
+    const int l = kRowsPerLoad * k + m / LE;  // only key(l) matters and it is periodic in q with period kClasses
+    return (uint32_t)(m % LE) ^ key(l);
   }
+};
+
+template <int LE>
+__device__ __forceinline__ void load_table(const FoldParams& p, uint32_t* lds_tab, int lane) {
+  const uint32_t* src = &p.table[0][0];
+  for (int i = lane; i < kTableEntries * kTableWords; i += kWave)
+    lds_tab[(i / kTableWords) * kTableStride + (i % kTableWords)] = src[i];
 }
 
-__device__ __forceinline__ void issue_tile_loads(const FoldParams& p, int64_t te0, char* lds, const uint32_t voff[4]) {
+template <int LE>
+__device__ __forceinline__ void issue_tile_loads(const FoldParams& p, int64_t te0, char* lds, const uint32_t* voff) {
+  using G = Geo<LE>;
   const char* base = (const char*)(p.events + te0);  // wave-uniform
-  if (te0 + kTileEvents <= p.n_events) {
+  if (te0 + G::kTile <= p.n_events) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + q * 1024 + voff[q & 3]), (lptr_t)(lds + q * 1024), 16, 0, kLoadAux);
+    for (int q = 0; q < G::kLoads; ++q)
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + q * 1024 + voff[q % G::kClasses]), (lptr_t)(lds + q * 1024), 16, 0,
+                                       kLoadAux);
   } else {  // the last tile of the buffer: clamp so nothing is read past the end
     const int64_t last = (p.n_events - 1 - te0) * 16;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      int64_t off = (int64_t)(q * 1024 + voff[q & 3]);
+    for (int q = 0; q < G::kLoads; ++q) {
+      int64_t off = (int64_t)(q * 1024 + voff[q % G::kClasses]);
       off = off < last ? off : last;
       __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(lds + q * 1024), 16, 0, kLoadAux);
     }
   }
 }
 
+// The walk over my LE events: one evaluation path, op-table entries prefetched one event ahead.
+// on_head(j) is called before event j when it starts a new segment (flat kernels only).
+template <int LE, bool HEADS, typename OnHead>
+__device__ __forceinline__ void walk_events(Acc& a, uint32_t& frozenM, uint32_t& corr, const uint4* ev, const uint32_t* tyc,
+                                            uint32_t hb, const uint32_t* lds_tab, const FoldParams& p, OnHead on_head) {
+  uint4 tq0, tq1, tq2, tq3;
+  {
+    const uint4* te = (const uint4*)(lds_tab + tyc[0]);
+    tq0 = te[0]; tq1 = te[1]; tq2 = te[2]; tq3 = te[3];
+  }
+#pragma unroll
+  for (int j = 0; j < LE; ++j) {
+    uint4 nq0 = tq0, nq1 = tq1, nq2 = tq2, nq3 = tq3;
+    if (j + 1 < LE) {
+      const uint4* te = (const uint4*)(lds_tab + tyc[j + 1]);
+      nq0 = te[0]; nq1 = te[1]; nq2 = te[2]; nq3 = te[3];
+    }
+    if (HEADS && ((hb >> j) & 1u)) on_head(j);
+    apply_event(a, frozenM, corr, tq0, tq1, tq2, tq3, ev[j].y, ev[j].z, ev[j].w, p);
+    tq0 = nq0; tq1 = nq1; tq2 = nq2; tq3 = nq3;
+    __builtin_amdgcn_sched_barrier(0);  // keep the table prefetch one event deep (bounds VGPR pressure)
+  }
+}
+
 enum { MODE_FIXED = 0, MODE_FLAT = 1 };
 
-template <int MODE>
+template <int MODE, int LE>
 __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
+  using G = Geo<LE>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_ev = smem;
-  uint32_t* lds_hb = (uint32_t*)(smem + kTileBytes);
-  uint32_t* lds_tab = (uint32_t*)(smem + kTileBytes + kHeadWords * 4);
+  uint32_t* lds_hb = (uint32_t*)(smem + G::kTileBytes);
+  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kHeadWords * 4);
 
   const int lane = threadIdx.x;
   const int64_t task = blockIdx.x;
@@ -273,23 +324,20 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
   }
   if (E1 <= E0) return;
 
-  {
-    const uint32_t* src = &p.table[0][0];
-    for (int i = lane; i < kTableEntries * kTableWords; i += kWave)
-      lds_tab[(i / kTableWords) * kTableStride + (i % kTableWords)] = src[i];
-  }
-  if (MODE == MODE_FLAT && lane < kHeadWords) lds_hb[lane] = 0u;
+  load_table<LE>(p, lds_tab, lane);
+  if (MODE == MODE_FLAT && lane < G::kHeadWords) lds_hb[lane] = 0u;
 
-  const int n_tiles = (int)((E1 - E0 + kTileEvents - 1) / kTileEvents);
-  uint32_t voff[4];
-  tile_lane_offsets(lane, voff);
-  const uint32_t ev_row = (uint32_t)lane * 256u + (uint32_t)(lane & 15) * 16u;  // my LDS row, pre-swizzled
-  issue_tile_loads(p, E0, lds_ev, voff);
+  const int n_tiles = (int)((E1 - E0 + G::kTile - 1) / G::kTile);
+  uint32_t voff[G::kClasses];
+#pragma unroll
+  for (int k = 0; k < G::kClasses; ++k) voff[k] = ((uint32_t)(lane / LE) * LE + G::load_j(lane, k)) * 16u;
+  const uint32_t ev_row = G::ev_row(lane);
+  issue_tile_loads<LE>(p, E0, lds_ev, voff);
 
   // FLAT: head marking.  next_s = first segment whose start has not been marked yet.
   int64_t next_s = S0;
   auto mark_heads = [&](int64_t te0) {
-    const int64_t te1 = (te0 + kTileEvents < E1) ? te0 + kTileEvents : E1;
+    const int64_t te1 = (te0 + G::kTile < E1) ? te0 + G::kTile : E1;
     while (true) {
       const int64_t s = next_s + lane;
       const int64_t v = (s < S1) ? p.seg_off[s] : E1;
@@ -313,19 +361,19 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
   const uint64_t below = (1ull << lane) - 1ull;
 
   for (int tile = 0; tile < n_tiles; ++tile) {
-    const int64_t te0 = E0 + (int64_t)tile * kTileEvents;
+    const int64_t te0 = E0 + (int64_t)tile * G::kTile;
 
     // tile `tile` has landed in LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint4 ev[kLaneEvents];
+    uint4 ev[LE];
 #pragma unroll
-    for (int j = 0; j < kLaneEvents; ++j) ev[j] = *(const uint4*)(lds_ev + (ev_row ^ (uint32_t)(j * 16)));
+    for (int j = 0; j < LE; ++j) ev[j] = *(const uint4*)(lds_ev + (ev_row ^ (uint32_t)(j * 16)));
 
     uint32_t hb;          // bit j: my event j starts a new segment
     int64_t seg_open;     // segment open when my chunk starts (before a head at j = 0)
     int heads_in_tile = 0;
     if (MODE == MODE_FLAT) {
-      hb = (lds_hb[lane >> 1] >> ((lane & 1) * 16)) & 0xffffu;
+      hb = (lds_hb[(lane * LE) >> 5] >> ((lane * LE) & 31)) & G::kLaneMask;
       int incl = __popc(hb);
 #pragma unroll
       for (int d = 1; d < kWave; d <<= 1) {
@@ -336,39 +384,39 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
       heads_in_tile = (int)rl((uint32_t)incl, 63);
     } else {
       const uint32_t L = (uint32_t)p.fixed_len;
-      const uint32_t e_rel = (uint32_t)(te0 - E0) + (uint32_t)lane * kLaneEvents;
+      const uint32_t e_rel = (uint32_t)(te0 - E0) + (uint32_t)lane * LE;
       const uint32_t q = e_rel / L;
       const uint32_t r = e_rel - q * L;
-      hb = (r == 0u && te0 + lane * kLaneEvents < E1) ? 1u : 0u;
+      hb = (r == 0u && te0 + lane * LE < E1) ? 1u : 0u;
       seg_open = S0 - 1 + (int64_t)q + (r != 0u ? 1 : 0);
     }
     // all my reads of the event buffer are done: it can take the next tile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (MODE == MODE_FLAT && lane < kHeadWords) lds_hb[lane] = 0u;
-    if (tile + 1 < n_tiles) issue_tile_loads(p, te0 + kTileEvents, lds_ev, voff);
+    if (MODE == MODE_FLAT && lane < G::kHeadWords) lds_hb[lane] = 0u;
+    if (tile + 1 < n_tiles) issue_tile_loads<LE>(p, te0 + G::kTile, lds_ev, voff);
 
     // LDS dword offset of each event's op-table entry.  Events past the end of the task (last tile
     // only) become the null event [17], an identity on every state, so nothing below needs a validity mask.
-    uint32_t tyc[kLaneEvents];
-    if (te0 + kTileEvents <= E1) {
+    uint32_t tyc[LE];
+    if (te0 + G::kTile <= E1) {
 #pragma unroll
-      for (int j = 0; j < kLaneEvents; ++j) tyc[j] = (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride;
+      for (int j = 0; j < LE; ++j) tyc[j] = (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride;
     } else {
-      const int64_t rem = E1 - (te0 + (int64_t)lane * kLaneEvents);
+      const int64_t rem = E1 - (te0 + (int64_t)lane * LE);
 #pragma unroll
-      for (int j = 0; j < kLaneEvents; ++j)
+      for (int j = 0; j < LE; ++j)
         tyc[j] = ((int64_t)j < rem ? (ev[j].x < 16u ? ev[j].x : 16u) : 17u) * kTableStride;
     }
 
     // ---- pass A: presence / poison only, bit-parallel ---------------------------------------------
-    // Three 16-bit masks over my events: P throws, D deletes, M materialises.  The piece that matters to
+    // Three LE-bit masks over my events: P throws, D deletes, M materialises.  The piece that matters to
     // later lanes is the one after my LAST head (or my whole chunk): events before its first throwing
     // event are live; the last live M|D event, if any, forces presence to a constant.
     bool has_head, c_const, c_val, poi;
     {
       uint32_t PD = 0u, Mb = 0u;
 #pragma unroll
-      for (int j = 0; j < kLaneEvents; ++j) {
+      for (int j = 0; j < LE; ++j) {
         PD |= lds_tab[tyc[j] + TW_FLAGS] << j;                 // bit j: throws ; bit 16+j: deletes
         Mb |= lds_tab[tyc[j] + TW_MATERIALIZES] & (1u << j);
       }
@@ -381,7 +429,7 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
         ifl = ((const uint32_t*)(p.init + ii * 4 + 2))[1];
       }
       const bool ib = (ifl & FL_PRESENT) != 0u, iq = (ifl & FL_POISONED) != 0u;
-      const uint32_t range = 0xffffu & ~((1u << lo) - 1u);
+      const uint32_t range = G::kLaneMask & ~((1u << lo) - 1u);
       const uint32_t Pm = PD & range;
       uint32_t live = Pm ? (range & ((1u << __builtin_ctz(Pm)) - 1u)) : range;
       live = iq ? 0u : live;
@@ -418,40 +466,30 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
     Acc lead = a;
     bool seen = false;
     const int64_t lead_seg = seg_open;
-    uint4 tq0, tq1, tq2, tq3;  // op-table entry of the current event (prefetched one event ahead)
-    {
-      const uint4* te = (const uint4*)(lds_tab + tyc[0]);
-      tq0 = te[0]; tq1 = te[1]; tq2 = te[2]; tq3 = te[3];
-    }
-#pragma unroll
-    for (int j = 0; j < kLaneEvents; ++j) {
-      uint4 nq0 = tq0, nq1 = tq1, nq2 = tq2, nq3 = tq3;
-      if (j + 1 < kLaneEvents) {
-        const uint4* te = (const uint4*)(lds_tab + tyc[j + 1]);
-        nq0 = te[0]; nq1 = te[1]; nq2 = te[2]; nq3 = te[3];
+    auto on_head = [&](int) {
+      a.sum = (int64_t)((uint64_t)a.sum + corr);
+      corr = 0u;
+      if (!seen) {
+        lead = a;
+        seen = true;
+      } else {
+        const int64_t oi = p.out_map ? p.out_map[seg_open] : seg_open;
+        store_state(p.out, oi, a);
       }
-      if ((MODE == MODE_FLAT || j == 0) && ((hb >> j) & 1u)) {
-        a.sum = (int64_t)((uint64_t)a.sum + corr);
-        corr = 0u;
-        if (!seen) {
-          lead = a;
-          seen = true;
-        } else {
-          const int64_t oi = p.out_map ? p.out_map[seg_open] : seg_open;
-          store_state(p.out, oi, a);
-        }
-        seg_open += 1;
-        if (p.init) {
-          const int64_t ii = p.out_map ? p.out_map[seg_open] : seg_open;
-          a = load_state(p.init, ii);
-        } else {
-          a = acc_none();
-        }
-        frozenM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 1, 1);
+      seg_open += 1;
+      if (p.init) {
+        const int64_t ii = p.out_map ? p.out_map[seg_open] : seg_open;
+        a = load_state(p.init, ii);
+      } else {
+        a = acc_none();
       }
-      apply_event(a, frozenM, corr, tq0, tq1, tq2, tq3, ev[j].y, ev[j].z, ev[j].w, p);
-      tq0 = nq0; tq1 = nq1; tq2 = nq2; tq3 = nq3;
-      __builtin_amdgcn_sched_barrier(0);  // keep the table prefetch one event deep (bounds VGPR pressure)
+      frozenM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 1, 1);
+    };
+    if (MODE == MODE_FIXED) {  // a head can only sit at j = 0 (L % LE == 0)
+      if (hb & 1u) on_head(0);
+      walk_events<LE, false>(a, frozenM, corr, ev, tyc, 0u, lds_tab, p, on_head);
+    } else {
+      walk_events<LE, true>(a, frozenM, corr, ev, tyc, hb, lds_tab, p, on_head);
     }
     a.sum = (int64_t)((uint64_t)a.sum + corr);
 
@@ -481,7 +519,7 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
 
     if (MODE == MODE_FLAT) {
       c += heads_in_tile;
-      if (tile + 1 < n_tiles) mark_heads(te0 + kTileEvents);
+      if (tile + 1 < n_tiles) mark_heads(te0 + G::kTile);
     }
   }
 
@@ -493,15 +531,17 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
 
 // ---- K1 "rows": uniform fan-in, one lane per aggregate --------------------------------------------
 // When every aggregate has the same number of events L (L % 16 == 0) a wave takes 64 consecutive
-// aggregates and walks them in lockstep: tile c holds events [16c, 16c+16) of each of its 64 rows
-// (64 pieces of 256 B at a row stride of 16 L bytes; measured 6.1-6.8 TB/s on MI355X, close to the
-// linear stream).  Lane l then owns row l outright, so its running state is CONCRETE from the first
+// aggregates and walks them in lockstep: tile c holds events [LE c, LE c + LE) of each of its 64 rows
+// (64 pieces of LE*16 bytes at a row stride of 16 L bytes; measured 6.1-6.8 TB/s on MI355X, close to
+// the linear stream).  Lane l then owns row l outright, so its running state is CONCRETE from the first
 // event on: no presence pre-pass, no transformer scan, no cross-lane traffic at all — the walk is the
 // same mask arithmetic as the flat kernel and the 64 B results leave as one contiguous 4 KiB store.
+template <int LE>
 __global__ void __launch_bounds__(kWave) fold_rows_kernel(const FoldParams p) {
+  using G = Geo<LE>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_ev = smem;
-  uint32_t* lds_tab = (uint32_t*)(smem + kTileBytes + kHeadWords * 4);
+  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kHeadWords * 4);
 
   const int lane = threadIdx.x;
   const int64_t S0 = (int64_t)blockIdx.x * p.segs_per_task;
@@ -509,42 +549,33 @@ __global__ void __launch_bounds__(kWave) fold_rows_kernel(const FoldParams p) {
   S1 = S1 < p.n_seg ? S1 : p.n_seg;
   if (S0 >= S1) return;
   const uint32_t L = (uint32_t)p.fixed_len;
-  const int chunks = (int)(L / kLaneEvents);
+  const int chunks = (int)(L / LE);
   const int n_groups = (int)((S1 - S0 + kWave - 1) / kWave);
   const int n_tiles = n_groups * chunks;
 
-  {
-    const uint32_t* src = &p.table[0][0];
-    for (int i = lane; i < kTableEntries * kTableWords; i += kWave)
-      lds_tab[(i / kTableWords) * kTableStride + (i % kTableWords)] = src[i];
-  }
+  load_table<LE>(p, lds_tab, lane);
 
-  // lane offsets of the four load-instruction classes (q & 3): row (m >> 4) of the instruction's four
-  // rows, swizzled slot j inside the 256 B piece
-  uint32_t voff[4];
+  // lane offsets of the load-instruction classes: row (m / LE) of the instruction's rows, swizzled slot
+  uint32_t voff[G::kClasses];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint32_t j = (uint32_t)(lane & 15) ^ (uint32_t)(4 * k + (lane >> 4));
-    voff[k] = ((uint32_t)(lane >> 4) * L + j) * 16u;
-  }
-  const uint32_t ev_row = (uint32_t)lane * 256u + (uint32_t)(lane & 15) * 16u;
+  for (int k = 0; k < G::kClasses; ++k) voff[k] = ((uint32_t)(lane / LE) * L + G::load_j(lane, k)) * 16u;
+  const uint32_t ev_row = G::ev_row(lane);
 
   auto issue = [&](int t) {
     const int g = t / chunks, c = t - g * chunks;
     const int64_t row0 = S0 + (int64_t)g * kWave;
-    const char* base = (const char*)(p.events + (row0 * L + (int64_t)c * kLaneEvents));  // wave-uniform
+    const char* base = (const char*)(p.events + (row0 * L + (int64_t)c * LE));  // wave-uniform
     if (row0 + kWave <= p.n_seg) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
-        __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)(4 * q) * L * 16u + voff[q & 3]),
+      for (int q = 0; q < G::kLoads; ++q)
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)(G::kRowsPerLoad * q) * L * 16u + voff[q % G::kClasses]),
                                          (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
     } else {  // last group of the log: rows past the end re-read the last row (their lanes are idle)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        int64_t row = row0 + 4 * q + (lane >> 4);
+      for (int q = 0; q < G::kLoads; ++q) {
+        int64_t row = row0 + G::kRowsPerLoad * q + lane / LE;
         row = row < p.n_seg ? row : p.n_seg - 1;
-        const uint32_t j = (uint32_t)(lane & 15) ^ (uint32_t)(4 * (q & 3) + (lane >> 4));
-        const uint4* src = p.events + (row * L + (int64_t)c * kLaneEvents + j);
+        const uint4* src = p.events + (row * L + (int64_t)c * LE + G::load_j(lane, q % G::kClasses));
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
       }
     }
@@ -562,31 +593,16 @@ __global__ void __launch_bounds__(kWave) fold_rows_kernel(const FoldParams p) {
       corr = 0u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint4 ev[kLaneEvents];
+    uint4 ev[LE];
 #pragma unroll
-    for (int j = 0; j < kLaneEvents; ++j) ev[j] = *(const uint4*)(lds_ev + (ev_row ^ (uint32_t)(j * 16)));
+    for (int j = 0; j < LE; ++j) ev[j] = *(const uint4*)(lds_ev + (ev_row ^ (uint32_t)(j * 16)));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (t + 1 < n_tiles) issue(t + 1);
 
-    uint32_t tyc[kLaneEvents];
+    uint32_t tyc[LE];
 #pragma unroll
-    for (int j = 0; j < kLaneEvents; ++j) tyc[j] = (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride;
-    uint4 tq0, tq1, tq2, tq3;
-    {
-      const uint4* te = (const uint4*)(lds_tab + tyc[0]);
-      tq0 = te[0]; tq1 = te[1]; tq2 = te[2]; tq3 = te[3];
-    }
-#pragma unroll
-    for (int j = 0; j < kLaneEvents; ++j) {
-      uint4 nq0 = tq0, nq1 = tq1, nq2 = tq2, nq3 = tq3;
-      if (j + 1 < kLaneEvents) {
-        const uint4* te = (const uint4*)(lds_tab + tyc[j + 1]);
-        nq0 = te[0]; nq1 = te[1]; nq2 = te[2]; nq3 = te[3];
-      }
-      apply_event(a, frozenM, corr, tq0, tq1, tq2, tq3, ev[j].y, ev[j].z, ev[j].w, p);
-      tq0 = nq0; tq1 = nq1; tq2 = nq2; tq3 = nq3;
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int j = 0; j < LE; ++j) tyc[j] = (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride;
+    walk_events<LE, false>(a, frozenM, corr, ev, tyc, 0u, lds_tab, p, [](int) {});
     if (++c == chunks) {
       c = 0;
       a.sum = (int64_t)((uint64_t)a.sum + corr);
@@ -782,21 +798,30 @@ __global__ void count_poisoned_kernel(const uint4* __restrict__ states, int64_t 
 
 }  // namespace
 
-hipError_t launch_fold_fixed(const FoldParams& p, int64_t n_tasks, hipStream_t stream) {
+hipError_t launch_fold_fixed(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream) {
   if (n_tasks <= 0) return hipSuccess;
-  hipLaunchKernelGGL(fold_kernel<MODE_FIXED>, dim3((unsigned)n_tasks), dim3(kWave), kFoldLdsBytes, stream, p);
+  if (lane_events == 8)
+    hipLaunchKernelGGL((fold_kernel<MODE_FIXED, 8>), dim3((unsigned)n_tasks), dim3(kWave), Geo<8>::kLdsBytes, stream, p);
+  else
+    hipLaunchKernelGGL((fold_kernel<MODE_FIXED, 16>), dim3((unsigned)n_tasks), dim3(kWave), Geo<16>::kLdsBytes, stream, p);
   return hipGetLastError();
 }
 
-hipError_t launch_fold_rows(const FoldParams& p, int64_t n_tasks, hipStream_t stream) {
+hipError_t launch_fold_rows(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream) {
   if (n_tasks <= 0) return hipSuccess;
-  hipLaunchKernelGGL(fold_rows_kernel, dim3((unsigned)n_tasks), dim3(kWave), kFoldLdsBytes, stream, p);
+  if (lane_events == 8)
+    hipLaunchKernelGGL((fold_rows_kernel<8>), dim3((unsigned)n_tasks), dim3(kWave), Geo<8>::kLdsBytes, stream, p);
+  else
+    hipLaunchKernelGGL((fold_rows_kernel<16>), dim3((unsigned)n_tasks), dim3(kWave), Geo<16>::kLdsBytes, stream, p);
   return hipGetLastError();
 }
 
-hipError_t launch_fold_flat(const FoldParams& p, int64_t n_tasks, hipStream_t stream) {
+hipError_t launch_fold_flat(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream) {
   if (n_tasks <= 0) return hipSuccess;
-  hipLaunchKernelGGL(fold_kernel<MODE_FLAT>, dim3((unsigned)n_tasks), dim3(kWave), kFoldLdsBytes, stream, p);
+  if (lane_events == 8)
+    hipLaunchKernelGGL((fold_kernel<MODE_FLAT, 8>), dim3((unsigned)n_tasks), dim3(kWave), Geo<8>::kLdsBytes, stream, p);
+  else
+    hipLaunchKernelGGL((fold_kernel<MODE_FLAT, 16>), dim3((unsigned)n_tasks), dim3(kWave), Geo<16>::kLdsBytes, stream, p);
   return hipGetLastError();
 }
 

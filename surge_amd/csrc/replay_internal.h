@@ -9,17 +9,13 @@
 
 namespace surge {
 
-// Tile geometry of the flat fold: one wave = 64 lanes x 16 contiguous events
-// = 1024 events = 16 KiB, staged through LDS with direct global->LDS loads.
+// Tile geometry: one wave = 64 lanes x LE consecutive events per tile (LE = 8 or 16), staged through
+// LDS with direct global->LDS loads; see Geo<LE> in fold_kernels.hip.
 constexpr int kWave = 64;
-constexpr int kLaneEvents = 16;
-constexpr int kTileEvents = kWave * kLaneEvents;          // 1024
-constexpr int kTileBytes = kTileEvents * 16;              // 16384
-constexpr int kHeadWords = kTileEvents / 32;              // 32 dwords = 128 B head bitmask
+constexpr int kTaskBytes = 256 * 1024;                    // a wave task streams about this many bytes of events
 constexpr int kTableEntries = 18;                         // 16 event types + [16] unknown type (poison) + [17] null (padding) event
 constexpr int kTableWords = 16;                           // 64 B of pre-expanded masks per event type
 constexpr int kTableStride = 20;                          // dwords between entries in LDS (80 B: conflict-free b128 reads)
-constexpr int kFoldLdsBytes = kTileBytes + kHeadWords * 4 + kTableEntries * kTableStride * 4;  // 17952 (16 B multiple)
 
 // Per-type op table, pre-expanded on the host from the ABI descriptor so the kernel applies an event
 // with VALU mask arithmetic only (no per-event decode, no compares, no branches).  Every word is an
@@ -42,8 +38,7 @@ enum {
   TW_MAX = 14,
   TW_FLAGS = 15,   // presence pre-pass: bit0 poison, bit16 delete, bit1 materializes (OR-ed in at << j)
 };
-constexpr int kMaxTaskTiles = 16;                         // a wave task streams <= ~256 KiB contiguous
-constexpr int kTargetTasks = 16384;                       // enough tasks to fill 256 CUs x 8 waves twice
+constexpr int kTargetTasks = 16384;                       // enough tasks to fill the chip several times over
 
 struct FoldParams {
   const uint4* events;      // 16 B records
@@ -74,9 +69,9 @@ struct CsrAnalysis {
 };
 
 // Launch wrappers (fold_kernels.hip).  All asynchronous on `stream`.
-hipError_t launch_fold_fixed(const FoldParams& p, int64_t n_tasks, hipStream_t stream);
-hipError_t launch_fold_flat(const FoldParams& p, int64_t n_tasks, hipStream_t stream);
-hipError_t launch_fold_rows(const FoldParams& p, int64_t n_tasks, hipStream_t stream);
+hipError_t launch_fold_fixed(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream);
+hipError_t launch_fold_flat(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream);
+hipError_t launch_fold_rows(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream);
 hipError_t launch_plan(const int64_t* off, int64_t n_seg, int64_t task_events, int64_t n_tasks,
                        int64_t* plan, hipStream_t stream);
 hipError_t launch_analyze_csr(const int64_t* off, int64_t n_seg, CsrAnalysis* d_result, hipStream_t stream);
