@@ -192,7 +192,7 @@ def main():
                 "workload": f"C2 per GPU: {A} aggregates x {L} events, 16 B events, 64 B state, log resident in HBM",
                 "aggregates_per_gpu": A,
                 "events_per_aggregate": L,
-                "algo": {S.ALGO_FIXED: "fixed", S.ALGO_FLAT: "flat"}.get(st.last_algo, str(st.last_algo)),
+                "algo": {S.ALGO_FIXED: "fixed", S.ALGO_FLAT: "flat", S.ALGO_ROWS: "rows"}.get(st.last_algo, str(st.last_algo)),
                 "wave_tasks": st.n_tasks,
                 "sharding": "single shard" if world == 1 else
                 f"murmur3(acct-%08d) % {N_PARTITIONS} -> gpu = partition % {world}; RCCL all-gather of the snapshot overlapped on a side stream",
@@ -204,7 +204,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": None,
-                "kernel": "fold_kernel<FIXED>" if st.last_algo == S.ALGO_FIXED else "fold_kernel<FLAT>",
+                "kernel": {S.ALGO_FIXED: "fold_kernel<FIXED,16>", S.ALGO_FLAT: "fold_kernel<FLAT,16>",
+                           S.ALGO_ROWS: "fold_rows_kernel<8>"}.get(st.last_algo, "?"),
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes": st.algorithmic_bytes,
                 "timed_launches": st.timed_folds,

@@ -107,12 +107,13 @@ def load() -> ctypes.CDLL:
         import torch  # noqa: F401  (side effect: loads torch's HIP runtime)
     except Exception:  # pragma: no cover - torch is optional for pure C hosts
         pass
-    if needs_build():
+    lib_path = os.environ.get("SURGE_REPLAY_LIB", LIB_PATH)  # experiments: load an alternative build
+    if lib_path == LIB_PATH and needs_build():
         build()
     try:
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(lib_path)
     except OSError as e:
-        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        raise NativeLibraryError(f"cannot load {lib_path}: {e}") from e
     vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
     sig = {
         "surge_replay_default_schema": ([ctypes.POINTER(CSchema)], i32),

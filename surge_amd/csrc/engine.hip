@@ -53,6 +53,7 @@ struct DeviceGuard {
 
 struct surge_replay_handle {
   int device = 0;
+  int n_cus = 256;
   hipStream_t stream = nullptr;
   surge_replay_schema schema{};
   std::string err;
@@ -159,7 +160,9 @@ void fill_params(const surge_replay_handle* h, FoldParams& p) {
 // events at most, small enough that short logs still spread over the chip.
 int64_t choose_task_events(int64_t n_events, int lane_events) {
   const int64_t tile = (int64_t)kWave * lane_events;
-  const int64_t max_tiles = kTaskBytes / (tile * 16);
+  int64_t task_bytes = kTaskBytes;
+  if (const char* v = std::getenv("SURGE_REPLAY_TASK_KB")) task_bytes = (int64_t)std::atoi(v) * 1024;
+  const int64_t max_tiles = task_bytes / (tile * 16) > 0 ? task_bytes / (tile * 16) : 1;
   int64_t tiles = (n_events / kTargetTasks + tile - 1) / tile;
   if (tiles < 1) tiles = 1;
   if (tiles > max_tiles) tiles = max_tiles;
@@ -303,6 +306,10 @@ int32_t surge_replay_create(const surge_replay_schema* schema, int32_t device_id
   if (!h) return fail(nullptr, SURGE_E_NOMEM, "out of host memory");
   h->device = device_id;
   h->schema = *schema;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) h->n_cus = cus;
+  }
   DeviceGuard g(device_id);
   if (!g.ok) {
     delete h;
@@ -449,10 +456,14 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       const int le = env_lane_events("SURGE_REPLAY_LE_ROWS", 8);
       const int64_t L = h->an.len0;
       // a task = G groups of 64 aggregates, about kTaskBytes of events
-      int64_t G = kTaskBytes / (kWave * L * 16);
-      if (G < 1) G = 1;
+      // Measured on MI355X: this access pattern runs fastest as ONE resident generation of waves (no
+      // re-dispatch, every wave streams from start to end): G groups of 64 aggregates per wave so that
+      // the grid just fits the chip's wave slots (CUs x 16 waves at 8 KiB tiles, x 9 at 16 KiB tiles).
       const int64_t groups = (h->n_agg + kWave - 1) / kWave;
-      if (groups / G < kTargetTasks / 4) G = 1;
+      const int64_t slots = (int64_t)h->n_cus * (le == 8 ? 16 : 9);
+      int64_t G = (groups + slots - 1) / slots;
+      if (const char* v = std::getenv("SURGE_REPLAY_ROWS_GROUPS")) G = std::atoi(v);
+      if (G < 1) G = 1;
       const int64_t per_task = G * kWave;
       const int64_t n_tasks = (h->n_agg + per_task - 1) / per_task;
       p.n_seg = h->n_agg;
@@ -730,9 +741,9 @@ int32_t surge_replay_stream_probe(surge_replay_handle* h, const void* d_src, int
   DeviceGuard g(h->device);
   HIPCHK(h, h->poison_count.reserve(8));
   float best = 0.f;
-  for (int variant = 0; variant < 2; ++variant) {  // plain and non-temporal 16 B/lane loads: report the faster
+  for (int variant = 0; variant < 3; ++variant) {  // plain / non-temporal register loads, LDS-DMA tile stream: report the fastest
     HIPCHK(h, hipEventRecord(h->ev_h0, h->stream));
-    HIPCHK(h, launch_stream_probe((const uint4*)d_src, n_bytes / 16, (uint32_t*)h->poison_count.ptr, variant == 1, h->stream));
+    HIPCHK(h, launch_stream_probe((const uint4*)d_src, n_bytes / 16, (uint32_t*)h->poison_count.ptr, variant, h->stream));
     HIPCHK(h, hipEventRecord(h->ev_h1, h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev_h1));
     float t = 0.f;

@@ -284,12 +284,18 @@ __device__ __forceinline__ void walk_events(Acc& a, uint32_t& frozenM, uint32_t&
 #pragma unroll
   for (int j = 0; j < LE; ++j) {
     uint4 nq0 = tq0, nq1 = tq1, nq2 = tq2, nq3 = tq3;
+#if !defined(SURGE_DBG_FIXED_TABLE)
     if (j + 1 < LE) {
       const uint4* te = (const uint4*)(lds_tab + tyc[j + 1]);
       nq0 = te[0]; nq1 = te[1]; nq2 = te[2]; nq3 = te[3];
     }
+#endif
     if (HEADS && ((hb >> j) & 1u)) on_head(j);
+#if defined(SURGE_DBG_SKIP_APPLY)  // experiment builds only: keep the loads alive, skip the arithmetic
+    a.count ^= (int32_t)(tq0.x ^ tq1.x ^ tq2.x ^ tq3.x ^ ev[j].y ^ ev[j].z ^ ev[j].w);
+#else
     apply_event(a, frozenM, corr, tq0, tq1, tq2, tq3, ev[j].y, ev[j].z, ev[j].w, p);
+#endif
     tq0 = nq0; tq1 = nq1; tq2 = nq2; tq3 = nq3;
     __builtin_amdgcn_sched_barrier(0);  // keep the table prefetch one event deep (bounds VGPR pressure)
   }
@@ -762,7 +768,10 @@ __global__ void partition_hash_kernel(const uint16_t* __restrict__ utf16, const 
   part_out[i] = r < 0 ? -r : r;
 }
 
-// ---- HBM read-stream ceiling probe -------------------------------------------------------------
+// ---- HBM read-stream ceiling probes -------------------------------------------------------------
+// (a) 16 B/lane register loads, plain or non-temporal; (b) the fold kernels' own transport with the
+// arithmetic removed: one wave streams a contiguous range in 16 KiB tiles through global_load_lds nt.
+// bench.py reports the fastest as the achievable streaming ceiling beside the 8 TB/s spec.
 template <bool NT>
 __global__ void __launch_bounds__(256) stream_probe_kernel(const uint4* __restrict__ src, int64_t n_vec,
                                                            uint32_t* __restrict__ sink) {
@@ -787,6 +796,27 @@ __global__ void __launch_bounds__(256) stream_probe_kernel(const uint4* __restri
     acc ^= a.x ^ a.y ^ a.z ^ a.w;
   }
   if (acc == 0x9e3779b9u) sink[0] = acc;  // practically never; keeps the loads alive
+}
+
+__global__ void __launch_bounds__(kWave) stream_probe_lds_kernel(const uint4* __restrict__ src, int64_t n_vec,
+                                                                 int64_t vec_per_wave, uint32_t* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const int64_t v0 = (int64_t)blockIdx.x * vec_per_wave;
+  int64_t v1 = v0 + vec_per_wave;
+  v1 = v1 < n_vec ? v1 : n_vec;
+  uint32_t acc = 0;
+  for (int64_t v = v0; v + 1024 <= v1; v += 1024) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint4 x = *(const uint4*)(smem + lane * 256);
+    acc ^= x.x ^ x.y ^ x.z ^ x.w;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + v + q * 64 + lane), (lptr_t)(smem + q * 1024), 16, 0, kLoadAux);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (acc == 0x9e3779b9u) sink[0] = acc;
 }
 
 __global__ void count_poisoned_kernel(const uint4* __restrict__ states, int64_t n, unsigned long long* count) {
@@ -869,8 +899,17 @@ hipError_t launch_partition_hash(const uint16_t* utf16, const int64_t* str_off, 
   return hipGetLastError();
 }
 
-hipError_t launch_stream_probe(const uint4* src, int64_t n_vec, uint32_t* sink, bool nontemporal, hipStream_t stream) {
-  if (nontemporal)
+hipError_t launch_stream_probe(const uint4* src, int64_t n_vec, uint32_t* sink, int variant, hipStream_t stream) {
+  if (variant == 2) {  // LDS-DMA tile stream, one resident generation of waves
+    const int64_t waves = 256 * 9;
+    int64_t per = (n_vec / waves) / 1024 * 1024;
+    if (per < 1024) per = 1024;
+    const int64_t n_waves = n_vec / per;
+    if (n_waves <= 0) return hipSuccess;
+    hipLaunchKernelGGL(stream_probe_lds_kernel, dim3((unsigned)n_waves), dim3(kWave), 16384, stream, src, n_vec, per, sink);
+    return hipGetLastError();
+  }
+  if (variant == 1)
     hipLaunchKernelGGL(stream_probe_kernel<true>, dim3(256 * 8), dim3(256), 0, stream, src, n_vec, sink);
   else
     hipLaunchKernelGGL(stream_probe_kernel<false>, dim3(256 * 8), dim3(256), 0, stream, src, n_vec, sink);
