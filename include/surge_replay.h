@@ -147,6 +147,8 @@ typedef struct surge_replay_schema {
 #define SURGE_ALGO_FIXED 1 /* K1b: flat fold with segment heads computed arithmetically (uniform L)   */
 #define SURGE_ALGO_FLAT  2 /* K2: load-balanced flat segmented scan over the CSR                      */
 #define SURGE_ALGO_ROWS  3 /* K1: uniform L, one lane per aggregate, no cross-lane scan               */
+#define SURGE_ALGO_SORTED 4 /* K2b: any CSR; segments counting-sorted by length at load time, persistent
+                               waves walk groups of 64 similar-length segments, one lane per aggregate  */
 
 typedef struct surge_replay_stats_t {
   int64_t n_aggregates;

@@ -43,6 +43,12 @@ lens = rng.integers(0, 3, size=3000) * rng.integers(0, 2000, size=3000)
 so, ev = synth.csr_log(lens, 8, synth.STRESS_MIX)
 init = oracle.fold_csr(*synth.csr_log(rng.integers(0, 4, size=3000), 9, synth.STRESS_MIX))
 allok &= check("init + empties + long", so, ev, init)
+for nm, (so_, ev_) in {"zipf 20000 sorted": synth.zipf_log(20000, 3), "zipf 20000 stress sorted": synth.zipf_log(20000, 4, mix=synth.STRESS_MIX),
+                       "fixed 4133x48 sorted": synth.fixed_log(4133, 48, 5, synth.STRESS_MIX), "tiny sorted": synth.zipf_log(70, 9, max_len=40)}.items():
+    allok &= check(nm, so_, ev_, algo=4)
+lens = rng.integers(0, 3, size=3000) * rng.integers(0, 2000, size=3000)
+so, ev = synth.csr_log(lens, 8, synth.STRESS_MIX)
+allok &= check("init + empties + long sorted", so, ev, init, algo=4)
 print("ALL OK" if allok else "FAILURES")
 
 # perf: C2
@@ -71,3 +77,25 @@ for (A, L) in [(1_000_000, 256)]:
     exp = oracle.fold_csr(so[:2001].cpu().numpy(), synth.to_event_records(ev[:2000*L]))
     print("C2 slice parity:", got.tobytes() == exp.tobytes())
     eng.close()
+
+# perf: Zipf (C3 shape, 2M aggregates)
+lens = synth.zipf_lengths(torch.arange(2_000_000, dtype=torch.int64, device=dev), 3)
+so, ev = synth.csr_log_device(lens, 3)
+A = lens.numel(); E = ev.shape[0]
+out = torch.empty((A, 64), dtype=torch.uint8, device=dev)
+eng = ReplayEngine()
+eng.load_csr(so, ev, None, out)
+res = {}
+for algo in (2, 4):
+    for _ in range(2):
+        eng.fold(algo)
+    eng.synchronize(); eng.stats_reset()
+    for _ in range(5):
+        eng.fold(algo)
+    st = eng.stats()
+    ms = st.sum_fold_kernel_ms / st.timed_folds
+    res[algo] = out.clone()
+    print(f"Zipf 2M aggs, {E/1e6:.0f}M events, algo={algo}: kernel {ms:.3f} ms, {E/ms/1e6:.1f} Gev/s, {st.algorithmic_bytes/ms/1e6:.0f} GB/s alg")
+print("zipf flat == sorted:", torch.equal(res[2], res[4]))
+exp = oracle.fold_csr(so[:5001].cpu().numpy(), synth.to_event_records(ev[:int(so[5000])]))
+print("zipf slice parity:", res[4][:5000].cpu().numpy().tobytes() == exp.tobytes())

@@ -618,6 +618,152 @@ __global__ void __launch_bounds__(kWave) fold_rows_kernel(const FoldParams p) {
   }
 }
 
+// ---- K2 "sorted rows": arbitrary CSR, one lane per aggregate ----------------------------------------
+// Segments are counting-sorted by length at load time (perm, longest first).  Persistent waves pull
+// groups of 64 consecutive perm entries from an atomic counter; inside a group the lengths are (almost)
+// equal, so the 64 lanes walk their own segments in lockstep exactly like the uniform rows kernel:
+// concrete running state, no presence pre-pass, no scan.  A lane whose segment ends early pads with the
+// null event.  Row pieces are LE*16 bytes at arbitrary 16 B-aligned addresses.
+constexpr int kSortBuckets = 65536;  // bucket = min(length, 65535); longer segments share the last one
+
+template <int LE>
+__global__ void __launch_bounds__(kWave) fold_sorted_kernel(const FoldParams p) {
+  using G = Geo<LE>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_ev = smem;
+  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kHeadWords * 4);
+  const int lane = threadIdx.x;
+  load_table<LE>(p, lds_tab, lane);
+  const uint32_t ev_row = G::ev_row(lane);
+  const int64_t n_groups = (p.n_seg + kWave - 1) / kWave;
+  const int64_t* perm = p.plan;
+
+  auto grab = [&]() -> int64_t {
+    unsigned long long g = 0;
+    if (lane == 0) g = atomicAdd(p.counter, 1ull);
+    return (int64_t)(((uint64_t)rl((uint32_t)(g >> 32), 0) << 32) | rl((uint32_t)g, 0));
+  };
+  struct Meta { int64_t s, start; uint32_t len; };
+  auto load_meta = [&](int64_t g) -> Meta {
+    Meta m; m.s = -1; m.start = 0; m.len = 0u;
+    const int64_t idx = g * kWave + lane;
+    if (g < n_groups && idx < p.n_seg) {
+      m.s = perm[idx];
+      m.start = p.seg_off[m.s];
+      m.len = (uint32_t)(p.seg_off[m.s + 1] - m.start);
+    }
+    return m;
+  };
+
+  int64_t g = grab();
+  Meta cur = load_meta(g);
+  while (g < n_groups) {
+    const int64_t g_next = grab();
+    const Meta nxt = load_meta(g_next);  // in flight while this group is walked
+
+    uint32_t maxlen = cur.len, minlen = cur.s >= 0 ? cur.len : 0xffffffffu;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, d, 64));
+      minlen = min(minlen, (uint32_t)__shfl_xor((int)minlen, d, 64));
+    }
+    const int n_tiles = (int)((maxlen + LE - 1) / LE);
+
+    // the rows each load instruction serves: start and length of row RPL*q + lane/LE
+    int64_t rs[G::kLoads];
+    uint32_t rlen[G::kLoads];
+#pragma unroll
+    for (int q = 0; q < G::kLoads; ++q) {
+      const int r = G::kRowsPerLoad * q + lane / LE;
+      rs[q] = __shfl(cur.start, r, 64);
+      rlen[q] = (uint32_t)__shfl((int)cur.len, r, 64);
+    }
+    auto issue = [&](int c) {
+      if ((uint32_t)(c + 1) * LE <= minlen) {
+#pragma unroll
+        for (int q = 0; q < G::kLoads; ++q) {
+          const int64_t e = rs[q] + (int64_t)c * LE + G::load_j(lane, q % G::kClasses);
+          __builtin_amdgcn_global_load_lds((gptr_t)(p.events + e), (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
+        }
+      } else {  // some row ends inside this tile: never read past a row's own events
+#pragma unroll
+        for (int q = 0; q < G::kLoads; ++q) {
+          uint32_t j = (uint32_t)c * LE + G::load_j(lane, q % G::kClasses);
+          const uint32_t lastj = rlen[q] ? rlen[q] - 1u : 0u;
+          j = j < lastj ? j : lastj;
+          __builtin_amdgcn_global_load_lds((gptr_t)(p.events + (rs[q] + j)), (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
+        }
+      }
+    };
+
+    const int64_t oi = cur.s >= 0 ? (p.out_map ? p.out_map[cur.s] : cur.s) : -1;
+    Acc a = (p.init && oi >= 0) ? load_state(p.init, oi) : acc_none();
+    uint32_t frozenM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 1, 1);
+    uint32_t corr = 0u;
+    issue(0);
+    for (int c = 0; c < n_tiles; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      uint4 ev[LE];
+#pragma unroll
+      for (int j = 0; j < LE; ++j) ev[j] = *(const uint4*)(lds_ev + (ev_row ^ (uint32_t)(j * 16)));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (c + 1 < n_tiles) issue(c + 1);
+
+      uint32_t tyc[LE];
+      if ((uint32_t)(c + 1) * LE <= minlen) {
+#pragma unroll
+        for (int j = 0; j < LE; ++j) tyc[j] = (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride;
+      } else {
+        const int32_t rem = (int32_t)cur.len - c * LE;  // my remaining events (may be <= 0)
+#pragma unroll
+        for (int j = 0; j < LE; ++j) tyc[j] = (j < rem ? (ev[j].x < 16u ? ev[j].x : 16u) : 17u) * kTableStride;
+      }
+      walk_events<LE, false>(a, frozenM, corr, ev, tyc, 0u, lds_tab, p, [](int) {});
+    }
+    a.sum = (int64_t)((uint64_t)a.sum + corr);
+    if (oi >= 0) store_state(p.out, oi, a);
+
+    g = g_next;
+    cur = nxt;
+  }
+}
+
+// load-time counting sort of the kernel-facing segments by length, longest first
+__global__ void sort_hist_kernel(const int64_t* __restrict__ off, int64_t n_seg, unsigned long long* __restrict__ hist) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_seg) return;
+  const int64_t len = off[s + 1] - off[s];
+  atomicAdd(&hist[len < kSortBuckets - 1 ? len : kSortBuckets - 1], 1ull);
+}
+
+// single block: hist[b] := number of segments in buckets > b (descending exclusive scan)
+__global__ void __launch_bounds__(1024) sort_scan_kernel(unsigned long long* hist) {
+  __shared__ unsigned long long part[1024];
+  const int tid = threadIdx.x;
+  const int per = kSortBuckets / 1024;
+  const int hi = kSortBuckets - 1 - tid * per;  // thread 0 owns the longest buckets
+  unsigned long long sum = 0;
+  for (int k = 0; k < per; ++k) sum += hist[hi - k];
+  part[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long run = 0;
+    for (int i = 0; i < 1024; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+  }
+  __syncthreads();
+  unsigned long long run = part[tid];
+  for (int k = 0; k < per; ++k) { const unsigned long long v = hist[hi - k]; hist[hi - k] = run; run += v; }
+}
+
+__global__ void sort_scatter_kernel(const int64_t* __restrict__ off, int64_t n_seg, unsigned long long* __restrict__ cursor,
+                                    int64_t* __restrict__ perm) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_seg) return;
+  const int64_t len = off[s + 1] - off[s];
+  const unsigned long long pos = atomicAdd(&cursor[len < kSortBuckets - 1 ? len : kSortBuckets - 1], 1ull);
+  perm[pos] = s;
+}
+
 // ---- plan: task k owns segments [lower_bound(off, off[0] + k*T), lower_bound(off, off[0] + (k+1)*T)) ----
 __global__ void plan_kernel(const int64_t* __restrict__ off, int64_t n_seg, int64_t task_events,
                             int64_t n_tasks, int64_t* __restrict__ plan) {
@@ -843,6 +989,30 @@ hipError_t launch_fold_rows(const FoldParams& p, int64_t n_tasks, int lane_event
     hipLaunchKernelGGL((fold_rows_kernel<8>), dim3((unsigned)n_tasks), dim3(kWave), Geo<8>::kLdsBytes, stream, p);
   else
     hipLaunchKernelGGL((fold_rows_kernel<16>), dim3((unsigned)n_tasks), dim3(kWave), Geo<16>::kLdsBytes, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_fold_sorted(const FoldParams& p, int64_t n_waves, int lane_events, hipStream_t stream) {
+  if (n_waves <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(p.counter, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  if (lane_events == 8)
+    hipLaunchKernelGGL((fold_sorted_kernel<8>), dim3((unsigned)n_waves), dim3(kWave), Geo<8>::kLdsBytes, stream, p);
+  else
+    hipLaunchKernelGGL((fold_sorted_kernel<16>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::kLdsBytes, stream, p);
+  return hipGetLastError();
+}
+
+// perm (n_seg int64) := kernel-facing segment ids sorted by length, longest first.  d_hist: kSortBuckets u64 scratch.
+hipError_t launch_sort_by_length(const int64_t* off, int64_t n_seg, unsigned long long* d_hist, int64_t* perm,
+                                 hipStream_t stream) {
+  if (n_seg <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(d_hist, 0, (size_t)kSortBuckets * 8, stream);
+  if (e != hipSuccess) return e;
+  const unsigned blocks = (unsigned)((n_seg + 255) / 256);
+  hipLaunchKernelGGL(sort_hist_kernel, dim3(blocks), dim3(256), 0, stream, off, n_seg, d_hist);
+  hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, stream, d_hist);
+  hipLaunchKernelGGL(sort_scatter_kernel, dim3(blocks), dim3(256), 0, stream, off, n_seg, d_hist, perm);
   return hipGetLastError();
 }
 

@@ -45,6 +45,8 @@ struct FoldParams {
   int64_t n_events;         // length of the events buffer (loads are clamped to it)
   const int64_t* seg_off;   // kernel-facing CSR offsets, strictly increasing (FLAT); unused for FIXED
   const int64_t* plan;      // FLAT: n_tasks+1 segment indices; task k owns segments [plan[k], plan[k+1])
+                            // SORTED: perm[n_seg], kernel-facing segment ids by descending length
+  unsigned long long* counter;  // SORTED: group dispenser, zeroed before every launch
   const int64_t* out_map;   // nullable: segment rank -> aggregate index (compacted CSR / micro-batch groups)
   const uint4* init;        // nullable: prior snapshot, 64 B per aggregate
   uint4* out;               // 64 B per aggregate
@@ -72,6 +74,10 @@ struct CsrAnalysis {
 hipError_t launch_fold_fixed(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream);
 hipError_t launch_fold_flat(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream);
 hipError_t launch_fold_rows(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream);
+hipError_t launch_fold_sorted(const FoldParams& p, int64_t n_waves, int lane_events, hipStream_t stream);
+constexpr int kSortBucketsHost = 65536;
+hipError_t launch_sort_by_length(const int64_t* off, int64_t n_seg, unsigned long long* d_hist, int64_t* perm,
+                                 hipStream_t stream);
 hipError_t launch_plan(const int64_t* off, int64_t n_seg, int64_t task_events, int64_t n_tasks,
                        int64_t* plan, hipStream_t stream);
 hipError_t launch_analyze_csr(const int64_t* off, int64_t n_seg, CsrAnalysis* d_result, hipStream_t stream);

@@ -52,18 +52,46 @@ def test_fixed_fan_in(n_agg, length, mix):
     exp = oracle.fold_csr(so, ev)
     got, st = gpu_fold(so, ev)
     assert_same(got, exp, so)
-    assert st.last_algo == (S.ALGO_FIXED if length % 16 == 0 else S.ALGO_FLAT)
+    assert st.last_algo == (S.ALGO_FIXED if length % 16 == 0 else S.ALGO_FLAT)  # too few aggregates for ROWS
     got_flat, st = gpu_fold(so, ev, algo=S.ALGO_FLAT)
     assert st.last_algo == S.ALGO_FLAT
     assert_same(got_flat, exp, so)
+    got_sorted, st = gpu_fold(so, ev, algo=S.ALGO_SORTED)
+    assert st.last_algo == S.ALGO_SORTED
+    assert_same(got_sorted, exp, so)
+    if length % 16 == 0:
+        got_rows, st = gpu_fold(so, ev, algo=S.ALGO_ROWS)
+        assert st.last_algo == S.ALGO_ROWS
+        assert_same(got_rows, exp, so)
 
 
 @pytest.mark.parametrize("seed,mix", [(3, synth.C2_MIX), (4, synth.STRESS_MIX)])
 def test_zipf_csr(seed, mix):
     so, ev = synth.zipf_log(20000, seed, mix=mix)
+    exp = oracle.fold_csr(so, ev)
     got, st = gpu_fold(so, ev)
     assert st.last_algo == S.ALGO_FLAT
-    assert_same(got, oracle.fold_csr(so, ev), so)
+    assert_same(got, exp, so)
+    got, st = gpu_fold(so, ev, algo=S.ALGO_SORTED)
+    assert st.last_algo == S.ALGO_SORTED
+    assert_same(got, exp, so)
+
+
+def test_auto_picks_rows_for_large_uniform_logs_and_all_uniform_kernels_agree():
+    so, ev = synth.fixed_log(140_000, 32, seed=21, mix=synth.STRESS_MIX)
+    exp = oracle.fold_csr(so, ev)
+    got, st = gpu_fold(so, ev)
+    assert st.last_algo == S.ALGO_ROWS
+    assert_same(got, exp, so)
+    for algo in (S.ALGO_FIXED, S.ALGO_FLAT, S.ALGO_SORTED):
+        got, st = gpu_fold(so, ev, algo=algo)
+        assert st.last_algo == algo
+        assert_same(got, exp, so)
+    # rows kernel with a prior snapshot and a ragged last group (n_agg % 64 != 0)
+    so, ev = synth.fixed_log(140_003, 16, seed=22, mix=synth.STRESS_MIX)
+    prior = oracle.fold_csr(*synth.fixed_log(140_003, 2, seed=23, mix=synth.STRESS_MIX))
+    got, st = gpu_fold(so, ev, prior, algo=S.ALGO_ROWS)
+    assert_same(got, oracle.fold_csr(so, ev, prior), so)
 
 
 def test_ragged_with_empty_segments_and_prior_snapshot():
@@ -72,6 +100,8 @@ def test_ragged_with_empty_segments_and_prior_snapshot():
     so, ev = synth.csr_log(lens, 8, synth.STRESS_MIX)
     prior = oracle.fold_csr(*synth.csr_log(rng.integers(0, 4, size=3000), 9, synth.STRESS_MIX))
     got, _ = gpu_fold(so, ev, prior)
+    assert_same(got, oracle.fold_csr(so, ev, prior), so)
+    got, _ = gpu_fold(so, ev, prior, algo=S.ALGO_SORTED)
     assert_same(got, oracle.fold_csr(so, ev, prior), so)
     # empties at both ends and in runs
     lens = np.concatenate([np.zeros(70, np.int64), rng.integers(1, 50, 500), np.zeros(200, np.int64),
