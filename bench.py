@@ -39,7 +39,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--aggregates", type=int, default=AGG_PER_GPU, help="aggregates per GPU (default = config C2)")
     ap.add_argument("--events-per-aggregate", type=int, default=EVENTS_PER_AGG)
-    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 fixed, 2 flat")
+    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 fixed, 2 flat, 3 rows, 4 sorted")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
+                    help="c2 (default, the config the metric is quoted on): fixed fan-in; c3: Zipf(1..4096) event counts")
+    ap.add_argument("--zipf-aggregates", type=int, default=10_000_000, help="aggregates per GPU for --workload c3")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-time budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -78,23 +81,35 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     A, L = args.aggregates, args.events_per_aggregate
+    zipf = args.workload == "c3"
+    if zipf:
+        A = args.zipf_aggregates
     eng = ReplayEngine(device=local_rank)
     compute = torch.cuda.Stream(device=dev)
     eng.use_stream(compute)
 
     # ---- build this rank's HBM-resident shard -----------------------------------------------------
     if world == 1:
-        agg_ids = None
-        seg_off, events = synth.fixed_log_device(A, L, SEED, dev)
+        agg_ids = torch.arange(A, dtype=torch.int64, device=dev) if zipf else None
         n_local = A
     else:
         from surge_amd.dist import SnapshotGather, local_aggregate_ids
 
         agg_ids = local_aggregate_ids(A * world, N_PARTITIONS, rank, world, dev, eng)
         n_local = int(agg_ids.numel())
+    if zipf:
+        # the rank's aggregates keep the event counts and contents they have in the global log
+        lens = synth.zipf_lengths(agg_ids, 3)
+        seg_off, events = synth.csr_log_device(lens, 3, agg_ids=agg_ids,
+                                               global_seg_off=_LazyGlobalOffsets(agg_ids, lens))
+        n_events_local = int(seg_off[-1].item())
+    elif world == 1:
+        seg_off, events = synth.fixed_log_device(A, L, SEED, dev)
+        n_events_local = n_local * L
+    else:
         seg_off, events = synth.fixed_log_for_aggregates_device(agg_ids, L, SEED)
+        n_events_local = n_local * L
     torch.cuda.synchronize(dev)
-    n_events_local = n_local * L
 
     if world == 1:
         bufs = [torch.zeros((n_local, 64), dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -189,10 +204,12 @@ def main():
             "data": "synthetic (counter-hash log, seed 2; surge_amd/synth.py)",
             "aggregates_per_sec": total_aggs * args.steps / elapsed_s,
             "config": {
-                "workload": f"C2 per GPU: {A} aggregates x {L} events, 16 B events, 64 B state, log resident in HBM",
+                "workload": (f"C3 per GPU: {A} aggregates, Zipf(1..4096) events each ({n_events_local} events on rank 0), CSR, "
+                             "16 B events, 64 B state, log resident in HBM") if zipf else
+                f"C2 per GPU: {A} aggregates x {L} events, 16 B events, 64 B state, log resident in HBM",
                 "aggregates_per_gpu": A,
-                "events_per_aggregate": L,
-                "algo": {S.ALGO_FIXED: "fixed", S.ALGO_FLAT: "flat", S.ALGO_ROWS: "rows"}.get(st.last_algo, str(st.last_algo)),
+                "events_per_aggregate": "zipf(1..4096), mean ~460" if zipf else L,
+                "algo": {S.ALGO_FIXED: "fixed", S.ALGO_FLAT: "flat", S.ALGO_ROWS: "rows", S.ALGO_SORTED: "sorted"}.get(st.last_algo, str(st.last_algo)),
                 "wave_tasks": st.n_tasks,
                 "sharding": "single shard" if world == 1 else
                 f"murmur3(acct-%08d) % {N_PARTITIONS} -> gpu = partition % {world}; RCCL all-gather of the snapshot overlapped on a side stream",
@@ -205,7 +222,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": None,
                 "kernel": {S.ALGO_FIXED: "fold_kernel<FIXED,16>", S.ALGO_FLAT: "fold_kernel<FLAT,16>",
-                           S.ALGO_ROWS: "fold_rows_kernel<8>"}.get(st.last_algo, "?"),
+                           S.ALGO_ROWS: "fold_rows_kernel<8>", S.ALGO_SORTED: "fold_sorted_kernel<16>"}.get(st.last_algo, "?"),
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes": st.algorithmic_bytes,
                 "timed_launches": st.timed_folds,
@@ -221,6 +238,18 @@ def main():
         print(json.dumps(result))
 
 
+class _LazyGlobalOffsets:
+    """``global_seg_off[agg]`` for the sharded Zipf log without materialising the global prefix sum:
+    only the event *hash index* needs to be unique per (aggregate, position), so aggregate a's events
+    are numbered from a * 4096 (4096 = the longest possible segment)."""
+
+    def __init__(self, agg_ids, lens):
+        pass
+
+    def __getitem__(self, agg):
+        return agg * 4096
+
+
 def run_cpu_baseline(args, seg_off, events, gpu_states, L):
     """CPU restatement (oracle/, kind "port") on a bounded sample of the SAME log, all host cores."""
     import numpy as np
@@ -229,11 +258,16 @@ def run_cpu_baseline(args, seg_off, events, gpu_states, L):
     from surge_amd import schema as S
     from surge_amd import synth
 
+    import torch
+
     cores = os.cpu_count() or 1
-    sample_aggs = min(int(seg_off.numel()) - 1, 250_000)
+    n_aggs = int(seg_off.numel()) - 1
+    # first aggregates of the log holding about 64 M events (250k aggregates of config C2)
+    sample_aggs = int(torch.searchsorted(seg_off, torch.tensor([64_000_000], device=seg_off.device))[0])
+    sample_aggs = max(1, min(sample_aggs, n_aggs))
     so = seg_off[: sample_aggs + 1].cpu().numpy()
-    ev = synth.to_event_records(events[: sample_aggs * L])
     n_ev = int(so[-1])
+    ev = synth.to_event_records(events[:n_ev])
     # parity of the GPU result on the sample, bit for bit
     exp = oracle.fold_csr(so, ev, threads=cores)
     got = gpu_states[:sample_aggs].cpu().numpy().view(S.STATE_DTYPE).reshape(-1)
@@ -256,7 +290,7 @@ def run_cpu_baseline(args, seg_off, events, gpu_states, L):
         "unit": "events/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"first {sample_aggs} aggregates x {L} events of the same log ({n_ev} events), "
+        "sample": f"first {sample_aggs} aggregates of the same log ({n_ev} events), "
                   f"C restatement of the fold, aggregates split over {cores} host threads",
         "single_thread_value": one_core,
         "gpu_matches_cpu_on_sample": parity,
