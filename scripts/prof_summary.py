@@ -24,7 +24,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         k = r.get("Kernel_Name", "")
         if "fold_" not in k and "stream_probe" not in k:
             continue
-        short = "fold_rows" if "fold_rows" in k else ("fold_kernel<FIXED>" if "ILi0" in k or "<0>" in k else ("fold_kernel<FLAT>" if "fold_kernel" in k else "stream_probe"))
+        short = "fold_sorted" if "fold_sorted" in k else "fold_rows" if "fold_rows" in k else ("fold_kernel<FIXED>" if "ILi0" in k or "<0>" in k else ("fold_kernel<FLAT>" if "fold_kernel" in k else "stream_probe"))
         acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in acc.items():
         for c, v in cs.items():
