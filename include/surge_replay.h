@@ -233,6 +233,11 @@ int32_t surge_replay_get(surge_replay_handle* h, int64_t agg_idx, void* state64_
  * publishes the host mirror used by surge_replay_get. */
 int32_t surge_replay_snapshot(surge_replay_handle* h, void* states_out, uint8_t* present_out);
 
+/* Bulk point read: states_out[i] = state[agg_idx[i]] for n host-side indices (device gather + one D2H).
+ * Serves the state-topic snapshot writer (SurgeModel.serializeState, SurgeModel.scala:57-65): after a
+ * micro-batch only the touched aggregates need new snapshot records. */
+int32_t surge_replay_gather(surge_replay_handle* h, const int64_t* agg_idx, int64_t n, void* states_out);
+
 /* Device pointer of the resident n_agg x 64 B state array (for the host layer's
  * RCCL all-gather of the final snapshot). */
 int32_t surge_replay_device_state(surge_replay_handle* h, void** d_states, int64_t* n_agg);

@@ -34,6 +34,7 @@ EXPORTS = (
     "surge_replay_append_fold",
     "surge_replay_append_fold_device",
     "surge_replay_get",
+    "surge_replay_gather",
     "surge_replay_snapshot",
     "surge_replay_device_state",
     "surge_replay_partition_hash",
@@ -128,6 +129,7 @@ def load() -> ctypes.CDLL:
         "surge_replay_append_fold": ([vp, vp, vp, i64, vp, i64], i32),
         "surge_replay_append_fold_device": ([vp, vp, vp, i64, vp, i64], i32),
         "surge_replay_get": ([vp, i64, vp, ctypes.POINTER(ctypes.c_uint8)], i32),
+        "surge_replay_gather": ([vp, vp, i64, vp], i32),
         "surge_replay_snapshot": ([vp, vp, vp], i32),
         "surge_replay_device_state": ([vp, ctypes.POINTER(vp), ctypes.POINTER(i64)], i32),
         "surge_replay_partition_hash": ([vp, vp, i64, i32, vp], i32),

@@ -75,7 +75,7 @@ struct surge_replay_handle {
   bool perm_valid = false;
 
   // per-fold scratch
-  DevBuf plan, batch_group_agg, batch_group_off, batch_events, poison_count;
+  DevBuf plan, batch_group_agg, batch_group_off, batch_events, poison_count, gather_idx, gather_out;
 
   hipEvent_t ev_total0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_total1 = nullptr, ev_h0 = nullptr,
              ev_h1 = nullptr;
@@ -337,7 +337,7 @@ int32_t surge_replay_destroy(surge_replay_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
                     &h->nz_map, &h->block_counts, &h->plan, &h->batch_group_agg, &h->batch_group_off,
-                    &h->batch_events, &h->poison_count};
+                    &h->batch_events, &h->poison_count, &h->gather_idx, &h->gather_out};
   for (DevBuf* b : bufs) b->release();
   hipEvent_t evs[] = {h->ev_total0, h->ev_total1, h->ev_h0, h->ev_h1};
   for (hipEvent_t ev : evs)
@@ -654,6 +654,24 @@ int32_t surge_replay_get(surge_replay_handle* h, int64_t agg_idx, void* state64_
     std::memcpy(&fl, (const uint8_t*)state64_out + 36, 4);
     *present_out = (uint8_t)(fl & SURGE_STATE_PRESENT);
   }
+  return SURGE_OK;
+}
+
+int32_t surge_replay_gather(surge_replay_handle* h, const int64_t* agg_idx, int64_t n, void* states_out) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->bound || h->st.n_folds == 0) return fail(h, SURGE_E_STATE, "gather before fold");
+  if (n < 0) return fail(h, SURGE_E_INVALID, "negative size");
+  if (n == 0) return SURGE_OK;
+  if (!agg_idx || !states_out) return fail(h, SURGE_E_INVALID, "NULL buffer");
+  for (int64_t i = 0; i < n; ++i)
+    if (agg_idx[i] < 0 || agg_idx[i] >= h->n_agg) return fail(h, SURGE_E_RANGE, "aggregate index out of range");
+  DeviceGuard g(h->device);
+  HIPCHK(h, h->gather_idx.reserve((size_t)n * 8));
+  HIPCHK(h, h->gather_out.reserve((size_t)n * 64));
+  HIPCHK(h, hipMemcpyAsync(h->gather_idx.ptr, agg_idx, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, launch_gather_states(h->d_state, (const int64_t*)h->gather_idx.ptr, n, (uint4*)h->gather_out.ptr, h->stream));
+  HIPCHK(h, hipMemcpyAsync(states_out, h->gather_out.ptr, (size_t)n * 64, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return SURGE_OK;
 }
 

@@ -965,6 +965,13 @@ __global__ void __launch_bounds__(kWave) stream_probe_lds_kernel(const uint4* __
   if (acc == 0x9e3779b9u) sink[0] = acc;
 }
 
+__global__ void gather_states_kernel(const uint4* __restrict__ states, const int64_t* __restrict__ idx, int64_t n,
+                                     uint4* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16 B quarter of a state per thread
+  if (i >= n * 4) return;
+  out[i] = states[idx[i >> 2] * 4 + (i & 3)];
+}
+
 __global__ void count_poisoned_kernel(const uint4* __restrict__ states, int64_t n, unsigned long long* count) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool p = s < n && (states[s * 4 + 2].y & FL_POISONED);
@@ -1083,6 +1090,12 @@ hipError_t launch_stream_probe(const uint4* src, int64_t n_vec, uint32_t* sink, 
     hipLaunchKernelGGL(stream_probe_kernel<true>, dim3(256 * 8), dim3(256), 0, stream, src, n_vec, sink);
   else
     hipLaunchKernelGGL(stream_probe_kernel<false>, dim3(256 * 8), dim3(256), 0, stream, src, n_vec, sink);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_states(const uint4* states, const int64_t* idx, int64_t n, uint4* out, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_states_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, stream, states, idx, n, out);
   return hipGetLastError();
 }
 

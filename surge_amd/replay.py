@@ -197,6 +197,13 @@ class ReplayEngine:
         self._check(self._lib.surge_replay_get(self._h, int(agg_idx), _np_ptr(out), None))
         return out[0]
 
+    def gather(self, agg_idx) -> np.ndarray:
+        """Fixed-width states of the listed aggregates (bulk point read)."""
+        idx = np.ascontiguousarray(agg_idx, dtype=np.int64)
+        out = np.zeros(idx.shape[0], dtype=STATE_DTYPE)
+        self._check(self._lib.surge_replay_gather(self._h, _np_ptr(idx), idx.shape[0], _np_ptr(out)))
+        return out
+
     def device_state(self):
         """The resident ``n_agg x 64`` byte state array as a ``torch.uint8`` view (no copy)."""
         import torch

@@ -149,3 +149,54 @@ def test_bank_account_recovery_with_prior_snapshot():
         assert json.loads(store.get_aggregate_bytes(str(c)))["balance"] == 7.5
     finally:
         store.close()
+
+
+@pytest.mark.gpu
+def test_incremental_snapshot_records_compact_to_the_full_refold():
+    """Config C5 in miniature: micro-batches -> incremental state-topic records -> log compaction ==
+    the KTable a full JVM-style re-fold would produce."""
+    import random
+
+    from surge_amd.snapshot import SnapshotWriter, compact
+    from surge_amd.store import GpuReplayStateStore
+
+    bl = CounterBusinessLogic()
+    model = bl.command_model()
+    rng = random.Random(4)
+    ids = [f"agg-{i}" for i in range(200)]
+    seqs = {k: 0 for k in ids}
+
+    def batch(n):
+        out = []
+        for _ in range(n):
+            k = rng.choice(ids)
+            seqs[k] += 1
+            out.append(CountIncremented(k, rng.randrange(-5, 50), seqs[k]) if rng.random() < 0.7 else CountDecremented(k, 3, seqs[k]))
+        return out
+
+    all_events, log = [], []
+    store = GpuReplayStateStore(bl)
+    try:
+        first = batch(500)
+        all_events += first
+        store.restore(first, capacity=256)
+        writer = SnapshotWriter(store, n_partitions=5)
+        log += writer.full_snapshot()
+        for _ in range(6):
+            b = batch(300)
+            all_events += b
+            store.apply_events(b)
+            log += writer.records_for(sorted({e.aggregateId for e in b}))  # only the touched aggregates
+        table = compact(log)
+        expect = {}
+        for e in all_events:
+            expect[e.aggregateId] = model.handle_event(expect.get(e.aggregateId), e)
+        assert set(table) == set(expect)
+        for k, st in expect.items():
+            assert table[k] == bl.aggregate_write_formatting().write_state(st).value
+        parts = {r.key: r.partition for r in log}
+        from surge_amd.kafka import PartitionStringUpToColon
+
+        assert all(p == PartitionStringUpToColon.instance.partition_for_key(k, 5) for k, p in parts.items())
+    finally:
+        store.close()
