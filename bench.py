@@ -168,6 +168,7 @@ def main():
 
     st = eng.stats()
     kernel_ms = st.sum_fold_kernel_ms / max(st.timed_folds, 1)
+    traffic, traffic_src = pmc_traffic(args, st.last_algo)
     achieved = st.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
     # ---- extras on rank 0 ---------------------------------------------------------------------------
@@ -220,7 +221,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": {S.ALGO_FIXED: "fold_kernel<FIXED,16>", S.ALGO_FLAT: "fold_kernel<FLAT,16>",
                            S.ALGO_ROWS: "fold_rows_kernel<8>", S.ALGO_SORTED: "fold_sorted_kernel<16>"}.get(st.last_algo, "?"),
                 "kernel_ms": kernel_ms,
@@ -236,6 +238,29 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def pmc_traffic(args, algo):
+    """HBM bytes per launch from the rocprofv3 PMC passes of THIS command (separate --pmc runs for
+    FETCH_SIZE and WRITE_SIZE, gfx950 correction x2 on FETCH_SIZE, KB -> bytes), as committed under
+    profiles/ by scripts/prof.sh.  bench.py cannot collect PMC counters itself; null when there is no
+    profile for the workload/kernel being run."""
+    if args.workload != "c2" or args.aggregates != AGG_PER_GPU or args.events_per_aggregate != EVENTS_PER_AGG:
+        return None, None
+    path = os.path.join(ROOT, "profiles", "r01_final_c2_rows_summary.txt")
+    want = {3: "fold_rows"}.get(algo)
+    if want is None or not os.path.exists(path):
+        return None, None
+    fetch = write = None
+    for line in open(path):
+        parts = line.split()
+        if len(parts) >= 5 and parts[1] == want and parts[2] == "FETCH_SIZE":
+            fetch = float(parts[-1].split("=")[1])
+        if len(parts) >= 5 and parts[1] == want and parts[2] == "WRITE_SIZE":
+            write = float(parts[-1].split("=")[1])
+    if fetch is None or write is None:
+        return None, None
+    return fetch * 1024 * 2 + write * 1024, "profiles/r01_final_c2_rows_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
 
 
 class _LazyGlobalOffsets:
@@ -285,6 +310,24 @@ def run_cpu_baseline(args, seg_off, events, gpu_states, L):
 
     all_cores = timed(cores, args.cpu_seconds)
     one_core = timed(1, min(args.cpu_seconds / 4, 4.0))
+
+    # PCIe-inclusive rate (NOT `value`): the same sample handed over as host buffers through
+    # surge_replay_load_csr (pageable memory, like a JNI direct buffer), then folded.
+    from surge_amd.replay import ReplayEngine
+
+    pcie = None
+    try:
+        with ReplayEngine(device=gpu_states.device.index or 0) as e2:
+            e2.load_csr(so, ev)  # warm-up (allocations)
+            t0 = time.perf_counter()
+            e2.load_csr(so, ev)
+            e2.fold()
+            e2.synchronize()
+            dt = time.perf_counter() - t0
+            pcie = {"events_per_sec": n_ev / dt, "h2d_ms": e2.stats().h2d_ms, "sample_events": n_ev,
+                    "GBps": (ev.nbytes + so.nbytes) / dt / 1e9}
+    except Exception as exc:  # pragma: no cover
+        pcie = {"error": str(exc)}
     return {
         "value": all_cores,
         "unit": "events/s",
@@ -294,6 +337,7 @@ def run_cpu_baseline(args, seg_off, events, gpu_states, L):
                   f"C restatement of the fold, aggregates split over {cores} host threads",
         "single_thread_value": one_core,
         "gpu_matches_cpu_on_sample": parity,
+        "pcie_inclusive_gpu": pcie,
     }
 
 

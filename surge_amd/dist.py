@@ -66,6 +66,7 @@ def partitions_of_ids(ids, n_partitions: int, engine=None):
             raise ValueError("device ids need a ReplayEngine to launch the hash kernel on")
         utf16, off = id_table_utf16(ids)
         out = torch.empty(ids.numel(), dtype=torch.int32, device=ids.device)
+        torch.cuda.current_stream(ids.device).synchronize()  # the id table was built on torch's stream, the kernel runs on the engine's
         engine.partition_hash_device(utf16, off, n_partitions, out)
         engine.synchronize()
         return out
