@@ -64,14 +64,14 @@ def main():
         words = synth.event_words(np.arange(B, dtype=np.int64) + b * B, agg_idx, np.arange(B, dtype=np.int64), 11, synth.C2_MIX)
         events = synth.to_event_records(words)
         t0 = time.perf_counter()
-        group_agg, group_off, sorted_ev = batch_groups(agg_idx, events)   # host: group by aggregate, order-preserving
-        eng.append_fold(group_agg, group_off, sorted_ev)                   # H2D + K3
+        eng.append_events(agg_idx, events)   # library: stable radix group-by (host) + H2D + K3
         eng.synchronize()
         t1 = time.perf_counter()
         lat.append((t1 - t0) * 1e3)
         kern.append(eng.stats().last_fold_kernel_ms)
-        dirty.append(group_agg)
+        dirty.append(agg_idx)
         if oracle_state is not None:
+            group_agg, group_off, sorted_ev = batch_groups(agg_idx, events)
             full_off = np.zeros(A + 1, np.int64)
             np.cumsum(np.bincount(agg_idx, minlength=A), out=full_off[1:])
             oracle_state = oracle.fold_csr(full_off, sorted_ev, oracle_state)

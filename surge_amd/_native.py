@@ -32,6 +32,7 @@ EXPORTS = (
     "surge_replay_bind_device_csr",
     "surge_replay_fold",
     "surge_replay_append_fold",
+    "surge_replay_append_events",
     "surge_replay_append_fold_device",
     "surge_replay_get",
     "surge_replay_gather",
@@ -128,6 +129,7 @@ def load() -> ctypes.CDLL:
         "surge_replay_fold": ([vp, i32], i32),
         "surge_replay_append_fold": ([vp, vp, vp, i64, vp, i64], i32),
         "surge_replay_append_fold_device": ([vp, vp, vp, i64, vp, i64], i32),
+        "surge_replay_append_events": ([vp, vp, vp, i64], i32),
         "surge_replay_get": ([vp, i64, vp, ctypes.POINTER(ctypes.c_uint8)], i32),
         "surge_replay_gather": ([vp, vp, i64, vp], i32),
         "surge_replay_snapshot": ([vp, vp, vp], i32),

@@ -1,6 +1,7 @@
 // engine.hip — host side of libsurge_replay.so: handle, device memory, launch sequencing and
 // the extern "C" boundary declared in include/surge_replay.h.  No torch types, no CPU fold:
 // if HIP is unusable every entry point reports SURGE_E_DEVICE.
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -84,6 +85,11 @@ struct surge_replay_handle {
   // one HIP-event pair per fold since the last stats_reset (kernel time of the dominant kernel)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> fold_events;
   size_t folds_since_reset = 0;
+
+  // host scratch of append_events (stable group-by)
+  std::vector<uint32_t> sort_a, sort_b;
+  std::vector<int64_t> h_group_agg, h_group_off;
+  std::vector<uint4> h_sorted_events;
 
   // host mirror for point reads (S2)
   std::mutex mu;
@@ -604,6 +610,55 @@ int32_t surge_replay_append_fold(surge_replay_handle* h, const int64_t* group_ag
   h->h2d_valid = true;
   return surge_replay_append_fold_device(h, (const int64_t*)h->batch_group_agg.ptr, (const int64_t*)h->batch_group_off.ptr,
                                          n_groups, h->batch_events.ptr, n_events);
+}
+
+int32_t surge_replay_append_events(surge_replay_handle* h, const int64_t* agg_idx, const void* events, int64_t n_events) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->bound) return fail(h, SURGE_E_STATE, "append_events before load_csr/bind_device_csr");
+  if (n_events < 0) return fail(h, SURGE_E_INVALID, "negative size");
+  if (n_events == 0) return SURGE_OK;
+  if (!agg_idx || !events) return fail(h, SURGE_E_INVALID, "NULL batch buffer");
+  if (n_events > 0xffffffffll) return fail(h, SURGE_E_UNSUPPORTED, "micro-batches are limited to 2^32 - 1 events");
+  const uint32_t n = (uint32_t)n_events;
+  for (uint32_t i = 0; i < n; ++i)
+    if (agg_idx[i] < 0 || agg_idx[i] >= h->n_agg) return fail(h, SURGE_E_RANGE, "agg_idx out of range");
+  try {
+    // stable LSD radix sort of the event positions by aggregate index, 16 bits per pass
+    h->sort_a.resize(n);
+    h->sort_b.resize(n);
+    for (uint32_t i = 0; i < n; ++i) h->sort_a[i] = i;
+    int bits = 1;
+    while (bits < 63 && (h->n_agg >> bits) != 0) ++bits;
+    std::vector<uint32_t> count(65536 + 1);
+    uint32_t* src = h->sort_a.data();
+    uint32_t* dst = h->sort_b.data();
+    for (int shift = 0; shift < bits; shift += 16) {
+      std::fill(count.begin(), count.end(), 0u);
+      for (uint32_t i = 0; i < n; ++i) ++count[((uint64_t)agg_idx[src[i]] >> shift & 0xffff) + 1];
+      for (int b = 0; b < 65536; ++b) count[b + 1] += count[b];
+      for (uint32_t i = 0; i < n; ++i) dst[count[(uint64_t)agg_idx[src[i]] >> shift & 0xffff]++] = src[i];
+      std::swap(src, dst);
+    }
+    const uint4* ev = (const uint4*)events;
+    h->h_sorted_events.resize(n);
+    h->h_group_agg.clear();
+    h->h_group_off.clear();
+    int64_t prev = -1;
+    for (uint32_t i = 0; i < n; ++i) {
+      const int64_t a = agg_idx[src[i]];
+      if (a != prev) {
+        h->h_group_agg.push_back(a);
+        h->h_group_off.push_back((int64_t)i);
+        prev = a;
+      }
+      std::memcpy(&h->h_sorted_events[i], &ev[src[i]], 16);
+    }
+    h->h_group_off.push_back((int64_t)n);
+  } catch (const std::bad_alloc&) {
+    return fail(h, SURGE_E_NOMEM, "out of host memory while grouping the micro-batch");
+  }
+  return surge_replay_append_fold(h, h->h_group_agg.data(), h->h_group_off.data(), (int64_t)h->h_group_agg.size(),
+                                  h->h_sorted_events.data(), n_events);
 }
 
 int32_t surge_replay_snapshot(surge_replay_handle* h, void* states_out, uint8_t* present_out) {

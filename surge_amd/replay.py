@@ -179,6 +179,14 @@ class ReplayEngine:
                 )
             )
 
+    def append_events(self, agg_idx, events) -> None:
+        """Micro-batch in topic order, event i tagged with ``agg_idx[i]``; grouping happens in the library."""
+        agg_idx = np.ascontiguousarray(agg_idx, dtype=np.int64)
+        events = np.ascontiguousarray(events, dtype=EVENT_DTYPE)
+        if agg_idx.shape[0] != events.shape[0]:
+            raise ValueError("one aggregate index per event")
+        self._check(self._lib.surge_replay_append_events(self._h, _np_ptr(agg_idx), _np_ptr(events), events.shape[0]))
+
     # -- read --------------------------------------------------------------------------------------
     def snapshot(self) -> np.ndarray:
         out = np.zeros(self.n_agg, dtype=STATE_DTYPE)

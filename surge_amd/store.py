@@ -75,8 +75,14 @@ class GpuReplayStateStore:
         """Streaming micro-batch (config C5): fold new events onto the resident state."""
         if not self._restored:
             raise RuntimeError("restore() first")
-        group_agg, group_off, ev = pack_batch(self.model, events_in_offset_order, self.keys, self.engine.n_agg)
-        self.engine.append_fold(group_agg, group_off, ev)
+        enc = self.model.encode_events(events_in_offset_order)
+        agg_idx = np.empty(len(events_in_offset_order), dtype=np.int64)
+        for i, e in enumerate(events_in_offset_order):
+            k = self.keys.intern(self.model.aggregate_id_of(e))
+            if k >= self.engine.n_agg:
+                raise IndexError(f"aggregate {self.model.aggregate_id_of(e)!r} exceeds the store capacity {self.engine.n_agg}")
+            agg_idx[i] = k
+        self.engine.append_events(agg_idx, enc)  # stable group-by + K3 inside the library
         self.engine.snapshot()
 
     # -- S2 ---------------------------------------------------------------------------------

@@ -213,7 +213,10 @@ def test_micro_batch_append_fold_matches_full_refold():
             from surge_amd.log import batch_groups
 
             group_agg, group_off, sorted_ev = batch_groups(agg_idx, be)
-            eng.append_fold(group_agg, group_off, sorted_ev)
+            if batch % 2 == 0:
+                eng.append_fold(group_agg, group_off, sorted_ev)  # caller groups
+            else:
+                eng.append_events(agg_idx, be)  # library groups (stable radix sort), same result
             # oracle: fold each group onto the previous state
             full_off = np.zeros(n_agg + 1, np.int64)
             np.cumsum(np.bincount(agg_idx, minlength=n_agg), out=full_off[1:])
