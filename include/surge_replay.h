@@ -143,7 +143,7 @@ typedef struct surge_replay_schema {
 
 /* ---- fold algorithms -------------------------------------------------------- */
 #define SURGE_ALGO_AUTO  0 /* uniform segment length L (L % 16 == 0): ROWS when there are enough aggregates
-                              to fill the chip, else FIXED; otherwise FLAT                             */
+                              to fill the chip, else FIXED; otherwise SORTED for large logs, else FLAT */
 #define SURGE_ALGO_FIXED 1 /* K1b: flat fold with segment heads computed arithmetically (uniform L)   */
 #define SURGE_ALGO_FLAT  2 /* K2: load-balanced flat segmented scan over the CSR                      */
 #define SURGE_ALGO_ROWS  3 /* K1: uniform L, one lane per aggregate, no cross-lane scan               */

@@ -183,7 +183,7 @@ int env_lane_events(const char* name, int dflt) {
   const char* v = std::getenv(name);
   if (!v) return dflt;
   const int x = std::atoi(v);
-  return (x == 8 || x == 16) ? x : dflt;
+  return (x == 8 || x == 16 || x == 32) ? x : dflt;
 }
 
 int32_t validate_schema(const surge_replay_schema* s) {
@@ -450,9 +450,13 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
   const bool rows_auto = rows_ok && h->n_agg / kWave >= 2048;
   const bool sorted_ok = h->an.max_len < (1ll << 31);
   if (algo == SURGE_ALGO_SORTED && !sorted_ok) return fail(h, SURGE_E_UNSUPPORTED, "ALGO_SORTED needs segments shorter than 2^31 events");
-  // Measured on MI355X (Zipf 1..4096, 2 M aggregates): FLAT 4.48 TB/s, SORTED 4.28 TB/s (256 B pieces) —
-  // the linear stream wins, so AUTO never picks SORTED; it stays selectable for experiments.
-  const int32_t use = (algo == SURGE_ALGO_AUTO) ? (uniform ? (rows_auto ? SURGE_ALGO_ROWS : SURGE_ALGO_FIXED) : SURGE_ALGO_FLAT) : algo;
+  // Measured on MI355X (C3: 10 M aggregates, Zipf 1..4096): FLAT 16.2 ms (4.6 TB/s); SORTED with 128 / 256 /
+  // 512 B row pieces 3.4 / 4.4 / 5.0 TB/s -> 14.8 ms with 512 B pieces.  SORTED needs enough groups of 64
+  // segments to keep its persistent waves busy; smaller logs stay on the linear-stream FLAT kernel.
+  const bool sorted_auto = sorted_ok && h->n_nz / kWave >= 4 * (int64_t)h->n_cus * 4;
+  const int32_t use = (algo == SURGE_ALGO_AUTO)
+                          ? (uniform ? (rows_auto ? SURGE_ALGO_ROWS : SURGE_ALGO_FIXED) : (sorted_auto ? SURGE_ALGO_SORTED : SURGE_ALGO_FLAT))
+                          : algo;
 
   FoldParams p;
   fill_params(h, p);
@@ -472,7 +476,7 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       // re-dispatch, every wave streams from start to end): G groups of 64 aggregates per wave so that
       // the grid just fits the chip's wave slots (CUs x 16 waves at 8 KiB tiles, x 9 at 16 KiB tiles).
       const int64_t groups = (h->n_agg + kWave - 1) / kWave;
-      const int64_t slots = (int64_t)h->n_cus * (le == 8 ? 16 : 9);
+      const int64_t slots = (int64_t)h->n_cus * (le == 8 ? 16 : (le == 16 ? 9 : 4));
       int64_t G = (groups + slots - 1) / slots;
       if (const char* v = std::getenv("SURGE_REPLAY_ROWS_GROUPS")) G = std::atoi(v);
       if (G < 1) G = 1;
@@ -506,7 +510,7 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       HIPCHK(h, hipEventRecord(e1, h->stream));
       h->st.n_tasks = (int32_t)n_tasks;
     } else if (use == SURGE_ALGO_SORTED) {
-      const int le = env_lane_events("SURGE_REPLAY_LE_SORTED", 16);
+      const int le = env_lane_events("SURGE_REPLAY_LE_SORTED", 32);
       const int64_t* off = h->an.n_empty > 0 ? (const int64_t*)h->nz_off.ptr : h->d_seg_off;
       const int64_t n_seg = h->an.n_empty > 0 ? h->n_nz : h->n_agg;
       if (!h->perm_valid) {  // once per bound log (part of its index, like the empty-segment compaction)
@@ -522,7 +526,7 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       p.counter = (unsigned long long*)h->counter.ptr;
       p.n_seg = n_seg;
       const int64_t groups = (n_seg + kWave - 1) / kWave;
-      const int64_t slots = (int64_t)h->n_cus * (le == 8 ? 16 : 9);
+      const int64_t slots = (int64_t)h->n_cus * (le == 8 ? 16 : (le == 16 ? 9 : 4));
       const int64_t n_waves = groups < slots ? groups : slots;
       hipEvent_t e0, e1;
       const int32_t rc = next_fold_events(h, &e0, &e1);

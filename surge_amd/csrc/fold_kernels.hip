@@ -231,10 +231,10 @@ struct Geo {
   static constexpr int kLoads = kTileBytes / 1024;
   static constexpr int kRowsPerLoad = kWave / LE;
   static constexpr int kHeadWords = kTile / 32;
-  static constexpr int kClasses = LE == 16 ? 4 : 2;
+  static constexpr int kClasses = LE == 32 ? 8 : (LE == 16 ? 4 : 2);
   static constexpr int kLdsBytes = kTileBytes + kHeadWords * 4 + kTableEntries * kTableStride * 4;
-  static constexpr uint32_t kLaneMask = (1u << LE) - 1u;
-  __device__ static __forceinline__ uint32_t key(int l) { return LE == 16 ? (uint32_t)(l & 15) : (uint32_t)((l >> 1) & 7); }
+  static constexpr uint32_t kLaneMask = LE >= 32 ? 0xffffffffu : ((1u << (LE & 31)) - 1u);
+  __device__ static __forceinline__ uint32_t key(int l) { return LE >= 16 ? (uint32_t)(l & 15) : (uint32_t)((l >> 1) & 7); }
   // my pre-swizzled LDS row: event j lives at (row ^ (j * 16))
   __device__ static __forceinline__ uint32_t ev_row(int lane) { return (uint32_t)lane * kRowBytes + key(lane) * 16u; }
   // event index j that load-lane m of an instruction of class k fetches, and its chunk-lane within the instruction
@@ -994,6 +994,8 @@ hipError_t launch_fold_rows(const FoldParams& p, int64_t n_tasks, int lane_event
   if (n_tasks <= 0) return hipSuccess;
   if (lane_events == 8)
     hipLaunchKernelGGL((fold_rows_kernel<8>), dim3((unsigned)n_tasks), dim3(kWave), Geo<8>::kLdsBytes, stream, p);
+  else if (lane_events == 32)
+    hipLaunchKernelGGL((fold_rows_kernel<32>), dim3((unsigned)n_tasks), dim3(kWave), Geo<32>::kLdsBytes, stream, p);
   else
     hipLaunchKernelGGL((fold_rows_kernel<16>), dim3((unsigned)n_tasks), dim3(kWave), Geo<16>::kLdsBytes, stream, p);
   return hipGetLastError();
@@ -1005,6 +1007,8 @@ hipError_t launch_fold_sorted(const FoldParams& p, int64_t n_waves, int lane_eve
   if (e != hipSuccess) return e;
   if (lane_events == 8)
     hipLaunchKernelGGL((fold_sorted_kernel<8>), dim3((unsigned)n_waves), dim3(kWave), Geo<8>::kLdsBytes, stream, p);
+  else if (lane_events == 32)
+    hipLaunchKernelGGL((fold_sorted_kernel<32>), dim3((unsigned)n_waves), dim3(kWave), Geo<32>::kLdsBytes, stream, p);
   else
     hipLaunchKernelGGL((fold_sorted_kernel<16>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::kLdsBytes, stream, p);
   return hipGetLastError();
