@@ -231,8 +231,9 @@ struct Geo {
   static constexpr int kLoads = kTileBytes / 1024;
   static constexpr int kRowsPerLoad = kWave / LE;
   static constexpr int kHeadWords = kTile / 32;
+  static constexpr int kAuxBytes = kHeadWords * 4 < 256 ? 256 : kHeadWords * 4;  // head bitmask (flat) / 64 row lengths (sorted)
   static constexpr int kClasses = LE == 32 ? 8 : (LE == 16 ? 4 : 2);
-  static constexpr int kLdsBytes = kTileBytes + kHeadWords * 4 + kTableEntries * kTableStride * 4;
+  static constexpr int kLdsBytes = kTileBytes + kAuxBytes + kTableEntries * kTableStride * 4;
   static constexpr uint32_t kLaneMask = LE >= 32 ? 0xffffffffu : ((1u << (LE & 31)) - 1u);
   __device__ static __forceinline__ uint32_t key(int l) { return LE >= 16 ? (uint32_t)(l & 15) : (uint32_t)((l >> 1) & 7); }
   // my pre-swizzled LDS row: event j lives at (row ^ (j * 16))
@@ -309,7 +310,7 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_ev = smem;
   uint32_t* lds_hb = (uint32_t*)(smem + G::kTileBytes);
-  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kHeadWords * 4);
+  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kAuxBytes);
 
   const int lane = threadIdx.x;
   const int64_t task = blockIdx.x;
@@ -547,7 +548,7 @@ __global__ void __launch_bounds__(kWave) fold_rows_kernel(const FoldParams p) {
   using G = Geo<LE>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_ev = smem;
-  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kHeadWords * 4);
+  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kAuxBytes);
 
   const int lane = threadIdx.x;
   const int64_t S0 = (int64_t)blockIdx.x * p.segs_per_task;
@@ -631,7 +632,9 @@ __global__ void __launch_bounds__(kWave) fold_sorted_kernel(const FoldParams p) 
   using G = Geo<LE>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_ev = smem;
-  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kHeadWords * 4);
+  uint32_t* lds_len = (uint32_t*)(smem + G::kTileBytes);  // 64 row lengths, in the aux area
+  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kAuxBytes);
+  static_assert(G::kAuxBytes >= kWave * 4, "aux area holds one length per lane");
   const int lane = threadIdx.x;
   load_table<LE>(p, lds_tab, lane);
   const uint32_t ev_row = G::ev_row(lane);
@@ -669,15 +672,12 @@ __global__ void __launch_bounds__(kWave) fold_sorted_kernel(const FoldParams p) 
     }
     const int n_tiles = (int)((maxlen + LE - 1) / LE);
 
-    // the rows each load instruction serves: start and length of row RPL*q + lane/LE
+    // the rows each load instruction serves: start of row RPL*q + lane/LE in registers, lengths (only needed
+    // by the clamped slow path) in a 256 B LDS table to keep the register budget for resident waves
     int64_t rs[G::kLoads];
-    uint32_t rlen[G::kLoads];
 #pragma unroll
-    for (int q = 0; q < G::kLoads; ++q) {
-      const int r = G::kRowsPerLoad * q + lane / LE;
-      rs[q] = __shfl(cur.start, r, 64);
-      rlen[q] = (uint32_t)__shfl((int)cur.len, r, 64);
-    }
+    for (int q = 0; q < G::kLoads; ++q) rs[q] = __shfl(cur.start, G::kRowsPerLoad * q + lane / LE, 64);
+    lds_len[lane] = cur.len;
     auto issue = [&](int c) {
       if ((uint32_t)(c + 1) * LE <= minlen) {
 #pragma unroll
@@ -688,8 +688,9 @@ __global__ void __launch_bounds__(kWave) fold_sorted_kernel(const FoldParams p) 
       } else {  // some row ends inside this tile: never read past a row's own events
 #pragma unroll
         for (int q = 0; q < G::kLoads; ++q) {
+          const uint32_t rlen = lds_len[G::kRowsPerLoad * q + lane / LE];
           uint32_t j = (uint32_t)c * LE + G::load_j(lane, q % G::kClasses);
-          const uint32_t lastj = rlen[q] ? rlen[q] - 1u : 0u;
+          const uint32_t lastj = rlen ? rlen - 1u : 0u;
           j = j < lastj ? j : lastj;
           __builtin_amdgcn_global_load_lds((gptr_t)(p.events + (rs[q] + j)), (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
         }
