@@ -248,6 +248,34 @@ int32_t surge_replay_gather(surge_replay_handle* h, const int64_t* agg_idx, int6
  * RCCL all-gather of the final snapshot). */
 int32_t surge_replay_device_state(surge_replay_handle* h, void** d_states, int64_t* n_agg);
 
+/* ---- serialized state -------------------------------------------------------------
+ * GPU-side encoder from the fixed 64-byte state to the plugin's serialized form, for bulk snapshot
+ * publishing (10 M aggregates are ~1 GB of JSON).  The shape is declared as a small template, e.g. the
+ * Counter fixture's play-json text  {"aggregateId":"<id>","count":N,"version":N}
+ * (TestBoundedContext.scala:15-16,127-129) = LITERAL KEY LITERAL I32@0 LITERAL I32@4 LITERAL.
+ * KEY is the aggregate id as a JSON string with Jackson's default escaping.  Absent (None) and poisoned
+ * aggregates get zero bytes (out_off[a+1] == out_off[a]): the caller writes a tombstone / nothing.
+ * Doubles are not supported (play-json's number text is parity-unpinned). */
+#define SURGE_JP_LITERAL 0u /* bytes literals[lit_off .. lit_off + lit_len)          */
+#define SURGE_JP_KEY     1u /* "<aggregate id>" escaped                               */
+#define SURGE_JP_I32     2u /* decimal int32 at state byte offset field_offset        */
+#define SURGE_JP_U32     3u
+#define SURGE_JP_I64     4u
+#define SURGE_JSON_MAX_PARTS 16
+typedef struct surge_json_template {
+  uint32_t n_parts;
+  struct { uint32_t kind, field_offset, lit_off, lit_len; } part[SURGE_JSON_MAX_PARTS];
+  uint8_t literals[256];
+} surge_json_template;
+
+/* d_keys_utf8 / d_key_off (n_agg + 1 entries): the key table on the device.  Two passes: lengths ->
+ * exclusive scan into d_out_off (n_agg + 1) -> bytes into d_out.  *total_bytes_out (host) receives the
+ * total; when it exceeds out_capacity nothing is written and SURGE_E_RANGE is returned (call again with
+ * a larger buffer). */
+int32_t surge_replay_encode_json(surge_replay_handle* h, const surge_json_template* tmpl, const uint8_t* d_keys_utf8,
+                                 const int64_t* d_key_off, uint8_t* d_out, int64_t out_capacity, int64_t* d_out_off,
+                                 int64_t* total_bytes_out);
+
 /* ---- shard map (R15) --------------------------------------------------------------
  * part_out[i] = abs(MurmurHash3.stringHash(str_i.takeWhile(_ != ':')) % n_partitions)
  * (KafkaPartitioner.scala:8,38-42) for n strings given as UTF-16 code units

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""N3: bulk GPU encoding of the resident snapshot into play-json text (Counter template)."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from surge_amd import synth
+from surge_amd.encode import JsonTemplate, encode_states
+from surge_amd.dist import ID_PREFIX, ID_DIGITS
+from surge_amd.replay import ReplayEngine
+
+A = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+dev = torch.device("cuda:0")
+so, ev = synth.fixed_log_device(A, 16, 5, dev)
+eng = ReplayEngine(); eng.load_csr(so, ev); eng.fold(); eng.synchronize()
+# key table "acct-%08d" as UTF-8 on the device
+ids = torch.arange(A, dtype=torch.int64, device=dev)
+w = len(ID_PREFIX) + ID_DIGITS
+keys = torch.empty((A, w), dtype=torch.uint8, device=dev)
+for k, ch in enumerate(ID_PREFIX): keys[:, k] = ord(ch)
+for k in range(ID_DIGITS): keys[:, len(ID_PREFIX) + k] = ((ids // 10 ** (ID_DIGITS - 1 - k)) % 10 + 48).to(torch.uint8)
+key_off = torch.arange(A + 1, dtype=torch.int64, device=dev) * w
+torch.cuda.synchronize()
+out, off = encode_states(eng, JsonTemplate.counter(), keys.reshape(-1), key_off)  # warm-up + sizing
+best = 1e9
+for _ in range(3):
+    t0 = time.perf_counter(); out, off = encode_states(eng, JsonTemplate.counter(), keys.reshape(-1), key_off, capacity_hint=out.numel()); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+sample = bytes(out[: int(off[2])].cpu().numpy())
+print(json.dumps({"aggregates": A, "json_bytes": int(out.numel()), "encode_ms": best * 1e3, "GBps_out": out.numel() / best / 1e9,
+                  "aggregates_per_sec": A / best, "first_two": sample.decode()}))

@@ -38,6 +38,7 @@ EXPORTS = (
     "surge_replay_gather",
     "surge_replay_snapshot",
     "surge_replay_device_state",
+    "surge_replay_encode_json",
     "surge_replay_partition_hash",
     "surge_replay_partition_hash_device",
     "surge_replay_set_state_out",
@@ -134,6 +135,7 @@ def load() -> ctypes.CDLL:
         "surge_replay_gather": ([vp, vp, i64, vp], i32),
         "surge_replay_snapshot": ([vp, vp, vp], i32),
         "surge_replay_device_state": ([vp, ctypes.POINTER(vp), ctypes.POINTER(i64)], i32),
+        "surge_replay_encode_json": ([vp, vp, vp, vp, vp, i64, vp, ctypes.POINTER(i64)], i32),
         "surge_replay_partition_hash": ([vp, vp, i64, i32, vp], i32),
         "surge_replay_partition_hash_device": ([vp, vp, vp, i64, i32, vp], i32),
         "surge_replay_set_state_out": ([vp, vp], i32),

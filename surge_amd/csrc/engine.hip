@@ -76,7 +76,7 @@ struct surge_replay_handle {
   bool perm_valid = false;
 
   // per-fold scratch
-  DevBuf plan, batch_group_agg, batch_group_off, batch_events, poison_count, gather_idx, gather_out;
+  DevBuf plan, batch_group_agg, batch_group_off, batch_events, poison_count, gather_idx, gather_out, scan_totals;
 
   hipEvent_t ev_total0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_total1 = nullptr, ev_h0 = nullptr,
              ev_h1 = nullptr;
@@ -343,7 +343,7 @@ int32_t surge_replay_destroy(surge_replay_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
                     &h->nz_map, &h->block_counts, &h->plan, &h->batch_group_agg, &h->batch_group_off,
-                    &h->batch_events, &h->poison_count, &h->gather_idx, &h->gather_out};
+                    &h->batch_events, &h->poison_count, &h->gather_idx, &h->gather_out, &h->scan_totals};
   for (DevBuf* b : bufs) b->release();
   hipEvent_t evs[] = {h->ev_total0, h->ev_total1, h->ev_h0, h->ev_h1};
   for (hipEvent_t ev : evs)
@@ -730,6 +730,42 @@ int32_t surge_replay_gather(surge_replay_handle* h, const int64_t* agg_idx, int6
   HIPCHK(h, hipMemcpyAsync(h->gather_idx.ptr, agg_idx, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, launch_gather_states(h->d_state, (const int64_t*)h->gather_idx.ptr, n, (uint4*)h->gather_out.ptr, h->stream));
   HIPCHK(h, hipMemcpyAsync(states_out, h->gather_out.ptr, (size_t)n * 64, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SURGE_OK;
+}
+
+int32_t surge_replay_encode_json(surge_replay_handle* h, const surge_json_template* tmpl, const uint8_t* d_keys_utf8,
+                                 const int64_t* d_key_off, uint8_t* d_out, int64_t out_capacity, int64_t* d_out_off,
+                                 int64_t* total_bytes_out) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->bound || h->st.n_folds == 0) return fail(h, SURGE_E_STATE, "encode_json before fold");
+  if (!tmpl || !d_key_off || !d_out_off || !total_bytes_out) return fail(h, SURGE_E_INVALID, "NULL argument");
+  if (tmpl->n_parts == 0 || tmpl->n_parts > SURGE_JSON_MAX_PARTS) return fail(h, SURGE_E_INVALID, "template.n_parts out of range");
+  for (uint32_t i = 0; i < tmpl->n_parts; ++i) {
+    const auto& pt = tmpl->part[i];
+    if (pt.kind > SURGE_JP_I64) return fail(h, SURGE_E_UNSUPPORTED, "unknown template part kind");
+    if (pt.kind == SURGE_JP_LITERAL && (pt.lit_off > 256 || pt.lit_len > 256 - pt.lit_off)) return fail(h, SURGE_E_INVALID, "literal out of range");
+    if (pt.kind >= SURGE_JP_I32 && pt.field_offset + (pt.kind == SURGE_JP_I64 ? 8u : 4u) > 64u) return fail(h, SURGE_E_INVALID, "field outside the 64-byte state");
+  }
+  *total_bytes_out = 0;
+  if (h->n_agg == 0) return SURGE_OK;
+  DeviceGuard g(h->device);
+  const int64_t nb = (h->n_agg + 1023) / 1024;
+  HIPCHK(h, h->scan_totals.reserve((size_t)(nb + 1) * 8));
+  HIPCHK(h, launch_json_encode(*tmpl, h->d_state, h->n_agg, d_keys_utf8, d_key_off, d_out_off, (int64_t*)h->scan_totals.ptr,
+                               d_out, false, h->stream));
+  int64_t total = 0;
+  HIPCHK(h, hipMemcpyAsync(&total, (int64_t*)h->scan_totals.ptr + nb, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpyAsync(d_out_off + h->n_agg, &total, 8, hipMemcpyHostToDevice, h->stream));
+  *total_bytes_out = total;
+  if (total > out_capacity) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return fail(h, SURGE_E_RANGE, "output buffer too small for the encoded snapshot");
+  }
+  if (total > 0 && !d_out) return fail(h, SURGE_E_INVALID, "d_out is NULL");
+  HIPCHK(h, launch_json_encode(*tmpl, h->d_state, h->n_agg, d_keys_utf8, d_key_off, d_out_off, (int64_t*)h->scan_totals.ptr,
+                               d_out, true, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return SURGE_OK;
 }

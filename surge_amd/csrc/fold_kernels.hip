@@ -966,6 +966,135 @@ __global__ void __launch_bounds__(kWave) stream_probe_lds_kernel(const uint4* __
   if (acc == 0x9e3779b9u) sink[0] = acc;
 }
 
+// ---- N3: fixed 64-byte state -> serialized text (two passes around an exclusive scan) -----------------
+struct JsonTemplateDev {
+  uint32_t n_parts;
+  uint32_t kind[SURGE_JSON_MAX_PARTS], field_offset[SURGE_JSON_MAX_PARTS], lit_off[SURGE_JSON_MAX_PARTS],
+      lit_len[SURGE_JSON_MAX_PARTS];
+  uint8_t literals[256];
+};
+
+__device__ __forceinline__ int dec_len_u64(uint64_t v) {
+  int n = 1;
+  while (v >= 10ull) { v /= 10ull; ++n; }
+  return n;
+}
+
+// Jackson's default JSON string escaping: \" \\ \b \f \n \r \t, other controls as \u00XX, the rest verbatim
+__device__ __forceinline__ int json_escaped_len(uint8_t c) {
+  if (c == '"' || c == '\\' || c == '\b' || c == '\f' || c == '\n' || c == '\r' || c == '\t') return 2;
+  return c < 0x20 ? 6 : 1;
+}
+
+__device__ __forceinline__ uint8_t* json_put_escaped(uint8_t* o, uint8_t c) {
+  const char* hex = "0123456789ABCDEF";
+  switch (c) {
+    case '"': *o++ = '\\'; *o++ = '"'; return o;
+    case '\\': *o++ = '\\'; *o++ = '\\'; return o;
+    case '\b': *o++ = '\\'; *o++ = 'b'; return o;
+    case '\f': *o++ = '\\'; *o++ = 'f'; return o;
+    case '\n': *o++ = '\\'; *o++ = 'n'; return o;
+    case '\r': *o++ = '\\'; *o++ = 'r'; return o;
+    case '\t': *o++ = '\\'; *o++ = 't'; return o;
+    default:
+      if (c < 0x20) {
+        *o++ = '\\'; *o++ = 'u'; *o++ = '0'; *o++ = '0'; *o++ = (uint8_t)hex[c >> 4]; *o++ = (uint8_t)hex[c & 15];
+        return o;
+      }
+      *o++ = c;
+      return o;
+  }
+}
+
+__device__ __forceinline__ void json_int_value(const uint8_t* st, uint32_t kind, uint32_t off, bool* neg, uint64_t* mag) {
+  if (kind == SURGE_JP_I32) {
+    const int32_t v = *(const int32_t*)(st + off);
+    *neg = v < 0;
+    *mag = v < 0 ? (uint64_t)(-(int64_t)v) : (uint64_t)v;
+  } else if (kind == SURGE_JP_U32) {
+    *neg = false;
+    *mag = *(const uint32_t*)(st + off);
+  } else {
+    const int64_t v = *(const int64_t*)(st + off);
+    *neg = v < 0;
+    *mag = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+  }
+}
+
+template <bool WRITE>
+__global__ void json_encode_kernel(const JsonTemplateDev t, const uint4* __restrict__ states, int64_t n,
+                                   const uint8_t* __restrict__ keys, const int64_t* __restrict__ key_off,
+                                   int64_t* __restrict__ len_or_off, uint8_t* __restrict__ out) {
+  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  const uint8_t* st = (const uint8_t*)(states + a * 4);
+  const uint32_t fl = *(const uint32_t*)(st + 36);
+  const bool emit = (fl & FL_PRESENT) && !(fl & FL_POISONED);
+  if (!WRITE) {
+    int64_t len = 0;
+    if (emit) {
+      for (uint32_t i = 0; i < t.n_parts; ++i) {
+        const uint32_t k = t.kind[i];
+        if (k == SURGE_JP_LITERAL) {
+          len += t.lit_len[i];
+        } else if (k == SURGE_JP_KEY) {
+          len += 2;
+          for (int64_t b = key_off[a]; b < key_off[a + 1]; ++b) len += json_escaped_len(keys[b]);
+        } else {
+          bool neg; uint64_t mag;
+          json_int_value(st, k, t.field_offset[i], &neg, &mag);
+          len += dec_len_u64(mag) + (neg ? 1 : 0);
+        }
+      }
+    }
+    len_or_off[a] = len;
+    return;
+  }
+  if (!emit) return;
+  uint8_t* o = out + len_or_off[a];
+  for (uint32_t i = 0; i < t.n_parts; ++i) {
+    const uint32_t k = t.kind[i];
+    if (k == SURGE_JP_LITERAL) {
+      for (uint32_t b = 0; b < t.lit_len[i]; ++b) *o++ = t.literals[t.lit_off[i] + b];
+    } else if (k == SURGE_JP_KEY) {
+      *o++ = '"';
+      for (int64_t b = key_off[a]; b < key_off[a + 1]; ++b) o = json_put_escaped(o, keys[b]);
+      *o++ = '"';
+    } else {
+      bool neg; uint64_t mag;
+      json_int_value(st, k, t.field_offset[i], &neg, &mag);
+      if (neg) *o++ = '-';
+      const int nd = dec_len_u64(mag);
+      for (int d = nd - 1; d >= 0; --d) { o[d] = (uint8_t)('0' + (int)(mag % 10ull)); mag /= 10ull; }
+      o += nd;
+    }
+  }
+}
+
+// exclusive scan of n int64 values in place (+ total at [n]): per-block scan, scan of block totals, add
+constexpr int kScanBlock = 1024;
+__global__ void __launch_bounds__(kScanBlock) scan_block_kernel(int64_t* __restrict__ v, int64_t n, int64_t* __restrict__ totals) {
+  __shared__ int64_t s[kScanBlock];
+  const int tid = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kScanBlock + tid;
+  const int64_t x = i < n ? v[i] : 0;
+  s[tid] = x;
+  __syncthreads();
+  for (int d = 1; d < kScanBlock; d <<= 1) {
+    const int64_t y = tid >= d ? s[tid - d] : 0;
+    __syncthreads();
+    s[tid] += y;
+    __syncthreads();
+  }
+  if (i < n) v[i] = s[tid] - x;  // exclusive
+  if (tid == kScanBlock - 1) totals[blockIdx.x] = s[tid];
+}
+
+__global__ void scan_add_kernel(int64_t* __restrict__ v, int64_t n, const int64_t* __restrict__ totals_excl) {
+  const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
+  if (i < n) v[i] += totals_excl[blockIdx.x];
+}
+
 __global__ void gather_states_kernel(const uint4* __restrict__ states, const int64_t* __restrict__ idx, int64_t n,
                                      uint4* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16 B quarter of a state per thread
@@ -1095,6 +1224,31 @@ hipError_t launch_stream_probe(const uint4* src, int64_t n_vec, uint32_t* sink, 
     hipLaunchKernelGGL(stream_probe_kernel<true>, dim3(256 * 8), dim3(256), 0, stream, src, n_vec, sink);
   else
     hipLaunchKernelGGL(stream_probe_kernel<false>, dim3(256 * 8), dim3(256), 0, stream, src, n_vec, sink);
+  return hipGetLastError();
+}
+
+// d_len_off: n + 1 entries; d_totals: ceil(n / 1024) + 1 entries of scratch
+hipError_t launch_json_encode(const surge_json_template& tmpl, const uint4* states, int64_t n, const uint8_t* keys,
+                              const int64_t* key_off, int64_t* d_len_off, int64_t* d_totals, uint8_t* out, bool write_pass,
+                              hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  JsonTemplateDev t;
+  t.n_parts = tmpl.n_parts;
+  for (uint32_t i = 0; i < SURGE_JSON_MAX_PARTS; ++i) {
+    t.kind[i] = tmpl.part[i].kind; t.field_offset[i] = tmpl.part[i].field_offset;
+    t.lit_off[i] = tmpl.part[i].lit_off; t.lit_len[i] = tmpl.part[i].lit_len;
+  }
+  for (int i = 0; i < 256; ++i) t.literals[i] = tmpl.literals[i];
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (!write_pass) {
+    hipLaunchKernelGGL(json_encode_kernel<false>, dim3(blocks), dim3(256), 0, stream, t, states, n, keys, key_off, d_len_off, out);
+    const int64_t nb = (n + kScanBlock - 1) / kScanBlock;
+    hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, stream, d_len_off, n, d_totals);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, stream, d_totals, nb);  // exclusive scan of block totals, grand total at [nb]
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, stream, d_len_off, n, d_totals);
+  } else {
+    hipLaunchKernelGGL(json_encode_kernel<true>, dim3(blocks), dim3(256), 0, stream, t, states, n, keys, key_off, d_len_off, out);
+  }
   return hipGetLastError();
 }
 

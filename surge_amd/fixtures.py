@@ -43,6 +43,24 @@ from .schema import (
 )
 
 
+_JSON_ESC = {'"': '\\"', "\\": "\\\\", "\b": "\\b", "\f": "\\f", "\n": "\\n", "\r": "\\r", "\t": "\\t"}
+
+
+def jackson_quote(s: str) -> str:
+    """JSON string with Jackson's default escaping (what play-json's ``Json.stringify`` emits): the seven
+    short escapes, other controls as ``\\u00XX`` with upper-case hex, everything else verbatim (UTF-8)."""
+    out = ['"']
+    for ch in s:
+        if ch in _JSON_ESC:
+            out.append(_JSON_ESC[ch])
+        elif ord(ch) < 0x20:
+            out.append("\\u%04X" % ord(ch))
+        else:
+            out.append(ch)
+    out.append('"')
+    return "".join(out)
+
+
 def _i32(x: int) -> int:
     """JVM ``Int`` arithmetic: wrap to 32-bit two's complement."""
     x &= 0xFFFFFFFF
@@ -207,11 +225,7 @@ class CounterAggregateFormat(SurgeAggregateFormatting[State]):
     """
 
     def write_state(self, agg: State) -> SerializedAggregate:
-        text = json.dumps(
-            {"aggregateId": agg.aggregateId, "count": agg.count, "version": agg.version},
-            separators=(",", ":"),
-            ensure_ascii=False,
-        )
+        text = '{"aggregateId":%s,"count":%d,"version":%d}' % (jackson_quote(agg.aggregateId), agg.count, agg.version)
         return SerializedAggregate(text.encode("utf-8"))
 
     def read_state(self, data: bytes) -> Optional[State]:

@@ -291,3 +291,38 @@ def test_partition_hash_kernel_matches_cpu_entry_point_and_oracle():
         eng.synchronize()
     assert (d_out.cpu().numpy() == cpu).all()
     assert (oracle.partition_hash_batch(data, off, 64) == cpu).all()
+
+
+def test_gpu_json_encoder_matches_play_json_text_of_the_counter_fixture():
+    # N3: bulk serialized state == Json.toJson(state).toString() (TestBoundedContext.scala:127-129), byte for byte
+    import torch
+
+    from surge_amd.encode import JsonTemplate, encode_states, key_table_utf8
+    from surge_amd.fixtures import CounterAggregateFormat, State
+
+    n = 5000
+    rng = np.random.default_rng(11)
+    keys = [f"agg-{i:05d}" for i in range(n)]
+    keys[7], keys[8], keys[9], keys[10] = 'we"ird\\id', "tab\there\nnl", "ünï-✓-ключ", "\x01\x1f"
+    lens = rng.integers(0, 12, size=n)
+    so, ev = synth.csr_log(lens, 12, synth.STRESS_MIX)
+    ev["raw"][(ev["type"] == S.EVT_INC) & (rng.random(ev.shape[0]) < 0.3)] = np.uint64(np.uint32(np.int32(-7)))
+    with ReplayEngine() as eng:
+        eng.load_csr(so, ev)
+        eng.fold()
+        states = eng.snapshot()
+        data, off = key_table_utf8(keys)
+        d_out, d_off = encode_states(eng, JsonTemplate.counter(), torch.from_numpy(data).cuda(), torch.from_numpy(off).cuda())
+        out, offs = d_out.cpu().numpy().tobytes(), d_off.cpu().numpy()
+    fmt = CounterAggregateFormat()
+    n_emitted = 0
+    for a in range(n):
+        text = out[offs[a]:offs[a + 1]]
+        fl = int(states[a]["flags"])
+        if fl == S.STATE_PRESENT:
+            n_emitted += 1
+            assert text == fmt.write_state(State(keys[a], int(states[a]["count"]), int(states[a]["version"]))).value
+            assert text == oracle.counter_state_json(keys[a], int(states[a]["count"]), int(states[a]["version"]))
+        else:
+            assert text == b""  # None => tombstone, poisoned => nothing
+    assert 0 < n_emitted < n
