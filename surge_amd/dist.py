@@ -108,9 +108,16 @@ class SnapshotGather:
     writes the other snapshot buffer.
     """
 
-    def __init__(self, n_local: int, device, group=None):
+    def __init__(self, n_local: int, device, group=None, mode: Optional[str] = None):
+        import os
+
         import torch
         import torch.distributed as dist
+
+        # "p2p": one grouped send/recv per peer — on the xGMI full mesh every one of the 7 links then carries
+        # exactly one peer's shard concurrently (a ring all-gather would push all N-1 shards through one link
+        # pair, SURVEY §8e).  "allgather": the library collective.
+        self.mode = mode or os.environ.get("SURGE_SNAPSHOT_GATHER", "p2p")
 
         self.dist, self.torch = dist, torch
         self.group = group
@@ -146,13 +153,31 @@ class SnapshotGather:
             with self.torch.cuda.stream(self.stream):
                 if ready_event is not None:
                     self.stream.wait_event(ready_event)
-                self.dist.all_gather_into_tensor(self.out[slot].view(-1), local_padded.view(-1), group=self.group)
+                if self.mode == "p2p":
+                    self._p2p(slot, local_padded)
+                else:
+                    self.dist.all_gather_into_tensor(self.out[slot].view(-1), local_padded.view(-1), group=self.group)
                 ev = self.torch.cuda.Event()
                 ev.record(self.stream)
                 self.done[slot] = ev
+        elif self.mode == "p2p":
+            self._p2p(slot, local_padded)
         else:
             parts = [self.out[slot][r] for r in range(self.world)]
             self.dist.all_gather(parts, local_padded, group=self.group)
+
+    def _p2p(self, slot: int, local_padded) -> None:
+        dist = self.dist
+        out = self.out[slot]
+        out[self.rank].copy_(local_padded)
+        ops = []
+        for d in range(1, self.world):  # skewed peer order: rank r talks to r+d / r-d in step d
+            to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
+            ops.append(dist.P2POp(dist.isend, local_padded, to, self.group))
+            ops.append(dist.P2POp(dist.irecv, out[frm], frm, self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
 
     def wait(self, slot: int, stream=None) -> None:
         """Make ``stream`` (default: current) wait for slot ``slot``'s gather."""
