@@ -1,0 +1,88 @@
+/*
+ * surge_ingest.h — C ABI of the events-topic ingest: the step immediately BEFORE
+ * the fold.  Host-side, no GPU: Kafka record batches of one partition of the events topic in, records
+ * in offset order with their aggregate index out (ready for surge_replay_load_csr /
+ * surge_replay_append_events).
+ *
+ * What it restates (third party, NOT vendored under /root/reference: org.apache.kafka:kafka-clients 3.2.3,
+ * message format v2 / KIP-98; LZ4 frame format — "parity unpinned"):
+ *   - RecordBatch v2 framing, CRC-32C over [attributes .. end], zig-zag varint records
+ *   - compression.type = lz4 (the reference's producer setting,
+ *     modules/common/src/main/resources/reference.conf:112) and none
+ *   - isolation.level = read_committed (modules/common/src/main/scala/surge/kafka/streams/
+ *     SurgeStateStoreConsumer.scala:38): transactional batches are held back until their producer's
+ *     COMMIT / ABORT control marker; aborted ones are dropped; nothing after an open transaction is
+ *     delivered (last-stable-offset order); control batches are never delivered
+ *   - the per-flush transaction the reference writes: events..., extra records, state
+ *     (modules/command-engine/core/src/main/scala/surge/internal/kafka/KafkaProducerActorImpl.scala:421-453)
+ *   - the producer's "flush" record, empty key and empty value (KafkaProducerActorImpl.scala:322-329), is skipped
+ *   - aggregate id = record key up to the first ':' (PartitionStringUpToColon,
+ *     modules/common/src/main/scala/surge/kafka/KafkaPartitioner.scala:38-42; event keys are "<id>:<seq>",
+ *     TestBoundedContext.scala:122-124)
+ */
+#ifndef SURGE_INGEST_H
+#define SURGE_INGEST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SURGE_INGEST_READ_UNCOMMITTED 0
+#define SURGE_INGEST_READ_COMMITTED   1
+
+/* status codes are surge_replay.h's: 0 OK, -1 INVALID, -2 STATE, -4 NOMEM, -5 UNSUPPORTED; plus: */
+#define SURGE_E_CORRUPT (-7) /* bad magic / CRC mismatch / malformed varint / bad LZ4 stream */
+
+typedef struct surge_ingest surge_ingest;
+
+typedef struct surge_ingest_record {
+  int64_t offset;      /* Kafka offset of the record                                   */
+  int64_t agg_idx;     /* dense index of the aggregate id (key up to ':') in the key table */
+  int64_t key_off;     /* span of the full key in the byte arena (surge_ingest_arena)   */
+  int32_t key_len;     /* -1 = null key                                                */
+  int32_t value_len;   /* -1 = null value (tombstone)                                  */
+  int64_t value_off;
+} surge_ingest_record;
+
+int32_t surge_ingest_create(int32_t isolation_level, surge_ingest** out);
+int32_t surge_ingest_destroy(surge_ingest* g);
+const char* surge_ingest_last_error(const surge_ingest* g);
+
+/* Feed bytes of consecutive record batches (a fetch response's record set / a log segment).  Whole
+ * batches are consumed; *consumed_out tells how many bytes were (a trailing partial batch is left for
+ * the next call, exactly like a fetch that cuts a batch).  Decoded records accumulate until drained. */
+int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int64_t* consumed_out);
+
+/* Records that are deliverable now (committed / non-transactional, before any open transaction). */
+int64_t surge_ingest_ready(const surge_ingest* g);
+
+/* Pops up to max deliverable records in offset order.  Spans point into the arena, valid until the next
+ * feed/drain/destroy. */
+int32_t surge_ingest_drain(surge_ingest* g, int64_t max, surge_ingest_record* out, int64_t* n_out);
+const uint8_t* surge_ingest_arena(const surge_ingest* g);
+
+/* Convenience for GPU-ready topics whose record value IS the 16-byte fixed event (surge_event16): pops
+ * records straight into the arrays surge_replay_append_events / a CSR packer take.  A value of any other
+ * length is an error (SURGE_E_INVALID). */
+int32_t surge_ingest_drain_fixed16(surge_ingest* g, int64_t max, int64_t* agg_idx_out, void* events16_out,
+                                   int64_t* offsets_out, int64_t* n_out);
+
+/* Key table: aggregate ids in first-seen order. */
+int64_t surge_ingest_key_count(const surge_ingest* g);
+int32_t surge_ingest_key(const surge_ingest* g, int64_t idx, const char** utf8_out, int64_t* len_out);
+
+/* Counters: [0] batches, [1] records decoded, [2] records delivered, [3] records dropped (aborted),
+ * [4] control batches, [5] flush records skipped, [6] bytes decompressed, [7] open transactions. */
+int32_t surge_ingest_counters(const surge_ingest* g, int64_t out[8]);
+
+/* Exposed for tests / other bindings. */
+uint32_t surge_crc32c(const uint8_t* data, int64_t len);
+/* LZ4 frame -> bytes.  Returns the decompressed size, or a negative status. */
+int64_t surge_lz4_frame_decompress(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SURGE_INGEST_H */

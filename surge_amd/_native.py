@@ -17,8 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
-SOURCES = ("fold_kernels.hip", "engine.hip")
-HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(INCLUDE, "surge_replay.h"))
+SOURCES = ("fold_kernels.hip", "engine.hip", "ingest.cpp")
+HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
 EXPORTS = (
@@ -45,6 +45,23 @@ EXPORTS = (
     "surge_replay_stats",
     "surge_replay_stats_reset",
     "surge_replay_stream_probe",
+)
+
+#: every symbol ``include/surge_ingest.h`` declares
+INGEST_EXPORTS = (
+    "surge_ingest_create",
+    "surge_ingest_destroy",
+    "surge_ingest_last_error",
+    "surge_ingest_feed",
+    "surge_ingest_ready",
+    "surge_ingest_drain",
+    "surge_ingest_arena",
+    "surge_ingest_drain_fixed16",
+    "surge_ingest_key_count",
+    "surge_ingest_key",
+    "surge_ingest_counters",
+    "surge_crc32c",
+    "surge_lz4_frame_decompress",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -143,7 +160,23 @@ def load() -> ctypes.CDLL:
         "surge_replay_stats_reset": ([vp], i32),
         "surge_replay_stream_probe": ([vp, vp, i64, ctypes.POINTER(ctypes.c_double)], i32),
     }
-    for name in EXPORTS:
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    sig.update({
+        "surge_ingest_create": ([i32, ctypes.POINTER(vp)], i32),
+        "surge_ingest_destroy": ([vp], i32),
+        "surge_ingest_last_error": ([vp], ctypes.c_char_p),
+        "surge_ingest_feed": ([vp, vp, i64, ctypes.POINTER(i64)], i32),
+        "surge_ingest_ready": ([vp], i64),
+        "surge_ingest_drain": ([vp, i64, vp, ctypes.POINTER(i64)], i32),
+        "surge_ingest_arena": ([vp], vp),
+        "surge_ingest_drain_fixed16": ([vp, i64, vp, vp, vp, ctypes.POINTER(i64)], i32),
+        "surge_ingest_key_count": ([vp], i64),
+        "surge_ingest_key": ([vp, i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i64)], i32),
+        "surge_ingest_counters": ([vp, ctypes.POINTER(i64 * 8)], i32),
+        "surge_crc32c": ([vp, i64], ctypes.c_uint32),
+        "surge_lz4_frame_decompress": ([vp, i64, vp, i64], i64),
+    })
+    for name in EXPORTS + INGEST_EXPORTS:
         try:
             fn = getattr(L, name)
         except AttributeError as e:

@@ -1,0 +1,439 @@
+// ingest.cpp — events-topic ingest, host side of libsurge_replay.so.
+// Kafka RecordBatch v2 + LZ4 frame + read_committed, restated from the published formats (kafka-clients
+// 3.2.3 is not vendored under /root/reference: parity unpinned, see include/surge_ingest.h).
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/surge_ingest.h"
+
+namespace {
+
+constexpr int32_t OK = 0, E_INVALID = -1, E_NOMEM = -4, E_UNSUPPORTED = -5;
+
+thread_local std::string g_err;
+
+struct Rec {
+  int64_t offset, key_off, value_off, agg_idx;
+  int32_t key_len, value_len;
+};
+
+struct Batch {
+  int64_t producer_id = -1;
+  bool transactional = false;
+  int decided = 1;  // 0 pending (open transaction), 1 committed / non-transactional, 2 aborted
+  std::vector<Rec> recs;
+  size_t next = 0;  // first record not yet drained
+};
+
+uint32_t g_crc_table[8][256];
+bool g_crc_init = false;
+
+void crc_init() {
+  if (g_crc_init) return;
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;  // Castagnoli, reflected
+    g_crc_table[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; ++i)
+    for (int t = 1; t < 8; ++t) g_crc_table[t][i] = (g_crc_table[t - 1][i] >> 8) ^ g_crc_table[0][g_crc_table[t - 1][i] & 0xff];
+  g_crc_init = true;
+}
+
+struct Reader {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool ok = true;
+  bool need(int64_t n) {
+    if (!ok || end - p < n) { ok = false; return false; }
+    return true;
+  }
+  uint8_t u8() { return need(1) ? *p++ : 0; }
+  int16_t i16() { if (!need(2)) return 0; int16_t v = (int16_t)((p[0] << 8) | p[1]); p += 2; return v; }
+  int32_t i32() { if (!need(4)) return 0; uint32_t v = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; p += 4; return (int32_t)v; }
+  int64_t i64() { if (!need(8)) return 0; uint64_t v = 0; for (int i = 0; i < 8; ++i) v = (v << 8) | p[i]; p += 8; return (int64_t)v; }
+  // zig-zag varint (protobuf style), as Kafka's ByteUtils.readVarlong
+  int64_t varlong() {
+    uint64_t v = 0;
+    int shift = 0;
+    while (true) {
+      if (!need(1) || shift > 63) { ok = false; return 0; }
+      const uint8_t b = *p++;
+      v |= (uint64_t)(b & 0x7f) << shift;
+      if (!(b & 0x80)) break;
+      shift += 7;
+    }
+    return (int64_t)(v >> 1) ^ -(int64_t)(v & 1);
+  }
+};
+
+// LZ4 block (sequence) decoder into dst[*op .. cap); matches may reach back into everything already written
+bool lz4_block(const uint8_t* ip, const uint8_t* iend, uint8_t* dst, int64_t* op_io, int64_t cap) {
+  int64_t op = *op_io;
+  while (ip < iend) {
+    const uint8_t token = *ip++;
+    int64_t lit = token >> 4;
+    if (lit == 15) {
+      uint8_t b;
+      do {
+        if (ip >= iend) return false;
+        b = *ip++;
+        lit += b;
+      } while (b == 255);
+    }
+    if (iend - ip < lit || cap - op < lit) return false;
+    std::memcpy(dst + op, ip, (size_t)lit);
+    ip += lit;
+    op += lit;
+    if (ip >= iend) break;  // the last sequence carries literals only
+    if (iend - ip < 2) return false;
+    const int64_t offset = ip[0] | (ip[1] << 8);
+    ip += 2;
+    if (offset == 0 || offset > op) return false;
+    int64_t ml = token & 15;
+    if (ml == 15) {
+      uint8_t b;
+      do {
+        if (ip >= iend) return false;
+        b = *ip++;
+        ml += b;
+      } while (b == 255);
+    }
+    ml += 4;
+    if (cap - op < ml) return false;
+    for (int64_t k = 0; k < ml; ++k) dst[op + k] = dst[op + k - offset];  // byte-wise: overlap is the point
+    op += ml;
+  }
+  *op_io = op;
+  return true;
+}
+
+}  // namespace
+
+struct surge_ingest {
+  int isolation = SURGE_INGEST_READ_COMMITTED;
+  std::string err;
+  std::vector<uint8_t> arena;
+  std::deque<Batch> queue;
+  std::unordered_map<std::string, int64_t> key_index;
+  std::vector<std::string> keys;
+  std::vector<uint8_t> scratch;
+  int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+int32_t fail(surge_ingest* g, int32_t code, const std::string& m) {
+  if (g) g->err = m;
+  g_err = m;
+  return code;
+}
+
+int64_t intern(surge_ingest* g, const uint8_t* key, int32_t len) {
+  int32_t n = 0;
+  while (n < len && key[n] != (uint8_t)':') ++n;  // PartitionStringUpToColon
+  std::string id((const char*)key, (size_t)n);
+  auto it = g->key_index.find(id);
+  if (it != g->key_index.end()) return it->second;
+  const int64_t idx = (int64_t)g->keys.size();
+  g->keys.push_back(id);
+  g->key_index.emplace(std::move(id), idx);
+  return idx;
+}
+
+// number of records deliverable from the head of the queue
+int64_t ready_count(const surge_ingest* g) {
+  int64_t n = 0;
+  for (const Batch& b : g->queue) {
+    if (b.decided == 0) break;  // an open transaction: nothing behind it is stable yet
+    if (b.decided == 1) n += (int64_t)(b.recs.size() - b.next);
+  }
+  return n;
+}
+
+int32_t parse_records(surge_ingest* g, Batch& b, const uint8_t* data, int64_t len, int32_t count, int64_t base_offset,
+                      bool control, int* control_type) {
+  Reader r{data, data + len};
+  for (int32_t i = 0; i < count; ++i) {
+    const int64_t rlen = r.varlong();
+    if (!r.ok || rlen < 0 || !r.need(rlen)) return fail(g, SURGE_E_CORRUPT, "record length runs past the batch");
+    Reader q{r.p, r.p + rlen};
+    r.p += rlen;
+    (void)q.u8();        // attributes
+    (void)q.varlong();   // timestampDelta
+    const int64_t offset_delta = q.varlong();
+    const int64_t klen = q.varlong();
+    if (!q.ok || klen < -1 || (klen >= 0 && !q.need(klen))) return fail(g, SURGE_E_CORRUPT, "bad record key");
+    const uint8_t* key = q.p;
+    if (klen > 0) q.p += klen;
+    const int64_t vlen = q.varlong();
+    if (!q.ok || vlen < -1 || (vlen >= 0 && !q.need(vlen))) return fail(g, SURGE_E_CORRUPT, "bad record value");
+    const uint8_t* val = q.p;
+    if (vlen > 0) q.p += vlen;
+    const int64_t n_headers = q.varlong();
+    if (!q.ok || n_headers < 0) return fail(g, SURGE_E_CORRUPT, "bad header count");
+    for (int64_t hdr = 0; hdr < n_headers; ++hdr) {
+      const int64_t hk = q.varlong();
+      if (!q.ok || hk < 0 || !q.need(hk)) return fail(g, SURGE_E_CORRUPT, "bad header key");
+      q.p += hk;
+      const int64_t hv = q.varlong();
+      if (!q.ok || hv < -1 || (hv > 0 && !q.need(hv))) return fail(g, SURGE_E_CORRUPT, "bad header value");
+      if (hv > 0) q.p += hv;
+    }
+    g->counters[1] += 1;
+    if (control) {
+      // control record key: version int16, type int16 (0 = ABORT, 1 = COMMIT)
+      if (klen >= 4) *control_type = (key[2] << 8) | key[3];
+      continue;
+    }
+    if (klen == 0 && vlen == 0) {  // the producer's "flush" record (KafkaProducerActorImpl.scala:322-329)
+      g->counters[5] += 1;
+      continue;
+    }
+    Rec rec;
+    rec.offset = base_offset + offset_delta;
+    rec.key_len = (int32_t)klen;
+    rec.value_len = (int32_t)vlen;
+    rec.key_off = (int64_t)g->arena.size();
+    if (klen > 0) g->arena.insert(g->arena.end(), key, key + klen);
+    rec.value_off = (int64_t)g->arena.size();
+    if (vlen > 0) g->arena.insert(g->arena.end(), val, val + vlen);
+    rec.agg_idx = klen >= 0 ? intern(g, key, (int32_t)klen) : -1;
+    b.recs.push_back(rec);
+  }
+  return OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t surge_crc32c(const uint8_t* data, int64_t len) {
+  crc_init();
+  uint32_t c = 0xffffffffu;
+  int64_t i = 0;
+  for (; i + 8 <= len; i += 8) {  // slicing-by-8
+    const uint32_t lo = c ^ ((uint32_t)data[i] | ((uint32_t)data[i + 1] << 8) | ((uint32_t)data[i + 2] << 16) | ((uint32_t)data[i + 3] << 24));
+    c = g_crc_table[7][lo & 0xff] ^ g_crc_table[6][(lo >> 8) & 0xff] ^ g_crc_table[5][(lo >> 16) & 0xff] ^ g_crc_table[4][lo >> 24] ^
+        g_crc_table[3][data[i + 4]] ^ g_crc_table[2][data[i + 5]] ^ g_crc_table[1][data[i + 6]] ^ g_crc_table[0][data[i + 7]];
+  }
+  for (; i < len; ++i) c = (c >> 8) ^ g_crc_table[0][(c ^ data[i]) & 0xff];
+  return c ^ 0xffffffffu;
+}
+
+int64_t surge_lz4_frame_decompress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap) {
+  if (!src || n < 7 || (!dst && cap > 0)) return E_INVALID;
+  const uint8_t* p = src;
+  const uint8_t* end = src + n;
+  if (!(p[0] == 0x04 && p[1] == 0x22 && p[2] == 0x4D && p[3] == 0x18)) return SURGE_E_CORRUPT;  // 0x184D2204 LE
+  p += 4;
+  const uint8_t flg = *p++;
+  p++;  // BD: block maximum size, not needed to decode
+  if ((flg >> 6) != 1) return SURGE_E_CORRUPT;  // version 01
+  const bool block_checksum = flg & 0x10, content_size = flg & 0x08, content_checksum = flg & 0x04, dict_id = flg & 0x01;
+  if (content_size) p += 8;
+  if (dict_id) p += 4;
+  p += 1;  // header checksum (xxh32 of the descriptor >> 8); not verified
+  if (p > end) return SURGE_E_CORRUPT;
+  int64_t op = 0;
+  while (true) {
+    if (end - p < 4) return SURGE_E_CORRUPT;
+    const uint32_t bs = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    p += 4;
+    if (bs == 0) break;  // EndMark
+    const uint32_t size = bs & 0x7fffffffu;
+    if ((int64_t)size > end - p) return SURGE_E_CORRUPT;
+    if (bs & 0x80000000u) {  // stored uncompressed
+      if (cap - op < (int64_t)size) return -6;
+      std::memcpy(dst + op, p, size);
+      op += size;
+    } else if (!lz4_block(p, p + size, dst, &op, cap)) {
+      return SURGE_E_CORRUPT;
+    }
+    p += size;
+    if (block_checksum) p += 4;
+  }
+  if (content_checksum) p += 4;
+  return op;
+}
+
+int32_t surge_ingest_create(int32_t isolation_level, surge_ingest** out) {
+  if (!out) return fail(nullptr, E_INVALID, "out is NULL");
+  *out = nullptr;
+  if (isolation_level != SURGE_INGEST_READ_UNCOMMITTED && isolation_level != SURGE_INGEST_READ_COMMITTED)
+    return fail(nullptr, E_INVALID, "unknown isolation level");
+  surge_ingest* g = new (std::nothrow) surge_ingest();
+  if (!g) return fail(nullptr, E_NOMEM, "out of host memory");
+  g->isolation = isolation_level;
+  *out = g;
+  return OK;
+}
+
+int32_t surge_ingest_destroy(surge_ingest* g) {
+  delete g;
+  return OK;
+}
+
+const char* surge_ingest_last_error(const surge_ingest* g) { return g ? g->err.c_str() : g_err.c_str(); }
+
+int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int64_t* consumed_out) {
+  if (!g) return fail(nullptr, E_INVALID, "handle is NULL");
+  if (len < 0 || (!data && len > 0)) return fail(g, E_INVALID, "bad buffer");
+  if (consumed_out) *consumed_out = 0;
+  if (g->queue.empty()) g->arena.clear();  // spans handed out by the last drain are released here
+  int64_t pos = 0;
+  try {
+    while (len - pos >= 12) {
+      Reader h{data + pos, data + len};
+      const int64_t base_offset = h.i64();
+      const int32_t batch_len = h.i32();
+      if (batch_len < 49) return fail(g, SURGE_E_CORRUPT, "batchLength below the v2 header size");
+      if (len - pos - 12 < batch_len) break;  // partial batch: wait for more bytes
+      const uint8_t* body = data + pos + 12;
+      Reader r{body, body + batch_len};
+      (void)r.i32();  // partitionLeaderEpoch
+      const uint8_t magic = r.u8();
+      if (magic != 2) return fail(g, E_UNSUPPORTED, "only message format v2 (magic 2) is supported");
+      const uint32_t crc = (uint32_t)r.i32();
+      if (surge_crc32c(r.p, r.end - r.p) != crc) return fail(g, SURGE_E_CORRUPT, "record batch CRC-32C mismatch");
+      const int16_t attrs = r.i16();
+      (void)r.i32();  // lastOffsetDelta
+      (void)r.i64();  // baseTimestamp
+      (void)r.i64();  // maxTimestamp
+      const int64_t producer_id = r.i64();
+      (void)r.i16();  // producerEpoch
+      (void)r.i32();  // baseSequence
+      const int32_t count = r.i32();
+      if (!r.ok || count < 0) return fail(g, SURGE_E_CORRUPT, "truncated batch header");
+      const int codec = attrs & 7;
+      const bool transactional = attrs & 0x10, control = attrs & 0x20;
+      const uint8_t* recs = r.p;
+      int64_t recs_len = r.end - r.p;
+      if (codec == 3) {
+        int64_t cap = recs_len * 8 + 1024;
+        int64_t got;
+        while (true) {
+          g->scratch.resize((size_t)cap);
+          got = surge_lz4_frame_decompress(recs, recs_len, g->scratch.data(), cap);
+          if (got != -6) break;
+          cap *= 4;
+          if (cap > (1ll << 31)) return fail(g, SURGE_E_CORRUPT, "LZ4 batch expands beyond 2 GiB");
+        }
+        if (got < 0) return fail(g, SURGE_E_CORRUPT, "bad LZ4 frame in record batch");
+        g->counters[6] += got;
+        recs = g->scratch.data();
+        recs_len = got;
+      } else if (codec != 0) {
+        return fail(g, E_UNSUPPORTED, "compression codec not supported (only none and lz4; the reference publishes lz4)");
+      }
+      Batch b;
+      b.producer_id = producer_id;
+      b.transactional = transactional;
+      int control_type = -1;
+      const int32_t rc = parse_records(g, b, recs, recs_len, count, base_offset, control, &control_type);
+      if (rc != OK) return rc;
+      g->counters[0] += 1;
+      if (control) {
+        g->counters[4] += 1;
+        if (control_type == 0 || control_type == 1) {  // ABORT / COMMIT ends this producer's open transaction
+          for (Batch& qb : g->queue)
+            if (qb.decided == 0 && qb.producer_id == producer_id) {
+              qb.decided = control_type == 1 ? 1 : 2;
+              if (control_type == 0) g->counters[3] += (int64_t)qb.recs.size();
+            }
+        }
+      } else {
+        b.decided = (transactional && g->isolation == SURGE_INGEST_READ_COMMITTED) ? 0 : 1;
+        if (!b.recs.empty()) g->queue.push_back(std::move(b));
+      }
+      pos += 12 + batch_len;
+    }
+  } catch (const std::bad_alloc&) {
+    return fail(g, E_NOMEM, "out of host memory while decoding");
+  }
+  if (consumed_out) *consumed_out = pos;
+  int64_t open = 0;
+  for (const Batch& qb : g->queue) open += qb.decided == 0;
+  g->counters[7] = open;
+  return OK;
+}
+
+int64_t surge_ingest_ready(const surge_ingest* g) { return g ? ready_count(g) : 0; }
+
+int32_t surge_ingest_drain(surge_ingest* g, int64_t max, surge_ingest_record* out, int64_t* n_out) {
+  if (!g || !n_out || max < 0 || (!out && max > 0)) return fail(g, E_INVALID, "bad argument");
+  int64_t n = 0;
+  while (n < max && !g->queue.empty()) {
+    Batch& b = g->queue.front();
+    if (b.decided == 0) break;
+    if (b.decided == 2) { g->queue.pop_front(); continue; }
+    while (n < max && b.next < b.recs.size()) {
+      const Rec& r = b.recs[b.next++];
+      out[n].offset = r.offset; out[n].agg_idx = r.agg_idx; out[n].key_off = r.key_off; out[n].key_len = r.key_len;
+      out[n].value_len = r.value_len; out[n].value_off = r.value_off;
+      ++n;
+    }
+    if (b.next == b.recs.size()) g->queue.pop_front();
+  }
+  g->counters[2] += n;
+  *n_out = n;
+  return OK;
+}
+
+const uint8_t* surge_ingest_arena(const surge_ingest* g) { return g ? g->arena.data() : nullptr; }
+
+int32_t surge_ingest_drain_fixed16(surge_ingest* g, int64_t max, int64_t* agg_idx_out, void* events16_out,
+                                   int64_t* offsets_out, int64_t* n_out) {
+  if (!g || !n_out || max < 0 || ((!agg_idx_out || !events16_out) && max > 0)) return fail(g, E_INVALID, "bad argument");
+  // validate before popping anything
+  int64_t avail = 0;
+  for (const Batch& b : g->queue) {
+    if (b.decided == 0) break;
+    if (b.decided == 2) continue;
+    for (size_t i = b.next; i < b.recs.size() && avail < max; ++i, ++avail)
+      if (b.recs[i].value_len != 16 || b.recs[i].agg_idx < 0)
+        return fail(g, E_INVALID, "record value is not a 16-byte fixed event (or the key is null)");
+    if (avail >= max) break;
+  }
+  int64_t n = 0;
+  uint8_t* ev = (uint8_t*)events16_out;
+  while (n < max && !g->queue.empty()) {
+    Batch& b = g->queue.front();
+    if (b.decided == 0) break;
+    if (b.decided == 2) { g->queue.pop_front(); continue; }
+    while (n < max && b.next < b.recs.size()) {
+      const Rec& r = b.recs[b.next++];
+      agg_idx_out[n] = r.agg_idx;
+      std::memcpy(ev + n * 16, g->arena.data() + r.value_off, 16);
+      if (offsets_out) offsets_out[n] = r.offset;
+      ++n;
+    }
+    if (b.next == b.recs.size()) g->queue.pop_front();
+  }
+  g->counters[2] += n;
+  *n_out = n;
+  return OK;
+}
+
+int64_t surge_ingest_key_count(const surge_ingest* g) { return g ? (int64_t)g->keys.size() : 0; }
+
+int32_t surge_ingest_key(const surge_ingest* g, int64_t idx, const char** utf8_out, int64_t* len_out) {
+  if (!g || !utf8_out || !len_out) return fail(nullptr, E_INVALID, "bad argument");
+  if (idx < 0 || idx >= (int64_t)g->keys.size()) return E_INVALID;
+  *utf8_out = g->keys[(size_t)idx].data();
+  *len_out = (int64_t)g->keys[(size_t)idx].size();
+  return OK;
+}
+
+int32_t surge_ingest_counters(const surge_ingest* g, int64_t out[8]) {
+  if (!g || !out) return E_INVALID;
+  for (int i = 0; i < 8; ++i) out[i] = g->counters[i];
+  return OK;
+}
+
+}  // extern "C"

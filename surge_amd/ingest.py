@@ -1,0 +1,109 @@
+"""Events-topic ingest: Kafka record batches of one partition -> records in offset order
+with their aggregate index, through the C ABI in ``include/surge_ingest.h`` (host side, no GPU).
+
+``EventsTopicIngest.feed(bytes)`` takes what a fetch of the events topic returns (RecordBatch v2, lz4 or
+uncompressed, ``read_committed`` by default like ``SurgeStateStoreConsumer.scala:38``);
+``drain_fixed16()`` returns ``(agg_idx, events, offsets)`` for GPU-ready topics whose record value is the
+16-byte fixed event, ``drain_records()`` returns ``(offset, key, value)`` tuples for plugin-decoded values.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _native
+from .log import KeyTable
+from .schema import EVENT_DTYPE
+
+READ_UNCOMMITTED, READ_COMMITTED = 0, 1
+
+RECORD_DTYPE = np.dtype([("offset", "<i8"), ("agg_idx", "<i8"), ("key_off", "<i8"), ("key_len", "<i4"),
+                         ("value_len", "<i4"), ("value_off", "<i8")])
+assert RECORD_DTYPE.itemsize == 40
+
+
+class IngestError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"surge_ingest status {status}: {message}")
+        self.status = status
+
+
+class EventsTopicIngest:
+    def __init__(self, isolation_level: int = READ_COMMITTED):
+        self._lib = _native.load()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.surge_ingest_create(isolation_level, ctypes.byref(self._h))
+        if rc != 0:
+            raise IngestError(rc, (self._lib.surge_ingest_last_error(None) or b"").decode())
+        self._tail = b""
+
+    def close(self):
+        if self._h:
+            self._lib.surge_ingest_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise IngestError(rc, (self._lib.surge_ingest_last_error(self._h) or b"").decode())
+
+    def feed(self, data: bytes) -> int:
+        """Decode whole batches; a trailing partial batch is kept and completed by the next call."""
+        buf = self._tail + bytes(data)
+        consumed = ctypes.c_int64(0)
+        arr = (ctypes.c_uint8 * len(buf)).from_buffer_copy(buf) if buf else None
+        self._check(self._lib.surge_ingest_feed(self._h, arr, len(buf), ctypes.byref(consumed)))
+        self._tail = buf[consumed.value:]
+        return consumed.value
+
+    @property
+    def ready(self) -> int:
+        return int(self._lib.surge_ingest_ready(self._h))
+
+    def counters(self) -> dict:
+        c = (ctypes.c_int64 * 8)()
+        self._check(self._lib.surge_ingest_counters(self._h, ctypes.byref(c)))
+        names = ["batches", "records_decoded", "records_delivered", "records_aborted", "control_batches",
+                 "flush_records_skipped", "bytes_decompressed", "open_transactions"]
+        return dict(zip(names, [int(x) for x in c]))
+
+    def drain_fixed16(self, max_records: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        n = self.ready if max_records is None else min(self.ready, max_records)
+        agg = np.zeros(n, dtype=np.int64)
+        ev = np.zeros(n, dtype=EVENT_DTYPE)
+        off = np.zeros(n, dtype=np.int64)
+        got = ctypes.c_int64(0)
+        self._check(self._lib.surge_ingest_drain_fixed16(
+            self._h, n, agg.ctypes.data_as(ctypes.c_void_p), ev.ctypes.data_as(ctypes.c_void_p),
+            off.ctypes.data_as(ctypes.c_void_p), ctypes.byref(got)))
+        return agg[: got.value], ev[: got.value], off[: got.value]
+
+    def drain_records(self, max_records: Optional[int] = None) -> List[Tuple[int, int, Optional[bytes], Optional[bytes]]]:
+        """``(offset, agg_idx, key, value)`` per record (``None`` for null key / value)."""
+        n = self.ready if max_records is None else min(self.ready, max_records)
+        recs = np.zeros(n, dtype=RECORD_DTYPE)
+        got = ctypes.c_int64(0)
+        self._check(self._lib.surge_ingest_drain(self._h, n, recs.ctypes.data_as(ctypes.c_void_p), ctypes.byref(got)))
+        base = self._lib.surge_ingest_arena(self._h)
+        out = []
+        for r in recs[: got.value]:
+            key = None if r["key_len"] < 0 else ctypes.string_at(base + int(r["key_off"]), int(r["key_len"]))
+            val = None if r["value_len"] < 0 else ctypes.string_at(base + int(r["value_off"]), int(r["value_len"]))
+            out.append((int(r["offset"]), int(r["agg_idx"]), key, val))
+        return out
+
+    def key_table(self) -> KeyTable:
+        kt = KeyTable()
+        n = int(self._lib.surge_ingest_key_count(self._h))
+        p, ln = ctypes.c_char_p(), ctypes.c_int64()
+        for i in range(n):
+            self._check(self._lib.surge_ingest_key(self._h, i, ctypes.byref(p), ctypes.byref(ln)))
+            kt.intern(ctypes.string_at(p, ln.value).decode("utf-8"))
+        return kt

@@ -64,6 +64,38 @@ class GpuReplayStateStore:
                 init[self.keys.index[k]] = self.model.state_to_fixed(agg)[0]
         self.restore_log(log, init, algo)
 
+    def restore_from_topic(self, record_batches: bytes, capacity: int = 0, algo: int = ALGO_AUTO) -> dict:
+        """Recover from the raw bytes of one events-topic partition (Kafka record batches v2, lz4 or none,
+        ``read_committed``): ingest (``include/surge_ingest.h``) -> CSR pack -> GPU fold.
+
+        Record values that are exactly 16 bytes are taken as fixed-width events; anything else goes through
+        the plugin's ``SurgeEventReadFormatting.read_event`` and the model's ``encode_event``.  Returns the
+        ingest counters."""
+        from .core import SerializedMessage
+        from .ingest import EventsTopicIngest
+        from .log import group_by_aggregate
+        from .schema import EVENT_DTYPE
+
+        with EventsTopicIngest() as g:
+            g.feed(record_batches)
+            recs = g.drain_records()
+            keys = g.key_table()
+            counters = g.counters()
+        reader = self.business_logic.event_write_formatting()
+        events = np.zeros(len(recs), dtype=EVENT_DTYPE)
+        agg_idx = np.zeros(len(recs), dtype=np.int64)
+        for i, (_, idx, key, value) in enumerate(recs):
+            agg_idx[i] = idx
+            if value is not None and len(value) == 16:
+                events[i] = np.frombuffer(value, dtype=EVENT_DTYPE)[0]
+            else:
+                evt = reader.read_event(SerializedMessage(key.decode("utf-8"), value or b""))
+                events[i] = self.model.encode_events([evt])[0]
+        n_agg = max(len(keys), capacity)
+        seg_off, sorted_ev = group_by_aggregate(agg_idx, events, n_agg)
+        self.restore_log(EventLog(seg_off, sorted_ev, keys), None, algo)
+        return counters
+
     def restore_log(self, log: EventLog, init_state: Optional[np.ndarray] = None, algo: int = ALGO_AUTO) -> None:
         self.keys = log.keys
         self.engine.load_csr(log.seg_off, log.events, init_state)

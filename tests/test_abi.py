@@ -12,10 +12,10 @@ from surge_amd.schema import CSchema, DEFAULT_ALGEBRA
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "surge_replay.h")).read()
+def header_symbols(name="surge_replay.h", prefix="surge_replay_"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(surge_replay_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]*)\s*\(", text)))
 
 
 def test_library_builds_for_gfx950_and_loads():
@@ -31,6 +31,14 @@ def test_exports_match_the_header():
     assert declared == sorted(_native.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in surge_replay.h but not exported"
+
+
+def test_ingest_exports_match_their_header():
+    lib = _native.load()
+    declared = header_symbols("surge_ingest.h", "surge_(?:ingest|crc32c|lz4)")
+    assert declared == sorted(_native.INGEST_EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in surge_ingest.h but not exported"
 
 
 def test_default_schema_matches_python_mirror():

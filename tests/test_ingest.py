@@ -1,0 +1,194 @@
+"""N1: events-topic ingest (record batch v2, LZ4 frame, read_committed) — CPU-only.
+
+The decoder (C++, surge_amd/csrc/ingest.cpp) is checked against an independent writer (tests/kafka_wire.py)
+and against the formats' own known answers (CRC-32C check value, hand-assembled LZ4 sequences).  kafka-clients
+is not available here, so parity with a real broker's bytes is unpinned."""
+import ctypes
+import os
+import random
+import struct
+
+import numpy as np
+import pytest
+
+import kafka_wire as kw
+from oracle import oracle
+from surge_amd import _native
+from surge_amd import schema as S
+from surge_amd.ingest import READ_COMMITTED, READ_UNCOMMITTED, EventsTopicIngest, IngestError
+from surge_amd.log import group_by_aggregate
+
+
+def lz4_decompress(frame: bytes, cap: int = 1 << 20) -> bytes:
+    L = _native.load()
+    dst = ctypes.create_string_buffer(cap)
+    n = L.surge_lz4_frame_decompress(frame, len(frame), dst, cap)
+    assert n >= 0, n
+    return dst.raw[:n]
+
+
+def test_crc32c_check_value():
+    L = _native.load()
+    assert L.surge_crc32c(b"123456789", 9) == 0xE3069283  # the CRC-32C (Castagnoli) check value
+    assert L.surge_crc32c(b"", 0) == 0
+    data = os.urandom(1000)
+    assert L.surge_crc32c(data, len(data)) == kw.crc32c(data)
+
+
+def test_lz4_hand_assembled_sequences():
+    hdr = struct.pack("<I", 0x184D2204) + bytes([0x60, 0x40, 0x00])
+    # literals only: token 0x50 = 5 literals, no match
+    blk = bytes([0x50]) + b"hello"
+    assert lz4_decompress(hdr + struct.pack("<I", len(blk)) + blk + struct.pack("<I", 0)) == b"hello"
+    # overlapping match (run-length): 1 literal 'a', match offset 1 length 4+7, then 5 trailing literals
+    blk = bytes([0x17]) + b"a" + struct.pack("<H", 1) + bytes([0x50]) + b"bcdef"
+    assert lz4_decompress(hdr + struct.pack("<I", len(blk)) + blk + struct.pack("<I", 0)) == b"a" * 12 + b"bcdef"
+    # long literal run (15 + 255 + 3) with extended length bytes
+    lit = bytes(range(256)) + b"xyz" * 5 + b"q" * 2
+    assert len(lit) == 273
+    blk = bytes([0xF0, 255, 3]) + lit
+    assert lz4_decompress(hdr + struct.pack("<I", len(blk)) + blk + struct.pack("<I", 0)) == lit
+    # stored (uncompressed) block + content checksum flag
+    raw = b"stored-block"
+    frame = struct.pack("<I", 0x184D2204) + bytes([0x64, 0x40, 0x00]) + struct.pack("<I", len(raw) | 0x80000000) + raw + struct.pack("<I", 0) + b"\0\0\0\0"
+    assert lz4_decompress(frame) == raw
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_lz4_round_trip_against_the_independent_compressor(seed):
+    rng = random.Random(seed)
+    words = [os.urandom(rng.randrange(1, 9)) for _ in range(40)]
+    data = b"".join(rng.choice(words) for _ in range(rng.randrange(1, 6000)))
+    frame = kw.lz4_frame(data, block_size=4096)
+    assert len(frame) < len(data) + 64
+    assert lz4_decompress(frame) == data
+    assert lz4_decompress(kw.lz4_frame(b"")) == b""
+    L = _native.load()
+    assert L.surge_lz4_frame_decompress(b"\x00" * 16, 16, ctypes.create_string_buffer(8), 8) == -7  # bad magic
+
+
+def counter_event(kind, seq, arg):
+    return S.make_events([kind], [seq], [arg]).tobytes()
+
+
+def test_batches_round_trip_with_and_without_lz4_and_split_feeds():
+    rng = random.Random(1)
+    recs, batches, off = [], [], 0
+    for b in range(30):
+        n = rng.randrange(1, 20)
+        rs = []
+        for _ in range(n):
+            agg = f"agg-{rng.randrange(50)}"
+            key = f"{agg}:{rng.randrange(1000)}".encode()
+            val = os.urandom(rng.randrange(0, 60)) or None
+            hdrs = [(b"aggregate_id", agg.encode())] if rng.random() < 0.3 else []
+            rs.append((key, val, hdrs))
+        batches.append(kw.record_batch(off, rs, compression=rng.choice(["none", "lz4"])))
+        recs += [(off + i, r[0], r[1]) for i, r in enumerate(rs)]
+        off += n
+    wire = b"".join(batches)
+    with EventsTopicIngest() as g:
+        pos = 0
+        while pos < len(wire):  # arbitrary fetch boundaries
+            step = rng.randrange(1, 700)
+            g.feed(wire[pos:pos + step])
+            pos += step
+        got = g.drain_records()
+        assert [(o, k, v) for o, _, k, v in got] == recs
+        kt = g.key_table()
+        for _, idx, k, _ in got:
+            assert kt.keys[idx] == k.decode().split(":")[0]  # PartitionStringUpToColon
+        c = g.counters()
+        assert c["batches"] == 30 and c["records_delivered"] == len(recs) and c["open_transactions"] == 0
+
+
+def test_read_committed_holds_back_open_transactions_and_drops_aborted_ones():
+    ev = lambda seq: counter_event(S.EVT_INC, seq, 1)
+    wire = b"".join([
+        kw.record_batch(0, [(b"a:1", ev(1))], transactional=True, producer_id=7),          # txn A (will commit)
+        kw.record_batch(1, [(b"b:1", ev(1)), (b"b:2", ev(2))], transactional=True, producer_id=9),  # txn B (will abort)
+        kw.record_batch(3, [(b"c:1", ev(1))]),                                               # plain, behind open txns
+        kw.control_batch(4, 9, kw.ABORT),
+    ])
+    with EventsTopicIngest(READ_COMMITTED) as g:
+        g.feed(wire)
+        assert g.ready == 0 and g.counters()["open_transactions"] == 1  # A still open: nothing is stable (LSO)
+        g.feed(kw.control_batch(5, 7, kw.COMMIT))
+        got = g.drain_records()
+        assert [(o, k) for o, _, k, _ in got] == [(0, b"a:1"), (3, b"c:1")]
+        c = g.counters()
+        assert c["records_aborted"] == 2 and c["control_batches"] == 2
+    with EventsTopicIngest(READ_UNCOMMITTED) as g:
+        g.feed(wire)
+        assert [k for _, _, k, _ in g.drain_records()] == [b"a:1", b"b:1", b"b:2", b"c:1"]
+
+
+def test_flush_record_null_values_and_errors():
+    wire = kw.record_batch(0, [(b"", b""), (b"k:1", None), (None, b"v")])
+    with EventsTopicIngest() as g:
+        g.feed(wire)
+        got = g.drain_records()
+        assert [(o, i, k, v) for o, i, k, v in got] == [(1, 0, b"k:1", None), (2, -1, None, b"v")]
+        assert g.counters()["flush_records_skipped"] == 1  # KafkaProducerActorImpl.scala:322-329
+    bad = bytearray(kw.record_batch(0, [(b"k:1", b"v")]))
+    bad[-1] ^= 0x55
+    with EventsTopicIngest() as g, pytest.raises(IngestError) as ei:
+        g.feed(bytes(bad))
+    assert ei.value.status == -7 and "CRC" in str(ei.value)
+    with EventsTopicIngest() as g, pytest.raises(IngestError) as ei:
+        g.feed(kw.record_batch(0, [(b"k", b"v")], magic=1))
+    assert ei.value.status == -5
+    with EventsTopicIngest() as g, pytest.raises(IngestError) as ei:
+        g.feed(kw.record_batch(0, [(b"k", b"v")], codec_override=1))  # gzip
+    assert ei.value.status == -5
+    with EventsTopicIngest() as g:
+        g.feed(kw.record_batch(0, [(b"k:1", b"not sixteen bytes")]))
+        with pytest.raises(IngestError):
+            g.drain_fixed16()
+
+
+def test_topic_to_csr_to_fold_matches_the_fold_of_the_published_events():
+    """One transaction per flush (events...), lz4, two interleaved producers, some aborted flushes:
+    ingest -> group by aggregate -> fold == fold of the committed events in offset order."""
+    rng = random.Random(3)
+    wire, off, committed = [], 0, []
+    seqs = {}
+    open_txn = {}
+    for flush in range(200):
+        pid = rng.choice([11, 12])
+        if pid in open_txn:
+            kind = kw.COMMIT if rng.random() < 0.8 else kw.ABORT
+            wire.append(kw.control_batch(off, pid, kind))
+            off += 1
+            if kind == kw.COMMIT:
+                committed += open_txn[pid]
+            del open_txn[pid]
+            continue
+        rs, evs = [], []
+        for _ in range(rng.randrange(1, 6)):
+            agg = f"acct-{rng.randrange(40):04d}"
+            seqs[agg] = seqs.get(agg, 0) + 1
+            val = counter_event(rng.choice([S.EVT_INC, S.EVT_DEC, S.EVT_NOOP, S.EVT_CREATE, S.EVT_SET_BALANCE]), seqs[agg], rng.randrange(-9, 99))
+            rs.append((f"{agg}:{seqs[agg]}".encode(), val))
+        wire.append(kw.record_batch(off, rs, compression="lz4", transactional=True, producer_id=pid))
+        open_txn[pid] = [(off + i, r[0], r[1]) for i, r in enumerate(rs)]
+        off += len(rs)
+    for pid in list(open_txn):
+        wire.append(kw.control_batch(off, pid, kw.COMMIT))
+        off += 1
+        committed += open_txn.pop(pid)
+    committed.sort()
+    with EventsTopicIngest() as g:
+        g.feed(b"".join(wire))
+        agg_idx, events, offsets = g.drain_fixed16()
+        kt = g.key_table()
+    assert list(offsets) == [o for o, _, _ in committed]
+    assert events.tobytes() == b"".join(v for _, _, v in committed)
+    seg_off, sorted_ev = group_by_aggregate(agg_idx, events, len(kt))
+    got = oracle.fold_csr(seg_off, sorted_ev)
+    # expectation: fold every aggregate's committed events, in offset order, one at a time
+    for a, key in enumerate(kt.keys):
+        mine = [v for _, k, v in committed if k.decode().split(":")[0] == key]
+        ev = np.frombuffer(b"".join(mine), dtype=S.EVENT_DTYPE)
+        exp = oracle.fold_csr(np.array([0, len(mine)], dtype=np.int64), ev)[0]
+        assert got[a].tobytes() == exp.tobytes()

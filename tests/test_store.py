@@ -200,3 +200,41 @@ def test_incremental_snapshot_records_compact_to_the_full_refold():
         assert all(p == PartitionStringUpToColon.instance.partition_for_key(k, 5) for k, p in parts.items())
     finally:
         store.close()
+
+
+@pytest.mark.gpu
+def test_recovery_from_raw_events_topic_bytes():
+    """N1 end to end: lz4 record batches, one transaction per flush, an aborted flush, JSON event values
+    (the Counter fixture's own writeEvent) -> ingest -> CSR -> GPU fold -> getAggregateBytes."""
+    import kafka_wire as kw
+    from surge_amd.store import GpuReplayStateStore
+
+    bl = CounterBusinessLogic()
+    model, fmt = bl.command_model(), bl.event_write_formatting()
+    flushes = [
+        ([CountIncremented("a", 1, 1), CountIncremented("b", 5, 1)], kw.COMMIT),
+        ([CountIncremented("a", 1, 2)], kw.ABORT),            # never happened as far as consumers are concerned
+        ([CountDecremented("b", 2, 2), NoOpEvent("c", 1)], kw.COMMIT),
+        ([CountIncremented("a", 10, 2)], kw.COMMIT),
+    ]
+    wire, off = [], 0
+    for events, outcome in flushes:
+        msgs = [fmt.write_event(e) for e in events]
+        wire.append(kw.record_batch(off, [(m.key.encode(), m.value) for m in msgs], compression="lz4", transactional=True, producer_id=5))
+        off += len(msgs)
+        wire.append(kw.control_batch(off, 5, outcome))
+        off += 1
+    store = GpuReplayStateStore(bl)
+    try:
+        counters = store.restore_from_topic(b"".join(wire))
+        assert counters["records_aborted"] == 1 and counters["records_delivered"] == 5
+        expect = {}
+        for events, outcome in flushes:
+            if outcome == kw.COMMIT:
+                for e in events:
+                    expect[e.aggregateId] = model.handle_event(expect.get(e.aggregateId), e)
+        for k, st in expect.items():
+            assert store.get_aggregate_bytes(k) == bl.aggregate_write_formatting().write_state(st).value
+        assert expect["a"] == State("a", 11, 2)
+    finally:
+        store.close()
