@@ -602,6 +602,13 @@ int32_t surge_replay_append_fold(surge_replay_handle* h, const int64_t* group_ag
     if (group_off[gidx + 1] <= group_off[gidx]) return fail(h, SURGE_E_INVALID, "batch groups must be non-empty and ordered");
     if (group_agg[gidx] < 0 || group_agg[gidx] >= h->n_agg) return fail(h, SURGE_E_RANGE, "group_agg out of range");
   }
+  {
+    // an aggregate may appear in one group only: two groups would race on the same resident state
+    std::vector<int64_t> seen(group_agg, group_agg + n_groups);
+    std::sort(seen.begin(), seen.end());
+    if (std::adjacent_find(seen.begin(), seen.end()) != seen.end())
+      return fail(h, SURGE_E_INVALID, "an aggregate appears in more than one group of the batch");
+  }
   DeviceGuard g(h->device);
   HIPCHK(h, h->batch_group_agg.reserve((size_t)n_groups * 8));
   HIPCHK(h, h->batch_group_off.reserve((size_t)(n_groups + 1) * 8));

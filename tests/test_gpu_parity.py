@@ -326,3 +326,39 @@ def test_gpu_json_encoder_matches_play_json_text_of_the_counter_fixture():
         else:
             assert text == b""  # None => tombstone, poisoned => nothing
     assert 0 < n_emitted < n
+
+
+def test_append_fold_rejects_a_batch_that_names_an_aggregate_twice():
+    so, ev = synth.fixed_log(10, 16, 4)
+    with ReplayEngine() as eng:
+        eng.load_csr(so, ev)
+        eng.fold()
+        with pytest.raises(ReplayError) as ei:
+            eng.append_fold(np.array([3, 3]), np.array([0, 1, 2]), ev[:2])
+        assert ei.value.status == -1 and "more than one group" in str(ei.value)
+
+
+def test_two_engines_on_two_streams_do_not_interfere():
+    import torch
+
+    dev = torch.device("cuda:0")
+    logs = [synth.fixed_log_device(150_000, 32, 40 + i, dev) for i in range(2)]
+    outs = [torch.empty((150_000, 64), dtype=torch.uint8, device=dev) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    engines = [ReplayEngine() for _ in range(2)]
+    try:
+        torch.cuda.synchronize()
+        for e, s, (so, ev), o in zip(engines, streams, logs, outs):
+            e.use_stream(s)
+            e.load_csr(so, ev, None, o)
+        for _ in range(5):  # interleaved launches on both streams
+            for e in engines:
+                e.fold()
+        for e in engines:
+            e.synchronize()
+        for (so, ev), o in zip(logs, outs):
+            exp = oracle.fold_csr(so[:3001].cpu().numpy(), synth.to_event_records(ev[: 3000 * 32]))
+            assert o[:3000].cpu().numpy().tobytes() == exp.tobytes()
+    finally:
+        for e in engines:
+            e.close()
