@@ -646,14 +646,20 @@ __global__ void __launch_bounds__(kWave) fold_sorted_kernel(const FoldParams p) 
     if (lane == 0) g = atomicAdd(p.counter, 1ull);
     return (int64_t)(((uint64_t)rl((uint32_t)(g >> 32), 0) << 32) | rl((uint32_t)g, 0));
   };
-  struct Meta { int64_t s, start; uint32_t len; };
+  // A row is tiled from the 128 B line that contains its first event: `start` is rounded down to a multiple
+  // of 8 events and the `pad` events in front of the segment (they belong to its predecessor) are treated as
+  // null events.  Every LE*16-byte piece is then line-aligned; without this each 512 B piece touched five
+  // lines instead of four (FETCH_SIZE was 22 % above the algorithmic bytes).
+  struct Meta { int64_t s, start; uint32_t len, pad; };
   auto load_meta = [&](int64_t g) -> Meta {
-    Meta m; m.s = -1; m.start = 0; m.len = 0u;
+    Meta m; m.s = -1; m.start = 0; m.len = 0u; m.pad = 0u;
     const int64_t idx = g * kWave + lane;
     if (g < n_groups && idx < p.n_seg) {
       m.s = perm[idx];
-      m.start = p.seg_off[m.s];
-      m.len = (uint32_t)(p.seg_off[m.s + 1] - m.start);
+      const int64_t st = p.seg_off[m.s];
+      m.pad = (uint32_t)(st & 7);
+      m.start = st - m.pad;
+      m.len = (uint32_t)(p.seg_off[m.s + 1] - st) + m.pad;
     }
     return m;
   };
@@ -711,13 +717,15 @@ __global__ void __launch_bounds__(kWave) fold_sorted_kernel(const FoldParams p) 
       if (c + 1 < n_tiles) issue(c + 1);
 
       uint32_t tyc[LE];
-      if ((uint32_t)(c + 1) * LE <= minlen) {
+      if (c > 0 && (uint32_t)(c + 1) * LE <= minlen) {
 #pragma unroll
         for (int j = 0; j < LE; ++j) tyc[j] = (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride;
       } else {
-        const int32_t rem = (int32_t)cur.len - c * LE;  // my remaining events (may be <= 0)
+        const int32_t rem = (int32_t)cur.len - c * LE;         // my remaining events (may be <= 0)
+        const int32_t skip = c == 0 ? (int32_t)cur.pad : 0;   // events in front of my segment
 #pragma unroll
-        for (int j = 0; j < LE; ++j) tyc[j] = (j < rem ? (ev[j].x < 16u ? ev[j].x : 16u) : 17u) * kTableStride;
+        for (int j = 0; j < LE; ++j)
+          tyc[j] = ((j >= skip && j < rem) ? (ev[j].x < 16u ? ev[j].x : 16u) : 17u) * kTableStride;
       }
       walk_events<LE, false>(a, frozenM, corr, ev, tyc, 0u, lds_tab, p, [](int) {});
     }
