@@ -224,7 +224,7 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "kernel": {S.ALGO_FIXED: "fold_kernel<FIXED,16>", S.ALGO_FLAT: "fold_kernel<FLAT,16>",
-                           S.ALGO_ROWS: "fold_rows_kernel<8>", S.ALGO_SORTED: "fold_sorted_kernel<32>"}.get(st.last_algo, "?"),
+                           S.ALGO_ROWS: "fold_rows_kernel<8>", S.ALGO_SORTED: "fold_sorted_kernel<16>"}.get(st.last_algo, "?"),
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes": st.algorithmic_bytes,
                 "timed_launches": st.timed_folds,

@@ -450,9 +450,9 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
   const bool rows_auto = rows_ok && h->n_agg / kWave >= 2048;
   const bool sorted_ok = h->an.max_len < (1ll << 31);
   if (algo == SURGE_ALGO_SORTED && !sorted_ok) return fail(h, SURGE_E_UNSUPPORTED, "ALGO_SORTED needs segments shorter than 2^31 events");
-  // Measured on MI355X (C3: 10 M aggregates, Zipf 1..4096): FLAT 16.2 ms (4.6 TB/s); SORTED with 128 / 256 /
-  // 512 B row pieces 3.4 / 4.4 / 5.0 TB/s -> 14.8 ms with 512 B pieces.  SORTED needs enough groups of 64
-  // segments to keep its persistent waves busy; smaller logs stay on the linear-stream FLAT kernel.
+  // Measured on MI355X (C3: 10 M aggregates, Zipf 1..4096): FLAT 16.2 ms (4.6 TB/s); SORTED (line-aligned
+  // 256 B row pieces, 8 resident waves per CU) 5.5 TB/s.  SORTED needs enough groups of 64 segments to keep
+  // its persistent waves busy; smaller logs stay on the linear-stream FLAT kernel.
   const bool sorted_auto = sorted_ok && h->n_nz / kWave >= 4 * (int64_t)h->n_cus * 4;
   const int32_t use = (algo == SURGE_ALGO_AUTO)
                           ? (uniform ? (rows_auto ? SURGE_ALGO_ROWS : SURGE_ALGO_FIXED) : (sorted_auto ? SURGE_ALGO_SORTED : SURGE_ALGO_FLAT))
@@ -510,7 +510,7 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       HIPCHK(h, hipEventRecord(e1, h->stream));
       h->st.n_tasks = (int32_t)n_tasks;
     } else if (use == SURGE_ALGO_SORTED) {
-      const int le = env_lane_events("SURGE_REPLAY_LE_SORTED", 32);
+      const int le = env_lane_events("SURGE_REPLAY_LE_SORTED", 16);
       const int64_t* off = h->an.n_empty > 0 ? (const int64_t*)h->nz_off.ptr : h->d_seg_off;
       const int64_t n_seg = h->an.n_empty > 0 ? h->n_nz : h->n_agg;
       if (!h->perm_valid) {  // once per bound log (part of its index, like the empty-segment compaction)
@@ -526,7 +526,8 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       p.counter = (unsigned long long*)h->counter.ptr;
       p.n_seg = n_seg;
       const int64_t groups = (n_seg + kWave - 1) / kWave;
-      const int64_t slots = (int64_t)h->n_cus * (le == 8 ? 16 : (le == 16 ? 9 : 4));
+      // resident waves per CU = min(LDS, registers): 8 KiB tiles 12 (136 VGPRs), 16 KiB tiles 8 (18.6 KB LDS), 32 KiB tiles 4
+      const int64_t slots = (int64_t)h->n_cus * (le == 8 ? 12 : (le == 16 ? 8 : 4));
       const int64_t n_waves = groups < slots ? groups : slots;
       hipEvent_t e0, e1;
       const int32_t rc = next_fold_events(h, &e0, &e1);

@@ -231,9 +231,13 @@ struct Geo {
   static constexpr int kLoads = kTileBytes / 1024;
   static constexpr int kRowsPerLoad = kWave / LE;
   static constexpr int kHeadWords = kTile / 32;
-  static constexpr int kAuxBytes = kHeadWords * 4 < 256 ? 256 : kHeadWords * 4;  // head bitmask (flat) / 64 row lengths (sorted)
+  // LDS layout of every fold kernel: [tile][aux][op table]; the aux area is the head bitmask of the flat
+  // kernels, 64 row starts + lengths of the sorted kernel, nothing for the uniform rows kernel
+  static constexpr int kAuxFlat = kHeadWords * 4;
+  static constexpr int kAuxSorted = kWave * 12;
+  static constexpr int kAuxRows = 0;
   static constexpr int kClasses = LE == 32 ? 8 : (LE == 16 ? 4 : 2);
-  static constexpr int kLdsBytes = kTileBytes + kAuxBytes + kTableEntries * kTableStride * 4;
+  static constexpr int lds_bytes(int aux) { return kTileBytes + aux + kTableEntries * kTableStride * 4; }
   static constexpr uint32_t kLaneMask = LE >= 32 ? 0xffffffffu : ((1u << (LE & 31)) - 1u);
   __device__ static __forceinline__ uint32_t key(int l) { return LE >= 16 ? (uint32_t)(l & 15) : (uint32_t)((l >> 1) & 7); }
   // my pre-swizzled LDS row: event j lives at (row ^ (j * 16))
@@ -310,7 +314,7 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_ev = smem;
   uint32_t* lds_hb = (uint32_t*)(smem + G::kTileBytes);
-  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kAuxBytes);
+  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kAuxFlat);
 
   const int lane = threadIdx.x;
   const int64_t task = blockIdx.x;
@@ -548,7 +552,7 @@ __global__ void __launch_bounds__(kWave) fold_rows_kernel(const FoldParams p) {
   using G = Geo<LE>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_ev = smem;
-  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kAuxBytes);
+  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kAuxRows);
 
   const int lane = threadIdx.x;
   const int64_t S0 = (int64_t)blockIdx.x * p.segs_per_task;
@@ -632,9 +636,9 @@ __global__ void __launch_bounds__(kWave) fold_sorted_kernel(const FoldParams p) 
   using G = Geo<LE>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_ev = smem;
-  uint32_t* lds_len = (uint32_t*)(smem + G::kTileBytes);  // 64 row lengths, in the aux area
-  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kAuxBytes);
-  static_assert(G::kAuxBytes >= kWave * 4, "aux area holds one length per lane");
+  int64_t* lds_rs = (int64_t*)(smem + G::kTileBytes);              // 64 row starts (aux area) ...
+  uint32_t* lds_len = (uint32_t*)(smem + G::kTileBytes + kWave * 8);  // ... and 64 row lengths
+  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kAuxSorted);
   const int lane = threadIdx.x;
   load_table<LE>(p, lds_tab, lane);
   const uint32_t ev_row = G::ev_row(lane);
@@ -678,27 +682,26 @@ __global__ void __launch_bounds__(kWave) fold_sorted_kernel(const FoldParams p) 
     }
     const int n_tiles = (int)((maxlen + LE - 1) / LE);
 
-    // the rows each load instruction serves: start of row RPL*q + lane/LE in registers, lengths (only needed
-    // by the clamped slow path) in a 256 B LDS table to keep the register budget for resident waves
-    int64_t rs[G::kLoads];
-#pragma unroll
-    for (int q = 0; q < G::kLoads; ++q) rs[q] = __shfl(cur.start, G::kRowsPerLoad * q + lane / LE, 64);
+    // the rows each load instruction serves (row RPL*q + lane/LE): starts and lengths live in a small LDS
+    // table rather than in 3 registers per load instruction — the register budget buys resident waves
+    lds_rs[lane] = cur.start;
     lds_len[lane] = cur.len;
     auto issue = [&](int c) {
       if ((uint32_t)(c + 1) * LE <= minlen) {
 #pragma unroll
         for (int q = 0; q < G::kLoads; ++q) {
-          const int64_t e = rs[q] + (int64_t)c * LE + G::load_j(lane, q % G::kClasses);
+          const int64_t e = lds_rs[G::kRowsPerLoad * q + lane / LE] + (int64_t)c * LE + G::load_j(lane, q % G::kClasses);
           __builtin_amdgcn_global_load_lds((gptr_t)(p.events + e), (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
         }
       } else {  // some row ends inside this tile: never read past a row's own events
 #pragma unroll
         for (int q = 0; q < G::kLoads; ++q) {
-          const uint32_t rlen = lds_len[G::kRowsPerLoad * q + lane / LE];
+          const int r = G::kRowsPerLoad * q + lane / LE;
+          const uint32_t rlen = lds_len[r];
           uint32_t j = (uint32_t)c * LE + G::load_j(lane, q % G::kClasses);
           const uint32_t lastj = rlen ? rlen - 1u : 0u;
           j = j < lastj ? j : lastj;
-          __builtin_amdgcn_global_load_lds((gptr_t)(p.events + (rs[q] + j)), (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
+          __builtin_amdgcn_global_load_lds((gptr_t)(p.events + (lds_rs[r] + j)), (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
         }
       }
     };
@@ -1122,20 +1125,20 @@ __global__ void count_poisoned_kernel(const uint4* __restrict__ states, int64_t 
 hipError_t launch_fold_fixed(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream) {
   if (n_tasks <= 0) return hipSuccess;
   if (lane_events == 8)
-    hipLaunchKernelGGL((fold_kernel<MODE_FIXED, 8>), dim3((unsigned)n_tasks), dim3(kWave), Geo<8>::kLdsBytes, stream, p);
+    hipLaunchKernelGGL((fold_kernel<MODE_FIXED, 8>), dim3((unsigned)n_tasks), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxFlat), stream, p);
   else
-    hipLaunchKernelGGL((fold_kernel<MODE_FIXED, 16>), dim3((unsigned)n_tasks), dim3(kWave), Geo<16>::kLdsBytes, stream, p);
+    hipLaunchKernelGGL((fold_kernel<MODE_FIXED, 16>), dim3((unsigned)n_tasks), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxFlat), stream, p);
   return hipGetLastError();
 }
 
 hipError_t launch_fold_rows(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream) {
   if (n_tasks <= 0) return hipSuccess;
   if (lane_events == 8)
-    hipLaunchKernelGGL((fold_rows_kernel<8>), dim3((unsigned)n_tasks), dim3(kWave), Geo<8>::kLdsBytes, stream, p);
+    hipLaunchKernelGGL((fold_rows_kernel<8>), dim3((unsigned)n_tasks), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxRows), stream, p);
   else if (lane_events == 32)
-    hipLaunchKernelGGL((fold_rows_kernel<32>), dim3((unsigned)n_tasks), dim3(kWave), Geo<32>::kLdsBytes, stream, p);
+    hipLaunchKernelGGL((fold_rows_kernel<32>), dim3((unsigned)n_tasks), dim3(kWave), Geo<32>::lds_bytes(Geo<32>::kAuxRows), stream, p);
   else
-    hipLaunchKernelGGL((fold_rows_kernel<16>), dim3((unsigned)n_tasks), dim3(kWave), Geo<16>::kLdsBytes, stream, p);
+    hipLaunchKernelGGL((fold_rows_kernel<16>), dim3((unsigned)n_tasks), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxRows), stream, p);
   return hipGetLastError();
 }
 
@@ -1144,11 +1147,11 @@ hipError_t launch_fold_sorted(const FoldParams& p, int64_t n_waves, int lane_eve
   hipError_t e = hipMemsetAsync(p.counter, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   if (lane_events == 8)
-    hipLaunchKernelGGL((fold_sorted_kernel<8>), dim3((unsigned)n_waves), dim3(kWave), Geo<8>::kLdsBytes, stream, p);
+    hipLaunchKernelGGL((fold_sorted_kernel<8>), dim3((unsigned)n_waves), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxSorted), stream, p);
   else if (lane_events == 32)
-    hipLaunchKernelGGL((fold_sorted_kernel<32>), dim3((unsigned)n_waves), dim3(kWave), Geo<32>::kLdsBytes, stream, p);
+    hipLaunchKernelGGL((fold_sorted_kernel<32>), dim3((unsigned)n_waves), dim3(kWave), Geo<32>::lds_bytes(Geo<32>::kAuxSorted), stream, p);
   else
-    hipLaunchKernelGGL((fold_sorted_kernel<16>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::kLdsBytes, stream, p);
+    hipLaunchKernelGGL((fold_sorted_kernel<16>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxSorted), stream, p);
   return hipGetLastError();
 }
 
@@ -1168,9 +1171,9 @@ hipError_t launch_sort_by_length(const int64_t* off, int64_t n_seg, unsigned lon
 hipError_t launch_fold_flat(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream) {
   if (n_tasks <= 0) return hipSuccess;
   if (lane_events == 8)
-    hipLaunchKernelGGL((fold_kernel<MODE_FLAT, 8>), dim3((unsigned)n_tasks), dim3(kWave), Geo<8>::kLdsBytes, stream, p);
+    hipLaunchKernelGGL((fold_kernel<MODE_FLAT, 8>), dim3((unsigned)n_tasks), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxFlat), stream, p);
   else
-    hipLaunchKernelGGL((fold_kernel<MODE_FLAT, 16>), dim3((unsigned)n_tasks), dim3(kWave), Geo<16>::kLdsBytes, stream, p);
+    hipLaunchKernelGGL((fold_kernel<MODE_FLAT, 16>), dim3((unsigned)n_tasks), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxFlat), stream, p);
   return hipGetLastError();
 }
 
