@@ -9,7 +9,7 @@ so, ev = synth.fixed_log_device(A, L, 2, dev)
 out = torch.empty((A, 64), dtype=torch.uint8, device=dev)
 eng = ReplayEngine()
 eng.load_csr(so, ev, None, out)
-for algo in (3, 1, 2):
+for algo in [int(a) for a in os.environ.get("ALGOS", "3,1,2").split(",")]:
     for _ in range(3): eng.fold(algo)
     eng.synchronize(); eng.stats_reset()
     for _ in range(10): eng.fold(algo)
