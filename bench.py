@@ -115,7 +115,7 @@ def main():
         bufs = [torch.zeros((n_local, 64), dtype=torch.uint8, device=dev) for _ in range(2)]
         gather = None
     else:
-        gather = SnapshotGather(n_local, dev)
+        gather = SnapshotGather(n_local, dev, engine=eng)
         bufs = gather.make_local_buffers()
     eng.load_csr(seg_off, events, None, bufs[0])
 
@@ -213,7 +213,8 @@ def main():
                 "algo": {S.ALGO_FIXED: "fixed", S.ALGO_FLAT: "flat", S.ALGO_ROWS: "rows", S.ALGO_SORTED: "sorted"}.get(st.last_algo, str(st.last_algo)),
                 "wave_tasks": st.n_tasks,
                 "sharding": "single shard" if world == 1 else
-                f"murmur3(acct-%08d) % {N_PARTITIONS} -> gpu = partition % {world}; RCCL all-gather of the snapshot overlapped on a side stream",
+                f"murmur3(acct-%08d) % {N_PARTITIONS} -> gpu = partition % {world}; final snapshot exchanged over RCCL (grouped per-peer send/recv, "
+                f"40-byte wire form) on a side stream, overlapped with the next fold",
             },
             "roofline": {
                 "bound": "hbm",

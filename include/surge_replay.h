@@ -287,6 +287,14 @@ int32_t surge_replay_partition_hash_device(surge_replay_handle* h, const uint16_
                                            const int64_t* d_str_off, int64_t n,
                                            int32_t n_partitions, int32_t* d_part_out);
 
+/* Wire form of a snapshot for the xGMI exchange: only the first 40 bytes of a state carry information (the
+ * 24-byte reserved tail is always zero), so shards travel packed (n x 40 B) and are expanded back to the
+ * canonical n x 64 B on arrival.  Device pointers; launched on hip_stream (NULL = the handle's stream) so
+ * the host can keep them on the collective's side stream. */
+#define SURGE_PACKED_STATE_SIZE 40
+int32_t surge_replay_pack_states(surge_replay_handle* h, const void* d_states64, int64_t n, void* d_packed40, void* hip_stream);
+int32_t surge_replay_unpack_states(surge_replay_handle* h, const void* d_packed40, int64_t n, void* d_states64, void* hip_stream);
+
 /* Redirect the fold's output to another device buffer (n_agg x 64 B, 16-byte aligned) without
  * re-analysing the bound log; lets a host double-buffer snapshots under an overlapped all-gather. */
 int32_t surge_replay_set_state_out(surge_replay_handle* h, void* d_state_out);

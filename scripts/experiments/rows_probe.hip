@@ -25,7 +25,8 @@ __global__ void __launch_bounds__(64) probe(const uint4* __restrict__ ev, int64_
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int64_t row = g + 4 * q + (lane >> 4);
-          const uint4* src = ev + (row * L + c * 16 + (lane & 15));
+          const int cc = ROWS == 2 ? (int)((c + (row & 15)) % chunks) : c;  // ROWS == 2: rows desynchronised by up to 15 chunks
+          const uint4* src = ev + (row * L + cc * 16 + (lane & 15));
           __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + q * 1024), 16, 0, 2);
         }
       }
@@ -60,13 +61,14 @@ int main() {
     hipMemcpy(d, h.data(), bytes, hipMemcpyHostToDevice);
   }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int lds_kb : {16, 18, 32}) {
-    for (int rows = 0; rows < 2; ++rows) {
+  for (int lds_kb : {16}) {
+    for (int rows = 0; rows < 3; ++rows) {
       for (int apt : {64, 128, 256}) {
         float best = 1e9;
         for (int rep = 0; rep < 5; ++rep) {
           hipEventRecord(e0);
-          if (rows) hipLaunchKernelGGL(probe<1>, dim3(A / apt), dim3(64), lds_kb * 1024, 0, d, A, L, apt, sink);
+          if (rows == 2) hipLaunchKernelGGL(probe<2>, dim3(A / apt), dim3(64), lds_kb * 1024, 0, d, A, L, apt, sink);
+          else if (rows) hipLaunchKernelGGL(probe<1>, dim3(A / apt), dim3(64), lds_kb * 1024, 0, d, A, L, apt, sink);
           else hipLaunchKernelGGL(probe<0>, dim3(A / apt), dim3(64), lds_kb * 1024, 0, d, A, L, apt, sink);
           hipEventRecord(e1); hipEventSynchronize(e1);
           float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;

@@ -39,6 +39,8 @@ EXPORTS = (
     "surge_replay_snapshot",
     "surge_replay_device_state",
     "surge_replay_encode_json",
+    "surge_replay_pack_states",
+    "surge_replay_unpack_states",
     "surge_replay_partition_hash",
     "surge_replay_partition_hash_device",
     "surge_replay_set_state_out",
@@ -153,6 +155,8 @@ def load() -> ctypes.CDLL:
         "surge_replay_snapshot": ([vp, vp, vp], i32),
         "surge_replay_device_state": ([vp, ctypes.POINTER(vp), ctypes.POINTER(i64)], i32),
         "surge_replay_encode_json": ([vp, vp, vp, vp, vp, i64, vp, ctypes.POINTER(i64)], i32),
+        "surge_replay_pack_states": ([vp, vp, i64, vp, vp], i32),
+        "surge_replay_unpack_states": ([vp, vp, i64, vp, vp], i32),
         "surge_replay_partition_hash": ([vp, vp, i64, i32, vp], i32),
         "surge_replay_partition_hash_device": ([vp, vp, vp, i64, i32, vp], i32),
         "surge_replay_set_state_out": ([vp, vp], i32),

@@ -888,6 +888,24 @@ int32_t surge_replay_set_state_out(surge_replay_handle* h, void* d_state_out) {
   return SURGE_OK;
 }
 
+int32_t surge_replay_pack_states(surge_replay_handle* h, const void* d_states64, int64_t n, void* d_packed40, void* hip_stream) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (n < 0 || (n > 0 && (!d_states64 || !d_packed40))) return fail(h, SURGE_E_INVALID, "bad argument");
+  if (((uintptr_t)d_states64 & 7) || ((uintptr_t)d_packed40 & 7)) return fail(h, SURGE_E_INVALID, "buffers must be 8-byte aligned");
+  DeviceGuard g(h->device);
+  HIPCHK(h, launch_pack_states(d_states64, n, d_packed40, false, hip_stream ? (hipStream_t)hip_stream : h->stream));
+  return SURGE_OK;
+}
+
+int32_t surge_replay_unpack_states(surge_replay_handle* h, const void* d_packed40, int64_t n, void* d_states64, void* hip_stream) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (n < 0 || (n > 0 && (!d_states64 || !d_packed40))) return fail(h, SURGE_E_INVALID, "bad argument");
+  if (((uintptr_t)d_states64 & 7) || ((uintptr_t)d_packed40 & 7)) return fail(h, SURGE_E_INVALID, "buffers must be 8-byte aligned");
+  DeviceGuard g(h->device);
+  HIPCHK(h, launch_pack_states(d_packed40, n, d_states64, true, hip_stream ? (hipStream_t)hip_stream : h->stream));
+  return SURGE_OK;
+}
+
 int32_t surge_replay_stream_probe(surge_replay_handle* h, const void* d_src, int64_t n_bytes, double* ms_out) {
   if (!h || !d_src || !ms_out) return fail(h, SURGE_E_INVALID, "NULL argument");
   if (n_bytes < 16 || (n_bytes & 15) || ((uintptr_t)d_src & 15)) return fail(h, SURGE_E_INVALID, "n_bytes/pointer must be 16-byte multiples");

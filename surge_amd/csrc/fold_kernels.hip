@@ -1106,6 +1106,22 @@ __global__ void scan_add_kernel(int64_t* __restrict__ v, int64_t n, const int64_
   if (i < n) v[i] += totals_excl[blockIdx.x];
 }
 
+// snapshot wire form: 5 of the 8 eight-byte words of a state (the reserved tail is always zero)
+__global__ void pack_states_kernel(const uint64_t* __restrict__ in, int64_t n, uint64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 8-byte word of the packed form
+  if (i >= n * 5) return;
+  const int64_t a = i / 5;
+  out[i] = in[a * 8 + (i - a * 5)];
+}
+
+__global__ void unpack_states_kernel(const uint64_t* __restrict__ in, int64_t n, uint64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 8-byte word of the 64-byte form
+  if (i >= n * 8) return;
+  const int64_t a = i >> 3;
+  const int k = (int)(i & 7);
+  out[i] = k < 5 ? in[a * 5 + k] : 0ull;
+}
+
 __global__ void gather_states_kernel(const uint4* __restrict__ states, const int64_t* __restrict__ idx, int64_t n,
                                      uint4* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16 B quarter of a state per thread
@@ -1260,6 +1276,15 @@ hipError_t launch_json_encode(const surge_json_template& tmpl, const uint4* stat
   } else {
     hipLaunchKernelGGL(json_encode_kernel<true>, dim3(blocks), dim3(256), 0, stream, t, states, n, keys, key_off, d_len_off, out);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_states(const void* in64, int64_t n, void* out40, bool unpack, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  if (unpack)
+    hipLaunchKernelGGL(unpack_states_kernel, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, stream, (const uint64_t*)in64, n, (uint64_t*)out40);
+  else
+    hipLaunchKernelGGL(pack_states_kernel, dim3((unsigned)((n * 5 + 255) / 256)), dim3(256), 0, stream, (const uint64_t*)in64, n, (uint64_t*)out40);
   return hipGetLastError();
 }
 

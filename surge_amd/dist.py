@@ -108,7 +108,7 @@ class SnapshotGather:
     writes the other snapshot buffer.
     """
 
-    def __init__(self, n_local: int, device, group=None, mode: Optional[str] = None):
+    def __init__(self, n_local: int, device, group=None, mode: Optional[str] = None, engine=None, packed: Optional[bool] = None):
         import os
 
         import torch
@@ -118,6 +118,10 @@ class SnapshotGather:
         # exactly one peer's shard concurrently (a ring all-gather would push all N-1 shards through one link
         # pair).  "allgather": the library collective.
         self.mode = mode or os.environ.get("SURGE_SNAPSHOT_GATHER", "p2p")
+        # shards travel in the 40-byte wire form (the 24-byte reserved tail of a state is always zero) and are
+        # expanded back to 64 bytes on arrival: 37.5 % less xGMI traffic, which is what bounds the exchange
+        self.engine = engine
+        self.packed = (os.environ.get("SURGE_SNAPSHOT_PACKED", "1") == "1") if packed is None else packed
 
         self.dist, self.torch = dist, torch
         self.group = group
@@ -132,6 +136,11 @@ class SnapshotGather:
         self.n_local = n_local
         self.out = [torch.zeros((self.world, self.max_count, 64), dtype=torch.uint8, device=self.device) for _ in range(2)]
         self.cuda = self.device.type == "cuda"
+        if self.cuda and self.engine is None:
+            self.packed = False  # the pack / unpack kernels are launched through the engine's C ABI
+        if self.packed:
+            self.wire = [torch.zeros((self.world, self.max_count, 40), dtype=torch.uint8, device=self.device) for _ in range(2)]
+            self.local_wire = [torch.zeros((self.max_count, 40), dtype=torch.uint8, device=self.device) for _ in range(2)]
         # gloo cannot all-gather device tensors: stage through the host (debug / single-GPU rehearsal only)
         self.stage_host = self.cuda and dist.get_backend(group) == "gloo"
         self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
@@ -153,28 +162,38 @@ class SnapshotGather:
             with self.torch.cuda.stream(self.stream):
                 if ready_event is not None:
                     self.stream.wait_event(ready_event)
-                if self.mode == "p2p":
-                    self._p2p(slot, local_padded)
+                if self.packed:
+                    self.engine.pack_states(local_padded, self.local_wire[slot], stream=self.stream)
+                    self._exchange(self.wire[slot], self.local_wire[slot])
+                    self.engine.unpack_states(self.wire[slot].view(-1, 40), self.out[slot].view(-1, 64), stream=self.stream)
                 else:
-                    self.dist.all_gather_into_tensor(self.out[slot].view(-1), local_padded.view(-1), group=self.group)
+                    self._exchange(self.out[slot], local_padded)
                 ev = self.torch.cuda.Event()
                 ev.record(self.stream)
                 self.done[slot] = ev
-        elif self.mode == "p2p":
-            self._p2p(slot, local_padded)
+        elif self.packed:
+            self.local_wire[slot].copy_(local_padded[:, :40])
+            self._exchange(self.wire[slot], self.local_wire[slot])
+            self.out[slot][:, :, :40] = self.wire[slot]
+            self.out[slot][:, :, 40:] = 0
         else:
-            parts = [self.out[slot][r] for r in range(self.world)]
-            self.dist.all_gather(parts, local_padded, group=self.group)
+            self._exchange(self.out[slot], local_padded)
 
-    def _p2p(self, slot: int, local_padded) -> None:
+    def _exchange(self, dst, src) -> None:
+        """dst[r] := rank r's src, for every rank."""
         dist = self.dist
-        out = self.out[slot]
-        out[self.rank].copy_(local_padded)
+        if self.mode != "p2p":
+            if self.cuda:
+                dist.all_gather_into_tensor(dst.view(-1), src.view(-1), group=self.group)
+            else:
+                dist.all_gather([dst[r] for r in range(self.world)], src, group=self.group)
+            return
+        dst[self.rank].copy_(src)
         ops = []
         for d in range(1, self.world):  # skewed peer order: rank r talks to r+d / r-d in step d
             to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
-            ops.append(dist.P2POp(dist.isend, local_padded, to, self.group))
-            ops.append(dist.P2POp(dist.irecv, out[frm], frm, self.group))
+            ops.append(dist.P2POp(dist.isend, src, to, self.group))
+            ops.append(dist.P2POp(dist.irecv, dst[frm], frm, self.group))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()

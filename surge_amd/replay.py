@@ -227,6 +227,17 @@ class ReplayEngine:
         holder = type("_DevView", (), {"__cuda_array_interface__": iface})()
         return torch.as_tensor(holder, device=f"cuda:{self.device}")
 
+    def pack_states(self, states64, packed40, stream=None) -> None:
+        """``n x 64`` -> ``n x 40`` bytes (snapshot wire form), on ``stream`` (default: the engine's)."""
+        n = states64.shape[0]
+        sp = None if stream is None else ctypes.c_void_p(stream.cuda_stream)
+        self._check(self._lib.surge_replay_pack_states(self._h, _dev_ptr(states64, n * 64), n, _dev_ptr(packed40, n * 40), sp))
+
+    def unpack_states(self, packed40, states64, stream=None) -> None:
+        n = states64.shape[0]
+        sp = None if stream is None else ctypes.c_void_p(stream.cuda_stream)
+        self._check(self._lib.surge_replay_unpack_states(self._h, _dev_ptr(packed40, n * 40), n, _dev_ptr(states64, n * 64), sp))
+
     def set_state_out(self, tensor) -> None:
         """Redirect the next folds' output to ``tensor`` (``n_agg x 64`` bytes on the device)."""
         self._check(self._lib.surge_replay_set_state_out(self._h, _dev_ptr(tensor, self.n_agg * 64)))

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, mode):
+def _worker(rank, world, port, out_dir, mode, packed):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -35,7 +35,7 @@ def _worker(rank, world, port, out_dir, mode):
     ids = torch.from_numpy(local_aggregate_ids(N_GLOBAL, N_PART, rank, world, "cpu"))
     seg_off, events = synth.fixed_log_for_aggregates_device(ids, L, SEED)
     states = oracle.fold_csr(seg_off.numpy(), synth.to_event_records(events))
-    gather = SnapshotGather(int(ids.numel()), "cpu", mode=mode)
+    gather = SnapshotGather(int(ids.numel()), "cpu", mode=mode, packed=packed)
     bufs = gather.make_local_buffers()
     bufs[0][: ids.numel()] = torch.from_numpy(states.view(np.uint8).reshape(-1, 64))
     gather.launch(0, bufs[0])
@@ -53,8 +53,8 @@ def _worker(rank, world, port, out_dir, mode):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("mode", ["p2p", "allgather"])
-def test_two_rank_sharded_replay_and_all_gather(tmp_path, mode):
+@pytest.mark.parametrize("mode,packed", [("p2p", True), ("allgather", False), ("p2p", False)])
+def test_two_rank_sharded_replay_and_all_gather(tmp_path, mode, packed):
     sys.path.insert(0, ROOT)
     from oracle import oracle
     from surge_amd import synth
@@ -62,7 +62,7 @@ def test_two_rank_sharded_replay_and_all_gather(tmp_path, mode):
     from surge_amd.kafka import partition_for_keys
 
     world, port = 2, _free_port()
-    mp.start_processes(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), mode, packed), nprocs=world, join=True, start_method="spawn")
     so, ev = synth.fixed_log(N_GLOBAL, L, SEED)
     expected = oracle.fold_csr(so, ev).view(np.uint8).reshape(-1, 64)
     ids = [np.load(tmp_path / f"ids{r}.npy") for r in range(world)]
