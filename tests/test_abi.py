@@ -82,3 +82,34 @@ def test_product_code_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not pat.search(text), f"{f}: product code must not import, link or call the oracle"
+
+
+def _build_c_demo(tmp_path):
+    import subprocess
+
+    exe = str(tmp_path / "c_host_demo")
+    lib_dir = os.path.join(ROOT, "surge_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_host_demo.c"),
+           "-L" + lib_dir, "-lsurge_replay", "-Wl,-rpath," + lib_dir, "-L/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True)
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    return subprocess.run([exe], capture_output=True, text=True, env=env)
+
+
+def test_plain_c_host_links_and_fails_loudly_without_a_gpu(tmp_path):
+    """The boundary is a C ABI: a C99 program with no Python/torch in the process links and runs it."""
+    import torch
+
+    _native.build()
+    res = _build_c_demo(tmp_path)
+    if torch.cuda.is_available():
+        assert res.returncode == 0, res.stdout + res.stderr
+    else:
+        assert res.returncode == 2 and "no CPU fallback" in res.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_host_replays_the_reference_known_answers(tmp_path):
+    res = _build_c_demo(tmp_path)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.count("PASS") == 6 and "FAIL" not in res.stdout
