@@ -113,3 +113,36 @@ def test_plain_c_host_replays_the_reference_known_answers(tmp_path):
     res = _build_c_demo(tmp_path)
     assert res.returncode == 0, res.stdout + res.stderr
     assert res.stdout.count("PASS") == 6 and "FAIL" not in res.stdout
+
+
+def _build_cpp_demo(tmp_path):
+    import subprocess
+
+    exe = str(tmp_path / "cpp_host_demo")
+    lib_dir = os.path.join(ROOT, "surge_amd")
+    cmd = ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "cpp_host_demo.cpp"),
+           "-L" + lib_dir, "-lsurge_replay", "-Wl,-rpath," + lib_dir, "-L/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True)
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    return subprocess.run([exe], capture_output=True, text=True, env=env)
+
+
+def test_cpp_host_mirror_compiles_and_partitions_like_the_reference(tmp_path):
+    """include/surge_replay.hpp (the compiled-language mirror of the plugin traits) builds warning-free; its
+    partitioner (CPU entry point) reproduces the pinned stringHash answers; the store fails loudly without a GPU."""
+    import torch
+
+    _native.build()
+    res = _build_cpp_demo(tmp_path)
+    assert res.stdout.count("PASS") >= 4 and "FAIL" not in res.stdout, res.stdout + res.stderr
+    if torch.cuda.is_available():
+        assert res.returncode == 0, res.stdout + res.stderr
+    else:
+        assert res.returncode == 2 and "no CPU fallback" in res.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_serves_get_aggregate_bytes_from_the_gpu_fold(tmp_path):
+    res = _build_cpp_demo(tmp_path)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "ALL PASS" in res.stdout and res.stdout.count("PASS  ") == 11 and "FAIL" not in res.stdout
