@@ -1,5 +1,5 @@
 // cpp_host_demo.cpp — the reference's Counter model written against the C++ host mirror (include/surge_replay.hpp):
-// the model keeps its literal handleEvent (TestBoundedContext.scala:77-89) and adds the replay declaration; the
+// the model keeps its literal handleEvent (scaladsl TestBoundedContext.scala:77-89) and adds the replay declaration; the
 // store serves getAggregateBytes (AggregateStateStoreKafkaStreams.scala:83-85) from the GPU fold.
 //
 //   g++ -std=c++17 -Iinclude examples/cpp_host_demo.cpp -Lsurge_amd -lsurge_replay -Wl,-rpath,$PWD/surge_amd -o /tmp/cpp_host_demo
@@ -33,7 +33,7 @@ struct CounterModel : surge::ReplayableCommandModel<State, BaseTestEvent> {
     const State current = agg.value_or(State{id, 0, 0});
     if (const auto* e = std::get_if<CountIncremented>(&evt)) return State{current.aggregateId, current.count + e->incrementBy, e->sequenceNumber};
     if (const auto* e = std::get_if<CountDecremented>(&evt)) return State{current.aggregateId, current.count - e->decrementBy, e->sequenceNumber};
-    if (std::holds_alternative<NoOpEvent>(evt)) return agg;
+    if (std::holds_alternative<NoOpEvent>(evt)) return current;  // Some(current): a no-op still materialises the aggregate
     throw std::runtime_error("This is expected");
   }
   // the same handler as data: what each event type does to the fixed-width state
@@ -57,7 +57,7 @@ struct CounterModel : surge::ReplayableCommandModel<State, BaseTestEvent> {
   State stateFromFixed(const std::string& id, const surge_state64& s) const override { return State{id, s.count, s.version}; }
 };
 
-// Json.toJson(state) with play-json's compact printer (TestBoundedContext.scala:146-152); ids here are plain ASCII
+// Json.toJson(state) with play-json's compact printer (scaladsl TestBoundedContext.scala:125-129); ids here are plain ASCII
 struct CounterFormat : surge::SurgeAggregateWriteFormatting<State> {
   surge::SerializedAggregate writeState(const State& s) const override {
     const std::string js = "{\"aggregateId\":\"" + s.aggregateId + "\",\"count\":" + std::to_string(s.count) + ",\"version\":" + std::to_string(s.version) + "}";
@@ -118,7 +118,8 @@ int main() {
     all = all && (want.has_value() == got.has_value()) && (!want || fmt->writeState(*want).value == *got);
   }
   check(all, "getAggregateBytes == writeState(events.foldLeft(None)(handleEvent)) for every aggregate");
-  check(!store->getAggregateBytes("c").has_value(), "only no-op events: the aggregate stays None");
+  const std::optional<std::vector<uint8_t>> c = store->getAggregateBytes("c");
+  check(c && std::string(c->begin(), c->end()) == "{\"aggregateId\":\"c\",\"count\":0,\"version\":0}", "only no-op events: materialised as State(id, 0, 0)");
   check(!store->getAggregateBytes("never-seen").has_value(), "unknown aggregate id is a KTable miss");
   bool threw = false;
   try { store->getAggregateBytes("poisoned"); } catch (const surge::AggregateInitializationException&) { threw = true; }

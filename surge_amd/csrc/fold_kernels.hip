@@ -1032,16 +1032,27 @@ __device__ __forceinline__ void json_int_value(const uint8_t* st, uint32_t kind,
   }
 }
 
+// Pass 1 (WRITE = false): the serialized length of every aggregate.  Pass 2 (WRITE = true), after the
+// exclusive scan turned lengths into offsets: a block's 256 values are contiguous in the output, so they are
+// composed in LDS (placed so that LDS offset == global address mod 16) and then stored as whole 16-byte
+// words by the block — per-thread byte stores to global were the bottleneck of the first version.  A block
+// whose output does not fit the staging buffer (very long keys) writes straight to global.
+constexpr int kJsonBlock = 256;
+constexpr int kJsonStageBytes = 32 * 1024;
+
 template <bool WRITE>
-__global__ void json_encode_kernel(const JsonTemplateDev t, const uint4* __restrict__ states, int64_t n,
-                                   const uint8_t* __restrict__ keys, const int64_t* __restrict__ key_off,
-                                   int64_t* __restrict__ len_or_off, uint8_t* __restrict__ out) {
-  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= n) return;
-  const uint8_t* st = (const uint8_t*)(states + a * 4);
+__global__ void __launch_bounds__(kJsonBlock) json_encode_kernel(const JsonTemplateDev t, const uint4* __restrict__ states, int64_t n,
+                                                                 const uint8_t* __restrict__ keys, const int64_t* __restrict__ key_off,
+                                                                 int64_t* __restrict__ len_or_off, uint8_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t json_stage[];
+  const int64_t a0 = (int64_t)blockIdx.x * kJsonBlock;
+  const int64_t a = a0 + threadIdx.x;
+  const bool live = a < n;
+  const uint8_t* st = (const uint8_t*)(states + (live ? a : 0) * 4);
   const uint32_t fl = *(const uint32_t*)(st + 36);
-  const bool emit = (fl & FL_PRESENT) && !(fl & FL_POISONED);
+  const bool emit = live && (fl & FL_PRESENT) && !(fl & FL_POISONED);
   if (!WRITE) {
+    if (!live) return;
     int64_t len = 0;
     if (emit) {
       for (uint32_t i = 0; i < t.n_parts; ++i) {
@@ -1061,24 +1072,42 @@ __global__ void json_encode_kernel(const JsonTemplateDev t, const uint4* __restr
     len_or_off[a] = len;
     return;
   }
-  if (!emit) return;
-  uint8_t* o = out + len_or_off[a];
-  for (uint32_t i = 0; i < t.n_parts; ++i) {
-    const uint32_t k = t.kind[i];
-    if (k == SURGE_JP_LITERAL) {
-      for (uint32_t b = 0; b < t.lit_len[i]; ++b) *o++ = t.literals[t.lit_off[i] + b];
-    } else if (k == SURGE_JP_KEY) {
-      *o++ = '"';
-      for (int64_t b = key_off[a]; b < key_off[a + 1]; ++b) o = json_put_escaped(o, keys[b]);
-      *o++ = '"';
-    } else {
-      bool neg; uint64_t mag;
-      json_int_value(st, k, t.field_offset[i], &neg, &mag);
-      if (neg) *o++ = '-';
-      const int nd = dec_len_u64(mag);
-      for (int d = nd - 1; d >= 0; --d) { o[d] = (uint8_t)('0' + (int)(mag % 10ull)); mag /= 10ull; }
-      o += nd;
+  const int64_t a1 = (a0 + kJsonBlock < n) ? a0 + kJsonBlock : n;
+  const int64_t base = len_or_off[a0], end = len_or_off[a1];  // [n] holds the total
+  const uint32_t shift = (uint32_t)((uintptr_t)(out + base) & 15u);
+  const bool staged = (end - base) + shift <= kJsonStageBytes;
+  if (emit) {
+    uint8_t* o = staged ? json_stage + shift + (len_or_off[a] - base) : out + len_or_off[a];
+    for (uint32_t i = 0; i < t.n_parts; ++i) {
+      const uint32_t k = t.kind[i];
+      if (k == SURGE_JP_LITERAL) {
+        for (uint32_t b = 0; b < t.lit_len[i]; ++b) *o++ = t.literals[t.lit_off[i] + b];
+      } else if (k == SURGE_JP_KEY) {
+        *o++ = '"';
+        for (int64_t b = key_off[a]; b < key_off[a + 1]; ++b) o = json_put_escaped(o, keys[b]);
+        *o++ = '"';
+      } else {
+        bool neg; uint64_t mag;
+        json_int_value(st, k, t.field_offset[i], &neg, &mag);
+        if (neg) *o++ = '-';
+        const int nd = dec_len_u64(mag);
+        for (int d = nd - 1; d >= 0; --d) { o[d] = (uint8_t)('0' + (int)(mag % 10ull)); mag /= 10ull; }
+        o += nd;
+      }
     }
+  }
+  if (!staged) return;  // block-uniform
+  __syncthreads();
+  const uint32_t total = (uint32_t)(end - base);
+  uint8_t* g = out + base - shift;                    // 16-byte aligned; LDS offset i <-> g[i]
+  const uint32_t lo = shift, hi = shift + total;      // valid span in that frame
+  const uint32_t body_lo = (lo + 15u) & ~15u, body_hi = hi & ~15u;
+  if (body_lo <= body_hi) {
+    for (uint32_t i = lo + threadIdx.x; i < body_lo; i += kJsonBlock) g[i] = json_stage[i];
+    for (uint32_t i = body_lo + threadIdx.x * 16u; i < body_hi; i += kJsonBlock * 16u) *(uint4*)(g + i) = *(const uint4*)(json_stage + i);
+    for (uint32_t i = body_hi + threadIdx.x; i < hi; i += kJsonBlock) g[i] = json_stage[i];
+  } else {
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += kJsonBlock) g[i] = json_stage[i];
   }
 }
 
@@ -1268,13 +1297,13 @@ hipError_t launch_json_encode(const surge_json_template& tmpl, const uint4* stat
   for (int i = 0; i < 256; ++i) t.literals[i] = tmpl.literals[i];
   const unsigned blocks = (unsigned)((n + 255) / 256);
   if (!write_pass) {
-    hipLaunchKernelGGL(json_encode_kernel<false>, dim3(blocks), dim3(256), 0, stream, t, states, n, keys, key_off, d_len_off, out);
+    hipLaunchKernelGGL(json_encode_kernel<false>, dim3(blocks), dim3(kJsonBlock), 0, stream, t, states, n, keys, key_off, d_len_off, out);
     const int64_t nb = (n + kScanBlock - 1) / kScanBlock;
     hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, stream, d_len_off, n, d_totals);
     hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, stream, d_totals, nb);  // exclusive scan of block totals, grand total at [nb]
     hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, stream, d_len_off, n, d_totals);
   } else {
-    hipLaunchKernelGGL(json_encode_kernel<true>, dim3(blocks), dim3(256), 0, stream, t, states, n, keys, key_off, d_len_off, out);
+    hipLaunchKernelGGL(json_encode_kernel<true>, dim3(blocks), dim3(kJsonBlock), kJsonStageBytes + 16, stream, t, states, n, keys, key_off, d_len_off, out);
   }
   return hipGetLastError();
 }

@@ -328,6 +328,34 @@ def test_gpu_json_encoder_matches_play_json_text_of_the_counter_fixture():
     assert 0 < n_emitted < n
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,long_every", [(1, 0), (255, 0), (256, 0), (257, 0), (1500, 0), (1500, 3)])
+def test_gpu_json_encoder_block_staging_and_long_key_fallback(n, long_every):
+    # the write pass composes a block's 256 values in LDS; blocks whose text exceeds the staging buffer
+    # (every third key ~600 bytes of escapes here) write straight to global.  Both must give the same bytes.
+    import torch
+
+    from surge_amd.encode import JsonTemplate, encode_states, key_table_utf8
+
+    rng = np.random.default_rng(n * 7 + long_every)
+    keys = [f"k{i}" * (1 + i % 5) for i in range(n)]
+    if long_every:
+        for i in range(0, n, long_every):
+            keys[i] = ("\x02long\"" * 40) + str(i)
+    lens = rng.integers(0, 6, size=n)
+    so, ev = synth.csr_log(lens, 21, synth.STRESS_MIX)
+    with ReplayEngine() as eng:
+        eng.load_csr(so, ev)
+        eng.fold()
+        states = eng.snapshot()
+        data, off = key_table_utf8(keys)
+        d_out, d_off = encode_states(eng, JsonTemplate.counter(), torch.from_numpy(data).cuda(), torch.from_numpy(off).cuda())
+        out, offs = d_out.cpu().numpy().tobytes(), d_off.cpu().numpy()
+    want = b"".join(oracle.counter_state_json(keys[a], int(states[a]["count"]), int(states[a]["version"]))
+                    for a in range(n) if int(states[a]["flags"]) == S.STATE_PRESENT)
+    assert out[: offs[n]] == want and offs[n] == len(want)
+
+
 def test_append_fold_rejects_a_batch_that_names_an_aggregate_twice():
     so, ev = synth.fixed_log(10, 16, 4)
     with ReplayEngine() as eng:
