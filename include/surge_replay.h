@@ -276,6 +276,16 @@ int32_t surge_replay_encode_json(surge_replay_handle* h, const surge_json_templa
                                  const int64_t* d_key_off, uint8_t* d_out, int64_t out_capacity, int64_t* d_out_off,
                                  int64_t* total_bytes_out);
 
+/* Same passes, but every emitted value is wrapped in the multilanguage module's protobuf message
+ *   message State { string aggregateId = 1; bytes payload = 2; }   (multilanguage-protocol.proto:7-10)
+ * = what GenericSurgeCommandBusinessLogic.aggregateWriteFormatting stores (pbState.toByteArray,
+ * GenericSurgeCommandBusinessLogic.scala:36-39): 0x0A varint(len id) id 0x12 varint(len payload) payload, with
+ * payload = the template's text (the SDK's serialized state) and the raw UTF-8 aggregate id; proto3 omits an
+ * empty field.  None / poisoned aggregates still get zero bytes. */
+int32_t surge_replay_encode_protobuf_state(surge_replay_handle* h, const surge_json_template* payload_tmpl,
+                                           const uint8_t* d_keys_utf8, const int64_t* d_key_off, uint8_t* d_out,
+                                           int64_t out_capacity, int64_t* d_out_off, int64_t* total_bytes_out);
+
 /* ---- shard map (R15) --------------------------------------------------------------
  * part_out[i] = abs(MurmurHash3.stringHash(str_i.takeWhile(_ != ':')) % n_partitions)
  * (KafkaPartitioner.scala:8,38-42) for n strings given as UTF-16 code units

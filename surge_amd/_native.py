@@ -39,6 +39,7 @@ EXPORTS = (
     "surge_replay_snapshot",
     "surge_replay_device_state",
     "surge_replay_encode_json",
+    "surge_replay_encode_protobuf_state",
     "surge_replay_pack_states",
     "surge_replay_unpack_states",
     "surge_replay_partition_hash",
@@ -155,6 +156,7 @@ def load() -> ctypes.CDLL:
         "surge_replay_snapshot": ([vp, vp, vp], i32),
         "surge_replay_device_state": ([vp, ctypes.POINTER(vp), ctypes.POINTER(i64)], i32),
         "surge_replay_encode_json": ([vp, vp, vp, vp, vp, i64, vp, ctypes.POINTER(i64)], i32),
+        "surge_replay_encode_protobuf_state": ([vp, vp, vp, vp, vp, i64, vp, ctypes.POINTER(i64)], i32),
         "surge_replay_pack_states": ([vp, vp, i64, vp, vp], i32),
         "surge_replay_unpack_states": ([vp, vp, i64, vp, vp], i32),
         "surge_replay_partition_hash": ([vp, vp, i64, i32, vp], i32),

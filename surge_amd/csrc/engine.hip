@@ -603,12 +603,14 @@ int32_t surge_replay_append_fold(surge_replay_handle* h, const int64_t* group_ag
     if (group_off[gidx + 1] <= group_off[gidx]) return fail(h, SURGE_E_INVALID, "batch groups must be non-empty and ordered");
     if (group_agg[gidx] < 0 || group_agg[gidx] >= h->n_agg) return fail(h, SURGE_E_RANGE, "group_agg out of range");
   }
-  {
+  try {
     // an aggregate may appear in one group only: two groups would race on the same resident state
     std::vector<int64_t> seen(group_agg, group_agg + n_groups);
     std::sort(seen.begin(), seen.end());
     if (std::adjacent_find(seen.begin(), seen.end()) != seen.end())
       return fail(h, SURGE_E_INVALID, "an aggregate appears in more than one group of the batch");
+  } catch (const std::bad_alloc&) {
+    return fail(h, SURGE_E_NOMEM, "out of host memory while validating the micro-batch");
   }
   DeviceGuard g(h->device);
   HIPCHK(h, h->batch_group_agg.reserve((size_t)n_groups * 8));
@@ -742,9 +744,9 @@ int32_t surge_replay_gather(surge_replay_handle* h, const int64_t* agg_idx, int6
   return SURGE_OK;
 }
 
-int32_t surge_replay_encode_json(surge_replay_handle* h, const surge_json_template* tmpl, const uint8_t* d_keys_utf8,
-                                 const int64_t* d_key_off, uint8_t* d_out, int64_t out_capacity, int64_t* d_out_off,
-                                 int64_t* total_bytes_out) {
+static int32_t encode_states(surge_replay_handle* h, const surge_json_template* tmpl, const uint8_t* d_keys_utf8,
+                             const int64_t* d_key_off, uint8_t* d_out, int64_t out_capacity, int64_t* d_out_off,
+                             int64_t* total_bytes_out, uint32_t envelope) {
   if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
   if (!h->bound || h->st.n_folds == 0) return fail(h, SURGE_E_STATE, "encode_json before fold");
   if (!tmpl || !d_key_off || !d_out_off || !total_bytes_out) return fail(h, SURGE_E_INVALID, "NULL argument");
@@ -761,7 +763,7 @@ int32_t surge_replay_encode_json(surge_replay_handle* h, const surge_json_templa
   const int64_t nb = (h->n_agg + 1023) / 1024;
   HIPCHK(h, h->scan_totals.reserve((size_t)(nb + 1) * 8));
   HIPCHK(h, launch_json_encode(*tmpl, h->d_state, h->n_agg, d_keys_utf8, d_key_off, d_out_off, (int64_t*)h->scan_totals.ptr,
-                               d_out, false, h->stream));
+                               d_out, false, envelope, h->stream));
   int64_t total = 0;
   HIPCHK(h, hipMemcpyAsync(&total, (int64_t*)h->scan_totals.ptr + nb, 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -773,9 +775,21 @@ int32_t surge_replay_encode_json(surge_replay_handle* h, const surge_json_templa
   }
   if (total > 0 && !d_out) return fail(h, SURGE_E_INVALID, "d_out is NULL");
   HIPCHK(h, launch_json_encode(*tmpl, h->d_state, h->n_agg, d_keys_utf8, d_key_off, d_out_off, (int64_t*)h->scan_totals.ptr,
-                               d_out, true, h->stream));
+                               d_out, true, envelope, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return SURGE_OK;
+}
+
+int32_t surge_replay_encode_json(surge_replay_handle* h, const surge_json_template* tmpl, const uint8_t* d_keys_utf8,
+                                 const int64_t* d_key_off, uint8_t* d_out, int64_t out_capacity, int64_t* d_out_off,
+                                 int64_t* total_bytes_out) {
+  return encode_states(h, tmpl, d_keys_utf8, d_key_off, d_out, out_capacity, d_out_off, total_bytes_out, 0u);
+}
+
+int32_t surge_replay_encode_protobuf_state(surge_replay_handle* h, const surge_json_template* payload_tmpl,
+                                           const uint8_t* d_keys_utf8, const int64_t* d_key_off, uint8_t* d_out,
+                                           int64_t out_capacity, int64_t* d_out_off, int64_t* total_bytes_out) {
+  return encode_states(h, payload_tmpl, d_keys_utf8, d_key_off, d_out, out_capacity, d_out_off, total_bytes_out, 1u);
 }
 
 int32_t surge_replay_device_state(surge_replay_handle* h, void** d_states, int64_t* n_agg) {

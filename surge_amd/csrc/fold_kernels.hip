@@ -980,6 +980,7 @@ __global__ void __launch_bounds__(kWave) stream_probe_lds_kernel(const uint4* __
 // ---- N3: fixed 64-byte state -> serialized text (two passes around an exclusive scan) -----------------
 struct JsonTemplateDev {
   uint32_t n_parts;
+  uint32_t envelope;  // 0: the template text itself; 1: protobuf State{aggregateId = 1, payload = 2 (the text)}
   uint32_t kind[SURGE_JSON_MAX_PARTS], field_offset[SURGE_JSON_MAX_PARTS], lit_off[SURGE_JSON_MAX_PARTS],
       lit_len[SURGE_JSON_MAX_PARTS];
   uint8_t literals[256];
@@ -1032,6 +1033,38 @@ __device__ __forceinline__ void json_int_value(const uint8_t* st, uint32_t kind,
   }
 }
 
+// length of the template text for aggregate a
+__device__ __forceinline__ int64_t json_text_len(const JsonTemplateDev& t, const uint8_t* st, const uint8_t* __restrict__ keys,
+                                                 const int64_t* __restrict__ key_off, int64_t a) {
+  int64_t len = 0;
+  for (uint32_t i = 0; i < t.n_parts; ++i) {
+    const uint32_t k = t.kind[i];
+    if (k == SURGE_JP_LITERAL) {
+      len += t.lit_len[i];
+    } else if (k == SURGE_JP_KEY) {
+      len += 2;
+      for (int64_t b = key_off[a]; b < key_off[a + 1]; ++b) len += json_escaped_len(keys[b]);
+    } else {
+      bool neg; uint64_t mag;
+      json_int_value(st, k, t.field_offset[i], &neg, &mag);
+      len += dec_len_u64(mag) + (neg ? 1 : 0);
+    }
+  }
+  return len;
+}
+
+__device__ __forceinline__ int varint_len(uint64_t v) {
+  int n = 1;
+  while (v >= 0x80ull) { v >>= 7; ++n; }
+  return n;
+}
+
+__device__ __forceinline__ uint8_t* put_varint(uint8_t* o, uint64_t v) {
+  while (v >= 0x80ull) { *o++ = (uint8_t)(v | 0x80ull); v >>= 7; }
+  *o++ = (uint8_t)v;
+  return o;
+}
+
 // Pass 1 (WRITE = false): the serialized length of every aggregate.  Pass 2 (WRITE = true), after the
 // exclusive scan turned lengths into offsets: a block's 256 values are contiguous in the output, so they are
 // composed in LDS (placed so that LDS offset == global address mod 16) and then stored as whole 16-byte
@@ -1055,18 +1088,10 @@ __global__ void __launch_bounds__(kJsonBlock) json_encode_kernel(const JsonTempl
     if (!live) return;
     int64_t len = 0;
     if (emit) {
-      for (uint32_t i = 0; i < t.n_parts; ++i) {
-        const uint32_t k = t.kind[i];
-        if (k == SURGE_JP_LITERAL) {
-          len += t.lit_len[i];
-        } else if (k == SURGE_JP_KEY) {
-          len += 2;
-          for (int64_t b = key_off[a]; b < key_off[a + 1]; ++b) len += json_escaped_len(keys[b]);
-        } else {
-          bool neg; uint64_t mag;
-          json_int_value(st, k, t.field_offset[i], &neg, &mag);
-          len += dec_len_u64(mag) + (neg ? 1 : 0);
-        }
+      len = json_text_len(t, st, keys, key_off, a);
+      if (t.envelope == 1) {  // proto3: empty fields are not written
+        const int64_t idlen = key_off[a + 1] - key_off[a];
+        len = (idlen ? 1 + varint_len((uint64_t)idlen) + idlen : 0) + (len ? 1 + varint_len((uint64_t)len) + len : 0);
       }
     }
     len_or_off[a] = len;
@@ -1078,6 +1103,19 @@ __global__ void __launch_bounds__(kJsonBlock) json_encode_kernel(const JsonTempl
   const bool staged = (end - base) + shift <= kJsonStageBytes;
   if (emit) {
     uint8_t* o = staged ? json_stage + shift + (len_or_off[a] - base) : out + len_or_off[a];
+    if (t.envelope == 1) {
+      const int64_t idlen = key_off[a + 1] - key_off[a];
+      if (idlen) {
+        *o++ = 0x0A;  // field 1, length-delimited
+        o = put_varint(o, (uint64_t)idlen);
+        for (int64_t b = key_off[a]; b < key_off[a + 1]; ++b) *o++ = keys[b];
+      }
+      const int64_t plen = json_text_len(t, st, keys, key_off, a);
+      if (plen) {
+        *o++ = 0x12;  // field 2, length-delimited
+        o = put_varint(o, (uint64_t)plen);
+      }
+    }
     for (uint32_t i = 0; i < t.n_parts; ++i) {
       const uint32_t k = t.kind[i];
       if (k == SURGE_JP_LITERAL) {
@@ -1286,10 +1324,11 @@ hipError_t launch_stream_probe(const uint4* src, int64_t n_vec, uint32_t* sink, 
 // d_len_off: n + 1 entries; d_totals: ceil(n / 1024) + 1 entries of scratch
 hipError_t launch_json_encode(const surge_json_template& tmpl, const uint4* states, int64_t n, const uint8_t* keys,
                               const int64_t* key_off, int64_t* d_len_off, int64_t* d_totals, uint8_t* out, bool write_pass,
-                              hipStream_t stream) {
+                              uint32_t envelope, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   JsonTemplateDev t;
   t.n_parts = tmpl.n_parts;
+  t.envelope = envelope;
   for (uint32_t i = 0; i < SURGE_JSON_MAX_PARTS; ++i) {
     t.kind[i] = tmpl.part[i].kind; t.field_offset[i] = tmpl.part[i].field_offset;
     t.lit_off[i] = tmpl.part[i].lit_off; t.lit_len[i] = tmpl.part[i].lit_len;

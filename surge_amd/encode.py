@@ -70,21 +70,29 @@ def key_table_utf8(keys: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
     return data, off
 
 
-def encode_states(engine: ReplayEngine, template: JsonTemplate, d_keys_utf8, d_key_off, capacity_hint: int = 0):
+def encode_states(engine: ReplayEngine, template: JsonTemplate, d_keys_utf8, d_key_off, capacity_hint: int = 0,
+                  envelope: str = "none"):
     """Encode every resident aggregate.  Returns ``(out, out_off)`` CUDA tensors: aggregate ``a``'s text is
-    ``out[out_off[a]:out_off[a+1]]`` (empty for None / poisoned aggregates)."""
+    ``out[out_off[a]:out_off[a+1]]`` (empty for None / poisoned aggregates).
+
+    ``envelope="protobuf_state"`` wraps each value in the multilanguage module's ``State{aggregateId, payload}``
+    message (``multilanguage-protocol.proto:7-10``; what ``GenericSurgeCommandBusinessLogic.scala:36-39`` stores),
+    with the template text as the payload."""
     import torch
 
+    if envelope not in ("none", "protobuf_state"):
+        raise ValueError(f"unknown envelope {envelope!r}")
     lib = _native.load()
+    fn = lib.surge_replay_encode_json if envelope == "none" else lib.surge_replay_encode_protobuf_state
     n = engine.n_agg
     dev = d_key_off.device
     d_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
-    cap = int(capacity_hint) if capacity_hint else max(64, int(d_keys_utf8.numel()) + 48 * n)
+    cap = int(capacity_hint) if capacity_hint else max(64, 2 * int(d_keys_utf8.numel()) + 64 * n)
     t = template.to_c()
     for _ in range(2):
         d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
         total = ctypes.c_int64(0)
-        rc = lib.surge_replay_encode_json(
+        rc = fn(
             engine._h, ctypes.byref(t), ctypes.c_void_p(d_keys_utf8.data_ptr()) if d_keys_utf8.numel() else None,
             ctypes.c_void_p(d_key_off.data_ptr()), ctypes.c_void_p(d_out.data_ptr()), cap,
             ctypes.c_void_p(d_off.data_ptr()), ctypes.byref(total))

@@ -111,6 +111,29 @@ def test_ragged_with_empty_segments_and_prior_snapshot():
     assert_same(got, oracle.fold_csr(so, ev), so)
 
 
+@pytest.mark.parametrize("lead,tail", [(1, 0), (37, 11), (1024, 5000)])
+def test_csr_window_into_a_larger_events_buffer(lead, tail):
+    # seg_off need not start at 0 or end at n_events (a shard's window into a bigger buffer): events outside
+    # [seg_off[0], seg_off[n]) are never read into a state, whatever their (misaligned) position
+    rng = np.random.default_rng(lead)
+    lens = rng.integers(0, 4, size=5000) * rng.integers(0, 300, size=5000)
+    so, ev = synth.csr_log(lens, 31, synth.STRESS_MIX)
+    junk = synth.csr_log(np.array([lead + tail]), 32, synth.STRESS_MIX)[1]
+    ev2 = np.concatenate([junk[:lead], ev, junk[lead:]])
+    so2 = so + lead
+    exp = oracle.fold_csr(so, ev)
+    assert oracle.fold_csr(so2, ev2).tobytes() == exp.tobytes()
+    for algo in (S.ALGO_AUTO, S.ALGO_FLAT, S.ALGO_SORTED):
+        got, _ = gpu_fold(so2, ev2, algo=algo)
+        assert_same(got, exp, so)
+    # a uniform log behind a lead cannot take the FIXED / ROWS fast paths, AUTO must still be right
+    so, ev = synth.fixed_log(3000, 32, seed=33, mix=synth.STRESS_MIX)
+    ev2 = np.concatenate([junk[:lead], ev, junk[lead:]])
+    got, st = gpu_fold(so + lead, ev2)
+    assert st.last_algo in (S.ALGO_FLAT, S.ALGO_SORTED)
+    assert_same(got, oracle.fold_csr(so, ev), so)
+
+
 def test_empty_log_and_all_empty_segments():
     so = np.zeros(1, dtype=np.int64)
     ev = S.make_events([], [], [])
@@ -326,6 +349,66 @@ def test_gpu_json_encoder_matches_play_json_text_of_the_counter_fixture():
         else:
             assert text == b""  # None => tombstone, poisoned => nothing
     assert 0 < n_emitted < n
+
+
+def _protobuf_state_class():
+    """message State { string aggregateId = 1; bytes payload = 2; } (multilanguage-protocol.proto:7-10), built with
+    the real protobuf runtime so the expected bytes come from Google's encoder, not from a restatement."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+
+    fd = descriptor_pb2.FileDescriptorProto(name="surge_multilanguage_state.proto", syntax="proto3")
+    m = fd.message_type.add(name="State")
+    F = descriptor_pb2.FieldDescriptorProto
+    m.field.add(name="aggregateId", number=1, type=F.TYPE_STRING, label=F.LABEL_OPTIONAL)
+    m.field.add(name="payload", number=2, type=F.TYPE_BYTES, label=F.LABEL_OPTIONAL)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    return message_factory.GetMessageClass(pool.FindMessageTypeByName("State"))
+
+
+@pytest.mark.gpu
+def test_gpu_protobuf_state_envelope_matches_the_protobuf_runtime():
+    # N3, multilanguage flavour: the stored value is protobuf State{aggregateId, payload}.toByteArray
+    # (GenericSurgeCommandBusinessLogic.scala:36-39); payload = the SDK's serialized state, here the Counter JSON
+    import torch
+
+    from surge_amd.encode import JsonTemplate, encode_states, key_table_utf8
+
+    State = _protobuf_state_class()
+    n = 3000
+    rng = np.random.default_rng(5)
+    keys = [f"agg-{i}" for i in range(n)]
+    keys[3] = ""                       # proto3 omits an empty string field
+    keys[4] = "k" * 127                # 1-byte varint boundary
+    keys[5] = "k" * 128                # 2-byte varint
+    keys[6] = "ключ-✓" * 40            # multi-byte UTF-8, payload > 127 bytes too
+    keys[7] = "q\"uote" * 30           # escaped in the JSON payload, raw in field 1
+    keys[8] = "z" * 20000              # 3-byte varints; also forces the un-staged block path
+    lens = rng.integers(0, 5, size=n)
+    lens[3:9] = 2
+    so, ev = synth.csr_log(lens, 41, synth.STRESS_MIX)
+    ev["type"][so[3]:so[9]] = S.EVT_INC  # the special keys must be Some(...)
+    with ReplayEngine() as eng:
+        eng.load_csr(so, ev)
+        eng.fold()
+        states = eng.snapshot()
+        assert all(int(states[a]["flags"]) == S.STATE_PRESENT for a in range(3, 9))
+        data, off = key_table_utf8(keys)
+        d_out, d_off = encode_states(eng, JsonTemplate.counter(), torch.from_numpy(data).cuda(), torch.from_numpy(off).cuda(),
+                                     envelope="protobuf_state")
+        out, offs = d_out.cpu().numpy().tobytes(), d_off.cpu().numpy()
+    n_emitted = 0
+    for a in range(n):
+        got = out[offs[a]:offs[a + 1]]
+        if int(states[a]["flags"]) == S.STATE_PRESENT:
+            n_emitted += 1
+            payload = oracle.counter_state_json(keys[a], int(states[a]["count"]), int(states[a]["version"]))
+            assert got == State(aggregateId=keys[a], payload=payload).SerializeToString(), a
+            back = State.FromString(got)
+            assert back.aggregateId == keys[a] and back.payload == payload
+        else:
+            assert got == b""
+    assert 0 < n_emitted < n and offs[n] == len(out)
 
 
 @pytest.mark.gpu
