@@ -47,7 +47,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
 
     from surge_amd import schema as S

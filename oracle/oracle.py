@@ -16,7 +16,6 @@ import numpy as np
 
 from surge_amd.schema import (
     CSchema,
-    CState64,
     DEFAULT_ALGEBRA,
     EVENT_DTYPE,
     STATE_DTYPE,

@@ -2,7 +2,7 @@
 """N3: bulk GPU encoding of the resident snapshot into play-json text (Counter template)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from surge_amd import synth
 from surge_amd.encode import JsonTemplate, encode_states
 from surge_amd.dist import ID_PREFIX, ID_DIGITS

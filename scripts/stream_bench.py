@@ -33,7 +33,6 @@ def main():
     import numpy as np
     import torch
 
-    from surge_amd import schema as S
     from surge_amd import synth
     from surge_amd.log import batch_groups
     from surge_amd.replay import ReplayEngine

@@ -13,7 +13,7 @@
 """
 from __future__ import annotations
 
-from typing import Generic, List, Optional, Sequence, Tuple, TypeVar
+from typing import Generic, Optional, Sequence, Tuple, TypeVar
 
 import numpy as np
 
@@ -26,7 +26,7 @@ from .core import (
     SurgeProcessingModel,
 )
 from .kafka import KafkaPartitioner, PartitionStringUpToColon
-from .schema import EVENT_DTYPE, STATE_DTYPE, EventAlgebra
+from .schema import EVENT_DTYPE, EventAlgebra
 
 Agg = TypeVar("Agg")
 Cmd = TypeVar("Cmd")

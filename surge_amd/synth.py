@@ -16,7 +16,6 @@ first event is forced to CREATE for half of the aggregates so both ``None`` path
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional, Tuple
 
 import numpy as np
 

@@ -10,7 +10,6 @@ Set SURGE_TEST_C3_AGGREGATES to shrink C3 (default 10_000_000).
 """
 import os
 
-import numpy as np
 import pytest
 import torch
 

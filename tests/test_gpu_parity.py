@@ -2,8 +2,6 @@
 
 Bit-exact is the bar: all state fields are integers or bit-copied f64 payloads.
 """
-import ctypes
-
 import numpy as np
 import pytest
 

@@ -17,7 +17,7 @@ from surge_amd.core import SurgeContext
 from surge_amd.fixtures import (
     BankAccount, BankAccountCommandModel, BankAccountCreated, BankAccountUpdated, CounterBusinessLogic,
     CounterCommandModel, CountDecremented, CountIncremented, CreateAccount, CreateNoOpEvent, CreditAccount,
-    DebitAccount, Decrement, DoNothing, ExceptionThrowingEvent, Increment, NoOpEvent, State,
+    DebitAccount, DoNothing, ExceptionThrowingEvent, Increment, NoOpEvent, State,
     AccountDoesNotExistException, InsufficientFundsException,
 )
 

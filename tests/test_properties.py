@@ -4,13 +4,11 @@ import os
 import random
 
 import numpy as np
-import pytest
 from hypothesis import given, settings, strategies as st
 
 import kafka_wire as kw
 from oracle import oracle
 from surge_amd import schema as S
-from surge_amd import synth
 from surge_amd.ingest import EventsTopicIngest, IngestError
 
 events_strategy = st.lists(

@@ -8,7 +8,7 @@ from surge_amd.fixtures import (
     BankAccountCommandModel, BankAccountCreated, BankAccountUpdated, BankAccountFormat, CounterBusinessLogic,
     CountDecremented, CountIncremented, ExceptionThrowingEvent, NoOpEvent, State,
 )
-from surge_amd.log import KeyTable, batch_groups, group_by_aggregate, pack_events
+from surge_amd.log import batch_groups, pack_events
 from surge_amd.store import GpuReplayKeyValueStore, GpuReplayPersistencePlugin
 
 
