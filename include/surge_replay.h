@@ -22,12 +22,15 @@
  *   - plain C, no exceptions across the boundary; every function returns an
  *     int32 status (0 = OK, negative = error class, see SURGE_E_*).
  *   - surge_replay_last_error(h) returns a NUL-terminated message owned by the
- *     handle (or by the calling thread when h == NULL).
+ *     handle (or by the calling thread when h == NULL; concurrent readers should
+ *     use the NULL form, which always reports the calling thread's own failure).
  *   - all buffers are caller-allocated.  "host" buffers are ordinary process
  *     memory (JNI passes DirectByteBuffer addresses); "_device" entry points
  *     take HIP device pointers (the Python host passes torch tensor pointers).
- *   - one handle per GPU; mutation of a handle is NOT thread-safe, reads
- *     (surge_replay_get after a snapshot) are.
+ *   - one handle per GPU; mutation of a handle is NOT thread-safe, point reads
+ *     (surge_replay_get) are: shared (reader) lock against the mirror published by
+ *     surge_replay_snapshot, serialized device reads otherwise (the reference reads
+ *     S2 from a 32-thread pool, ThreadPools.scala:10-11).
  *   - There is NO CPU fallback inside this library: without a usable HIP device
  *     surge_replay_create fails with SURGE_E_DEVICE.
  */

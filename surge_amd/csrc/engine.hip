@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -58,6 +59,7 @@ struct surge_replay_handle {
   hipStream_t stream = nullptr;
   surge_replay_schema schema{};
   std::string err;
+  std::mutex err_mu;  // concurrent point readers may fail at the same time
 
   // the bound log (owned copies or borrowed device pointers)
   DevBuf own_seg_off, own_events, own_init, own_state;
@@ -92,7 +94,7 @@ struct surge_replay_handle {
   std::vector<uint4> h_sorted_events;
 
   // host mirror for point reads (S2)
-  std::mutex mu;
+  std::shared_mutex mu;  // readers share it against the published mirror; snapshot / device reads take it exclusively
   std::vector<uint8_t> mirror;
   std::atomic<int64_t> fold_epoch{0};
   int64_t mirror_epoch = -1;
@@ -101,8 +103,11 @@ struct surge_replay_handle {
 namespace {
 
 int32_t fail(surge_replay_handle* h, int32_t code, const std::string& msg) {
-  if (h) h->err = msg;
-  g_last_error = msg;
+  if (h) {
+    std::lock_guard<std::mutex> lk(h->err_mu);
+    h->err = msg;
+  }
+  g_last_error = msg;  // thread-local: what surge_replay_last_error(NULL) returns to the failing thread
   return code;
 }
 
@@ -680,7 +685,7 @@ int32_t surge_replay_snapshot(surge_replay_handle* h, void* states_out, uint8_t*
   if (!h->bound) return fail(h, SURGE_E_STATE, "snapshot before load_csr/bind_device_csr");
   if (h->st.n_folds == 0) return fail(h, SURGE_E_STATE, "snapshot before fold");
   DeviceGuard g(h->device);
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::unique_lock<std::shared_mutex> lk(h->mu);
   const int64_t epoch = h->fold_epoch.load();
   const size_t bytes = (size_t)h->n_agg * 64;
   try {
@@ -710,10 +715,16 @@ int32_t surge_replay_get(surge_replay_handle* h, int64_t agg_idx, void* state64_
   if (!state64_out) return fail(h, SURGE_E_INVALID, "state64_out is NULL");
   if (!h->bound || h->st.n_folds == 0) return fail(h, SURGE_E_STATE, "get before fold");
   if (agg_idx < 0 || agg_idx >= h->n_agg) return fail(h, SURGE_E_RANGE, "aggregate index out of range");
-  std::lock_guard<std::mutex> lk(h->mu);
-  if (h->mirror_epoch == h->fold_epoch.load()) {
-    std::memcpy(state64_out, h->mirror.data() + agg_idx * 64, 64);
-  } else {
+  bool served = false;
+  {
+    std::shared_lock<std::shared_mutex> lk(h->mu);
+    if (h->mirror_epoch == h->fold_epoch.load()) {
+      std::memcpy(state64_out, h->mirror.data() + agg_idx * 64, 64);
+      served = true;
+    }
+  }
+  if (!served) {  // no mirror for this fold epoch: one device read at a time
+    std::unique_lock<std::shared_mutex> lk(h->mu);
     DeviceGuard g(h->device);
     HIPCHK(h, hipMemcpyAsync(state64_out, h->d_state + agg_idx * 4, 64, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

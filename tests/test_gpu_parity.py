@@ -349,6 +349,33 @@ def test_gpu_json_encoder_matches_play_json_text_of_the_counter_fixture():
     assert 0 < n_emitted < n
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("publish_mirror", [True, False])
+def test_point_reads_tolerate_32_concurrent_readers(publish_mirror):
+    # S2 is called from the reference's 32-thread IO pool (ThreadPools.scala:10-11): point reads must be safe under
+    # that concurrency, both against a published host mirror and when every read goes to the device
+    from concurrent.futures import ThreadPoolExecutor
+
+    n = 20000
+    so, ev = synth.csr_log(np.random.default_rng(9).integers(0, 20, size=n), 51, synth.STRESS_MIX)
+    exp = oracle.fold_csr(so, ev)
+    with ReplayEngine() as eng:
+        eng.load_csr(so, ev)
+        eng.fold()
+        if publish_mirror:
+            eng.snapshot()
+
+        def reader(seed):
+            rng = np.random.default_rng(seed)
+            bad = 0
+            for a in rng.integers(0, n, size=300 if publish_mirror else 60):
+                bad += eng.get_raw(int(a)).tobytes() != exp[int(a)].tobytes()
+            return bad
+
+        with ThreadPoolExecutor(max_workers=32) as pool:
+            assert sum(pool.map(reader, range(32))) == 0
+
+
 def _protobuf_state_class():
     """message State { string aggregateId = 1; bytes payload = 2; } (multilanguage-protocol.proto:7-10), built with
     the real protobuf runtime so the expected bytes come from Google's encoder, not from a restatement."""
