@@ -1,8 +1,9 @@
 /*
  * surge_replay_jni.c — thin JNI shim over include/surge_replay.h.
  *
- * SOURCE-ONLY in this repository: the build image has no JDK (no jni.h), so this file is compiled
- * only where JAVA_HOME is set:
+ * The build image has no JDK (no jni.h): for a JVM this file is compiled where JAVA_HOME is set (below); in
+ * this repository it is compiled unchanged against the stand-in header tests/jni_mock/jni.h and driven by a
+ * fake JNIEnv (tests/jni_mock/jni_harness.c, tests/test_abi.py).
  *
  *   gcc -shared -fPIC -I"$JAVA_HOME/include" -I"$JAVA_HOME/include/linux" -I../../include \
  *       surge_replay_jni.c -L../../surge_amd -lsurge_replay -o libsurge_replay_jni.so
@@ -21,7 +22,8 @@
 static jint check(JNIEnv* env, surge_replay_handle* h, int32_t rc) {
   if (rc != SURGE_OK) {
     jclass ex = (*env)->FindClass(env, "java/io/IOException");
-    const char* msg = surge_replay_last_error(h);
+    const char* msg = surge_replay_last_error(NULL); /* the calling thread's own failure (get() runs on a 32-thread pool) */
+    (void)h;
     if (ex) (*env)->ThrowNew(env, ex, msg ? msg : "surge_replay call failed");
   }
   return rc;
@@ -69,7 +71,7 @@ JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_appendFold(JNIEnv* env
                                                     nEvents));
 }
 
-/* Publishes the host mirror that makes get() lock-free; states may be null. */
+/* Publishes the host mirror that concurrent get() calls then read under a shared lock; states may be null. */
 JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_snapshot(JNIEnv* env, jclass c, jlong h, jobject states,
                                                                      jobject present) {
   (void)c;
