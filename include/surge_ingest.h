@@ -78,7 +78,8 @@ int32_t surge_ingest_key(const surge_ingest* g, int64_t idx, const char** utf8_o
 int32_t surge_ingest_counters(const surge_ingest* g, int64_t out[8]);
 
 /* Exposed for tests / other bindings. */
-uint32_t surge_crc32c(const uint8_t* data, int64_t len);
+uint32_t surge_crc32c(const uint8_t* data, int64_t len);          /* SSE4.2 CRC32 instruction when the CPU has it */
+uint32_t surge_crc32c_portable(const uint8_t* data, int64_t len); /* table walk; must always agree with the above */
 /* LZ4 frame -> bytes.  Returns the decompressed size, or a negative status. */
 int64_t surge_lz4_frame_decompress(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
 

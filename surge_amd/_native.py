@@ -64,6 +64,7 @@ INGEST_EXPORTS = (
     "surge_ingest_key",
     "surge_ingest_counters",
     "surge_crc32c",
+    "surge_crc32c_portable",
     "surge_lz4_frame_decompress",
 )
 
@@ -180,6 +181,7 @@ def load() -> ctypes.CDLL:
         "surge_ingest_key": ([vp, i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i64)], i32),
         "surge_ingest_counters": ([vp, ctypes.POINTER(i64 * 8)], i32),
         "surge_crc32c": ([vp, i64], ctypes.c_uint32),
+        "surge_crc32c_portable": ([vp, i64], ctypes.c_uint32),
         "surge_lz4_frame_decompress": ([vp, i64, vp, i64], i64),
     })
     for name in EXPORTS + INGEST_EXPORTS:

@@ -54,6 +54,39 @@ def test_lz4_hand_assembled_sequences():
     assert lz4_decompress(frame) == raw
 
 
+@pytest.mark.parametrize("period", [1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 64])
+def test_lz4_overlapping_matches_of_every_period(period):
+    # a match whose offset is shorter than its length replicates the last `period` bytes: the decoder's three
+    # copy regimes (offset >= length, 8 <= offset < length, offset < 8) must all produce the periodic extension
+    hdr = struct.pack("<I", 0x184D2204) + bytes([0x60, 0x40, 0x00])
+    seedb = bytes((37 * i + 11) & 0xFF for i in range(period))
+    for ml in (4, 5, period, period + 1, 3 * period + 5, 300):
+        if ml < 4:
+            continue
+        lit_tok = min(period, 15)
+        blk = bytearray([(lit_tok << 4) | min(ml - 4, 15)])
+        if period >= 15:
+            blk.append(period - 15)
+        blk += seedb + struct.pack("<H", period)
+        if ml - 4 >= 15:
+            r = ml - 4 - 15
+            while r >= 255:
+                blk.append(255)
+                r -= 255
+            blk.append(r)
+        blk += bytes([0x50]) + b"TAIL!"
+        want = bytes(seedb[i % period] for i in range(period + ml)) + b"TAIL!"
+        assert lz4_decompress(hdr + struct.pack("<I", len(blk)) + bytes(blk) + struct.pack("<I", 0)) == want, (period, ml)
+
+
+def test_crc32c_instruction_path_equals_the_table_walk():
+    L = _native.load()
+    rng = random.Random(3)
+    for n in list(range(0, 40)) + [255, 256, 257, 4095, 65537]:
+        data = bytes(rng.randrange(256) for _ in range(n))
+        assert L.surge_crc32c(data, n) == L.surge_crc32c_portable(data, n) == kw.crc32c(data)
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_lz4_round_trip_against_the_independent_compressor(seed):
     rng = random.Random(seed)
@@ -100,6 +133,28 @@ def test_batches_round_trip_with_and_without_lz4_and_split_feeds():
             assert kt.keys[idx] == k.decode().split(":")[0]  # PartitionStringUpToColon
         c = g.counters()
         assert c["batches"] == 30 and c["records_delivered"] == len(recs) and c["open_transactions"] == 0
+
+
+def test_key_interning_across_table_growth():
+    # 6000 distinct aggregate ids (the index grows several times), each seen three times in shuffled order, with
+    # ids that are prefixes of one another: every record must map to the dense index of ITS id, in first-seen order
+    rng = random.Random(5)
+    ids = [f"agg-{i}" for i in range(5000)] + ["a" * k for k in range(1, 1001)]
+    seq = ids * 3
+    rng.shuffle(seq)
+    wire, off = [], 0
+    for s0 in range(0, len(seq), 400):
+        chunk = seq[s0:s0 + 400]
+        wire.append(kw.record_batch(off, [(f"{a}:{j}".encode(), b"v") for j, a in enumerate(chunk)]))
+        off += len(chunk)
+    with EventsTopicIngest() as g:
+        g.feed(b"".join(wire))
+        got = g.drain_records()
+        kt = g.key_table()
+    assert len(got) == len(seq) and len(kt.keys) == len(ids) and len(set(kt.keys)) == len(ids)
+    first_seen = list(dict.fromkeys(seq))
+    assert kt.keys == first_seen
+    assert all(kt.keys[idx] == a for (_, idx, _, _), a in zip(got, seq))
 
 
 def test_read_committed_holds_back_open_transactions_and_drops_aborted_ones():
