@@ -436,3 +436,131 @@ class BankAccountFormat(SurgeAggregateFormatting[BankAccount]):
             return BankAccount(uuid.UUID(o["accountNumber"]), o["accountOwner"], o["securityCode"], float(o["balance"]))
         except Exception:
             return None
+
+
+# ======================================================================================================
+# Multilanguage Scala SDK sample: the second copy of the fold, behind the gRPC bridge.
+#   CQRSModel.applyEvents = e.foldLeft(s)(eventHandler)
+#       modules/multilanguage-scala-sdk/src/main/scala/com/ukg/surge/multilanguage/scalasdk/Model.scala:9-19
+#   sample model BankAccount(balance: Int) / MoneyDeposited(amount: Int) / DepositMoney(amount: Int)
+#       modules/multilanguage-scala-sdk-sample/src/main/scala/com/ukg/surge/multilanguage/scalasdk/sample/Main.scala:19-37
+#   stored state = protobuf State{aggregateId, payload = json4s write(state)} (GenericSurgeCommandBusinessLogic.scala:36-39,
+#       Main.scala:41-60)
+# ======================================================================================================
+@dataclass(frozen=True)
+class SdkBankAccount:
+    balance: int
+
+
+@dataclass(frozen=True)
+class MoneyDeposited:
+    amount: int
+
+
+@dataclass(frozen=True)
+class DepositMoney:
+    amount: int
+
+
+@dataclass(frozen=True)
+class SdkEvent:
+    """The SDK's events carry no aggregate id of their own: the bridge passes it beside the payload
+    (``Event{aggregateId, payload}``, multilanguage-protocol.proto:17-20)."""
+
+    aggregateId: str
+    payload: MoneyDeposited
+
+
+class CQRSModel:
+    """``CQRSModel[S, E, C](eventHandler, commandHandler)`` — Model.scala:9-19."""
+
+    def __init__(self, event_handler, command_handler):
+        self.event_handler = event_handler
+        self.command_handler = command_handler
+
+    def apply_events(self, s, events):
+        for e in events:  # e.foldLeft(s)((s, e) => eventHandler(s, e)) — Model.scala:11-13
+            s = self.event_handler(s, e)
+        return s
+
+    def execute_command(self, s, c):
+        """``Left(msg)`` -> ``("Left", msg)``; ``Right((events, newState))`` -> ``("Right", (events, new_state))``."""
+        tag, val = self.command_handler(s, c)
+        if tag == "Left":
+            return tag, val
+        return "Right", (val, self.apply_events(s, val))
+
+
+def sdk_sample_event_handler(agg: Optional[SdkBankAccount], evt: MoneyDeposited) -> Optional[SdkBankAccount]:
+    # Main.scala:25-30
+    if agg is None:
+        return SdkBankAccount(_i32(evt.amount))
+    return SdkBankAccount(_i32(agg.balance + evt.amount))
+
+
+def sdk_sample_command_handler(agg: Optional[SdkBankAccount], cmd: DepositMoney):
+    # Main.scala:32-38
+    if cmd.amount >= 0:
+        return "Right", [MoneyDeposited(cmd.amount)]
+    return "Left", "Amount cannot be < 0"
+
+
+SDK_SAMPLE_MODEL = CQRSModel(sdk_sample_event_handler, sdk_sample_command_handler)
+
+SDK_DEPOSITED = 0
+SDK_SAMPLE_ALGEBRA = EventAlgebra(
+    desc=(CLS_MATERIALIZE | D_COUNT_ADD,),  # None => BankAccount(0 + amount); Some(b) => BankAccount(b + amount)
+    names=("MoneyDeposited",),
+)
+
+
+class SdkSampleCommandModel(ReplayableCommandModel[SdkBankAccount, DepositMoney, SdkEvent]):
+    """The sample's ``CQRSModel`` behind the replayable-model interface; ``balance`` lives in the ``count`` field."""
+
+    def process_command(self, aggregate, command):
+        tag, val = SDK_SAMPLE_MODEL.command_handler(aggregate, command)
+        if tag == "Left":
+            raise ValueError(val)
+        return val
+
+    def handle_event(self, aggregate: Optional[SdkBankAccount], event: SdkEvent) -> Optional[SdkBankAccount]:
+        return SDK_SAMPLE_MODEL.event_handler(aggregate, event.payload)
+
+    def event_algebra(self) -> EventAlgebra:
+        return SDK_SAMPLE_ALGEBRA
+
+    def encode_event(self, event: SdkEvent):
+        return SDK_DEPOSITED, 0, event.payload.amount, None
+
+    def aggregate_id_of(self, event: SdkEvent) -> str:
+        return event.aggregateId
+
+    def state_from_fixed(self, aggregate_id: str, fixed) -> SdkBankAccount:
+        return SdkBankAccount(int(fixed["count"]))
+
+    def state_to_fixed(self, aggregate: SdkBankAccount) -> np.ndarray:
+        s = np.zeros(1, dtype=STATE_DTYPE)
+        a = self.event_algebra()
+        s["min_arg"], s["max_arg"] = a.default_min_arg, a.default_max_arg
+        s["count"], s["flags"] = aggregate.balance, STATE_PRESENT
+        return s
+
+
+def protobuf_varint(v: int) -> bytes:
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def sdk_sample_state_bytes(aggregate_id: str, state: SdkBankAccount) -> bytes:
+    """``protobuf.State(aggregateId, ByteString(write(state))).toByteArray``: json4s' compact text in field 2, the
+    id in field 1; proto3 leaves an empty field out."""
+    payload = ('{"balance":%d}' % state.balance).encode("ascii")
+    key = aggregate_id.encode("utf-8")
+    out = b""
+    if key:
+        out += b"\x0a" + protobuf_varint(len(key)) + key
+    return out + b"\x12" + protobuf_varint(len(payload)) + payload

@@ -437,6 +437,41 @@ def test_gpu_protobuf_state_envelope_matches_the_protobuf_runtime():
 
 
 @pytest.mark.gpu
+def test_sdk_sample_model_replays_and_encodes_to_its_stored_protobuf_form():
+    # R8 end to end: deposits folded on the GPU under the sample's one-type algebra, then encoded in bulk as
+    # State{aggregateId, payload = {"balance":N}} — byte-equal to what the multilanguage gateway stores
+    import torch
+
+    from surge_amd.encode import JP_I32, JsonTemplate, encode_states, key_table_utf8
+    from surge_amd.fixtures import SDK_SAMPLE_MODEL, MoneyDeposited, SdkBankAccount, SdkEvent, SdkSampleCommandModel, sdk_sample_state_bytes
+
+    rng = np.random.default_rng(77)
+    model = SdkSampleCommandModel()
+    n = 700
+    keys = [f"0c3f1d9e-7a55-4a5c-9d5e-{i:012x}" for i in range(n)]
+    per_agg = [[MoneyDeposited(int(a)) for a in rng.integers(0, 2**31, size=int(k))] for k in rng.integers(0, 40, size=n)]
+    so = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(d) for d in per_agg], out=so[1:])
+    ev = model.encode_events([SdkEvent(keys[a], d) for a in range(n) for d in per_agg[a]])
+    with ReplayEngine(model.event_algebra()) as eng:
+        eng.load_csr(so, ev)
+        eng.fold()
+        states = eng.snapshot()
+        data, off = key_table_utf8(keys)
+        tmpl = JsonTemplate((b'{"balance":', (JP_I32, 0), b"}"))
+        d_out, d_off = encode_states(eng, tmpl, torch.from_numpy(data).cuda(), torch.from_numpy(off).cuda(), envelope="protobuf_state")
+        out, offs = d_out.cpu().numpy().tobytes(), d_off.cpu().numpy()
+    for a in range(n):
+        want = SDK_SAMPLE_MODEL.apply_events(None, per_agg[a])
+        got = out[offs[a]:offs[a + 1]]
+        if want is None:
+            assert got == b"" and not int(states[a]["flags"]) & S.STATE_PRESENT
+        else:
+            assert model.state_from_fixed(keys[a], states[a]) == want
+            assert got == sdk_sample_state_bytes(keys[a], want)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,long_every", [(1, 0), (255, 0), (256, 0), (257, 0), (1500, 0), (1500, 3)])
 def test_gpu_json_encoder_block_staging_and_long_key_fallback(n, long_every):
     # the write pass composes a block's 256 values in LDS; blocks whose text exceeds the staging buffer
