@@ -311,6 +311,9 @@ enum { MODE_FIXED = 0, MODE_FLAT = 1 };
 template <int MODE, int LE>
 __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
   using G = Geo<LE>;
+  // one dynamic LDS buffer: splitting it into separate objects (which lets hipcc drop its conservative
+  // s_waitcnt vmcnt(0) between the tile fetch and the op-table reads, see fold_rows_kernel) measured 3 % SLOWER
+  // here — more VGPRs, and the head bookkeeping loads wait on vmcnt anyway
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_ev = smem;
   uint32_t* lds_hb = (uint32_t*)(smem + G::kTileBytes);
@@ -550,9 +553,12 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
 template <int LE>
 __global__ void __launch_bounds__(kWave) fold_rows_kernel(const FoldParams p) {
   using G = Geo<LE>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* lds_ev = smem;
-  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kAuxRows);
+  // Two separate LDS objects, not one carved-up buffer: the compiler orders every LDS read after all outstanding
+  // global->LDS loads that MAY alias it.  With a single dynamic buffer the op-table reads of the walk "may alias"
+  // the tile being fetched, and hipcc put an s_waitcnt vmcnt(0) in front of the first table read — i.e. each wave
+  // waited for its NEXT tile before walking the current one.  Distinct objects let alias analysis drop that wait.
+  __shared__ __attribute__((aligned(16))) char lds_ev[G::kTileBytes];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_tab[kTableEntries * kTableStride];
 
   const int lane = threadIdx.x;
   const int64_t S0 = (int64_t)blockIdx.x * p.segs_per_task;
@@ -634,6 +640,7 @@ constexpr int kSortBuckets = 65536;  // bucket = min(length, 65535); longer segm
 template <int LE>
 __global__ void __launch_bounds__(kWave) fold_sorted_kernel(const FoldParams p) {
   using G = Geo<LE>;
+  // one dynamic LDS buffer (separate objects as in fold_rows_kernel made no measurable difference here)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_ev = smem;
   int64_t* lds_rs = (int64_t*)(smem + G::kTileBytes);              // 64 row starts (aux area) ...
@@ -1217,11 +1224,11 @@ hipError_t launch_fold_fixed(const FoldParams& p, int64_t n_tasks, int lane_even
 hipError_t launch_fold_rows(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream) {
   if (n_tasks <= 0) return hipSuccess;
   if (lane_events == 8)
-    hipLaunchKernelGGL((fold_rows_kernel<8>), dim3((unsigned)n_tasks), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxRows), stream, p);
+    hipLaunchKernelGGL((fold_rows_kernel<8>), dim3((unsigned)n_tasks), dim3(kWave), 0, stream, p);  // LDS is static in the kernel
   else if (lane_events == 32)
-    hipLaunchKernelGGL((fold_rows_kernel<32>), dim3((unsigned)n_tasks), dim3(kWave), Geo<32>::lds_bytes(Geo<32>::kAuxRows), stream, p);
+    hipLaunchKernelGGL((fold_rows_kernel<32>), dim3((unsigned)n_tasks), dim3(kWave), 0, stream, p);  // LDS is static in the kernel
   else
-    hipLaunchKernelGGL((fold_rows_kernel<16>), dim3((unsigned)n_tasks), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxRows), stream, p);
+    hipLaunchKernelGGL((fold_rows_kernel<16>), dim3((unsigned)n_tasks), dim3(kWave), 0, stream, p);  // LDS is static in the kernel
   return hipGetLastError();
 }
 
