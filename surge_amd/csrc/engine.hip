@@ -456,9 +456,15 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
   const bool sorted_ok = h->an.max_len < (1ll << 31);
   if (algo == SURGE_ALGO_SORTED && !sorted_ok) return fail(h, SURGE_E_UNSUPPORTED, "ALGO_SORTED needs segments shorter than 2^31 events");
   // Measured on MI355X (C3: 10 M aggregates, Zipf 1..4096): FLAT 16.2 ms (4.6 TB/s); SORTED (line-aligned
-  // 256 B row pieces, 8 resident waves per CU) 12.1 ms (6.2 TB/s).  SORTED needs enough groups of 64 segments to keep
-  // its persistent waves busy; smaller logs stay on the linear-stream FLAT kernel.
-  const bool sorted_auto = sorted_ok && h->n_nz / kWave >= 4 * (int64_t)h->n_cus * 4;
+  // 256 B row pieces, 8 resident waves per CU) 12.1 ms (6.2 TB/s).  One lane per aggregate pays only when
+  //  - there are enough groups of 64 segments to keep the persistent waves busy,
+  //  - rows are long enough to fill their 256-byte pieces (mean >= 64 events: at <= 32 events per aggregate
+  //    SORTED measured 2-4x slower than the linear-stream FLAT kernel, at ~64 they tie), and
+  //  - the log is big enough to hide the critical path of the longest group, which one wave walks alone
+  //    (max_len / 16 tiles at ~4 us: Zipf(1..4096) ties at ~1 M aggregates = 7 GB, FLAT wins below).
+  const double mean_len = h->n_nz > 0 ? (double)span / (double)h->n_nz : 0.0;
+  const bool sorted_auto = sorted_ok && h->n_nz / kWave >= 4 * (int64_t)h->n_cus * 4 && mean_len >= 64.0 &&
+                           (double)h->st.algorithmic_bytes >= 1.6e6 * (double)h->an.max_len;
   const int32_t use = (algo == SURGE_ALGO_AUTO)
                           ? (uniform ? (rows_auto ? SURGE_ALGO_ROWS : SURGE_ALGO_FIXED) : (sorted_auto ? SURGE_ALGO_SORTED : SURGE_ALGO_FLAT))
                           : algo;
