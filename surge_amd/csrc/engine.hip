@@ -451,8 +451,9 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
     return fail(h, SURGE_E_UNSUPPORTED, "ALGO_FIXED / ALGO_ROWS need equal segment lengths that are a multiple of 16");
   const bool rows_ok = uniform && h->an.len0 <= (1 << 24);
   if (algo == SURGE_ALGO_ROWS && !rows_ok) return fail(h, SURGE_E_UNSUPPORTED, "ALGO_ROWS needs L <= 2^24");
-  // one lane per aggregate only pays when 64-aggregate groups alone can fill the chip
-  const bool rows_auto = rows_ok && h->n_agg / kWave >= 2048;
+  // one lane per aggregate only pays when 64-aggregate groups alone can fill the chip: measured crossover
+  // with FIXED between 512 groups (FIXED 20-50 % faster) and 1024 groups (ROWS 10-18 % faster, L = 64..1024)
+  const bool rows_auto = rows_ok && h->n_agg / kWave >= 1024;
   const bool sorted_ok = h->an.max_len < (1ll << 31);
   if (algo == SURGE_ALGO_SORTED && !sorted_ok) return fail(h, SURGE_E_UNSUPPORTED, "ALGO_SORTED needs segments shorter than 2^31 events");
   // Measured on MI355X (C3: 10 M aggregates, Zipf 1..4096): FLAT 16.2 ms (4.6 TB/s); SORTED (line-aligned
