@@ -164,6 +164,38 @@ def test_segment_boundaries_on_every_tile_alignment():
         assert_same(got, oracle.fold_csr(so, ev), so)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_log_shapes_through_every_kernel(seed):
+    # shape fuzz: segment-length distributions that stress different paths (all short, a few giants, runs of
+    # empties, lengths around the 8/16/64-event tile edges), random type mixes, with and without a prior snapshot;
+    # every kernel that accepts the shape must give the oracle's bytes
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(12):
+        n = int(rng.integers(1, 3000))
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            lens = rng.integers(0, 6, size=n)
+        elif kind == 1:
+            lens = rng.integers(0, 40, size=n)
+            lens[rng.integers(0, n, size=max(1, n // 200))] = rng.integers(2000, 20000)
+        elif kind == 2:
+            lens = rng.choice([0, 7, 8, 9, 15, 16, 17, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025], size=n)
+        elif kind == 3:
+            lens = np.where(rng.random(n) < 0.7, 0, rng.integers(1, 300, size=n))
+        else:
+            lens = np.full(n, int(rng.choice([16, 32, 48, 256])))
+        mix = [synth.C1_MIX, synth.C2_MIX, synth.STRESS_MIX][int(rng.integers(0, 3))]
+        so, ev = synth.csr_log(lens.astype(np.int64), int(rng.integers(1, 1 << 30)), mix)
+        prior = None
+        if rng.random() < 0.5:
+            prior = oracle.fold_csr(*synth.csr_log(rng.integers(0, 4, size=n), int(rng.integers(1, 1 << 30)), synth.STRESS_MIX))
+        exp = oracle.fold_csr(so, ev, prior)
+        algos = [S.ALGO_AUTO, S.ALGO_FLAT, S.ALGO_SORTED] + ([S.ALGO_FIXED, S.ALGO_ROWS] if kind == 4 else [])
+        for algo in algos:
+            got, _ = gpu_fold(so, ev, prior, algo=algo)
+            assert got.tobytes() == exp.tobytes(), (seed, kind, n, algo)
+
+
 def test_every_aggregate_poisoned_or_deleted():
     n = 3000
     ev = S.make_events(np.tile([S.EVT_INC, S.EVT_THROW, S.EVT_INC], n), np.tile([1, 2, 3], n), np.tile([4, 0, 9], n))
