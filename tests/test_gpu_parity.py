@@ -2,6 +2,8 @@
 
 Bit-exact is the bar: all state fields are integers or bit-copied f64 payloads.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -164,7 +166,7 @@ def test_segment_boundaries_on_every_tile_alignment():
         assert_same(got, oracle.fold_csr(so, ev), so)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SURGE_TEST_FUZZ_SEEDS", "6"))))
 def test_random_log_shapes_through_every_kernel(seed):
     # shape fuzz: segment-length distributions that stress different paths (all short, a few giants, runs of
     # empties, lengths around the 8/16/64-event tile edges), random type mixes, with and without a prior snapshot;
