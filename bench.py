@@ -247,10 +247,13 @@ def pmc_traffic(args, algo):
     FETCH_SIZE and WRITE_SIZE, gfx950 correction x2 on FETCH_SIZE, KB -> bytes), as committed under
     profiles/ by scripts/prof.sh.  bench.py cannot collect PMC counters itself; null when there is no
     profile for the workload/kernel being run."""
-    if args.workload != "c2" or args.aggregates != AGG_PER_GPU or args.events_per_aggregate != EVENTS_PER_AGG:
+    if args.workload == "c2" and args.aggregates == AGG_PER_GPU and args.events_per_aggregate == EVENTS_PER_AGG:
+        name, want = "r01_final_c2_rows_summary.txt", {3: "fold_rows"}.get(algo)
+    elif args.workload == "c3" and args.zipf_aggregates == 10_000_000:
+        name, want = "r01_final_c3_sorted16_10Magg_summary.txt", {4: "fold_sorted"}.get(algo)
+    else:
         return None, None
-    path = os.path.join(ROOT, "profiles", "r01_final_c2_rows_summary.txt")
-    want = {3: "fold_rows"}.get(algo)
+    path = os.path.join(ROOT, "profiles", name)
     if want is None or not os.path.exists(path):
         return None, None
     fetch = write = None
@@ -262,7 +265,7 @@ def pmc_traffic(args, algo):
             write = float(parts[-1].split("=")[1])
     if fetch is None or write is None:
         return None, None
-    return fetch * 1024 * 2 + write * 1024, "profiles/r01_final_c2_rows_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
+    return fetch * 1024 * 2 + write * 1024, f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
 
 
 class _LazyGlobalOffsets:
