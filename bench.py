@@ -214,8 +214,9 @@ def main():
                 "algo": {S.ALGO_FIXED: "fixed", S.ALGO_FLAT: "flat", S.ALGO_ROWS: "rows", S.ALGO_SORTED: "sorted"}.get(st.last_algo, str(st.last_algo)),
                 "wave_tasks": st.n_tasks,
                 "sharding": "single shard" if world == 1 else
-                f"murmur3(acct-%08d) % {N_PARTITIONS} -> gpu = partition % {world}; final snapshot exchanged over RCCL (grouped per-peer send/recv, "
-                f"40-byte wire form) on a side stream, overlapped with the next fold",
+                f"murmur3(acct-%08d) % {N_PARTITIONS} -> gpu = partition % {world}; final snapshot exchanged over "
+                f"{'gloo (single-GPU rehearsal)' if rehearsal else 'RCCL'} ({'grouped per-peer send/recv' if gather.mode == 'p2p' else 'all_gather_into_tensor'}, "
+                f"{'40-byte wire form' if gather.packed else '64-byte states'}) on a side stream, overlapped with the next fold",
             },
             "roofline": {
                 "bound": "hbm",
