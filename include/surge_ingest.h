@@ -52,7 +52,10 @@ const char* surge_ingest_last_error(const surge_ingest* g);
 
 /* Feed bytes of consecutive record batches (a fetch response's record set / a log segment).  Whole
  * batches are consumed; *consumed_out tells how many bytes were (a trailing partial batch is left for
- * the next call, exactly like a fetch that cuts a batch).  Decoded records accumulate until drained. */
+ * the next call, exactly like a fetch that cuts a batch).  Decoded records accumulate until drained.
+ * On a failure in batch k (CRC, codec, malformed record) the status is returned with *consumed_out = the
+ * byte offset of batch k: batches 0..k-1 of the buffer stay decoded and queued, so a caller must not feed
+ * them again. */
 int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int64_t* consumed_out);
 
 /* Records that are deliverable now (committed / non-transactional, before any open transaction). */
@@ -69,7 +72,8 @@ const uint8_t* surge_ingest_arena(const surge_ingest* g);
 int32_t surge_ingest_drain_fixed16(surge_ingest* g, int64_t max, int64_t* agg_idx_out, void* events16_out,
                                    int64_t* offsets_out, int64_t* n_out);
 
-/* Key table: aggregate ids in first-seen order. */
+/* Key table: aggregate ids in first-DELIVERED order (a key is interned when its record is drained, so the
+ * keys of aborted or still-open transactions never appear). */
 int64_t surge_ingest_key_count(const surge_ingest* g);
 int32_t surge_ingest_key(const surge_ingest* g, int64_t idx, const char** utf8_out, int64_t* len_out);
 

@@ -229,6 +229,13 @@ int32_t surge_replay_append_fold_device(surge_replay_handle* h, const int64_t* d
                                         const int64_t* d_group_off, int64_t n_groups,
                                         const void* d_events, int64_t n_events);
 
+/* New aggregates after recovery (the normal Surge case: ids that first appear in a later micro-batch): extends the
+ * RESIDENT state to new_n_agg aggregates, the new ones None.  Indices below the old n_agg keep their states.  Only
+ * for a state buffer the handle owns (SURGE_E_UNSUPPORTED otherwise).  The bound CSR no longer covers the state
+ * afterwards: surge_replay_fold returns SURGE_E_STATE until the next load/bind; append_*, get, gather, snapshot and
+ * the encoders keep working. */
+int32_t surge_replay_grow(surge_replay_handle* h, int64_t new_n_agg);
+
 /* ---- read (S2) ------------------------------------------------------------------
  * Point read of the recovered state; serves
  * AggregateStateStoreKafkaStreams.getAggregateBytes (…KafkaStreams.scala:83-85)
@@ -290,15 +297,24 @@ int32_t surge_replay_encode_protobuf_state(surge_replay_handle* h, const surge_j
                                            int64_t out_capacity, int64_t* d_out_off, int64_t* total_bytes_out);
 
 /* ---- shard map (R15) --------------------------------------------------------------
- * part_out[i] = abs(MurmurHash3.stringHash(str_i.takeWhile(_ != ':')) % n_partitions)
- * (KafkaPartitioner.scala:8,38-42) for n strings given as UTF-16 code units
- * utf16[str_off[i] .. str_off[i+1]).  CPU (host buffers) and GPU (K4, device
- * buffers) variants give identical results. */
+ * surge_replay_partition_hash:  part_out[i] = abs(MurmurHash3.stringHash(str_i) % n_partitions)
+ *   = KafkaPartitionProvider.partitionForKey(partitionByString, numberOfPartitions), KafkaPartitioner.scala:8 —
+ *   the WHOLE string is hashed, exactly as there (StringIdentityPartitioner, :29-31, routes this way).
+ * surge_replay_partition_hash_up_to_colon:  the same after PartitionStringUpToColon.partitionBy =
+ *   str.takeWhile(_ != ':') (KafkaPartitioner.scala:38-42), i.e. how the default partitioner routes event
+ *   keys "<aggregateId>:<seq>" to their aggregate's partition.
+ * n strings given as UTF-16 code units utf16[str_off[i] .. str_off[i+1]) (what JVM String.charAt sees).
+ * CPU (host buffers) and GPU (K4, device buffers) variants give identical results. */
 int32_t surge_replay_partition_hash(const uint16_t* utf16, const int64_t* str_off, int64_t n,
                                     int32_t n_partitions, int32_t* part_out);
+int32_t surge_replay_partition_hash_up_to_colon(const uint16_t* utf16, const int64_t* str_off, int64_t n,
+                                                int32_t n_partitions, int32_t* part_out);
 int32_t surge_replay_partition_hash_device(surge_replay_handle* h, const uint16_t* d_utf16,
                                            const int64_t* d_str_off, int64_t n,
                                            int32_t n_partitions, int32_t* d_part_out);
+int32_t surge_replay_partition_hash_up_to_colon_device(surge_replay_handle* h, const uint16_t* d_utf16,
+                                                       const int64_t* d_str_off, int64_t n,
+                                                       int32_t n_partitions, int32_t* d_part_out);
 
 /* Wire form of a snapshot for the xGMI exchange: only the first 40 bytes of a state carry information (the
  * 24-byte reserved tail is always zero), so shards travel packed (n x 40 B) and are expanded back to the

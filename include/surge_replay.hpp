@@ -95,8 +95,7 @@ inline std::vector<uint16_t> utf16_of(const std::string& s) {
 // trait KafkaPartitionProvider { def partitionForKey(partitionByString: String, numberOfPartitions: Int): Int }
 struct KafkaPartitionProvider {
   virtual ~KafkaPartitionProvider() = default;
-  // abs(MurmurHash3.stringHash(partitionByString) % numberOfPartitions); the C entry point also cuts the key
-  // at ':' — harmless here because partitionBy has already done so for the default partitioner.
+  // abs(MurmurHash3.stringHash(partitionByString) % numberOfPartitions): the whole string, as KafkaPartitioner.scala:8
   virtual int partitionForKey(const std::string& partitionByString, int numberOfPartitions) const {
     const std::vector<uint16_t> u = utf16_of(partitionByString);
     const int64_t off[2] = {0, (int64_t)u.size()};

@@ -94,3 +94,11 @@ JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_partitionHash(JNIEnv* 
   return check(env, NULL, surge_replay_partition_hash((const uint16_t*)addr(env, utf16), (const int64_t*)addr(env, strOff),
                                                        n, nPartitions, (int32_t*)addr(env, partOut)));
 }
+
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_partitionHashUpToColon(JNIEnv* env, jclass c, jobject utf16,
+                                                                                   jobject strOff, jlong n, jint nPartitions,
+                                                                                   jobject partOut) {
+  (void)c;
+  return check(env, NULL, surge_replay_partition_hash_up_to_colon((const uint16_t*)addr(env, utf16), (const int64_t*)addr(env, strOff),
+                                                                   n, nPartitions, (int32_t*)addr(env, partOut)));
+}

@@ -56,8 +56,12 @@ def lib() -> ctypes.CDLL:
         L.oracle_murmur3_string_hash.restype = i32
         L.oracle_partition_for_key.argtypes = [vp, i64, i32]
         L.oracle_partition_for_key.restype = i32
-        L.oracle_partition_hash_batch.argtypes = [vp, vp, i64, i32, vp]
+        L.oracle_partition_by_up_to_colon.argtypes = [vp, i64]
+        L.oracle_partition_by_up_to_colon.restype = i64
+        L.oracle_partition_hash_batch.argtypes = [vp, vp, i64, i32, i32, vp]
         L.oracle_partition_hash_batch.restype = i32
+        L.oracle_murmur3_x86_32.argtypes = [ctypes.c_char_p, i64, ctypes.c_uint32]
+        L.oracle_murmur3_x86_32.restype = ctypes.c_uint32
         L.oracle_counter_state_json.argtypes = [ctypes.c_char_p, i32, i32, ctypes.c_char_p, i64]
         L.oracle_counter_state_json.restype = i64
         _lib = L
@@ -115,17 +119,30 @@ def murmur3_string_hash(s: str) -> int:
     return int(lib().oracle_murmur3_string_hash(_ptr(u) if u.size else None, u.size))
 
 
+def murmur3_x86_32(data: bytes, seed: int = 0) -> int:
+    """Appleby's MurmurHash3_x86_32 over bytes, from the same primitives as ``murmur3_string_hash``."""
+    return int(lib().oracle_murmur3_x86_32(data, len(data), seed & 0xFFFFFFFF))
+
+
 def partition_for_key(key: str, n_partitions: int) -> int:
+    """``KafkaPartitionProvider.partitionForKey``: the WHOLE string (KafkaPartitioner.scala:8)."""
     u = np.ascontiguousarray(_utf16(key))
     return int(lib().oracle_partition_for_key(_ptr(u) if u.size else None, u.size, n_partitions))
 
 
-def partition_hash_batch(utf16: np.ndarray, str_off: np.ndarray, n_partitions: int) -> np.ndarray:
+def partition_by_up_to_colon(key: str) -> str:
+    """``PartitionStringUpToColon.partitionBy`` (KafkaPartitioner.scala:38-42)."""
+    u = np.ascontiguousarray(_utf16(key))
+    n = int(lib().oracle_partition_by_up_to_colon(_ptr(u) if u.size else None, u.size))
+    return u[:n].tobytes().decode("utf-16-le")
+
+
+def partition_hash_batch(utf16: np.ndarray, str_off: np.ndarray, n_partitions: int, up_to_colon: bool = False) -> np.ndarray:
     utf16 = np.ascontiguousarray(utf16, dtype=np.uint16)
     str_off = np.ascontiguousarray(str_off, dtype=np.int64)
     n = str_off.shape[0] - 1
     out = np.zeros(n, dtype=np.int32)
-    rc = lib().oracle_partition_hash_batch(_ptr(utf16), _ptr(str_off), n, n_partitions, _ptr(out))
+    rc = lib().oracle_partition_hash_batch(_ptr(utf16), _ptr(str_off), n, n_partitions, 1 if up_to_colon else 0, _ptr(out))
     if rc != 0:
         raise RuntimeError("oracle_partition_hash_batch failed")
     return out

@@ -283,25 +283,54 @@ int32_t oracle_murmur3_string_hash(const uint16_t* s, int64_t len) {
   return (int32_t)mm3_finalize(h, (uint32_t)len);
 }
 
-/* math.abs(MurmurHash3.stringHash(partitionByString) % numberOfPartitions)
- * — KafkaPartitioner.scala:8 ; partitionBy = str.takeWhile(_ != ':') — :39-41.
- * JVM `%` truncates toward zero, like C99. */
+/* KafkaPartitionProvider.partitionForKey(partitionByString, numberOfPartitions) =
+ * math.abs(MurmurHash3.stringHash(partitionByString) % numberOfPartitions) — KafkaPartitioner.scala:8:
+ * the WHOLE string.  JVM `%` truncates toward zero, like C99. */
 int32_t oracle_partition_for_key(const uint16_t* s, int64_t len, int32_t n_partitions) {
-  int64_t n = 0;
-  int32_t h, r;
-  while (n < len && s[n] != (uint16_t)':') ++n;
-  h = oracle_murmur3_string_hash(s, n);
-  r = h % n_partitions;
+  const int32_t h = oracle_murmur3_string_hash(s, len);
+  const int32_t r = h % n_partitions;
   return r < 0 ? -r : r;
 }
 
+/* PartitionStringUpToColon.partitionBy = str.takeWhile(_ != ':') — KafkaPartitioner.scala:38-42.
+ * Returns the length of the prefix. */
+int64_t oracle_partition_by_up_to_colon(const uint16_t* s, int64_t len) {
+  int64_t n = 0;
+  while (n < len && s[n] != (uint16_t)':') ++n;
+  return n;
+}
+
 int32_t oracle_partition_hash_batch(const uint16_t* utf16, const int64_t* str_off, int64_t n,
-                                    int32_t n_partitions, int32_t* part_out) {
+                                    int32_t n_partitions, int32_t up_to_colon, int32_t* part_out) {
   int64_t i;
   if (n_partitions <= 0) return -1;
-  for (i = 0; i < n; ++i)
-    part_out[i] = oracle_partition_for_key(utf16 + str_off[i], str_off[i + 1] - str_off[i], n_partitions);
+  for (i = 0; i < n; ++i) {
+    const uint16_t* s = utf16 + str_off[i];
+    int64_t len = str_off[i + 1] - str_off[i];
+    if (up_to_colon) len = oracle_partition_by_up_to_colon(s, len);
+    part_out[i] = oracle_partition_for_key(s, len, n_partitions);
+  }
   return 0;
+}
+
+/* Standard MurmurHash3_x86_32 over bytes (Appleby's published algorithm), built from the SAME mix /
+ * mixLast / finalize primitives as oracle_murmur3_string_hash above, so that the published verification
+ * values of MurmurHash3_x86_32 pin those primitives (tests/test_oracle_kat.py). */
+uint32_t oracle_murmur3_x86_32(const uint8_t* data, int64_t len, uint32_t seed) {
+  uint32_t h = seed, k = 0;
+  int64_t i = 0;
+  for (; i + 4 <= len; i += 4) {
+    k = (uint32_t)data[i] | ((uint32_t)data[i + 1] << 8) | ((uint32_t)data[i + 2] << 16) | ((uint32_t)data[i + 3] << 24);
+    h = mm3_mix(h, k);
+  }
+  k = 0;
+  switch (len & 3) {
+    case 3: k ^= (uint32_t)data[i + 2] << 16; /* fallthrough */
+    case 2: k ^= (uint32_t)data[i + 1] << 8;  /* fallthrough */
+    case 1: k ^= (uint32_t)data[i];
+            h = mm3_mix_last(h, k);
+  }
+  return mm3_finalize(h, (uint32_t)len);
 }
 
 /* ---------------------------------------------------------------------------

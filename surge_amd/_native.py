@@ -44,7 +44,10 @@ EXPORTS = (
     "surge_replay_unpack_states",
     "surge_replay_partition_hash",
     "surge_replay_partition_hash_device",
+    "surge_replay_partition_hash_up_to_colon",
+    "surge_replay_partition_hash_up_to_colon_device",
     "surge_replay_set_state_out",
+    "surge_replay_grow",
     "surge_replay_stats",
     "surge_replay_stats_reset",
     "surge_replay_stream_probe",
@@ -162,7 +165,10 @@ def load() -> ctypes.CDLL:
         "surge_replay_unpack_states": ([vp, vp, i64, vp, vp], i32),
         "surge_replay_partition_hash": ([vp, vp, i64, i32, vp], i32),
         "surge_replay_partition_hash_device": ([vp, vp, vp, i64, i32, vp], i32),
+        "surge_replay_partition_hash_up_to_colon": ([vp, vp, i64, i32, vp], i32),
+        "surge_replay_partition_hash_up_to_colon_device": ([vp, vp, vp, i64, i32, vp], i32),
         "surge_replay_set_state_out": ([vp, vp], i32),
+        "surge_replay_grow": ([vp, i64], i32),
         "surge_replay_stats": ([vp, ctypes.POINTER(CStats)], i32),
         "surge_replay_stats_reset": ([vp], i32),
         "surge_replay_stream_probe": ([vp, vp, i64, ctypes.POINTER(ctypes.c_double)], i32),

@@ -69,6 +69,7 @@ struct surge_replay_handle {
   uint4* d_state = nullptr;
   int64_t n_agg = 0, n_events = 0;
   bool bound = false;
+  bool log_valid = false;  // false once the resident state was grown past the bound CSR (append_* only until the next load)
 
   // analysis of the bound CSR (computed at load/bind time)
   CsrAnalysis an{};
@@ -405,6 +406,7 @@ int32_t surge_replay_bind_device_csr(surge_replay_handle* h, const int64_t* d_se
   const int32_t rc = analyze_bound(h);
   if (rc != SURGE_OK) return rc;
   h->bound = true;
+  h->log_valid = true;
   h->st.n_aggregates = n_agg;
   h->st.n_events = h->an.last - h->an.first;
   h->st.algorithmic_bytes = algorithmic_bytes(h->st.n_events, n_agg, d_init_state != nullptr);
@@ -442,6 +444,7 @@ int32_t surge_replay_load_csr(surge_replay_handle* h, const int64_t* seg_off, in
 int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
   if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
   if (!h->bound) return fail(h, SURGE_E_STATE, "fold before load_csr/bind_device_csr");
+  if (!h->log_valid) return fail(h, SURGE_E_STATE, "the resident state was grown past the bound log (surge_replay_grow): load a log again");
   if (algo < SURGE_ALGO_AUTO || algo > SURGE_ALGO_SORTED) return fail(h, SURGE_E_INVALID, "unknown algo");
   DeviceGuard g(h->device);
   const int64_t span = h->an.last - h->an.first;
@@ -822,16 +825,19 @@ int32_t surge_replay_device_state(surge_replay_handle* h, void** d_states, int64
  * GPU round trip), written independently of oracle/. */
 static inline uint32_t rotl32_host(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 
-int32_t surge_replay_partition_hash(const uint16_t* utf16, const int64_t* str_off, int64_t n, int32_t n_partitions,
-                                    int32_t* part_out) {
+static int32_t partition_hash_host(const uint16_t* utf16, const int64_t* str_off, int64_t n, int32_t n_partitions,
+                                   int32_t* part_out, bool up_to_colon) {
   if (n < 0 || n_partitions <= 0) return fail(nullptr, SURGE_E_INVALID, "bad n or n_partitions");
   if (n == 0) return SURGE_OK;
   if (!str_off || !part_out) return fail(nullptr, SURGE_E_INVALID, "NULL buffer");
   for (int64_t i = 0; i < n; ++i) {
     const int64_t b = str_off[i], e = str_off[i + 1];
     if (e < b) return fail(nullptr, SURGE_E_INVALID, "str_off is not monotone");
-    int64_t len = 0;
-    while (b + len < e && utf16[b + len] != (uint16_t)':') ++len;
+    int64_t len = e - b;
+    if (up_to_colon) {  // PartitionStringUpToColon.partitionBy (KafkaPartitioner.scala:38-42)
+      len = 0;
+      while (b + len < e && utf16[b + len] != (uint16_t)':') ++len;
+    }
     uint32_t hsh = 0xf7ca7fd2u;
     int64_t k = 0;
     for (; k + 1 < len; k += 2) {
@@ -852,15 +858,36 @@ int32_t surge_replay_partition_hash(const uint16_t* utf16, const int64_t* str_of
   return SURGE_OK;
 }
 
-int32_t surge_replay_partition_hash_device(surge_replay_handle* h, const uint16_t* d_utf16, const int64_t* d_str_off,
-                                           int64_t n, int32_t n_partitions, int32_t* d_part_out) {
+int32_t surge_replay_partition_hash(const uint16_t* utf16, const int64_t* str_off, int64_t n, int32_t n_partitions,
+                                    int32_t* part_out) {
+  return partition_hash_host(utf16, str_off, n, n_partitions, part_out, false);
+}
+
+int32_t surge_replay_partition_hash_up_to_colon(const uint16_t* utf16, const int64_t* str_off, int64_t n,
+                                                int32_t n_partitions, int32_t* part_out) {
+  return partition_hash_host(utf16, str_off, n, n_partitions, part_out, true);
+}
+
+static int32_t partition_hash_dev(surge_replay_handle* h, const uint16_t* d_utf16, const int64_t* d_str_off, int64_t n,
+                                  int32_t n_partitions, int32_t* d_part_out, bool up_to_colon) {
   if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
   if (n < 0 || n_partitions <= 0) return fail(h, SURGE_E_INVALID, "bad n or n_partitions");
   if (n == 0) return SURGE_OK;
   if (!d_str_off || !d_part_out) return fail(h, SURGE_E_INVALID, "NULL buffer");
   DeviceGuard g(h->device);
-  HIPCHK(h, launch_partition_hash(d_utf16, d_str_off, n, n_partitions, d_part_out, h->stream));
+  HIPCHK(h, launch_partition_hash(d_utf16, d_str_off, n, n_partitions, d_part_out, up_to_colon, h->stream));
   return SURGE_OK;
+}
+
+int32_t surge_replay_partition_hash_device(surge_replay_handle* h, const uint16_t* d_utf16, const int64_t* d_str_off,
+                                           int64_t n, int32_t n_partitions, int32_t* d_part_out) {
+  return partition_hash_dev(h, d_utf16, d_str_off, n, n_partitions, d_part_out, false);
+}
+
+int32_t surge_replay_partition_hash_up_to_colon_device(surge_replay_handle* h, const uint16_t* d_utf16,
+                                                       const int64_t* d_str_off, int64_t n, int32_t n_partitions,
+                                                       int32_t* d_part_out) {
+  return partition_hash_dev(h, d_utf16, d_str_off, n, n_partitions, d_part_out, true);
 }
 
 int32_t surge_replay_stats(surge_replay_handle* h, surge_replay_stats_t* out) {
@@ -908,6 +935,40 @@ int32_t surge_replay_stats_reset(surge_replay_handle* h) {
   h->timing_valid = false;
   h->st.sum_fold_kernel_ms = 0.0;
   h->st.timed_folds = 0;
+  return SURGE_OK;
+}
+
+int32_t surge_replay_grow(surge_replay_handle* h, int64_t new_n_agg) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->bound) return fail(h, SURGE_E_STATE, "grow before load_csr/bind_device_csr");
+  if (new_n_agg <= h->n_agg) return SURGE_OK;
+  if (h->d_state != (uint4*)h->own_state.ptr)
+    return fail(h, SURGE_E_UNSUPPORTED, "the state buffer belongs to the caller (bind_device_csr / set_state_out): grow it there");
+  DeviceGuard g(h->device);
+  std::unique_lock<std::shared_mutex> lk(h->mu);
+  if ((size_t)new_n_agg * 64 > h->own_state.cap) {
+    // amortised: at least double, so a stream of new aggregates reallocates O(log n) times
+    size_t want = h->own_state.cap * 2;
+    if (want < (size_t)new_n_agg * 64) want = (size_t)new_n_agg * 64;
+    void* fresh = nullptr;
+    HIPCHK(h, hipMalloc(&fresh, want));
+    hipError_t e = hipMemcpyAsync(fresh, h->own_state.ptr, (size_t)h->n_agg * 64, hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(fresh);
+      return fail_hip(h, e, "copying the resident state");
+    }
+    (void)hipFree(h->own_state.ptr);
+    h->own_state.ptr = fresh;
+    h->own_state.cap = want;
+    h->d_state = (uint4*)fresh;
+  }
+  // new aggregates are None (all-zero, the canonical encoding)
+  HIPCHK(h, hipMemsetAsync((char*)h->d_state + (size_t)h->n_agg * 64, 0, (size_t)(new_n_agg - h->n_agg) * 64, h->stream));
+  h->n_agg = new_n_agg;
+  h->st.n_aggregates = new_n_agg;
+  h->log_valid = false;
+  h->fold_epoch.fetch_add(1);
   return SURGE_OK;
 }
 

@@ -903,18 +903,23 @@ __global__ void __launch_bounds__(kCompactBlock) compact_scatter_kernel(const in
   if (blockIdx.x == 0 && threadIdx.x == 0) nz_off[block_counts[nb]] = off[n_seg];
 }
 
-// ---- K4: shard map  abs(MurmurHash3.stringHash(id.takeWhile(_ != ':')) % n)
-// (modules/common/src/main/scala/surge/kafka/KafkaPartitioner.scala:8,38-42; scala-library 2.13.8 algorithm)
+// ---- K4: shard map  partitionForKey(s, n) = abs(MurmurHash3.stringHash(s) % n)
+// (modules/common/src/main/scala/surge/kafka/KafkaPartitioner.scala:8; scala-library 2.13.8 algorithm); CUT = true
+// first applies PartitionStringUpToColon.partitionBy = s.takeWhile(_ != ':') (KafkaPartitioner.scala:38-42)
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 
+template <bool CUT>
 __global__ void partition_hash_kernel(const uint16_t* __restrict__ utf16, const int64_t* __restrict__ str_off, int64_t n,
                                       int32_t n_partitions, int32_t* __restrict__ part_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint16_t* s = utf16 + str_off[i];
   const int64_t full = str_off[i + 1] - str_off[i];
-  int64_t len = 0;
-  while (len < full && s[len] != (uint16_t)':') ++len;
+  int64_t len = full;
+  if (CUT) {
+    len = 0;
+    while (len < full && s[len] != (uint16_t)':') ++len;
+  }
   uint32_t h = 0xf7ca7fd2u;
   int64_t k = 0;
   for (; k + 1 < len; k += 2) {
@@ -1304,10 +1309,14 @@ hipError_t launch_compact_nonempty(const int64_t* off, int64_t n_seg, int64_t* d
 }
 
 hipError_t launch_partition_hash(const uint16_t* utf16, const int64_t* str_off, int64_t n, int32_t n_partitions,
-                                 int32_t* part_out, hipStream_t stream) {
+                                 int32_t* part_out, bool up_to_colon, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(partition_hash_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, utf16, str_off, n,
-                     n_partitions, part_out);
+  if (up_to_colon)
+    hipLaunchKernelGGL(partition_hash_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, utf16, str_off, n,
+                       n_partitions, part_out);
+  else
+    hipLaunchKernelGGL(partition_hash_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, utf16, str_off, n,
+                       n_partitions, part_out);
   return hipGetLastError();
 }
 

@@ -91,8 +91,10 @@ struct Reader {
   }
 };
 
-// LZ4 block (sequence) decoder into dst[*op .. cap); matches may reach back into everything already written
-bool lz4_block(const uint8_t* ip, const uint8_t* iend, uint8_t* dst, int64_t* op_io, int64_t cap) {
+// LZ4 block (sequence) decoder into dst[*op .. cap); matches may reach back into everything already written.
+// LZ4_OK, LZ4_CORRUPT (malformed input) or LZ4_NOSPACE (dst too small: the caller grows it and retries).
+enum { LZ4_OK = 0, LZ4_CORRUPT = 1, LZ4_NOSPACE = 2 };
+int lz4_block(const uint8_t* ip, const uint8_t* iend, uint8_t* dst, int64_t* op_io, int64_t cap) {
   int64_t op = *op_io;
   while (ip < iend) {
     const uint8_t token = *ip++;
@@ -100,31 +102,32 @@ bool lz4_block(const uint8_t* ip, const uint8_t* iend, uint8_t* dst, int64_t* op
     if (lit == 15) {
       uint8_t b;
       do {
-        if (ip >= iend) return false;
+        if (ip >= iend) return LZ4_CORRUPT;
         b = *ip++;
         lit += b;
       } while (b == 255);
     }
-    if (iend - ip < lit || cap - op < lit) return false;
+    if (iend - ip < lit) return LZ4_CORRUPT;
+    if (cap - op < lit) return LZ4_NOSPACE;
     std::memcpy(dst + op, ip, (size_t)lit);
     ip += lit;
     op += lit;
     if (ip >= iend) break;  // the last sequence carries literals only
-    if (iend - ip < 2) return false;
+    if (iend - ip < 2) return LZ4_CORRUPT;
     const int64_t offset = ip[0] | (ip[1] << 8);
     ip += 2;
-    if (offset == 0 || offset > op) return false;
+    if (offset == 0 || offset > op) return LZ4_CORRUPT;
     int64_t ml = token & 15;
     if (ml == 15) {
       uint8_t b;
       do {
-        if (ip >= iend) return false;
+        if (ip >= iend) return LZ4_CORRUPT;
         b = *ip++;
         ml += b;
       } while (b == 255);
     }
     ml += 4;
-    if (cap - op < ml) return false;
+    if (cap - op < ml) return LZ4_NOSPACE;
     if (offset >= ml) {
       std::memcpy(dst + op, dst + op - offset, (size_t)ml);
     } else if (offset >= 8) {  // overlapping, but every 8-byte step reads bytes already final
@@ -137,7 +140,7 @@ bool lz4_block(const uint8_t* ip, const uint8_t* iend, uint8_t* dst, int64_t* op
     op += ml;
   }
   *op_io = op;
-  return true;
+  return LZ4_OK;
 }
 
 }  // namespace
@@ -212,6 +215,12 @@ int64_t intern(surge_ingest* g, const uint8_t* key, int32_t len) {
   return idx;
 }
 
+// dense aggregate index of a record that is being delivered
+inline int64_t deliver_idx(surge_ingest* g, Rec& r) {
+  if (r.agg_idx == -2) r.agg_idx = intern(g, g->arena.data() + r.key_off, r.key_len);
+  return r.agg_idx;
+}
+
 // number of records deliverable from the head of the queue
 int64_t ready_count(const surge_ingest* g) {
   int64_t n = 0;
@@ -270,7 +279,8 @@ int32_t parse_records(surge_ingest* g, Batch& b, const uint8_t* data, int64_t le
     if (klen > 0) g->arena.insert(g->arena.end(), key, key + klen);
     rec.value_off = (int64_t)g->arena.size();
     if (vlen > 0) g->arena.insert(g->arena.end(), val, val + vlen);
-    rec.agg_idx = klen >= 0 ? intern(g, key, (int32_t)klen) : -1;
+    rec.agg_idx = klen >= 0 ? -2 : -1;  // -2: interned when the record is DELIVERED (drain): the keys of aborted or
+                                        // still-open transactions never enter the key table
     b.recs.push_back(rec);
   }
   return OK;
@@ -331,8 +341,10 @@ int64_t surge_lz4_frame_decompress(const uint8_t* src, int64_t n, uint8_t* dst, 
       if (cap - op < (int64_t)size) return -6;
       std::memcpy(dst + op, p, size);
       op += size;
-    } else if (!lz4_block(p, p + size, dst, &op, cap)) {
-      return SURGE_E_CORRUPT;
+    } else {
+      const int rc = lz4_block(p, p + size, dst, &op, cap);
+      if (rc == LZ4_NOSPACE) return -6;
+      if (rc != LZ4_OK) return SURGE_E_CORRUPT;
     }
     p += size;
     if (block_checksum) p += 4;
@@ -366,20 +378,26 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
   if (consumed_out) *consumed_out = 0;
   if (g->queue.empty()) g->arena.clear();  // spans handed out by the last drain are released here
   int64_t pos = 0;
+  // A failure in batch k leaves batches 0..k-1 of this buffer decoded and queued: report them as consumed so a
+  // caller that retries (or skips the bad batch) never feeds them twice.
+  auto bail = [&](int32_t code, const char* msg) {
+    if (consumed_out) *consumed_out = pos;
+    return fail(g, code, msg);
+  };
   try {
     while (len - pos >= 12) {
       Reader h{data + pos, data + len};
       const int64_t base_offset = h.i64();
       const int32_t batch_len = h.i32();
-      if (batch_len < 49) return fail(g, SURGE_E_CORRUPT, "batchLength below the v2 header size");
+      if (batch_len < 49) return bail(SURGE_E_CORRUPT, "batchLength below the v2 header size");
       if (len - pos - 12 < batch_len) break;  // partial batch: wait for more bytes
       const uint8_t* body = data + pos + 12;
       Reader r{body, body + batch_len};
       (void)r.i32();  // partitionLeaderEpoch
       const uint8_t magic = r.u8();
-      if (magic != 2) return fail(g, E_UNSUPPORTED, "only message format v2 (magic 2) is supported");
+      if (magic != 2) return bail(E_UNSUPPORTED, "only message format v2 (magic 2) is supported");
       const uint32_t crc = (uint32_t)r.i32();
-      if (surge_crc32c(r.p, r.end - r.p) != crc) return fail(g, SURGE_E_CORRUPT, "record batch CRC-32C mismatch");
+      if (surge_crc32c(r.p, r.end - r.p) != crc) return bail(SURGE_E_CORRUPT, "record batch CRC-32C mismatch");
       const int16_t attrs = r.i16();
       (void)r.i32();  // lastOffsetDelta
       (void)r.i64();  // baseTimestamp
@@ -388,34 +406,44 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
       (void)r.i16();  // producerEpoch
       (void)r.i32();  // baseSequence
       const int32_t count = r.i32();
-      if (!r.ok || count < 0) return fail(g, SURGE_E_CORRUPT, "truncated batch header");
+      if (!r.ok || count < 0) return bail(SURGE_E_CORRUPT, "truncated batch header");
       const int codec = attrs & 7;
       const bool transactional = attrs & 0x10, control = attrs & 0x20;
       const uint8_t* recs = r.p;
       int64_t recs_len = r.end - r.p;
       if (codec == 3) {
+        // first guess: the frame's content-size field when the producer wrote one, else 8x (Kafka's LZ4 output
+        // stream omits it); a too-small guess comes back as -6 (out of space) and is grown, never as "corrupt"
         int64_t cap = recs_len * 8 + 1024;
+        if (recs_len >= 15 && (recs[4] & 0x08)) {
+          uint64_t cs = 0;
+          for (int k = 7; k >= 0; --k) cs = (cs << 8) | recs[6 + k];
+          if (cs > 0 && cs <= (1ull << 31)) cap = (int64_t)cs;
+        }
         int64_t got;
         while (true) {
           g->scratch.resize((size_t)cap);
           got = surge_lz4_frame_decompress(recs, recs_len, g->scratch.data(), cap);
           if (got != -6) break;
           cap *= 4;
-          if (cap > (1ll << 31)) return fail(g, SURGE_E_CORRUPT, "LZ4 batch expands beyond 2 GiB");
+          if (cap > (1ll << 31)) return bail(SURGE_E_CORRUPT, "LZ4 batch expands beyond 2 GiB");
         }
-        if (got < 0) return fail(g, SURGE_E_CORRUPT, "bad LZ4 frame in record batch");
+        if (got < 0) return bail(SURGE_E_CORRUPT, "bad LZ4 frame in record batch");
         g->counters[6] += got;
         recs = g->scratch.data();
         recs_len = got;
       } else if (codec != 0) {
-        return fail(g, E_UNSUPPORTED, "compression codec not supported (only none and lz4; the reference publishes lz4)");
+        return bail(E_UNSUPPORTED, "compression codec not supported (only none and lz4; the reference publishes lz4)");
       }
       Batch b;
       b.producer_id = producer_id;
       b.transactional = transactional;
       int control_type = -1;
       const int32_t rc = parse_records(g, b, recs, recs_len, count, base_offset, control, &control_type);
-      if (rc != OK) return rc;
+      if (rc != OK) {
+        if (consumed_out) *consumed_out = pos;
+        return rc;
+      }
       g->counters[0] += 1;
       if (control) {
         g->counters[4] += 1;
@@ -433,6 +461,7 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
       pos += 12 + batch_len;
     }
   } catch (const std::bad_alloc&) {
+    if (consumed_out) *consumed_out = pos;
     return fail(g, E_NOMEM, "out of host memory while decoding");
   }
   if (consumed_out) *consumed_out = pos;
@@ -452,8 +481,8 @@ int32_t surge_ingest_drain(surge_ingest* g, int64_t max, surge_ingest_record* ou
     if (b.decided == 0) break;
     if (b.decided == 2) { g->queue.pop_front(); continue; }
     while (n < max && b.next < b.recs.size()) {
-      const Rec& r = b.recs[b.next++];
-      out[n].offset = r.offset; out[n].agg_idx = r.agg_idx; out[n].key_off = r.key_off; out[n].key_len = r.key_len;
+      Rec& r = b.recs[b.next++];
+      out[n].offset = r.offset; out[n].agg_idx = deliver_idx(g, r); out[n].key_off = r.key_off; out[n].key_len = r.key_len;
       out[n].value_len = r.value_len; out[n].value_off = r.value_off;
       ++n;
     }
@@ -475,7 +504,7 @@ int32_t surge_ingest_drain_fixed16(surge_ingest* g, int64_t max, int64_t* agg_id
     if (b.decided == 0) break;
     if (b.decided == 2) continue;
     for (size_t i = b.next; i < b.recs.size() && avail < max; ++i, ++avail)
-      if (b.recs[i].value_len != 16 || b.recs[i].agg_idx < 0)
+      if (b.recs[i].value_len != 16 || b.recs[i].agg_idx == -1)
         return fail(g, E_INVALID, "record value is not a 16-byte fixed event (or the key is null)");
     if (avail >= max) break;
   }
@@ -486,8 +515,8 @@ int32_t surge_ingest_drain_fixed16(surge_ingest* g, int64_t max, int64_t* agg_id
     if (b.decided == 0) break;
     if (b.decided == 2) { g->queue.pop_front(); continue; }
     while (n < max && b.next < b.recs.size()) {
-      const Rec& r = b.recs[b.next++];
-      agg_idx_out[n] = r.agg_idx;
+      Rec& r = b.recs[b.next++];
+      agg_idx_out[n] = deliver_idx(g, r);
       std::memcpy(ev + n * 16, g->arena.data() + r.value_off, 16);
       if (offsets_out) offsets_out[n] = r.offset;
       ++n;

@@ -88,7 +88,7 @@ hipError_t launch_fill_empty(const int64_t* off, int64_t n_seg, const uint4* ini
 hipError_t launch_compact_nonempty(const int64_t* off, int64_t n_seg, int64_t* d_block_counts,
                                    int64_t* nz_off, int64_t* nz_map, hipStream_t stream);
 hipError_t launch_partition_hash(const uint16_t* utf16, const int64_t* str_off, int64_t n,
-                                 int32_t n_partitions, int32_t* part_out, hipStream_t stream);
+                                 int32_t n_partitions, int32_t* part_out, bool up_to_colon, hipStream_t stream);
 hipError_t launch_stream_probe(const uint4* src, int64_t n_vec, uint32_t* sink, int variant, hipStream_t stream);
 hipError_t launch_json_encode(const surge_json_template& tmpl, const uint4* states, int64_t n, const uint8_t* keys,
                               const int64_t* key_off, int64_t* d_len_off, int64_t* d_totals, uint8_t* out, bool write_pass,

@@ -59,8 +59,10 @@ class EventsTopicIngest:
         buf = self._tail + bytes(data)
         consumed = ctypes.c_int64(0)
         arr = (ctypes.c_uint8 * len(buf)).from_buffer_copy(buf) if buf else None
-        self._check(self._lib.surge_ingest_feed(self._h, arr, len(buf), ctypes.byref(consumed)))
+        rc = self._lib.surge_ingest_feed(self._h, arr, len(buf), ctypes.byref(consumed))
+        # also on failure: batches decoded before the failing one ARE queued and must not be fed again
         self._tail = buf[consumed.value:]
+        self._check(rc)
         return consumed.value
 
     @property

@@ -4,7 +4,8 @@
 ``modules/common/src/main/scala/surge/kafka/KafkaPartitioner.scala:8``; the default partitioner cuts
 the key at the first ``':'`` (``PartitionStringUpToColon``, :38-42) so events keyed
 ``"<id>:<seq>"`` land with their aggregate.  The hash itself is computed by the C ABI
-(``surge_replay_partition_hash``: CPU; ``surge_replay_partition_hash_device``: GPU kernel K4).
+(``surge_replay_partition_hash[_up_to_colon]``: CPU; ``..._device``: GPU kernel K4); the cut belongs to the
+partitioner's ``partitionBy``, not to ``partitionForKey``.
 """
 from __future__ import annotations
 
@@ -26,8 +27,9 @@ def utf16_table(keys: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
     return np.ascontiguousarray(data, dtype=np.uint16), off
 
 
-def partition_for_keys(keys: Sequence[str], n_partitions: int) -> np.ndarray:
-    """Batch ``partitionForKey`` with ``PartitionStringUpToColon`` semantics (CPU entry point)."""
+def partition_for_keys(keys: Sequence[str], n_partitions: int, up_to_colon: bool = False) -> np.ndarray:
+    """Batch ``partitionForKey`` (CPU entry point): hashes each WHOLE string, like ``KafkaPartitioner.scala:8``;
+    ``up_to_colon=True`` first applies ``PartitionStringUpToColon.partitionBy`` (``:38-42``)."""
     if n_partitions <= 0:
         raise ValueError("numberOfPartitions must be positive")
     data, off = utf16_table(keys)
@@ -35,7 +37,8 @@ def partition_for_keys(keys: Sequence[str], n_partitions: int) -> np.ndarray:
     if len(keys) == 0:
         return out
     lib = _native.load()
-    rc = lib.surge_replay_partition_hash(
+    fn = lib.surge_replay_partition_hash_up_to_colon if up_to_colon else lib.surge_replay_partition_hash
+    rc = fn(
         data.ctypes.data_as(ctypes.c_void_p) if data.size else None,
         off.ctypes.data_as(ctypes.c_void_p),
         len(keys),
@@ -48,9 +51,16 @@ def partition_for_keys(keys: Sequence[str], n_partitions: int) -> np.ndarray:
 
 
 class KafkaPartitionProvider:
+    """``trait KafkaPartitionProvider`` (KafkaPartitioner.scala:7-9): hashes the string it is given, whole."""
+
     def partition_for_key(self, partition_by_string: str, number_of_partitions: int) -> int:
-        # the C entry point already applies takeWhile(_ != ':'); a key without ':' hashes whole
         return int(partition_for_keys([partition_by_string], number_of_partitions)[0])
+
+    def partition_for(self, key: str, number_of_partitions: int) -> int:
+        """What the producer / router computes for a record key: ``partitionForKey(partitionBy(key), n)``
+        (``KafkaProducer.scala:45-57``)."""
+        by = getattr(self, "partition_by", None)
+        return self.partition_for_key(by(key) if by is not None else key, number_of_partitions)
 
 
 class KafkaPartitioner(KafkaPartitionProvider):
@@ -65,19 +75,12 @@ class KafkaPartitioner(KafkaPartitionProvider):
 
 
 class StringIdentityPartitioner(KafkaPartitioner):
-    """Hashes the whole key, colons included (KafkaPartitioner.scala:30-32).
-
-    The C entry points restate the default routing (cut at ``':'`` then hash), so this rarely
-    used partitioner hashes on the host instead.
-    """
+    """Hashes the whole key, colons included (KafkaPartitioner.scala:29-31)."""
 
     instance: "StringIdentityPartitioner"
 
     def partition_by(self, key: str) -> str:
         return key
-
-    def partition_for_key(self, partition_by_string: str, number_of_partitions: int) -> int:
-        return _partition_whole(partition_by_string, number_of_partitions)
 
 
 class PartitionStringUpToColon(KafkaPartitioner):
@@ -97,37 +100,3 @@ class NoPartitioner(KafkaPartitionProvider):
 
 StringIdentityPartitioner.instance = StringIdentityPartitioner()
 PartitionStringUpToColon.instance = PartitionStringUpToColon()
-
-
-def _partition_whole(s: str, n: int) -> int:
-    """Hash a full string including any ':' (host-only path for StringIdentityPartitioner)."""
-    u = np.frombuffer(s.encode("utf-16-le"), dtype=np.uint16).astype(np.uint32)
-    M = 0xFFFFFFFF
-
-    def rotl(x, r):
-        return ((x << r) | (x >> (32 - r))) & M
-
-    def mix_last(h, k):
-        k = (k * 0xCC9E2D51) & M
-        k = rotl(k, 15)
-        k = (k * 0x1B873593) & M
-        return h ^ k
-
-    h = 0xF7CA7FD2
-    i = 0
-    while i + 1 < len(u):
-        h = mix_last(h, ((int(u[i]) << 16) + int(u[i + 1])) & M)
-        h = rotl(h, 13)
-        h = (h * 5 + 0xE6546B64) & M
-        i += 2
-    if i < len(u):
-        h = mix_last(h, int(u[i]))
-    h ^= len(u)
-    h ^= h >> 16
-    h = (h * 0x85EBCA6B) & M
-    h ^= h >> 13
-    h = (h * 0xC2B2AE35) & M
-    h ^= h >> 16
-    signed = h - (1 << 32) if h & 0x80000000 else h
-    r = abs(signed) % n if signed >= 0 else -((-signed) % n)  # JVM truncated %
-    return abs(r)

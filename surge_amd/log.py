@@ -78,12 +78,13 @@ def pack_events(model: ReplayableCommandModel, events_in_offset_order: Sequence,
 def pack_batch(model: ReplayableCommandModel, events_in_offset_order: Sequence, keys: KeyTable, n_agg: int):
     """Micro-batch for ``append_fold``: ``(group_agg, group_off, events)``, one group per touched aggregate."""
     enc = model.encode_events(events_in_offset_order)
-    agg_idx = np.empty(len(events_in_offset_order), dtype=np.int64)
-    for i, e in enumerate(events_in_offset_order):
-        k = keys.intern(model.aggregate_id_of(e))
-        if k >= n_agg:
-            raise IndexError(f"aggregate {model.aggregate_id_of(e)!r} exceeds the store capacity {n_agg}")
-        agg_idx[i] = k
+    ids = [model.aggregate_id_of(e) for e in events_in_offset_order]
+    # check the capacity BEFORE interning anything: a rejected batch must not leave ids in the key table
+    fresh = list(dict.fromkeys(k for k in ids if keys.get(k) is None))
+    if len(keys) + len(fresh) > n_agg:
+        raise IndexError(f"aggregate {fresh[max(0, n_agg - len(keys))]!r} exceeds the store capacity {n_agg} "
+                         "(grow the resident state first: ReplayEngine.grow)")
+    agg_idx = np.fromiter((keys.intern(k) for k in ids), dtype=np.int64, count=len(ids))
     return batch_groups(agg_idx, enc)
 
 

@@ -187,6 +187,11 @@ class ReplayEngine:
             raise ValueError("one aggregate index per event")
         self._check(self._lib.surge_replay_append_events(self._h, _np_ptr(agg_idx), _np_ptr(events), events.shape[0]))
 
+    def grow(self, new_n_agg: int) -> None:
+        """Extend the resident state to ``new_n_agg`` aggregates (the new ones ``None``); see ``surge_replay_grow``."""
+        self._check(self._lib.surge_replay_grow(self._h, int(new_n_agg)))
+        self.n_agg = max(self.n_agg, int(new_n_agg))
+
     # -- read --------------------------------------------------------------------------------------
     def snapshot(self) -> np.ndarray:
         out = np.zeros(self.n_agg, dtype=STATE_DTYPE)
@@ -260,10 +265,9 @@ class ReplayEngine:
         self._check(self._lib.surge_replay_stream_probe(self._h, _dev_ptr(tensor), nbytes, ctypes.byref(ms)))
         return ms.value
 
-    def partition_hash_device(self, d_utf16, d_str_off, n_partitions: int, d_out) -> None:
+    def partition_hash_device(self, d_utf16, d_str_off, n_partitions: int, d_out, up_to_colon: bool = False) -> None:
+        """K4: ``partitionForKey`` of whole strings (``KafkaPartitioner.scala:8``); ``up_to_colon`` first applies
+        ``PartitionStringUpToColon.partitionBy`` (``:38-42``)."""
         n = d_str_off.numel() - 1
-        self._check(
-            self._lib.surge_replay_partition_hash_device(
-                self._h, _dev_ptr(d_utf16), _dev_ptr(d_str_off), n, n_partitions, _dev_ptr(d_out)
-            )
-        )
+        fn = self._lib.surge_replay_partition_hash_up_to_colon_device if up_to_colon else self._lib.surge_replay_partition_hash_device
+        self._check(fn(self._h, _dev_ptr(d_utf16), _dev_ptr(d_str_off), n, n_partitions, _dev_ptr(d_out)))

@@ -43,12 +43,13 @@ class SnapshotWriter:
         self.topic = store.business_logic.state_topic.name
 
     def records_for(self, aggregate_ids: Sequence[str]) -> List[StateRecord]:
-        ids = [k for k in aggregate_ids if self.store.keys.get(k) is not None]
+        n_agg = self.store.engine.n_agg  # ids interned beyond the resident state have no state yet (like get_aggregate)
+        ids = [k for k in aggregate_ids if self.store.keys.get(k) is not None and self.store.keys.index[k] < n_agg]
         if not ids:
             return []
         idx = np.array([self.store.keys.index[k] for k in ids], dtype=np.int64)
         states = self.store.engine.gather(idx)
-        parts = partition_for_keys(ids, self.n_partitions)  # events and state share the partitioner (KafkaPartitioner.scala:8)
+        parts = partition_for_keys(ids, self.n_partitions, up_to_colon=True)  # events and state share the default partitioner (KafkaPartitioner.scala:8,38-42)
         fmt = self.store.business_logic.aggregate_write_formatting()
         out = []
         for k, st, part in zip(ids, states, parts):

@@ -107,13 +107,14 @@ class GpuReplayStateStore:
         """Streaming micro-batch (config C5): fold new events onto the resident state."""
         if not self._restored:
             raise RuntimeError("restore() first")
-        enc = self.model.encode_events(events_in_offset_order)
-        agg_idx = np.empty(len(events_in_offset_order), dtype=np.int64)
-        for i, e in enumerate(events_in_offset_order):
-            k = self.keys.intern(self.model.aggregate_id_of(e))
-            if k >= self.engine.n_agg:
-                raise IndexError(f"aggregate {self.model.aggregate_id_of(e)!r} exceeds the store capacity {self.engine.n_agg}")
-            agg_idx[i] = k
+        enc = self.model.encode_events(events_in_offset_order)  # may raise: nothing has been interned yet
+        ids = [self.model.aggregate_id_of(e) for e in events_in_offset_order]
+        # aggregates that first appear after recovery are the normal Surge case: the resident state grows
+        # (surge_replay_grow) BEFORE any id is interned, so a failure leaves the key table consistent
+        fresh = len({k for k in ids if self.keys.get(k) is None})
+        if len(self.keys) + fresh > self.engine.n_agg:
+            self.engine.grow(len(self.keys) + fresh)
+        agg_idx = np.fromiter((self.keys.intern(k) for k in ids), dtype=np.int64, count=len(ids))
         self.engine.append_events(agg_idx, enc)  # stable group-by + K3 inside the library
         self.engine.snapshot()
 

@@ -19,7 +19,16 @@ def gpu_available():
     return torch.cuda.is_available()
 
 
-def pytest_collection_modifyitems(config, items):
-    # A GPU test must never pass silently on a box without a GPU: without one it errors loudly
-    # unless it was deselected with -m "not gpu".
-    pass
+@pytest.fixture(autouse=True)
+def _gpu_tests_fail_loudly_without_a_gpu(request):
+    """A test marked ``gpu`` must never pass (or skip) silently on a box without a GPU: it FAILS, unless it
+    was deselected with ``-m "not gpu"``.  Same for a box whose HIP library did not load."""
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("test is marked gpu but no GPU is visible (deselect with -m 'not gpu' on CPU boxes)", pytrace=False)
+    from surge_amd import _native
+
+    _native.load()  # raises NativeLibraryError when libsurge_replay.so is missing: no eager fallback exists

@@ -19,6 +19,7 @@ jint Java_surge_replay_gpu_NativeReplay_appendFold(JNIEnv*, jclass, jlong, jobje
 jint Java_surge_replay_gpu_NativeReplay_snapshot(JNIEnv*, jclass, jlong, jobject, jobject);
 jint Java_surge_replay_gpu_NativeReplay_get(JNIEnv*, jclass, jlong, jlong, jobject);
 jint Java_surge_replay_gpu_NativeReplay_partitionHash(JNIEnv*, jclass, jobject, jobject, jlong, jint, jobject);
+jint Java_surge_replay_gpu_NativeReplay_partitionHashUpToColon(JNIEnv*, jclass, jobject, jobject, jlong, jint, jobject);
 
 typedef struct { void* address; } fake_direct_buffer;
 
@@ -59,8 +60,10 @@ int main(void) {
     const int64_t off[] = {0, 0, 1, 4};
     int32_t part[3] = {-1, -1, -1};
     fake_direct_buffer b_utf16 = {(void*)utf16}, b_off = {(void*)off}, b_part = {part};
-    const jint rc = Java_surge_replay_gpu_NativeReplay_partitionHash(env, NULL, &b_utf16, &b_off, 3, 1000003, &b_part);
-    check(rc == 0 && part[0] == 926349 && part[1] == 229102 && part[2] == 229102, "partitionHash known answers, key cut at ':'");
+    jint rc = Java_surge_replay_gpu_NativeReplay_partitionHash(env, NULL, &b_utf16, &b_off, 3, 1000003, &b_part);
+    check(rc == 0 && part[0] == 926349 && part[1] == 229102 && part[2] == 324673, "partitionHash = partitionForKey of the whole string (\"\", \"a\", \"a:7\")");
+    rc = Java_surge_replay_gpu_NativeReplay_partitionHashUpToColon(env, NULL, &b_utf16, &b_off, 3, 1000003, &b_part);
+    check(rc == 0 && part[0] == 926349 && part[1] == 229102 && part[2] == 229102, "partitionHashUpToColon: key cut at ':' (PartitionStringUpToColon)");
   }
 
   const jlong h = Java_surge_replay_gpu_NativeReplay_create(env, NULL, NULL, 0);

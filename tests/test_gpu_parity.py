@@ -376,13 +376,16 @@ def test_partition_hash_kernel_matches_cpu_entry_point_and_oracle():
 
     keys = [f"acct-{i:08d}:{i % 13}" for i in range(20000)] + ["", ":", "a", "ab:c", "ünï-✓", "x" * 301]
     data, off = utf16_table(keys)
-    cpu = partition_for_keys(keys, 64)
     with ReplayEngine() as eng:
-        d_out = torch.zeros(len(keys), dtype=torch.int32, device="cuda:0")
-        eng.partition_hash_device(torch.from_numpy(data.view(np.int16)).cuda(), torch.from_numpy(off).cuda(), 64, d_out)
-        eng.synchronize()
-    assert (d_out.cpu().numpy() == cpu).all()
-    assert (oracle.partition_hash_batch(data, off, 64) == cpu).all()
+        for cut in (False, True):  # partitionForKey of the whole string / after PartitionStringUpToColon.partitionBy
+            cpu = partition_for_keys(keys, 64, up_to_colon=cut)
+            d_out = torch.zeros(len(keys), dtype=torch.int32, device="cuda:0")
+            eng.partition_hash_device(torch.from_numpy(data.view(np.int16)).cuda(), torch.from_numpy(off).cuda(), 64, d_out,
+                                      up_to_colon=cut)
+            eng.synchronize()
+            assert (d_out.cpu().numpy() == cpu).all()
+            assert (oracle.partition_hash_batch(data, off, 64, up_to_colon=cut) == cpu).all()
+    assert (partition_for_keys(keys, 64) != partition_for_keys(keys, 64, up_to_colon=True)).any()
 
 
 def test_gpu_json_encoder_matches_play_json_text_of_the_counter_fixture():

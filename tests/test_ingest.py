@@ -247,3 +247,70 @@ def test_topic_to_csr_to_fold_matches_the_fold_of_the_published_events():
         ev = np.frombuffer(b"".join(mine), dtype=S.EVENT_DTYPE)
         exp = oracle.fold_csr(np.array([0, len(mine)], dtype=np.int64), ev)[0]
         assert got[a].tobytes() == exp.tobytes()
+
+
+# ---- round-2 regressions -------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("n_events, zero_fill", [(500, False), (4000, True), (60000, True)])
+def test_lz4_batches_that_compress_more_than_8x_are_decoded(n_events, zero_fill):
+    # 500 Counter JSON events of one aggregate compress ~8.1x, zero-filled values ~24x, 60 000 zero-filled values
+    # > 255x across several 64 KiB blocks: the scratch buffer must GROW on "out of space", never report "corrupt"
+    if zero_fill:
+        recs = [(f"acct-1:{i}".encode(), b"\x00" * 64) for i in range(n_events)]
+    else:
+        recs = [(f"acct-1:{i}".encode(),
+                 ('{"aggregateId":"acct-1","incrementBy":1,"sequenceNumber":%d}' % i).encode()) for i in range(n_events)]
+    wire = kw.record_batch(0, recs, compression="lz4")
+    raw = kw.record_batch(0, recs)
+    assert len(raw) > (8 if zero_fill else 5) * len(wire)
+    with EventsTopicIngest() as g:
+        g.feed(wire)
+        got = g.drain_records()
+    assert [(k, v) for _, _, k, v in got] == recs
+
+
+def test_lz4_frame_with_a_content_size_field_sizes_the_first_attempt():
+    import struct
+
+    data = b"\x00" * 300000
+    body = kw.lz4_frame(data)
+    # same frame with FLG.content_size set and the 8-byte size after BD (the header checksum is not verified)
+    frame = body[:4] + bytes([body[4] | 0x08, body[5]]) + struct.pack("<Q", len(data)) + body[6:]
+    out = ctypes.create_string_buffer(len(data))
+    assert _native.load().surge_lz4_frame_decompress(frame, len(frame), out, len(data)) == len(data)
+    assert out.raw == data
+    small = ctypes.create_string_buffer(1000)
+    assert _native.load().surge_lz4_frame_decompress(frame, len(frame), small, 1000) == -6  # out of space, not corrupt
+    # truncated block: corrupt, not "out of space"
+    assert _native.load().surge_lz4_frame_decompress(body[:-9], len(body) - 9, out, len(data)) == -7
+
+
+def test_a_failing_batch_does_not_replay_the_batches_before_it():
+    ev = lambda seq: counter_event(S.EVT_INC, seq, 1)
+    good = kw.record_batch(0, [(b"a:1", ev(1)), (b"b:1", ev(1))]) + kw.record_batch(2, [(b"a:2", ev(2))])
+    bad = bytearray(kw.record_batch(3, [(b"c:1", ev(1))]))
+    bad[-1] ^= 0x55
+    with EventsTopicIngest() as g:
+        with pytest.raises(IngestError):
+            g.feed(good + bytes(bad))
+        assert g.ready == 3  # the two good batches are queued exactly once ...
+        with pytest.raises(IngestError):
+            g.feed(b"")  # ... and a retry stops at the same bad batch without decoding them again
+        assert g.ready == 3
+        assert [k for _, _, k, _ in g.drain_records()] == [b"a:1", b"b:1", b"a:2"]
+        assert g.counters()["records_delivered"] == 3
+
+
+def test_keys_of_aborted_transactions_never_enter_the_key_table():
+    ev = lambda seq: counter_event(S.EVT_INC, seq, 1)
+    wire = b"".join([
+        kw.record_batch(0, [(b"ghost:1", ev(1))], transactional=True, producer_id=9),
+        kw.control_batch(1, 9, kw.ABORT),
+        kw.record_batch(2, [(b"real:1", ev(1))]),
+    ])
+    with EventsTopicIngest() as g:
+        g.feed(wire)
+        got = g.drain_records()
+        assert [(i, k) for _, i, k, _ in got] == [(0, b"real:1")]
+        assert g.key_table().keys == ["real"]

@@ -173,9 +173,78 @@ def test_counter_state_json_text():
 def test_partitioner_structure():
     for n in (1, 5, 64, 1000):
         for k in ("", "a", "acct-00000001", "stateKey1:17", "::", "aggregate:with:colons"):
-            p = oracle.partition_for_key(k, n)
+            p = oracle.partition_for_key(oracle.partition_by_up_to_colon(k), n)
             assert 0 <= p < n
-            assert p == oracle.partition_for_key(k.split(":")[0] + ":anything", n)  # PartitionStringUpToColon
+            # PartitionStringUpToColon: everything from the first ':' on is ignored ...
+            assert p == oracle.partition_for_key(oracle.partition_by_up_to_colon(k.split(":")[0] + ":anything"), n)
+            assert oracle.partition_by_up_to_colon(k) == k.split(":")[0]
+    # ... but partitionForKey itself hashes the string it is given, colons included (KafkaPartitioner.scala:8;
+    # StringIdentityPartitioner :29-31 relies on it)
+    assert oracle.partition_for_key("ab:c", 1 << 30) != oracle.partition_for_key("ab", 1 << 30)
+
+
+# Published verification values of MurmurHash3_x86_32 (Appleby's SMHasher; the vectors quoted with the algorithm's
+# public descriptions).  oracle_murmur3_x86_32 is assembled from the SAME mix / mixLast / finalize primitives as the
+# stringHash restatement, so these pin the primitives (constants c1/c2, rotations 15/13, h*5+0xe6546b64, fmix32).
+MURMUR3_X86_32_VECTORS = [
+    (b"", 0, 0x00000000),
+    (b"", 1, 0x514E28B7),
+    (b"", 0xFFFFFFFF, 0x81F16F39),
+    (b"\xff\xff\xff\xff", 0, 0x76293B50),
+    (b"\x21\x43\x65\x87", 0, 0xF55B516B),
+    (b"\x21\x43\x65\x87", 0x5082EDEE, 0x2362F9DE),
+    (b"\x21\x43\x65", 0, 0x7E4A8634),
+    (b"\x21\x43", 0, 0xA0F7B07A),
+    (b"\x21", 0, 0x72661CF4),
+    (b"\x00\x00\x00\x00", 0, 0x2362F9DE),
+    (b"\x00\x00\x00", 0, 0x85F0B427),
+    (b"\x00\x00", 0, 0x30F4C306),
+    (b"\x00", 0, 0x514E28B7),
+    (b"test", 0, 0xBA6BD213),
+    (b"test", 0x9747B28C, 0x704B81DC),
+    (b"Hello, world!", 0, 0xC0363E43),
+    (b"Hello, world!", 0x9747B28C, 0x24884CBA),
+    (b"The quick brown fox jumps over the lazy dog", 0, 0x2E4FF723),
+    (b"The quick brown fox jumps over the lazy dog", 0x9747B28C, 0x2FA826CD),
+    (b"aaaa", 0x9747B28C, 0x5A97808A),
+    (b"aaa", 0x9747B28C, 0x283E0130),
+    (b"aa", 0x9747B28C, 0x5D211726),
+    (b"a", 0x9747B28C, 0x7FA09EA6),
+    (b"abcd", 0x9747B28C, 0xF0478627),
+    (b"abc", 0x9747B28C, 0xC84A62DD),
+    (b"ab", 0x9747B28C, 0x74875592),
+]
+
+
+def test_murmur3_primitives_against_the_published_x86_32_vectors():
+    for data, seed, want in MURMUR3_X86_32_VECTORS:
+        assert oracle.murmur3_x86_32(data, seed) == want, (data, hex(seed))
+
+
+def test_string_hash_is_x86_32_over_the_char_pair_words_with_the_char_count_as_length():
+    # scala.util.hashing.MurmurHash3.stringHash (scala-library 2.13.8) = MurmurHash3_x86_32 with seed 0xf7ca7fd2 over
+    # the words (c[i] << 16) + c[i+1] (odd tail: c[i] alone through mixLast), finalised with the CHAR count instead
+    # of the byte count.  Given the primitives pinned above, only that framing (seed, pair order, length) remains
+    # parity-unpinned against a Scala runtime (tools/MurmurPin.scala generates the pin when a JVM exists).
+    import struct
+
+    for s in ("", "a", "ab", "abc", "acct-00000042", "CounterAggregate", "ünï-✓", "stateKey1:17"):
+        u = [int(x) for x in np.frombuffer(s.encode("utf-16-le"), dtype=np.uint16)]
+        body = b"".join(struct.pack("<I", ((u[i] << 16) + u[i + 1]) & 0xFFFFFFFF) for i in range(0, len(u) - 1, 2))
+        tail = struct.pack("<H", u[-1]) if len(u) % 2 else b""
+        x = oracle.murmur3_x86_32(body + tail, 0xF7CA7FD2)
+        # undo x86_32's finalisation with the byte length, redo it with the char count
+        def fmix(h):
+            h ^= h >> 16; h = (h * 0x85EBCA6B) & 0xFFFFFFFF; h ^= h >> 13; h = (h * 0xC2B2AE35) & 0xFFFFFFFF; h ^= h >> 16
+            return h
+        def unfmix(h):
+            inv1, inv2 = pow(0x85EBCA6B, -1, 1 << 32), pow(0xC2B2AE35, -1, 1 << 32)
+            h ^= h >> 16; h = (h * inv2) & 0xFFFFFFFF; h ^= (h >> 13) ^ (h >> 26); h = (h * inv1) & 0xFFFFFFFF; h ^= h >> 16
+            return h
+        raw = unfmix(x) ^ (len(body) + len(tail))
+        want = fmix(raw ^ len(u))
+        got = oracle.murmur3_string_hash(s) & 0xFFFFFFFF
+        assert got == want, s
 
 
 def test_murmur3_regression_values():
@@ -197,6 +266,58 @@ def test_murmur3_regression_values():
         return h - (1 << 32) if h & 0x80000000 else h
     for s in ("", "a", "ab", "abc", "acct-00000042", "CounterAggregate"):
         assert oracle.murmur3_string_hash(s) == ref(s)
+
+
+def test_scala_runtime_pin_of_the_shard_map():
+    """Oracle and product entry points vs values printed by a real Scala runtime (tools/MurmurPin.scala).
+    Skipped — and the shard map stays "parity unpinned" — until a JVM has produced tests/golden/murmur_pin.tsv."""
+    import os
+    import shutil
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    pin = os.path.join(here, "golden", "murmur_pin.tsv")
+    if shutil.which("scala"):
+        out = subprocess.run(["scala", os.path.join(here, "..", "tools", "MurmurPin.scala")], capture_output=True, text=True, timeout=300)
+        if out.returncode == 0 and out.stdout.strip():
+            open(pin, "w").write(out.stdout)
+    if not os.path.exists(pin):
+        pytest.skip("no Scala runtime here and no tests/golden/murmur_pin.tsv yet: MurmurHash3.stringHash framing is unpinned")
+    from surge_amd.kafka import partition_for_keys
+
+    for line in open(pin).read().splitlines():
+        hx, h, part = line.split("\t")
+        s = bytes.fromhex("".join(hx[i + 2:i + 4] + hx[i:i + 2] for i in range(0, len(hx), 4))).decode("utf-16-le", "surrogatepass")
+        assert oracle.murmur3_string_hash(s) == int(h), s
+        assert oracle.partition_for_key(s, 64) == int(part), s
+        assert int(partition_for_keys([s], 64)[0]) == int(part), s
+
+
+def test_product_cpu_shard_map_equals_the_oracle_in_both_forms():
+    import random
+
+    from surge_amd.kafka import (KafkaPartitionProvider, NoPartitioner, PartitionStringUpToColon, StringIdentityPartitioner,
+                                 partition_for_keys, utf16_table)
+
+    rng = random.Random(7)
+    alphabet = "abcXYZ019:-_ü✓"
+    keys = ["", ":", "a:", ":a", "acct-00000042", "acct-00000042:7"] + [
+        "".join(rng.choice(alphabet) for _ in range(rng.randrange(0, 40))) for _ in range(3000)]
+    data, off = utf16_table(keys)
+    for n in (1, 5, 64, 1000):
+        whole = partition_for_keys(keys, n)
+        cut = partition_for_keys(keys, n, up_to_colon=True)
+        assert (whole == oracle.partition_hash_batch(data, off, n)).all()
+        assert (cut == oracle.partition_hash_batch(data, off, n, up_to_colon=True)).all()
+        assert [oracle.partition_for_key(k, n) for k in keys[:50]] == [int(x) for x in whole[:50]]
+    # trait semantics (KafkaPartitioner.scala:7-9, 17-19, 29-31, 38-42): partitionForKey hashes what it is given; only
+    # PartitionStringUpToColon.partitionBy cuts
+    k = "acct-00000042:7"
+    assert KafkaPartitionProvider().partition_for_key(k, 1 << 20) == oracle.partition_for_key(k, 1 << 20)
+    assert NoPartitioner().partition_for_key(k, 1 << 20) == oracle.partition_for_key(k, 1 << 20)
+    assert StringIdentityPartitioner.instance.partition_for(k, 1 << 20) == oracle.partition_for_key(k, 1 << 20)
+    assert PartitionStringUpToColon.instance.partition_for(k, 1 << 20) == oracle.partition_for_key("acct-00000042", 1 << 20)
+    assert PartitionStringUpToColon.instance.partition_for_key(k, 1 << 20) == oracle.partition_for_key(k, 1 << 20)
 
 
 def test_multithreaded_oracle_equals_single_thread():

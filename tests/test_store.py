@@ -197,7 +197,7 @@ def test_incremental_snapshot_records_compact_to_the_full_refold():
         parts = {r.key: r.partition for r in log}
         from surge_amd.kafka import PartitionStringUpToColon
 
-        assert all(p == PartitionStringUpToColon.instance.partition_for_key(k, 5) for k, p in parts.items())
+        assert all(p == PartitionStringUpToColon.instance.partition_for(k, 5) for k, p in parts.items())
     finally:
         store.close()
 
@@ -236,5 +236,61 @@ def test_recovery_from_raw_events_topic_bytes():
         for k, st in expect.items():
             assert store.get_aggregate_bytes(k) == bl.aggregate_write_formatting().write_state(st).value
         assert expect["a"] == State("a", 11, 2)
+    finally:
+        store.close()
+
+
+# ---- round-2 regressions (aggregates that first appear after recovery) ------------------------------
+def test_pack_batch_rejects_an_over_capacity_batch_without_interning_anything():
+    from surge_amd.log import KeyTable, pack_batch
+
+    model = CounterBusinessLogic().command_model()
+    keys = KeyTable()
+    keys.intern("a")
+    with pytest.raises(IndexError):
+        pack_batch(model, [CountIncremented("a", 1, 1), CountIncremented("b", 1, 1), CountIncremented("c", 1, 1)], keys, n_agg=2)
+    assert keys.keys == ["a"]  # a rejected batch leaves the key table as it was
+    g, off, ev = pack_batch(model, [CountIncremented("b", 1, 1), CountIncremented("a", 2, 2)], keys, n_agg=2)
+    assert list(g) == [0, 1] and keys.keys == ["a", "b"]
+
+
+@pytest.mark.gpu
+def test_new_aggregates_after_recovery_grow_the_resident_state():
+    # restore() with the default capacity, then micro-batches that introduce new ids: the normal Surge case
+    from surge_amd.snapshot import SnapshotWriter, compact
+    from surge_amd.store import GpuReplayStateStore
+
+    bl = CounterBusinessLogic()
+    model = bl.command_model()
+    store = GpuReplayStateStore(bl)
+    try:
+        first = [CountIncremented("a", 1, 1), CountIncremented("b", 2, 1), CountIncremented("a", 3, 2)]
+        store.restore(first)
+        assert store.engine.n_agg == 2
+        expect = {}
+        for e in first:
+            expect[e.aggregateId] = model.handle_event(expect.get(e.aggregateId), e)
+        seq = 0
+        for round_ in range(4):  # each round brings ids the store has never seen (several reallocations)
+            batch = []
+            for i in range(50 * (round_ + 1)):
+                seq += 1
+                k = f"new-{round_}-{i % (20 * (round_ + 1))}"
+                batch.append(CountIncremented(k, i, seq))
+            batch.append(CountDecremented("a", 1, 100 + round_))
+            store.apply_events(batch)
+            for e in batch:
+                expect[e.aggregateId] = model.handle_event(expect.get(e.aggregateId), e)
+            assert store.engine.n_agg == len(store.keys) == len(expect)
+        fmt = bl.aggregate_write_formatting()
+        for k, st in expect.items():
+            assert store.get_aggregate_bytes(k) == fmt.write_state(st).value
+        table = compact(SnapshotWriter(store, n_partitions=5).full_snapshot())
+        assert table == {k: fmt.write_state(st).value for k, st in expect.items()}
+        # a full fold of the (now too short) bound log is refused loudly, not silently wrong
+        from surge_amd.replay import ReplayError
+
+        with pytest.raises(ReplayError):
+            store.engine.fold()
     finally:
         store.close()
