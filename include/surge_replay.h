@@ -146,12 +146,16 @@ typedef struct surge_replay_schema {
 
 /* ---- fold algorithms -------------------------------------------------------- */
 #define SURGE_ALGO_AUTO  0 /* uniform segment length L (L % 16 == 0): ROWS when there are enough aggregates
-                              to fill the chip, else FIXED; otherwise SORTED for large logs, else FLAT */
+                              to fill the chip, else FIXED; otherwise CHUNKED for logs whose aggregates average
+                              >= 64 events, else FLAT */
 #define SURGE_ALGO_FIXED 1 /* K1b: flat fold with segment heads computed arithmetically (uniform L)   */
 #define SURGE_ALGO_FLAT  2 /* K2: load-balanced flat segmented scan over the CSR                      */
 #define SURGE_ALGO_ROWS  3 /* K1: uniform L, one lane per aggregate, no cross-lane scan               */
 #define SURGE_ALGO_SORTED 4 /* K2b: any CSR; segments counting-sorted by length at load time, persistent
                                waves walk groups of 64 similar-length segments, one lane per aggregate  */
+#define SURGE_ALGO_CHUNKED 5 /* K2c: like SORTED, but an aggregate longer than T events (default 256) is cut into
+                                2^k line-aligned chunks walked by adjacent lanes of one wave and stitched with
+                                shuffles: no wave ever walks more than ~T events alone (mid-size ragged logs) */
 
 typedef struct surge_replay_stats_t {
   int64_t n_aggregates;

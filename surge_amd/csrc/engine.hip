@@ -77,6 +77,10 @@ struct surge_replay_handle {
   int64_t n_nz = 0;
   DevBuf perm, sort_hist, counter;  // SORTED: segments by descending length (built lazily, per bound log)
   bool perm_valid = false;
+  DevBuf v_start, v_len, v_info, v_seg, v_total;  // CHUNKED: the chunk table (built lazily, per bound log) ...
+  DevBuf v_side, r_slot0, r_c, r_out, v_ctr;       // ... the chunk summaries and the list of cut aggregates
+  int64_t n_vrows = 0, n_cut_rows = 0;
+  uint32_t chunk_T = 0;                            // the chunk target the table was built for (0 = none built)
 
   // per-fold scratch
   DevBuf plan, batch_group_agg, batch_group_off, batch_events, poison_count, gather_idx, gather_out, scan_totals;
@@ -347,7 +351,7 @@ int32_t surge_replay_destroy(surge_replay_handle* h) {
   if (!h) return SURGE_OK;
   DeviceGuard g(h->device);
   (void)hipStreamSynchronize(h->stream);
-  DevBuf* bufs[] = {&h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
+  DevBuf* bufs[] = {&h->v_side, &h->r_slot0, &h->r_c, &h->r_out, &h->v_ctr, &h->v_start, &h->v_len, &h->v_info, &h->v_seg, &h->v_total, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
                     &h->nz_map, &h->block_counts, &h->plan, &h->batch_group_agg, &h->batch_group_off,
                     &h->batch_events, &h->poison_count, &h->gather_idx, &h->gather_out, &h->scan_totals};
   for (DevBuf* b : bufs) b->release();
@@ -392,6 +396,7 @@ int32_t surge_replay_bind_device_csr(surge_replay_handle* h, const int64_t* d_se
   DeviceGuard g(h->device);
   h->bound = false;
   h->perm_valid = false;
+  h->chunk_T = 0;
   h->d_seg_off = d_seg_off;
   h->d_events = (const uint4*)d_events;
   h->d_init = (const uint4*)d_init_state;
@@ -445,7 +450,7 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
   if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
   if (!h->bound) return fail(h, SURGE_E_STATE, "fold before load_csr/bind_device_csr");
   if (!h->log_valid) return fail(h, SURGE_E_STATE, "the resident state was grown past the bound log (surge_replay_grow): load a log again");
-  if (algo < SURGE_ALGO_AUTO || algo > SURGE_ALGO_SORTED) return fail(h, SURGE_E_INVALID, "unknown algo");
+  if (algo < SURGE_ALGO_AUTO || algo > SURGE_ALGO_CHUNKED) return fail(h, SURGE_E_INVALID, "unknown algo");
   DeviceGuard g(h->device);
   const int64_t span = h->an.last - h->an.first;
   const bool uniform = h->n_agg > 0 && !h->an.nonuniform && h->an.n_empty == 0 && h->an.len0 > 0 &&
@@ -458,20 +463,41 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
   // with FIXED between 512 groups (FIXED 20-50 % faster) and 1024 groups (ROWS 10-18 % faster, L = 64..1024)
   const bool rows_auto = rows_ok && h->n_agg / kWave >= 1024;
   const bool sorted_ok = h->an.max_len < (1ll << 31);
-  if (algo == SURGE_ALGO_SORTED && !sorted_ok) return fail(h, SURGE_E_UNSUPPORTED, "ALGO_SORTED needs segments shorter than 2^31 events");
+  if ((algo == SURGE_ALGO_SORTED || algo == SURGE_ALGO_CHUNKED) && !sorted_ok)
+    return fail(h, SURGE_E_UNSUPPORTED, "ALGO_SORTED / ALGO_CHUNKED need segments shorter than 2^31 events");
   // Measured on MI355X (C3: 10 M aggregates, Zipf 1..4096): FLAT 16.2 ms (4.6 TB/s); SORTED (line-aligned
-  // 256 B row pieces, 8 resident waves per CU) 12.1 ms (6.2 TB/s).  One lane per aggregate pays only when
-  //  - there are enough groups of 64 segments to keep the persistent waves busy,
-  //  - rows are long enough to fill their 256-byte pieces (mean >= 64 events: at <= 32 events per aggregate
-  //    SORTED measured 2-4x slower than the linear-stream FLAT kernel, at ~64 they tie), and
-  //  - the log is big enough to hide the critical path of the longest group, which one wave walks alone
-  //    (max_len / 16 tiles at ~4 us: Zipf(1..4096) ties at ~1 M aggregates = 7 GB, FLAT wins below).
+  // 256 B row pieces, 8 resident waves per CU) 12.1-12.7 ms (5.9-6.2 TB/s).  One lane per aggregate pays only when
+  // rows are long enough to fill their 256-byte pieces (mean >= 64 events: at <= 32 events per aggregate the
+  // lane-per-aggregate kernels measured 2-4x slower than the linear-stream FLAT kernel, at ~64 they tie).
   const double mean_len = h->n_nz > 0 ? (double)span / (double)h->n_nz : 0.0;
-  const bool sorted_auto = sorted_ok && h->n_nz / kWave >= 4 * (int64_t)h->n_cus * 4 && mean_len >= 64.0 &&
-                           (double)h->st.algorithmic_bytes >= 1.6e6 * (double)h->an.max_len;
-  const int32_t use = (algo == SURGE_ALGO_AUTO)
-                          ? (uniform ? (rows_auto ? SURGE_ALGO_ROWS : SURGE_ALGO_FIXED) : (sorted_auto ? SURGE_ALGO_SORTED : SURGE_ALGO_FLAT))
-                          : algo;
+  // CHUNKED bounds the critical path: no wave walks more than ~T events alone.  T grows with the log (the longest
+  // chunk's walk should stay a small fraction of the kernel; measured optimum on Zipf(1..4096) logs of 2–15 GB:
+  // T ~ algorithmic bytes / 6 MB) and cut aggregates get at most 256 chunks (the stitch kernel walks them one by one).
+  // When T reaches the longest aggregate nothing is cut and the plain sorted-rows kernel runs instead.
+  uint32_t chunk_T = 0;
+  {
+    double t = (double)h->st.algorithmic_bytes / 6.0e6;
+    const double t_min = (double)h->an.max_len / 256.0;
+    t = t < t_min ? t_min : t;
+    t = t < 256.0 ? 256.0 : (t > 65528.0 ? 65528.0 : t);
+    chunk_T = ((uint32_t)t + 7u) & ~7u;
+    if (const char* v = std::getenv("SURGE_REPLAY_CHUNK_T")) chunk_T = (uint32_t)std::atoi(v);
+    chunk_T = chunk_T < 16u ? 16u : (chunk_T > 65528u ? 65528u : chunk_T);
+    chunk_T &= ~7u;
+  }
+  const bool nothing_to_cut = (int64_t)chunk_T >= h->an.max_len + 7;
+  // one lane per aggregate / chunk pays from ~1.5 GB of log and a mean of 64 events per aggregate (shorter aggregates
+  // run 2-4x faster on the linear-stream FLAT kernel; at 0.2 M Zipf aggregates = 1.5 GB CHUNKED and FLAT tie)
+  const bool lanes_auto = sorted_ok && mean_len >= 64.0 && (double)h->st.algorithmic_bytes >= 1.5e9;
+  int32_t use = algo;
+  if (algo == SURGE_ALGO_AUTO) {
+    if (uniform)
+      use = rows_auto ? SURGE_ALGO_ROWS : SURGE_ALGO_FIXED;
+    else if (lanes_auto)
+      use = nothing_to_cut ? SURGE_ALGO_SORTED : SURGE_ALGO_CHUNKED;
+    else
+      use = SURGE_ALGO_FLAT;
+  }
 
   FoldParams p;
   fill_params(h, p);
@@ -549,6 +575,53 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       if (rc != SURGE_OK) return rc;
       HIPCHK(h, hipEventRecord(e0, h->stream));
       HIPCHK(h, launch_fold_sorted(p, n_waves, le, h->stream));
+      HIPCHK(h, hipEventRecord(e1, h->stream));
+      h->st.n_tasks = (int32_t)n_waves;
+    } else if (use == SURGE_ALGO_CHUNKED) {
+      const int le = env_lane_events("SURGE_REPLAY_LE_CHUNKED", 16) == 8 ? 8 : 16;
+      const int64_t* off = h->an.n_empty > 0 ? (const int64_t*)h->nz_off.ptr : h->d_seg_off;
+      const int64_t n_seg = h->an.n_empty > 0 ? h->n_nz : h->n_agg;
+      if (h->chunk_T != chunk_T) {  // once per bound log (part of its index, like the empty-segment compaction)
+        HIPCHK(h, h->sort_hist.reserve((size_t)kChunkBucketsHost * 8));
+        HIPCHK(h, h->v_total.reserve(8));
+        HIPCHK(h, h->v_ctr.reserve(32));
+        HIPCHK(h, h->counter.reserve(8));
+        unsigned long long total = 0, ctr[4] = {0, 0, 0, 0};
+        HIPCHK(h, launch_chunk_count(off, n_seg, chunk_T, (unsigned long long*)h->sort_hist.ptr, (unsigned long long*)h->v_total.ptr,
+                                     (unsigned long long*)h->v_ctr.ptr, h->stream));
+        HIPCHK(h, hipMemcpyAsync(ctr, h->v_ctr.ptr, 32, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(&total, h->v_total.ptr, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->n_vrows = (int64_t)total;
+        h->n_cut_rows = (int64_t)ctr[0];
+        HIPCHK(h, h->v_start.reserve((size_t)h->n_vrows * 8));
+        HIPCHK(h, h->v_seg.reserve((size_t)h->n_vrows * 8));
+        HIPCHK(h, h->v_len.reserve((size_t)h->n_vrows * 4));
+        HIPCHK(h, h->v_info.reserve((size_t)h->n_vrows * 4));
+        HIPCHK(h, h->v_side.reserve((size_t)ctr[1] * 80));
+        HIPCHK(h, h->r_slot0.reserve((size_t)ctr[0] * 8));
+        HIPCHK(h, h->r_out.reserve((size_t)ctr[0] * 8));
+        HIPCHK(h, h->r_c.reserve((size_t)ctr[0] * 4));
+        HIPCHK(h, launch_chunk_scatter(off, n_seg, h->an.n_empty > 0 ? (const int64_t*)h->nz_map.ptr : nullptr, chunk_T,
+                                       (unsigned long long*)h->sort_hist.ptr, (unsigned long long*)h->v_ctr.ptr,
+                                       (int64_t*)h->v_start.ptr, (uint32_t*)h->v_len.ptr, (uint32_t*)h->v_info.ptr,
+                                       (int64_t*)h->v_seg.ptr, (int64_t*)h->r_slot0.ptr, (uint32_t*)h->r_c.ptr,
+                                       (int64_t*)h->r_out.ptr, h->stream));
+        h->chunk_T = chunk_T;
+      }
+      p.counter = (unsigned long long*)h->counter.ptr;
+      p.n_seg = n_seg;
+      const int64_t groups = (h->n_vrows + kWave - 1) / kWave;
+      // resident waves per CU: 16 KiB tiles 8 (2 per SIMD, 8 x 18.7 KB of LDS), 8 KiB tiles 12 (3 per SIMD)
+      const int64_t slots = (int64_t)h->n_cus * (le == 8 ? 12 : 8);
+      const int64_t n_waves = groups < slots ? groups : slots;
+      hipEvent_t e0, e1;
+      const int32_t rc = next_fold_events(h, &e0, &e1);
+      if (rc != SURGE_OK) return rc;
+      HIPCHK(h, hipEventRecord(e0, h->stream));  // the stitch kernel is timed with the fold: it is part of it
+      HIPCHK(h, launch_fold_chunked(p, (const int64_t*)h->v_start.ptr, (const uint32_t*)h->v_len.ptr, (const uint32_t*)h->v_info.ptr,
+                                    (const int64_t*)h->v_seg.ptr, h->n_vrows, (uint32_t*)h->v_side.ptr, (const int64_t*)h->r_slot0.ptr,
+                                    (const uint32_t*)h->r_c.ptr, (const int64_t*)h->r_out.ptr, h->n_cut_rows, n_waves, le, h->stream));
       HIPCHK(h, hipEventRecord(e1, h->stream));
       h->st.n_tasks = (int32_t)n_waves;
     } else if (h->an.n_empty > 0) {

@@ -1,0 +1,438 @@
+// fold_chunked.hip — K2c "chunked rows": any CSR, one lane per CHUNK of an aggregate's events.
+//
+// Why (round-1 profile): in the sorted-rows kernel one lane walks one whole aggregate, so a group
+// of 4096-event aggregates is ~1 ms of critical path for ONE wave, whatever the log size: a 1.25 M-aggregate
+// Zipf shard (what each GPU of the 8-GPU config holds) ran at 55–62 % of the HBM roofline while the 10 M-aggregate
+// log reached 73–77 %, and logs under ~0.5 M aggregates fell to 18–37 %.  Here an aggregate longer than T events
+// is cut into c = ceil(len / T) chunks of equal length (boundaries on 128-byte lines).  Every chunk is an
+// independent "virtual row": the virtual rows of the whole log are ordered by length like the sorted-rows kernel
+// orders aggregates, 64 of them per wave, so no wave ever walks more than ~T events alone.  A chunk of a cut
+// aggregate leaves a 80-byte summary in a side buffer; a second, tiny kernel stitches each cut aggregate left to
+// right.  (Putting the chunks of one aggregate on ADJACENT lanes of one wave and stitching with shuffles — no side
+// buffer, no second kernel — was built and measured first: 4–6 % slower per tile at every size; a wave whose lanes
+// stream 64 unrelated rows is what the memory system likes.)
+//
+// T is chosen per log by the host (engine.hip): about algorithmic_bytes / 6 MB — the longest chunk's walk stays a
+// small fraction of the whole kernel — and the engine falls back to the sorted-rows kernel when T >= the longest
+// aggregate (nothing to cut).  Measured on MI355X, Zipf(1..4096) logs, % of 8 TB/s (FLAT / SORTED / CHUNKED):
+// 0.3 M aggregates 50 / 26 / 57, 0.5 M 52 / 37 / 62, 0.8 M 54 / 48 / 64, 1.25 M 54 / 61 / 68, 2 M 57 / 69 / 70.
+//
+// foldLeft is sequential; a chunk that does not start its aggregate does not know its incoming state.  It still
+// needs only ONE evaluation path per lane (no "both hypotheses" double work):
+//   * fields compose as transformers (delta / clamp / set), exactly like the flat kernel's lane transformers;
+//   * PRESENCE (Some/None decides whether REQUIRE-class events apply and whether MATERIALIZE resets to the
+//     defaults) is split at the chunk's first live event that is NOT of class REQUIRE ("deciding" event):
+//       P = the events before it  — all REQUIRE-class: applied iff the incoming state is Some, skipped if None
+//       S = the deciding event and everything after it, walked as "state is Some" — which is what it is in
+//           BOTH cases: after P when the incoming state was Some, after materialising the defaults when it was
+//           None (CREATE / DELETE make S absolute and the incoming state irrelevant)
+//     so   result = incoming is Some ? S(P(incoming)) : (decided ? S(defaults) : None).
+//   * a throwing event freezes the walk in either case at the same event (throwing does not depend on presence).
+// An aggregate in one piece (the vast majority) is walked concretely from its prior state and stores its own
+// 64-byte result, exactly as in the sorted-rows kernel.
+//
+// The event transport (LDS-DMA tiles, XOR swizzle, line-aligned row pieces, LDS row table) and the per-event mask
+// arithmetic are the sorted-rows kernel's (fold_device.h).  Integer adds wrap exactly like JVM Int/Long under
+// any association and min/max/set are exact, so the result is bit-identical to the sequential fold.
+#include <type_traits>
+
+#include "fold_device.h"
+
+namespace surge {
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int kChunkBuckets = 65536;  // chunk-length histogram: bucket = min(chunk length, 65535)
+
+constexpr uint32_t VI_RELATIVE = 1u;        // bit 0: chunk of a cut aggregate (walked relative to an unknown incoming state)
+constexpr int VI_PAD_SHIFT = 16;            // bits 16..18: null events in front of an aggregate's first event (line alignment)
+constexpr uint32_t VI_SIDE = 1u << 25;      // the chunk's summary goes to the side buffer (slot = v_dest), not to the state array
+constexpr uint32_t SIDE_DECIDED = 1u << 31; // in a side entry's S.fl: the chunk contained a deciding event
+constexpr int kSideDwords = 20;             // a side entry: P (10 dwords) then S (10 dwords)
+
+// chunks of an aggregate whose events span `span` slots from its 128-byte line start
+__host__ __device__ __forceinline__ uint32_t chunks_of(int64_t span, uint32_t T) {
+  const int64_t c = (span + T - 1) / T;
+  return (uint32_t)(c < 1 ? 1 : c);
+}
+
+// hist[chunk length] += chunks of every aggregate; ctr[0] += aggregates cut into several chunks, ctr[1] += their chunks
+__global__ void chunk_hist_kernel(const int64_t* __restrict__ off, int64_t n_seg, uint32_t T, unsigned long long* __restrict__ hist,
+                                  unsigned long long* __restrict__ ctr) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_seg) return;
+  const int64_t st = off[s], len = off[s + 1] - st;
+  const int64_t span = len + (st & 7);
+  const uint32_t c = chunks_of(span, T);
+  const int64_t cl = (span + c - 1) / c;
+  atomicAdd(&hist[cl < kChunkBuckets - 1 ? cl : kChunkBuckets - 1], (unsigned long long)c);
+  if (c > 1) {
+    atomicAdd(&ctr[0], 1ull);
+    atomicAdd(&ctr[1], (unsigned long long)c);
+  }
+}
+
+// single block: hist[b] := number of virtual rows in buckets > b (longest first); total[0] := number of virtual rows
+__global__ void __launch_bounds__(1024) chunk_scan_kernel(unsigned long long* hist, unsigned long long* total) {
+  __shared__ unsigned long long part[1024];
+  const int tid = threadIdx.x;
+  const int per = kChunkBuckets / 1024;
+  const int hi = kChunkBuckets - 1 - tid * per;  // thread 0 owns the longest buckets
+  unsigned long long sum = 0;
+  for (int k = 0; k < per; ++k) sum += hist[hi - k];
+  part[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long run = 0;
+    for (int i = 0; i < 1024; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+    total[0] = run;
+  }
+  __syncthreads();
+  unsigned long long run = part[tid];
+  for (int k = 0; k < per; ++k) { const unsigned long long v = hist[hi - k]; hist[hi - k] = run; run += v; }
+}
+
+// one thread per aggregate: describe its chunks as virtual rows (each claims one slot of its length bucket, so the
+// chunks of one aggregate end up on unrelated lanes) and, if it is cut, register it for the stitch kernel
+__global__ void chunk_scatter_kernel(const int64_t* __restrict__ off, int64_t n_seg, const int64_t* __restrict__ out_map,
+                                     unsigned long long* __restrict__ cursor, unsigned long long* __restrict__ ctr, uint32_t T,
+                                     int64_t* __restrict__ v_start, uint32_t* __restrict__ v_len, uint32_t* __restrict__ v_info,
+                                     int64_t* __restrict__ v_dest, int64_t* __restrict__ r_slot0, uint32_t* __restrict__ r_c,
+                                     int64_t* __restrict__ r_out) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_seg) return;
+  const int64_t st = off[s], len = off[s + 1] - st;
+  const uint32_t pad = (uint32_t)(st & 7);
+  const int64_t base = st - pad;  // the 128-byte line that holds the first event
+  const int64_t span = len + pad, end = st + len;
+  const uint32_t c = chunks_of(span, T);
+  const int64_t cl = (span + c - 1) / c;
+  const int64_t b = cl < kChunkBuckets - 1 ? cl : kChunkBuckets - 1;
+  const int64_t oi = out_map ? out_map[s] : s;
+  int64_t slot0 = 0;
+  if (c > 1) {
+    const unsigned long long r = atomicAdd(&ctr[2], 1ull);
+    slot0 = (int64_t)atomicAdd(&ctr[3], (unsigned long long)c);
+    r_slot0[r] = slot0; r_c[r] = c; r_out[r] = oi;
+  }
+  // chunk k = [base + floor8(k span / c), base + floor8((k+1) span / c)): boundaries on whole lines, lengths within 8
+  // events of each other
+  for (uint32_t k = 0; k < c; ++k) {
+    const int64_t lo = base + (((int64_t)k * span / c) & ~7ll);
+    const int64_t hiE = k + 1 == c ? end : base + (((int64_t)(k + 1) * span / c) & ~7ll);
+    const bool empty = hiE <= lo;  // cannot happen while T >= 16 (span / c >= 8); kept as a guard
+    const unsigned long long pos = atomicAdd(&cursor[b], 1ull);
+    v_start[pos] = empty ? 0 : lo;  // an empty chunk still "reads" (clamped, ignored): keep it in bounds
+    v_len[pos] = empty ? 0u : (uint32_t)(hiE - lo);
+    // every chunk of a cut aggregate is walked relative, chunk 0 included: the stitch kernel starts from the
+    // aggregate's prior state; an aggregate in one piece is walked concretely and stores its own state
+    v_info[pos] = (c > 1 ? (VI_RELATIVE | VI_SIDE) : 0u) | ((k == 0 ? pad : 0u) << VI_PAD_SHIFT);
+    v_dest[pos] = c > 1 ? slot0 + k : oi;
+  }
+}
+
+// walk of LE events that also watches for the lane's first "deciding" event (see the file comment); lanes with
+// undecM == 0 (an aggregate in one piece, or already decided) just walk
+template <int LE>
+__device__ __forceinline__ void walk_events_track(Acc& a, Acc& P, uint32_t& undecM, uint32_t& frozenM, uint32_t& corr,
+                                                  const uint4* ev, const uint32_t* tyc, const uint32_t* lds_tab,
+                                                  const FoldParams& p) {
+  uint4 tq0, tq1, tq2, tq3;
+  {
+    const uint4* te = (const uint4*)(lds_tab + tyc[0]);
+    tq0 = te[0]; tq1 = te[1]; tq2 = te[2]; tq3 = te[3];
+  }
+#pragma unroll
+  for (int j = 0; j < LE; ++j) {
+    uint4 nq0 = tq0, nq1 = tq1, nq2 = tq2, nq3 = tq3;
+    if (j + 1 < LE) {
+      const uint4* te = (const uint4*)(lds_tab + tyc[j + 1]);
+      nq0 = te[0]; nq1 = te[1]; nq2 = te[2]; nq3 = te[3];
+    }
+    // live (not ignored, not throwing) and not of class REQUIRE: from here on the state is Some or an absolute None
+    const uint32_t firstM = undecM & tq2.w & ~(frozenM | tq2.x);
+    if (__builtin_amdgcn_ballot_w64(firstM != 0u) != 0ull) {  // wave-uniform; taken once or twice per chunk
+      a.sum = (int64_t)((uint64_t)a.sum + corr);
+      corr = 0u;
+      const bool f = firstM != 0u;
+      P = select_acc(f, a, P);
+      a = select_acc(f, acc_identity(), a);
+      undecM = andn(undecM, firstM);
+    }
+    apply_event(a, frozenM, corr, tq0, tq1, tq2, tq3, ev[j].y, ev[j].z, ev[j].w, p);
+    tq0 = nq0; tq1 = nq1; tq2 = nq2; tq3 = nq3;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__device__ __forceinline__ Acc acc_defaults(const FoldParams& p) {  // Some(defaults), absolute
+  Acc a;
+  a.count = p.d_count; a.version = p.d_version; a.sum = p.d_sum; a.bal = p.d_balance; a.mn = p.d_min; a.mx = p.d_max;
+  a.n = p.d_evcount;
+  a.fl = FL_PRESENT | SM_ALL;
+  return a;
+}
+
+// the state after a chunk whose incoming state is x (concrete): see the file comment
+__device__ __forceinline__ Acc resolve_chunk(const Acc& x, const Acc& P, const Acc& S, bool decided, const FoldParams& p) {
+  const Acc some = seq_acc(seq_acc(x, P), S);
+  const Acc none_dec = seq_acc(acc_defaults(p), S);
+  Acc none_und = x;
+  none_und.fl |= P.fl & FL_POISONED;
+  const bool xpres = (x.fl & FL_PRESENT) != 0u, xpois = (x.fl & FL_POISONED) != 0u;
+  Acc r = select_acc(xpres, some, select_acc(decided, none_dec, none_und));
+  return select_acc(xpois, x, r);  // an aggregate that threw ignores every later event
+}
+
+__device__ __forceinline__ void acc_to_words(const Acc& a, uint32_t* w) {
+  w[0] = (uint32_t)a.count; w[1] = (uint32_t)a.version; w[2] = (uint32_t)a.sum; w[3] = (uint32_t)((uint64_t)a.sum >> 32);
+  w[4] = (uint32_t)a.bal; w[5] = (uint32_t)(a.bal >> 32); w[6] = (uint32_t)a.mn; w[7] = (uint32_t)a.mx; w[8] = a.n; w[9] = a.fl;
+}
+__device__ __forceinline__ Acc acc_from_words(const uint32_t* w) {
+  Acc a;
+  a.count = (int32_t)w[0]; a.version = (int32_t)w[1]; a.sum = (int64_t)(((uint64_t)w[3] << 32) | w[2]);
+  a.bal = ((uint64_t)w[5] << 32) | w[4]; a.mn = (int32_t)w[6]; a.mx = (int32_t)w[7]; a.n = w[8]; a.fl = w[9];
+  return a;
+}
+__device__ __forceinline__ void store_side(uint32_t* side, int64_t slot, const Acc& P, const Acc& S) {
+  uint32_t w[kSideDwords];
+  acc_to_words(P, w);
+  acc_to_words(S, w + 10);
+  uint4* o = (uint4*)(side + slot * kSideDwords);  // 80-byte entries: 16-byte aligned
+#pragma unroll
+  for (int i = 0; i < 5; ++i) o[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// second kernel: one thread per cut aggregate composes its chunk summaries left to right onto the prior state
+__global__ void chunk_stitch_kernel(const FoldParams p, const uint32_t* __restrict__ side, const int64_t* __restrict__ r_slot0,
+                                    const uint32_t* __restrict__ r_c, const int64_t* __restrict__ r_out, int64_t n_rows) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const int64_t slot0 = r_slot0[r];
+  const uint32_t c = r_c[r];
+  const int64_t oi = r_out[r];
+  Acc x = p.init ? load_state(p.init, oi) : acc_none();  // the aggregate's prior state (or None)
+  for (uint32_t k = 0; k < c; ++k) {
+    uint32_t w[kSideDwords];
+    const uint4* q = (const uint4*)(side + (slot0 + k) * kSideDwords);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+    const Acc P = acc_from_words(w);
+    Acc S = acc_from_words(w + 10);
+    const bool decided = (S.fl & SIDE_DECIDED) != 0u;
+    S.fl &= ~SIDE_DECIDED;
+    x = resolve_chunk(x, P, S, decided, p);
+  }
+  store_state(p.out, oi, x);
+}
+
+struct ChunkTable {
+  const int64_t* v_start;  // first event slot of the virtual row (a multiple of 8 events: line aligned)
+  const uint32_t* v_len;   // event slots from there (pad included)
+  const uint32_t* v_info;  // VI_*
+  const int64_t* v_dest;   // aggregate index (state array) or side-buffer slot
+  int64_t n_vrows;
+  uint32_t* side;
+};
+
+// Register budget = resident waves: 2 per SIMD (<= 256 VGPRs) with 16 KiB tiles, 3 per SIMD (<= 168) with 8 KiB tiles.
+template <int LE>
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(LE == 8 ? 3 : 2)))
+fold_chunked_kernel(const FoldParams p, const ChunkTable t) {
+  using G = Geo<LE>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_ev = smem;
+  int64_t* lds_rs = (int64_t*)(smem + G::kTileBytes);                  // 64 chunk starts ...
+  uint32_t* lds_len = (uint32_t*)(smem + G::kTileBytes + kWave * 8);   // ... and 64 chunk lengths
+  uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kAuxSorted);
+  const int lane = threadIdx.x;
+  load_table<LE>(p, lds_tab, lane);
+  const uint32_t ev_row = G::ev_row(lane);
+  const int64_t n_groups = (t.n_vrows + kWave - 1) / kWave;
+
+  auto grab = [&]() -> int64_t {
+    unsigned long long g = 0;
+    if (lane == 0) g = atomicAdd(p.counter, 1ull);
+    return (int64_t)(((uint64_t)rl((uint32_t)(g >> 32), 0) << 32) | rl((uint32_t)g, 0));
+  };
+  struct Meta { int64_t dest, start; uint32_t len, info; };
+  auto load_meta = [&](int64_t g) -> Meta {
+    Meta m; m.dest = -1; m.start = 0; m.len = 0u; m.info = 0u;
+    const int64_t idx = g * kWave + lane;
+    if (g < n_groups && idx < t.n_vrows) {
+      m.dest = t.v_dest[idx]; m.start = t.v_start[idx]; m.len = t.v_len[idx]; m.info = t.v_info[idx];
+    }
+    return m;
+  };
+  // longest / shortest non-empty chunk of a group (empty chunks do not bound the fast path) and its tile count
+  struct Shape { uint32_t maxlen, minlen; int n_tiles; };
+  auto shape_of = [&](const Meta& m) -> Shape {
+    Shape sh;
+    sh.maxlen = m.len;
+    sh.minlen = m.len ? m.len : 0xffffffffu;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      sh.maxlen = max(sh.maxlen, (uint32_t)__shfl_xor((int)sh.maxlen, d, 64));
+      sh.minlen = min(sh.minlen, (uint32_t)__shfl_xor((int)sh.minlen, d, 64));
+    }
+    sh.n_tiles = (int)((sh.maxlen + LE - 1) / LE);
+    return sh;
+  };
+  // the chunk starts / lengths each load instruction needs (chunk RPL*q + lane/LE) live in a small LDS table
+  auto publish = [&](const Meta& m) {
+    lds_rs[lane] = m.start;
+    lds_len[lane] = m.len;
+  };
+  auto issue = [&](int c, uint32_t minlen) {
+    if ((uint32_t)(c + 1) * LE <= minlen) {
+#pragma unroll
+      for (int q = 0; q < G::kLoads; ++q) {
+        const int64_t e = lds_rs[G::kRowsPerLoad * q + lane / LE] + (int64_t)c * LE + G::load_j(lane, q % G::kClasses);
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.events + e), (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
+      }
+    } else {  // some chunk ends inside this tile: never read past a chunk's own events
+#pragma unroll
+      for (int q = 0; q < G::kLoads; ++q) {
+        const int r = G::kRowsPerLoad * q + lane / LE;
+        const uint32_t rlen = lds_len[r];
+        uint32_t j = (uint32_t)c * LE + G::load_j(lane, q % G::kClasses);
+        const uint32_t lastj = rlen ? rlen - 1u : 0u;
+        j = j < lastj ? j : lastj;
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.events + (lds_rs[r] + j)), (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
+      }
+    }
+  };
+
+  int64_t g = grab();
+  Meta cur = load_meta(g);
+  Shape sh = shape_of(cur);
+  publish(cur);
+  if (g < n_groups) issue(0, sh.minlen);
+  while (g < n_groups) {
+    const int64_t g_next = grab();
+    const Meta nxt = load_meta(g_next);  // in flight while this group is walked
+    Shape sh_next = sh;
+    const uint32_t minlen = sh.minlen;
+    const int n_tiles = sh.n_tiles;
+
+    const uint32_t pad = (cur.info >> VI_PAD_SHIFT) & 7u;
+    const bool whole = (cur.info & VI_RELATIVE) == 0u;
+    // an aggregate in one piece starts from its known state, a chunk from "whatever comes in" (relative)
+    Acc a = whole ? ((p.init && cur.dest >= 0) ? load_state(p.init, cur.dest) : acc_none()) : acc_identity();
+    Acc P = acc_identity();
+    uint32_t undecM = whole ? 0u : ~0u;
+    uint32_t frozenM = whole ? (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 1, 1) : 0u;
+    uint32_t corr = 0u;
+    // wave-uniform: is any chunk here still waiting for its deciding event?  (usually settled within the first tile)
+    bool watching = __builtin_amdgcn_ballot_w64(!whole) != 0ull;
+    // one tile: wait for it, pull my LE events out of LDS, start the next tile's fetch, walk
+    auto tile_step = [&](int c, auto tracking) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      uint4 ev[LE];
+#pragma unroll
+      for (int j = 0; j < LE; ++j) ev[j] = *(const uint4*)(lds_ev + (ev_row ^ (uint32_t)(j * 16)));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (c + 1 < n_tiles) {
+        issue(c + 1, minlen);
+      } else {
+        // last tile of this group: the NEXT group's first tile is fetched while this one is walked (its meta loads
+        // were issued a whole group ago and, loads returning in order, landed before the tile just waited for)
+        sh_next = shape_of(nxt);
+        publish(nxt);
+        if (g_next < n_groups) issue(0, sh_next.minlen);
+      }
+
+      uint32_t tyc[LE];
+      if (c > 0 && (uint32_t)(c + 1) * LE <= minlen) {
+#pragma unroll
+        for (int j = 0; j < LE; ++j) tyc[j] = (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride;
+      } else {
+        const int32_t rem = (int32_t)cur.len - c * LE;   // my remaining events (may be <= 0)
+        const int32_t skip = c == 0 ? (int32_t)pad : 0;  // events in front of my aggregate (its first chunk only)
+#pragma unroll
+        for (int j = 0; j < LE; ++j)
+          tyc[j] = (j >= skip && j < rem) ? (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride : (uint32_t)kNullEntryOff;
+      }
+      if constexpr (decltype(tracking)::value) {
+        walk_events_track<LE>(a, P, undecM, frozenM, corr, ev, tyc, lds_tab, p);
+        watching = __builtin_amdgcn_ballot_w64(undecM != 0u && frozenM == 0u) != 0ull;
+      } else {
+        walk_events<LE, false>(a, frozenM, corr, ev, tyc, 0u, lds_tab, p, [](int) {});
+      }
+    };
+    // Two loops, not one loop with a branch: the watching loop (usually just the first tile of a group that holds
+    // chunks of cut aggregates) carries P and the deciding-event test; the plain loop is the sorted-rows kernel's walk
+    // and gets scheduled like it (one loop with both walks cost +13 % VALU instructions in the plain path).
+    int c = 0;
+    for (; c < n_tiles && watching; ++c) tile_step(c, std::true_type{});
+    for (; c < n_tiles; ++c) tile_step(c, std::false_type{});
+    a.sum = (int64_t)((uint64_t)a.sum + corr);
+
+    if (cur.dest >= 0) {
+      if (cur.info & VI_SIDE) {
+        // a chunk without a deciding event (or an empty one, which walked clamped garbage) is all prefix
+        const bool empty = cur.len == 0u;
+        const bool undecided = undecM != 0u || empty;
+        const Acc Pw = empty ? acc_identity() : select_acc(undecided, a, P);
+        Acc Sw = select_acc(undecided, acc_identity(), a);
+        if (!undecided) Sw.fl |= SIDE_DECIDED;
+        store_side(t.side, cur.dest, Pw, Sw);
+      } else {
+        store_state(p.out, cur.dest, a);
+      }
+    }
+
+    g = g_next;
+    cur = nxt;
+    sh = sh_next;
+  }
+}
+
+}  // namespace
+
+// Build the chunk table of a kernel-facing CSR (once per bound log).  d_hist: kChunkBuckets u64 scratch; d_total:
+// one u64; d_ctr: four u64.  Phase 1 (count) leaves the number of virtual rows in *d_total and {cut aggregates, their
+// chunks, 0, 0} in d_ctr; the host reads them, sizes the arrays and runs phase 2 (scatter).
+hipError_t launch_chunk_count(const int64_t* off, int64_t n_seg, uint32_t T, unsigned long long* d_hist,
+                              unsigned long long* d_total, unsigned long long* d_ctr, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(d_hist, 0, (size_t)kChunkBuckets * 8, stream);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(d_ctr, 0, 32, stream);
+  if (e != hipSuccess) return e;
+  if (n_seg > 0)
+    hipLaunchKernelGGL(chunk_hist_kernel, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, stream, off, n_seg, T, d_hist, d_ctr);
+  hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, stream, d_hist, d_total);
+  return hipGetLastError();
+}
+
+hipError_t launch_chunk_scatter(const int64_t* off, int64_t n_seg, const int64_t* out_map, uint32_t T,
+                                unsigned long long* d_cursor, unsigned long long* d_ctr, int64_t* v_start, uint32_t* v_len,
+                                uint32_t* v_info, int64_t* v_dest, int64_t* r_slot0, uint32_t* r_c, int64_t* r_out,
+                                hipStream_t stream) {
+  if (n_seg <= 0) return hipSuccess;
+  hipLaunchKernelGGL(chunk_scatter_kernel, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, stream, off, n_seg, out_map,
+                     d_cursor, d_ctr, T, v_start, v_len, v_info, v_dest, r_slot0, r_c, r_out);
+  return hipGetLastError();
+}
+
+// the fold over the chunk table + the stitch of the cut aggregates
+hipError_t launch_fold_chunked(const FoldParams& p, const int64_t* v_start, const uint32_t* v_len, const uint32_t* v_info,
+                               const int64_t* v_dest, int64_t n_vrows, uint32_t* side, const int64_t* r_slot0, const uint32_t* r_c,
+                               const int64_t* r_out, int64_t n_cut, int64_t n_waves, int lane_events, hipStream_t stream) {
+  if (n_waves <= 0 || n_vrows <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(p.counter, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  ChunkTable t;
+  t.v_start = v_start; t.v_len = v_len; t.v_info = v_info; t.v_dest = v_dest; t.n_vrows = n_vrows; t.side = side;
+  if (lane_events == 8)
+    hipLaunchKernelGGL((fold_chunked_kernel<8>), dim3((unsigned)n_waves), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxSorted), stream, p, t);
+  else  // 32-event lanes spill (337 VGPRs): 16 is the widest tile of this kernel
+    hipLaunchKernelGGL((fold_chunked_kernel<16>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxSorted), stream, p, t);
+  if (n_cut > 0)
+    hipLaunchKernelGGL(chunk_stitch_kernel, dim3((unsigned)((n_cut + 127) / 128)), dim3(128), 0, stream, p, side, r_slot0, r_c, r_out, n_cut);
+  return hipGetLastError();
+}
+
+}  // namespace surge

@@ -29,282 +29,10 @@
 //     plan kernel from the CSR offsets, so waves never exchange carries through memory: the
 //     running state of a segment that spans tiles is carried in scalar registers.
 //   * No MFMA: this is an HBM-bound fold (16 B in per event, 64 B out per aggregate).
-#include "replay_internal.h"
+#include "fold_device.h"
 
 namespace surge {
 namespace {
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// Cache policy of the event-stream loads: the log is read exactly once, so mark it non-temporal
-// (aux bit 1 = nt on gfx950 global_load_lds).
-#ifndef SURGE_LOAD_AUX
-#define SURGE_LOAD_AUX 2
-#endif
-constexpr int kLoadAux = SURGE_LOAD_AUX;
-
-constexpr uint32_t FL_PRESENT = 1u;
-constexpr uint32_t FL_POISONED = 2u;
-constexpr uint32_t FL_HEAD = 16u;
-constexpr uint32_t SM_COUNT = 1u << 8;
-constexpr uint32_t SM_VERSION = 1u << 9;
-constexpr uint32_t SM_BAL = 1u << 11;
-constexpr uint32_t SM_ALL = 0x7Fu << 8;  // count, version, sum, balance, min, max, event_count
-
-// A lane's transformer.  With fl & SM_x the field x holds an absolute value, otherwise a value
-// relative to the incoming state.  sum64/min/max/event_count only become absolute through a
-// reset (SM_ALL); count/version/balance also through their SET ops.
-struct Acc {
-  int32_t count, version;
-  int64_t sum;
-  uint64_t bal;
-  int32_t mn, mx;
-  uint32_t n, fl;
-};
-
-__device__ __forceinline__ Acc acc_none() {  // the aggregate is None (absolute)
-  Acc a;
-  a.count = 0; a.version = 0; a.sum = 0; a.bal = 0; a.mn = 0x7fffffff; a.mx = (int32_t)0x80000000; a.n = 0;
-  a.fl = SM_ALL;
-  return a;
-}
-
-__device__ __forceinline__ Acc acc_identity() {  // "whatever came in", present
-  Acc a = acc_none();
-  a.fl = FL_PRESENT;
-  return a;
-}
-
-__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
-
-__device__ __forceinline__ uint32_t andn(uint32_t x, uint32_t m) { return bfi(m, 0u, x); }  // x & ~m in one v_bfi
-
-// One case of handleEvent applied to one evaluation path, as pure VALU mask arithmetic: every
-// "condition" is an all-ones / all-zero dword (table words q0..q3, see TW_* in replay_internal.h),
-// selects are v_bfi_b32, nothing touches the scalar unit.  frozenM: events are being ignored
-// (the aggregate is poisoned).  validM: this event exists (tail of the last tile).
-__device__ __forceinline__ void apply_event(Acc& a, uint32_t& frozenM, uint32_t& corr, const uint4 q0, const uint4 q1,
-                                            const uint4 q2, const uint4 q3, uint32_t seq, uint32_t raw_lo,
-                                            uint32_t raw_hi, const FoldParams& p) {
-  const uint32_t ispM = andn(q2.x, frozenM);                            // throws (and is not ignored)
-  const uint32_t goM = ~(frozenM | q2.x);
-  const uint32_t presentM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 0, 1);
-  const uint32_t delM = goM & q2.y;
-  const uint32_t appM = andn(goM, q2.y) & (presentM | q2.w);            // REQUIRE-class events skip None
-  const uint32_t rstM = appM & bfi(presentM, q3.x, ~0u);                // CREATE, or materialising from None
-  frozenM |= ispM;
-
-  uint32_t fl = a.fl | (ispM & FL_POISONED);
-  fl = andn(fl, delM & FL_PRESENT) | (delM & SM_ALL);
-  fl |= rstM & (FL_PRESENT | SM_ALL);
-
-  uint32_t count = bfi(rstM, (uint32_t)p.d_count, (uint32_t)a.count);
-  uint32_t version = bfi(rstM, (uint32_t)p.d_version, (uint32_t)a.version);
-  uint32_t sum_lo = bfi(rstM, (uint32_t)p.d_sum, (uint32_t)a.sum);
-  uint32_t sum_hi = bfi(rstM, (uint32_t)((uint64_t)p.d_sum >> 32), (uint32_t)((uint64_t)a.sum >> 32));
-  uint32_t bal_lo = bfi(rstM, (uint32_t)p.d_balance, (uint32_t)a.bal);
-  uint32_t bal_hi = bfi(rstM, (uint32_t)(p.d_balance >> 32), (uint32_t)(a.bal >> 32));
-  uint32_t mn = bfi(rstM, (uint32_t)p.d_min, (uint32_t)a.mn);
-  uint32_t mx = bfi(rstM, (uint32_t)p.d_max, (uint32_t)a.mx);
-  uint32_t n = bfi(rstM, p.d_evcount, a.n);
-  corr = andn(corr, rstM);
-
-  const uint32_t arg = raw_lo;
-  // count: += / -= arg (JVM Int wrap) or := arg
-  count += ((arg ^ q0.y) - q0.y) & (q0.x & appM);
-  const uint32_t msetM = q0.z & appM;
-  count = bfi(msetM, arg, count);
-  const uint32_t mverM = q0.w & appM;
-  version = bfi(mverM, seq, version);
-  // sum64 += / -= (long) arg.  -(long)x == (long)~x + 1 exactly (also for Int.MinValue), so add the
-  // sign-extended complement now and count the "+1"s in corr (folded into the sum when the walk ends).
-  {
-    const uint32_t m = q1.x & appM;
-    const uint32_t x = (arg ^ q1.y) & m;
-    const uint64_t sum = (((uint64_t)sum_hi << 32) | sum_lo) + (uint64_t)(int64_t)(int32_t)x;
-    sum_lo = (uint32_t)sum;
-    sum_hi = (uint32_t)(sum >> 32);
-    corr -= q1.y & m;
-  }
-  // balance := value (bit copy)
-  const uint32_t mbalM = q1.z & appM;
-  bal_lo = bfi(mbalM, raw_lo, bal_lo);
-  bal_hi = bfi(mbalM, raw_hi, bal_hi);
-  mn = (uint32_t)min((int32_t)mn, (int32_t)bfi(q3.y & appM, arg, 0x7fffffffu));
-  mx = (uint32_t)max((int32_t)mx, (int32_t)bfi(q3.z & appM, arg, 0x80000000u));
-  n += q1.w & appM;
-  fl |= (msetM & SM_COUNT) | (mverM & SM_VERSION) | (mbalM & SM_BAL);
-
-  a.count = (int32_t)count; a.version = (int32_t)version;
-  a.sum = (int64_t)(((uint64_t)sum_hi << 32) | sum_lo);
-  a.bal = ((uint64_t)bal_hi << 32) | bal_lo;
-  a.mn = (int32_t)mn; a.mx = (int32_t)mx; a.n = n; a.fl = fl;
-}
-
-// g after f.  Absolute fields of g win, relative ones combine with f's.  A poisoned f is only ever
-// followed (inside its segment) by lanes that ignored their events, i.e. by identity transformers,
-// so the fields need no special case; the presence bit then has to come from f.
-__device__ __forceinline__ Acc seq_acc(const Acc& f, const Acc& g) {
-  Acc r;
-  const bool all = (g.fl & SM_ALL) == SM_ALL;  // sum/min/max/n become absolute only through a reset
-  r.count = (g.fl & SM_COUNT) ? g.count : (int32_t)((uint32_t)f.count + (uint32_t)g.count);
-  r.version = (g.fl & SM_VERSION) ? g.version : f.version;
-  r.sum = all ? g.sum : (int64_t)((uint64_t)f.sum + (uint64_t)g.sum);
-  r.bal = (g.fl & SM_BAL) ? g.bal : f.bal;
-  r.mn = all ? g.mn : min(f.mn, g.mn);
-  r.mx = all ? g.mx : max(f.mx, g.mx);
-  r.n = all ? g.n : f.n + g.n;
-  const uint32_t present = (f.fl & FL_POISONED) ? (f.fl & FL_PRESENT) : (g.fl & FL_PRESENT);
-  r.fl = present | ((f.fl | g.fl) & (FL_POISONED | SM_ALL)) | (f.fl & FL_HEAD);
-  return r;
-}
-
-__device__ __forceinline__ Acc select_acc(bool c, const Acc& a, const Acc& b) {
-  Acc r;
-  r.count = c ? a.count : b.count; r.version = c ? a.version : b.version;
-  r.sum = c ? a.sum : b.sum; r.bal = c ? a.bal : b.bal;
-  r.mn = c ? a.mn : b.mn; r.mx = c ? a.mx : b.mx; r.n = c ? a.n : b.n; r.fl = c ? a.fl : b.fl;
-  return r;
-}
-
-__device__ __forceinline__ Acc shfl_up_acc(const Acc& a, int d) {
-  Acc r;
-  r.count = __shfl_up(a.count, d, 64); r.version = __shfl_up(a.version, d, 64);
-  r.sum = __shfl_up(a.sum, d, 64); r.bal = __shfl_up(a.bal, d, 64);
-  r.mn = __shfl_up(a.mn, d, 64); r.mx = __shfl_up(a.mx, d, 64);
-  r.n = __shfl_up(a.n, d, 64); r.fl = __shfl_up(a.fl, d, 64);
-  return r;
-}
-
-__device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-
-__device__ __forceinline__ Acc readlane_acc(const Acc& a, int lane) {
-  Acc r;
-  r.count = (int32_t)rl((uint32_t)a.count, lane); r.version = (int32_t)rl((uint32_t)a.version, lane);
-  r.sum = (int64_t)(((uint64_t)rl((uint32_t)((uint64_t)a.sum >> 32), lane) << 32) | rl((uint32_t)a.sum, lane));
-  r.bal = ((uint64_t)rl((uint32_t)(a.bal >> 32), lane) << 32) | rl((uint32_t)a.bal, lane);
-  r.mn = (int32_t)rl((uint32_t)a.mn, lane); r.mx = (int32_t)rl((uint32_t)a.mx, lane);
-  r.n = rl(a.n, lane); r.fl = rl(a.fl, lane);
-  return r;
-}
-
-__device__ __forceinline__ void store_state(uint4* out, int64_t idx, const Acc& a) {
-  const bool pr = (a.fl & FL_PRESENT) != 0;
-  uint4 v0, v1, v2, v3;
-  v0.x = pr ? (uint32_t)a.count : 0u; v0.y = pr ? (uint32_t)a.version : 0u;
-  v0.z = pr ? (uint32_t)a.sum : 0u; v0.w = pr ? (uint32_t)((uint64_t)a.sum >> 32) : 0u;
-  v1.x = pr ? (uint32_t)a.bal : 0u; v1.y = pr ? (uint32_t)(a.bal >> 32) : 0u;
-  v1.z = pr ? (uint32_t)a.mn : 0u; v1.w = pr ? (uint32_t)a.mx : 0u;
-  v2.x = pr ? a.n : 0u; v2.y = a.fl & (FL_PRESENT | FL_POISONED); v2.z = 0u; v2.w = 0u;
-  v3.x = v3.y = v3.z = v3.w = 0u;
-  uint4* o = out + idx * 4;
-  o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3;
-}
-
-__device__ __forceinline__ Acc load_state(const uint4* in, int64_t idx) {
-  const uint4* s = in + idx * 4;
-  const uint4 v0 = s[0], v1 = s[1], v2 = s[2];
-  Acc a;
-  a.count = (int32_t)v0.x; a.version = (int32_t)v0.y;
-  a.sum = (int64_t)(((uint64_t)v0.w << 32) | v0.z);
-  a.bal = ((uint64_t)v1.y << 32) | v1.x;
-  a.mn = (int32_t)v1.z; a.mx = (int32_t)v1.w; a.n = v2.x;
-  a.fl = (v2.y & (FL_PRESENT | FL_POISONED)) | SM_ALL;
-  return a;
-}
-
-// ---- tile geometry ---------------------------------------------------------------------------------
-// One wave = 64 lanes x LE consecutive events per tile (LE = 16: 16 KiB tiles, LE = 8: 8 KiB tiles and
-// twice the resident waves).  A tile is fetched by direct global->LDS loads; instruction q writes LDS
-// bytes [q*1024, q*1024+1024) linearly by lane (that is what the hardware does); WHICH event a lane
-// fetches is ours to choose: LDS slot (q*64 + m) belongs to chunk-lane l = (64/LE) q + m / LE and holds
-// its event j = (m % LE) ^ key(l), an XOR swizzle inside the lane's own LE*16-byte row that makes the
-// later ds_read_b128 of "event j of lane l" bank-conflict free.  Every instruction still covers one
-// contiguous, fully used 1 KiB of the log.  The lane offset inside a 1 KiB piece only depends on
-// q mod kClasses, so it is computed once per wave.
-template <int LE>
-struct Geo {
-  static constexpr int kTile = kWave * LE;
-  static constexpr int kTileBytes = kTile * 16;
-  static constexpr int kRowBytes = LE * 16;
-  static constexpr int kLoads = kTileBytes / 1024;
-  static constexpr int kRowsPerLoad = kWave / LE;
-  static constexpr int kHeadWords = kTile / 32;
-  // LDS layout of every fold kernel: [tile][aux][op table]; the aux area is the head bitmask of the flat
-  // kernels, 64 row starts + lengths of the sorted kernel, nothing for the uniform rows kernel
-  static constexpr int kAuxFlat = kHeadWords * 4;
-  static constexpr int kAuxSorted = kWave * 12;
-  static constexpr int kAuxRows = 0;
-  static constexpr int kClasses = LE == 32 ? 8 : (LE == 16 ? 4 : 2);
-  static constexpr int lds_bytes(int aux) { return kTileBytes + aux + kTableEntries * kTableStride * 4; }
-  static constexpr uint32_t kLaneMask = LE >= 32 ? 0xffffffffu : ((1u << (LE & 31)) - 1u);
-  __device__ static __forceinline__ uint32_t key(int l) { return LE >= 16 ? (uint32_t)(l & 15) : (uint32_t)((l >> 1) & 7); }
-  // my pre-swizzled LDS row: event j lives at (row ^ (j * 16))
-  __device__ static __forceinline__ uint32_t ev_row(int lane) { return (uint32_t)lane * kRowBytes + key(lane) * 16u; }
-  // event index j that load-lane m of an instruction of class k fetches, and its chunk-lane within the instruction
-  __device__ static __forceinline__ uint32_t load_j(int m, int k) {
-    const int l = kRowsPerLoad * k + m / LE;  // only key(l) matters and it is periodic in q with period kClasses
-    return (uint32_t)(m % LE) ^ key(l);
-  }
-};
-
-template <int LE>
-__device__ __forceinline__ void load_table(const FoldParams& p, uint32_t* lds_tab, int lane) {
-  const uint32_t* src = &p.table[0][0];
-  for (int i = lane; i < kTableEntries * kTableWords; i += kWave)
-    lds_tab[(i / kTableWords) * kTableStride + (i % kTableWords)] = src[i];
-}
-
-template <int LE>
-__device__ __forceinline__ void issue_tile_loads(const FoldParams& p, int64_t te0, char* lds, const uint32_t* voff) {
-  using G = Geo<LE>;
-  const char* base = (const char*)(p.events + te0);  // wave-uniform
-  if (te0 + G::kTile <= p.n_events) {
-#pragma unroll
-    for (int q = 0; q < G::kLoads; ++q)
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + q * 1024 + voff[q % G::kClasses]), (lptr_t)(lds + q * 1024), 16, 0,
-                                       kLoadAux);
-  } else {  // the last tile of the buffer: clamp so nothing is read past the end
-    const int64_t last = (p.n_events - 1 - te0) * 16;
-#pragma unroll
-    for (int q = 0; q < G::kLoads; ++q) {
-      int64_t off = (int64_t)(q * 1024 + voff[q % G::kClasses]);
-      off = off < last ? off : last;
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(lds + q * 1024), 16, 0, kLoadAux);
-    }
-  }
-}
-
-// The walk over my LE events: one evaluation path, op-table entries prefetched one event ahead.
-// on_head(j) is called before event j when it starts a new segment (flat kernels only).
-template <int LE, bool HEADS, typename OnHead>
-__device__ __forceinline__ void walk_events(Acc& a, uint32_t& frozenM, uint32_t& corr, const uint4* ev, const uint32_t* tyc,
-                                            uint32_t hb, const uint32_t* lds_tab, const FoldParams& p, OnHead on_head) {
-  uint4 tq0, tq1, tq2, tq3;
-  {
-    const uint4* te = (const uint4*)(lds_tab + tyc[0]);
-    tq0 = te[0]; tq1 = te[1]; tq2 = te[2]; tq3 = te[3];
-  }
-#pragma unroll
-  for (int j = 0; j < LE; ++j) {
-    uint4 nq0 = tq0, nq1 = tq1, nq2 = tq2, nq3 = tq3;
-#if !defined(SURGE_DBG_FIXED_TABLE)
-    if (j + 1 < LE) {
-      const uint4* te = (const uint4*)(lds_tab + tyc[j + 1]);
-      nq0 = te[0]; nq1 = te[1]; nq2 = te[2]; nq3 = te[3];
-    }
-#endif
-    if (HEADS && ((hb >> j) & 1u)) on_head(j);
-#if defined(SURGE_DBG_SKIP_APPLY)  // experiment builds only: keep the loads alive, skip the arithmetic
-    a.count ^= (int32_t)(tq0.x ^ tq1.x ^ tq2.x ^ tq3.x ^ ev[j].y ^ ev[j].z ^ ev[j].w);
-#else
-    apply_event(a, frozenM, corr, tq0, tq1, tq2, tq3, ev[j].y, ev[j].z, ev[j].w, p);
-#endif
-    tq0 = nq0; tq1 = nq1; tq2 = nq2; tq3 = nq3;
-    __builtin_amdgcn_sched_barrier(0);  // keep the table prefetch one event deep (bounds VGPR pressure)
-  }
-}
 
 enum { MODE_FIXED = 0, MODE_FLAT = 1 };
 
@@ -419,7 +147,7 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
       const int64_t rem = E1 - (te0 + (int64_t)lane * LE);
 #pragma unroll
       for (int j = 0; j < LE; ++j)
-        tyc[j] = ((int64_t)j < rem ? (ev[j].x < 16u ? ev[j].x : 16u) : 17u) * kTableStride;
+        tyc[j] = (int64_t)j < rem ? (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride : (uint32_t)kNullEntryOff;
     }
 
     // ---- pass A: presence / poison only, bit-parallel ---------------------------------------------
@@ -558,7 +286,7 @@ __global__ void __launch_bounds__(kWave) fold_rows_kernel(const FoldParams p) {
   // the tile being fetched, and hipcc put an s_waitcnt vmcnt(0) in front of the first table read — i.e. each wave
   // waited for its NEXT tile before walking the current one.  Distinct objects let alias analysis drop that wait.
   __shared__ __attribute__((aligned(16))) char lds_ev[G::kTileBytes];
-  __shared__ __attribute__((aligned(16))) uint32_t lds_tab[kTableEntries * kTableStride];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_tab[kTableLdsDwords];
 
   const int lane = threadIdx.x;
   const int64_t S0 = (int64_t)blockIdx.x * p.segs_per_task;
@@ -735,7 +463,7 @@ __global__ void __launch_bounds__(kWave) fold_sorted_kernel(const FoldParams p) 
         const int32_t skip = c == 0 ? (int32_t)cur.pad : 0;   // events in front of my segment
 #pragma unroll
         for (int j = 0; j < LE; ++j)
-          tyc[j] = ((j >= skip && j < rem) ? (ev[j].x < 16u ? ev[j].x : 16u) : 17u) * kTableStride;
+          tyc[j] = (j >= skip && j < rem) ? (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride : (uint32_t)kNullEntryOff;
       }
       walk_events<LE, false>(a, frozenM, corr, ev, tyc, 0u, lds_tab, p, [](int) {});
     }

@@ -16,6 +16,12 @@ constexpr int kTaskBytes = 256 * 1024;                    // a wave task streams
 constexpr int kTableEntries = 18;                         // 16 event types + [16] unknown type (poison) + [17] null (padding) event
 constexpr int kTableWords = 16;                           // 64 B of pre-expanded masks per event type
 constexpr int kTableStride = 20;                          // dwords between entries in LDS (80 B: conflict-free b128 reads)
+// The 16 type entries at a stride of 20 dwords tile the 64 LDS banks exactly (20 e mod 64 hits every multiple of 4 once),
+// so a 17th / 18th entry must share banks with one of them.  [16] (unknown type) sits at 320 = bank 0 with type 0; the
+// null (padding) event, which every partial tile is full of, is moved off bank 20 (type 1, the commonest event of the
+// Counter model) onto bank 44, shared with type 15.
+constexpr int kNullEntryOff = 17 * kTableStride + 24;     // dword offset of the null entry [17] in LDS
+constexpr int kTableLdsDwords = kNullEntryOff + 16;
 
 // Per-type op table, pre-expanded on the host from the ABI descriptor so the kernel applies an event
 // with VALU mask arithmetic only (no per-event decode, no compares, no branches).  Every word is an
@@ -78,6 +84,17 @@ hipError_t launch_fold_sorted(const FoldParams& p, int64_t n_waves, int lane_eve
 constexpr int kSortBucketsHost = 65536;
 hipError_t launch_sort_by_length(const int64_t* off, int64_t n_seg, unsigned long long* d_hist, int64_t* perm,
                                  hipStream_t stream);
+// CHUNKED (fold_chunked.hip): chunk table of the kernel-facing CSR, then the fold over it + the stitch kernel
+constexpr int kChunkBucketsHost = 65536;
+hipError_t launch_chunk_count(const int64_t* off, int64_t n_seg, uint32_t T, unsigned long long* d_hist,
+                              unsigned long long* d_total, unsigned long long* d_ctr, hipStream_t stream);
+hipError_t launch_chunk_scatter(const int64_t* off, int64_t n_seg, const int64_t* out_map, uint32_t T,
+                                unsigned long long* d_cursor, unsigned long long* d_ctr, int64_t* v_start, uint32_t* v_len,
+                                uint32_t* v_info, int64_t* v_dest, int64_t* r_slot0, uint32_t* r_c, int64_t* r_out,
+                                hipStream_t stream);
+hipError_t launch_fold_chunked(const FoldParams& p, const int64_t* v_start, const uint32_t* v_len, const uint32_t* v_info,
+                               const int64_t* v_dest, int64_t n_vrows, uint32_t* side, const int64_t* r_slot0, const uint32_t* r_c,
+                               const int64_t* r_out, int64_t n_cut, int64_t n_waves, int lane_events, hipStream_t stream);
 hipError_t launch_plan(const int64_t* off, int64_t n_seg, int64_t task_events, int64_t n_tasks,
                        int64_t* plan, hipStream_t stream);
 hipError_t launch_analyze_csr(const int64_t* off, int64_t n_seg, CsrAnalysis* d_result, hipStream_t stream);

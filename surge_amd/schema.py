@@ -57,6 +57,7 @@ ALGO_FIXED = 1
 ALGO_FLAT = 2
 ALGO_ROWS = 3
 ALGO_SORTED = 4
+ALGO_CHUNKED = 5
 
 INT32_MAX = 2**31 - 1
 INT32_MIN = -(2**31)

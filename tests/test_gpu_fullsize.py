@@ -113,8 +113,9 @@ def test_c3_full_size_10m_aggregates_zipf():
     lens = synth.zipf_lengths(torch.arange(A, dtype=torch.int64, device=DEV), 3)
     # C3 type mix: oracle slices + agreement between the linear-stream and the sorted-rows kernels
     so, ev = synth.csr_log_device(lens, 3)
-    res = fold_all(so, ev, [S.ALGO_FLAT, S.ALGO_SORTED])
+    res = fold_all(so, ev, [S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED])
     assert torch.equal(res[S.ALGO_FLAT], res[S.ALGO_SORTED]), "flat and sorted-rows differ on the full C3 log"
+    assert torch.equal(res[S.ALGO_FLAT], res[S.ALGO_CHUNKED]), "flat and chunked-rows differ on the full C3 log"
     slice_parity(res[S.ALGO_FLAT], so, ev, 0, 4_000)
     slice_parity(res[S.ALGO_FLAT], so, ev, A - 3_000, A)
     slice_parity(res[S.ALGO_FLAT], so, ev, A // 2, A // 2 + 3_000)
@@ -127,9 +128,30 @@ def test_c3_full_size_10m_aggregates_zipf():
         eng.load_csr(so, ev, None, buf)
         eng.fold()
         eng.synchronize()
-        # AUTO takes the sorted-rows kernel from ~6.6 GB of Zipf(1..4096) log up (~0.9 M aggregates), FLAT below
-        if A >= 1_200_000:
+        # AUTO: sorted rows once the chunk target (bytes / 6 MB) reaches the longest aggregate (~3.3 M Zipf(1..4096)
+        # aggregates = 24.6 GB), chunked rows from ~1.5 GB (0.2 M aggregates), FLAT below
+        if A >= 3_500_000:
             assert eng.stats().last_algo == S.ALGO_SORTED
-        elif A <= 700_000:
+        elif 250_000 <= A <= 3_000_000:
+            assert eng.stats().last_algo == S.ALGO_CHUNKED
+        elif A <= 150_000:
             assert eng.stats().last_algo == S.ALGO_FLAT
     check_counter_fields(buf, so, ev)
+
+
+def test_c4_shard_size_1_25m_aggregates_zipf_every_kernel_agrees():
+    # what ONE GPU of the 8-GPU config holds (BASELINE C4: 10 M Zipf aggregates / 8): AUTO = chunked rows here
+    A = 1_250_000
+    lens = synth.zipf_lengths(torch.arange(A, dtype=torch.int64, device=DEV), 3)
+    so, ev = synth.csr_log_device(lens, 3, mix=synth.STRESS_MIX)  # tombstones, throws, REQUIRE runs across chunk cuts
+    res = fold_all(so, ev, [S.ALGO_CHUNKED, S.ALGO_FLAT, S.ALGO_SORTED])
+    assert torch.equal(res[S.ALGO_CHUNKED], res[S.ALGO_FLAT]) and torch.equal(res[S.ALGO_CHUNKED], res[S.ALGO_SORTED])
+    slice_parity(res[S.ALGO_CHUNKED], so, ev, 0, 6_000)
+    slice_parity(res[S.ALGO_CHUNKED], so, ev, A - 4_000, A)
+    with ReplayEngine() as eng:
+        buf = torch.empty((A, 64), dtype=torch.uint8, device=DEV)
+        eng.load_csr(so, ev, None, buf)
+        eng.fold()
+        eng.synchronize()
+        assert eng.stats().last_algo == S.ALGO_CHUNKED
+        assert torch.equal(buf, res[S.ALGO_CHUNKED])

@@ -70,11 +70,73 @@ def test_zipf_csr(seed, mix):
     so, ev = synth.zipf_log(20000, seed, mix=mix)
     exp = oracle.fold_csr(so, ev)
     got, st = gpu_fold(so, ev)
-    assert st.last_algo == S.ALGO_FLAT
+    assert st.last_algo == S.ALGO_FLAT  # 150 MB: below the ~1.5 GB where one lane per chunk starts to pay
     assert_same(got, exp, so)
-    got, st = gpu_fold(so, ev, algo=S.ALGO_SORTED)
-    assert st.last_algo == S.ALGO_SORTED
-    assert_same(got, exp, so)
+    for algo in (S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED):
+        got, st = gpu_fold(so, ev, algo=algo)
+        assert st.last_algo == algo
+        assert_same(got, exp, so)
+
+
+@pytest.mark.parametrize("chunk_t", [16, 64, 256, 1016])
+def test_chunked_rows_resolve_presence_across_chunks(chunk_t, monkeypatch):
+    # K2c: an aggregate longer than T is cut into chunks walked by unrelated lanes; a chunk learns its incoming state
+    # only afterwards (stitch kernel).  Hand-built event sequences that make the two presence hypotheses
+    # differ as late and as often as possible: REQUIRE-only stretches (dropped on None, applied on Some), the first
+    # MATERIALIZE / CREATE / DELETE deep inside a chunk, tombstones followed by REQUIRE runs, throws before and after
+    # the deciding event, aggregates that stay None through whole chunks — with prior snapshots of every kind.
+    monkeypatch.setenv("SURGE_REPLAY_CHUNK_T", str(chunk_t))
+    rng = np.random.default_rng(chunk_t)
+    REQ, MAT, CRE, DEL, THR, NOP = S.EVT_SET_BALANCE, S.EVT_INC, S.EVT_CREATE, S.EVT_DELETE, S.EVT_THROW, S.EVT_NOOP
+    rows = []
+    for length in (1, 15, 17, chunk_t, chunk_t + 1, 3 * chunk_t + 5, 8 * chunk_t, 64 * chunk_t + 9, 70 * chunk_t):
+        length = min(length, 30000)
+        for pattern in range(10):
+            ty = np.full(length, REQ, dtype=np.int64)                   # default: REQUIRE-class everywhere
+            if pattern == 1:
+                ty[:] = MAT
+            elif pattern == 2:
+                ty[rng.integers(0, length)] = MAT                        # one deciding event somewhere
+            elif pattern == 3:
+                ty[rng.integers(0, length)] = CRE
+            elif pattern == 4:
+                ty[rng.integers(0, length)] = DEL
+            elif pattern == 5:
+                ty[rng.integers(0, length)] = THR                        # throw inside a REQUIRE-only aggregate
+            elif pattern == 6:
+                k = rng.integers(0, length, size=max(1, length // 40))
+                ty[k] = rng.choice([MAT, CRE, DEL, NOP, MAT], size=k.shape[0])
+            elif pattern == 7:
+                ty[:] = rng.choice([REQ, REQ, REQ, MAT, DEL, NOP, S.EVT_DEC], size=length)
+                ty[rng.integers(0, length)] = THR
+            elif pattern == 8:
+                ty[:] = rng.choice([REQ, DEL, CRE, 13], size=length, p=[0.9, 0.05, 0.049, 0.001])  # 13: unknown type = MatchError
+            elif pattern == 9:
+                ty[: length // 2] = DEL                                   # None through whole chunks, then REQUIRE only
+            rows.append(ty)
+    order = rng.permutation(len(rows))
+    rows = [rows[i] for i in order]
+    lens = np.array([r.shape[0] for r in rows], dtype=np.int64)
+    so = np.zeros(lens.shape[0] + 1, dtype=np.int64)
+    np.cumsum(lens, out=so[1:])
+    n = int(so[-1])
+    ev = np.zeros(n, dtype=S.EVENT_DTYPE)
+    ev["type"] = np.concatenate(rows)
+    ev["seq"] = rng.integers(1, 1 << 30, size=n)
+    raw = rng.integers(-(1 << 31), 1 << 31, size=n).astype(np.int64)
+    f64 = (ev["type"] == REQ) | (ev["type"] == CRE)
+    vals = (rng.integers(-(1 << 20), 1 << 20, size=n) / 128.0).astype(np.float64).view(np.int64)
+    ev["raw"] = np.where(f64, vals, raw & 0xFFFFFFFF).astype(np.uint64) if "raw" in ev.dtype.names else 0
+    for prior_kind in ("none", "mixed"):
+        prior = None
+        if prior_kind == "mixed":  # Some / None / poisoned priors
+            prior = oracle.fold_csr(*synth.csr_log(rng.integers(0, 4, size=lens.shape[0]), 77, synth.STRESS_MIX))
+        exp = oracle.fold_csr(so, ev, prior)
+        got, st = gpu_fold(so, ev, prior, algo=S.ALGO_CHUNKED)
+        assert st.last_algo == S.ALGO_CHUNKED
+        assert_same(got, exp, so)
+        got, _ = gpu_fold(so, ev, prior, algo=S.ALGO_FLAT)  # the flat kernel resolves presence its own way: same bytes
+        assert_same(got, exp, so)
 
 
 def test_auto_picks_rows_for_large_uniform_logs_and_all_uniform_kernels_agree():
@@ -83,7 +145,7 @@ def test_auto_picks_rows_for_large_uniform_logs_and_all_uniform_kernels_agree():
     got, st = gpu_fold(so, ev)
     assert st.last_algo == S.ALGO_ROWS
     assert_same(got, exp, so)
-    for algo in (S.ALGO_FIXED, S.ALGO_FLAT, S.ALGO_SORTED):
+    for algo in (S.ALGO_FIXED, S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED):
         got, st = gpu_fold(so, ev, algo=algo)
         assert st.last_algo == algo
         assert_same(got, exp, so)
@@ -123,14 +185,14 @@ def test_csr_window_into_a_larger_events_buffer(lead, tail):
     so2 = so + lead
     exp = oracle.fold_csr(so, ev)
     assert oracle.fold_csr(so2, ev2).tobytes() == exp.tobytes()
-    for algo in (S.ALGO_AUTO, S.ALGO_FLAT, S.ALGO_SORTED):
+    for algo in (S.ALGO_AUTO, S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED):
         got, _ = gpu_fold(so2, ev2, algo=algo)
         assert_same(got, exp, so)
     # a uniform log behind a lead cannot take the FIXED / ROWS fast paths, AUTO must still be right
     so, ev = synth.fixed_log(3000, 32, seed=33, mix=synth.STRESS_MIX)
     ev2 = np.concatenate([junk[:lead], ev, junk[lead:]])
     got, st = gpu_fold(so + lead, ev2)
-    assert st.last_algo in (S.ALGO_FLAT, S.ALGO_SORTED)
+    assert st.last_algo in (S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED)
     assert_same(got, oracle.fold_csr(so, ev), so)
 
 
@@ -192,7 +254,7 @@ def test_random_log_shapes_through_every_kernel(seed):
         if rng.random() < 0.5:
             prior = oracle.fold_csr(*synth.csr_log(rng.integers(0, 4, size=n), int(rng.integers(1, 1 << 30)), synth.STRESS_MIX))
         exp = oracle.fold_csr(so, ev, prior)
-        algos = [S.ALGO_AUTO, S.ALGO_FLAT, S.ALGO_SORTED] + ([S.ALGO_FIXED, S.ALGO_ROWS] if kind == 4 else [])
+        algos = [S.ALGO_AUTO, S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED] + ([S.ALGO_FIXED, S.ALGO_ROWS] if kind == 4 else [])
         for algo in algos:
             got, _ = gpu_fold(so, ev, prior, algo=algo)
             assert got.tobytes() == exp.tobytes(), (seed, kind, n, algo)
