@@ -3,20 +3,26 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload at every N: BASELINE.json ``configs[1]`` (SURVEY §8d "C2") PER GPU — 1,000,000
-aggregates x 256 fixed-width events (16 B events, 64 B state), i.e. weak scaling: the global log has
-N x 1M aggregates, sharded by the reference's Kafka partitioner (murmur3(id) % 64 -> gpu =
-partition % N, KafkaPartitioner.scala:8).  One "step" = one full replay of the rank's HBM-resident
-shard (plan + fold kernel) and, for N > 1, the RCCL all-gather of the final snapshot, overlapped
-with the next step's fold on a side stream.  Inputs are resident in HBM before the timed region.
+Workload at every N (the log BASELINE.json's target is quoted on): the 10,000,000-aggregate synthetic log with Zipf(1..4096)
+event counts (~4.6e9 events, 74 GB, 16 B events, 64 B state), ids ``acct-%08d``, STRONG-scaled: sharded
+by the reference's own shard map — partition = partitionForKey(id, 64) (KafkaPartitioner.scala:8), gpu = partition % N
+(ownership like PartitionAssignments.scala:51-63) — every rank generating only its shard.  N = 1 is BASELINE config C3 (the
+whole log on one GPU: it fits), N = 8 is config C4.  One "step" = one full replay of the rank's HBM-resident shard and,
+for N > 1, the all-gather of the final snapshot through the C ABI (RCCL inside libsurge_replay.so: grouped per-peer
+send/recv of the 40-byte wire form on the library's side stream), overlapped with the next step's fold.  Inputs are
+resident in HBM before the timed region.  ``--workload c2`` runs BASELINE config C2 (1 M aggregates x 256 events) instead;
+``--workload c2-weak`` is round 1's weak-scaled C2-per-GPU run.
 
-Rank 0 prints ONE JSON line.  ``roofline`` prices the fold kernel against the 8 TB/s HBM peak using
-the algorithmic bytes 16*E + 8*(A+1) + 64*A and the kernel's HIP-event time measured
-inside the timed region on the launch stream.  ``cpu_baseline`` (rank 0, N == 1 only) times the CPU
-restatement (oracle/, "port") on a bounded sample of the same log on this box's host cores, and
-the GPU result for that sample is checked bit-for-bit against it.
+Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant fold kernel against the 8 TB/s HBM peak using the
+algorithmic bytes 16*E + 8*(A+1) + 64*A and the kernel's HIP-event times measured inside the timed region on
+the launch stream (mean for ``achieved``; min / median / max reported).  ``traffic`` comes from the rocprofv3 PMC passes
+committed under profiles/ for exactly this kernel and shape (profiles/traffic_manifest.json; null when there is none or
+the kernel sources changed since).  At N = 1 ``secondary`` carries config C2 with its own roofline, and ``cpu_baseline``
+times the CPU restatement (oracle/, "port") on a bounded sample of the same log on this box's host cores; the GPU result
+for that sample is checked bit-for-bit against it.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,10 +34,102 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
-AGG_PER_GPU = 1_000_000
-EVENTS_PER_AGG = 256
+N_AGGREGATES = 10_000_000
 N_PARTITIONS = 64
-SEED = 2
+ZIPF_SEED = 3
+C2_AGGREGATES, C2_EVENTS, C2_SEED = 1_000_000, 256, 2
+
+
+def kernel_name(S, algo):
+    return {S.ALGO_FIXED: "fold_kernel<FIXED,16>", S.ALGO_FLAT: "fold_kernel<FLAT,16>", S.ALGO_ROWS: "fold_rows_kernel<8>",
+            S.ALGO_SORTED: "fold_sorted_kernel<16>", S.ALGO_CHUNKED: "fold_chunked_kernel<16> + chunk_stitch_kernel"}.get(algo, str(algo))
+
+
+def algo_name(S, algo):
+    return {S.ALGO_FIXED: "fixed", S.ALGO_FLAT: "flat", S.ALGO_ROWS: "rows", S.ALGO_SORTED: "sorted", S.ALGO_CHUNKED: "chunked"}.get(algo, str(algo))
+
+
+def csrc_sha16():
+    """Identity of the kernel sources a profile was taken with (profiles/traffic_manifest.json records it)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "surge_amd", "csrc")
+    for name in ("fold_device.h", "fold_kernels.hip", "fold_chunked.hip", "replay_internal.h"):  # what the fold kernels are built from
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel, algorithmic_bytes):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ for THIS kernel and THIS shape
+    (separate --pmc passes for FETCH_SIZE and WRITE_SIZE, gfx950 x2 correction on FETCH_SIZE, KB -> bytes; written by
+    scripts/prof_traffic.py).  bench.py cannot collect PMC counters itself: null when no profile matches, and null —
+    saying so — when the kernel sources changed after the profile was taken."""
+    path = os.path.join(ROOT, "profiles", "traffic_manifest.json")
+    if not os.path.exists(path):
+        return None, None
+    try:
+        entries = json.load(open(path))
+    except Exception:  # pragma: no cover
+        return None, None
+    sha = csrc_sha16()
+    stale = None
+    for e in entries:
+        if e.get("kernel") == kernel and int(e.get("algorithmic_bytes", -1)) == int(algorithmic_bytes):
+            if e.get("csrc_sha16") == sha:
+                return e["traffic_bytes"], e.get("source")
+            stale = e.get("source")
+    if stale:
+        return None, f"stale: kernel sources changed since {stale}"
+    return None, None
+
+
+class _LazyGlobalOffsets:
+    """``global_seg_off[agg]`` for the sharded Zipf log without materialising the global prefix sum: only the event
+    *hash index* needs to be unique per (aggregate, position), so aggregate a's events are numbered from a * 4096
+    (4096 = the longest possible segment)."""
+
+    def __getitem__(self, agg):
+        return agg * 4096
+
+
+def time_folds(eng, torch, dev, algo, steps, warmup):
+    """K timed folds of the bound log on the engine's stream (no exchange); returns (elapsed_s, stats, per-launch ms)."""
+    for _ in range(warmup):
+        eng.fold(algo)
+    torch.cuda.synchronize(dev)
+    eng.stats_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.fold(algo)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return dt, eng.stats(), eng.fold_times_ms()
+
+
+def roofline_of(S, st, times_ms, probe_gbps=None):
+    import numpy as np
+
+    kernel_ms = float(np.mean(times_ms)) if len(times_ms) else 0.0
+    achieved = st.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    kname = kernel_name(S, st.last_algo)
+    traffic, traffic_src = pmc_traffic(kname, st.algorithmic_bytes)
+    r = {
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS,
+        "traffic": traffic,
+        "traffic_source": traffic_src,
+        "kernel": kname,
+        "kernel_ms": kernel_ms,
+        "kernel_ms_min_median_max": [float(np.min(times_ms)), float(np.median(times_ms)), float(np.max(times_ms))] if len(times_ms) else None,
+        "algorithmic_bytes": st.algorithmic_bytes,
+        "timed_launches": int(len(times_ms)),
+    }
+    if probe_gbps is not None:
+        r["stream_read_probe_GBps"] = probe_gbps
+    return r
 
 
 def main():
@@ -39,16 +137,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--aggregates", type=int, default=AGG_PER_GPU, help="aggregates per GPU (default = config C2)")
-    ap.add_argument("--events-per-aggregate", type=int, default=EVENTS_PER_AGG)
-    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 fixed, 2 flat, 3 rows, 4 sorted")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
-                    help="c2 (default, the config the metric is quoted on): fixed fan-in; c3: Zipf(1..4096) event counts")
-    ap.add_argument("--zipf-aggregates", type=int, default=10_000_000, help="aggregates per GPU for --workload c3")
+    ap.add_argument("--workload", default="c4", choices=["c4", "c3", "c2", "c2-weak"],
+                    help="c4 / c3 (default): the 10 M-aggregate Zipf log, strong-scaled over the GPUs; c2: 1 M x 256 fixed fan-in "
+                         "(strong-scaled); c2-weak: 1 M x 256 PER GPU (round 1's run)")
+    ap.add_argument("--aggregates", type=int, default=None, help="global aggregate count (default 10 M for c4, 1 M for c2)")
+    ap.add_argument("--events-per-aggregate", type=int, default=C2_EVENTS, help="c2 only")
+    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 fixed, 2 flat, 3 rows, 4 sorted, 5 chunked")
+    ap.add_argument("--gather", default="native", choices=["native", "torch", "none"],
+                    help="N > 1 snapshot exchange: native = RCCL behind the C ABI (default), torch = torch.distributed, none = fold only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-time budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config-C2 secondary line at N = 1")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
 
     from surge_amd import schema as S
@@ -64,10 +166,6 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the replay engine has no CPU fallback")
-    # rehearsal of the N > 1 control flow on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL
-    rehearsal = os.environ.get("SURGE_BENCH_SINGLE_GPU_REHEARSAL") == "1"
-    if rehearsal:
-        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -76,56 +174,72 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=dev)  # control plane: barriers, the timing reductions, the communicator id
 
-    A, L = args.aggregates, args.events_per_aggregate
-    zipf = args.workload == "c3"
-    if zipf:
-        A = args.zipf_aggregates
+    zipf = args.workload in ("c4", "c3")
+    weak = args.workload == "c2-weak"
+    L = args.events_per_aggregate
+    n_global = args.aggregates or (N_AGGREGATES if zipf else C2_AGGREGATES)
+    if weak:
+        n_global *= world
     eng = ReplayEngine(device=local_rank)
     compute = torch.cuda.Stream(device=dev)
     eng.use_stream(compute)
 
-    # ---- build this rank's HBM-resident shard -----------------------------------------------------
+    # ---- this rank's HBM-resident shard ---------------------------------------------------------------
+    t_gen = time.perf_counter()
     if world == 1:
-        agg_ids = torch.arange(A, dtype=torch.int64, device=dev) if zipf else None
-        n_local = A
+        agg_ids = torch.arange(n_global, dtype=torch.int64, device=dev)
     else:
-        from surge_amd.dist import SnapshotGather, local_aggregate_ids
+        from surge_amd.dist import local_aggregate_ids
 
-        agg_ids = local_aggregate_ids(A * world, N_PARTITIONS, rank, world, dev, eng)
-        n_local = int(agg_ids.numel())
+        agg_ids = local_aggregate_ids(n_global, N_PARTITIONS, rank, world, dev, eng)
+    n_local = int(agg_ids.numel())
     if zipf:
         # the rank's aggregates keep the event counts and contents they have in the global log
-        lens = synth.zipf_lengths(agg_ids, 3)
-        seg_off, events = synth.csr_log_device(lens, 3, agg_ids=agg_ids,
-                                               global_seg_off=_LazyGlobalOffsets(agg_ids, lens))
+        lens = synth.zipf_lengths(agg_ids, ZIPF_SEED)
+        seg_off, events = synth.csr_log_device(lens, ZIPF_SEED, agg_ids=agg_ids, global_seg_off=_LazyGlobalOffsets())
         n_events_local = int(seg_off[-1].item())
+        del lens
     elif world == 1:
-        seg_off, events = synth.fixed_log_device(A, L, SEED, dev)
+        seg_off, events = synth.fixed_log_device(n_global, L, C2_SEED, dev)
         n_events_local = n_local * L
     else:
-        seg_off, events = synth.fixed_log_for_aggregates_device(agg_ids, L, SEED)
+        seg_off, events = synth.fixed_log_for_aggregates_device(agg_ids, L, C2_SEED)
         n_events_local = n_local * L
     torch.cuda.synchronize(dev)
+    gen_s = time.perf_counter() - t_gen
 
-    if world == 1:
-        bufs = [torch.zeros((n_local, 64), dtype=torch.uint8, device=dev) for _ in range(2)]
-        gather = None
-    else:
-        gather = SnapshotGather(n_local, dev, engine=eng)
+    # ---- the exchange (N > 1) -------------------------------------------------------------------------
+    gather, gather_kind = None, None
+    if world > 1 and args.gather != "none":
+        from surge_amd.dist import NativeSnapshotGather, SnapshotGather
+
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        if args.gather == "native":
+            try:
+                gather = NativeSnapshotGather(n_local, dev, eng)
+                gather_kind = "C ABI (surge_replay_allgather_snapshot): RCCL inside libsurge_replay.so"
+            except Exception as exc:  # pragma: no cover - depends on the box
+                print(f"[bench] rank {rank}: native exchange unavailable: {exc}", file=sys.stderr)
+                ok[0] = 0
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if args.gather == "torch" or int(ok.item()) == 0:
+            if gather is not None:
+                eng.comm_destroy()
+            gather = SnapshotGather(n_local, dev, engine=eng)
+            gather_kind = "torch.distributed (nccl = RCCL)" + (" — FALLBACK: the C-ABI exchange failed to initialise" if args.gather == "native" else "")
+    if gather is not None:
         bufs = gather.make_local_buffers()
+    else:
+        bufs = [torch.zeros((n_local, 64), dtype=torch.uint8, device=dev) for _ in range(2)]
     eng.load_csr(seg_off, events, None, bufs[0])
-
     fold_done = [torch.cuda.Event(), torch.cuda.Event()]
 
     def step(i):
         slot = i & 1
         if gather is not None:
-            gather.wait(slot, compute)  # the gather that last read bufs[slot] must be finished
+            gather.wait(slot, compute)  # the exchange that last read bufs[slot] must be finished
         eng.set_state_out(bufs[slot])
         eng.fold(args.algo)
         if gather is not None:
@@ -133,64 +247,82 @@ def main():
             gather.launch(slot, bufs[slot], fold_done[slot])
 
     def sync_all():
-        torch.cuda.synchronize(dev)
+        torch.cuda.synchronize(dev)  # every stream of the device, the library's side stream included
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
-
-    def reduce_(t, op):
-        if dist is None:
-            return t
-        if rehearsal:
-            h = t.cpu()
-            dist.all_reduce(h, op=op)
-            return h.to(dev)
-        dist.all_reduce(t, op=op)
-        return t
 
     for i in range(args.warmup):
         step(i)
     sync_all()
     eng.stats_reset()
-
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     sync_all()
     t1 = time.perf_counter()
+    last = (args.warmup + args.steps - 1) & 1
 
+    st = eng.stats()
+    times_ms = eng.fold_times_ms()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     totals = torch.tensor([n_events_local, n_local], dtype=torch.int64, device=dev)
+    per_rank = torch.tensor([float(n_events_local), float(np.mean(times_ms)) if len(times_ms) else 0.0], dtype=torch.float64, device=dev)
+    exchange = None
     if dist is not None:
-        elapsed = reduce_(elapsed, dist.ReduceOp.MAX)
-        totals = reduce_(totals, dist.ReduceOp.SUM)
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+        allr = [torch.zeros_like(per_rank) for _ in range(world)]
+        dist.all_gather(allr, per_rank)
+        per_rank_events = [int(t[0].item()) for t in allr]
+        per_rank_fold_ms = [float(t[1].item()) for t in allr]
+        if gather is not None:
+            # (a) the gathered snapshot holds every rank's shard: checksum of each rank's block against that rank's own
+            torch.cuda.synchronize(dev)
+            res = gather.result(last)
+            own = torch.stack([bufs[last][: n_local].view(torch.int64).sum()])
+            sums = [torch.zeros_like(own) for _ in range(world)]
+            dist.all_gather(sums, own)
+            for r in range(world):
+                got = res[r, : gather.counts[r]].reshape(-1).view(torch.int64).sum()
+                assert int(got.item()) == int(sums[r].item()), f"rank {rank}: gathered block of rank {r} differs from its shard"
+            assert torch.equal(res[rank, :n_local], bufs[last][:n_local]), "all-gathered snapshot does not contain the local shard"
+            # (b) the exchange alone, not overlapped (barrier, launch, wait)
+            ex = []
+            for _ in range(5):
+                sync_all()
+                ta = time.perf_counter()
+                gather.launch(last, bufs[last], None)
+                torch.cuda.synchronize(dev)
+                ex.append((time.perf_counter() - ta) * 1e3)
+            exm = torch.tensor([float(np.median(ex))], dtype=torch.float64, device=dev)
+            dist.all_reduce(exm, op=dist.ReduceOp.MAX)
+            exchange = float(exm.item())
+    else:
+        per_rank_events, per_rank_fold_ms = [n_events_local], [float(np.mean(times_ms)) if len(times_ms) else 0.0]
     elapsed_s = float(elapsed.item())
     total_events, total_aggs = int(totals[0].item()), int(totals[1].item())
 
-    st = eng.stats()
-    kernel_ms = st.sum_fold_kernel_ms / max(st.timed_folds, 1)
-    traffic, traffic_src = pmc_traffic(args, st.last_algo)
-    achieved = st.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-
-    # ---- extras on rank 0 ---------------------------------------------------------------------------
     result = None
     if rank == 0:
         probe_gbps = None
         try:
-            ms = min(eng.stream_probe_ms(events) for _ in range(5))
-            probe_gbps = events.numel() * 8 / (ms * 1e-3) / 1e9
+            ms = min(eng.stream_probe_ms(events[: min(events.shape[0], 1 << 28)]) for _ in range(5))
+            probe_gbps = min(events.shape[0], 1 << 28) * 16 / (ms * 1e-3) / 1e9
         except Exception as e:  # pragma: no cover
             print(f"stream probe failed: {e}", file=sys.stderr)
+        ms_per_step = elapsed_s / args.steps * 1e3
+        roof = roofline_of(S, st, times_ms, probe_gbps)
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu_baseline = run_cpu_baseline(args, seg_off, events, bufs[(args.warmup + args.steps - 1) & 1], L)
-        ms_per_step = elapsed_s / args.steps * 1e3
-        if world > 1:
-            # the gathered snapshot must contain this rank's own shard, bit for bit
-            last = (args.warmup + args.steps - 1) & 1
-            torch.cuda.synchronize(dev)
-            own = gather.result(last)[rank, :n_local]
-            assert torch.equal(own, bufs[last][:n_local]), "all-gathered snapshot does not contain the local shard"
+            cpu_baseline = run_cpu_baseline(args, seg_off, events, bufs[last])
+        if zipf:
+            wl = (f"C{'3' if world == 1 else '4'}: {n_global} aggregates, Zipf(1..4096) events each, CSR, 16 B events, 64 B state, "
+                  f"ids acct-%08d sharded over {world} GPU(s) by partitionForKey(id, {N_PARTITIONS}) % {world}; log resident in HBM")
+        else:
+            wl = (f"C2{' per GPU (weak)' if weak else ''}: {n_global} aggregates x {L} events, 16 B events, 64 B state, sharded over {world} "
+                  f"GPU(s); log resident in HBM")
+        fold_ms = max(per_rank_fold_ms)
         result = {
             "metric": "events/sec replayed",
             "value": total_events * args.steps / elapsed_s,
@@ -200,41 +332,32 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
             "dtype": "int32/int64 adds + bit-copied f64",
-            "data": "synthetic (counter-hash log, seed 2; surge_amd/synth.py)",
+            "data": "synthetic (counter-hash log; surge_amd/synth.py), generated on the device in %.0f s" % gen_s,
             "aggregates_per_sec": total_aggs * args.steps / elapsed_s,
             "config": {
-                "workload": (f"C3 per GPU: {A} aggregates, Zipf(1..4096) events each ({n_events_local} events on rank 0), CSR, "
-                             "16 B events, 64 B state, log resident in HBM") if zipf else
-                f"C2 per GPU: {A} aggregates x {L} events, 16 B events, 64 B state, log resident in HBM",
-                "aggregates_per_gpu": A,
+                "workload": wl,
+                "aggregates": n_global,
+                "events": total_events,
                 "events_per_aggregate": "zipf(1..4096), mean ~460" if zipf else L,
-                "algo": {S.ALGO_FIXED: "fixed", S.ALGO_FLAT: "flat", S.ALGO_ROWS: "rows", S.ALGO_SORTED: "sorted"}.get(st.last_algo, str(st.last_algo)),
+                "algo": algo_name(S, st.last_algo),
                 "wave_tasks": st.n_tasks,
-                "sharding": "single shard" if world == 1 else
-                f"murmur3(acct-%08d) % {N_PARTITIONS} -> gpu = partition % {world}; final snapshot exchanged over "
-                f"{'gloo (single-GPU rehearsal)' if rehearsal else 'RCCL'} ({'grouped per-peer send/recv' if gather.mode == 'p2p' else 'all_gather_into_tensor'}, "
-                f"{'40-byte wire form' if gather.packed else '64-byte states'}) on a side stream, overlapped with the next fold",
+                "per_rank_events": per_rank_events,
+                "per_rank_fold_kernel_ms": per_rank_fold_ms,
+                "exchange": None if world == 1 else (gather_kind or "none (fold only)"),
+                "exchange_transport": None if gather is None else
+                f"{'grouped per-peer ncclSend/ncclRecv' if gather.mode == 'p2p' else 'ncclAllGather, max-padded'}, "
+                f"{'40-byte wire form' if gather.packed else '64-byte states'}, side stream, overlapped with the next fold",
+                "exchange_alone_ms": exchange,
+                "exchange_hidden_fraction": None if not exchange else max(0.0, min(1.0, 1.0 - max(0.0, ms_per_step - fold_ms) / exchange)),
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "kernel": {S.ALGO_FIXED: "fold_kernel<FIXED,16>", S.ALGO_FLAT: "fold_kernel<FLAT,16>",
-                           S.ALGO_ROWS: "fold_rows_kernel<8>", S.ALGO_SORTED: "fold_sorted_kernel<16>"}.get(st.last_algo, "?"),
-                "kernel_ms": kernel_ms,
-                "algorithmic_bytes": st.algorithmic_bytes,
-                "timed_launches": st.timed_folds,
-                "stream_read_probe_GBps": probe_gbps,
-            },
+            "roofline": roof,
             "cpu_baseline": cpu_baseline,
         }
+        if world == 1 and zipf and not args.no_secondary:
+            result["secondary"] = run_secondary_c2(args, S, synth, ReplayEngine, torch, dev, local_rank)
     eng.close()
     if dist is not None:
         dist.barrier()
@@ -243,57 +366,37 @@ def main():
         print(json.dumps(result))
 
 
-def pmc_traffic(args, algo):
-    """HBM bytes per launch from the rocprofv3 PMC passes of THIS command (separate --pmc runs for
-    FETCH_SIZE and WRITE_SIZE, gfx950 correction x2 on FETCH_SIZE, KB -> bytes), as committed under
-    profiles/ by scripts/prof.sh.  bench.py cannot collect PMC counters itself; null when there is no
-    profile for the workload/kernel being run."""
-    if args.workload == "c2" and args.aggregates == AGG_PER_GPU and args.events_per_aggregate == EVENTS_PER_AGG:
-        name, want = "r01_final_c2_rows_summary.txt", {3: "fold_rows"}.get(algo)
-    elif args.workload == "c3" and args.zipf_aggregates == 10_000_000:
-        name, want = "r01_final_c3_sorted16_10Magg_summary.txt", {4: "fold_sorted"}.get(algo)
-    else:
-        return None, None
-    path = os.path.join(ROOT, "profiles", name)
-    if want is None or not os.path.exists(path):
-        return None, None
-    fetch = write = None
-    for line in open(path):
-        parts = line.split()
-        if len(parts) >= 5 and parts[1] == want and parts[2] == "FETCH_SIZE":
-            fetch = float(parts[-1].split("=")[1])
-        if len(parts) >= 5 and parts[1] == want and parts[2] == "WRITE_SIZE":
-            write = float(parts[-1].split("=")[1])
-    if fetch is None or write is None:
-        return None, None
-    return fetch * 1024 * 2 + write * 1024, f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
+def run_secondary_c2(args, S, synth, ReplayEngine, torch, dev, local_rank):
+    """BASELINE config C2 (1 M aggregates x 256 events, uniform fan-in) on the same GPU, with its own roofline."""
+    so, ev = synth.fixed_log_device(C2_AGGREGATES, C2_EVENTS, C2_SEED, dev)
+    out = torch.zeros((C2_AGGREGATES, 64), dtype=torch.uint8, device=dev)
+    with ReplayEngine(device=local_rank) as e2:
+        e2.load_csr(so, ev, None, out)
+        steps = 150  # ~0.7 ms each: a > 100 ms timed region
+        dt, st, times_ms = time_folds(e2, torch, dev, 0, steps, 5)
+        return {
+            "config": {"workload": f"C2: {C2_AGGREGATES} aggregates x {C2_EVENTS} events, 16 B events, 64 B state, single GPU, log resident in HBM",
+                       "algo": algo_name(S, st.last_algo), "wave_tasks": st.n_tasks},
+            "metric": "events/sec replayed",
+            "value": C2_AGGREGATES * C2_EVENTS * steps / dt,
+            "unit": "events/s",
+            "steps": steps,
+            "ms_per_step": dt / steps * 1e3,
+            "roofline": roofline_of(S, st, times_ms),
+        }
 
 
-class _LazyGlobalOffsets:
-    """``global_seg_off[agg]`` for the sharded Zipf log without materialising the global prefix sum:
-    only the event *hash index* needs to be unique per (aggregate, position), so aggregate a's events
-    are numbered from a * 4096 (4096 = the longest possible segment)."""
-
-    def __init__(self, agg_ids, lens):
-        pass
-
-    def __getitem__(self, agg):
-        return agg * 4096
-
-
-def run_cpu_baseline(args, seg_off, events, gpu_states, L):
+def run_cpu_baseline(args, seg_off, events, gpu_states):
     """CPU restatement (oracle/, kind "port") on a bounded sample of the SAME log, all host cores."""
-    import numpy as np
+    import torch
 
     from oracle import oracle
     from surge_amd import schema as S
     from surge_amd import synth
 
-    import torch
-
     cores = os.cpu_count() or 1
     n_aggs = int(seg_off.numel()) - 1
-    # first aggregates of the log holding about 64 M events (250k aggregates of config C2)
+    # first aggregates of the log holding about 64 M events
     sample_aggs = int(torch.searchsorted(seg_off, torch.tensor([64_000_000], device=seg_off.device))[0])
     sample_aggs = max(1, min(sample_aggs, n_aggs))
     so = seg_off[: sample_aggs + 1].cpu().numpy()
@@ -305,14 +408,15 @@ def run_cpu_baseline(args, seg_off, events, gpu_states, L):
     parity = got.tobytes() == exp.tobytes()
 
     def timed(threads, budget_s):
-        oracle.fold_csr(so, ev, threads=threads)  # warm-up pass
-        reps, t0 = 0, time.perf_counter()
-        while True:
-            oracle.fold_csr(so, ev, threads=threads)
-            reps += 1
-            dt = time.perf_counter() - t0
-            if dt * threads >= budget_s or reps >= 200:
-                return n_ev * reps / dt
+        # threads keep folding their share of the sample `reps` times each (no thread start per pass); reps is sized
+        # from a first pass so the leg spends about budget_s of CPU time
+        t0 = time.perf_counter()
+        oracle.fold_csr_repeated(so, ev, threads, 1)
+        one = time.perf_counter() - t0
+        reps = int(max(1, min(400, budget_s / max(one * threads, 1e-6))))
+        t0 = time.perf_counter()
+        oracle.fold_csr_repeated(so, ev, threads, reps)
+        return n_ev * reps / (time.perf_counter() - t0)
 
     all_cores = timed(cores, args.cpu_seconds)
     one_core = timed(1, min(args.cpu_seconds / 4, 4.0))
@@ -342,6 +446,7 @@ def run_cpu_baseline(args, seg_off, events, gpu_states, L):
         "sample": f"first {sample_aggs} aggregates of the same log ({n_ev} events), "
                   f"C restatement of the fold, aggregates split over {cores} host threads",
         "single_thread_value": one_core,
+        "thread_scaling_efficiency": all_cores / (one_core * cores) if one_core > 0 else None,
         "gpu_matches_cpu_on_sample": parity,
         "pcie_inclusive_gpu": pcie,
     }

@@ -53,6 +53,8 @@ extern "C" {
 #define SURGE_E_NOMEM       (-4) /* host or device allocation failed                            */
 #define SURGE_E_UNSUPPORTED (-5) /* schema / algorithm not supported by this build              */
 #define SURGE_E_RANGE       (-6) /* aggregate index out of range                                */
+/* (-7 is SURGE_E_CORRUPT of surge_ingest.h)                                                        */
+#define SURGE_E_COMM        (-8) /* RCCL not loadable / a collective call failed                    */
 
 /* ---- fixed-width layouts (little-endian) ----------------------------------
  *
@@ -328,6 +330,39 @@ int32_t surge_replay_partition_hash_up_to_colon_device(surge_replay_handle* h, c
 int32_t surge_replay_pack_states(surge_replay_handle* h, const void* d_states64, int64_t n, void* d_packed40, void* hip_stream);
 int32_t surge_replay_unpack_states(surge_replay_handle* h, const void* d_packed40, int64_t n, void* d_states64, void* hip_stream);
 
+/* ---- multi-GPU exchange (SURVEY §8b surge_replay_allgather, §8e) ---------------------------------------
+ * The path shards by the reference's own shard map (partition = partitionForKey(aggregateId), gpu = partition %
+ * n_gpus; KafkaPartitioner.scala:8,38-42; ownership PartitionAssignments.scala:51-63) and folds with NO
+ * communication.  Its one exchange step is the all-gather(v) of the final snapshot: one process per GPU, one
+ * communicator rank per handle, RCCL over xGMI.  librccl is dlopen'ed on first use (SURGE_RCCL_LIBRARY overrides
+ * the search; a copy already loaded in the process — e.g. PyTorch's — is reused); everything else works without it.
+ *
+ *   rank 0:  surge_replay_comm_unique_id(id)  -> hand the 128 bytes to every rank over any channel the host has
+ *   all:     surge_replay_comm_init(h, rank, world, id)                       (collective, blocking)
+ *   all:     surge_replay_comm_counts(h, n_local, counts[world], &max_count)  (collective; cached per n_local)
+ *   all:     surge_replay_allgather_snapshot(h, d_states, n_local, d_out, rows_per_rank, slot, mode)
+ *              d_out[r * rows_per_rank + i] = state i of rank r (64 B); rows i >= counts[r] are None (zero).
+ *              d_states NULL = the handle's resident state.  Asynchronous: runs on the handle's side stream after
+ *              everything enqueued so far on its fold stream, so the next fold overlaps it; two slots alternate.
+ *   all:     surge_replay_comm_wait(h, slot, host_sync)   make the fold stream (or the host) wait for that slot
+ *
+ * Transport (mode): SURGE_GATHER_P2P — one ncclSend/ncclRecv pair per peer inside one group: xGMI is a point-to-point
+ * full mesh, so every link carries exactly one peer's shard, all links at once; SURGE_GATHER_ALLGATHER — the library's
+ * ncclAllGather over max-padded shards.  Shards travel in the 40-byte wire form (see surge_replay_pack_states). */
+#define SURGE_COMM_ID_BYTES    128
+#define SURGE_GATHER_P2P       0
+#define SURGE_GATHER_ALLGATHER 1
+int32_t surge_replay_comm_unique_id(uint8_t id_out[SURGE_COMM_ID_BYTES]);
+int32_t surge_replay_comm_init(surge_replay_handle* h, int32_t rank, int32_t world, const uint8_t id[SURGE_COMM_ID_BYTES]);
+int32_t surge_replay_comm_destroy(surge_replay_handle* h);
+/* library = path the RCCL symbols came from (owned by the library); version = ncclGetVersion */
+int32_t surge_replay_comm_info(surge_replay_handle* h, int32_t* rank, int32_t* world, int32_t* rccl_version,
+                               const char** library);
+int32_t surge_replay_comm_counts(surge_replay_handle* h, int64_t n_local, int64_t* counts_out, int64_t* max_count_out);
+int32_t surge_replay_allgather_snapshot(surge_replay_handle* h, const void* d_states, int64_t n_local, void* d_out,
+                                        int64_t rows_per_rank, int32_t slot, int32_t mode);
+int32_t surge_replay_comm_wait(surge_replay_handle* h, int32_t slot, int32_t host_sync);
+
 /* Redirect the fold's output to another device buffer (n_agg x 64 B, 16-byte aligned) without
  * re-analysing the bound log; lets a host double-buffer snapshots under an overlapped all-gather. */
 int32_t surge_replay_set_state_out(surge_replay_handle* h, void* d_state_out);
@@ -335,6 +370,9 @@ int32_t surge_replay_set_state_out(surge_replay_handle* h, void* d_state_out);
 /* ---- measurement --------------------------------------------------------------- */
 int32_t surge_replay_stats(surge_replay_handle* h, surge_replay_stats_t* out);
 int32_t surge_replay_stats_reset(surge_replay_handle* h);
+/* ms_out[i] = HIP-event time of the dominant kernel of the i-th fold since stats_reset (at most 256 are kept; the
+ * events sit on the handle's stream right around the launch).  *n_out = how many were written (<= cap). */
+int32_t surge_replay_fold_times(surge_replay_handle* h, double* ms_out, int64_t cap, int64_t* n_out);
 
 /* HBM read-stream ceiling probe: reads n_bytes (multiple of 16) from d_src with
  * 16 B/lane loads and returns the HIP-event time of one launch.  Used by

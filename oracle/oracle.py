@@ -50,6 +50,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_fold_csr.restype = i32
         L.oracle_fold_csr_mt.argtypes = [ctypes.POINTER(CSchema), vp, i64, vp, vp, vp, i32]
         L.oracle_fold_csr_mt.restype = i32
+        L.oracle_fold_csr_mt_reps.argtypes = [ctypes.POINTER(CSchema), vp, i64, vp, vp, vp, i32, i32]
+        L.oracle_fold_csr_mt_reps.restype = i32
         L.oracle_handle_event.argtypes = [ctypes.POINTER(CSchema), vp, vp, vp]
         L.oracle_handle_event.restype = i32
         L.oracle_murmur3_string_hash.argtypes = [vp, i64]
@@ -97,6 +99,19 @@ def fold_csr(
         )
     if rc != 0:
         raise RuntimeError(f"oracle_fold_csr failed: {rc}")
+    return out
+
+
+def fold_csr_repeated(seg_off, events, threads: int, reps: int, algebra: EventAlgebra = DEFAULT_ALGEBRA) -> np.ndarray:
+    """``reps`` folds per host thread over its share of the aggregates (timing helper: no thread start per pass)."""
+    seg_off = np.ascontiguousarray(seg_off, dtype=np.int64)
+    events = np.ascontiguousarray(events, dtype=EVENT_DTYPE)
+    n_agg = seg_off.shape[0] - 1
+    out = np.zeros(n_agg, dtype=STATE_DTYPE)
+    sc = algebra.to_c()
+    rc = lib().oracle_fold_csr_mt_reps(ctypes.byref(sc), _ptr(seg_off), n_agg, _ptr(events), None, _ptr(out), threads, reps)
+    if rc != 0:
+        raise RuntimeError(f"oracle_fold_csr_mt_reps failed: {rc}")
     return out
 
 

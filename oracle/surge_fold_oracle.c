@@ -189,17 +189,31 @@ typedef struct {
   const surge_event16* events;
   const surge_state64* init;
   surge_state64* out;
+  int32_t reps;
 } fold_job;
 
 static void* fold_thread(void* p) {
   fold_job* j = (fold_job*)p;
-  fold_range(j->sc, j->seg_off, j->a0, j->a1, j->events, j->init, j->out);
+  int32_t r;
+  for (r = 0; r < j->reps; ++r) fold_range(j->sc, j->seg_off, j->a0, j->a1, j->events, j->init, j->out);
   return NULL;
 }
+
+/* `reps` full folds per thread over its range (same result every time): lets a benchmark time sustained all-core
+ * folding without paying a pthread_create per pass (bench.py's cpu_baseline). */
+int32_t oracle_fold_csr_mt_reps(const surge_replay_schema* sc, const int64_t* seg_off, int64_t n_agg,
+                                const void* events, const void* init_state, void* out_states,
+                                int32_t n_threads, int32_t reps);
 
 int32_t oracle_fold_csr_mt(const surge_replay_schema* sc, const int64_t* seg_off, int64_t n_agg,
                            const void* events, const void* init_state, void* out_states,
                            int32_t n_threads) {
+  return oracle_fold_csr_mt_reps(sc, seg_off, n_agg, events, init_state, out_states, n_threads, 1);
+}
+
+int32_t oracle_fold_csr_mt_reps(const surge_replay_schema* sc, const int64_t* seg_off, int64_t n_agg,
+                                const void* events, const void* init_state, void* out_states,
+                                int32_t n_threads, int32_t reps) {
   enum { MAXT = 256 };
   pthread_t th[MAXT];
   fold_job jobs[MAXT];
@@ -227,6 +241,7 @@ int32_t oracle_fold_csr_mt(const surge_replay_schema* sc, const int64_t* seg_off
     jobs[t].events = (const surge_event16*)events;
     jobs[t].init = (const surge_state64*)init_state;
     jobs[t].out = (surge_state64*)out_states;
+    jobs[t].reps = reps < 1 ? 1 : reps;
     a = a_end;
   }
   for (t = 0; t < n_threads; ++t) {

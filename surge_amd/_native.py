@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
-SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "engine.hip", "ingest.cpp")
+SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "engine.hip", "comm.hip", "ingest.cpp")
 HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
@@ -48,8 +48,16 @@ EXPORTS = (
     "surge_replay_partition_hash_up_to_colon_device",
     "surge_replay_set_state_out",
     "surge_replay_grow",
+    "surge_replay_comm_unique_id",
+    "surge_replay_comm_init",
+    "surge_replay_comm_destroy",
+    "surge_replay_comm_info",
+    "surge_replay_comm_counts",
+    "surge_replay_allgather_snapshot",
+    "surge_replay_comm_wait",
     "surge_replay_stats",
     "surge_replay_stats_reset",
+    "surge_replay_fold_times",
     "surge_replay_stream_probe",
 )
 
@@ -169,8 +177,16 @@ def load() -> ctypes.CDLL:
         "surge_replay_partition_hash_up_to_colon_device": ([vp, vp, vp, i64, i32, vp], i32),
         "surge_replay_set_state_out": ([vp, vp], i32),
         "surge_replay_grow": ([vp, i64], i32),
+        "surge_replay_comm_unique_id": ([vp], i32),
+        "surge_replay_comm_init": ([vp, i32, i32, vp], i32),
+        "surge_replay_comm_destroy": ([vp], i32),
+        "surge_replay_comm_info": ([vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_char_p)], i32),
+        "surge_replay_comm_counts": ([vp, i64, vp, ctypes.POINTER(i64)], i32),
+        "surge_replay_allgather_snapshot": ([vp, vp, i64, vp, i64, i32, i32], i32),
+        "surge_replay_comm_wait": ([vp, i32, i32], i32),
         "surge_replay_stats": ([vp, ctypes.POINTER(CStats)], i32),
         "surge_replay_stats_reset": ([vp], i32),
+        "surge_replay_fold_times": ([vp, vp, i64, ctypes.POINTER(i64)], i32),
         "surge_replay_stream_probe": ([vp, vp, i64, ctypes.POINTER(ctypes.c_double)], i32),
     }
     u8p = ctypes.POINTER(ctypes.c_uint8)

@@ -98,6 +98,8 @@ struct surge_replay_handle {
   std::vector<int64_t> h_group_agg, h_group_off;
   std::vector<uint4> h_sorted_events;
 
+  CommState* comm = nullptr;  // the snapshot exchange (comm.hip), created by surge_replay_comm_init
+
   // host mirror for point reads (S2)
   std::shared_mutex mu;  // readers share it against the published mirror; snapshot / device reads take it exclusively
   std::vector<uint8_t> mirror;
@@ -351,6 +353,8 @@ int32_t surge_replay_destroy(surge_replay_handle* h) {
   if (!h) return SURGE_OK;
   DeviceGuard g(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->comm) comm_destroy(h->comm);
+  h->comm = nullptr;
   DevBuf* bufs[] = {&h->v_side, &h->r_slot0, &h->r_c, &h->r_out, &h->v_ctr, &h->v_start, &h->v_len, &h->v_info, &h->v_seg, &h->v_total, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
                     &h->nz_map, &h->block_counts, &h->plan, &h->batch_group_agg, &h->batch_group_off,
                     &h->batch_events, &h->poison_count, &h->gather_idx, &h->gather_out, &h->scan_totals};
@@ -1000,6 +1004,23 @@ int32_t surge_replay_stats(surge_replay_handle* h, surge_replay_stats_t* out) {
   return SURGE_OK;
 }
 
+int32_t surge_replay_fold_times(surge_replay_handle* h, double* ms_out, int64_t cap, int64_t* n_out) {
+  if (!h || !n_out || cap < 0 || (!ms_out && cap > 0)) return fail(h, SURGE_E_INVALID, "bad argument");
+  *n_out = 0;
+  if (!h->timing_valid) return SURGE_OK;
+  DeviceGuard g(h->device);
+  HIPCHK(h, hipEventSynchronize(h->ev_total1));
+  size_t n = h->folds_since_reset < kMaxTimedFolds ? h->folds_since_reset : kMaxTimedFolds;
+  if ((int64_t)n > cap) n = (size_t)cap;
+  for (size_t i = 0; i < n; ++i) {
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->fold_events[i].first, h->fold_events[i].second));
+    ms_out[i] = ms;
+  }
+  *n_out = (int64_t)n;
+  return SURGE_OK;
+}
+
 int32_t surge_replay_stats_reset(surge_replay_handle* h) {
   if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
   DeviceGuard g(h->device);
@@ -1043,6 +1064,73 @@ int32_t surge_replay_grow(surge_replay_handle* h, int64_t new_n_agg) {
   h->log_valid = false;
   h->fold_epoch.fetch_add(1);
   return SURGE_OK;
+}
+
+int32_t surge_replay_comm_unique_id(uint8_t id_out[SURGE_COMM_ID_BYTES]) {
+  if (!id_out) return fail(nullptr, SURGE_E_INVALID, "id_out is NULL");
+  std::string err;
+  const int32_t rc = comm_unique_id(id_out, &err);
+  return rc == SURGE_OK ? rc : fail(nullptr, rc, err);
+}
+
+int32_t surge_replay_comm_init(surge_replay_handle* h, int32_t rank, int32_t world, const uint8_t id[SURGE_COMM_ID_BYTES]) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!id) return fail(h, SURGE_E_INVALID, "id is NULL");
+  if (h->comm) return fail(h, SURGE_E_STATE, "the handle already has a communicator (surge_replay_comm_destroy first)");
+  DeviceGuard g(h->device);
+  std::string err;
+  const int32_t rc = comm_create(h->device, rank, world, id, &h->comm, &err);
+  return rc == SURGE_OK ? rc : fail(h, rc, err);
+}
+
+int32_t surge_replay_comm_destroy(surge_replay_handle* h) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  DeviceGuard g(h->device);
+  if (h->comm) comm_destroy(h->comm);
+  h->comm = nullptr;
+  return SURGE_OK;
+}
+
+int32_t surge_replay_comm_info(surge_replay_handle* h, int32_t* rank, int32_t* world, int32_t* rccl_version, const char** library) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->comm) return fail(h, SURGE_E_STATE, "no communicator: surge_replay_comm_init first");
+  return comm_info(h->comm, rank, world, rccl_version, library);
+}
+
+int32_t surge_replay_comm_counts(surge_replay_handle* h, int64_t n_local, int64_t* counts_out, int64_t* max_count_out) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->comm) return fail(h, SURGE_E_STATE, "no communicator: surge_replay_comm_init first");
+  if (n_local < 0) return fail(h, SURGE_E_INVALID, "negative size");
+  DeviceGuard g(h->device);
+  std::string err;
+  const int32_t rc = comm_counts(h->comm, n_local, counts_out, max_count_out, &err);
+  return rc == SURGE_OK ? rc : fail(h, rc, err);
+}
+
+int32_t surge_replay_allgather_snapshot(surge_replay_handle* h, const void* d_states, int64_t n_local, void* d_out,
+                                        int64_t rows_per_rank, int32_t slot, int32_t mode) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->comm) return fail(h, SURGE_E_STATE, "no communicator: surge_replay_comm_init first");
+  if (mode != SURGE_GATHER_P2P && mode != SURGE_GATHER_ALLGATHER) return fail(h, SURGE_E_INVALID, "unknown gather mode");
+  if (!d_states) {
+    if (!h->bound) return fail(h, SURGE_E_STATE, "allgather_snapshot of the resident state before load_csr/bind_device_csr");
+    if (n_local > h->n_agg) return fail(h, SURGE_E_RANGE, "n_local exceeds the resident state");
+    d_states = h->d_state;
+  }
+  if (((uintptr_t)d_states & 7) || ((uintptr_t)d_out & 7)) return fail(h, SURGE_E_INVALID, "buffers must be 8-byte aligned");
+  DeviceGuard g(h->device);
+  std::string err;
+  const int32_t rc = comm_allgather(h->comm, h->stream, d_states, n_local, d_out, rows_per_rank, slot, mode, &err);
+  return rc == SURGE_OK ? rc : fail(h, rc, err);
+}
+
+int32_t surge_replay_comm_wait(surge_replay_handle* h, int32_t slot, int32_t host_sync) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->comm) return fail(h, SURGE_E_STATE, "no communicator: surge_replay_comm_init first");
+  DeviceGuard g(h->device);
+  std::string err;
+  const int32_t rc = comm_wait(h->comm, h->stream, slot, host_sync != 0, &err);
+  return rc == SURGE_OK ? rc : fail(h, rc, err);
 }
 
 int32_t surge_replay_set_state_out(surge_replay_handle* h, void* d_state_out) {

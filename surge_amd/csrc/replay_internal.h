@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 #include "../../include/surge_replay.h"
 
 namespace surge {
@@ -115,5 +117,17 @@ hipError_t launch_pack_states(const void* in, int64_t n, void* out, bool unpack,
 hipError_t launch_gather_states(const uint4* states, const int64_t* idx, int64_t n, uint4* out, hipStream_t stream);
 hipError_t launch_count_poisoned(const uint4* states, int64_t n, unsigned long long* d_count,
                                  hipStream_t stream);
+
+
+// ---- comm.hip: the snapshot exchange over RCCL (dlopen'ed) ----------------------------------------------------
+struct CommState;
+int32_t comm_unique_id(uint8_t* id_out, std::string* err);
+int32_t comm_create(int device, int rank, int world, const uint8_t* id, CommState** out, std::string* err);
+void comm_destroy(CommState* c);
+int32_t comm_info(const CommState* c, int32_t* rank, int32_t* world, int32_t* version, const char** library);
+int32_t comm_counts(CommState* c, int64_t n_local, int64_t* counts_out, int64_t* max_count_out, std::string* err);
+int32_t comm_allgather(CommState* c, hipStream_t compute, const void* d_states, int64_t n_local, void* d_out,
+                       int64_t out_rows_per_rank, int slot, int mode, std::string* err);
+int32_t comm_wait(CommState* c, hipStream_t compute, int slot, bool host, std::string* err);
 
 }  // namespace surge

@@ -99,6 +99,56 @@ def local_aggregate_ids(n_global: int, n_partitions: int, rank: int, world_size:
     return ids[shard_of_partition(part, world_size) == rank]
 
 
+class NativeSnapshotGather:
+    """The exchange through the C ABI (``surge_replay_comm_*`` / ``surge_replay_allgather_snapshot``): RCCL inside
+    ``libsurge_replay.so``, no ``torch.distributed`` on the data path.  ``torch.distributed`` (any backend) is only the
+    out-of-band channel that hands rank 0's 128-byte communicator id to the other ranks — a JVM host would use
+    whatever channel it has (the Kafka Streams group metadata, a config topic, ...).
+
+    Same surface as :class:`SnapshotGather`: two output slots alternate so a gather can still be in flight on the
+    library's side stream while the next fold writes the other snapshot buffer."""
+
+    def __init__(self, n_local: int, device, engine, group=None, mode: Optional[str] = None):
+        import os
+
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.engine = torch, engine
+        self.device = torch.device(device)
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.mode = mode or os.environ.get("SURGE_SNAPSHOT_GATHER", "p2p")
+        self.packed = True  # the library always ships the 40-byte wire form
+        uid = [engine.comm_unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0, group=group)
+        engine.comm_init(self.rank, self.world, uid[0])
+        counts, self.max_count = engine.comm_counts(n_local)
+        self.counts = [int(c) for c in counts]
+        self.n_local = n_local
+        self.out = [torch.zeros((self.world, self.max_count, 64), dtype=torch.uint8, device=self.device) for _ in range(2)]
+
+    def make_local_buffers(self):
+        return [self.torch.zeros((self.max_count, 64), dtype=self.torch.uint8, device=self.device) for _ in range(2)]
+
+    def launch(self, slot: int, local_padded, ready_event=None) -> None:
+        # the library orders the exchange after everything already enqueued on the engine's fold stream
+        self.engine.allgather_snapshot(local_padded, self.n_local, self.out[slot], self.max_count, slot,
+                                       1 if self.mode == "allgather" else 0)
+
+    def wait(self, slot: int, stream=None) -> None:
+        self.engine.comm_wait(slot)  # the engine's fold stream waits for that slot's exchange
+
+    def synchronize(self, slot: int) -> None:
+        self.engine.comm_wait(slot, host_sync=True)
+
+    def result(self, slot: int):
+        return self.out[slot]
+
+    def info(self) -> dict:
+        return self.engine.comm_info()
+
+
 class SnapshotGather:
     """All-gather of the per-rank final snapshots, overlapped with the next fold.
 

@@ -27,7 +27,7 @@ from .schema import (
     EventAlgebra,
 )
 
-_STATUS = {0: "OK", -1: "INVALID", -2: "STATE", -3: "DEVICE", -4: "NOMEM", -5: "UNSUPPORTED", -6: "RANGE"}
+_STATUS = {0: "OK", -1: "INVALID", -2: "STATE", -3: "DEVICE", -4: "NOMEM", -5: "UNSUPPORTED", -6: "RANGE", -7: "CORRUPT", -8: "COMM"}
 
 
 class ReplayError(RuntimeError):
@@ -250,9 +250,60 @@ class ReplayEngine:
         if len(self._keep) > 8:
             del self._keep[4]
 
+    # -- multi-GPU exchange (RCCL behind the C ABI) ----------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128 bytes rank 0 creates and hands to every rank (``surge_replay_comm_unique_id``)."""
+        buf = (ctypes.c_uint8 * 128)()
+        lib = _native.load()
+        rc = lib.surge_replay_comm_unique_id(buf)
+        if rc != 0:
+            msg = lib.surge_replay_last_error(None)
+            raise ReplayError(rc, msg.decode() if msg else "surge_replay_comm_unique_id failed")
+        return bytes(buf)
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes) -> None:
+        if len(unique_id) != 128:
+            raise ValueError("the communicator id is 128 bytes")
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.surge_replay_comm_init(self._h, rank, world, buf))
+        self.comm_rank, self.comm_world = rank, world
+
+    def comm_destroy(self) -> None:
+        self._check(self._lib.surge_replay_comm_destroy(self._h))
+
+    def comm_info(self) -> dict:
+        r, w, v = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        lib = ctypes.c_char_p()
+        self._check(self._lib.surge_replay_comm_info(self._h, ctypes.byref(r), ctypes.byref(w), ctypes.byref(v), ctypes.byref(lib)))
+        return {"rank": r.value, "world": w.value, "rccl_version": v.value, "library": (lib.value or b"").decode()}
+
+    def comm_counts(self, n_local: int):
+        """``(counts per rank, max_count)`` for shards of ``n_local`` states on this rank (collective)."""
+        counts = np.zeros(self.comm_world, dtype=np.int64)
+        mx = ctypes.c_int64()
+        self._check(self._lib.surge_replay_comm_counts(self._h, int(n_local), _np_ptr(counts), ctypes.byref(mx)))
+        return counts, mx.value
+
+    def allgather_snapshot(self, states, n_local: int, out, rows_per_rank: int, slot: int = 0, mode: int = 0) -> None:
+        """``out[r, i] = state i of rank r`` for every rank (``surge_replay_allgather_snapshot``); asynchronous."""
+        self._check(self._lib.surge_replay_allgather_snapshot(
+            self._h, _dev_ptr(states, n_local * 64) if states is not None else None, int(n_local),
+            _dev_ptr(out, self.comm_world * rows_per_rank * 64), int(rows_per_rank), slot, mode))
+
+    def comm_wait(self, slot: int, host_sync: bool = False) -> None:
+        self._check(self._lib.surge_replay_comm_wait(self._h, slot, 1 if host_sync else 0))
+
     # -- measurement ----------------------------------------------------------------------------------
     def stats_reset(self) -> None:
         self._check(self._lib.surge_replay_stats_reset(self._h))
+
+    def fold_times_ms(self) -> np.ndarray:
+        """HIP-event time of the dominant kernel of every fold since ``stats_reset`` (at most 256 are kept)."""
+        out = np.zeros(256, dtype=np.float64)
+        n = ctypes.c_int64()
+        self._check(self._lib.surge_replay_fold_times(self._h, _np_ptr(out), 256, ctypes.byref(n)))
+        return out[: n.value]
 
     def stats(self) -> CStats:
         st = CStats()
