@@ -362,6 +362,13 @@ int32_t surge_replay_comm_counts(surge_replay_handle* h, int64_t n_local, int64_
 int32_t surge_replay_allgather_snapshot(surge_replay_handle* h, const void* d_states, int64_t n_local, void* d_out,
                                         int64_t rows_per_rank, int32_t slot, int32_t mode);
 int32_t surge_replay_comm_wait(surge_replay_handle* h, int32_t slot, int32_t host_sync);
+/* Hosts without device pointers (a JVM): pass d_out = NULL to surge_replay_allgather_snapshot and the handle keeps the
+ * gathered snapshot of that slot in a buffer it owns (rows_per_rank = the largest shard).  surge_replay_gathered_read
+ * waits for the slot's exchange and copies rows [first_row, first_row + n_rows) of rank `rank`'s block to host memory;
+ * surge_replay_gathered returns the device pointer and row pitch for hosts that can use them. */
+int32_t surge_replay_gathered(surge_replay_handle* h, int32_t slot, void** d_out, int64_t* rows_per_rank);
+int32_t surge_replay_gathered_read(surge_replay_handle* h, int32_t slot, int32_t rank, int64_t first_row, int64_t n_rows,
+                                   void* states_out);
 
 /* Redirect the fold's output to another device buffer (n_agg x 64 B, 16-byte aligned) without
  * re-analysing the bound log; lets a host double-buffer snapshots under an overlapped all-gather. */

@@ -3,14 +3,16 @@
  *
  * The build image has no JDK (no jni.h): for a JVM this file is compiled where JAVA_HOME is set (below); in
  * this repository it is compiled unchanged against the stand-in header tests/jni_mock/jni.h and driven by a
- * fake JNIEnv (tests/jni_mock/jni_harness.c, tests/test_abi.py).
+ * fake JNIEnv (tests/jni_mock/jni_harness.c, tests/test_abi.py) through every Java_… export below.
  *
  *   gcc -shared -fPIC -I"$JAVA_HOME/include" -I"$JAVA_HOME/include/linux" -I../../include \
  *       surge_replay_jni.c -L../../surge_amd -lsurge_replay -o libsurge_replay_jni.so
  *
- * Binds `surge.replay.gpu.NativeReplay` (integration/scala/NativeReplay.scala).  Handles are jlong,
- * bulk data are direct java.nio.ByteBuffers (no array copies), a negative status becomes an
- * IOException carrying surge_replay_last_error().
+ * Binds `surge.replay.gpu.NativeReplay` (integration/scala/NativeReplay.scala).  Handles are jlong, bulk data are
+ * DIRECT java.nio.ByteBuffers in native byte order (no array copies); every buffer's address AND capacity are
+ * checked against what the call will touch before the C ABI sees it — a heap buffer or a short one becomes an
+ * IllegalArgumentException, never an out-of-bounds access.  A negative status becomes an IOException carrying
+ * surge_replay_last_error().
  */
 #include <jni.h>
 #include <stddef.h>
@@ -19,28 +21,46 @@
 
 #define H(h) ((surge_replay_handle*)(intptr_t)(h))
 
-static jint check(JNIEnv* env, surge_replay_handle* h, int32_t rc) {
+static jint check(JNIEnv* env, int32_t rc) {
   if (rc != SURGE_OK) {
     jclass ex = (*env)->FindClass(env, "java/io/IOException");
     const char* msg = surge_replay_last_error(NULL); /* the calling thread's own failure (get() runs on a 32-thread pool) */
-    (void)h;
-    if (ex) (*env)->ThrowNew(env, ex, msg ? msg : "surge_replay call failed");
+    if (ex) (*env)->ThrowNew(env, ex, msg && msg[0] ? msg : "surge_replay call failed");
   }
   return rc;
 }
 
-static void* addr(JNIEnv* env, jobject buf) { return buf ? (*env)->GetDirectBufferAddress(env, buf) : NULL; }
+/* Address of a direct buffer that must hold at least `need` bytes (need < 0: unchecked).  NULL buffers are allowed
+ * only where the C ABI takes a nullable pointer (`nullable`).  On violation: IllegalArgumentException, *bad = 1. */
+static void* buf(JNIEnv* env, jobject b, int64_t need, int nullable, int* bad, const char* what) {
+  void* p;
+  if (!b) {
+    if (nullable) return NULL;
+  } else {
+    p = (*env)->GetDirectBufferAddress(env, b);
+    if (p && (need < 0 || (int64_t)(*env)->GetDirectBufferCapacity(env, b) >= need)) return p;
+  }
+  if (!*bad) {
+    jclass ex = (*env)->FindClass(env, "java/lang/IllegalArgumentException");
+    if (ex) (*env)->ThrowNew(env, ex, what);
+  }
+  *bad = 1;
+  return NULL;
+}
 
 JNIEXPORT jlong JNICALL Java_surge_replay_gpu_NativeReplay_create(JNIEnv* env, jclass c, jobject schemaBuf, jint device) {
   surge_replay_handle* h = NULL;
   surge_replay_schema sc;
+  int bad = 0;
   (void)c;
   if (schemaBuf) {
-    sc = *(const surge_replay_schema*)addr(env, schemaBuf);
+    const void* p = buf(env, schemaBuf, (int64_t)sizeof(sc), 0, &bad, "schema: direct buffer of sizeof(surge_replay_schema) bytes expected");
+    if (bad) return 0;
+    sc = *(const surge_replay_schema*)p;
   } else {
     surge_replay_default_schema(&sc);
   }
-  check(env, NULL, surge_replay_create(&sc, device, &h));
+  check(env, surge_replay_create(&sc, device, &h));
   return (jlong)(intptr_t)h;
 }
 
@@ -52,53 +72,158 @@ JNIEXPORT void JNICALL Java_surge_replay_gpu_NativeReplay_destroy(JNIEnv* env, j
 JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_loadCsr(JNIEnv* env, jclass c, jlong h, jobject segOff,
                                                                     jlong nAgg, jobject events, jlong nEvents,
                                                                     jobject initState) {
+  int bad = 0;
+  const int64_t* so = (const int64_t*)buf(env, segOff, (nAgg + 1) * 8, 0, &bad, "segOff: direct buffer of (nAgg + 1) longs expected");
+  const void* ev = buf(env, events, nEvents * 16, nEvents == 0, &bad, "events: direct buffer of nEvents x 16 bytes expected");
+  const void* in = buf(env, initState, nAgg * 64, 1, &bad, "initState: direct buffer of nAgg x 64 bytes expected");
   (void)c;
-  return check(env, H(h), surge_replay_load_csr(H(h), (const int64_t*)addr(env, segOff), nAgg, addr(env, events),
-                                                 nEvents, addr(env, initState)));
+  if (bad || nAgg < 0 || nEvents < 0) return SURGE_E_INVALID;
+  return check(env, surge_replay_load_csr(H(h), so, nAgg, ev, nEvents, in));
 }
 
 JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_fold(JNIEnv* env, jclass c, jlong h, jint algo) {
   (void)c;
-  return check(env, H(h), surge_replay_fold(H(h), algo));
+  return check(env, surge_replay_fold(H(h), algo));
 }
 
 JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_appendFold(JNIEnv* env, jclass c, jlong h, jobject groupAgg,
                                                                        jobject groupOff, jlong nGroups, jobject events,
                                                                        jlong nEvents) {
+  int bad = 0;
+  const int64_t* ga = (const int64_t*)buf(env, groupAgg, nGroups * 8, 0, &bad, "groupAgg: direct buffer of nGroups longs expected");
+  const int64_t* go = (const int64_t*)buf(env, groupOff, (nGroups + 1) * 8, 0, &bad, "groupOff: direct buffer of (nGroups + 1) longs expected");
+  const void* ev = buf(env, events, nEvents * 16, 0, &bad, "events: direct buffer of nEvents x 16 bytes expected");
   (void)c;
-  return check(env, H(h), surge_replay_append_fold(H(h), (const int64_t*)addr(env, groupAgg),
-                                                    (const int64_t*)addr(env, groupOff), nGroups, addr(env, events),
-                                                    nEvents));
+  if (bad || nGroups < 0 || nEvents < 0) return SURGE_E_INVALID;
+  return check(env, surge_replay_append_fold(H(h), ga, go, nGroups, ev, nEvents));
 }
 
-/* Publishes the host mirror that concurrent get() calls then read under a shared lock; states may be null. */
-JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_snapshot(JNIEnv* env, jclass c, jlong h, jobject states,
+/* n events in topic order, event i tagged with aggIdx[i]: grouped inside the library (surge_replay_append_events) */
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_appendEvents(JNIEnv* env, jclass c, jlong h, jobject aggIdx,
+                                                                         jobject events, jlong nEvents) {
+  int bad = 0;
+  const int64_t* ai = (const int64_t*)buf(env, aggIdx, nEvents * 8, 0, &bad, "aggIdx: direct buffer of nEvents longs expected");
+  const void* ev = buf(env, events, nEvents * 16, 0, &bad, "events: direct buffer of nEvents x 16 bytes expected");
+  (void)c;
+  if (bad || nEvents < 0) return SURGE_E_INVALID;
+  return check(env, surge_replay_append_events(H(h), ai, ev, nEvents));
+}
+
+/* New aggregates after recovery: extend the resident state (surge_replay_grow) */
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_grow(JNIEnv* env, jclass c, jlong h, jlong newNAgg) {
+  (void)c;
+  return check(env, surge_replay_grow(H(h), newNAgg));
+}
+
+/* Publishes the host mirror that concurrent get() calls then read under a shared lock; states / present may be null. */
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_snapshot(JNIEnv* env, jclass c, jlong h, jlong nAgg, jobject states,
                                                                      jobject present) {
+  int bad = 0;
+  void* st = buf(env, states, nAgg * 64, 1, &bad, "states: direct buffer of nAgg x 64 bytes expected");
+  uint8_t* pr = (uint8_t*)buf(env, present, nAgg, 1, &bad, "present: direct buffer of nAgg bytes expected");
   (void)c;
-  return check(env, H(h), surge_replay_snapshot(H(h), addr(env, states), (uint8_t*)addr(env, present)));
+  if (bad) return SURGE_E_INVALID;
+  return check(env, surge_replay_snapshot(H(h), st, pr));
 }
 
-/* Returns 1 when the aggregate is present (state64 filled), 0 for None. */
-JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_get(JNIEnv* env, jclass c, jlong h, jlong aggIdx,
-                                                                jobject state64) {
+/* 1 = Some (state64 filled), 0 = None, 2 = POISONED (replay of this aggregate hit an event whose handler throws: the
+ * caller must fail the actor's initialisation, PersistentActor.scala:328-333 — never serve the frozen state), -1 = error. */
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_get(JNIEnv* env, jclass c, jlong h, jlong aggIdx, jobject state64) {
   uint8_t present = 0;
+  int bad = 0;
+  surge_state64* st = (surge_state64*)buf(env, state64, 64, 0, &bad, "state64: direct buffer of 64 bytes expected");
   (void)c;
-  if (check(env, H(h), surge_replay_get(H(h), aggIdx, addr(env, state64), &present)) != SURGE_OK) return -1;
+  if (bad) return -1;
+  if (check(env, surge_replay_get(H(h), aggIdx, st, &present)) != SURGE_OK) return -1;
+  if (st->flags & SURGE_STATE_POISONED) return 2;
   return present;
 }
 
+/* Bulk point read: states[i] = state of aggIdx[i] (surge_replay_gather); the snapshot writer's read */
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_gather(JNIEnv* env, jclass c, jlong h, jobject aggIdx, jlong n,
+                                                                   jobject states) {
+  int bad = 0;
+  const int64_t* ai = (const int64_t*)buf(env, aggIdx, n * 8, n == 0, &bad, "aggIdx: direct buffer of n longs expected");
+  void* st = buf(env, states, n * 64, n == 0, &bad, "states: direct buffer of n x 64 bytes expected");
+  (void)c;
+  if (bad || n < 0) return SURGE_E_INVALID;
+  return check(env, surge_replay_gather(H(h), ai, n, st));
+}
+
+/* partitionForKey of whole strings (KafkaPartitioner.scala:8) */
 JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_partitionHash(JNIEnv* env, jclass c, jobject utf16,
                                                                           jobject strOff, jlong n, jint nPartitions,
                                                                           jobject partOut) {
+  int bad = 0;
+  const int64_t* so = (const int64_t*)buf(env, strOff, (n + 1) * 8, 0, &bad, "strOff: direct buffer of (n + 1) longs expected");
+  const uint16_t* u = (const uint16_t*)buf(env, utf16, bad ? -1 : so[n] * 2, 1, &bad, "utf16: direct buffer of strOff[n] chars expected");
+  int32_t* po = (int32_t*)buf(env, partOut, n * 4, 0, &bad, "partOut: direct buffer of n ints expected");
   (void)c;
-  return check(env, NULL, surge_replay_partition_hash((const uint16_t*)addr(env, utf16), (const int64_t*)addr(env, strOff),
-                                                       n, nPartitions, (int32_t*)addr(env, partOut)));
+  if (bad || n < 0) return SURGE_E_INVALID;
+  return check(env, surge_replay_partition_hash(u, so, n, nPartitions, po));
 }
 
+/* ... after PartitionStringUpToColon.partitionBy (KafkaPartitioner.scala:38-42) */
 JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_partitionHashUpToColon(JNIEnv* env, jclass c, jobject utf16,
                                                                                    jobject strOff, jlong n, jint nPartitions,
                                                                                    jobject partOut) {
+  int bad = 0;
+  const int64_t* so = (const int64_t*)buf(env, strOff, (n + 1) * 8, 0, &bad, "strOff: direct buffer of (n + 1) longs expected");
+  const uint16_t* u = (const uint16_t*)buf(env, utf16, bad ? -1 : so[n] * 2, 1, &bad, "utf16: direct buffer of strOff[n] chars expected");
+  int32_t* po = (int32_t*)buf(env, partOut, n * 4, 0, &bad, "partOut: direct buffer of n ints expected");
   (void)c;
-  return check(env, NULL, surge_replay_partition_hash_up_to_colon((const uint16_t*)addr(env, utf16), (const int64_t*)addr(env, strOff),
-                                                                   n, nPartitions, (int32_t*)addr(env, partOut)));
+  if (bad || n < 0) return SURGE_E_INVALID;
+  return check(env, surge_replay_partition_hash_up_to_colon(u, so, n, nPartitions, po));
+}
+
+/* ---- multi-GPU exchange: RCCL behind the C ABI; the host moves only the 128-byte communicator id ---- */
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_commUniqueId(JNIEnv* env, jclass c, jobject idOut) {
+  int bad = 0;
+  uint8_t* id = (uint8_t*)buf(env, idOut, SURGE_COMM_ID_BYTES, 0, &bad, "idOut: direct buffer of 128 bytes expected");
+  (void)c;
+  if (bad) return SURGE_E_INVALID;
+  return check(env, surge_replay_comm_unique_id(id));
+}
+
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_commInit(JNIEnv* env, jclass c, jlong h, jint rank, jint world,
+                                                                     jobject id) {
+  int bad = 0;
+  const uint8_t* p = (const uint8_t*)buf(env, id, SURGE_COMM_ID_BYTES, 0, &bad, "id: direct buffer of 128 bytes expected");
+  (void)c;
+  if (bad) return SURGE_E_INVALID;
+  return check(env, surge_replay_comm_init(H(h), rank, world, p));
+}
+
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_commDestroy(JNIEnv* env, jclass c, jlong h) {
+  (void)c;
+  return check(env, surge_replay_comm_destroy(H(h)));
+}
+
+/* counts[r] = states rank r contributes; returns the largest (rows per rank of the gathered snapshot), -1 on error */
+JNIEXPORT jlong JNICALL Java_surge_replay_gpu_NativeReplay_commCounts(JNIEnv* env, jclass c, jlong h, jlong nLocal, jint world,
+                                                                        jobject countsOut) {
+  int bad = 0;
+  int64_t mx = 0;
+  int64_t* co = (int64_t*)buf(env, countsOut, (int64_t)world * 8, 1, &bad, "countsOut: direct buffer of `world` longs expected");
+  (void)c;
+  if (bad) return -1;
+  if (check(env, surge_replay_comm_counts(H(h), nLocal, co, &mx)) != SURGE_OK) return -1;
+  return (jlong)mx;
+}
+
+/* all-gather of the handle's resident state into a buffer the handle owns (a JVM has no device pointers) */
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_allgatherSnapshot(JNIEnv* env, jclass c, jlong h, jlong nLocal,
+                                                                              jint slot, jint mode) {
+  (void)c;
+  return check(env, surge_replay_allgather_snapshot(H(h), NULL, nLocal, NULL, 0, slot, mode));
+}
+
+/* rows [firstRow, firstRow + nRows) of rank `rank`'s block of the gathered snapshot (waits for that slot's exchange) */
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_gatheredRead(JNIEnv* env, jclass c, jlong h, jint slot, jint rank,
+                                                                         jlong firstRow, jlong nRows, jobject states) {
+  int bad = 0;
+  void* st = buf(env, states, nRows * 64, nRows == 0, &bad, "states: direct buffer of nRows x 64 bytes expected");
+  (void)c;
+  if (bad || nRows < 0) return SURGE_E_INVALID;
+  return check(env, surge_replay_gathered_read(H(h), slot, rank, firstRow, nRows, st));
 }

@@ -1,58 +1,182 @@
-// SOURCE-ONLY sketch (no JVM/sbt in the build image): how the engine plugs into an unmodified Surge
-// node through the reference's own seams.  Python mirror with the same behaviour, exercised by the
-// tests: surge_amd/store.py (GpuReplayStateStore, GpuReplayKeyValueStore, GpuReplayPersistencePlugin).
+// How the engine plugs into an unmodified Surge node through the reference's own seams (SURVEY §8b S1 / S2).
+// Source-only in this repository (no JDK / scalac / Kafka jars in the build image); complete against
+// kafka-streams 3.2.3 (Dependencies.scala:42) — every abstract member of KeyValueStore[Bytes, Array[Byte]] and
+// KeyValueBytesStoreSupplier is implemented, the same set the reference's own test store implements
+// (modules/common/src/test/scala/surge/kafka/streams/SingleExceptionThrowingKeyValueStore.scala).
+// Behavioural twin, exercised by the test-suite on the GPU: surge_amd/store.py.
 package surge.replay.gpu
 
 import java.nio.{ ByteBuffer, ByteOrder }
+import java.util
+import java.util.concurrent.{ ConcurrentHashMap, ConcurrentSkipListMap }
+
 import org.apache.kafka.common.utils.Bytes
-import org.apache.kafka.streams.state.{ KeyValueBytesStoreSupplier, KeyValueStore }
+import org.apache.kafka.streams.KeyValue
+import org.apache.kafka.streams.processor.{ ProcessorContext, StateStore }
+import org.apache.kafka.streams.state.{ KeyValueBytesStoreSupplier, KeyValueIterator, KeyValueStore }
 import surge.kafka.streams.SurgeKafkaStreamsPersistencePlugin
+
+import scala.jdk.CollectionConverters._
 
 /** What a replayable model declares beside its handleEvent (additive to AggregateCommandModel,
  *  CommandModels.scala:12-31): the event algebra and the fixed-width codecs. */
 trait ReplayableModel[Agg, Evt] {
-  def schema: ByteBuffer                                   // surge_replay_schema, little-endian
-  def encodeEvent(evt: Evt, out: ByteBuffer): Unit         // 16 bytes: type, seq, payload
-  def stateFromFixed(aggregateId: String, state64: ByteBuffer): Agg
+  /** surge_replay_schema (include/surge_replay.h), little-endian, direct buffer */
+  def schema: ByteBuffer
+  /** 16 bytes at out.position(): type, sequenceNumber, payload */
+  def encodeEvent(evt: Evt, out: ByteBuffer): Unit
+  def aggregateIdOf(evt: Evt): String
+  /** bytes == aggregateWriteFormatting.writeState(state).value for the state held in the 64-byte record */
+  def writeStateFromFixed(aggregateId: String, state64: ByteBuffer): Array[Byte]
 }
 
 /** Seam S1 — SurgeKafkaStreamsPersistencePlugin (SurgeKafkaStreamsPersistencePlugin.scala:12-15).
  *  Selected with:   surge.kafka-streams.state-store-plugin = "gpu-replay"
  *                   gpu-replay.plugin-class = "surge.replay.gpu.GpuReplayPersistencePlugin"
- *  (loader contract: SurgeKafkaStreamsPersistencePlugin.scala:30-50; needs a public no-arg constructor.)
- *  enableLogging = false: the store is rebuilt from the events topic and needs no changelog. */
+ *  (loader contract: SurgeKafkaStreamsPersistencePlugin.scala:30-50 — public no-arg constructor; ANY failure in it makes
+ *  the loader fall back to RocksDB with only a log line, :34-47, so the constructor does nothing that can fail and
+ *  createSupplier is where a missing native library / missing recovery surfaces, loudly.)
+ *  enableLogging = false: the store is rebuilt from the events topic and needs no changelog; the reference then builds
+ *  the topology un-optimised (SurgeStateStoreConsumer.scala:63-75). */
 class GpuReplayPersistencePlugin extends SurgeKafkaStreamsPersistencePlugin {
   override def enableLogging: Boolean = false
-  override def createSupplier(storeName: String): KeyValueBytesStoreSupplier =
+  override def createSupplier(storeName: String): KeyValueBytesStoreSupplier = {
+    NativeReplay.ensureLoaded() // throws GpuReplayUnavailableException: no silent RocksDB fallback (SURVEY appendix B)
     new GpuReplayStoreSupplier(storeName, GpuReplayRegistry.recoveredFor(storeName))
-}
-
-/** KeyValueStore[Bytes, Array[Byte]] whose reads fall through to the GPU-recovered snapshot and whose
- *  puts (later state-topic records) overlay it: last write wins, null = tombstone
- *  (SurgeStateStoreConsumer.scala:69).  get() is what serves seam S2,
- *  AggregateStateStoreKafkaStreams.getAggregateBytes (AggregateStateStoreKafkaStreams.scala:83-85). */
-final class GpuReplayKeyValueStore(name: String, recovered: RecoveredSnapshot) /* extends KeyValueStore[Bytes, Array[Byte]] */ {
-  private val overlay = new java.util.concurrent.ConcurrentHashMap[String, Option[Array[Byte]]]()
-  def put(key: Bytes, value: Array[Byte]): Unit = overlay.put(key.toString, Option(value))
-  def get(key: Bytes): Array[Byte] = {
-    val k = key.toString
-    Option(overlay.get(k)) match {
-      case Some(v) => v.orNull
-      case None    => recovered.getAggregateBytes(k).orNull // surge_replay_get + the plugin's writeState
-    }
   }
 }
 
-/** Recovery driver: pack the events topic into CSR (order by offset, group by aggregate id), fold on
- *  the GPU, publish the host mirror.  One instance per assigned state-topic partition / GPU. */
-final class RecoveredSnapshot(handle: Long, keyIndex: java.util.Map[String, java.lang.Long], writeState: (String, ByteBuffer) => Array[Byte]) {
+final class GpuReplayStoreSupplier(val name: String, recovered: RecoveredSnapshot) extends KeyValueBytesStoreSupplier {
+  override def get(): KeyValueStore[Bytes, Array[Byte]] = new GpuReplayKeyValueStore(name, recovered)
+  override def metricsScope(): String = "gpu-replay"
+}
+
+/** storeName ("<aggregateName>AggregateStateStore", SurgeStateStoreConsumer.scala:110) -> the recovery that backs it.
+ *  The application registers a recovery before it starts the Surge engine; a store created without one is a
+ *  configuration error and fails the stream thread (never an empty store that looks like "no aggregates"). */
+object GpuReplayRegistry {
+  private val recoveries = new ConcurrentHashMap[String, RecoveredSnapshot]()
+  def register(storeName: String, recovered: RecoveredSnapshot): Unit = recoveries.put(storeName, recovered)
+  def unregister(storeName: String): Unit = Option(recoveries.remove(storeName)).foreach(_.close())
+  def recoveredFor(storeName: String): RecoveredSnapshot =
+    Option(recoveries.get(storeName)).getOrElse(throw new IllegalStateException(
+      s"no GPU recovery registered for state store [$storeName]: call GpuReplayRegistry.register before starting the engine"))
+}
+
+/** KeyValueStore[Bytes, Array[Byte]] whose reads fall through to the GPU-recovered snapshot and whose puts (the
+ *  state-topic records the KTable topology keeps indexing after recovery) overlay it: last write wins, null =
+ *  tombstone (SurgeStateStoreConsumer.scala:69).  get() is what serves seam S2,
+ *  AggregateStateStoreKafkaStreams.getAggregateBytes (AggregateStateStoreKafkaStreams.scala:83-85), on the 32-thread
+ *  IO pool (ThreadPools.scala:10-11): the overlay is concurrent, the native get is lock-free against the mirror. */
+final class GpuReplayKeyValueStore(val name: String, recovered: RecoveredSnapshot) extends KeyValueStore[Bytes, Array[Byte]] {
+  private val Tombstone = new Array[Byte](0)
+  private val overlay = new ConcurrentSkipListMap[Bytes, Array[Byte]]() // Bytes orders lexicographically, like RocksDB
+  @volatile private var open = false
+
+  private def key(k: Bytes): String = new String(k.get(), java.nio.charset.StandardCharsets.UTF_8)
+
+  override def get(k: Bytes): Array[Byte] = {
+    val o = overlay.get(k)
+    if (o ne null) { if (o eq Tombstone) null else o }
+    else recovered.getAggregateBytes(key(k)).orNull // surge_replay_get + the plugin's writeState
+  }
+  override def put(k: Bytes, value: Array[Byte]): Unit = overlay.put(k, if (value eq null) Tombstone else value)
+  override def putIfAbsent(k: Bytes, value: Array[Byte]): Array[Byte] = {
+    val prev = get(k)
+    if (prev eq null) put(k, value)
+    prev
+  }
+  override def putAll(entries: util.List[KeyValue[Bytes, Array[Byte]]]): Unit = entries.asScala.foreach(kv => put(kv.key, kv.value))
+  override def delete(k: Bytes): Array[Byte] = {
+    val prev = get(k)
+    put(k, null)
+    prev
+  }
+
+  /** key-ordered view of overlay ∪ recovered ids, tombstones removed (KafkaStreamsKeyValueStoreSpec.scala:37-91) */
+  private def view(from: Option[Bytes], to: Option[Bytes]): KeyValueIterator[Bytes, Array[Byte]] = {
+    val keys = new util.TreeSet[Bytes](overlay.keySet())
+    recovered.aggregateIds.foreach(id => keys.add(Bytes.wrap(id.getBytes(java.nio.charset.StandardCharsets.UTF_8))))
+    val in = keys.asScala.iterator
+      .filter(k => from.forall(k.compareTo(_) >= 0) && to.forall(k.compareTo(_) <= 0)) // range is inclusive on both ends
+      .flatMap(k => Option(get(k)).map(v => new KeyValue[Bytes, Array[Byte]](k, v)))
+      .buffered
+    new KeyValueIterator[Bytes, Array[Byte]] {
+      override def close(): Unit = ()
+      override def peekNextKey(): Bytes = in.head.key
+      override def hasNext: Boolean = in.hasNext
+      override def next(): KeyValue[Bytes, Array[Byte]] = in.next()
+    }
+  }
+  override def range(from: Bytes, to: Bytes): KeyValueIterator[Bytes, Array[Byte]] = view(Option(from), Option(to))
+  override def all(): KeyValueIterator[Bytes, Array[Byte]] = view(None, None)
+  override def approximateNumEntries(): Long = recovered.aggregateIds.size.toLong + overlay.size()
+
+  override def init(context: ProcessorContext, root: StateStore): Unit = {
+    // logging is disabled for this store, so the restore callback is never fed a changelog; it exists because
+    // register() is how Kafka Streams learns the store is initialised
+    context.register(root, (k: Array[Byte], v: Array[Byte]) => put(Bytes.wrap(k), v))
+    open = true
+  }
+  override def flush(): Unit = ()
+  override def close(): Unit = open = false
+  override def persistent(): Boolean = false // nothing on local disk: recovered from the events topic every time
+  override def isOpen: Boolean = open
+}
+
+/** One recovered shard: the native handle (one GPU / one assigned state-topic partition set), the key table
+ *  (aggregate id -> dense index; ids never cross the C ABI) and the model's fixed-width -> bytes codec. */
+final class RecoveredSnapshot(handle: Long, keyIndex: util.Map[String, java.lang.Long], model: ReplayableModel[_, _]) extends AutoCloseable {
+  private val scratch = ThreadLocal.withInitial[ByteBuffer](() => ByteBuffer.allocateDirect(64).order(ByteOrder.LITTLE_ENDIAN))
+
+  def aggregateIds: Iterable[String] = keyIndex.keySet().asScala
+
+  /** Some(bytes) / None exactly like getAggregateBytes; a failed read or a POISONED aggregate throws, which fails the
+   *  Future and sends KTableInitializationSupport.fetchState into its retry loop (:63-81), ending — after
+   *  max-initialization-attempts — in ACKError(AggregateInitializationException) (PersistentActor.scala:328-333). */
   def getAggregateBytes(aggregateId: String): Option[Array[Byte]] =
     Option(keyIndex.get(aggregateId)).flatMap { idx =>
-      val st = ByteBuffer.allocateDirect(64).order(ByteOrder.LITTLE_ENDIAN)
+      val st = scratch.get()
+      st.clear()
       NativeReplay.get(handle, idx, st) match {
-        case 1 => Some(writeState(aggregateId, st)) // bytes == aggregateWriteFormatting.writeState(state).value
-        case 0 => None                               // KTable miss / tombstone
-        case _ => throw new java.io.IOException("surge_replay_get failed") // => failed Future => fetchState retry
+        case 1 => Some(model.writeStateFromFixed(aggregateId, st))
+        case 0 => None // KTable miss / tombstone
+        case 2 => throw new GpuReplayPoisonedAggregateException(aggregateId)
+        case _ => throw new java.io.IOException(s"surge_replay_get failed for $aggregateId")
       }
     }
+
+  override def close(): Unit = NativeReplay.destroy(handle)
+}
+
+final class GpuReplayPoisonedAggregateException(aggregateId: String)
+    extends RuntimeException(s"replay of aggregate [$aggregateId] hit an event whose handler throws; its state is frozen before that event and is not served")
+
+/** Recovery driver: pack the events topic of the partitions this node owns into CSR (order by offset, group by
+ *  aggregate id = record key up to ':', PartitionStringUpToColon), fold on the GPU, publish the host mirror. */
+object GpuReplayRecovery {
+  /** records: (key, value-as-16-byte-fixed-event) in offset order, already filtered to read_committed
+   *  (SurgeStateStoreConsumer.scala:38); the native ingest (include/surge_ingest.h) produces exactly this shape. */
+  def recover[Agg, Evt](model: ReplayableModel[Agg, Evt], device: Int, records: Iterator[(String, Array[Byte])]): RecoveredSnapshot = {
+    NativeReplay.ensureLoaded()
+    val keyIndex = new util.HashMap[String, java.lang.Long]()
+    val perAgg = new util.ArrayList[util.ArrayList[Array[Byte]]]()
+    records.foreach { case (key, ev) =>
+      val id = key.takeWhile(_ != ':')
+      val idx = keyIndex.computeIfAbsent(id, _ => { perAgg.add(new util.ArrayList[Array[Byte]]()); java.lang.Long.valueOf(perAgg.size() - 1L) })
+      perAgg.get(idx.intValue()).add(ev)
+    }
+    val nAgg = perAgg.size()
+    val nEvents = perAgg.asScala.map(_.size().toLong).sum
+    val segOff = ByteBuffer.allocateDirect((nAgg + 1) * 8).order(ByteOrder.LITTLE_ENDIAN)
+    val events = ByteBuffer.allocateDirect(math.max(16L, nEvents * 16).toInt).order(ByteOrder.LITTLE_ENDIAN)
+    var off = 0L
+    segOff.putLong(0L)
+    perAgg.asScala.foreach { evs => evs.asScala.foreach(e => events.put(e, 0, 16)); off += evs.size(); segOff.putLong(off) }
+    val h = NativeReplay.create(model.schema, device) // IOException("... no CPU fallback") without a GPU
+    NativeReplay.loadCsr(h, segOff, nAgg.toLong, events, nEvents, null)
+    NativeReplay.fold(h, 0)
+    NativeReplay.snapshot(h, nAgg.toLong, null, null) // publishes the mirror that serves the 32 concurrent readers
+    new RecoveredSnapshot(h, keyIndex, model)
+  }
 }

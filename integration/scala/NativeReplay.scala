@@ -1,18 +1,40 @@
-// SOURCE-ONLY (no JVM/sbt in the build image).  JNI binding of include/surge_replay.h; the native
-// side is integration/jni/surge_replay_jni.c.
+// JNI binding of include/surge_replay.h; the native side is integration/jni/surge_replay_jni.c (every method below
+// has its Java_surge_replay_gpu_NativeReplay_<name> export there, checked by tests/test_abi.py).  Source-only in this
+// repository: the build image has no JDK / scalac; written against Scala 2.13 like the reference (build.sbt:6).
 package surge.replay.gpu
 
 import java.nio.ByteBuffer
 
+/** All buffers are DIRECT ByteBuffers in native byte order; the shim checks address and capacity of every one. */
 object NativeReplay {
-  System.loadLibrary("surge_replay_jni") // links libsurge_replay.so (the HIP engine)
+  /** Loads libsurge_replay_jni.so (which links libsurge_replay.so, the HIP engine).  Failure is loud by design:
+   *  the reference silently falls back to RocksDB when a plugin fails to load
+   *  (SurgeKafkaStreamsPersistencePlugin.scala:34-47) — this plugin must never do that. */
+  private val loaded: Boolean =
+    try { System.loadLibrary("surge_replay_jni"); true }
+    catch { case e: UnsatisfiedLinkError => throw new GpuReplayUnavailableException("libsurge_replay_jni.so / libsurge_replay.so not loadable", e) }
+
+  def ensureLoaded(): Unit = require(loaded)
 
   @native def create(schema: ByteBuffer /* null = built-in algebra */, device: Int): Long
   @native def destroy(handle: Long): Unit
   @native def loadCsr(handle: Long, segOff: ByteBuffer, nAgg: Long, events: ByteBuffer, nEvents: Long, initState: ByteBuffer): Int
   @native def fold(handle: Long, algo: Int): Int
   @native def appendFold(handle: Long, groupAgg: ByteBuffer, groupOff: ByteBuffer, nGroups: Long, events: ByteBuffer, nEvents: Long): Int
-  @native def snapshot(handle: Long, states: ByteBuffer, present: ByteBuffer): Int
+  @native def appendEvents(handle: Long, aggIdx: ByteBuffer, events: ByteBuffer, nEvents: Long): Int
+  @native def grow(handle: Long, newNAgg: Long): Int
+  @native def snapshot(handle: Long, nAgg: Long, states: ByteBuffer, present: ByteBuffer): Int
+  /** 1 = Some (state64 filled), 0 = None, 2 = POISONED (replay hit a throwing event), -1 = error (IOException pending) */
   @native def get(handle: Long, aggIdx: Long, state64: ByteBuffer): Int
+  @native def gather(handle: Long, aggIdx: ByteBuffer, n: Long, states: ByteBuffer): Int
   @native def partitionHash(utf16: ByteBuffer, strOff: ByteBuffer, n: Long, nPartitions: Int, partOut: ByteBuffer): Int
+  @native def partitionHashUpToColon(utf16: ByteBuffer, strOff: ByteBuffer, n: Long, nPartitions: Int, partOut: ByteBuffer): Int
+  @native def commUniqueId(idOut: ByteBuffer): Int
+  @native def commInit(handle: Long, rank: Int, world: Int, id: ByteBuffer): Int
+  @native def commDestroy(handle: Long): Int
+  @native def commCounts(handle: Long, nLocal: Long, world: Int, countsOut: ByteBuffer): Long
+  @native def allgatherSnapshot(handle: Long, nLocal: Long, slot: Int, mode: Int): Int
+  @native def gatheredRead(handle: Long, slot: Int, rank: Int, firstRow: Long, nRows: Long, states: ByteBuffer): Int
 }
+
+final class GpuReplayUnavailableException(msg: String, cause: Throwable) extends RuntimeException(msg, cause)

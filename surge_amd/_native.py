@@ -55,6 +55,8 @@ EXPORTS = (
     "surge_replay_comm_counts",
     "surge_replay_allgather_snapshot",
     "surge_replay_comm_wait",
+    "surge_replay_gathered",
+    "surge_replay_gathered_read",
     "surge_replay_stats",
     "surge_replay_stats_reset",
     "surge_replay_fold_times",
@@ -184,6 +186,8 @@ def load() -> ctypes.CDLL:
         "surge_replay_comm_counts": ([vp, i64, vp, ctypes.POINTER(i64)], i32),
         "surge_replay_allgather_snapshot": ([vp, vp, i64, vp, i64, i32, i32], i32),
         "surge_replay_comm_wait": ([vp, i32, i32], i32),
+        "surge_replay_gathered": ([vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)], i32),
+        "surge_replay_gathered_read": ([vp, i32, i32, i64, i64, vp], i32),
         "surge_replay_stats": ([vp, ctypes.POINTER(CStats)], i32),
         "surge_replay_stats_reset": ([vp], i32),
         "surge_replay_fold_times": ([vp, vp, i64, ctypes.POINTER(i64)], i32),

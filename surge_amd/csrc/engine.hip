@@ -99,6 +99,9 @@ struct surge_replay_handle {
   std::vector<uint4> h_sorted_events;
 
   CommState* comm = nullptr;  // the snapshot exchange (comm.hip), created by surge_replay_comm_init
+  DevBuf gathered[2];         // handle-owned output of allgather_snapshot(d_out = NULL), per slot
+  int64_t gathered_rows[2] = {0, 0};
+  int32_t comm_world = 1;
 
   // host mirror for point reads (S2)
   std::shared_mutex mu;  // readers share it against the published mirror; snapshot / device reads take it exclusively
@@ -355,7 +358,7 @@ int32_t surge_replay_destroy(surge_replay_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->comm) comm_destroy(h->comm);
   h->comm = nullptr;
-  DevBuf* bufs[] = {&h->v_side, &h->r_slot0, &h->r_c, &h->r_out, &h->v_ctr, &h->v_start, &h->v_len, &h->v_info, &h->v_seg, &h->v_total, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
+  DevBuf* bufs[] = {&h->gathered[0], &h->gathered[1], &h->v_side, &h->r_slot0, &h->r_c, &h->r_out, &h->v_ctr, &h->v_start, &h->v_len, &h->v_info, &h->v_seg, &h->v_total, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
                     &h->nz_map, &h->block_counts, &h->plan, &h->batch_group_agg, &h->batch_group_off,
                     &h->batch_events, &h->poison_count, &h->gather_idx, &h->gather_out, &h->scan_totals};
   for (DevBuf* b : bufs) b->release();
@@ -1080,6 +1083,7 @@ int32_t surge_replay_comm_init(surge_replay_handle* h, int32_t rank, int32_t wor
   DeviceGuard g(h->device);
   std::string err;
   const int32_t rc = comm_create(h->device, rank, world, id, &h->comm, &err);
+  if (rc == SURGE_OK) h->comm_world = world;
   return rc == SURGE_OK ? rc : fail(h, rc, err);
 }
 
@@ -1118,10 +1122,53 @@ int32_t surge_replay_allgather_snapshot(surge_replay_handle* h, const void* d_st
     d_states = h->d_state;
   }
   if (((uintptr_t)d_states & 7) || ((uintptr_t)d_out & 7)) return fail(h, SURGE_E_INVALID, "buffers must be 8-byte aligned");
+  if (slot < 0 || slot > 1) return fail(h, SURGE_E_INVALID, "slot must be 0 or 1");
   DeviceGuard g(h->device);
   std::string err;
+  if (!d_out) {  // the handle keeps the gathered snapshot (hosts without device pointers)
+    int64_t mx = 0;
+    const int32_t rc0 = comm_counts(h->comm, n_local, nullptr, &mx, &err);
+    if (rc0 != SURGE_OK) return fail(h, rc0, err);
+    rows_per_rank = mx;
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // a reallocation must not pull the buffer from under an earlier exchange
+    {
+      std::string e2;
+      (void)comm_wait(h->comm, h->stream, slot, true, &e2);
+    }
+    HIPCHK(h, h->gathered[slot].reserve((size_t)h->comm_world * (size_t)(mx > 0 ? mx : 1) * 64));
+    h->gathered_rows[slot] = mx;
+    d_out = h->gathered[slot].ptr;
+  }
   const int32_t rc = comm_allgather(h->comm, h->stream, d_states, n_local, d_out, rows_per_rank, slot, mode, &err);
   return rc == SURGE_OK ? rc : fail(h, rc, err);
+}
+
+int32_t surge_replay_gathered(surge_replay_handle* h, int32_t slot, void** d_out, int64_t* rows_per_rank) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (slot < 0 || slot > 1) return fail(h, SURGE_E_INVALID, "slot must be 0 or 1");
+  if (!h->gathered[slot].ptr) return fail(h, SURGE_E_STATE, "no handle-owned gathered snapshot in this slot (allgather_snapshot with d_out = NULL first)");
+  if (d_out) *d_out = h->gathered[slot].ptr;
+  if (rows_per_rank) *rows_per_rank = h->gathered_rows[slot];
+  return SURGE_OK;
+}
+
+int32_t surge_replay_gathered_read(surge_replay_handle* h, int32_t slot, int32_t rank, int64_t first_row, int64_t n_rows,
+                                   void* states_out) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->comm) return fail(h, SURGE_E_STATE, "no communicator: surge_replay_comm_init first");
+  if (slot < 0 || slot > 1) return fail(h, SURGE_E_INVALID, "slot must be 0 or 1");
+  if (!h->gathered[slot].ptr) return fail(h, SURGE_E_STATE, "no handle-owned gathered snapshot in this slot");
+  if (rank < 0 || rank >= h->comm_world || first_row < 0 || n_rows < 0 || first_row + n_rows > h->gathered_rows[slot])
+    return fail(h, SURGE_E_RANGE, "rank / rows outside the gathered snapshot");
+  if (n_rows == 0) return SURGE_OK;
+  if (!states_out) return fail(h, SURGE_E_INVALID, "states_out is NULL");
+  DeviceGuard g(h->device);
+  std::string err;
+  const int32_t rc = comm_wait(h->comm, h->stream, slot, true, &err);
+  if (rc != SURGE_OK) return fail(h, rc, err);
+  const char* src = (const char*)h->gathered[slot].ptr + ((size_t)rank * (size_t)h->gathered_rows[slot] + (size_t)first_row) * 64;
+  HIPCHK(h, hipMemcpy(states_out, src, (size_t)n_rows * 64, hipMemcpyDeviceToHost));
+  return SURGE_OK;
 }
 
 int32_t surge_replay_comm_wait(surge_replay_handle* h, int32_t slot, int32_t host_sync) {

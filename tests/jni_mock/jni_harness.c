@@ -1,9 +1,10 @@
 /*
- * jni_harness.c — TEST-ONLY: drives the JNI shim (integration/jni/surge_replay_jni.c, compiled unchanged against
- * the stand-in jni.h next to this file) the way surge.replay.gpu.NativeReplay would, with a fake JNIEnv:
- * a "direct ByteBuffer" is a struct holding an address, ThrowNew records the pending exception.
- * Known answers: PersistentActorSpec.scala:134-168, 466-493 ((3,3) + two increments = (5,5)),
- * scala MurmurHash3.stringHash("") / ("a") (tests/test_oracle_kat.py).
+ * jni_harness.c — TEST-ONLY: drives EVERY Java_… export of the JNI shim (integration/jni/surge_replay_jni.c, compiled
+ * unchanged against the stand-in jni.h next to this file) the way surge.replay.gpu.NativeReplay would, with a fake
+ * JNIEnv: a "direct ByteBuffer" is a struct holding an address and a capacity (address NULL = a heap buffer), ThrowNew
+ * records the pending exception.
+ * Known answers: PersistentActorSpec.scala:134-168, 466-493 ((3,3) + two increments = (5,5)), the throwing event of
+ * :431-464, scala MurmurHash3.stringHash("") / ("a") (tests/test_oracle_kat.py).
  * Exit code 0 = all good, 2 = no GPU (create threw IOException "... no CPU fallback").
  */
 #include <stdio.h>
@@ -16,12 +17,22 @@ void Java_surge_replay_gpu_NativeReplay_destroy(JNIEnv*, jclass, jlong);
 jint Java_surge_replay_gpu_NativeReplay_loadCsr(JNIEnv*, jclass, jlong, jobject, jlong, jobject, jlong, jobject);
 jint Java_surge_replay_gpu_NativeReplay_fold(JNIEnv*, jclass, jlong, jint);
 jint Java_surge_replay_gpu_NativeReplay_appendFold(JNIEnv*, jclass, jlong, jobject, jobject, jlong, jobject, jlong);
-jint Java_surge_replay_gpu_NativeReplay_snapshot(JNIEnv*, jclass, jlong, jobject, jobject);
+jint Java_surge_replay_gpu_NativeReplay_appendEvents(JNIEnv*, jclass, jlong, jobject, jobject, jlong);
+jint Java_surge_replay_gpu_NativeReplay_grow(JNIEnv*, jclass, jlong, jlong);
+jint Java_surge_replay_gpu_NativeReplay_snapshot(JNIEnv*, jclass, jlong, jlong, jobject, jobject);
 jint Java_surge_replay_gpu_NativeReplay_get(JNIEnv*, jclass, jlong, jlong, jobject);
+jint Java_surge_replay_gpu_NativeReplay_gather(JNIEnv*, jclass, jlong, jobject, jlong, jobject);
 jint Java_surge_replay_gpu_NativeReplay_partitionHash(JNIEnv*, jclass, jobject, jobject, jlong, jint, jobject);
 jint Java_surge_replay_gpu_NativeReplay_partitionHashUpToColon(JNIEnv*, jclass, jobject, jobject, jlong, jint, jobject);
+jint Java_surge_replay_gpu_NativeReplay_commUniqueId(JNIEnv*, jclass, jobject);
+jint Java_surge_replay_gpu_NativeReplay_commInit(JNIEnv*, jclass, jlong, jint, jint, jobject);
+jint Java_surge_replay_gpu_NativeReplay_commDestroy(JNIEnv*, jclass, jlong);
+jlong Java_surge_replay_gpu_NativeReplay_commCounts(JNIEnv*, jclass, jlong, jlong, jint, jobject);
+jint Java_surge_replay_gpu_NativeReplay_allgatherSnapshot(JNIEnv*, jclass, jlong, jlong, jint, jint);
+jint Java_surge_replay_gpu_NativeReplay_gatheredRead(JNIEnv*, jclass, jlong, jint, jint, jlong, jlong, jobject);
 
-typedef struct { void* address; } fake_direct_buffer;
+typedef struct { void* address; jlong capacity; } fake_direct_buffer;
+#define DB(ptr, bytes) { (void*)(ptr), (jlong)(bytes) }
 
 static char pending_class[64];
 static char pending_msg[512];
@@ -42,6 +53,10 @@ static void* fake_GetDirectBufferAddress(JNIEnv* env, jobject buf) {
   (void)env;
   return ((fake_direct_buffer*)buf)->address;
 }
+static jlong fake_GetDirectBufferCapacity(JNIEnv* env, jobject buf) {
+  (void)env;
+  return ((fake_direct_buffer*)buf)->address ? ((fake_direct_buffer*)buf)->capacity : -1;
+}
 
 static int fails = 0;
 static void check(int ok, const char* what) {
@@ -50,7 +65,7 @@ static void check(int ok, const char* what) {
 }
 
 int main(void) {
-  const struct JNINativeInterface_ table = {fake_FindClass, fake_ThrowNew, fake_GetDirectBufferAddress};
+  const struct JNINativeInterface_ table = {fake_FindClass, fake_ThrowNew, fake_GetDirectBufferAddress, fake_GetDirectBufferCapacity};
   JNIEnv env_obj = &table;
   JNIEnv* env = &env_obj;
 
@@ -59,13 +74,23 @@ int main(void) {
     const uint16_t utf16[] = {'a', 'a', ':', '7'};
     const int64_t off[] = {0, 0, 1, 4};
     int32_t part[3] = {-1, -1, -1};
-    fake_direct_buffer b_utf16 = {(void*)utf16}, b_off = {(void*)off}, b_part = {part};
+    fake_direct_buffer b_utf16 = DB(utf16, sizeof(utf16)), b_off = DB(off, sizeof(off)), b_part = DB(part, sizeof(part));
     jint rc = Java_surge_replay_gpu_NativeReplay_partitionHash(env, NULL, &b_utf16, &b_off, 3, 1000003, &b_part);
     check(rc == 0 && part[0] == 926349 && part[1] == 229102 && part[2] == 324673, "partitionHash = partitionForKey of the whole string (\"\", \"a\", \"a:7\")");
     rc = Java_surge_replay_gpu_NativeReplay_partitionHashUpToColon(env, NULL, &b_utf16, &b_off, 3, 1000003, &b_part);
     check(rc == 0 && part[0] == 926349 && part[1] == 229102 && part[2] == 229102, "partitionHashUpToColon: key cut at ':' (PartitionStringUpToColon)");
+    /* a short or a heap (non-direct) buffer is refused before the C ABI sees it */
+    fake_direct_buffer b_short = DB(part, 8), b_heap = DB(NULL, 0);
+    n_thrown = 0;
+    rc = Java_surge_replay_gpu_NativeReplay_partitionHash(env, NULL, &b_utf16, &b_off, 3, 1000003, &b_short);
+    check(rc == SURGE_E_INVALID && n_thrown == 1 && strcmp(pending_class, "java/lang/IllegalArgumentException") == 0,
+          "a too-small direct buffer -> IllegalArgumentException, no native access");
+    n_thrown = 0;
+    rc = Java_surge_replay_gpu_NativeReplay_partitionHash(env, NULL, &b_heap, &b_off, 3, 1000003, &b_part);
+    check(rc == SURGE_E_INVALID && n_thrown == 1, "a heap (non-direct) buffer -> IllegalArgumentException");
   }
 
+  n_thrown = 0;
   const jlong h = Java_surge_replay_gpu_NativeReplay_create(env, NULL, NULL, 0);
   if (h == 0) {
     check(n_thrown == 1 && strcmp(pending_class, "java/io/IOException") == 0, "create without a GPU throws IOException");
@@ -78,27 +103,36 @@ int main(void) {
   check(Java_surge_replay_gpu_NativeReplay_fold(env, NULL, h, 0) == SURGE_E_STATE && n_thrown == 1 &&
             strstr(pending_msg, "fold before") != NULL, "fold before loadCsr -> IOException(\"fold before ...\")");
 
-  surge_state64 init[2], out[2], one;
-  surge_event16 ev[3];
-  int64_t seg_off[3] = {0, 2, 3};
-  uint8_t present[2] = {9, 9};
+  surge_state64 init[3], out[3], one;
+  surge_event16 ev[4];
+  int64_t seg_off[4] = {0, 2, 3, 4};
+  uint8_t present[3] = {9, 9, 9};
   memset(init, 0, sizeof(init)); memset(ev, 0, sizeof(ev)); memset(out, 0, sizeof(out));
   init[0].count = 3; init[0].version = 3; init[0].min_arg = 0x7fffffff; init[0].max_arg = (int32_t)0x80000000;
   init[0].flags = SURGE_STATE_PRESENT;
   ev[0].type = SURGE_EVT_INC; ev[0].seq = 4; ev[0].p.i.arg = 1;
   ev[1].type = SURGE_EVT_INC; ev[1].seq = 5; ev[1].p.i.arg = 1;
   ev[2].type = SURGE_EVT_SET_BALANCE; ev[2].p.value = 5.0; /* update before create: stays None */
-  fake_direct_buffer b_off = {seg_off}, b_ev = {ev}, b_init = {init}, b_out = {out}, b_present = {present}, b_one = {&one};
+  ev[3].type = SURGE_EVT_THROW;                            /* ExceptionThrowingEvent: aggregate 2 is poisoned */
+  fake_direct_buffer b_off = DB(seg_off, sizeof(seg_off)), b_ev = DB(ev, sizeof(ev)), b_init = DB(init, sizeof(init)),
+                     b_out = DB(out, sizeof(out)), b_present = DB(present, sizeof(present)), b_one = DB(&one, sizeof(one));
   n_thrown = 0;
-  check(Java_surge_replay_gpu_NativeReplay_loadCsr(env, NULL, h, &b_off, 2, &b_ev, 3, &b_init) == 0 &&
+  check(Java_surge_replay_gpu_NativeReplay_loadCsr(env, NULL, h, &b_off, 3, &b_ev, 4, &b_init) == 0 &&
             Java_surge_replay_gpu_NativeReplay_fold(env, NULL, h, 0) == 0 &&
-            Java_surge_replay_gpu_NativeReplay_snapshot(env, NULL, h, &b_out, &b_present) == 0 && n_thrown == 0,
+            Java_surge_replay_gpu_NativeReplay_snapshot(env, NULL, h, 3, &b_out, &b_present) == 0 && n_thrown == 0,
         "loadCsr / fold / snapshot through direct buffers");
   check(out[0].count == 5 && out[0].version == 5 && present[0] == 1 && present[1] == 0, "(3,3) + two increments = (5,5); orphan update stays None");
   check(Java_surge_replay_gpu_NativeReplay_get(env, NULL, h, 0, &b_one) == 1 && one.count == 5 &&
             Java_surge_replay_gpu_NativeReplay_get(env, NULL, h, 1, &b_one) == 0, "get: 1 = Some(state64 filled), 0 = None");
+  check(Java_surge_replay_gpu_NativeReplay_get(env, NULL, h, 2, &b_one) == 2, "get: 2 = POISONED (replay hit a throwing event): never served as a state");
   n_thrown = 0;
   check(Java_surge_replay_gpu_NativeReplay_get(env, NULL, h, 7, &b_one) == -1 && n_thrown == 1, "get out of range -> IOException, -1");
+  {
+    fake_direct_buffer b_small = DB(&one, 32);
+    n_thrown = 0;
+    check(Java_surge_replay_gpu_NativeReplay_get(env, NULL, h, 0, &b_small) == -1 && n_thrown == 1 &&
+              strcmp(pending_class, "java/lang/IllegalArgumentException") == 0, "get into a 32-byte buffer -> IllegalArgumentException");
+  }
 
   /* micro-batch: one more increment on aggregate 0 */
   {
@@ -106,10 +140,46 @@ int main(void) {
     surge_event16 e;
     memset(&e, 0, sizeof(e));
     e.type = SURGE_EVT_INC; e.seq = 6; e.p.i.arg = 1;
-    fake_direct_buffer b_ga = {group_agg}, b_go = {group_off}, b_e = {&e};
+    fake_direct_buffer b_ga = DB(group_agg, 8), b_go = DB(group_off, 16), b_e = DB(&e, 16);
     check(Java_surge_replay_gpu_NativeReplay_appendFold(env, NULL, h, &b_ga, &b_go, 1, &b_e, 1) == 0 &&
               Java_surge_replay_gpu_NativeReplay_get(env, NULL, h, 0, &b_one) == 1 && one.count == 6 && one.version == 6,
           "appendFold onto the resident state: (6,6)");
+  }
+  /* a new aggregate appears after recovery: grow, then an ungrouped micro-batch in topic order */
+  {
+    int64_t agg_idx[3] = {3, 0, 3}, gidx[2] = {3, 0};
+    surge_event16 e[3];
+    surge_state64 two[2];
+    memset(e, 0, sizeof(e));
+    e[0].type = SURGE_EVT_INC; e[0].seq = 1; e[0].p.i.arg = 10;
+    e[1].type = SURGE_EVT_DEC; e[1].seq = 7; e[1].p.i.arg = 2;
+    e[2].type = SURGE_EVT_INC; e[2].seq = 2; e[2].p.i.arg = 5;
+    fake_direct_buffer b_ai = DB(agg_idx, sizeof(agg_idx)), b_e = DB(e, sizeof(e)), b_gi = DB(gidx, sizeof(gidx)), b_two = DB(two, sizeof(two));
+    check(Java_surge_replay_gpu_NativeReplay_grow(env, NULL, h, 4) == 0 &&
+              Java_surge_replay_gpu_NativeReplay_appendEvents(env, NULL, h, &b_ai, &b_e, 3) == 0 &&
+              Java_surge_replay_gpu_NativeReplay_gather(env, NULL, h, &b_gi, 2, &b_two) == 0 &&
+              two[0].count == 15 && two[0].version == 2 && (two[0].flags & SURGE_STATE_PRESENT) && two[1].count == 4 && two[1].version == 7,
+          "grow + appendEvents + gather: new aggregate (15,2), aggregate 0 (4,7)");
+  }
+  /* the exchange through JNI: one rank, the handle keeps the gathered snapshot */
+  {
+    uint8_t id[SURGE_COMM_ID_BYTES];
+    int64_t counts[1] = {-1};
+    surge_state64 g[4];
+    fake_direct_buffer b_id = DB(id, sizeof(id)), b_counts = DB(counts, sizeof(counts)), b_g = DB(g, sizeof(g));
+    n_thrown = 0;
+    const int ok = Java_surge_replay_gpu_NativeReplay_commUniqueId(env, NULL, &b_id) == 0 &&
+                   Java_surge_replay_gpu_NativeReplay_commInit(env, NULL, h, 0, 1, &b_id) == 0 &&
+                   Java_surge_replay_gpu_NativeReplay_commCounts(env, NULL, h, 4, 1, &b_counts) == 4 && counts[0] == 4 &&
+                   Java_surge_replay_gpu_NativeReplay_allgatherSnapshot(env, NULL, h, 4, 0, SURGE_GATHER_P2P) == 0 &&
+                   Java_surge_replay_gpu_NativeReplay_gatheredRead(env, NULL, h, 0, 0, 0, 4, &b_g) == 0;
+    check(ok && n_thrown == 0 && g[0].count == 4 && g[0].version == 7 && g[3].count == 15 && !(g[1].flags & SURGE_STATE_PRESENT) &&
+              (g[2].flags & SURGE_STATE_POISONED),
+          "commUniqueId / commInit / commCounts / allgatherSnapshot / gatheredRead: RCCL behind JNI, one rank");
+    n_thrown = 0;
+    check(Java_surge_replay_gpu_NativeReplay_gatheredRead(env, NULL, h, 0, 1, 0, 1, &b_g) == SURGE_E_RANGE && n_thrown == 1,
+          "gatheredRead of a rank outside the communicator -> IOException");
+    check(Java_surge_replay_gpu_NativeReplay_commDestroy(env, NULL, h) == 0, "commDestroy");
   }
   Java_surge_replay_gpu_NativeReplay_destroy(env, NULL, h);
   printf("%s\n", fails ? "FAILED" : "ALL PASS");

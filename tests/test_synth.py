@@ -43,3 +43,33 @@ def test_zipf_shape():
     lens = synth.zipf_lengths(np.arange(200000, dtype=np.int64), 3)
     assert lens.min() == 1 and lens.max() == 4096
     assert 430 < lens.mean() < 490  # 4096 / H_4096 ~ 460
+
+
+def test_c4_shards_are_slices_of_the_one_global_zipf_log():
+    # bench.py --gpus N: every rank generates only its shard of the 10 M-aggregate Zipf log (BASELINE C4).  The shards
+    # must partition the aggregates by the reference's shard map and carry, aggregate for aggregate, exactly the events
+    # the aggregate has in the global log (so N = 1 and N = 8 replay the same log and fold to the same states).
+    import torch
+
+    from bench import N_PARTITIONS, ZIPF_SEED, _LazyGlobalOffsets
+    from oracle import oracle
+    from surge_amd.dist import local_aggregate_ids
+
+    n_global, world = 4000, 4
+    all_ids = torch.arange(n_global, dtype=torch.int64)
+    g_lens = synth.zipf_lengths(all_ids, ZIPF_SEED, max_len=64)
+    g_so, g_ev = synth.csr_log_device(g_lens, ZIPF_SEED, agg_ids=all_ids, global_seg_off=_LazyGlobalOffsets())
+    g_states = oracle.fold_csr(g_so.numpy(), synth.to_event_records(g_ev))
+    seen = []
+    for rank in range(world):
+        ids = torch.from_numpy(local_aggregate_ids(n_global, N_PARTITIONS, rank, world, "cpu"))
+        seen.append(ids.numpy())
+        lens = synth.zipf_lengths(ids, ZIPF_SEED, max_len=64)
+        assert torch.equal(lens, g_lens[ids])
+        so, ev = synth.csr_log_device(lens, ZIPF_SEED, agg_ids=ids, global_seg_off=_LazyGlobalOffsets())
+        for k in (0, len(ids) // 2, len(ids) - 1):  # the aggregate's events are the global log's, bit for bit
+            a = int(ids[k])
+            assert torch.equal(ev[int(so[k]): int(so[k + 1])], g_ev[int(g_so[a]): int(g_so[a + 1])])
+        states = oracle.fold_csr(so.numpy(), synth.to_event_records(ev))
+        assert states.tobytes() == g_states[ids.numpy()].tobytes()
+    assert sorted(np.concatenate(seen).tolist()) == list(range(n_global))
