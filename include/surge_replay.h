@@ -302,6 +302,23 @@ int32_t surge_replay_encode_protobuf_state(surge_replay_handle* h, const surge_j
                                            const uint8_t* d_keys_utf8, const int64_t* d_key_off, uint8_t* d_out,
                                            int64_t out_capacity, int64_t* d_out_off, int64_t* total_bytes_out);
 
+/* ---- snapshot publishing (SURVEY §8f N2 x N3) ---------------------------------------------------------------
+ * What the state topic needs after a replay / a run of micro-batches, relative to the last COMMITTED snapshot of this
+ * handle: the reference publishes a state record only when the state changed (PersistentActor.scala:212 for commands,
+ * :255-257 for ApplyEvents), `null` (a tombstone) when it became None (SurgeModel.scala:62).
+ *   d_kind_out[a] = SURGE_SNAP_SKIP       unchanged since the last commit, or POISONED (nothing the JVM fold ever had)
+ *                   SURGE_SNAP_VALUE      changed and Some: publish writeState(state)
+ *                   SURGE_SNAP_TOMBSTONE  changed and None: publish a null value
+ * The first call compares against "nothing published" (all None).  commit != 0 makes the current states the new
+ * baseline for the aggregates reported.  surge_replay_set_encode_filter(h, d_kind) then restricts the encoders below
+ * to the SURGE_SNAP_VALUE aggregates (NULL removes the filter), so only what is published is encoded and copied. */
+#define SURGE_SNAP_SKIP      0
+#define SURGE_SNAP_VALUE     1
+#define SURGE_SNAP_TOMBSTONE 2
+int32_t surge_replay_snapshot_delta(surge_replay_handle* h, uint8_t* d_kind_out, int64_t* n_values_out, int64_t* n_tombstones_out,
+                                    int32_t commit);
+int32_t surge_replay_set_encode_filter(surge_replay_handle* h, const uint8_t* d_kind);
+
 /* ---- shard map (R15) --------------------------------------------------------------
  * surge_replay_partition_hash:  part_out[i] = abs(MurmurHash3.stringHash(str_i) % n_partitions)
  *   = KafkaPartitionProvider.partitionForKey(partitionByString, numberOfPartitions), KafkaPartitioner.scala:8 —

@@ -17,8 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
-SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "engine.hip", "comm.hip", "ingest.cpp")
-HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"))
+SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "engine.hip", "comm.hip", "ingest.cpp", "snapshot_writer.cpp")
+HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
 EXPORTS = (
@@ -38,6 +38,8 @@ EXPORTS = (
     "surge_replay_gather",
     "surge_replay_snapshot",
     "surge_replay_device_state",
+    "surge_replay_snapshot_delta",
+    "surge_replay_set_encode_filter",
     "surge_replay_encode_json",
     "surge_replay_encode_protobuf_state",
     "surge_replay_pack_states",
@@ -79,6 +81,17 @@ INGEST_EXPORTS = (
     "surge_crc32c",
     "surge_crc32c_portable",
     "surge_lz4_frame_decompress",
+)
+
+#: every symbol ``include/surge_snapshot.h`` declares
+SNAPSHOT_EXPORTS = (
+    "surge_snapshot_writer_create",
+    "surge_snapshot_writer_destroy",
+    "surge_snapshot_writer_last_error",
+    "surge_snapshot_writer_append",
+    "surge_snapshot_writer_flush",
+    "surge_snapshot_writer_partition",
+    "surge_snapshot_writer_reset",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -169,6 +182,8 @@ def load() -> ctypes.CDLL:
         "surge_replay_gather": ([vp, vp, i64, vp], i32),
         "surge_replay_snapshot": ([vp, vp, vp], i32),
         "surge_replay_device_state": ([vp, ctypes.POINTER(vp), ctypes.POINTER(i64)], i32),
+        "surge_replay_snapshot_delta": ([vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64), i32], i32),
+        "surge_replay_set_encode_filter": ([vp, vp], i32),
         "surge_replay_encode_json": ([vp, vp, vp, vp, vp, i64, vp, ctypes.POINTER(i64)], i32),
         "surge_replay_encode_protobuf_state": ([vp, vp, vp, vp, vp, i64, vp, ctypes.POINTER(i64)], i32),
         "surge_replay_pack_states": ([vp, vp, i64, vp, vp], i32),
@@ -210,7 +225,16 @@ def load() -> ctypes.CDLL:
         "surge_crc32c_portable": ([vp, i64], ctypes.c_uint32),
         "surge_lz4_frame_decompress": ([vp, i64, vp, i64], i64),
     })
-    for name in EXPORTS + INGEST_EXPORTS:
+    sig.update({
+        "surge_snapshot_writer_create": ([i32, i32, i64, ctypes.POINTER(vp)], i32),
+        "surge_snapshot_writer_destroy": ([vp], i32),
+        "surge_snapshot_writer_last_error": ([vp], ctypes.c_char_p),
+        "surge_snapshot_writer_append": ([vp, i64, vp, vp, vp, vp, vp, vp, i64], i32),
+        "surge_snapshot_writer_flush": ([vp], i32),
+        "surge_snapshot_writer_partition": ([vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
+        "surge_snapshot_writer_reset": ([vp], i32),
+    })
+    for name in EXPORTS + INGEST_EXPORTS + SNAPSHOT_EXPORTS:
         try:
             fn = getattr(L, name)
         except AttributeError as e:

@@ -98,6 +98,10 @@ struct surge_replay_handle {
   std::vector<int64_t> h_group_agg, h_group_off;
   std::vector<uint4> h_sorted_events;
 
+  DevBuf published;                      // the last committed snapshot (surge_replay_snapshot_delta), n_agg x 64 B
+  int64_t published_n = 0;
+  const uint8_t* encode_filter = nullptr;  // surge_replay_set_encode_filter
+
   CommState* comm = nullptr;  // the snapshot exchange (comm.hip), created by surge_replay_comm_init
   DevBuf gathered[2];         // handle-owned output of allgather_snapshot(d_out = NULL), per slot
   int64_t gathered_rows[2] = {0, 0};
@@ -358,7 +362,7 @@ int32_t surge_replay_destroy(surge_replay_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->comm) comm_destroy(h->comm);
   h->comm = nullptr;
-  DevBuf* bufs[] = {&h->gathered[0], &h->gathered[1], &h->v_side, &h->r_slot0, &h->r_c, &h->r_out, &h->v_ctr, &h->v_start, &h->v_len, &h->v_info, &h->v_seg, &h->v_total, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
+  DevBuf* bufs[] = {&h->published, &h->gathered[0], &h->gathered[1], &h->v_side, &h->r_slot0, &h->r_c, &h->r_out, &h->v_ctr, &h->v_start, &h->v_len, &h->v_info, &h->v_seg, &h->v_total, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
                     &h->nz_map, &h->block_counts, &h->plan, &h->batch_group_agg, &h->batch_group_off,
                     &h->batch_events, &h->poison_count, &h->gather_idx, &h->gather_out, &h->scan_totals};
   for (DevBuf* b : bufs) b->release();
@@ -864,7 +868,7 @@ static int32_t encode_states(surge_replay_handle* h, const surge_json_template* 
   const int64_t nb = (h->n_agg + 1023) / 1024;
   HIPCHK(h, h->scan_totals.reserve((size_t)(nb + 1) * 8));
   HIPCHK(h, launch_json_encode(*tmpl, h->d_state, h->n_agg, d_keys_utf8, d_key_off, d_out_off, (int64_t*)h->scan_totals.ptr,
-                               d_out, false, envelope, h->stream));
+                               d_out, false, envelope, h->encode_filter, h->stream));
   int64_t total = 0;
   HIPCHK(h, hipMemcpyAsync(&total, (int64_t*)h->scan_totals.ptr + nb, 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -876,7 +880,7 @@ static int32_t encode_states(surge_replay_handle* h, const surge_json_template* 
   }
   if (total > 0 && !d_out) return fail(h, SURGE_E_INVALID, "d_out is NULL");
   HIPCHK(h, launch_json_encode(*tmpl, h->d_state, h->n_agg, d_keys_utf8, d_key_off, d_out_off, (int64_t*)h->scan_totals.ptr,
-                               d_out, true, envelope, h->stream));
+                               d_out, true, envelope, h->encode_filter, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return SURGE_OK;
 }
@@ -891,6 +895,45 @@ int32_t surge_replay_encode_protobuf_state(surge_replay_handle* h, const surge_j
                                            const uint8_t* d_keys_utf8, const int64_t* d_key_off, uint8_t* d_out,
                                            int64_t out_capacity, int64_t* d_out_off, int64_t* total_bytes_out) {
   return encode_states(h, payload_tmpl, d_keys_utf8, d_key_off, d_out, out_capacity, d_out_off, total_bytes_out, 1u);
+}
+
+int32_t surge_replay_snapshot_delta(surge_replay_handle* h, uint8_t* d_kind_out, int64_t* n_values_out, int64_t* n_tombstones_out,
+                                    int32_t commit) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->bound || h->st.n_folds == 0) return fail(h, SURGE_E_STATE, "snapshot_delta before fold");
+  if (!d_kind_out && h->n_agg > 0) return fail(h, SURGE_E_INVALID, "d_kind_out is NULL");
+  DeviceGuard g(h->device);
+  if (h->published_n < h->n_agg) {  // first use, or the resident state grew: new aggregates have never been published
+    const size_t want = (size_t)h->n_agg * 64;
+    if (want > h->published.cap) {
+      void* fresh = nullptr;
+      size_t cap = h->published.cap * 2 > want ? h->published.cap * 2 : want;
+      HIPCHK(h, hipMalloc(&fresh, cap));
+      if (h->published_n > 0)
+        HIPCHK(h, hipMemcpyAsync(fresh, h->published.ptr, (size_t)h->published_n * 64, hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      if (h->published.ptr) (void)hipFree(h->published.ptr);
+      h->published.ptr = fresh;
+      h->published.cap = cap;
+    }
+    HIPCHK(h, hipMemsetAsync((char*)h->published.ptr + (size_t)h->published_n * 64, 0, (size_t)(h->n_agg - h->published_n) * 64, h->stream));
+    h->published_n = h->n_agg;
+  }
+  HIPCHK(h, h->poison_count.reserve(16));
+  HIPCHK(h, launch_snapshot_delta(h->d_state, (uint4*)h->published.ptr, h->n_agg, d_kind_out, (unsigned long long*)h->poison_count.ptr,
+                                  commit != 0, h->stream));
+  unsigned long long c[2] = {0, 0};
+  HIPCHK(h, hipMemcpyAsync(c, h->poison_count.ptr, 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (n_values_out) *n_values_out = (int64_t)c[0];
+  if (n_tombstones_out) *n_tombstones_out = (int64_t)c[1];
+  return SURGE_OK;
+}
+
+int32_t surge_replay_set_encode_filter(surge_replay_handle* h, const uint8_t* d_kind) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  h->encode_filter = d_kind;
+  return SURGE_OK;
 }
 
 int32_t surge_replay_device_state(surge_replay_handle* h, void** d_states, int64_t* n_agg) {

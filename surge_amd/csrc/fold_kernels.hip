@@ -724,6 +724,7 @@ struct JsonTemplateDev {
   uint32_t kind[SURGE_JSON_MAX_PARTS], field_offset[SURGE_JSON_MAX_PARTS], lit_off[SURGE_JSON_MAX_PARTS],
       lit_len[SURGE_JSON_MAX_PARTS];
   uint8_t literals[256];
+  const uint8_t* filter;  // nullable: per-aggregate SURGE_SNAP_* kinds; only SURGE_SNAP_VALUE aggregates are encoded
 };
 
 __device__ __forceinline__ int dec_len_u64(uint64_t v) {
@@ -823,7 +824,7 @@ __global__ void __launch_bounds__(kJsonBlock) json_encode_kernel(const JsonTempl
   const bool live = a < n;
   const uint8_t* st = (const uint8_t*)(states + (live ? a : 0) * 4);
   const uint32_t fl = *(const uint32_t*)(st + 36);
-  const bool emit = live && (fl & FL_PRESENT) && !(fl & FL_POISONED);
+  const bool emit = live && (fl & FL_PRESENT) && !(fl & FL_POISONED) && (!t.filter || t.filter[a] == SURGE_SNAP_VALUE);
   if (!WRITE) {
     if (!live) return;
     int64_t len = 0;
@@ -934,6 +935,37 @@ __global__ void gather_states_kernel(const uint4* __restrict__ states, const int
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16 B quarter of a state per thread
   if (i >= n * 4) return;
   out[i] = states[idx[i >> 2] * 4 + (i & 3)];
+}
+
+// snapshot delta: kind[a] = what the state topic needs for aggregate a relative to the last committed snapshot
+// ("publish only if the state changed", PersistentActor.scala:212,257): unchanged or poisoned -> SKIP, Some -> VALUE,
+// Some -> None -> TOMBSTONE.  counts[0] += values, counts[1] += tombstones.
+__global__ void snapshot_delta_kernel(const uint4* __restrict__ states, const uint4* __restrict__ published, int64_t n,
+                                      uint8_t* __restrict__ kind, unsigned long long* __restrict__ counts) {
+  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t k = SURGE_SNAP_SKIP;
+  if (a < n) {
+    const uint4 s0 = states[a * 4], s1 = states[a * 4 + 1], s2 = states[a * 4 + 2];
+    const uint4 p0 = published[a * 4], p1 = published[a * 4 + 1], p2 = published[a * 4 + 2];
+    const bool same = s0.x == p0.x && s0.y == p0.y && s0.z == p0.z && s0.w == p0.w && s1.x == p1.x && s1.y == p1.y && s1.z == p1.z &&
+                      s1.w == p1.w && s2.x == p2.x && s2.y == p2.y;  // bytes 0..39 carry the state (the tail is always zero)
+    const bool poisoned = (s2.y & FL_POISONED) != 0u;
+    if (!same && !poisoned) k = (s2.y & FL_PRESENT) ? SURGE_SNAP_VALUE : SURGE_SNAP_TOMBSTONE;
+    kind[a] = (uint8_t)k;
+  }
+  const int nv = __popcll(__ballot(k == SURGE_SNAP_VALUE)), nt = __popcll(__ballot(k == SURGE_SNAP_TOMBSTONE));
+  if ((threadIdx.x & 63) == 0) {
+    if (nv) atomicAdd(&counts[0], (unsigned long long)nv);
+    if (nt) atomicAdd(&counts[1], (unsigned long long)nt);
+  }
+}
+
+// published[a] := states[a] for every aggregate that was just published (kind != SKIP)
+__global__ void snapshot_commit_kernel(const uint4* __restrict__ states, uint4* __restrict__ published, int64_t n,
+                                       const uint8_t* __restrict__ kind) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16 B quarter of a state per thread
+  if (i >= n * 4) return;
+  if (kind[i >> 2] != SURGE_SNAP_SKIP) published[i] = states[i];
 }
 
 __global__ void count_poisoned_kernel(const uint4* __restrict__ states, int64_t n, unsigned long long* count) {
@@ -1068,11 +1100,12 @@ hipError_t launch_stream_probe(const uint4* src, int64_t n_vec, uint32_t* sink, 
 // d_len_off: n + 1 entries; d_totals: ceil(n / 1024) + 1 entries of scratch
 hipError_t launch_json_encode(const surge_json_template& tmpl, const uint4* states, int64_t n, const uint8_t* keys,
                               const int64_t* key_off, int64_t* d_len_off, int64_t* d_totals, uint8_t* out, bool write_pass,
-                              uint32_t envelope, hipStream_t stream) {
+                              uint32_t envelope, const uint8_t* filter, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   JsonTemplateDev t;
   t.n_parts = tmpl.n_parts;
   t.envelope = envelope;
+  t.filter = filter;
   for (uint32_t i = 0; i < SURGE_JSON_MAX_PARTS; ++i) {
     t.kind[i] = tmpl.part[i].kind; t.field_offset[i] = tmpl.part[i].field_offset;
     t.lit_off[i] = tmpl.part[i].lit_off; t.lit_len[i] = tmpl.part[i].lit_len;
@@ -1103,6 +1136,16 @@ hipError_t launch_pack_states(const void* in64, int64_t n, void* out40, bool unp
 hipError_t launch_gather_states(const uint4* states, const int64_t* idx, int64_t n, uint4* out, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(gather_states_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, stream, states, idx, n, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_snapshot_delta(const uint4* states, uint4* published, int64_t n, uint8_t* kind, unsigned long long* d_counts,
+                                 bool commit, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(d_counts, 0, 16, stream);
+  if (e != hipSuccess || n <= 0) return e;
+  hipLaunchKernelGGL(snapshot_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, states, published, n, kind, d_counts);
+  if (commit)
+    hipLaunchKernelGGL(snapshot_commit_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, stream, states, published, n, kind);
   return hipGetLastError();
 }
 

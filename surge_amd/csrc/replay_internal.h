@@ -111,7 +111,10 @@ hipError_t launch_partition_hash(const uint16_t* utf16, const int64_t* str_off, 
 hipError_t launch_stream_probe(const uint4* src, int64_t n_vec, uint32_t* sink, int variant, hipStream_t stream);
 hipError_t launch_json_encode(const surge_json_template& tmpl, const uint4* states, int64_t n, const uint8_t* keys,
                               const int64_t* key_off, int64_t* d_len_off, int64_t* d_totals, uint8_t* out, bool write_pass,
-                              uint32_t envelope, hipStream_t stream);
+                              uint32_t envelope, const uint8_t* filter, hipStream_t stream);
+// kind[a] in SURGE_SNAP_*; d_counts: two u64 {values, tombstones}; commit: published := states where kind != SKIP
+hipError_t launch_snapshot_delta(const uint4* states, uint4* published, int64_t n, uint8_t* kind, unsigned long long* d_counts,
+                                 bool commit, hipStream_t stream);
 // unpack == false: in = n x 64 B, out = n x 40 B; unpack == true: in = n x 40 B, out = n x 64 B
 hipError_t launch_pack_states(const void* in, int64_t n, void* out, bool unpack, hipStream_t stream);
 hipError_t launch_gather_states(const uint4* states, const int64_t* idx, int64_t n, uint4* out, hipStream_t stream);

@@ -1,0 +1,212 @@
+// snapshot_writer.cpp — state-topic snapshot writer, host side of libsurge_replay.so.
+// Kafka RecordBatch v2 ENCODER, restated from the published format (KIP-98), the mirror image of ingest.cpp's decoder.
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/surge_ingest.h"    // surge_crc32c
+#include "../../include/surge_replay.h"    // SURGE_SNAP_*
+#include "../../include/surge_snapshot.h"
+
+namespace {
+
+constexpr int32_t OK = 0, E_INVALID = -1, E_NOMEM = -4, E_RANGE = -6;
+constexpr size_t kHeader = 61;  // baseOffset .. recordCount
+
+thread_local std::string g_err;
+
+struct PartitionLog {
+  std::vector<uint8_t> bytes;   // closed batches
+  std::vector<uint8_t> open;    // records of the batch being filled
+  int64_t next_offset = 0;      // offset of the next record
+  int64_t base_offset = 0;      // offset of the open batch's first record
+  int64_t base_ts = 0, max_ts = 0;
+  int32_t open_records = 0;
+  int64_t n_records = 0;
+};
+
+inline void put_be(std::vector<uint8_t>& v, uint64_t x, int n) {
+  for (int i = n - 1; i >= 0; --i) v.push_back((uint8_t)(x >> (8 * i)));
+}
+
+// zig-zag varint / varlong (ByteUtils.writeVarlong)
+inline void put_varlong(std::vector<uint8_t>& v, int64_t x) {
+  uint64_t z = ((uint64_t)x << 1) ^ (uint64_t)(x >> 63);
+  while (z >= 0x80) {
+    v.push_back((uint8_t)(z | 0x80));
+    z >>= 7;
+  }
+  v.push_back((uint8_t)z);
+}
+
+inline int varlong_size(int64_t x) {
+  uint64_t z = ((uint64_t)x << 1) ^ (uint64_t)(x >> 63);
+  int n = 1;
+  while (z >= 0x80) { z >>= 7; ++n; }
+  return n;
+}
+
+}  // namespace
+
+struct surge_snapshot_writer {
+  std::vector<PartitionLog> parts;
+  int32_t max_records = 10000;
+  int64_t max_bytes = 1 << 20;
+  std::string err;
+};
+
+namespace {
+
+int32_t fail(surge_snapshot_writer* w, int32_t code, const std::string& m) {
+  if (w) w->err = m;
+  g_err = m;
+  return code;
+}
+
+void close_batch(PartitionLog& p) {
+  if (p.open_records == 0) return;
+  std::vector<uint8_t>& o = p.bytes;
+  const size_t start = o.size();
+  put_be(o, (uint64_t)p.base_offset, 8);
+  put_be(o, (uint64_t)(kHeader - 12 + p.open.size()), 4);  // batchLength: everything after this field
+  put_be(o, 0, 4);                                         // partitionLeaderEpoch
+  o.push_back(2);                                          // magic
+  const size_t crc_at = o.size();
+  put_be(o, 0, 4);                                         // crc, patched below
+  const size_t crc_from = o.size();
+  put_be(o, 0, 2);                                         // attributes: no compression, CreateTime, not transactional
+  put_be(o, (uint64_t)(p.open_records - 1), 4);            // lastOffsetDelta
+  put_be(o, (uint64_t)p.base_ts, 8);
+  put_be(o, (uint64_t)p.max_ts, 8);
+  put_be(o, (uint64_t)-1ll, 8);                            // producerId
+  put_be(o, (uint64_t)0xffff, 2);                          // producerEpoch -1
+  put_be(o, (uint64_t)0xffffffffu, 4);                     // baseSequence -1
+  put_be(o, (uint64_t)p.open_records, 4);
+  o.insert(o.end(), p.open.begin(), p.open.end());
+  const uint32_t crc = surge_crc32c(o.data() + crc_from, (int64_t)(o.size() - crc_from));  // CRC-32C over attributes .. end
+  o[crc_at] = (uint8_t)(crc >> 24); o[crc_at + 1] = (uint8_t)(crc >> 16); o[crc_at + 2] = (uint8_t)(crc >> 8); o[crc_at + 3] = (uint8_t)crc;
+  (void)start;
+  p.open.clear();
+  p.open_records = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t surge_snapshot_writer_create(int32_t n_partitions, int32_t max_records_per_batch, int64_t max_batch_bytes,
+                                     surge_snapshot_writer** out) {
+  if (!out) return fail(nullptr, E_INVALID, "out is NULL");
+  *out = nullptr;
+  if (n_partitions <= 0 || max_records_per_batch < 0 || max_batch_bytes < 0) return fail(nullptr, E_INVALID, "bad argument");
+  surge_snapshot_writer* w = new (std::nothrow) surge_snapshot_writer();
+  if (!w) return fail(nullptr, E_NOMEM, "out of host memory");
+  try {
+    w->parts.resize((size_t)n_partitions);
+  } catch (const std::bad_alloc&) {
+    delete w;
+    return fail(nullptr, E_NOMEM, "out of host memory");
+  }
+  if (max_records_per_batch > 0) w->max_records = max_records_per_batch;
+  if (max_batch_bytes > 0) w->max_bytes = max_batch_bytes;
+  *out = w;
+  return OK;
+}
+
+int32_t surge_snapshot_writer_destroy(surge_snapshot_writer* w) {
+  delete w;
+  return OK;
+}
+
+const char* surge_snapshot_writer_last_error(const surge_snapshot_writer* w) { return w ? w->err.c_str() : g_err.c_str(); }
+
+int32_t surge_snapshot_writer_append(surge_snapshot_writer* w, int64_t n, const uint8_t* kind, const int32_t* partition,
+                                     const uint8_t* keys_utf8, const int64_t* key_off, const uint8_t* values,
+                                     const int64_t* val_off, int64_t timestamp_ms) {
+  if (!w) return fail(nullptr, E_INVALID, "writer is NULL");
+  if (n < 0) return fail(w, E_INVALID, "negative size");
+  if (n == 0) return OK;
+  if (!partition || !key_off) return fail(w, E_INVALID, "NULL buffer");
+  const int32_t P = (int32_t)w->parts.size();
+  try {
+    for (int64_t i = 0; i < n; ++i) {
+      const uint8_t k = kind ? kind[i] : (uint8_t)SURGE_SNAP_VALUE;
+      if (k == SURGE_SNAP_SKIP) continue;
+      if (k != SURGE_SNAP_VALUE && k != SURGE_SNAP_TOMBSTONE) return fail(w, E_INVALID, "unknown record kind");
+      const int32_t pi = partition[i];
+      if (pi < 0 || pi >= P) return fail(w, E_RANGE, "partition out of range");
+      const int64_t klen = key_off[i + 1] - key_off[i];
+      if (klen < 0 || (klen > 0 && !keys_utf8)) return fail(w, E_INVALID, "bad key span");
+      int64_t vlen = -1;
+      if (k == SURGE_SNAP_VALUE) {
+        if (!val_off) return fail(w, E_INVALID, "values expected");
+        vlen = val_off[i + 1] - val_off[i];
+        if (vlen < 0 || (vlen > 0 && !values)) return fail(w, E_INVALID, "bad value span");
+      }
+      PartitionLog& p = w->parts[(size_t)pi];
+      if (p.open_records == 0) {
+        p.base_offset = p.next_offset;
+        p.base_ts = p.max_ts = timestamp_ms;
+      }
+      if (timestamp_ms > p.max_ts) p.max_ts = timestamp_ms;
+      const int64_t off_delta = p.next_offset - p.base_offset, ts_delta = timestamp_ms - p.base_ts;
+      // record body: attributes, timestampDelta, offsetDelta, key, value, header count
+      const int64_t body = 1 + varlong_size(ts_delta) + varlong_size(off_delta) + varlong_size(klen) + klen +
+                           varlong_size(vlen) + (vlen > 0 ? vlen : 0) + 1;
+      std::vector<uint8_t>& o = p.open;
+      put_varlong(o, body);
+      o.push_back(0);
+      put_varlong(o, ts_delta);
+      put_varlong(o, off_delta);
+      put_varlong(o, klen);
+      if (klen > 0) o.insert(o.end(), keys_utf8 + key_off[i], keys_utf8 + key_off[i + 1]);
+      put_varlong(o, vlen);
+      if (vlen > 0) o.insert(o.end(), values + val_off[i], values + val_off[i + 1]);
+      put_varlong(o, 0);
+      p.next_offset += 1;
+      p.open_records += 1;
+      p.n_records += 1;
+      if (p.open_records >= w->max_records || (int64_t)o.size() >= w->max_bytes) close_batch(p);
+    }
+  } catch (const std::bad_alloc&) {
+    return fail(w, E_NOMEM, "out of host memory while encoding");
+  }
+  return OK;
+}
+
+int32_t surge_snapshot_writer_flush(surge_snapshot_writer* w) {
+  if (!w) return fail(nullptr, E_INVALID, "writer is NULL");
+  try {
+    for (PartitionLog& p : w->parts) close_batch(p);
+  } catch (const std::bad_alloc&) {
+    return fail(w, E_NOMEM, "out of host memory while encoding");
+  }
+  return OK;
+}
+
+int32_t surge_snapshot_writer_partition(const surge_snapshot_writer* w, int32_t partition, const uint8_t** data, int64_t* len,
+                                        int64_t* n_records, int64_t* next_offset) {
+  if (!w) return fail(nullptr, E_INVALID, "writer is NULL");
+  if (partition < 0 || partition >= (int32_t)w->parts.size()) return fail(nullptr, E_RANGE, "partition out of range");
+  const PartitionLog& p = w->parts[(size_t)partition];
+  if (data) *data = p.bytes.data();
+  if (len) *len = (int64_t)p.bytes.size();
+  if (n_records) *n_records = p.n_records;
+  if (next_offset) *next_offset = p.next_offset;
+  return OK;
+}
+
+int32_t surge_snapshot_writer_reset(surge_snapshot_writer* w) {
+  if (!w) return fail(nullptr, E_INVALID, "writer is NULL");
+  for (PartitionLog& p : w->parts) {
+    p.bytes.clear();
+    p.open.clear();
+    p.open_records = 0;
+    p.n_records = 0;
+  }
+  return OK;
+}
+
+}  // extern "C"

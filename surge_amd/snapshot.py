@@ -15,11 +15,14 @@ last-record-per-key rule, which is also what the KTable applies on restore
 """
 from __future__ import annotations
 
+import ctypes
+import time
 from dataclasses import dataclass, field
-from typing import Dict, Iterable, List, Optional, Sequence
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from . import _native
 from .kafka import partition_for_keys
 from .schema import STATE_POISONED, STATE_PRESENT
 from .store import GpuReplayStateStore
@@ -65,6 +68,128 @@ class SnapshotWriter:
 
     def full_snapshot(self) -> List[StateRecord]:
         return self.records_for(list(self.store.keys.keys))
+
+
+class RecordBatchWriter:
+    """Kafka record batches (message format v2) of a state topic, one log per partition, through the C ABI of
+    ``include/surge_snapshot.h`` (host C++; the same library decodes them again in ``include/surge_ingest.h``)."""
+
+    def __init__(self, n_partitions: int, max_records_per_batch: int = 0, max_batch_bytes: int = 0):
+        self._lib = _native.load()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.surge_snapshot_writer_create(n_partitions, max_records_per_batch, max_batch_bytes, ctypes.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(f"surge_snapshot_writer_create: {rc}: {(self._lib.surge_snapshot_writer_last_error(None) or b'').decode()}")
+        self.n_partitions = n_partitions
+
+    def close(self):
+        if self._h:
+            self._lib.surge_snapshot_writer_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"surge_snapshot_writer: {rc}: {(self._lib.surge_snapshot_writer_last_error(self._h) or b'').decode()}")
+
+    def append(self, kind, partition, keys_utf8, key_off, values, val_off, timestamp_ms: Optional[int] = None) -> None:
+        """One record per index with ``kind != SKIP`` (``kind=None``: all values); numpy arrays, no per-record Python."""
+        p = lambda a, dt: None if a is None else np.ascontiguousarray(a, dtype=dt)  # noqa: E731
+        kind, partition = p(kind, np.uint8), p(partition, np.int32)
+        keys_utf8, key_off, values, val_off = p(keys_utf8, np.uint8), p(key_off, np.int64), p(values, np.uint8), p(val_off, np.int64)
+        n = partition.shape[0]
+        ptr = lambda a: None if a is None or a.size == 0 else a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        self._check(self._lib.surge_snapshot_writer_append(
+            self._h, n, ptr(kind), ptr(partition), ptr(keys_utf8), ptr(key_off), ptr(values), ptr(val_off),
+            int(time.time() * 1000) if timestamp_ms is None else int(timestamp_ms)))
+
+    def partition_bytes(self, partition: int) -> Tuple[bytes, int, int]:
+        """``(record batches, records, next offset)`` of one partition's log (flushes the open batches)."""
+        self._check(self._lib.surge_snapshot_writer_flush(self._h))
+        data, ln, nrec, nxt = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self._check(self._lib.surge_snapshot_writer_partition(self._h, partition, ctypes.byref(data), ctypes.byref(ln), ctypes.byref(nrec), ctypes.byref(nxt)))
+        return (ctypes.string_at(data, ln.value) if ln.value else b""), nrec.value, nxt.value
+
+    def reset(self) -> None:
+        self._check(self._lib.surge_snapshot_writer_reset(self._h))
+
+
+class BulkSnapshotPublisher:
+    """State-topic record batches straight from the GPU-resident states, no per-aggregate host work (N2 x N3):
+
+        delta kernel (what changed since the last publish: PersistentActor.scala:212,257)
+          -> GPU encoder restricted to the changed Some aggregates (writeState text; N3)
+          -> K4 partitions of the aggregate ids (once per key table)
+          -> one D2H of {kinds, text, offsets} -> RecordBatch v2 encoder (C++; N2) -> bytes per partition.
+
+    ``keys`` are the aggregate ids in dense-index order; ``template`` declares the model's serialized state."""
+
+    def __init__(self, engine, keys: Sequence[str], n_partitions: int, template=None, device=None):
+        import torch
+
+        from .encode import JsonTemplate, key_table_utf8
+        from .kafka import utf16_table
+
+        self.engine, self.n_partitions = engine, n_partitions
+        self.template = template or JsonTemplate.counter()
+        self.device = torch.device(device or f"cuda:{engine.device}")
+        self.writer = RecordBatchWriter(n_partitions)
+        data, off = key_table_utf8(keys)
+        self.h_keys, self.h_key_off = data, off
+        self.d_keys = torch.from_numpy(data).to(self.device)
+        self.d_key_off = torch.from_numpy(off).to(self.device)
+        u16, o16 = utf16_table(keys)
+        d_part = torch.zeros(len(keys), dtype=torch.int32, device=self.device)
+        if len(keys):
+            engine.partition_hash_device(torch.from_numpy(u16.view(np.int16)).to(self.device), torch.from_numpy(o16).to(self.device),
+                                         n_partitions, d_part, up_to_colon=True)
+            engine.synchronize()
+        self.partitions = d_part.cpu().numpy()
+        self.timings: Dict[str, float] = {}
+
+    def close(self):
+        self.writer.close()
+
+    def publish(self, commit: bool = True, timestamp_ms: Optional[int] = None) -> Dict[int, bytes]:
+        """Record batches (per partition) for everything that changed since the last committed publish."""
+        import torch
+
+        from .encode import encode_states
+
+        eng = self.engine
+        n = eng.n_agg
+        if n > len(self.partitions):
+            raise ValueError("the resident state has aggregates the publisher has no key for: rebuild it with the current key table")
+        lib = _native.load()
+        t0 = time.perf_counter()
+        d_kind = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        nv, nt = ctypes.c_int64(), ctypes.c_int64()
+        eng._check(lib.surge_replay_snapshot_delta(eng._h, ctypes.c_void_p(d_kind.data_ptr()), ctypes.byref(nv), ctypes.byref(nt), 1 if commit else 0))
+        eng._check(lib.surge_replay_set_encode_filter(eng._h, ctypes.c_void_p(d_kind.data_ptr())))
+        try:
+            d_out, d_off = encode_states(eng, self.template, self.d_keys, self.d_key_off, capacity_hint=max(64, 96 * nv.value + int(self.d_keys.numel())))
+        finally:
+            eng._check(lib.surge_replay_set_encode_filter(eng._h, None))
+        torch.cuda.synchronize(self.device)
+        t1 = time.perf_counter()
+        kind, text, off = d_kind.cpu().numpy(), d_out.cpu().numpy(), d_off.cpu().numpy()
+        t2 = time.perf_counter()
+        self.writer.reset()
+        self.writer.append(kind, self.partitions[:n], self.h_keys, self.h_key_off[: n + 1], text, off, timestamp_ms)
+        out = {}
+        for p in range(self.n_partitions):
+            data, nrec, _ = self.writer.partition_bytes(p)
+            if nrec:
+                out[p] = data
+        t3 = time.perf_counter()
+        self.timings = {"gpu_delta_and_encode_ms": (t1 - t0) * 1e3, "d2h_ms": (t2 - t1) * 1e3, "record_batches_ms": (t3 - t2) * 1e3,
+                        "values": nv.value, "tombstones": nt.value, "text_bytes": int(text.nbytes)}
+        return out
 
 
 def compact(records: Iterable[StateRecord]) -> Dict[str, Optional[bytes]]:

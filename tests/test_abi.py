@@ -41,6 +41,14 @@ def test_ingest_exports_match_their_header():
         assert hasattr(lib, name), f"{name} declared in surge_ingest.h but not exported"
 
 
+def test_snapshot_writer_exports_match_their_header():
+    lib = _native.load()
+    declared = header_symbols("surge_snapshot.h", "surge_snapshot_writer")
+    assert declared == sorted(_native.SNAPSHOT_EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in surge_snapshot.h but not exported"
+
+
 def test_default_schema_matches_python_mirror():
     lib = _native.load()
     s = CSchema()

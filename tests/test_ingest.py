@@ -314,3 +314,38 @@ def test_keys_of_aborted_transactions_never_enter_the_key_table():
         got = g.drain_records()
         assert [(i, k) for _, i, k, _ in got] == [(0, b"real:1")]
         assert g.key_table().keys == ["real"]
+
+
+# ---- N2: the product's RecordBatch v2 ENCODER (include/surge_snapshot.h) ------------------------------------------------
+def test_snapshot_writer_batches_are_what_the_test_side_writer_and_the_decoder_agree_on():
+    from surge_amd.snapshot import RecordBatchWriter
+
+    rng = random.Random(11)
+    keys = [f"acct-{i:05d}" for i in range(700)] + ["", "ünï-✓", "k" * 300]
+    vals = [os.urandom(rng.randrange(0, 90)) for _ in keys]
+    kind = np.array([rng.choice([0, 1, 1, 1, 2]) for _ in keys], dtype=np.uint8)  # SKIP / VALUE / TOMBSTONE
+    part = np.array([rng.randrange(3) for _ in keys], dtype=np.int32)
+    kb = [k.encode() for k in keys]
+    key_off = np.zeros(len(keys) + 1, np.int64); np.cumsum([len(b) for b in kb], out=key_off[1:])
+    val_off = np.zeros(len(keys) + 1, np.int64); np.cumsum([len(v) for v in vals], out=val_off[1:])
+    with RecordBatchWriter(3, max_records_per_batch=64) as w:
+        w.append(kind, part, np.frombuffer(b"".join(kb), np.uint8), key_off, np.frombuffer(b"".join(vals), np.uint8), val_off, timestamp_ms=1_700_000_000_000)
+        for p in range(3):
+            data, nrec, nxt = w.partition_bytes(p)
+            want = [(kb[i], vals[i] if kind[i] == 1 else None) for i in range(len(keys)) if part[i] == p and kind[i] != 0]
+            assert nrec == nxt == len(want)
+            # (a) byte-identical to the independent test-side writer, batch for batch (same framing, same CRC-32C)
+            ref = b"".join(kw.record_batch(s0, want[s0:s0 + 64], base_timestamp=1_700_000_000_000, producer_epoch=-1) for s0 in range(0, len(want), 64))
+            assert data == ref
+            # (b) the product's own decoder reads them back: keys, values, tombstones, offsets
+            with EventsTopicIngest() as g:
+                g.feed(data)
+                got = g.drain_records()
+            assert [(k, v) for _, _, k, v in got] == want
+            assert [o for o, _, _, _ in got] == list(range(len(want)))
+        # the log continues after a reset: offsets keep counting
+        w.reset()
+        w.append(None, np.array([1], np.int32), np.frombuffer(b"x", np.uint8), np.array([0, 1], np.int64), np.frombuffer(b"v", np.uint8), np.array([0, 1], np.int64), 5)
+        data, nrec, nxt = w.partition_bytes(1)
+        n1 = sum(1 for i in range(len(keys)) if part[i] == 1 and kind[i] != 0)
+        assert nrec == 1 and nxt == n1 + 1 and data == kw.record_batch(n1, [(b"x", b"v")], base_timestamp=5, producer_epoch=-1)
