@@ -40,7 +40,12 @@ def test_c_abi_exchange_two_ranks(tmp_path, mode):
     import torch
 
     n = torch.cuda.device_count()
-    outs = run_ranks(2, tmp_path, [0, 1] if n >= 2 else [0, 0], mode)
+    if n < 2 and os.environ.get("SURGE_TEST_FORCE_2RANK") != "1":
+        # measured on the 1-GPU MI355X boxes (RCCL 2.26.6): ncclCommInitRank answers "invalid usage" for the second rank on
+        # the same device and leaves rank 0 waiting in the bootstrap until it is killed (~50 s per attempt): do not burn that
+        pytest.skip("one GPU visible: RCCL refuses two communicator ranks on one device (ncclCommInitRank: invalid usage); "
+                    "SURGE_TEST_FORCE_2RANK=1 tries anyway")
+    outs = run_ranks(2, tmp_path, [0, 1] if n >= 2 else [0, 0], mode, timeout=120)
     if any(rc == 3 for rc, _ in outs) or (n < 2 and any(rc != 0 for rc, _ in outs)):
         pytest.skip("RCCL refused two ranks on this box's single GPU: " + " | ".join(o.strip().splitlines()[-1] for _, o in outs if o.strip()))
     for r, (rc, out) in enumerate(outs):
