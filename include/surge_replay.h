@@ -226,11 +226,14 @@ int32_t surge_replay_append_fold(surge_replay_handle* h, const int64_t* group_ag
                                  const int64_t* group_off, int64_t n_groups,
                                  const void* events, int64_t n_events);
 /* Ungrouped variant: n events in topic (offset) order, event i belongs to aggregate agg_idx[i].  The
- * library groups them by aggregate with a stable radix sort on the host (order inside an aggregate is
- * kept), then runs the same micro-batch fold.  This is the shape a consumer of the events topic has
- * after interning record keys "<aggregateId>:<seq>" (TestBoundedContext.scala:122-124). */
+ * library groups them by aggregate ON THE DEVICE (stable radix sort of (index, position), head scan, gather;
+ * order inside an aggregate is kept), then runs the same micro-batch fold.  This is the shape a consumer of
+ * the events topic has after interning record keys "<aggregateId>:<seq>" (TestBoundedContext.scala:122-124).
+ * Host buffers are staged through pinned memory; the _device variant takes device pointers. */
 int32_t surge_replay_append_events(surge_replay_handle* h, const int64_t* agg_idx, const void* events,
                                    int64_t n_events);
+int32_t surge_replay_append_events_device(surge_replay_handle* h, const int64_t* d_agg_idx, const void* d_events,
+                                          int64_t n_events);
 int32_t surge_replay_append_fold_device(surge_replay_handle* h, const int64_t* d_group_agg,
                                         const int64_t* d_group_off, int64_t n_groups,
                                         const void* d_events, int64_t n_events);

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
-SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "engine.hip", "comm.hip", "ingest.cpp", "snapshot_writer.cpp")
+SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "snapshot_writer.cpp")
 HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
@@ -33,6 +33,7 @@ EXPORTS = (
     "surge_replay_fold",
     "surge_replay_append_fold",
     "surge_replay_append_events",
+    "surge_replay_append_events_device",
     "surge_replay_append_fold_device",
     "surge_replay_get",
     "surge_replay_gather",
@@ -178,6 +179,7 @@ def load() -> ctypes.CDLL:
         "surge_replay_append_fold": ([vp, vp, vp, i64, vp, i64], i32),
         "surge_replay_append_fold_device": ([vp, vp, vp, i64, vp, i64], i32),
         "surge_replay_append_events": ([vp, vp, vp, i64], i32),
+        "surge_replay_append_events_device": ([vp, vp, vp, i64], i32),
         "surge_replay_get": ([vp, i64, vp, ctypes.POINTER(ctypes.c_uint8)], i32),
         "surge_replay_gather": ([vp, vp, i64, vp], i32),
         "surge_replay_snapshot": ([vp, vp, vp], i32),

@@ -93,10 +93,10 @@ struct surge_replay_handle {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> fold_events;
   size_t folds_since_reset = 0;
 
-  // host scratch of append_events (stable group-by)
-  std::vector<uint32_t> sort_a, sort_b;
-  std::vector<int64_t> h_group_agg, h_group_off;
-  std::vector<uint4> h_sorted_events;
+  // append_events: device group-by scratch (stream_kernels.hip) and pinned H2D staging of host batches
+  DevBuf gb_temp, gb_u32, gb_flags, gb_agg_idx, gb_events;
+  void* pinned = nullptr;  // hipHostMalloc'ed staging: agg_idx then events of one batch
+  size_t pinned_cap = 0;
 
   DevBuf published;                      // the last committed snapshot (surge_replay_snapshot_delta), n_agg x 64 B
   int64_t published_n = 0;
@@ -362,7 +362,9 @@ int32_t surge_replay_destroy(surge_replay_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->comm) comm_destroy(h->comm);
   h->comm = nullptr;
-  DevBuf* bufs[] = {&h->published, &h->gathered[0], &h->gathered[1], &h->v_side, &h->r_slot0, &h->r_c, &h->r_out, &h->v_ctr, &h->v_start, &h->v_len, &h->v_info, &h->v_seg, &h->v_total, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
+  if (h->pinned) (void)hipHostFree(h->pinned);
+  h->pinned = nullptr;
+  DevBuf* bufs[] = {&h->gb_temp, &h->gb_u32, &h->gb_flags, &h->gb_agg_idx, &h->gb_events, &h->published, &h->gathered[0], &h->gathered[1], &h->v_side, &h->r_slot0, &h->r_c, &h->r_out, &h->v_ctr, &h->v_start, &h->v_len, &h->v_info, &h->v_seg, &h->v_total, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
                     &h->nz_map, &h->block_counts, &h->plan, &h->batch_group_agg, &h->batch_group_off,
                     &h->batch_events, &h->poison_count, &h->gather_idx, &h->gather_out, &h->scan_totals};
   for (DevBuf* b : bufs) b->release();
@@ -725,6 +727,39 @@ int32_t surge_replay_append_fold(surge_replay_handle* h, const int64_t* group_ag
                                          n_groups, h->batch_events.ptr, n_events);
 }
 
+int32_t surge_replay_append_events_device(surge_replay_handle* h, const int64_t* d_agg_idx, const void* d_events, int64_t n_events) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->bound) return fail(h, SURGE_E_STATE, "append_events before load_csr/bind_device_csr");
+  if (n_events < 0) return fail(h, SURGE_E_INVALID, "negative size");
+  if (n_events == 0) return SURGE_OK;
+  if (!d_agg_idx || !d_events) return fail(h, SURGE_E_INVALID, "NULL batch buffer");
+  if (n_events > 0xffffffffll) return fail(h, SURGE_E_UNSUPPORTED, "micro-batches are limited to 2^32 - 1 events");
+  if (h->n_agg > 0xffffffffll) return fail(h, SURGE_E_UNSUPPORTED, "the device group-by needs fewer than 2^32 aggregates");
+  if ((uintptr_t)d_events & 15) return fail(h, SURGE_E_INVALID, "events must be 16-byte aligned");
+  DeviceGuard g(h->device);
+  const uint32_t n = (uint32_t)n_events;
+  unsigned bits = 1;
+  while (bits < 32 && (h->n_agg >> bits) != 0) ++bits;
+  size_t temp = 0;
+  HIPCHK(h, groupby_temp_bytes(n, bits, &temp));
+  HIPCHK(h, h->gb_temp.reserve(temp));
+  HIPCHK(h, h->gb_u32.reserve((size_t)n * 4 * 6));
+  HIPCHK(h, h->gb_flags.reserve(8));
+  HIPCHK(h, h->batch_group_agg.reserve((size_t)n * 8));
+  HIPCHK(h, h->batch_group_off.reserve((size_t)(n + 1) * 8));
+  HIPCHK(h, h->batch_events.reserve((size_t)n * 16));
+  uint32_t* u = (uint32_t*)h->gb_u32.ptr;
+  HIPCHK(h, launch_groupby(d_agg_idx, (const uint4*)d_events, n, h->n_agg, bits, h->gb_temp.ptr, temp, u, u + n, u + 2 * (size_t)n,
+                           u + 3 * (size_t)n, u + 4 * (size_t)n, u + 5 * (size_t)n, (uint4*)h->batch_events.ptr,
+                           (int64_t*)h->batch_group_agg.ptr, (int64_t*)h->batch_group_off.ptr, (uint32_t*)h->gb_flags.ptr, h->stream));
+  uint32_t flags[2] = {0, 0};
+  HIPCHK(h, hipMemcpyAsync(flags, h->gb_flags.ptr, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // the fold's launch is sized by the number of groups
+  if (flags[1]) return fail(h, SURGE_E_RANGE, "agg_idx out of range");
+  return surge_replay_append_fold_device(h, (const int64_t*)h->batch_group_agg.ptr, (const int64_t*)h->batch_group_off.ptr,
+                                         (int64_t)flags[0], h->batch_events.ptr, n_events);
+}
+
 int32_t surge_replay_append_events(surge_replay_handle* h, const int64_t* agg_idx, const void* events, int64_t n_events) {
   if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
   if (!h->bound) return fail(h, SURGE_E_STATE, "append_events before load_csr/bind_device_csr");
@@ -732,46 +767,29 @@ int32_t surge_replay_append_events(surge_replay_handle* h, const int64_t* agg_id
   if (n_events == 0) return SURGE_OK;
   if (!agg_idx || !events) return fail(h, SURGE_E_INVALID, "NULL batch buffer");
   if (n_events > 0xffffffffll) return fail(h, SURGE_E_UNSUPPORTED, "micro-batches are limited to 2^32 - 1 events");
-  const uint32_t n = (uint32_t)n_events;
-  for (uint32_t i = 0; i < n; ++i)
-    if (agg_idx[i] < 0 || agg_idx[i] >= h->n_agg) return fail(h, SURGE_E_RANGE, "agg_idx out of range");
-  try {
-    // stable LSD radix sort of the event positions by aggregate index, 16 bits per pass
-    h->sort_a.resize(n);
-    h->sort_b.resize(n);
-    for (uint32_t i = 0; i < n; ++i) h->sort_a[i] = i;
-    int bits = 1;
-    while (bits < 63 && (h->n_agg >> bits) != 0) ++bits;
-    std::vector<uint32_t> count(65536 + 1);
-    uint32_t* src = h->sort_a.data();
-    uint32_t* dst = h->sort_b.data();
-    for (int shift = 0; shift < bits; shift += 16) {
-      std::fill(count.begin(), count.end(), 0u);
-      for (uint32_t i = 0; i < n; ++i) ++count[((uint64_t)agg_idx[src[i]] >> shift & 0xffff) + 1];
-      for (int b = 0; b < 65536; ++b) count[b + 1] += count[b];
-      for (uint32_t i = 0; i < n; ++i) dst[count[(uint64_t)agg_idx[src[i]] >> shift & 0xffff]++] = src[i];
-      std::swap(src, dst);
-    }
-    const uint4* ev = (const uint4*)events;
-    h->h_sorted_events.resize(n);
-    h->h_group_agg.clear();
-    h->h_group_off.clear();
-    int64_t prev = -1;
-    for (uint32_t i = 0; i < n; ++i) {
-      const int64_t a = agg_idx[src[i]];
-      if (a != prev) {
-        h->h_group_agg.push_back(a);
-        h->h_group_off.push_back((int64_t)i);
-        prev = a;
-      }
-      std::memcpy(&h->h_sorted_events[i], &ev[src[i]], 16);
-    }
-    h->h_group_off.push_back((int64_t)n);
-  } catch (const std::bad_alloc&) {
-    return fail(h, SURGE_E_NOMEM, "out of host memory while grouping the micro-batch");
+  DeviceGuard g(h->device);
+  // host buffers (pageable: a JNI direct buffer, a numpy array) go through one pinned staging area so the H2D copy
+  // runs at PCIe speed; grouping happens on the device
+  const size_t need = (size_t)n_events * 24;
+  if (need > h->pinned_cap) {
+    if (h->pinned) (void)hipHostFree(h->pinned);
+    h->pinned = nullptr;
+    h->pinned_cap = 0;
+    const size_t cap = need < (4u << 20) ? (4u << 20) : need + need / 2;
+    HIPCHK(h, hipHostMalloc(&h->pinned, cap, hipHostMallocDefault));
+    h->pinned_cap = cap;
   }
-  return surge_replay_append_fold(h, h->h_group_agg.data(), h->h_group_off.data(), (int64_t)h->h_group_agg.size(),
-                                  h->h_sorted_events.data(), n_events);
+  HIPCHK(h, h->gb_agg_idx.reserve((size_t)n_events * 8));
+  HIPCHK(h, h->gb_events.reserve((size_t)n_events * 16));
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // the previous batch's copy out of the staging area is done
+  std::memcpy(h->pinned, agg_idx, (size_t)n_events * 8);
+  std::memcpy((char*)h->pinned + (size_t)n_events * 8, events, (size_t)n_events * 16);
+  HIPCHK(h, hipEventRecord(h->ev_h0, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->gb_agg_idx.ptr, h->pinned, (size_t)n_events * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->gb_events.ptr, (char*)h->pinned + (size_t)n_events * 8, (size_t)n_events * 16, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_h1, h->stream));
+  h->h2d_valid = true;
+  return surge_replay_append_events_device(h, (const int64_t*)h->gb_agg_idx.ptr, h->gb_events.ptr, n_events);
 }
 
 int32_t surge_replay_snapshot(surge_replay_handle* h, void* states_out, uint8_t* present_out) {

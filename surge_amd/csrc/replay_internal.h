@@ -122,6 +122,13 @@ hipError_t launch_count_poisoned(const uint4* states, int64_t n, unsigned long l
                                  hipStream_t stream);
 
 
+// ---- stream_kernels.hip: K3 micro-batch group-by on the device ------------------------------------------------
+hipError_t groupby_temp_bytes(uint32_t n, unsigned key_bits, size_t* bytes);
+hipError_t launch_groupby(const int64_t* d_agg_idx, const uint4* d_events, uint32_t n, int64_t n_agg, unsigned key_bits, void* d_temp,
+                          size_t temp_bytes, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* head,
+                          uint32_t* gid, uint4* d_sorted_events, int64_t* d_group_agg, int64_t* d_group_off, uint32_t* d_flags,
+                          hipStream_t stream);
+
 // ---- comm.hip: the snapshot exchange over RCCL (dlopen'ed) ----------------------------------------------------
 struct CommState;
 int32_t comm_unique_id(uint8_t* id_out, std::string* err);

@@ -1,0 +1,88 @@
+// stream_kernels.hip — K3 micro-batch group-by on the device (SURVEY §8d C5, §8f N1's drain): n events in topic
+// (offset) order, event i tagged with its aggregate's dense index, become the grouped batch the flat fold kernel takes:
+//   stable sort of (aggregate index, position) pairs   — rocPRIM's LSD radix sort over the bits the index needs
+//   -> heads (first event of every aggregate's run)   — one compare per event
+//   -> exclusive scan of the head flags               — group id of every run
+//   -> scatter {group_agg, group_off} + gather of the 16-byte events into sorted order.
+// Order inside an aggregate is the topic's order (the sort is stable and the value is the position), which is all
+// foldLeft needs (CommandModels.scala:26).  Round 1 did this on the host (LSD radix sort in engine.hip, 5e7 events/s).
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "replay_internal.h"
+
+namespace surge {
+namespace {
+
+// keys[i] = low 32 bits of agg_idx[i] (n_agg < 2^32 is checked by the caller), vals[i] = i; bad[0] |= out-of-range index
+__global__ void groupby_keys_kernel(const int64_t* __restrict__ agg_idx, uint32_t n, int64_t n_agg, uint32_t* __restrict__ keys,
+                                    uint32_t* __restrict__ vals, uint32_t* __restrict__ bad) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t a = agg_idx[i];
+  if (a < 0 || a >= n_agg) atomicOr(bad, 1u);
+  keys[i] = (uint32_t)a;
+  vals[i] = i;
+}
+
+__global__ void groupby_heads_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ head) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+// gid = exclusive scan of head: run r starts at the event where head == 1 and gid == r
+__global__ void groupby_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                       const uint32_t* __restrict__ head, const uint32_t* __restrict__ gid, uint32_t n,
+                                       const uint4* __restrict__ events, uint4* __restrict__ sorted_events,
+                                       int64_t* __restrict__ group_agg, int64_t* __restrict__ group_off, uint32_t* __restrict__ n_groups) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  sorted_events[i] = events[vals[i]];
+  if (head[i]) {
+    group_agg[gid[i]] = (int64_t)keys[i];
+    group_off[gid[i]] = (int64_t)i;
+  }
+  if (i == n - 1) {
+    const uint32_t g = gid[i] + head[i];
+    group_off[g] = (int64_t)n;
+    n_groups[0] = g;
+  }
+}
+
+}  // namespace
+
+// scratch bytes the two rocPRIM primitives need for n events (the larger of the two)
+hipError_t groupby_temp_bytes(uint32_t n, unsigned key_bits, size_t* bytes) {
+  size_t a = 0, b = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                           (uint32_t*)nullptr, (size_t)n, 0u, key_bits, (hipStream_t) nullptr);
+  if (e != hipSuccess) return e;
+  e = rocprim::exclusive_scan(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n, rocprim::plus<uint32_t>(),
+                              (hipStream_t) nullptr);
+  if (e != hipSuccess) return e;
+  *bytes = a > b ? a : b;
+  return hipSuccess;
+}
+
+// All buffers device: keys_a/keys_b/vals_a/vals_b/head/gid: n x u32 each; d_flags: {n_groups, bad} (2 x u32).
+hipError_t launch_groupby(const int64_t* d_agg_idx, const uint4* d_events, uint32_t n, int64_t n_agg, unsigned key_bits, void* d_temp,
+                          size_t temp_bytes, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* head,
+                          uint32_t* gid, uint4* d_sorted_events, int64_t* d_group_agg, int64_t* d_group_off, uint32_t* d_flags,
+                          hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const unsigned blocks = (n + 255u) / 256u;
+  hipError_t e = hipMemsetAsync(d_flags, 0, 8, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(groupby_keys_kernel, dim3(blocks), dim3(256), 0, stream, d_agg_idx, n, n_agg, keys_a, vals_a, d_flags + 1);
+  e = rocprim::radix_sort_pairs(d_temp, temp_bytes, (const uint32_t*)keys_a, keys_b, (const uint32_t*)vals_a, vals_b, (size_t)n, 0u, key_bits, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(groupby_heads_kernel, dim3(blocks), dim3(256), 0, stream, keys_b, n, head);
+  e = rocprim::exclusive_scan(d_temp, temp_bytes, (const uint32_t*)head, gid, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(groupby_scatter_kernel, dim3(blocks), dim3(256), 0, stream, keys_b, vals_b, head, gid, n, d_events, d_sorted_events,
+                     d_group_agg, d_group_off, d_flags);
+  return hipGetLastError();
+}
+
+}  // namespace surge

@@ -180,7 +180,15 @@ class ReplayEngine:
             )
 
     def append_events(self, agg_idx, events) -> None:
-        """Micro-batch in topic order, event i tagged with ``agg_idx[i]``; grouping happens in the library."""
+        """Micro-batch in topic order, event i tagged with ``agg_idx[i]``; grouping happens in the library, on the
+        device.  CUDA tensors are taken in place, numpy arrays are staged through pinned memory."""
+        if _is_torch(events):
+            n_events = (events.numel() * events.element_size()) // 16
+            if agg_idx.numel() != n_events:
+                raise ValueError("one aggregate index per event")
+            self._check(self._lib.surge_replay_append_events_device(self._h, _dev_ptr(agg_idx), _dev_ptr(events), n_events))
+            self._keep_batch = [agg_idx, events]
+            return
         agg_idx = np.ascontiguousarray(agg_idx, dtype=np.int64)
         events = np.ascontiguousarray(events, dtype=EVENT_DTYPE)
         if agg_idx.shape[0] != events.shape[0]:

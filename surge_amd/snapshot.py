@@ -129,7 +129,9 @@ class BulkSnapshotPublisher:
 
     ``keys`` are the aggregate ids in dense-index order; ``template`` declares the model's serialized state."""
 
-    def __init__(self, engine, keys: Sequence[str], n_partitions: int, template=None, device=None):
+    def __init__(self, engine, keys: Optional[Sequence[str]], n_partitions: int, template=None, device=None, tables=None):
+        """``keys``: aggregate ids in dense-index order; or ``tables = (keys_utf8, key_off, keys_utf16, off16)`` as
+        tensors / arrays built without Python strings (large synthetic populations)."""
         import torch
 
         from .encode import JsonTemplate, key_table_utf8
@@ -139,15 +141,20 @@ class BulkSnapshotPublisher:
         self.template = template or JsonTemplate.counter()
         self.device = torch.device(device or f"cuda:{engine.device}")
         self.writer = RecordBatchWriter(n_partitions)
-        data, off = key_table_utf8(keys)
-        self.h_keys, self.h_key_off = data, off
-        self.d_keys = torch.from_numpy(data).to(self.device)
-        self.d_key_off = torch.from_numpy(off).to(self.device)
-        u16, o16 = utf16_table(keys)
-        d_part = torch.zeros(len(keys), dtype=torch.int32, device=self.device)
-        if len(keys):
-            engine.partition_hash_device(torch.from_numpy(u16.view(np.int16)).to(self.device), torch.from_numpy(o16).to(self.device),
-                                         n_partitions, d_part, up_to_colon=True)
+        if tables is None:
+            data, off = key_table_utf8(keys)
+            u16, o16 = utf16_table(keys)
+            u16 = u16.view(np.int16)
+        else:
+            data, off, u16, o16 = tables
+        as_t = lambda a: a.to(self.device) if hasattr(a, "to") else torch.from_numpy(np.ascontiguousarray(a)).to(self.device)  # noqa: E731
+        self.d_keys, self.d_key_off = as_t(data), as_t(off)
+        self.h_keys, self.h_key_off = self.d_keys.cpu().numpy(), self.d_key_off.cpu().numpy()
+        n_keys = int(self.d_key_off.numel()) - 1
+        d_part = torch.zeros(n_keys, dtype=torch.int32, device=self.device)
+        if n_keys:
+            torch.cuda.current_stream(self.device).synchronize()
+            engine.partition_hash_device(as_t(u16), as_t(o16), n_partitions, d_part, up_to_colon=True)
             engine.synchronize()
         self.partitions = d_part.cpu().numpy()
         self.timings: Dict[str, float] = {}
