@@ -137,6 +137,70 @@ typedef struct surge_replay_schema {
                                         flags/reserved ignored                      */
 } surge_replay_schema;
 
+/* ---- ABI v2: field SLOTS (generalised) --------------------------------------------------------
+ * handleEvent is arbitrary (CommandModels.scala:14); the v1 descriptor above can only express its seven named
+ * fields.  A v2 schema declares up to 7 typed 8-byte SLOTS inside the same 64-byte state and, per event type, one
+ * operation per slot.  A model with two counters and a Long version — which v1 cannot express — is three slots.
+ *
+ *   state (64 B): slot 0..3 at bytes 0, 8, 16, 24 | u32 event_count at 32 | u32 flags at 36 (as in v1) | slot 4..6 at 40, 48, 56
+ *                 an I32 slot uses the low 4 bytes of its 8 (the rest stay zero); None is all-zero, as in v1
+ *   slot i:  type  SURGE_SLOT_I32 / _I64 / _F64
+ *            source of the operand x of every operation on it:
+ *              SURGE_SRC_ARG      (int32) low half of the event payload   (incrementBy)
+ *              SURGE_SRC_SEQ      (int32) event.seq                       (sequenceNumber)
+ *              SURGE_SRC_PAYLOAD  the 8-byte payload (i64 / f64 bits; an I32 slot takes its low half)
+ *              SURGE_SRC_ONE      the constant 1 (1.0 for F64)
+ *              (ARG / SEQ are sign-extended for I64 and converted exactly for F64)
+ *            default_bits: what an absent aggregate materialises to
+ *   event type t:  cls[t] = presence class (SURGE_CLS_*, as v1) | SURGE_D_POISON
+ *                  ops[t] = 4 bits per slot, slot i in bits [4i, 4i+4): SURGE_OP_KEEP / ADD / SUB / SET / MIN / MAX
+ *   integer ADD / SUB wrap like JVM Int / Long; F64 ADD / SUB are IEEE double operations applied STRICTLY in event
+ *   order (the JVM fold's order; the library is built with -ffp-contract=off), so the result is bit-identical to the
+ *   sequential fold — no tolerance needed; F64 MIN / MAX are `if (x < cur) x else cur` / `if (x > cur) x else cur`.
+ * Any mix of operations on one slot is allowed: v2 handles always fold with ONE lane per aggregate (or per
+ * micro-batch group) walking its events in order — the sorted-rows transport with a slot interpreter
+ * (fold_slots.hip) — so nothing has to be associative.  Everything else of the ABI (load / bind, fold, append_*, get,
+ * gather, snapshot, grow, encoders, snapshot_delta, the exchange) works on v2 handles; surge_replay_fold accepts
+ * SURGE_ALGO_AUTO only. */
+#define SURGE_REPLAY_ABI_VERSION_2 2u
+#define SURGE_MAX_SLOTS 7
+#define SURGE_SLOT_I32 1u
+#define SURGE_SLOT_I64 2u
+#define SURGE_SLOT_F64 3u
+#define SURGE_SRC_ARG     0u
+#define SURGE_SRC_SEQ     1u
+#define SURGE_SRC_PAYLOAD 2u
+#define SURGE_SRC_ONE     3u
+#define SURGE_OP_KEEP 0u
+#define SURGE_OP_ADD  1u
+#define SURGE_OP_SUB  2u
+#define SURGE_OP_SET  3u
+#define SURGE_OP_MIN  4u
+#define SURGE_OP_MAX  5u
+#define SURGE_V2_COUNT_EVENTS 1u /* schema flag: event_count += 1 for every event that applies */
+
+typedef struct surge_slot_def {
+  uint8_t  type;          /* SURGE_SLOT_*                  */
+  uint8_t  source;        /* SURGE_SRC_*                   */
+  uint8_t  reserved[6];
+  uint64_t default_bits;  /* the slot of a materialised default state (I32: low 4 bytes) */
+} surge_slot_def;
+
+typedef struct surge_replay_schema_v2 {
+  uint32_t abi_version;   /* SURGE_REPLAY_ABI_VERSION_2 */
+  uint32_t state_size;    /* 64 */
+  uint32_t event_size;    /* 16 */
+  uint32_t n_types;       /* 1..SURGE_MAX_EVENT_TYPES */
+  uint32_t n_slots;       /* 1..SURGE_MAX_SLOTS */
+  uint32_t flags;         /* SURGE_V2_* */
+  surge_slot_def slot[SURGE_MAX_SLOTS];
+  uint32_t cls[SURGE_MAX_EVENT_TYPES];
+  uint32_t ops[SURGE_MAX_EVENT_TYPES];
+} surge_replay_schema_v2;
+
+/* byte offset of slot i in the 64-byte state */
+#define SURGE_SLOT_OFFSET(i) ((i) < 4 ? 8 * (i) : 8 * (i) + 8)
+
 /* Built-in event types of the reference fixtures' algebra (default schema). */
 #define SURGE_EVT_NOOP        0 /* NoOpEvent            TestBoundedContext.scala:63,85    */
 #define SURGE_EVT_INC         1 /* CountIncremented     TestBoundedContext.scala:55,81-82 */
@@ -155,6 +219,7 @@ typedef struct surge_replay_schema {
 #define SURGE_ALGO_ROWS  3 /* K1: uniform L, one lane per aggregate, no cross-lane scan               */
 #define SURGE_ALGO_SORTED 4 /* K2b: any CSR; segments counting-sorted by length at load time, persistent
                                waves walk groups of 64 similar-length segments, one lane per aggregate  */
+#define SURGE_ALGO_SLOTS 6 /* v2 handles only: sorted-rows transport + slot interpreter, one lane per aggregate */
 #define SURGE_ALGO_CHUNKED 5 /* K2c: like SORTED, but an aggregate longer than T events (default 256) is cut into
                                 2^k line-aligned chunks walked by adjacent lanes of one wave and stitched with
                                 shuffles: no wave ever walks more than ~T events alone (mid-size ragged logs) */
@@ -185,6 +250,8 @@ int32_t surge_replay_default_schema(surge_replay_schema* out);
  * SurgeKafkaStreamsPersistencePlugin.createSupplier (…PersistencePlugin.scala:13). */
 int32_t surge_replay_create(const surge_replay_schema* schema, int32_t device_id,
                             surge_replay_handle** out);
+/* Same, for a v2 slot schema. */
+int32_t surge_replay_create_v2(const surge_replay_schema_v2* schema, int32_t device_id, surge_replay_handle** out);
 int32_t surge_replay_destroy(surge_replay_handle* h);
 const char* surge_replay_last_error(const surge_replay_handle* h);
 

@@ -48,6 +48,8 @@ def lib() -> ctypes.CDLL:
         vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
         L.oracle_fold_csr.argtypes = [ctypes.POINTER(CSchema), vp, i64, vp, vp, vp]
         L.oracle_fold_csr.restype = i32
+        L.oracle_fold_csr_v2.argtypes = [vp, vp, i64, vp, vp, vp]
+        L.oracle_fold_csr_v2.restype = i32
         L.oracle_fold_csr_mt.argtypes = [ctypes.POINTER(CSchema), vp, i64, vp, vp, vp, i32]
         L.oracle_fold_csr_mt.restype = i32
         L.oracle_fold_csr_mt_reps.argtypes = [ctypes.POINTER(CSchema), vp, i64, vp, vp, vp, i32, i32]
@@ -99,6 +101,23 @@ def fold_csr(
         )
     if rc != 0:
         raise RuntimeError(f"oracle_fold_csr failed: {rc}")
+    return out
+
+
+def fold_csr_v2(seg_off, events, algebra, init_state=None) -> np.ndarray:
+    """The sequential fold under an ABI v2 ``SlotAlgebra``; returns ``n_agg x 64`` raw bytes viewed with the
+    algebra's ``state_dtype()``."""
+    seg_off = np.ascontiguousarray(seg_off, dtype=np.int64)
+    events = np.ascontiguousarray(events, dtype=EVENT_DTYPE)
+    n_agg = seg_off.shape[0] - 1
+    out = np.zeros(n_agg, dtype=algebra.state_dtype())
+    if init_state is not None:
+        init_state = np.ascontiguousarray(init_state)
+        assert init_state.nbytes == n_agg * 64
+    sc = algebra.to_c()
+    rc = lib().oracle_fold_csr_v2(ctypes.byref(sc), _ptr(seg_off), n_agg, _ptr(events), _ptr(init_state), _ptr(out))
+    if rc != 0:
+        raise RuntimeError(f"oracle_fold_csr_v2 failed: {rc}")
     return out
 
 

@@ -181,6 +181,127 @@ int32_t oracle_fold_csr(const surge_replay_schema* sc, const int64_t* seg_off, i
   return 0;
 }
 
+/* ---------------------------------------------------------------------------
+ * ABI v2 slot schemas (include/surge_replay.h): the same fold, handleEvent restated per event type as one
+ * operation per typed slot.  Literal and sequential: one event at a time, doubles added in event order
+ * (built with -ffp-contract=off), exactly what events.foldLeft(state)(handleEvent) does on the JVM.
+ * ------------------------------------------------------------------------- */
+static uint64_t slot_operand(const surge_slot_def* sd, const surge_event16* ev) {
+  if (sd->type == SURGE_SLOT_F64) {
+    double d;
+    uint64_t bits;
+    if (sd->source == SURGE_SRC_PAYLOAD) return ev->p.raw;
+    d = sd->source == SURGE_SRC_ONE ? 1.0 : (double)(sd->source == SURGE_SRC_SEQ ? ev->seq : ev->p.i.arg);
+    memcpy(&bits, &d, 8);
+    return bits;
+  } else {
+    int64_t v = sd->source == SURGE_SRC_PAYLOAD ? (int64_t)ev->p.raw
+              : sd->source == SURGE_SRC_ONE ? 1
+              : (int64_t)(sd->source == SURGE_SRC_SEQ ? ev->seq : ev->p.i.arg);
+    return sd->type == SURGE_SLOT_I32 ? (uint64_t)(uint32_t)v : (uint64_t)v;
+  }
+}
+
+static uint64_t slot_apply(const surge_slot_def* sd, uint32_t op, uint64_t cur, uint64_t x) {
+  if (op == SURGE_OP_KEEP) return cur;
+  if (op == SURGE_OP_SET) return x;
+  if (sd->type == SURGE_SLOT_F64) {
+    double a, b, r;
+    uint64_t bits;
+    memcpy(&a, &cur, 8);
+    memcpy(&b, &x, 8);
+    switch (op) {
+      case SURGE_OP_ADD: r = a + b; break;
+      case SURGE_OP_SUB: r = a - b; break;
+      case SURGE_OP_MIN: return b < a ? x : cur;
+      default: return b > a ? x : cur; /* SURGE_OP_MAX */
+    }
+    memcpy(&bits, &r, 8);
+    return bits;
+  }
+  if (sd->type == SURGE_SLOT_I64) {
+    switch (op) {
+      case SURGE_OP_ADD: return cur + x;
+      case SURGE_OP_SUB: return cur - x;
+      case SURGE_OP_MIN: return (int64_t)x < (int64_t)cur ? x : cur;
+      default: return (int64_t)x > (int64_t)cur ? x : cur;
+    }
+  }
+  {
+    uint32_t a = (uint32_t)cur, b = (uint32_t)x;
+    switch (op) {
+      case SURGE_OP_ADD: return (uint64_t)(uint32_t)(a + b);
+      case SURGE_OP_SUB: return (uint64_t)(uint32_t)(a - b);
+      case SURGE_OP_MIN: return (int32_t)b < (int32_t)a ? (uint64_t)b : (uint64_t)a;
+      default: return (int32_t)b > (int32_t)a ? (uint64_t)b : (uint64_t)a;
+    }
+  }
+}
+
+typedef struct { uint64_t s[SURGE_MAX_SLOTS]; uint32_t evc; int present, poisoned; } slot_state;
+
+static void slots_from64(const uint8_t* in, slot_state* o) {
+  uint32_t fl;
+  int i;
+  for (i = 0; i < SURGE_MAX_SLOTS; ++i) memcpy(&o->s[i], in + SURGE_SLOT_OFFSET(i), 8);
+  memcpy(&o->evc, in + 32, 4);
+  memcpy(&fl, in + 36, 4);
+  o->present = (fl & SURGE_STATE_PRESENT) != 0;
+  o->poisoned = (fl & SURGE_STATE_POISONED) != 0;
+}
+
+static void slots_to64(const slot_state* o, uint8_t* out) {
+  uint32_t fl = (o->present ? SURGE_STATE_PRESENT : 0u) | (o->poisoned ? SURGE_STATE_POISONED : 0u);
+  int i;
+  memset(out, 0, 64); /* None is canonically all-zero */
+  if (o->present) {
+    for (i = 0; i < SURGE_MAX_SLOTS; ++i) memcpy(out + SURGE_SLOT_OFFSET(i), &o->s[i], 8);
+    memcpy(out + 32, &o->evc, 4);
+  }
+  memcpy(out + 36, &fl, 4);
+}
+
+/* returns nonzero when the event "throws" */
+static int handle_event_v2(const surge_replay_schema_v2* sc, slot_state* agg, const surge_event16* ev) {
+  uint32_t cls, ops, c, i;
+  if (ev->type < 0 || (uint32_t)ev->type >= sc->n_types) return 1; /* MatchError */
+  cls = sc->cls[ev->type];
+  ops = sc->ops[ev->type];
+  if (cls & SURGE_D_POISON) return 1;
+  c = cls & SURGE_CLS_MASK;
+  if (c == SURGE_CLS_DELETE) { agg->present = 0; return 0; }
+  if (c == SURGE_CLS_REQUIRE && !agg->present) return 0;
+  if (c == SURGE_CLS_CREATE || !agg->present) { /* Some(<built from the event>) / getOrElse(default) */
+    for (i = 0; i < sc->n_slots; ++i)
+      agg->s[i] = sc->slot[i].type == SURGE_SLOT_I32 ? (uint64_t)(uint32_t)sc->slot[i].default_bits : sc->slot[i].default_bits;
+    for (i = sc->n_slots; i < SURGE_MAX_SLOTS; ++i) agg->s[i] = 0;
+    agg->evc = 0;
+    agg->present = 1;
+  }
+  if (sc->flags & SURGE_V2_COUNT_EVENTS) agg->evc += 1u;
+  for (i = 0; i < sc->n_slots; ++i)
+    agg->s[i] = slot_apply(&sc->slot[i], (ops >> (4 * i)) & 15u, agg->s[i], slot_operand(&sc->slot[i], ev));
+  return 0;
+}
+
+int32_t oracle_fold_csr_v2(const surge_replay_schema_v2* sc, const int64_t* seg_off, int64_t n_agg, const void* events,
+                           const void* init_state, void* out_states) {
+  const surge_event16* ev = (const surge_event16*)events;
+  const uint8_t* init = (const uint8_t*)init_state;
+  uint8_t* out = (uint8_t*)out_states;
+  int64_t a, e;
+  if (!sc || !seg_off || n_agg < 0 || !out_states) return -1;
+  for (a = 0; a < n_agg; ++a) {
+    slot_state acc;
+    if (init) slots_from64(init + a * 64, &acc);
+    else memset(&acc, 0, sizeof(acc));
+    for (e = seg_off[a]; e < seg_off[a + 1] && !acc.poisoned; ++e)
+      if (handle_event_v2(sc, &acc, &ev[e])) acc.poisoned = 1;
+    slots_to64(&acc, out + a * 64);
+  }
+  return 0;
+}
+
 /* Same fold with aggregates split over host threads (baseline B2). */
 typedef struct {
   const surge_replay_schema* sc;

@@ -17,13 +17,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
-SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "snapshot_writer.cpp")
+SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_slots.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "snapshot_writer.cpp")
 HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
 EXPORTS = (
     "surge_replay_default_schema",
     "surge_replay_create",
+    "surge_replay_create_v2",
     "surge_replay_destroy",
     "surge_replay_last_error",
     "surge_replay_set_stream",
@@ -169,6 +170,7 @@ def load() -> ctypes.CDLL:
     sig = {
         "surge_replay_default_schema": ([ctypes.POINTER(CSchema)], i32),
         "surge_replay_create": ([ctypes.POINTER(CSchema), i32, ctypes.POINTER(vp)], i32),
+        "surge_replay_create_v2": ([vp, i32, ctypes.POINTER(vp)], i32),
         "surge_replay_destroy": ([vp], i32),
         "surge_replay_last_error": ([vp], ctypes.c_char_p),
         "surge_replay_set_stream": ([vp, vp], i32),

@@ -250,7 +250,7 @@ int32_t comm_counts(CommState* c, int64_t n_local, int64_t* counts_out, int64_t*
 // d_out[r * max_count + i] := rank r's state i (64 B); rows i >= counts[r] are None (zero).  Asynchronous: the side
 // stream first waits for everything enqueued so far on `compute`, and records done[slot] at the end.
 int32_t comm_allgather(CommState* c, hipStream_t compute, const void* d_states, int64_t n_local, void* d_out,
-                       int64_t out_rows_per_rank, int slot, int mode, std::string* err) {
+                       int64_t out_rows_per_rank, int slot, int mode, bool packed, std::string* err) {
   if (slot < 0 || slot > 1) return comm_fail(err, SURGE_E_INVALID, "slot must be 0 or 1");
   if (n_local < 0 || (n_local > 0 && !d_states) || !d_out) return comm_fail(err, SURGE_E_INVALID, "bad argument");
   int32_t rc = exchange_counts(c, n_local, err);
@@ -258,6 +258,32 @@ int32_t comm_allgather(CommState* c, hipStream_t compute, const void* d_states, 
   if (out_rows_per_rank < c->max_count)
     return comm_fail(err, SURGE_E_RANGE, "d_out holds fewer rows per rank than the largest shard (see surge_replay_comm_counts)");
   const int64_t M = c->max_count;
+  if (!packed) {
+    // v2 slot schemas use all 64 bytes of a state: shards travel as they are, straight between the state arrays
+    // (grouped per-peer send / recv; rows beyond a rank's count are zeroed first so they read as None)
+    COMM_HIP(hipEventRecord(c->ready, compute));
+    COMM_HIP(hipStreamWaitEvent(c->side, c->ready, 0));
+    char* out = (char*)d_out;
+    const size_t pitch = (size_t)out_rows_per_rank * 64;
+    COMM_HIP(hipMemsetAsync(out, 0, (size_t)c->world * pitch, c->side));
+    if (n_local > 0) COMM_HIP(hipMemcpyAsync(out + (size_t)c->rank * pitch, d_states, (size_t)n_local * 64, hipMemcpyDeviceToDevice, c->side));
+    if (c->world > 1) {
+      COMM_NCCL(c, c->api->GroupStart());
+      ncclResult_t r = ncclSuccess;
+      for (int d = 1; d < c->world && r == ncclSuccess; ++d) {
+        const int to = (c->rank + d) % c->world, frm = (c->rank - d + c->world) % c->world;
+        const size_t sb = (size_t)n_local * 64, rb = (size_t)c->counts[(size_t)frm] * 64;
+        if (sb) r = c->api->Send(d_states, sb, ncclUint8, to, c->comm, c->side);
+        if (r == ncclSuccess && rb) r = c->api->Recv(out + (size_t)frm * pitch, rb, ncclUint8, frm, c->comm, c->side);
+      }
+      const ncclResult_t g = c->api->GroupEnd();
+      if (r != ncclSuccess) return comm_fail(err, SURGE_E_COMM, std::string("ncclSend/ncclRecv: ") + c->api->GetErrorString(r));
+      if (g != ncclSuccess) return comm_fail(err, SURGE_E_COMM, std::string("ncclGroupEnd: ") + c->api->GetErrorString(g));
+    }
+    COMM_HIP(hipEventRecord(c->done[slot], c->side));
+    c->launched[slot] = true;
+    return SURGE_OK;
+  }
   rc = reserve_dev(&c->d_wire_local, &c->wire_local_cap, (size_t)(M > 0 ? M : 1) * SURGE_PACKED_STATE_SIZE, err);
   if (rc != SURGE_OK) return rc;
   rc = reserve_dev(&c->d_wire_all, &c->wire_all_cap, (size_t)c->world * (size_t)(M > 0 ? M : 1) * SURGE_PACKED_STATE_SIZE, err);

@@ -58,6 +58,9 @@ struct surge_replay_handle {
   int n_cus = 256;
   hipStream_t stream = nullptr;
   surge_replay_schema schema{};
+  bool v2 = false;                     // ABI v2 slot schema: folds only through fold_slots.hip
+  surge_replay_schema_v2 schema2{};
+  alignas(16) unsigned char slot_params[kSlotParamsBytes] = {};
   std::string err;
   std::mutex err_mu;  // concurrent point readers may fail at the same time
 
@@ -294,6 +297,65 @@ int32_t run_flat(surge_replay_handle* h, FoldParams& p, const int64_t* off, int6
   return SURGE_OK;
 }
 
+// v2: length-sort the kernel-facing segments (once per bound log / per micro-batch), then one lane per segment
+int32_t run_slots(surge_replay_handle* h, FoldParams& p, const int64_t* off, int64_t n_seg, bool cache_perm) {
+  if (!cache_perm || !h->perm_valid) {
+    HIPCHK(h, h->perm.reserve((size_t)(n_seg > 0 ? n_seg : 1) * 8));
+    HIPCHK(h, h->sort_hist.reserve((size_t)kSortBucketsHost * 8));
+    HIPCHK(h, h->counter.reserve(8));
+    HIPCHK(h, launch_sort_by_length(off, n_seg, (unsigned long long*)h->sort_hist.ptr, (int64_t*)h->perm.ptr, h->stream));
+    h->perm_valid = cache_perm;
+  }
+  p.seg_off = off;
+  p.plan = (const int64_t*)h->perm.ptr;
+  p.counter = (unsigned long long*)h->counter.ptr;
+  p.n_seg = n_seg;
+  const int64_t groups = (n_seg + kWave - 1) / kWave;
+  const int64_t slots = (int64_t)h->n_cus * 8;
+  const int64_t n_waves = groups < slots ? groups : slots;
+  hipEvent_t e0, e1;
+  const int32_t rc = next_fold_events(h, &e0, &e1);
+  if (rc != SURGE_OK) return rc;
+  HIPCHK(h, hipEventRecord(e0, h->stream));
+  HIPCHK(h, launch_fold_slots(p, *(const SlotParams*)h->slot_params, n_waves, h->stream));
+  HIPCHK(h, hipEventRecord(e1, h->stream));
+  h->st.n_tasks = (int32_t)n_waves;
+  return SURGE_OK;
+}
+
+int32_t fold_slots_bound(surge_replay_handle* h) {
+  FoldParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.events = h->d_events;
+  p.n_events = h->n_events;
+  p.init = h->d_init;
+  p.out = h->d_state;
+  const int64_t span = h->an.last - h->an.first;
+  HIPCHK(h, hipEventRecord(h->ev_total0, h->stream));
+  h->st.n_tasks = 0;
+  if (h->n_agg > 0 && span > 0) {
+    if (h->an.max_len >= (1ll << 31)) return fail(h, SURGE_E_UNSUPPORTED, "segments must be shorter than 2^31 events");
+    const bool nz = h->an.n_empty > 0;
+    if (nz) p.out_map = (const int64_t*)h->nz_map.ptr;
+    const int32_t rc = run_slots(h, p, nz ? (const int64_t*)h->nz_off.ptr : h->d_seg_off, nz ? h->n_nz : h->n_agg, true);
+    if (rc != SURGE_OK) return rc;
+  } else {
+    hipEvent_t e0, e1;
+    const int32_t rc = next_fold_events(h, &e0, &e1);
+    if (rc != SURGE_OK) return rc;
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+  }
+  if (h->an.n_empty > 0 || span == 0) HIPCHK(h, launch_fill_empty(h->d_seg_off, h->n_agg, h->d_init, h->d_state, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_total1, h->stream));
+  h->timing_valid = true;
+  h->st.last_algo = SURGE_ALGO_SLOTS;
+  h->st.n_folds += 1;
+  h->st.n_poisoned = -1;
+  h->fold_epoch.fetch_add(1);
+  return SURGE_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -353,6 +415,37 @@ int32_t surge_replay_create(const surge_replay_schema* schema, int32_t device_id
   }
   h->st.n_poisoned = -1;
   *out = h;
+  return SURGE_OK;
+}
+
+int32_t surge_replay_create_v2(const surge_replay_schema_v2* sc, int32_t device_id, surge_replay_handle** out) {
+  if (!out) return fail(nullptr, SURGE_E_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!sc) return fail(nullptr, SURGE_E_INVALID, "schema is NULL");
+  if (sc->abi_version != SURGE_REPLAY_ABI_VERSION_2) return fail(nullptr, SURGE_E_UNSUPPORTED, "schema.abi_version is not 2");
+  if (sc->state_size != 64 || sc->event_size != 16) return fail(nullptr, SURGE_E_UNSUPPORTED, "only 64-byte states and 16-byte events are supported");
+  if (sc->n_types < 1 || sc->n_types > SURGE_MAX_EVENT_TYPES) return fail(nullptr, SURGE_E_INVALID, "schema.n_types out of range");
+  if (sc->n_slots < 1 || sc->n_slots > SURGE_MAX_SLOTS) return fail(nullptr, SURGE_E_INVALID, "schema.n_slots out of range");
+  if (sc->flags & ~SURGE_V2_COUNT_EVENTS) return fail(nullptr, SURGE_E_UNSUPPORTED, "schema.flags uses unknown bits");
+  for (uint32_t i = 0; i < sc->n_slots; ++i) {
+    if (sc->slot[i].type < SURGE_SLOT_I32 || sc->slot[i].type > SURGE_SLOT_F64) return fail(nullptr, SURGE_E_UNSUPPORTED, "unknown slot type");
+    if (sc->slot[i].source > SURGE_SRC_ONE) return fail(nullptr, SURGE_E_UNSUPPORTED, "unknown operand source");
+  }
+  for (uint32_t t = 0; t < sc->n_types; ++t) {
+    if (sc->cls[t] & ~(SURGE_CLS_MASK | SURGE_D_POISON)) return fail(nullptr, SURGE_E_UNSUPPORTED, "cls uses unknown bits");
+    for (uint32_t i = 0; i < 8; ++i) {
+      const uint32_t op = (sc->ops[t] >> (4 * i)) & 15u;
+      if (op > SURGE_OP_MAX) return fail(nullptr, SURGE_E_UNSUPPORTED, "unknown slot operation");
+      if (i >= sc->n_slots && op != SURGE_OP_KEEP) return fail(nullptr, SURGE_E_INVALID, "operation on a slot the schema does not declare");
+    }
+  }
+  surge_replay_schema v1;
+  surge_replay_default_schema(&v1);  // the handle's v1 half is inert; every fold of a v2 handle goes through the slot kernel
+  const int32_t rc = surge_replay_create(&v1, device_id, out);
+  if (rc != SURGE_OK) return rc;
+  (*out)->v2 = true;
+  (*out)->schema2 = *sc;
+  slot_params_from_schema(*sc, (SlotParams*)(*out)->slot_params);
   return SURGE_OK;
 }
 
@@ -463,8 +556,12 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
   if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
   if (!h->bound) return fail(h, SURGE_E_STATE, "fold before load_csr/bind_device_csr");
   if (!h->log_valid) return fail(h, SURGE_E_STATE, "the resident state was grown past the bound log (surge_replay_grow): load a log again");
-  if (algo < SURGE_ALGO_AUTO || algo > SURGE_ALGO_CHUNKED) return fail(h, SURGE_E_INVALID, "unknown algo");
+  if (algo < SURGE_ALGO_AUTO || algo > SURGE_ALGO_SLOTS) return fail(h, SURGE_E_INVALID, "unknown algo");
+  if (h->v2 != (algo == SURGE_ALGO_SLOTS) && !(h->v2 && algo == SURGE_ALGO_AUTO))
+    return fail(h, SURGE_E_UNSUPPORTED, h->v2 ? "a v2 slot schema folds with SURGE_ALGO_AUTO / SURGE_ALGO_SLOTS only"
+                                               : "SURGE_ALGO_SLOTS needs a handle created with surge_replay_create_v2");
   DeviceGuard g(h->device);
+  if (h->v2) return fold_slots_bound(h);
   const int64_t span = h->an.last - h->an.first;
   const bool uniform = h->n_agg > 0 && !h->an.nonuniform && h->an.n_empty == 0 && h->an.len0 > 0 &&
                        (h->an.len0 % 16) == 0 && h->an.len0 < (1ll << 31) && h->an.first == 0;
@@ -680,11 +777,13 @@ int32_t surge_replay_append_fold_device(surge_replay_handle* h, const int64_t* d
   p.out = h->d_state;
   p.out_map = d_group_agg;
   HIPCHK(h, hipEventRecord(h->ev_total0, h->stream));
-  const int32_t rc = run_flat(h, p, d_group_off, n_groups, n_events);
+  if (h->v2) std::memset(p.table, 0, sizeof(p.table));
+  const int32_t rc = h->v2 ? run_slots(h, p, d_group_off, n_groups, false) : run_flat(h, p, d_group_off, n_groups, n_events);
   if (rc != SURGE_OK) return rc;
+  if (h->v2) h->perm_valid = false;  // the length order of the micro-batch replaced the bound log's
   HIPCHK(h, hipEventRecord(h->ev_total1, h->stream));
   h->timing_valid = true;
-  h->st.last_algo = SURGE_ALGO_FLAT;
+  h->st.last_algo = h->v2 ? SURGE_ALGO_SLOTS : SURGE_ALGO_FLAT;
   h->st.n_folds += 1;
   h->st.n_poisoned = -1;
   h->fold_epoch.fetch_add(1);
@@ -939,7 +1038,7 @@ int32_t surge_replay_snapshot_delta(surge_replay_handle* h, uint8_t* d_kind_out,
   }
   HIPCHK(h, h->poison_count.reserve(16));
   HIPCHK(h, launch_snapshot_delta(h->d_state, (uint4*)h->published.ptr, h->n_agg, d_kind_out, (unsigned long long*)h->poison_count.ptr,
-                                  commit != 0, h->stream));
+                                  commit != 0, h->v2, h->stream));
   unsigned long long c[2] = {0, 0};
   HIPCHK(h, hipMemcpyAsync(c, h->poison_count.ptr, 16, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1200,7 +1299,7 @@ int32_t surge_replay_allgather_snapshot(surge_replay_handle* h, const void* d_st
     h->gathered_rows[slot] = mx;
     d_out = h->gathered[slot].ptr;
   }
-  const int32_t rc = comm_allgather(h->comm, h->stream, d_states, n_local, d_out, rows_per_rank, slot, mode, &err);
+  const int32_t rc = comm_allgather(h->comm, h->stream, d_states, n_local, d_out, rows_per_rank, slot, mode, !h->v2, &err);
   return rc == SURGE_OK ? rc : fail(h, rc, err);
 }
 

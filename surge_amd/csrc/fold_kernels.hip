@@ -940,6 +940,7 @@ __global__ void gather_states_kernel(const uint4* __restrict__ states, const int
 // snapshot delta: kind[a] = what the state topic needs for aggregate a relative to the last committed snapshot
 // ("publish only if the state changed", PersistentActor.scala:212,257): unchanged or poisoned -> SKIP, Some -> VALUE,
 // Some -> None -> TOMBSTONE.  counts[0] += values, counts[1] += tombstones.
+template <bool FULL64>
 __global__ void snapshot_delta_kernel(const uint4* __restrict__ states, const uint4* __restrict__ published, int64_t n,
                                       uint8_t* __restrict__ kind, unsigned long long* __restrict__ counts) {
   const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -947,8 +948,12 @@ __global__ void snapshot_delta_kernel(const uint4* __restrict__ states, const ui
   if (a < n) {
     const uint4 s0 = states[a * 4], s1 = states[a * 4 + 1], s2 = states[a * 4 + 2];
     const uint4 p0 = published[a * 4], p1 = published[a * 4 + 1], p2 = published[a * 4 + 2];
-    const bool same = s0.x == p0.x && s0.y == p0.y && s0.z == p0.z && s0.w == p0.w && s1.x == p1.x && s1.y == p1.y && s1.z == p1.z &&
-                      s1.w == p1.w && s2.x == p2.x && s2.y == p2.y;  // bytes 0..39 carry the state (the tail is always zero)
+    bool same = s0.x == p0.x && s0.y == p0.y && s0.z == p0.z && s0.w == p0.w && s1.x == p1.x && s1.y == p1.y && s1.z == p1.z &&
+                s1.w == p1.w && s2.x == p2.x && s2.y == p2.y;  // v1: bytes 0..39 carry the state (the tail is always zero)
+    if (FULL64) {  // v2 slot schemas use all 64 bytes
+      const uint4 s3 = states[a * 4 + 3], p3 = published[a * 4 + 3];
+      same = same && s2.z == p2.z && s2.w == p2.w && s3.x == p3.x && s3.y == p3.y && s3.z == p3.z && s3.w == p3.w;
+    }
     const bool poisoned = (s2.y & FL_POISONED) != 0u;
     if (!same && !poisoned) k = (s2.y & FL_PRESENT) ? SURGE_SNAP_VALUE : SURGE_SNAP_TOMBSTONE;
     kind[a] = (uint8_t)k;
@@ -1140,10 +1145,13 @@ hipError_t launch_gather_states(const uint4* states, const int64_t* idx, int64_t
 }
 
 hipError_t launch_snapshot_delta(const uint4* states, uint4* published, int64_t n, uint8_t* kind, unsigned long long* d_counts,
-                                 bool commit, hipStream_t stream) {
+                                 bool commit, bool full64, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(d_counts, 0, 16, stream);
   if (e != hipSuccess || n <= 0) return e;
-  hipLaunchKernelGGL(snapshot_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, states, published, n, kind, d_counts);
+  if (full64)
+    hipLaunchKernelGGL(snapshot_delta_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, states, published, n, kind, d_counts);
+  else
+    hipLaunchKernelGGL(snapshot_delta_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, states, published, n, kind, d_counts);
   if (commit)
     hipLaunchKernelGGL(snapshot_commit_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, stream, states, published, n, kind);
   return hipGetLastError();

@@ -114,7 +114,13 @@ hipError_t launch_json_encode(const surge_json_template& tmpl, const uint4* stat
                               uint32_t envelope, const uint8_t* filter, hipStream_t stream);
 // kind[a] in SURGE_SNAP_*; d_counts: two u64 {values, tombstones}; commit: published := states where kind != SKIP
 hipError_t launch_snapshot_delta(const uint4* states, uint4* published, int64_t n, uint8_t* kind, unsigned long long* d_counts,
-                                 bool commit, hipStream_t stream);
+                                 bool commit, bool full64, hipStream_t stream);
+
+// ---- fold_slots.hip: the fold of ABI v2 slot schemas ------------------------------------------------------------
+struct SlotParams;
+constexpr size_t kSlotParamsBytes = 512;  // >= sizeof(SlotParams): the engine keeps it as opaque storage
+void slot_params_from_schema(const surge_replay_schema_v2& sc, SlotParams* out);
+hipError_t launch_fold_slots(const FoldParams& p, const SlotParams& sp, int64_t n_waves, hipStream_t stream);
 // unpack == false: in = n x 64 B, out = n x 40 B; unpack == true: in = n x 40 B, out = n x 64 B
 hipError_t launch_pack_states(const void* in, int64_t n, void* out, bool unpack, hipStream_t stream);
 hipError_t launch_gather_states(const uint4* states, const int64_t* idx, int64_t n, uint4* out, hipStream_t stream);
@@ -137,7 +143,7 @@ void comm_destroy(CommState* c);
 int32_t comm_info(const CommState* c, int32_t* rank, int32_t* world, int32_t* version, const char** library);
 int32_t comm_counts(CommState* c, int64_t n_local, int64_t* counts_out, int64_t* max_count_out, std::string* err);
 int32_t comm_allgather(CommState* c, hipStream_t compute, const void* d_states, int64_t n_local, void* d_out,
-                       int64_t out_rows_per_rank, int slot, int mode, std::string* err);
+                       int64_t out_rows_per_rank, int slot, int mode, bool packed, std::string* err);
 int32_t comm_wait(CommState* c, hipStream_t compute, int slot, bool host, std::string* err);
 
 }  // namespace surge

@@ -67,17 +67,21 @@ def default_schema_from_library() -> CSchema:
 class ReplayEngine:
     """One handle = one GPU = one shard of the event log."""
 
-    def __init__(self, algebra: EventAlgebra = DEFAULT_ALGEBRA, device: int = 0):
+    def __init__(self, algebra=DEFAULT_ALGEBRA, device: int = 0):
+        """``algebra``: an ``EventAlgebra`` (ABI v1: the seven named fields) or a ``SlotAlgebra`` (ABI v2: typed slots)."""
         self._lib = _native.load()
         self._h = ctypes.c_void_p()
         self.algebra = algebra
         self.device = device
         sc = algebra.to_c()
-        rc = self._lib.surge_replay_create(ctypes.byref(sc), device, ctypes.byref(self._h))
+        self.v2 = getattr(sc, "abi_version", 1) == 2  # a SlotAlgebra (ABI v2 slot schema)
+        create = self._lib.surge_replay_create_v2 if self.v2 else self._lib.surge_replay_create
+        rc = create(ctypes.byref(sc), device, ctypes.byref(self._h))
         if rc != 0:
             msg = self._lib.surge_replay_last_error(None)
             raise ReplayError(rc, msg.decode() if msg else "surge_replay_create failed")
         self.n_agg = 0
+        self.state_dtype = algebra.state_dtype() if self.v2 else STATE_DTYPE  # numpy view of one 64-byte state
         self._keep = []  # tensors bound zero-copy must outlive the binding
 
     # -- lifecycle -------------------------------------------------------------------------
@@ -141,7 +145,7 @@ class ReplayEngine:
             if n_agg < 0:
                 raise ValueError("seg_off needs at least one entry")
             if init_state is not None:
-                init_state = np.ascontiguousarray(init_state, dtype=STATE_DTYPE)
+                init_state = np.ascontiguousarray(init_state, dtype=self.state_dtype)
                 if init_state.shape[0] != n_agg:
                     raise ValueError("init_state must have one entry per aggregate")
             self._keep = []
@@ -202,26 +206,26 @@ class ReplayEngine:
 
     # -- read --------------------------------------------------------------------------------------
     def snapshot(self) -> np.ndarray:
-        out = np.zeros(self.n_agg, dtype=STATE_DTYPE)
+        out = np.zeros(self.n_agg, dtype=self.state_dtype)
         self._check(self._lib.surge_replay_snapshot(self._h, _np_ptr(out), None))
         return out
 
     def get(self, agg_idx: int) -> Optional[np.ndarray]:
         """Fixed-width state of one aggregate, or ``None`` when it is absent (KTable miss)."""
-        out = np.zeros(1, dtype=STATE_DTYPE)
+        out = np.zeros(1, dtype=self.state_dtype)
         present = ctypes.c_uint8(0)
         self._check(self._lib.surge_replay_get(self._h, int(agg_idx), _np_ptr(out), ctypes.byref(present)))
         return out[0] if present.value else None
 
     def get_raw(self, agg_idx: int) -> np.ndarray:
-        out = np.zeros(1, dtype=STATE_DTYPE)
+        out = np.zeros(1, dtype=self.state_dtype)
         self._check(self._lib.surge_replay_get(self._h, int(agg_idx), _np_ptr(out), None))
         return out[0]
 
     def gather(self, agg_idx) -> np.ndarray:
         """Fixed-width states of the listed aggregates (bulk point read)."""
         idx = np.ascontiguousarray(agg_idx, dtype=np.int64)
-        out = np.zeros(idx.shape[0], dtype=STATE_DTYPE)
+        out = np.zeros(idx.shape[0], dtype=self.state_dtype)
         self._check(self._lib.surge_replay_gather(self._h, _np_ptr(idx), idx.shape[0], _np_ptr(out)))
         return out
 

@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import ctypes
 from dataclasses import dataclass, field
-from typing import Sequence
+from typing import Dict, Tuple, Union, Sequence
 
 import numpy as np
 
@@ -184,6 +184,87 @@ DEFAULT_ALGEBRA = EventAlgebra(
     ),
     names=("NOOP", "INC", "DEC", "CREATE", "SET_BALANCE", "DELETE", "THROW"),
 )
+
+
+# ---- ABI v2: slot schemas (include/surge_replay.h) ---------------------------------------------------------------
+SLOT_I32, SLOT_I64, SLOT_F64 = 1, 2, 3
+SRC_ARG, SRC_SEQ, SRC_PAYLOAD, SRC_ONE = 0, 1, 2, 3
+OP_KEEP, OP_ADD, OP_SUB, OP_SET, OP_MIN, OP_MAX = 0, 1, 2, 3, 4, 5
+MAX_SLOTS = 7
+ALGO_SLOTS = 6
+V2_COUNT_EVENTS = 1
+
+
+def slot_offset(i: int) -> int:
+    """Byte offset of slot ``i`` in the 64-byte state (``SURGE_SLOT_OFFSET``)."""
+    return 8 * i if i < 4 else 8 * i + 8
+
+
+class _CSlotDef(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_uint8), ("source", ctypes.c_uint8), ("reserved", ctypes.c_uint8 * 6), ("default_bits", ctypes.c_uint64)]
+
+
+class CSchemaV2(ctypes.Structure):
+    _fields_ = [("abi_version", ctypes.c_uint32), ("state_size", ctypes.c_uint32), ("event_size", ctypes.c_uint32),
+                ("n_types", ctypes.c_uint32), ("n_slots", ctypes.c_uint32), ("flags", ctypes.c_uint32),
+                ("slot", _CSlotDef * MAX_SLOTS), ("cls", ctypes.c_uint32 * MAX_EVENT_TYPES), ("ops", ctypes.c_uint32 * MAX_EVENT_TYPES)]
+
+
+@dataclass(frozen=True)
+class Slot:
+    """One typed 8-byte slot of a v2 state: its value type, where its operand comes from, its default."""
+
+    name: str
+    type: int
+    source: int
+    default: Union[int, float] = 0
+
+    def default_bits(self) -> int:
+        if self.type == SLOT_F64:
+            return int(np.float64(self.default).view(np.uint64))
+        return int(self.default) & (0xFFFFFFFF if self.type == SLOT_I32 else 0xFFFFFFFFFFFFFFFF)
+
+
+@dataclass(frozen=True)
+class SlotAlgebra:
+    """ABI v2 declaration of a model's ``handleEvent``: ``slots`` and, per event type, ``(cls, {slot name: op})``."""
+
+    slots: Sequence[Slot]
+    types: Sequence[Tuple[int, Dict[str, int]]]
+    count_events: bool = False
+    names: Sequence[str] = field(default_factory=tuple)
+
+    def __post_init__(self):
+        if not 1 <= len(self.slots) <= MAX_SLOTS or not 1 <= len(self.types) <= MAX_EVENT_TYPES:
+            raise ValueError(f"a slot algebra has 1..{MAX_SLOTS} slots and 1..{MAX_EVENT_TYPES} event types")
+
+    def to_c(self) -> CSchemaV2:
+        s = CSchemaV2()
+        s.abi_version, s.state_size, s.event_size = 2, STATE_SIZE, EVENT_SIZE
+        s.n_types, s.n_slots, s.flags = len(self.types), len(self.slots), V2_COUNT_EVENTS if self.count_events else 0
+        index = {}
+        for i, sl in enumerate(self.slots):
+            s.slot[i].type, s.slot[i].source, s.slot[i].default_bits = sl.type, sl.source, sl.default_bits()
+            index[sl.name] = i
+        for t, (cls, ops) in enumerate(self.types):
+            s.cls[t] = cls
+            word = 0
+            for name, op in ops.items():
+                word |= (op & 15) << (4 * index[name])
+            s.ops[t] = word
+        return s
+
+    def state_dtype(self) -> np.dtype:
+        """numpy view of a v2 state: one field per slot (at its offset), ``event_count`` and ``flags``."""
+        names, formats, offsets = [], [], []
+        for i, sl in enumerate(self.slots):
+            names.append(sl.name)
+            formats.append({SLOT_I32: "<i4", SLOT_I64: "<i8", SLOT_F64: "<f8"}[sl.type])
+            offsets.append(slot_offset(i))
+        names += ["event_count", "flags"]
+        formats += ["<u4", "<u4"]
+        offsets += [32, 36]
+        return np.dtype({"names": names, "formats": formats, "offsets": offsets, "itemsize": 64})
 
 
 def empty_states(n: int) -> np.ndarray:
