@@ -85,7 +85,12 @@ def main():
     if bench_line:
         json.dump(bench_line, open(os.path.join(out, f"{tag}_bench.json"), "w"))
         roof = bench_line["roofline"]
-        parts = [p.split("<")[0].strip() for p in roof["kernel"].split("+")]
+        parts = []
+        for lbl in roof["kernel"].split("+"):
+            name = lbl.split("<")[0].strip()
+            if name == "fold_kernel":
+                name = "fold_kernel<FLAT>" if "FLAT" in lbl else "fold_kernel<FIXED>"
+            parts.append(name)
         fetch = sum(avg.get(p, {}).get("FETCH_SIZE", 0.0) for p in parts)
         write = sum(avg.get(p, {}).get("WRITE_SIZE", 0.0) for p in parts)
         if fetch > 0:
