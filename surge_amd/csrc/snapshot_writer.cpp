@@ -3,7 +3,10 @@
 #include <cstdint>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "../../include/surge_ingest.h"    // surge_crc32c
@@ -131,6 +134,9 @@ int32_t surge_snapshot_writer_append(surge_snapshot_writer* w, int64_t n, const 
   if (!partition || !key_off) return fail(w, E_INVALID, "NULL buffer");
   const int32_t P = (int32_t)w->parts.size();
   try {
+    // pass 1 (validation + a counting sort of the published indices by partition): partitions are independent logs,
+    // so pass 2 frames them on several host threads, each partition's records still in index order
+    std::vector<int64_t> start((size_t)P + 1, 0);
     for (int64_t i = 0; i < n; ++i) {
       const uint8_t k = kind ? kind[i] : (uint8_t)SURGE_SNAP_VALUE;
       if (k == SURGE_SNAP_SKIP) continue;
@@ -139,39 +145,81 @@ int32_t surge_snapshot_writer_append(surge_snapshot_writer* w, int64_t n, const 
       if (pi < 0 || pi >= P) return fail(w, E_RANGE, "partition out of range");
       const int64_t klen = key_off[i + 1] - key_off[i];
       if (klen < 0 || (klen > 0 && !keys_utf8)) return fail(w, E_INVALID, "bad key span");
-      int64_t vlen = -1;
       if (k == SURGE_SNAP_VALUE) {
         if (!val_off) return fail(w, E_INVALID, "values expected");
-        vlen = val_off[i + 1] - val_off[i];
+        const int64_t vlen = val_off[i + 1] - val_off[i];
         if (vlen < 0 || (vlen > 0 && !values)) return fail(w, E_INVALID, "bad value span");
       }
+      start[(size_t)pi + 1] += 1;
+    }
+    for (int32_t p = 0; p < P; ++p) start[(size_t)p + 1] += start[(size_t)p];
+    const int64_t total = start[(size_t)P];
+    if (total == 0) return OK;
+    std::vector<int64_t> order((size_t)total);
+    {
+      std::vector<int64_t> cur(start.begin(), start.end() - 1);
+      for (int64_t i = 0; i < n; ++i)
+        if (!kind || kind[i] != SURGE_SNAP_SKIP) order[(size_t)cur[(size_t)partition[i]]++] = i;
+    }
+    auto encode_partition = [&](int32_t pi) {
       PartitionLog& p = w->parts[(size_t)pi];
-      if (p.open_records == 0) {
-        p.base_offset = p.next_offset;
-        p.base_ts = p.max_ts = timestamp_ms;
+      for (int64_t r = start[(size_t)pi]; r < start[(size_t)pi + 1]; ++r) {
+        const int64_t i = order[(size_t)r];
+        const uint8_t k = kind ? kind[i] : (uint8_t)SURGE_SNAP_VALUE;
+        const int64_t klen = key_off[i + 1] - key_off[i];
+        const int64_t vlen = k == SURGE_SNAP_VALUE ? val_off[i + 1] - val_off[i] : -1;
+        if (p.open_records == 0) {
+          p.base_offset = p.next_offset;
+          p.base_ts = p.max_ts = timestamp_ms;
+        }
+        if (timestamp_ms > p.max_ts) p.max_ts = timestamp_ms;
+        const int64_t off_delta = p.next_offset - p.base_offset, ts_delta = timestamp_ms - p.base_ts;
+        // record body: attributes, timestampDelta, offsetDelta, key, value, header count
+        const int64_t body = 1 + varlong_size(ts_delta) + varlong_size(off_delta) + varlong_size(klen) + klen +
+                             varlong_size(vlen) + (vlen > 0 ? vlen : 0) + 1;
+        std::vector<uint8_t>& o = p.open;
+        put_varlong(o, body);
+        o.push_back(0);
+        put_varlong(o, ts_delta);
+        put_varlong(o, off_delta);
+        put_varlong(o, klen);
+        if (klen > 0) o.insert(o.end(), keys_utf8 + key_off[i], keys_utf8 + key_off[i + 1]);
+        put_varlong(o, vlen);
+        if (vlen > 0) o.insert(o.end(), values + val_off[i], values + val_off[i + 1]);
+        put_varlong(o, 0);
+        p.next_offset += 1;
+        p.open_records += 1;
+        p.n_records += 1;
+        if (p.open_records >= w->max_records || (int64_t)o.size() >= w->max_bytes) close_batch(p);
       }
-      if (timestamp_ms > p.max_ts) p.max_ts = timestamp_ms;
-      const int64_t off_delta = p.next_offset - p.base_offset, ts_delta = timestamp_ms - p.base_ts;
-      // record body: attributes, timestampDelta, offsetDelta, key, value, header count
-      const int64_t body = 1 + varlong_size(ts_delta) + varlong_size(off_delta) + varlong_size(klen) + klen +
-                           varlong_size(vlen) + (vlen > 0 ? vlen : 0) + 1;
-      std::vector<uint8_t>& o = p.open;
-      put_varlong(o, body);
-      o.push_back(0);
-      put_varlong(o, ts_delta);
-      put_varlong(o, off_delta);
-      put_varlong(o, klen);
-      if (klen > 0) o.insert(o.end(), keys_utf8 + key_off[i], keys_utf8 + key_off[i + 1]);
-      put_varlong(o, vlen);
-      if (vlen > 0) o.insert(o.end(), values + val_off[i], values + val_off[i + 1]);
-      put_varlong(o, 0);
-      p.next_offset += 1;
-      p.open_records += 1;
-      p.n_records += 1;
-      if (p.open_records >= w->max_records || (int64_t)o.size() >= w->max_bytes) close_batch(p);
+    };
+    unsigned hw = std::thread::hardware_concurrency();
+    int n_threads = (int)(hw ? hw : 1);
+    if (n_threads > 16) n_threads = 16;
+    if (n_threads > P) n_threads = P;
+    if (total < 50000) n_threads = 1;  // not worth a thread start
+    if (n_threads <= 1) {
+      for (int32_t p = 0; p < P; ++p) encode_partition(p);
+    } else {
+      (void)surge_crc32c((const uint8_t*)"", 0);  // initialise the CRC dispatch / tables before the threads race for them
+      std::atomic<int32_t> next{0};
+      std::atomic<bool> oom{false};
+      auto worker = [&]() {
+        try {
+          for (int32_t p = next.fetch_add(1); p < P; p = next.fetch_add(1)) encode_partition(p);
+        } catch (const std::bad_alloc&) {
+          oom = true;
+        }
+      };
+      std::vector<std::thread> th;
+      for (int t = 0; t < n_threads; ++t) th.emplace_back(worker);
+      for (std::thread& t : th) t.join();
+      if (oom) return fail(w, E_NOMEM, "out of host memory while encoding");
     }
   } catch (const std::bad_alloc&) {
     return fail(w, E_NOMEM, "out of host memory while encoding");
+  } catch (const std::system_error&) {
+    return fail(w, E_NOMEM, "could not start an encoder thread");
   }
   return OK;
 }

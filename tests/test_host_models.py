@@ -188,3 +188,51 @@ def test_formats_round_trip_and_match_oracle_json_text():
     msg = bl.event_write_formatting().write_event(CountIncremented("stateKey1", 1, 4))
     assert msg.key == "stateKey1:4"  # TestBoundedContext.scala:123
     assert bl.event_write_formatting().read_event(msg) == CountIncremented("stateKey1", 1, 4)
+
+
+# ---- the other model flavours that compile to the same core (R4) -----------------------------------
+def test_event_only_batched_and_java_models_fold_like_the_scala_command_model():
+    import random
+
+    from surge_amd.command import AggregateEventModel, BatchedAggregateCommandModel, JavaAggregateCommandModel, Optional_
+    from surge_amd.core import SurgeContext
+    from surge_amd.fixtures import CounterCommandModel, CountDecremented, CountIncremented, Increment, NoOpEvent, State
+
+    scala = CounterCommandModel()
+
+    class EventOnly(AggregateEventModel):  # AggregateEventModel.scala:10-22
+        def handle_events(self, state, events):
+            for e in events:
+                state = scala.handle_event(state, e)
+            return state
+
+    class Batched(BatchedAggregateCommandModel):  # AsyncAggregateCommandModel, CommandModels.scala:33-57
+        def process_command(self, agg, cmd):
+            return scala.process_command(agg, cmd)
+
+        def handle_events(self, agg, events):
+            return EventOnly().handle_events(agg, events)
+
+    class Java(JavaAggregateCommandModel):  # javadsl CommandModels.scala:17-40, over Optional
+        def process_command(self, agg, cmd):
+            return scala.process_command(agg.or_else(None), cmd)
+
+        def handle_event(self, agg, evt):
+            return Optional_.of_nullable(scala.handle_event(agg.or_else(None), evt))
+
+    rng = random.Random(3)
+    for _ in range(50):
+        events = []
+        for seq in range(1, rng.randrange(1, 30)):
+            events.append(rng.choice([CountIncremented("a", rng.randrange(9), seq), CountDecremented("a", rng.randrange(9), seq), NoOpEvent("a", seq)]))
+        start = rng.choice([None, State("a", 3, 3)])
+        want = scala.to_core().apply_async(SurgeContext(state=start), start, events).state
+        for model in (EventOnly(), Batched(), Java()):
+            assert model.to_core().apply_async(SurgeContext(state=start), start, events).state == want
+    # commands: the batched and the Java model persist the same events and reach the same state; the event-only model refuses
+    for model in (Batched(), Java()):
+        ctx = model.to_core().handle(SurgeContext(state=State("a", 3, 3)), State("a", 3, 3), Increment("a"))
+        assert ctx.state == State("a", 4, 4) and [e for e, _ in ctx.events] == [CountIncremented("a", 1, 4)]
+    with pytest.raises(NotImplementedError):
+        EventOnly().to_core().handle(SurgeContext(), None, Increment("a"))
+    assert Optional_.empty() == Optional_.of_nullable(None) and Optional_.of(5).get() == 5 and not Optional_.empty().is_present()
