@@ -311,13 +311,17 @@ int32_t run_slots(surge_replay_handle* h, FoldParams& p, const int64_t* off, int
   p.counter = (unsigned long long*)h->counter.ptr;
   p.n_seg = n_seg;
   const int64_t groups = (n_seg + kWave - 1) / kWave;
-  const int64_t slots = (int64_t)h->n_cus * 8;
+  // the interpreter is VALU-bound and light on registers (93 VGPRs): 8 KiB tiles and as many resident waves as LDS allows
+  const int le = env_lane_events("SURGE_REPLAY_LE_SLOTS", 8) == 16 ? 16 : 8;
+  int64_t per_cu = le == 8 ? 14 : 8;
+  if (const char* v = std::getenv("SURGE_REPLAY_SLOTS_WAVES")) per_cu = std::atoi(v) > 0 ? std::atoi(v) : per_cu;
+  const int64_t slots = (int64_t)h->n_cus * per_cu;
   const int64_t n_waves = groups < slots ? groups : slots;
   hipEvent_t e0, e1;
   const int32_t rc = next_fold_events(h, &e0, &e1);
   if (rc != SURGE_OK) return rc;
   HIPCHK(h, hipEventRecord(e0, h->stream));
-  HIPCHK(h, launch_fold_slots(p, *(const SlotParams*)h->slot_params, n_waves, h->stream));
+  HIPCHK(h, launch_fold_slots(p, *(const SlotParams*)h->slot_params, n_waves, le, h->stream));
   HIPCHK(h, hipEventRecord(e1, h->stream));
   h->st.n_tasks = (int32_t)n_waves;
   return SURGE_OK;

@@ -204,18 +204,29 @@ __global__ void __launch_bounds__(kWave) fold_slots_kernel(const FoldParams p, c
     issue(0);
     for (int c = 0; c < n_tiles; ++c) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      uint4 ev[LE];
-#pragma unroll
-      for (int j = 0; j < LE; ++j) ev[j] = *(const uint4*)(lds_ev + (ev_row ^ (uint32_t)(j * 16)));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (c + 1 < n_tiles) issue(c + 1);
+      // The interpreter is a ROLLED loop over my LE events, each read from LDS when its turn comes (one ahead): unrolling
+      // 16 events x 7 slots x 3 value types made ~190 KB of code, far beyond the instruction cache, and holding the tile in
+      // registers to free the buffer early cost a 45-select chain per event.  So, unlike the v1 kernels, the next tile is
+      // fetched AFTER this one is walked — the interpreter is VALU-bound, the other resident waves cover the latency.
       const int32_t rem = (int32_t)cur.len - c * LE;
       const int32_t skip = c == 0 ? (int32_t)cur.pad : 0;
-#pragma unroll
+      uint4 e_n = *(const uint4*)(lds_ev + ev_row);
+      uint32_t t_n = (0 >= skip && 0 < rem) ? (e_n.x < 16u ? e_n.x : 16u) : 17u;
+      uint32_t cls_n = lds_cls[t_n], ops_n = lds_ops[t_n];
+#pragma unroll 2
       for (int j = 0; j < LE; ++j) {
-        const uint32_t t = (j >= skip && j < rem) ? (ev[j].x < 16u ? ev[j].x : 16u) : 17u;
-        slots_apply(st, frozen, lds_cls[t], lds_ops[t], ev[j].y, ev[j].z, ev[j].w, sp);
+        const uint4 e = e_n;
+        const uint32_t cls = cls_n, ops = ops_n;
+        if (j + 1 < LE) {
+          e_n = *(const uint4*)(lds_ev + (ev_row ^ (uint32_t)((j + 1) * 16)));
+          t_n = (j + 1 >= skip && j + 1 < rem) ? (e_n.x < 16u ? e_n.x : 16u) : 17u;
+          cls_n = lds_cls[t_n];
+          ops_n = lds_ops[t_n];
+        }
+        slots_apply(st, frozen, cls, ops, e.y, e.z, e.w, sp);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (c + 1 < n_tiles) issue(c + 1);
     }
     if (oi >= 0) slots_store(p.out, oi, st);
     g = g_next;
@@ -248,11 +259,14 @@ void slot_params_from_schema(const surge_replay_schema_v2& sc, SlotParams* out) 
   *out = p;
 }
 
-hipError_t launch_fold_slots(const FoldParams& p, const SlotParams& sp, int64_t n_waves, hipStream_t stream) {
+hipError_t launch_fold_slots(const FoldParams& p, const SlotParams& sp, int64_t n_waves, int lane_events, hipStream_t stream) {
   if (n_waves <= 0) return hipSuccess;
   hipError_t e = hipMemsetAsync(p.counter, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((fold_slots_kernel<16>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxSorted), stream, p, sp);
+  if (lane_events == 8)
+    hipLaunchKernelGGL((fold_slots_kernel<8>), dim3((unsigned)n_waves), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxSorted), stream, p, sp);
+  else
+    hipLaunchKernelGGL((fold_slots_kernel<16>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxSorted), stream, p, sp);
   return hipGetLastError();
 }
 

@@ -120,7 +120,7 @@ hipError_t launch_snapshot_delta(const uint4* states, uint4* published, int64_t 
 struct SlotParams;
 constexpr size_t kSlotParamsBytes = 512;  // >= sizeof(SlotParams): the engine keeps it as opaque storage
 void slot_params_from_schema(const surge_replay_schema_v2& sc, SlotParams* out);
-hipError_t launch_fold_slots(const FoldParams& p, const SlotParams& sp, int64_t n_waves, hipStream_t stream);
+hipError_t launch_fold_slots(const FoldParams& p, const SlotParams& sp, int64_t n_waves, int lane_events, hipStream_t stream);
 // unpack == false: in = n x 64 B, out = n x 40 B; unpack == true: in = n x 40 B, out = n x 64 B
 hipError_t launch_pack_states(const void* in, int64_t n, void* out, bool unpack, hipStream_t stream);
 hipError_t launch_gather_states(const uint4* states, const int64_t* idx, int64_t n, uint4* out, hipStream_t stream);
