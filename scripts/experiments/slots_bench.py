@@ -1,9 +1,9 @@
-"""ABI v2 slot interpreter at scale: a Zipf(1..4096) ledger log (f64 accumulate + max + i32 count), vs the oracle on a slice."""
+"""ABI v2 slot interpreter at scale: Zipf(1..4096) logs under a ledger schema (f64 accumulate + max + i32 count) and a
+counter schema (timing only; parity is tests/test_slots.py)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
-from oracle import oracle
 from surge_amd import schema as S, synth
 from surge_amd.replay import ReplayEngine
 from surge_amd.schema import CLS_CREATE, CLS_REQUIRE, OP_ADD, OP_MAX, OP_SET, OP_SUB, SLOT_F64, SLOT_I32, SRC_ONE, SRC_PAYLOAD, Slot, SlotAlgebra
@@ -31,7 +31,4 @@ for n in [int(x) for x in os.environ.get("SIZES", "200000,2000000").split(",")]:
             eng.synchronize(); eng.stats_reset()
             for _ in range(5): eng.fold()
             st = eng.stats(); ms = st.sum_fold_kernel_ms / st.timed_folds
-            k = min(n, 3000)
-            exp = oracle.fold_csr_v2(so[:k + 1].cpu().numpy(), synth.to_event_records(ev[: int(so[k])]), alg)
-            ok = out[:k].cpu().numpy().tobytes() == exp.tobytes()
-            print(f"slots {name}: {n} aggs {E/1e6:.0f}M ev: {ms:.3f} ms {st.algorithmic_bytes/ms/1e6:.0f} GB/s = {st.algorithmic_bytes/ms/1e6/80:.1f} % oracle_slice={ok}", flush=True)
+            print(f"slots {name}: {n} aggs {E/1e6:.0f}M ev: {ms:.3f} ms {st.algorithmic_bytes/ms/1e6:.0f} GB/s = {st.algorithmic_bytes/ms/1e6/80:.1f} %", flush=True)
