@@ -53,7 +53,7 @@ def csrc_sha16():
     """Identity of the kernel sources a profile was taken with (profiles/traffic_manifest.json records it)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "surge_amd", "csrc")
-    for name in ("fold_device.h", "fold_kernels.hip", "fold_chunked.hip", "replay_internal.h"):  # what the fold kernels are built from
+    for name in ("fold_layout.h", "fold_device.h", "fold_kernels.hip", "fold_chunked.hip"):  # what the fold kernels are built from
         h.update(name.encode())
         h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]

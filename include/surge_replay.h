@@ -457,6 +457,20 @@ int32_t surge_replay_gathered(surge_replay_handle* h, int32_t slot, void** d_out
 int32_t surge_replay_gathered_read(surge_replay_handle* h, int32_t slot, int32_t rank, int64_t first_row, int64_t n_rows,
                                    void* states_out);
 
+/* The same exchange for ONE host process that drives several GPUs (a JVM with one handle per device) — the literal
+ * SURVEY §8b form `surge_replay_allgather(h[], n_gpus, states_out_per_gpu[])`.  No RCCL and no rendezvous: hs[r] becomes
+ * rank r of an in-process group of n, every rank stages its shard in wire form on its own side stream and every
+ * destination pulls the n shards with peer copies (hipMemcpyPeerAsync: one xGMI link per source, all of a
+ * destination's links at once; handles that share a device copy locally).  One call covers all ranks:
+ *   n_local[r]  states rank r contributes (NULL = every handle's whole resident state)
+ *   d_out[r]    rank r's copy of the snapshot, n x rows_per_rank x 64 B on ITS device (NULL array = each handle keeps
+ *               it, as with surge_replay_allgather_snapshot(d_out = NULL); rows_per_rank is then the largest shard)
+ * Asynchronous like the RCCL form; afterwards surge_replay_comm_wait / _gathered / _gathered_read / _comm_info /
+ * _comm_counts / _comm_destroy work per handle.  A handle holds either an RCCL rank or an in-process rank, not both
+ * (SURGE_E_STATE); the handles must all be v1 or all v2 and must not be used from other threads during the call. */
+int32_t surge_replay_allgather(surge_replay_handle* const* hs, int32_t n, const int64_t* n_local, void* const* d_out,
+                               int64_t rows_per_rank, int32_t slot);
+
 /* Redirect the fold's output to another device buffer (n_agg x 64 B, 16-byte aligned) without
  * re-analysing the bound log; lets a host double-buffer snapshots under an overlapped all-gather. */
 int32_t surge_replay_set_state_out(surge_replay_handle* h, void* d_state_out);

@@ -218,6 +218,23 @@ JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_allgatherSnapshot(JNIE
   return check(env, surge_replay_allgather_snapshot(H(h), NULL, nLocal, NULL, 0, slot, mode));
 }
 
+/* One JVM drives several GPUs: handles = direct buffer of n native-order longs (handle r = rank r of an in-process
+ * group; peer copies, no RCCL, no rendezvous).  Every handle keeps the gathered snapshot (gatheredRead). */
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_allgatherGroup(JNIEnv* env, jclass c, jobject handles, jint n, jint slot) {
+  int bad = 0;
+  surge_replay_handle* hs[64];
+  const int64_t* raw = (const int64_t*)buf(env, handles, (int64_t)n * 8, 0, &bad, "handles: direct buffer of n longs expected");
+  (void)c;
+  if (bad) return SURGE_E_INVALID;
+  if (n < 1 || n > 64) {
+    jclass ex = (*env)->FindClass(env, "java/lang/IllegalArgumentException");
+    if (ex) (*env)->ThrowNew(env, ex, "allgatherGroup: 1..64 handles");
+    return SURGE_E_INVALID;
+  }
+  for (jint r = 0; r < n; ++r) hs[r] = H(raw[r]);
+  return check(env, surge_replay_allgather(hs, n, NULL, NULL, 0, slot));
+}
+
 /* rows [firstRow, firstRow + nRows) of rank `rank`'s block of the gathered snapshot (waits for that slot's exchange) */
 JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_gatheredRead(JNIEnv* env, jclass c, jlong h, jint slot, jint rank,
                                                                          jlong firstRow, jlong nRows, jobject states) {

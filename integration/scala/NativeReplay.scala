@@ -34,6 +34,7 @@ object NativeReplay {
   @native def commDestroy(handle: Long): Int
   @native def commCounts(handle: Long, nLocal: Long, world: Int, countsOut: ByteBuffer): Long
   @native def allgatherSnapshot(handle: Long, nLocal: Long, slot: Int, mode: Int): Int
+  @native def allgatherGroup(handles: ByteBuffer, n: Int, slot: Int): Int
   @native def gatheredRead(handle: Long, slot: Int, rank: Int, firstRow: Long, nRows: Long, states: ByteBuffer): Int
 }
 

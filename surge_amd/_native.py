@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
 SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_slots.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "snapshot_writer.cpp")
-HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
+HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
 EXPORTS = (
@@ -58,6 +58,7 @@ EXPORTS = (
     "surge_replay_comm_info",
     "surge_replay_comm_counts",
     "surge_replay_allgather_snapshot",
+    "surge_replay_allgather",
     "surge_replay_comm_wait",
     "surge_replay_gathered",
     "surge_replay_gathered_read",
@@ -204,6 +205,7 @@ def load() -> ctypes.CDLL:
         "surge_replay_comm_info": ([vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_char_p)], i32),
         "surge_replay_comm_counts": ([vp, i64, vp, ctypes.POINTER(i64)], i32),
         "surge_replay_allgather_snapshot": ([vp, vp, i64, vp, i64, i32, i32], i32),
+        "surge_replay_allgather": ([vp, i32, vp, vp, i64, i32], i32),
         "surge_replay_comm_wait": ([vp, i32, i32], i32),
         "surge_replay_gathered": ([vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)], i32),
         "surge_replay_gathered_read": ([vp, i32, i32, i64, i64, vp], i32),

@@ -109,6 +109,8 @@ struct CommState {
   hipStream_t side = nullptr;          // the exchange runs here, beside the fold's stream
   hipEvent_t ready = nullptr;          // "the states to publish are final" (recorded on the fold's stream)
   hipEvent_t done[2] = {nullptr, nullptr};  // exchange of slot s finished (recorded on the side stream)
+  hipEvent_t staged = nullptr;         // in-process groups: this rank's wire form is complete (peers copy after it)
+  bool local = false;                  // rank of an in-process group (no RCCL communicator; peer copies)
   bool launched[2] = {false, false};
   std::vector<int64_t> counts;         // states per rank of the current shard sizes
   int64_t counts_for = -1;             // n_local the counts were exchanged for
@@ -167,7 +169,7 @@ void comm_destroy(CommState* c) {
   if (!c) return;
   if (c->side) (void)hipStreamSynchronize(c->side);
   if (c->comm) (void)c->api->CommDestroy(c->comm);
-  for (hipEvent_t e : {c->ready, c->done[0], c->done[1]})
+  for (hipEvent_t e : {c->ready, c->done[0], c->done[1], c->staged})
     if (e) (void)hipEventDestroy(e);
   if (c->side) (void)hipStreamDestroy(c->side);
   for (void* p : {c->d_wire_local, c->d_wire_all, c->d_counts})
@@ -213,10 +215,10 @@ int32_t comm_info(const CommState* c, int32_t* rank, int32_t* world, int32_t* ve
   if (world) *world = c->world;
   if (version) {
     int v = 0;
-    (void)c->api->GetVersion(&v);
+    if (c->api) (void)c->api->GetVersion(&v);
     *version = v;
   }
-  if (library) *library = c->api->path.c_str();
+  if (library) *library = c->api ? c->api->path.c_str() : "in-process peer copies";
   return SURGE_OK;
 }
 
@@ -240,8 +242,12 @@ static int32_t exchange_counts(CommState* c, int64_t n_local, std::string* err) 
 }
 
 int32_t comm_counts(CommState* c, int64_t n_local, int64_t* counts_out, int64_t* max_count_out, std::string* err) {
-  const int32_t rc = exchange_counts(c, n_local, err);
-  if (rc != SURGE_OK) return rc;
+  if (c->local) {  // an in-process group learns its shard sizes in surge_replay_allgather
+    if (c->counts_for < 0) return comm_fail(err, SURGE_E_STATE, "in-process group: shard sizes are set by surge_replay_allgather");
+  } else {
+    const int32_t rc = exchange_counts(c, n_local, err);
+    if (rc != SURGE_OK) return rc;
+  }
   if (counts_out) std::memcpy(counts_out, c->counts.data(), (size_t)c->world * 8);
   if (max_count_out) *max_count_out = c->max_count;
   return SURGE_OK;
@@ -253,6 +259,7 @@ int32_t comm_allgather(CommState* c, hipStream_t compute, const void* d_states, 
                        int64_t out_rows_per_rank, int slot, int mode, bool packed, std::string* err) {
   if (slot < 0 || slot > 1) return comm_fail(err, SURGE_E_INVALID, "slot must be 0 or 1");
   if (n_local < 0 || (n_local > 0 && !d_states) || !d_out) return comm_fail(err, SURGE_E_INVALID, "bad argument");
+  if (c->local) return comm_fail(err, SURGE_E_STATE, "rank of an in-process group: exchange with surge_replay_allgather");
   int32_t rc = exchange_counts(c, n_local, err);
   if (rc != SURGE_OK) return rc;
   if (out_rows_per_rank < c->max_count)
@@ -329,6 +336,116 @@ int32_t comm_allgather(CommState* c, hipStream_t compute, const void* d_states, 
   }
   COMM_HIP(hipEventRecord(c->done[slot], c->side));
   c->launched[slot] = true;
+  return SURGE_OK;
+}
+
+// ---- in-process groups: one host process drives every rank, shards move as peer copies (xGMI between GPUs) --------
+int32_t comm_create_local(int device, int rank, int world, CommState** out, std::string* err) {
+  *out = nullptr;
+  if (world < 1 || rank < 0 || rank >= world) return comm_fail(err, SURGE_E_INVALID, "rank / world out of range");
+  CommState* c = new (std::nothrow) CommState();
+  if (!c) return comm_fail(err, SURGE_E_NOMEM, "out of host memory");
+  c->local = true;
+  c->device = device;
+  c->rank = rank;
+  c->world = world;
+  hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+  for (hipEvent_t* ev : {&c->ready, &c->done[0], &c->done[1], &c->staged})
+    if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    comm_destroy(c);
+    return comm_fail(err, SURGE_E_DEVICE, std::string("comm resources: ") + hipGetErrorString(e));
+  }
+  c->counts.assign((size_t)world, 0);
+  *out = c;
+  return SURGE_OK;
+}
+
+bool comm_is_local(const CommState* c) { return c->local; }
+
+// Every rank at once.  Rank r stages its shard in wire form on its own side stream (40-byte packed rows, or the raw 64
+// bytes of a v2 state); every destination then pulls the n staged shards with (peer) copies on ITS side stream — with
+// the ranks on different GPUs each copy crosses exactly one xGMI link and all links of a destination run at once — and
+// expands them into d_out[d].  Nothing here blocks the host.
+int32_t comm_allgather_local(CommState* const* cs, const hipStream_t* compute, const void* const* d_states, const int64_t* n_local,
+                             void* const* d_out, int64_t out_rows_per_rank, int world, int slot, bool packed, std::string* err) {
+  if (slot < 0 || slot > 1) return comm_fail(err, SURGE_E_INVALID, "slot must be 0 or 1");
+  int64_t M = 0;
+  for (int r = 0; r < world; ++r) {
+    if (!cs[r] || !cs[r]->local || cs[r]->world != world || cs[r]->rank != r) return comm_fail(err, SURGE_E_STATE, "not rank r of this in-process group");
+    if (n_local[r] < 0 || (n_local[r] > 0 && !d_states[r]) || !d_out[r]) return comm_fail(err, SURGE_E_INVALID, "bad argument");
+    M = n_local[r] > M ? n_local[r] : M;
+  }
+  if (out_rows_per_rank < M) return comm_fail(err, SURGE_E_RANGE, "d_out holds fewer rows per rank than the largest shard");
+  const size_t W = packed ? (size_t)SURGE_PACKED_STATE_SIZE : 64;
+  const size_t stride = (size_t)M * W;
+  int prev_dev = 0;
+  COMM_HIP(hipGetDevice(&prev_dev));
+  struct Restore {
+    int d;
+    ~Restore() { (void)hipSetDevice(d); }
+  } restore{prev_dev};
+
+  for (int r = 0; r < world; ++r) {  // stage
+    CommState* c = cs[r];
+    COMM_HIP(hipSetDevice(c->device));
+    bool same = c->counts_for == n_local[r];
+    for (int q = 0; q < world && same; ++q) same = c->counts[(size_t)q] == n_local[q];
+    if (!same) {
+      for (int q = 0; q < world; ++q) c->counts[(size_t)q] = n_local[q];
+      c->counts_for = n_local[r];
+      c->max_count = M;
+      c->wire_dirty = true;
+    }
+    int32_t rc = reserve_dev(&c->d_wire_local, &c->wire_local_cap, (size_t)(M > 0 ? M : 1) * 64, err);
+    if (rc == SURGE_OK && packed) rc = reserve_dev(&c->d_wire_all, &c->wire_all_cap, (size_t)world * (size_t)(M > 0 ? M : 1) * W, err);
+    if (rc != SURGE_OK) return rc;
+    COMM_HIP(hipEventRecord(c->ready, compute[r]));
+    COMM_HIP(hipStreamWaitEvent(c->side, c->ready, 0));
+    // the peers may still be pulling the previous exchange out of this rank's staging buffer
+    for (int q = 0; q < world; ++q)
+      for (int s = 0; s < 2; ++s)
+        if (q != r && cs[q]->launched[s]) COMM_HIP(hipStreamWaitEvent(c->side, cs[q]->done[s], 0));
+    if (c->wire_dirty && packed) COMM_HIP(hipMemsetAsync(c->d_wire_all, 0, c->wire_all_cap, c->side));
+    c->wire_dirty = false;
+    if (n_local[r] > 0) {
+      if (packed)
+        COMM_HIP(launch_pack_states(d_states[r], n_local[r], c->d_wire_local, false, c->side));
+      else
+        COMM_HIP(hipMemcpyAsync(c->d_wire_local, d_states[r], (size_t)n_local[r] * 64, hipMemcpyDeviceToDevice, c->side));
+    }
+    COMM_HIP(hipEventRecord(c->staged, c->side));
+  }
+  for (int d = 0; d < world; ++d) {  // pull + expand
+    CommState* c = cs[d];
+    COMM_HIP(hipSetDevice(c->device));
+    const size_t pitch = (size_t)out_rows_per_rank * 64;
+    if (!packed)  // rows between a rank's count and the largest shard read as None
+      for (int r = 0; r < world; ++r)
+        if (n_local[r] < M)
+          COMM_HIP(hipMemsetAsync((char*)d_out[d] + (size_t)r * pitch + (size_t)n_local[r] * 64, 0, (size_t)(M - n_local[r]) * 64, c->side));
+    for (int k = 0; k < world; ++k) {
+      const int r = (d + k) % world;  // skewed: at step k every destination reads a different source
+      const size_t bytes = (size_t)n_local[r] * W;
+      if (r != d) COMM_HIP(hipStreamWaitEvent(c->side, cs[r]->staged, 0));
+      if (!bytes) continue;
+      char* dst = packed ? (char*)c->d_wire_all + (size_t)r * stride : (char*)d_out[d] + (size_t)r * pitch;
+      if (cs[r]->device == c->device)
+        COMM_HIP(hipMemcpyAsync(dst, cs[r]->d_wire_local, bytes, hipMemcpyDeviceToDevice, c->side));
+      else
+        COMM_HIP(hipMemcpyPeerAsync(dst, c->device, cs[r]->d_wire_local, cs[r]->device, bytes, c->side));
+    }
+    if (packed) {
+      if (out_rows_per_rank == M) {
+        COMM_HIP(launch_pack_states(c->d_wire_all, (int64_t)world * M, d_out[d], true, c->side));
+      } else {
+        for (int r = 0; r < world; ++r)
+          COMM_HIP(launch_pack_states((char*)c->d_wire_all + (size_t)r * stride, M, (char*)d_out[d] + (size_t)r * pitch, true, c->side));
+      }
+    }
+    COMM_HIP(hipEventRecord(c->done[slot], c->side));
+    c->launched[slot] = true;
+  }
   return SURGE_OK;
 }
 

@@ -1307,6 +1307,65 @@ int32_t surge_replay_allgather_snapshot(surge_replay_handle* h, const void* d_st
   return rc == SURGE_OK ? rc : fail(h, rc, err);
 }
 
+int32_t surge_replay_allgather(surge_replay_handle* const* hs, int32_t n, const int64_t* n_local, void* const* d_out,
+                               int64_t rows_per_rank, int32_t slot) {
+  if (!hs || n < 1) return fail(nullptr, SURGE_E_INVALID, "no handles");
+  for (int32_t r = 0; r < n; ++r)
+    if (!hs[r]) return fail(nullptr, SURGE_E_INVALID, "a handle is NULL");
+  surge_replay_handle* h0 = hs[0];
+  if (slot < 0 || slot > 1) return fail(h0, SURGE_E_INVALID, "slot must be 0 or 1");
+  std::vector<int64_t> counts((size_t)n);
+  std::vector<CommState*> cs((size_t)n);
+  std::vector<hipStream_t> streams((size_t)n);
+  std::vector<const void*> src((size_t)n);
+  std::vector<void*> dst((size_t)n);
+  int64_t mx = 0;
+  for (int32_t r = 0; r < n; ++r) {
+    surge_replay_handle* h = hs[r];
+    for (int32_t q = 0; q < r; ++q)
+      if (hs[q] == h) return fail(h0, SURGE_E_INVALID, "a handle appears twice in the group");
+    if (!h->bound) return fail(h0, SURGE_E_STATE, "allgather before load_csr/bind_device_csr on every handle");
+    if (h->v2 != h0->v2) return fail(h0, SURGE_E_INVALID, "v1 and v2 handles cannot share a group");
+    if (h->comm && !comm_is_local(h->comm)) return fail(h0, SURGE_E_STATE, "a handle holds an RCCL rank (surge_replay_comm_destroy first)");
+    counts[(size_t)r] = n_local ? n_local[r] : h->n_agg;
+    if (counts[(size_t)r] < 0 || counts[(size_t)r] > h->n_agg) return fail(h0, SURGE_E_RANGE, "n_local outside the resident state");
+    mx = counts[(size_t)r] > mx ? counts[(size_t)r] : mx;
+    if (d_out && (!d_out[r] || ((uintptr_t)d_out[r] & 7))) return fail(h0, SURGE_E_INVALID, "d_out entries must be non-NULL and 8-byte aligned");
+  }
+  if (!d_out) rows_per_rank = mx;
+  std::string err;
+  for (int32_t r = 0; r < n; ++r) {
+    surge_replay_handle* h = hs[r];
+    DeviceGuard g(h->device);
+    int32_t cr = -1, cw = -1;
+    if (h->comm) (void)comm_info(h->comm, &cr, &cw, nullptr, nullptr);
+    if (h->comm && (cr != r || cw != n)) {  // the group changed shape
+      comm_destroy(h->comm);
+      h->comm = nullptr;
+    }
+    if (!h->comm) {
+      const int32_t rc = comm_create_local(h->device, r, n, &h->comm, &err);
+      if (rc != SURGE_OK) return fail(h0, rc, err);
+      h->comm_world = n;
+    }
+    if (!d_out) {
+      HIPCHK(h0, hipStreamSynchronize(h->stream));  // a reallocation must not pull the buffer from under an earlier exchange
+      std::string e2;
+      (void)comm_wait(h->comm, h->stream, slot, true, &e2);
+      HIPCHK(h0, h->gathered[slot].reserve((size_t)n * (size_t)(mx > 0 ? mx : 1) * 64));
+      h->gathered_rows[slot] = mx;
+      dst[(size_t)r] = h->gathered[slot].ptr;
+    } else {
+      dst[(size_t)r] = d_out[r];
+    }
+    cs[(size_t)r] = h->comm;
+    streams[(size_t)r] = h->stream;
+    src[(size_t)r] = h->d_state;
+  }
+  const int32_t rc = comm_allgather_local(cs.data(), streams.data(), src.data(), counts.data(), dst.data(), rows_per_rank, n, slot, !h0->v2, &err);
+  return rc == SURGE_OK ? rc : fail(h0, rc, err);
+}
+
 int32_t surge_replay_gathered(surge_replay_handle* h, int32_t slot, void** d_out, int64_t* rows_per_rank) {
   if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
   if (slot < 0 || slot > 1) return fail(h, SURGE_E_INVALID, "slot must be 0 or 1");

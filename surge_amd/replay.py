@@ -303,6 +303,30 @@ class ReplayEngine:
             self._h, _dev_ptr(states, n_local * 64) if states is not None else None, int(n_local),
             _dev_ptr(out, self.comm_world * rows_per_rank * 64), int(rows_per_rank), slot, mode))
 
+    @staticmethod
+    def allgather_group(engines, n_local=None, outs=None, rows_per_rank: int = 0, slot: int = 0) -> None:
+        """One host process, several handles (one per GPU): ``surge_replay_allgather`` — every engine ends up with every
+        engine's resident states (peer copies, no RCCL).  ``outs`` = one device tensor per engine, or None: each engine
+        keeps the gathered snapshot (``gathered_read``)."""
+        n = len(engines)
+        hs = (ctypes.c_void_p * n)(*[e._h for e in engines])
+        cnt = None if n_local is None else np.ascontiguousarray(n_local, dtype=np.int64)
+        if cnt is not None and cnt.shape != (n,):
+            raise ValueError("n_local holds one count per engine")
+        ptrs = None
+        if outs is not None:
+            ptrs = (ctypes.c_void_p * n)(*[_dev_ptr(o, n * rows_per_rank * 64) for o in outs])
+        rc = engines[0]._lib.surge_replay_allgather(hs, n, _np_ptr(cnt), ptrs, int(rows_per_rank), slot)
+        engines[0]._check(rc)
+        for r, e in enumerate(engines):
+            e.comm_rank, e.comm_world = r, n
+
+    def gathered_read(self, slot: int, rank: int, first_row: int, n_rows: int) -> np.ndarray:
+        """Rows of rank ``rank``'s block of the handle-owned gathered snapshot (waits for the slot's exchange)."""
+        out = np.zeros(n_rows, dtype=self.state_dtype)
+        self._check(self._lib.surge_replay_gathered_read(self._h, slot, rank, int(first_row), int(n_rows), _np_ptr(out)))
+        return out
+
     def comm_wait(self, slot: int, host_sync: bool = False) -> None:
         self._check(self._lib.surge_replay_comm_wait(self._h, slot, 1 if host_sync else 0))
 

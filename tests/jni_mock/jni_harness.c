@@ -29,6 +29,7 @@ jint Java_surge_replay_gpu_NativeReplay_commInit(JNIEnv*, jclass, jlong, jint, j
 jint Java_surge_replay_gpu_NativeReplay_commDestroy(JNIEnv*, jclass, jlong);
 jlong Java_surge_replay_gpu_NativeReplay_commCounts(JNIEnv*, jclass, jlong, jlong, jint, jobject);
 jint Java_surge_replay_gpu_NativeReplay_allgatherSnapshot(JNIEnv*, jclass, jlong, jlong, jint, jint);
+jint Java_surge_replay_gpu_NativeReplay_allgatherGroup(JNIEnv*, jclass, jobject, jint, jint);
 jint Java_surge_replay_gpu_NativeReplay_gatheredRead(JNIEnv*, jclass, jlong, jint, jint, jlong, jlong, jobject);
 
 typedef struct { void* address; jlong capacity; } fake_direct_buffer;
@@ -180,6 +181,28 @@ int main(void) {
     check(Java_surge_replay_gpu_NativeReplay_gatheredRead(env, NULL, h, 0, 1, 0, 1, &b_g) == SURGE_E_RANGE && n_thrown == 1,
           "gatheredRead of a rank outside the communicator -> IOException");
     check(Java_surge_replay_gpu_NativeReplay_commDestroy(env, NULL, h) == 0, "commDestroy");
+  }
+  /* one JVM, two handles: the in-process group (peer copies; both handles end up with both shards) */
+  {
+    surge_state64 g[4];
+    surge_event16 e2[2];
+    int64_t off2[3] = {0, 1, 2}, hs[2];
+    fake_direct_buffer b_g = DB(g, sizeof(g)), b_hs = DB(hs, sizeof(hs)), b_off2 = DB(off2, sizeof(off2)), b_e2 = DB(e2, sizeof(e2));
+    const jlong h2 = Java_surge_replay_gpu_NativeReplay_create(env, NULL, NULL, 0);
+    memset(e2, 0, sizeof(e2));
+    e2[0].type = SURGE_EVT_INC; e2[0].seq = 1; e2[0].p.i.arg = 21;
+    e2[1].type = SURGE_EVT_INC; e2[1].seq = 1; e2[1].p.i.arg = 22;
+    hs[0] = (int64_t)h; hs[1] = (int64_t)h2;
+    n_thrown = 0;
+    const int ok = h2 != 0 && Java_surge_replay_gpu_NativeReplay_loadCsr(env, NULL, h2, &b_off2, 2, &b_e2, 2, NULL) == 0 &&
+                   Java_surge_replay_gpu_NativeReplay_fold(env, NULL, h2, 0) == 0 &&
+                   Java_surge_replay_gpu_NativeReplay_allgatherGroup(env, NULL, &b_hs, 2, 1) == 0 &&
+                   Java_surge_replay_gpu_NativeReplay_gatheredRead(env, NULL, h2, 1, 0, 0, 4, &b_g) == 0;
+    const int first = ok && g[0].count == 4 && g[0].version == 7 && g[3].count == 15;
+    const int ok2 = first && Java_surge_replay_gpu_NativeReplay_gatheredRead(env, NULL, h, 1, 1, 0, 4, &b_g) == 0;
+    check(ok2 && n_thrown == 0 && g[0].count == 21 && g[1].count == 22 && !(g[2].flags & SURGE_STATE_PRESENT) && !(g[3].flags & SURGE_STATE_PRESENT),
+          "allgatherGroup: two handles in one process, each reads the other's shard; short shard padded with None");
+    if (h2) Java_surge_replay_gpu_NativeReplay_destroy(env, NULL, h2);
   }
   Java_surge_replay_gpu_NativeReplay_destroy(env, NULL, h);
   printf("%s\n", fails ? "FAILED" : "ALL PASS");

@@ -187,7 +187,7 @@ def test_jni_shim_compiles_and_turns_a_missing_gpu_into_an_ioexception(tmp_path)
 def test_jni_shim_replays_the_reference_known_answers_through_direct_buffers(tmp_path):
     res = _build_jni_harness(tmp_path)
     assert res.returncode == 0, res.stdout + res.stderr
-    assert "ALL PASS" in res.stdout and res.stdout.count("PASS  ") == 16 and "FAIL" not in res.stdout
+    assert "ALL PASS" in res.stdout and res.stdout.count("PASS  ") == 17 and "FAIL" not in res.stdout
 
 
 def test_the_fake_jnienv_harness_drives_every_jni_export():
@@ -197,7 +197,7 @@ def test_the_fake_jnienv_harness_drives_every_jni_export():
     harness = open(os.path.join(ROOT, "tests", "jni_mock", "jni_harness.c")).read()
     scala = open(os.path.join(ROOT, "integration", "scala", "NativeReplay.scala")).read()
     exports = re.findall(r"Java_surge_replay_gpu_NativeReplay_(\w+)\(", shim)
-    assert len(exports) >= 18 and len(set(exports)) == len(exports)
+    assert len(exports) >= 19 and len(set(exports)) == len(exports)
     for name in exports:
         assert harness.count(f"Java_surge_replay_gpu_NativeReplay_{name}(env") >= 1, f"{name} is never called by the harness"
         assert re.search(rf"@native def {name}\(", scala), f"{name} has no @native declaration in NativeReplay.scala"

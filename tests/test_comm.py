@@ -50,3 +50,112 @@ def test_c_abi_exchange_two_ranks(tmp_path, mode):
         pytest.skip("RCCL refused two ranks on this box's single GPU: " + " | ".join(o.strip().splitlines()[-1] for _, o in outs if o.strip()))
     for r, (rc, out) in enumerate(outs):
         assert rc == 0 and f"OK {r}" in out, out
+
+
+# ---- in-process group: one host process drives every rank (surge_replay_allgather, the literal SURVEY §8b form) ----
+def _group_shard(rank, world):
+    import numpy as np
+
+    from surge_amd import synth
+
+    ids = np.arange(4000, dtype=np.int64)
+    mine = ids[ids % world == rank][: 500 + 61 * rank]  # ragged shard sizes: all-gather-v
+    so, ev = synth.csr_log(synth.zipf_lengths(mine, 5, max_len=300), 200 + rank, synth.STRESS_MIX)
+    return so, ev
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_in_process_group_gathers_every_shard_on_every_handle(world):
+    """All ranks in ONE process (handles on whatever GPUs are visible — all on cuda:0 on a one-GPU box): peer copies
+    instead of RCCL, same result contract as the RCCL exchange."""
+    import numpy as np
+    import torch
+
+    from oracle import oracle
+    from surge_amd.replay import ReplayEngine, ReplayError
+
+    ndev = torch.cuda.device_count()
+    engines = [ReplayEngine(device=r % ndev) for r in range(world)]
+    try:
+        shards = [_group_shard(r, world) for r in range(world)]
+        exp = [oracle.fold_csr(so, ev).view(np.uint8).reshape(-1, 64) for so, ev in shards]
+        for e, (so, ev) in zip(engines, shards):
+            e.load_csr(so, ev)
+            e.fold()
+        mx = max(x.shape[0] for x in exp)
+        for slot in (0, 1, 0):  # handle-owned result, both slots, a slot reused
+            ReplayEngine.allgather_group(engines, slot=slot)
+            for d, e in enumerate(engines):
+                info = e.comm_info()
+                assert info["rank"] == d and info["world"] == world and info["rccl_version"] == 0 and "in-process" in info["library"]
+                counts, m = e.comm_counts(0)
+                assert list(counts) == [x.shape[0] for x in exp] and m == mx
+                for r in range(world):
+                    got = e.gathered_read(slot, r, 0, mx).view(np.uint8).reshape(-1, 64)
+                    assert got[: exp[r].shape[0]].tobytes() == exp[r].tobytes(), f"handle {d}: shard of rank {r} differs"
+                    assert not got[exp[r].shape[0]:].any(), "padding rows must be None (zero)"
+        # caller-owned outputs, wider than needed, and only a prefix of every shard
+        part = [x.shape[0] // 2 for x in exp]
+        rows = max(part) + 3
+        outs = [torch.full((world, rows, 64), 0xAB, dtype=torch.uint8, device=f"cuda:{r % ndev}") for r in range(world)]
+        ReplayEngine.allgather_group(engines, n_local=part, outs=outs, rows_per_rank=rows, slot=1)
+        for d, e in enumerate(engines):
+            e.comm_wait(1, host_sync=True)
+            got = outs[d].cpu().numpy()
+            for r in range(world):
+                assert got[r, : part[r]].tobytes() == exp[r][: part[r]].tobytes()
+                assert not got[r, part[r]: max(part)].any(), "rows between a shard and the largest shard are None"
+                assert (got[r, max(part):] == 0xAB).all(), "rows beyond the largest shard are not touched"
+        # the next fold overlaps the exchange: fold new events, exchange again, the snapshot moves on
+        for e, (so, ev) in zip(engines, shards):
+            e.load_csr(so, ev, e.snapshot())
+            e.fold()
+        ReplayEngine.allgather_group(engines, slot=0)
+        for r, (so, ev) in enumerate(shards):
+            exp2 = oracle.fold_csr(so, ev, oracle.fold_csr(so, ev))
+            got = engines[(r + 1) % world].gathered_read(0, r, 0, exp[r].shape[0])
+            assert got.tobytes() == exp2.tobytes()
+        # error paths: duplicate handle; a handle that holds an RCCL rank is refused
+        if world > 1:
+            with pytest.raises(ReplayError):
+                ReplayEngine.allgather_group([engines[0], engines[0]])
+    finally:
+        for e in engines:
+            e.close()
+
+
+@pytest.mark.gpu
+def test_in_process_group_moves_v2_states_whole():
+    """Slot schemas use all 64 bytes of a state: no 40-byte wire form."""
+    import numpy as np
+
+    from oracle import oracle
+    from surge_amd.replay import ReplayEngine
+    from test_slots import LEDGER, LG_CLOSE, LG_CREDIT, LG_DEBIT, LG_OPEN, make_log
+
+    rng = np.random.default_rng(11)
+    types, p = [LG_OPEN, LG_CREDIT, LG_DEBIT, LG_CLOSE], [0.03, 0.55, 0.415, 0.005]
+    engines = [ReplayEngine(LEDGER) for _ in range(2)]
+    try:
+        exp = []
+        for e, n_agg in zip(engines, (700, 333)):
+            so, ev = make_log(rng, n_agg, 60, types, p, (LG_OPEN, LG_CREDIT, LG_DEBIT))
+            e.load_csr(so, ev)
+            e.fold()
+            exp.append(oracle.fold_csr_v2(so, ev, LEDGER))
+        ReplayEngine.allgather_group(engines)
+        for e in engines:
+            for r in range(2):
+                got = e.gathered_read(0, r, 0, 700)
+                assert got[: exp[r].shape[0]].tobytes() == exp[r].tobytes()
+                assert not got[exp[r].shape[0]:].view(np.uint8).any()
+        with ReplayEngine() as v1:
+            so, ev = _group_shard(0, 1)
+            v1.load_csr(so, ev)
+            v1.fold()
+            with pytest.raises(Exception):
+                ReplayEngine.allgather_group([engines[0], v1])
+    finally:
+        for e in engines:
+            e.close()
