@@ -45,9 +45,19 @@ def main():
     def prof(sub, flags):
         d = os.path.join(out, sub)
         log = os.path.join(out, sub + ".log")
+        # one pass hung for 25 GPU-minutes once (a FETCH_SIZE pass of the 10 M-aggregate log, rocprofv3 idle after HSA
+        # init): every pass gets its own budget and its own process group, and a pass that exceeds it is killed and skipped
+        budget = int(os.environ.get("PROF_PASS_TIMEOUT", "240"))
         with open(log, "w") as fh:
-            subprocess.run(["rocprofv3", "--output-format", "csv"] + flags + ["-d", d, "-o", sub, "--"] + cmd, cwd="/tmp", env=env,
-                           stdout=fh, stderr=subprocess.STDOUT, timeout=1500)
+            pr = subprocess.Popen(["rocprofv3", "--output-format", "csv"] + flags + ["-d", d, "-o", sub, "--"] + cmd, cwd="/tmp", env=env,
+                                  stdout=fh, stderr=subprocess.STDOUT, start_new_session=True)
+            try:
+                pr.wait(timeout=budget)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, 9)  # exactly the process group started above
+                pr.wait()
+                fh.write(f"\nPASS KILLED after {budget} s\n")
+                print(f"pass {sub}: killed after {budget} s", flush=True)
         return d, log
 
     d_trace, log_trace = prof("trace", ["--kernel-trace", "--stats"])
@@ -57,10 +67,11 @@ def main():
             bench_line = json.loads(line)
     prof("pmc_fetch", ["--pmc", "FETCH_SIZE"])
     prof("pmc_write", ["--pmc", "WRITE_SIZE"])
-    prof("pmc_sq", ["--pmc", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
-                    "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"])
-    prof("pmc_sq2", ["--pmc", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM",
-                     "SQ_ACTIVE_INST_LDS", "SQ_INST_CYCLES_SALU"])
+    if os.environ.get("PROF_SKIP_SQ") != "1":
+        prof("pmc_sq", ["--pmc", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
+                        "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"])
+        prof("pmc_sq2", ["--pmc", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM",
+                         "SQ_ACTIVE_INST_LDS", "SQ_INST_CYCLES_SALU"])
 
     lines = ["== kernel stats (rocprofv3 --kernel-trace --stats) of: " + " ".join(cmd[1:]) + " =="]
     for f in glob.glob(os.path.join(d_trace, "**", "*kernel_stats.csv"), recursive=True):

@@ -297,18 +297,31 @@ int32_t run_flat(surge_replay_handle* h, FoldParams& p, const int64_t* off, int6
   return SURGE_OK;
 }
 
+// The persistent kernels pull groups from an atomic ticket counter that the last wave of every launch re-arms; the
+// host only zeroes it when it is allocated.
+int32_t dispenser_begin(surge_replay_handle* h, FoldParams& p) {
+  if (!h->counter.ptr) {
+    HIPCHK(h, h->counter.reserve(16));
+    HIPCHK(h, hipMemset(h->counter.ptr, 0, 16));
+  }
+  p.counter = (unsigned long long*)h->counter.ptr;
+  return SURGE_OK;
+}
+
 // v2: length-sort the kernel-facing segments (once per bound log / per micro-batch), then one lane per segment
 int32_t run_slots(surge_replay_handle* h, FoldParams& p, const int64_t* off, int64_t n_seg, bool cache_perm) {
   if (!cache_perm || !h->perm_valid) {
     HIPCHK(h, h->perm.reserve((size_t)(n_seg > 0 ? n_seg : 1) * 8));
     HIPCHK(h, h->sort_hist.reserve((size_t)kSortBucketsHost * 8));
-    HIPCHK(h, h->counter.reserve(8));
     HIPCHK(h, launch_sort_by_length(off, n_seg, (unsigned long long*)h->sort_hist.ptr, (int64_t*)h->perm.ptr, h->stream));
     h->perm_valid = cache_perm;
   }
   p.seg_off = off;
   p.plan = (const int64_t*)h->perm.ptr;
-  p.counter = (unsigned long long*)h->counter.ptr;
+  {
+    const int32_t rcd = dispenser_begin(h, p);
+    if (rcd != SURGE_OK) return rcd;
+  }
   p.n_seg = n_seg;
   const int64_t groups = (n_seg + kWave - 1) / kWave;
   // the interpreter is VALU-bound and light on registers (93 VGPRs): 8 KiB tiles and as many resident waves as LDS allows
@@ -671,14 +684,16 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       if (!h->perm_valid) {  // once per bound log (part of its index, like the empty-segment compaction)
         HIPCHK(h, h->perm.reserve((size_t)n_seg * 8));
         HIPCHK(h, h->sort_hist.reserve((size_t)kSortBucketsHost * 8));
-        HIPCHK(h, h->counter.reserve(8));
         HIPCHK(h, launch_sort_by_length(off, n_seg, (unsigned long long*)h->sort_hist.ptr, (int64_t*)h->perm.ptr, h->stream));
         h->perm_valid = true;
       }
       if (h->an.n_empty > 0) p.out_map = (const int64_t*)h->nz_map.ptr;
       p.seg_off = off;
       p.plan = (const int64_t*)h->perm.ptr;
-      p.counter = (unsigned long long*)h->counter.ptr;
+      {
+        const int32_t rcd = dispenser_begin(h, p);
+        if (rcd != SURGE_OK) return rcd;
+      }
       p.n_seg = n_seg;
       const int64_t groups = (n_seg + kWave - 1) / kWave;
       // resident waves per CU = min(LDS, registers): 8 KiB tiles 12 (136 VGPRs), 16 KiB tiles 8 (18.6 KB LDS), 32 KiB tiles 4
@@ -699,7 +714,6 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
         HIPCHK(h, h->sort_hist.reserve((size_t)kChunkBucketsHost * 8));
         HIPCHK(h, h->v_total.reserve(8));
         HIPCHK(h, h->v_ctr.reserve(32));
-        HIPCHK(h, h->counter.reserve(8));
         unsigned long long total = 0, ctr[4] = {0, 0, 0, 0};
         HIPCHK(h, launch_chunk_count(off, n_seg, chunk_T, (unsigned long long*)h->sort_hist.ptr, (unsigned long long*)h->v_total.ptr,
                                      (unsigned long long*)h->v_ctr.ptr, h->stream));
@@ -723,7 +737,10 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
                                        (int64_t*)h->r_out.ptr, h->stream));
         h->chunk_T = chunk_T;
       }
-      p.counter = (unsigned long long*)h->counter.ptr;
+      {
+        const int32_t rcd = dispenser_begin(h, p);
+        if (rcd != SURGE_OK) return rcd;
+      }
       p.n_seg = n_seg;
       const int64_t groups = (h->n_vrows + kWave - 1) / kWave;
       // resident waves per CU: 16 KiB tiles 8 (2 per SIMD, 8 x 18.7 KB of LDS), 8 KiB tiles 12 (3 per SIMD)

@@ -388,6 +388,7 @@ fold_chunked_kernel(const FoldParams p, const ChunkTable t) {
     cur = nxt;
     sh = sh_next;
   }
+  dispenser_leave(p.counter, lane);
 }
 
 }  // namespace
@@ -422,8 +423,6 @@ hipError_t launch_fold_chunked(const FoldParams& p, const int64_t* v_start, cons
                                const int64_t* v_dest, int64_t n_vrows, uint32_t* side, const int64_t* r_slot0, const uint32_t* r_c,
                                const int64_t* r_out, int64_t n_cut, int64_t n_waves, int lane_events, hipStream_t stream) {
   if (n_waves <= 0 || n_vrows <= 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(p.counter, 0, sizeof(unsigned long long), stream);
-  if (e != hipSuccess) return e;
   ChunkTable t;
   t.v_start = v_start; t.v_len = v_len; t.v_info = v_info; t.v_dest = v_dest; t.n_vrows = n_vrows; t.side = side;
   if (lane_events == 8)

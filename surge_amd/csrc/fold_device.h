@@ -282,4 +282,17 @@ __device__ __forceinline__ void walk_events(Acc& a, uint32_t& frozenM, uint32_t&
 
 
 }  // namespace
+// Persistent kernels pull groups of 64 rows from an atomic ticket counter.  Every wave draws until its first ticket
+// beyond the last group and then checks out; the last wave to check out re-arms the dispenser for the next launch (every
+// other wave's final draw returned before that wave checked out, so nothing can still be drawing).
+__device__ __forceinline__ void dispenser_leave(unsigned long long* counter, int lane) {
+  if (lane == 0) {
+    const unsigned long long left = atomicAdd(counter + 1, 1ull);
+    if (left == (unsigned long long)gridDim.x - 1ull) {
+      atomicExch(counter + 1, 0ull);
+      atomicExch(counter, 0ull);
+    }
+  }
+}
+
 }  // namespace surge

@@ -52,7 +52,8 @@ struct FoldParams {
   const int64_t* seg_off;   // kernel-facing CSR offsets, strictly increasing (FLAT); unused for FIXED
   const int64_t* plan;      // FLAT: n_tasks+1 segment indices; task k owns segments [plan[k], plan[k+1])
                             // SORTED: perm[n_seg], kernel-facing segment ids by descending length
-  unsigned long long* counter;  // SORTED: group dispenser, zeroed before every launch
+  unsigned long long* counter;  // SORTED / CHUNKED / SLOTS: {group tickets, waves done}: zero before the first launch; the
+                                // last wave to leave a launch zeroes both again (no memset node in front of every fold)
   const int64_t* out_map;   // nullable: segment rank -> aggregate index (compacted CSR / micro-batch groups)
   const uint4* init;        // nullable: prior snapshot, 64 B per aggregate
   uint4* out;               // 64 B per aggregate

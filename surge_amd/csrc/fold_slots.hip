@@ -232,6 +232,7 @@ __global__ void __launch_bounds__(kWave) fold_slots_kernel(const FoldParams p, c
     g = g_next;
     cur = nxt;
   }
+  dispenser_leave(p.counter, lane);
 }
 
 }  // namespace
@@ -261,8 +262,6 @@ void slot_params_from_schema(const surge_replay_schema_v2& sc, SlotParams* out) 
 
 hipError_t launch_fold_slots(const FoldParams& p, const SlotParams& sp, int64_t n_waves, int lane_events, hipStream_t stream) {
   if (n_waves <= 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(p.counter, 0, sizeof(unsigned long long), stream);
-  if (e != hipSuccess) return e;
   if (lane_events == 8)
     hipLaunchKernelGGL((fold_slots_kernel<8>), dim3((unsigned)n_waves), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxSorted), stream, p, sp);
   else
