@@ -76,6 +76,28 @@ int main(void) {
     CHECK(rc == SURGE_OK && p && one.balance == 1100.0, "point read after snapshot");
     CHECK(surge_replay_get(h, 9, &one, &p) == SURGE_E_RANGE, "out-of-range read is an error");
   }
+  {
+    /* one host, two handles (one per GPU on a multi-GPU node; both on device 0 here): the snapshot exchange as peer
+     * copies, no RCCL, no rendezvous — every handle ends up with every handle's shard */
+    surge_replay_handle* h2 = NULL;
+    surge_replay_handle* group[2];
+    surge_event16 ev2[2];
+    int64_t off2[3] = {0, 1, 2};
+    surge_state64 got[4];
+    ev2[0] = ev_int(SURGE_EVT_INC, 1, 40);
+    ev2[1] = ev_int(SURGE_EVT_INC, 1, 41);
+    rc = surge_replay_create(&sc, 0, &h2);
+    if (rc == SURGE_OK) rc = surge_replay_load_csr(h2, off2, 2, ev2, 2, NULL);
+    if (rc == SURGE_OK) rc = surge_replay_fold(h2, SURGE_ALGO_AUTO);
+    group[0] = h; group[1] = h2;
+    if (rc == SURGE_OK) rc = surge_replay_allgather(group, 2, NULL, NULL, 0, 0);
+    if (rc == SURGE_OK) rc = surge_replay_gathered_read(h, 0, 1, 0, 4, got);   /* handle 0 reads handle 1's shard */
+    CHECK(rc == SURGE_OK && got[0].count == 40 && got[1].count == 41 && got[2].flags == 0 && got[3].flags == 0,
+          "in-process exchange: the other handle's shard, padded with None up to the largest shard");
+    if (rc == SURGE_OK) rc = surge_replay_gathered_read(h2, 0, 0, 0, 4, got);  /* and the other way round */
+    CHECK(rc == SURGE_OK && got[0].count == 5 && got[1].balance == 1100.0, "in-process exchange: both directions");
+    if (h2) surge_replay_destroy(h2);
+  }
   surge_replay_destroy(h);
   return fails ? 1 : 0;
 }

@@ -111,6 +111,7 @@ struct CommState {
   hipEvent_t done[2] = {nullptr, nullptr};  // exchange of slot s finished (recorded on the side stream)
   hipEvent_t staged = nullptr;         // in-process groups: this rank's wire form is complete (peers copy after it)
   bool local = false;                  // rank of an in-process group (no RCCL communicator; peer copies)
+  bool peers_enabled = false;          // in-process groups: peer access to the other ranks' devices has been requested
   bool launched[2] = {false, false};
   std::vector<int64_t> counts;         // states per rank of the current shard sizes
   int64_t counts_for = -1;             // n_local the counts were exchanged for
@@ -419,6 +420,16 @@ int32_t comm_allgather_local(CommState* const* cs, const hipStream_t* compute, c
   for (int d = 0; d < world; ++d) {  // pull + expand
     CommState* c = cs[d];
     COMM_HIP(hipSetDevice(c->device));
+    if (!c->peers_enabled) {  // direct xGMI reads of the peers' staging buffers (hipMemcpyPeerAsync stages through the host otherwise)
+      for (int r = 0; r < world; ++r) {
+        int can = 0;
+        if (cs[r]->device != c->device && hipDeviceCanAccessPeer(&can, c->device, cs[r]->device) == hipSuccess && can) {
+          const hipError_t pe = hipDeviceEnablePeerAccess(cs[r]->device, 0);
+          if (pe != hipSuccess) (void)hipGetLastError();  // already enabled (by the host, by another handle): fine
+        }
+      }
+      c->peers_enabled = true;
+    }
     const size_t pitch = (size_t)out_rows_per_rank * 64;
     if (!packed)  // rows between a rank's count and the largest shard read as None
       for (int r = 0; r < world; ++r)

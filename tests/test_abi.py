@@ -120,7 +120,7 @@ def test_plain_c_host_links_and_fails_loudly_without_a_gpu(tmp_path):
 def test_plain_c_host_replays_the_reference_known_answers(tmp_path):
     res = _build_c_demo(tmp_path)
     assert res.returncode == 0, res.stdout + res.stderr
-    assert res.stdout.count("PASS") == 6 and "FAIL" not in res.stdout
+    assert res.stdout.count("PASS") == 8 and "FAIL" not in res.stdout
 
 
 def _build_cpp_demo(tmp_path):
