@@ -166,15 +166,25 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the replay engine has no CPU fallback")
+    # Rehearsal (SURGE_BENCH_REHEARSAL=1): every rank on cuda:0, gloo control plane on CPU tensors — exercises the whole
+    # N > 1 code path on a one-GPU box (with SURGE_RCCL_LIBRARY = tests/rccl_stub for the data exchange, since RCCL refuses
+    # two ranks on one device).  The line it prints is labelled; its throughput means nothing.
+    rehearsal = world > 1 and os.environ.get("SURGE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ctl = torch.device("cpu") if rehearsal else dev  # where the control-plane tensors live
 
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # control plane: barriers, the timing reductions, the communicator id
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # control plane: barriers, the timing reductions, the communicator id
 
     zipf = args.workload in ("c4", "c3")
     weak = args.workload == "c2-weak"
@@ -215,7 +225,7 @@ def main():
     if world > 1 and args.gather != "none":
         from surge_amd.dist import NativeSnapshotGather, SnapshotGather
 
-        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        ok = torch.ones(1, dtype=torch.int32, device=ctl)
         if args.gather == "native":
             try:
                 gather = NativeSnapshotGather(n_local, dev, eng)
@@ -265,9 +275,9 @@ def main():
 
     st = eng.stats()
     times_ms = eng.fold_times_ms()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    totals = torch.tensor([n_events_local, n_local], dtype=torch.int64, device=dev)
-    per_rank = torch.tensor([float(n_events_local), float(np.mean(times_ms)) if len(times_ms) else 0.0], dtype=torch.float64, device=dev)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=ctl)
+    totals = torch.tensor([n_events_local, n_local], dtype=torch.int64, device=ctl)
+    per_rank = torch.tensor([float(n_events_local), float(np.mean(times_ms)) if len(times_ms) else 0.0], dtype=torch.float64, device=ctl)
     exchange = None
     if dist is not None:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -280,7 +290,7 @@ def main():
             # (a) the gathered snapshot holds every rank's shard: checksum of each rank's block against that rank's own
             torch.cuda.synchronize(dev)
             res = gather.result(last)
-            own = torch.stack([bufs[last][: n_local].view(torch.int64).sum()])
+            own = torch.stack([bufs[last][: n_local].view(torch.int64).sum()]).to(ctl)
             sums = [torch.zeros_like(own) for _ in range(world)]
             dist.all_gather(sums, own)
             for r in range(world):
@@ -295,7 +305,7 @@ def main():
                 gather.launch(last, bufs[last], None)
                 torch.cuda.synchronize(dev)
                 ex.append((time.perf_counter() - ta) * 1e3)
-            exm = torch.tensor([float(np.median(ex))], dtype=torch.float64, device=dev)
+            exm = torch.tensor([float(np.median(ex))], dtype=torch.float64, device=ctl)
             dist.all_reduce(exm, op=dist.ReduceOp.MAX)
             exchange = float(exm.item())
     else:
@@ -336,6 +346,7 @@ def main():
             "vs_baseline": None,
             "dtype": "int32/int64 adds + bit-copied f64",
             "data": "synthetic (counter-hash log; surge_amd/synth.py), generated on the device in %.0f s" % gen_s,
+            **({"rehearsal": "every rank on cuda:0, gloo control plane: a functional run of the N > 1 path, not a measurement"} if rehearsal else {}),
             "aggregates_per_sec": total_aggs * args.steps / elapsed_s,
             "config": {
                 "workload": wl,

@@ -10,7 +10,8 @@
 //
 // librccl is dlopen'ed at the first comm call, not linked: the fold, the point reads and every single-GPU host work
 // without it, and inside a process that already carries an RCCL (PyTorch bundles one) that same copy is used
-// (RTLD_NOLOAD first) instead of a second runtime.  SURGE_RCCL_LIBRARY overrides the search.
+// (RTLD_NOLOAD first) instead of a second runtime.  SURGE_RCCL_LIBRARY names the library to use instead (it wins over a
+// copy already in the process; tests/rccl_stub uses it to put two ranks on one GPU).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -65,17 +66,20 @@ const RcclApi* rccl(std::string* err) {
     return nullptr;
   }
   g_api_tried = true;
-  std::vector<std::string> names;
-  if (const char* v = std::getenv("SURGE_RCCL_LIBRARY")) names.push_back(v);
-  for (const char* n : {"librccl.so.1", "librccl.so"}) names.push_back(n);
-  names.push_back("/opt/rocm/lib/librccl.so.1");
   void* lib = nullptr;
   std::string used;
-  for (int pass = 0; pass < 2 && !lib; ++pass)  // pass 0: a copy this process already loaded
-    for (const std::string& n : names) {
-      lib = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
-      if (lib) { used = n; break; }
-    }
+  if (const char* v = std::getenv("SURGE_RCCL_LIBRARY")) {
+    // an explicit choice wins over whatever the process already carries (RTLD_LOCAL: its symbols stay out of the global scope)
+    lib = dlopen(v, RTLD_NOW | RTLD_LOCAL);
+    used = v;
+  } else {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (int pass = 0; pass < 2 && !lib; ++pass)  // pass 0: a copy this process already loaded (PyTorch bundles one)
+      for (const char* n : names) {
+        lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+        if (lib) { used = n; break; }
+      }
+  }
   if (!lib) {
     const char* why = dlerror();
     g_api_err = std::string("cannot load librccl (set SURGE_RCCL_LIBRARY): ") + (why ? why : "not found");

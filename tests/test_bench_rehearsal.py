@@ -1,0 +1,54 @@
+"""bench.py's N > 1 path, run for real on a one-GPU box: two ranks on cuda:0 (SURGE_BENCH_REHEARSAL=1: gloo control plane),
+the snapshot exchange through the C ABI over tests/rccl_stub (RCCL itself refuses two ranks on one device).  A functional
+check of code the 8-GPU driver run depends on — shard generation by Kafka partition, the overlapped exchange, the gathered
+snapshot's verification, the JSON contract — not a measurement."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from test_comm import build_rccl_stub
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_bench(tmp_path, extra, world=2):
+    env = dict(os.environ, SURGE_BENCH_REHEARSAL="1", SURGE_RCCL_LIBRARY=build_rccl_stub(), SURGE_RCCL_STUB_DIR=str(tmp_path),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2"] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra,algo", [(["--aggregates", "400000"], None), (["--workload", "c2", "--aggregates", "200000"], "rows")])
+def test_two_rank_bench_rehearsal_on_one_gpu(tmp_path, extra, algo):
+    d = run_bench(tmp_path, extra)
+    cfg = d["config"]
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "strong" and "rehearsal" in d
+    assert d["metric"] == "events/sec replayed" and d["unit"] == "events/s" and d["higher_is_better"] is True
+    assert len(cfg["per_rank_events"]) == 2 and sum(cfg["per_rank_events"]) == cfg["events"] and min(cfg["per_rank_events"]) > 0
+    assert "C ABI" in cfg["exchange"] and "FALLBACK" not in cfg["exchange"] and cfg["exchange_alone_ms"] > 0
+    assert abs(d["value"] - cfg["events"] * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0 and d["cpu_baseline"] is None
+    if algo:
+        assert algo in cfg["algo"].lower()
+
+
+@pytest.mark.gpu
+def test_bench_rehearsal_falls_back_to_the_torch_exchange_and_says_so(tmp_path):
+    d = run_bench(tmp_path, ["--aggregates", "200000", "--gather", "torch"])
+    assert "torch.distributed" in d["config"]["exchange"] and d["config"]["exchange_alone_ms"] > 0
