@@ -52,3 +52,15 @@ def test_two_rank_bench_rehearsal_on_one_gpu(tmp_path, extra, algo):
 def test_bench_rehearsal_falls_back_to_the_torch_exchange_and_says_so(tmp_path):
     d = run_bench(tmp_path, ["--aggregates", "200000", "--gather", "torch"])
     assert "torch.distributed" in d["config"]["exchange"] and d["config"]["exchange_alone_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_eight_rank_bench_rehearsal_has_the_shape_of_config_c4(tmp_path):
+    """World size 8 — the driver's scaling run — with a small log: 64 Kafka partitions over 8 ranks (8 partitions each),
+    every rank exchanges with 7 peers per step."""
+    d = run_bench(tmp_path, ["--aggregates", "320000"], world=8)
+    cfg = d["config"]
+    assert d["n_gpus"] == 8 and len(cfg["per_rank_events"]) == 8 and sum(cfg["per_rank_events"]) == cfg["events"]
+    assert "C4:" in cfg["workload"] and "% 8" in cfg["workload"] and "C ABI" in cfg["exchange"]
+    # shards by partitionForKey(id, 64) % 8 are balanced to a few percent at this size
+    assert max(cfg["per_rank_events"]) < 1.15 * min(cfg["per_rank_events"])
