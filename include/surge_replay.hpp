@@ -169,8 +169,12 @@ class AggregateStateStore {
     std::vector<surge_event16> enc(eventsInOffsetOrder.size());
     for (size_t i = 0; i < eventsInOffsetOrder.size(); ++i) {
       agg[i] = intern(model_->aggregateIdOf(eventsInOffsetOrder[i]));
-      if ((size_t)agg[i] >= n_agg_) throw std::out_of_range("aggregate exceeds the store capacity");
       enc[i] = model_->encodeEvent(eventsInOffsetOrder[i]);
+    }
+    if (keys_.size() > n_agg_) {  // aggregates born after recovery: the resident state grows, new rows are None
+      const size_t grown = std::max(keys_.size(), n_agg_ + n_agg_ / 2);
+      check(surge_replay_grow(h_, (int64_t)grown));
+      n_agg_ = grown;
     }
     check(surge_replay_append_events(h_, agg.data(), enc.data(), (int64_t)enc.size()));
     check(surge_replay_snapshot(h_, nullptr, nullptr));
