@@ -126,7 +126,7 @@ final class GpuReplayKeyValueStore(val name: String, recovered: RecoveredSnapsho
 
 /** One recovered shard: the native handle (one GPU / one assigned state-topic partition set), the key table
  *  (aggregate id -> dense index; ids never cross the C ABI) and the model's fixed-width -> bytes codec. */
-final class RecoveredSnapshot(handle: Long, keyIndex: util.Map[String, java.lang.Long], model: ReplayableModel[_, _]) extends AutoCloseable {
+final class RecoveredSnapshot(private[gpu] val handle: Long, keyIndex: util.Map[String, java.lang.Long], model: ReplayableModel[_, _]) extends AutoCloseable {
   private val scratch = ThreadLocal.withInitial[ByteBuffer](() => ByteBuffer.allocateDirect(64).order(ByteOrder.LITTLE_ENDIAN))
 
   def aggregateIds: Iterable[String] = keyIndex.keySet().asScala
@@ -178,5 +178,27 @@ object GpuReplayRecovery {
     NativeReplay.fold(h, 0)
     NativeReplay.snapshot(h, nAgg.toLong, null, null) // publishes the mirror that serves the 32 concurrent readers
     new RecoveredSnapshot(h, keyIndex, model)
+  }
+}
+
+/** One JVM that owns every GPU of the node (one RecoveredSnapshot per device): after the shards are folded, every device
+ *  gets every shard's final states — the path's single exchange step (SURVEY §8e) — without RCCL or a rendezvous:
+ *  surge_replay_allgather moves the shards with peer copies over xGMI.  Shard r = the state-topic partitions p with
+ *  p % shards.size == r (PartitionAssignments.scala:51-63 gives the node its partitions; KafkaPartitioner.scala:8 the
+ *  partition of a key). */
+object GpuReplayNodeExchange {
+  /** Asynchronous on every handle's side stream; `slot` (0 / 1) lets the next fold overlap it. */
+  def exchange(shards: IndexedSeq[RecoveredSnapshot], slot: Int): Unit = {
+    val hs = ByteBuffer.allocateDirect(8 * shards.size).order(ByteOrder.nativeOrder)
+    shards.foreach(s => hs.putLong(s.handle))
+    NativeReplay.allgatherGroup(hs, shards.size, slot)
+  }
+
+  /** State `row` of shard `ofShard` as device `onShard` holds it after `exchange` (waits for that slot's exchange);
+   *  64 bytes, little-endian, all-zero = None. */
+  def peerState(shards: IndexedSeq[RecoveredSnapshot], onShard: Int, ofShard: Int, row: Long, slot: Int): ByteBuffer = {
+    val st = ByteBuffer.allocateDirect(64).order(ByteOrder.LITTLE_ENDIAN)
+    NativeReplay.gatheredRead(shards(onShard).handle, slot, ofShard, row, 1L, st)
+    st
   }
 }
