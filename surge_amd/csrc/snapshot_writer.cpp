@@ -71,7 +71,6 @@ int32_t fail(surge_snapshot_writer* w, int32_t code, const std::string& m) {
 void close_batch(PartitionLog& p) {
   if (p.open_records == 0) return;
   std::vector<uint8_t>& o = p.bytes;
-  const size_t start = o.size();
   put_be(o, (uint64_t)p.base_offset, 8);
   put_be(o, (uint64_t)(kHeader - 12 + p.open.size()), 4);  // batchLength: everything after this field
   put_be(o, 0, 4);                                         // partitionLeaderEpoch
@@ -90,7 +89,6 @@ void close_batch(PartitionLog& p) {
   o.insert(o.end(), p.open.begin(), p.open.end());
   const uint32_t crc = surge_crc32c(o.data() + crc_from, (int64_t)(o.size() - crc_from));  // CRC-32C over attributes .. end
   o[crc_at] = (uint8_t)(crc >> 24); o[crc_at + 1] = (uint8_t)(crc >> 16); o[crc_at + 2] = (uint8_t)(crc >> 8); o[crc_at + 3] = (uint8_t)crc;
-  (void)start;
   p.open.clear();
   p.open_records = 0;
 }
