@@ -4,6 +4,7 @@ The decoder (C++, surge_amd/csrc/ingest.cpp) is checked against an independent w
 and against the formats' own known answers (CRC-32C check value, hand-assembled LZ4 sequences).  kafka-clients
 is not available here, so parity with a real broker's bytes is unpinned."""
 import ctypes
+import json
 import os
 import random
 import struct
@@ -33,6 +34,23 @@ def test_crc32c_check_value():
     assert L.surge_crc32c(b"", 0) == 0
     data = os.urandom(1000)
     assert L.surge_crc32c(data, len(data)) == kw.crc32c(data)
+
+
+def test_crc32c_published_vectors_of_rfc_3720():
+    """RFC 3720 (iSCSI) Appendix B.4 "CRC Examples": the published known answers of CRC-32C — the checksum Kafka's record
+    batches carry (DefaultRecordBatch: Crc32C over attributes .. end)."""
+    L = _native.load()
+
+    def crc(b):
+        return L.surge_crc32c(b, len(b)) & 0xFFFFFFFF
+
+    assert crc(bytes(32)) == 0x8A9136AA                     # 32 bytes of zeroes
+    assert crc(b"\xff" * 32) == 0x62A8AB43                  # 32 bytes of ones
+    assert crc(bytes(range(32))) == 0x46DD794E              # 32 bytes of incrementing 00..1f
+    assert crc(bytes(range(31, -1, -1))) == 0x113FDB5C      # 32 bytes of decrementing 1f..00
+    read10 = bytes([0x01, 0xC0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x14, 0, 0, 0, 0, 0, 0x04, 0, 0, 0, 0, 0x14, 0, 0, 0, 0x18,
+                    0x28, 0, 0, 0, 0, 0, 0, 0, 0x02, 0, 0, 0, 0, 0, 0, 0])
+    assert len(read10) == 48 and crc(read10) == 0xD9963A56  # an iSCSI SCSI Read (10) command PDU
 
 
 def test_lz4_hand_assembled_sequences():
@@ -349,3 +367,109 @@ def test_snapshot_writer_batches_are_what_the_test_side_writer_and_the_decoder_a
         data, nrec, nxt = w.partition_bytes(1)
         n1 = sum(1 for i in range(len(keys)) if part[i] == 1 and kind[i] != 0)
         assert nrec == 1 and nxt == n1 + 1 and data == kw.record_batch(n1, [(b"x", b"v")], base_timestamp=5, producer_epoch=-1)
+
+
+# ---- third-party pin: the reference LZ4 library (liblz4, as bundled by Apache Arrow) writes, the product reads -----------
+def _arrow_lz4_frame(data: bytes) -> bytes:
+    pa = pytest.importorskip("pyarrow")
+    if not pa.Codec.is_available("lz4"):
+        pytest.skip("this pyarrow build has no LZ4 frame codec")
+    return pa.compress(data, codec="lz4", asbytes=True)
+
+
+@pytest.mark.parametrize("kind", ["empty", "tiny", "json", "random", "zeros", "multi_block", "mixed"])
+def test_lz4_frames_written_by_liblz4_decode_to_the_original_bytes(kind):
+    """The frame format Kafka's lz4 codec uses (LZ4F: magic 0x184D2204, FLG version 01 + block independence, 64 KiB
+    blocks) produced by liblz4 itself — not by tests/kafka_wire.py, which shares its author with the decoder."""
+    rng = np.random.default_rng(7)
+    data = {
+        "empty": b"",
+        "tiny": b"a",
+        "json": b"".join(b'{"aggregateId":"acct-%08d","incrementBy":1,"sequenceNumber":%d}' % (i % 97, i) for i in range(20000)),
+        "random": rng.integers(0, 256, 300_000, dtype=np.uint8).tobytes(),            # incompressible: stored blocks
+        "zeros": bytes(5 << 20),                                                       # > 255x: long match-length chains, many blocks
+        "multi_block": bytes(rng.integers(0, 4, 1_000_000, dtype=np.uint8)),            # low-entropy, crosses many 64 KiB blocks
+        "mixed": b"".join((bytes(rng.integers(0, 256, 5000, dtype=np.uint8)) if i % 2 else b"surge" * 1000) for i in range(60)),
+    }[kind]
+    frame = _arrow_lz4_frame(data)
+    assert frame[:4] == b"\x04\x22\x4d\x18"
+    assert lz4_decompress(frame, cap=len(data) + 64) == data
+
+
+def test_record_batches_compressed_by_liblz4_are_ingested():
+    """A RecordBatch v2 whose records section is an LZ4 frame from liblz4: what a Kafka producer with
+    compression.type = lz4 (the reference's default, reference.conf of common :112) puts on the wire."""
+    recs = [(f"agg-{i % 13}:{i}".encode(), json.dumps({"aggregateId": f"agg-{i % 13}", "incrementBy": 1, "sequenceNumber": i}).encode())
+            for i in range(3000)]
+    wire = b"".join(kw.record_batch(off, recs[off:off + 500], compression="lz4", compressor=_arrow_lz4_frame) for off in range(0, 3000, 500))
+    with EventsTopicIngest() as g:
+        g.feed(wire)
+        got = g.drain_records()
+        assert [(o, k, v) for o, _, k, v in got] == [(i, k, v) for i, (k, v) in enumerate(recs)]
+        assert g.counters()["batches"] == 6
+
+
+# ---- third-party pin: the varint layer against Google's protobuf runtime -------------------------------------------------
+def _pb_zigzag_varint(v: int) -> bytes:
+    """Kafka's ByteUtils.writeVarint / writeVarlong = protobuf's sint32 / sint64 encoding (zig-zag, base-128)."""
+    from google.protobuf.internal import encoder, wire_format
+
+    return encoder._VarintBytes(wire_format.ZigZagEncode(v))
+
+
+def test_record_varints_written_by_the_protobuf_runtime_are_read_and_the_writers_output_parses_with_it():
+    from google.protobuf.internal import decoder, wire_format
+
+    # (a) decode: records whose every varint comes from protobuf's encoder, at the 1/2/3-byte boundaries and with nulls
+    def rec(offset_delta, key, value, ts_delta):
+        body = b"\x00" + _pb_zigzag_varint(ts_delta) + _pb_zigzag_varint(offset_delta)
+        body += _pb_zigzag_varint(-1) if key is None else _pb_zigzag_varint(len(key)) + key
+        body += _pb_zigzag_varint(-1) if value is None else _pb_zigzag_varint(len(value)) + value
+        body += _pb_zigzag_varint(0)
+        return _pb_zigzag_varint(len(body)) + body
+
+    cases = [(b"k" * n, b"v" * m) for n, m in ((1, 0), (63, 64), (64, 63), (8191, 8192), (8192, 70000))] + [(b"only-key", None), (None, b"only-value")]
+    body = b"".join(rec(i, k, v, (1 << 35) + i) for i, (k, v) in enumerate(cases))
+    n = len(cases)
+    after_crc = struct.pack(">hiqqqhii", 0, n - 1, 5, 5 + (1 << 35) + n, -1, -1, -1, n) + body
+    batch_body = struct.pack(">ib", 0, 2) + struct.pack(">I", kw.crc32c(after_crc)) + after_crc
+    wire = struct.pack(">qi", 1000, len(batch_body)) + batch_body
+    with EventsTopicIngest() as g:
+        g.feed(wire)
+        got = g.drain_records()
+    assert [(o, k, v) for o, _, k, v in got] == [(1000 + i, k, v) for i, (k, v) in enumerate(cases)]
+
+    # (b) encode: the product's snapshot writer, its record section walked with protobuf's decoder
+    from surge_amd.snapshot import RecordBatchWriter
+
+    keys = [b"k" * n for n in (1, 63, 64, 8191, 8192)]
+    vals = [b"v" * m for m in (0, 64, 63, 8192, 70000)]
+    key_off = np.cumsum([0] + [len(k) for k in keys])
+    val_off = np.cumsum([0] + [len(v) for v in vals])
+    with RecordBatchWriter(1, max_records_per_batch=100, max_batch_bytes=1 << 30) as w:
+        w.append(None, np.zeros(len(keys), np.int32), np.frombuffer(b"".join(keys), np.uint8), key_off,
+                 np.frombuffer(b"".join(vals), np.uint8), val_off, timestamp_ms=1234567890123)
+        data, n_rec, _ = w.partition_bytes(0)
+    assert n_rec == len(keys)
+    pos = 61  # first record of the only batch
+    read_u, read_s = decoder._DecodeVarint, None
+    for i, (k, v) in enumerate(zip(keys, vals)):
+        def sv(p):
+            x, p = read_u(data, p)
+            return wire_format.ZigZagDecode(x), p
+
+        ln, pos = sv(pos)
+        end = pos + ln
+        assert data[pos] == 0
+        pos += 1
+        ts, pos = sv(pos)
+        od, pos = sv(pos)
+        kl, pos = sv(pos)
+        assert (ts, od, kl) == (0, i, len(k)) and data[pos:pos + kl] == k
+        pos += kl
+        vl, pos = sv(pos)
+        assert vl == len(v) and data[pos:pos + vl] == v
+        pos += vl
+        nh, pos = sv(pos)
+        assert nh == 0 and pos == end
+    assert pos == len(data)
