@@ -13,8 +13,9 @@
  *   - scala.util.hashing.MurmurHash3.stringHash (scala-library 2.13.8) used by
  *     KafkaPartitioner.scala:8 — restated from the published algorithm; its mix / mixLast /
  *     finalize primitives ARE pinned, on the published MurmurHash3_x86_32 verification vectors
- *     (oracle_murmur3_x86_32 below is assembled from the same primitives); what remains unpinned
- *     is stringHash's framing (seed, char-pair order, char count) — tools/MurmurPin.scala;
+ *     (oracle_murmur3_x86_32 below is assembled from the same primitives) and against scikit-learn's
+ *     bundled reference MurmurHash3_x86_32 on random inputs; what remains unpinned is stringHash's
+ *     framing (seed, char-pair order, char count) — tools/MurmurPin.scala;
  *   - play-json 2.9.2 number/text formatting used by TestBoundedContext.scala:127-133.
  *
  * Everything here is written as a literal, sequential, one-event-at-a-time
