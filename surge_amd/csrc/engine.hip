@@ -598,12 +598,14 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
   // lane-per-aggregate kernels measured 2-4x slower than the linear-stream FLAT kernel, at ~64 they tie).
   const double mean_len = h->n_nz > 0 ? (double)span / (double)h->n_nz : 0.0;
   // CHUNKED bounds the critical path: no wave walks more than ~T events alone.  T grows with the log (the longest
-  // chunk's walk should stay a small fraction of the kernel; measured optimum on Zipf(1..4096) logs of 2–15 GB:
-  // T ~ algorithmic bytes / 6 MB) and cut aggregates get at most 256 chunks (the stitch kernel walks them one by one).
+  // chunk's walk should stay a small fraction of the kernel; measured optimum on Zipf(1..4096) logs of 2–15 GB with the
+  // final kernels: T ~ algorithmic bytes / 4 MB — 0.5 M aggregates 925, 0.8 M 1475, 1.25 M 2320; the optimum is flat
+  // to the right and falls off quickly to the left of it) and cut aggregates get at most 256 chunks (the stitch kernel
+  // walks them one by one).
   // When T reaches the longest aggregate nothing is cut and the plain sorted-rows kernel runs instead.
   uint32_t chunk_T = 0;
   {
-    double t = (double)h->st.algorithmic_bytes / 6.0e6;
+    double t = (double)h->st.algorithmic_bytes / 4.0e6;
     const double t_min = (double)h->an.max_len / 256.0;
     t = t < t_min ? t_min : t;
     t = t < 256.0 ? 256.0 : (t > 65528.0 ? 65528.0 : t);

@@ -128,11 +128,11 @@ def test_c3_full_size_10m_aggregates_zipf():
         eng.load_csr(so, ev, None, buf)
         eng.fold()
         eng.synchronize()
-        # AUTO: sorted rows once the chunk target (bytes / 6 MB) reaches the longest aggregate (~3.3 M Zipf(1..4096)
-        # aggregates = 24.6 GB), chunked rows from ~1.5 GB (0.2 M aggregates), FLAT below
-        if A >= 3_500_000:
+        # AUTO: sorted rows once the chunk target (bytes / 4 MB) reaches the longest aggregate (~2.2 M Zipf(1..4096)
+        # aggregates = 16.4 GB), chunked rows from ~1.5 GB (0.2 M aggregates), FLAT below
+        if A >= 2_500_000:
             assert eng.stats().last_algo == S.ALGO_SORTED
-        elif 250_000 <= A <= 3_000_000:
+        elif 250_000 <= A <= 2_000_000:
             assert eng.stats().last_algo == S.ALGO_CHUNKED
         elif A <= 150_000:
             assert eng.stats().last_algo == S.ALGO_FLAT
