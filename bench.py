@@ -397,6 +397,27 @@ def run_secondary_c2(args, S, synth, ReplayEngine, torch, dev, local_rank):
         }
 
 
+def effective_cpus():
+    """CPUs this process can really use: the scheduler affinity, capped by the cgroup CPU quota (the GPU boxes of this
+    project show 256 logical CPUs and a quota of 16 — the C restatement scales linearly to 16 threads and not beyond)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2: "<quota|max> <period>"
+        if q != "max":
+            quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    eff = n if quota is None else max(1, min(n, int(quota + 0.999)))
+    return eff, n, quota
+
+
 def run_cpu_baseline(args, seg_off, events, gpu_states):
     """CPU restatement (oracle/, kind "port") on a bounded sample of the SAME log, all host cores."""
     import torch
@@ -405,7 +426,7 @@ def run_cpu_baseline(args, seg_off, events, gpu_states):
     from surge_amd import schema as S
     from surge_amd import synth
 
-    cores = os.cpu_count() or 1
+    cores, logical, quota = effective_cpus()
     n_aggs = int(seg_off.numel()) - 1
     # first aggregates of the log holding about 64 M events
     sample_aggs = int(torch.searchsorted(seg_off, torch.tensor([64_000_000], device=seg_off.device))[0])
@@ -455,7 +476,10 @@ def run_cpu_baseline(args, seg_off, events, gpu_states):
         "cores": cores,
         "kind": "port",
         "sample": f"first {sample_aggs} aggregates of the same log ({n_ev} events), "
-                  f"C restatement of the fold, aggregates split over {cores} host threads",
+                  f"C restatement of the fold, aggregates split over {cores} host threads "
+                  f"({logical} logical CPUs visible, cgroup CPU quota {'none' if quota is None else round(quota, 2)})",
+        "host_logical_cpus": logical,
+        "cgroup_cpu_quota": quota,
         "single_thread_value": one_core,
         "thread_scaling_efficiency": all_cores / (one_core * cores) if one_core > 0 else None,
         "gpu_matches_cpu_on_sample": parity,
