@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--aggregates", type=int, default=10_000_000)
     ap.add_argument("--batch-events", type=int, default=100_000)
     ap.add_argument("--batches", type=int, default=600)
-    ap.add_argument("--snapshot-every", type=int, default=30)
+    ap.add_argument("--snapshot-every", type=int, default=30, help="publish a state-topic delta every N batches (0 = never)")
     ap.add_argument("--device-batches", action="store_true", help="batches already in HBM (no staging / H2D)")
     args = ap.parse_args()
 
@@ -79,7 +79,7 @@ def main():
         t1 = time.perf_counter()
         lat.append((t1 - t0) * 1e3)
         kern.append(eng.stats().last_fold_kernel_ms)
-        if (b + 1) % args.snapshot_every == 0:
+        if args.snapshot_every > 0 and (b + 1) % args.snapshot_every == 0:
             t0 = time.perf_counter()
             batches = pub.publish()
             snap_ms.append((time.perf_counter() - t0) * 1e3)
