@@ -359,7 +359,7 @@ def main():
                 "per_rank_fold_kernel_ms": per_rank_fold_ms,
                 "exchange": None if world == 1 else (gather_kind or "none (fold only)"),
                 "exchange_transport": None if gather is None else
-                f"{'grouped per-peer ncclSend/ncclRecv' if gather.mode == 'p2p' else 'ncclAllGather, max-padded'}, "
+                f"{'ncclAllGather, max-padded' if gather.mode == 'allgather' else 'grouped per-peer ncclSend/ncclRecv'}, "
                 f"{'40-byte wire form' if gather.packed else '64-byte states'}, side stream, overlapped with the next fold",
                 "exchange_alone_ms": exchange,
                 "exchange_hidden_fraction": None if not exchange else max(0.0, min(1.0, 1.0 - max(0.0, ms_per_step - fold_ms) / exchange)),

@@ -435,10 +435,15 @@ int32_t surge_replay_unpack_states(surge_replay_handle* h, const void* d_packed4
  *
  * Transport (mode): SURGE_GATHER_P2P — one ncclSend/ncclRecv pair per peer inside one group: xGMI is a point-to-point
  * full mesh, so every link carries exactly one peer's shard, all links at once; SURGE_GATHER_ALLGATHER — the library's
- * ncclAllGather over max-padded shards.  Shards travel in the 40-byte wire form (see surge_replay_pack_states). */
+ * ncclAllGather over max-padded shards.  Both ship the 40-byte wire form (see surge_replay_pack_states): least link
+ * traffic, at the price of a pack pass on the sender and an expansion pass (40 -> 64 B for the WHOLE gathered snapshot)
+ * on every receiver.  SURGE_GATHER_P2P_RAW — the same per-peer send/recv of the 64-byte states as they are, straight
+ * between the state arrays: 1.6x the link bytes, but no pack / expand passes — about a third less HBM traffic per
+ * exchange, which is what an exchange overlapped with an HBM-bound fold competes for (v2 handles always travel raw). */
 #define SURGE_COMM_ID_BYTES    128
 #define SURGE_GATHER_P2P       0
 #define SURGE_GATHER_ALLGATHER 1
+#define SURGE_GATHER_P2P_RAW   2
 int32_t surge_replay_comm_unique_id(uint8_t id_out[SURGE_COMM_ID_BYTES]);
 int32_t surge_replay_comm_init(surge_replay_handle* h, int32_t rank, int32_t world, const uint8_t id[SURGE_COMM_ID_BYTES]);
 int32_t surge_replay_comm_destroy(surge_replay_handle* h);

@@ -271,13 +271,16 @@ int32_t comm_allgather(CommState* c, hipStream_t compute, const void* d_states, 
     return comm_fail(err, SURGE_E_RANGE, "d_out holds fewer rows per rank than the largest shard (see surge_replay_comm_counts)");
   const int64_t M = c->max_count;
   if (!packed) {
-    // v2 slot schemas use all 64 bytes of a state: shards travel as they are, straight between the state arrays
-    // (grouped per-peer send / recv; rows beyond a rank's count are zeroed first so they read as None)
+    // v2 slot schemas use all 64 bytes of a state, and SURGE_GATHER_P2P_RAW asks for it: shards travel as they are,
+    // straight between the state arrays (grouped per-peer send / recv; rows between a rank's count and the largest
+    // shard are zeroed so they read as None; rows beyond the largest shard of a wider d_out stay untouched)
     COMM_HIP(hipEventRecord(c->ready, compute));
     COMM_HIP(hipStreamWaitEvent(c->side, c->ready, 0));
     char* out = (char*)d_out;
     const size_t pitch = (size_t)out_rows_per_rank * 64;
-    COMM_HIP(hipMemsetAsync(out, 0, (size_t)c->world * pitch, c->side));
+    for (int r = 0; r < c->world; ++r)  // rows between a rank's count and the largest shard read as None
+      if (c->counts[(size_t)r] < M)
+        COMM_HIP(hipMemsetAsync(out + (size_t)r * pitch + (size_t)c->counts[(size_t)r] * 64, 0, (size_t)(M - c->counts[(size_t)r]) * 64, c->side));
     if (n_local > 0) COMM_HIP(hipMemcpyAsync(out + (size_t)c->rank * pitch, d_states, (size_t)n_local * 64, hipMemcpyDeviceToDevice, c->side));
     if (c->world > 1) {
       COMM_NCCL(c, c->api->GroupStart());

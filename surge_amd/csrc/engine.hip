@@ -1298,7 +1298,7 @@ int32_t surge_replay_allgather_snapshot(surge_replay_handle* h, const void* d_st
                                         int64_t rows_per_rank, int32_t slot, int32_t mode) {
   if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
   if (!h->comm) return fail(h, SURGE_E_STATE, "no communicator: surge_replay_comm_init first");
-  if (mode != SURGE_GATHER_P2P && mode != SURGE_GATHER_ALLGATHER) return fail(h, SURGE_E_INVALID, "unknown gather mode");
+  if (mode != SURGE_GATHER_P2P && mode != SURGE_GATHER_ALLGATHER && mode != SURGE_GATHER_P2P_RAW) return fail(h, SURGE_E_INVALID, "unknown gather mode");
   if (!d_states) {
     if (!h->bound) return fail(h, SURGE_E_STATE, "allgather_snapshot of the resident state before load_csr/bind_device_csr");
     if (n_local > h->n_agg) return fail(h, SURGE_E_RANGE, "n_local exceeds the resident state");
@@ -1322,7 +1322,7 @@ int32_t surge_replay_allgather_snapshot(surge_replay_handle* h, const void* d_st
     h->gathered_rows[slot] = mx;
     d_out = h->gathered[slot].ptr;
   }
-  const int32_t rc = comm_allgather(h->comm, h->stream, d_states, n_local, d_out, rows_per_rank, slot, mode, !h->v2, &err);
+  const int32_t rc = comm_allgather(h->comm, h->stream, d_states, n_local, d_out, rows_per_rank, slot, mode, !h->v2 && mode != SURGE_GATHER_P2P_RAW, &err);
   return rc == SURGE_OK ? rc : fail(h, rc, err);
 }
 

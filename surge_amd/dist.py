@@ -118,8 +118,12 @@ class NativeSnapshotGather:
         self.device = torch.device(device)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.mode = mode or os.environ.get("SURGE_SNAPSHOT_GATHER", "p2p")
-        self.packed = True  # the library always ships the 40-byte wire form
+        # p2p_raw (default): per-peer send / recv of the 64-byte states, no pack / expand passes — least HBM traffic, which is
+        # what an exchange overlapped with the HBM-bound fold competes for; p2p / allgather: the 40-byte wire form
+        self.mode = mode or os.environ.get("SURGE_SNAPSHOT_GATHER", "p2p_raw")
+        if self.mode not in ("p2p", "p2p_raw", "allgather"):
+            raise ValueError(f"unknown snapshot gather mode {self.mode!r}")
+        self.packed = self.mode != "p2p_raw"
         uid = [engine.comm_unique_id() if self.rank == 0 else None]
         dist.broadcast_object_list(uid, src=0, group=group)
         engine.comm_init(self.rank, self.world, uid[0])
@@ -134,7 +138,7 @@ class NativeSnapshotGather:
     def launch(self, slot: int, local_padded, ready_event=None) -> None:
         # the library orders the exchange after everything already enqueued on the engine's fold stream
         self.engine.allgather_snapshot(local_padded, self.n_local, self.out[slot], self.max_count, slot,
-                                       1 if self.mode == "allgather" else 0)
+                                       {"p2p": 0, "allgather": 1, "p2p_raw": 2}[self.mode])
 
     def wait(self, slot: int, stream=None) -> None:
         self.engine.comm_wait(slot)  # the engine's fold stream waits for that slot's exchange
@@ -169,9 +173,11 @@ class SnapshotGather:
         # pair).  "allgather": the library collective.
         self.mode = mode or os.environ.get("SURGE_SNAPSHOT_GATHER", "p2p")
         # shards travel in the 40-byte wire form (the 24-byte reserved tail of a state is always zero) and are
-        # expanded back to 64 bytes on arrival: 37.5 % less xGMI traffic, which is what bounds the exchange
+        # expanded back to 64 bytes on arrival: 37.5 % less xGMI traffic; "p2p_raw" = p2p without that (64-byte states)
         self.engine = engine
         self.packed = (os.environ.get("SURGE_SNAPSHOT_PACKED", "1") == "1") if packed is None else packed
+        if self.mode == "p2p_raw":
+            self.mode, self.packed = "p2p", False
 
         self.dist, self.torch = dist, torch
         self.group = group

@@ -26,7 +26,7 @@ def run_ranks(world, tmp_path, devices, mode=0, timeout=240, env=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_c_abi_exchange_single_rank(tmp_path, mode):
     (rc, out), = run_ranks(1, tmp_path, [0], mode)
     assert rc == 0 and "OK 0" in out, out
@@ -75,7 +75,7 @@ def test_rccl_stub_builds_and_exports_what_the_product_binds():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,mode", [(2, 0), (2, 1), (3, 0)])
+@pytest.mark.parametrize("world,mode", [(2, 0), (2, 1), (2, 2), (3, 0), (3, 2)])  # mode 2 = 64-byte states, no pack / expand
 def test_c_abi_exchange_several_ranks_one_gpu_over_the_stub_transport(tmp_path, world, mode):
     """The N > 1 code of comm.hip with real processes: SURGE_RCCL_LIBRARY points the product at tests/rccl_stub, whose
     transport (files) does not mind that every rank sits on cuda:0.  Counts exchange, per-peer send/recv pairing, ragged
