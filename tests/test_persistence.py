@@ -214,3 +214,88 @@ def test_multilanguage_gateway_sequence_on_a_new_aggregate():
         assert store.get_aggregate("someone-else") == State("someone-else", 3, 3)
     finally:
         store.close()
+
+
+# ---- CPU property test: the protocol over random command / ApplyEvents sequences, against a literal KTable ------------------
+class _LiteralKTable:
+    """S2 backed by the model's literal handle_event (no GPU): what the GPU store must be indistinguishable from."""
+
+    def __init__(self, bl):
+        self.bl, self.state = bl, {}
+
+    def apply_events(self, events):
+        model = self.bl.command_model()
+        for e in events:
+            self.state[e.aggregateId] = model.handle_event(self.state.get(e.aggregateId), e)
+
+    def get_aggregate_bytes(self, aggregate_id):
+        s = self.state.get(aggregate_id)
+        return None if s is None else self.bl.aggregate_write_formatting().write_state(s).value
+
+
+def test_random_sequences_keep_actor_store_and_published_state_records_in_step():
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    step = st.tuples(st.sampled_from(["a", "b", "c"]),
+                     st.sampled_from(["inc", "dec", "nothing", "noop", "fail", "throwing", "apply", "apply0", "progress", "restart"]))
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(step, min_size=1, max_size=40), st.booleans())
+    def run(steps, state_only):
+        bl = CounterBusinessLogic()
+        bl.publish_state_only = state_only
+        store = _LiteralKTable(bl)
+        pub = StatePublisher(store)
+        actors, expect = {}, {}
+
+        def actor(agg):
+            if agg not in actors:
+                pub.ktable_progress()  # an actor may only initialise once the KTable has caught up
+                actors[agg] = GpuPersistentActor(bl, agg, store, pub)
+            return actors[agg]
+
+        for agg, op in steps:
+            before = len(pub.published)
+            cur = expect.get(agg)
+            version = cur.version if cur else 0
+            if op == "progress":
+                pub.ktable_progress()
+                continue
+            if op == "restart":  # passivation: the next message creates a fresh actor that re-reads the store
+                actors.pop(agg, None)
+                continue
+            a = actor(agg)
+            if op in ("inc", "dec"):
+                r = a.process_message(Increment(agg) if op == "inc" else Decrement(agg))
+                count = (cur.count if cur else 0) + (1 if op == "inc" else -1)
+                expect[agg] = State(agg, count, version + 1)
+                assert r == ACKSuccess(expect[agg]) and len(pub.published) == before + 1
+                assert len(pub.published[-1]) == (1 if state_only else 2)
+            elif op == "nothing":
+                assert a.process_message(DoNothing(agg)) == ACKSuccess(cur) and len(pub.published) == before
+            elif op == "noop":  # the event is published although the state may not change
+                r = a.process_message(CreateNoOpEvent(agg))
+                expect[agg] = cur if cur else State(agg, 0, 0)
+                assert r == ACKSuccess(expect[agg]) and len(pub.published) == before + 1
+            elif op == "fail":
+                assert isinstance(a.process_message(FailCommandProcessing(agg, RuntimeError("x"))), ACKError) and len(pub.published) == before
+            elif op == "throwing":
+                assert isinstance(a.process_message(CreateExceptionThrowingEvent(agg, RuntimeError("x"))), ACKError) and len(pub.published) == before
+            elif op == "apply":
+                r = a.apply_events([CountIncremented(agg, 2, version + 1)])
+                expect[agg] = State(agg, (cur.count if cur else 0) + 2, version + 1)
+                assert r == ACKSuccess(expect[agg]) and [type(x) for x in pub.published[-1]] == [StateRecord]
+            elif op == "apply0" and cur is not None:  # an event that leaves the state equal publishes nothing
+                assert a.apply_events([CountIncremented(agg, 0, version)]) == ACKSuccess(cur) and len(pub.published) == before
+            if len(pub.published) > before:  # the last record of every publish is the state the actor now holds
+                last = pub.published[-1][-1]
+                assert isinstance(last, StateRecord) and last.key == agg
+                assert last.value == bl.aggregate_write_formatting().write_state(expect[agg]).value
+        pub.ktable_progress()
+        for agg, s in expect.items():  # the KTable (here literal; on the GPU: the resident state) ends where the actors are
+            assert store.get_aggregate_bytes(agg) == (None if s is None else bl.aggregate_write_formatting().write_state(s).value)
+            assert pub.tracker.is_aggregate_state_current(agg)
+
+    run()
