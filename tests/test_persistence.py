@@ -299,3 +299,72 @@ def test_random_sequences_keep_actor_store_and_published_state_records_in_step()
             assert pub.tracker.is_aggregate_state_current(agg)
 
     run()
+
+
+@pytest.mark.gpu
+def test_bank_account_command_sequence_state_of_record_on_the_gpu():
+    """The docs sample (BankAccountCommandModel.scala:53-86; the disabled BankAccountCommandEngineSpec.scala:44-68 holds the
+    numbers: create 1000.0, credit 100.0 -> 1100.0) through the actor protocol: f64 balances are bit-copied by the fold
+    (CREATE / REQUIRE classes), domain rejections publish nothing."""
+    import uuid
+
+    from surge_amd.command import SurgeCommandBusinessLogic
+    from surge_amd.core import KafkaTopic
+    from surge_amd.fixtures import (
+        AccountDoesNotExistException, BankAccount, BankAccountCommandModel, BankAccountFormat, CreateAccount, CreditAccount,
+        DebitAccount, InsufficientFundsException,
+    )
+    from surge_amd.store import GpuReplayStateStore
+
+    class BL(SurgeCommandBusinessLogic):
+        aggregate_name = "BankAccount"
+        state_topic, events_topic = KafkaTopic("bank-account-state"), KafkaTopic("bank-account-events")
+        publish_state_only = True  # the sample publishes events too; their text (play-json Double) is parity-unpinned
+
+        def __init__(self):
+            self.m, self.f = BankAccountCommandModel(), BankAccountFormat()
+
+        def command_model(self):
+            return self.m
+
+        def aggregate_read_formatting(self):
+            return self.f
+
+        def aggregate_write_formatting(self):
+            return self.f
+
+    bl = BL()
+    store = GpuReplayStateStore(bl)
+    try:
+        other = uuid.UUID(int=99)
+        from surge_amd.fixtures import BankAccountCreated
+
+        store.restore([BankAccountCreated(other, "Someone Else", "0000", 5.0)])
+        pub = StatePublisher(store)
+        acct = uuid.UUID(int=7)
+        actor = GpuPersistentActor(bl, str(acct), store, pub, assigned_partition=3)
+        assert actor.get_state() is None
+        r = actor.process_message(CreateAccount(acct, "Jane Doe", "1234", 1000.0))
+        assert r == ACKSuccess(BankAccount(acct, "Jane Doe", "1234", 1000.0))
+        assert actor.process_message(CreditAccount(acct, 100.0)) == ACKSuccess(BankAccount(acct, "Jane Doe", "1234", 1100.0))
+        n = len(pub.published)
+        r = actor.process_message(DebitAccount(acct, 2000.0))
+        assert isinstance(r, ACKError) and isinstance(r.exception, InsufficientFundsException) and len(pub.published) == n
+        assert actor.process_message(DebitAccount(acct, 100.25)) == ACKSuccess(BankAccount(acct, "Jane Doe", "1234", 999.75))
+        n = len(pub.published)
+        # creating an existing account yields no events and the same state: nothing to publish (PersistentActor.scala:212)
+        assert actor.process_message(CreateAccount(acct, "Mallory", "6666", 1.0)) == ACKSuccess(BankAccount(acct, "Jane Doe", "1234", 999.75))
+        assert len(pub.published) == n
+        stranger = GpuPersistentActor(bl, str(uuid.UUID(int=8)), store, pub)
+        r = stranger.process_message(CreditAccount(uuid.UUID(int=8), 1.0))
+        assert isinstance(r, ACKError) and isinstance(r.exception, AccountDoesNotExistException) and len(pub.published) == n
+        assert [[type(x) for x in b] for b in pub.published] == [[StateRecord]] * 3  # create, credit, debit
+        last = pub.published[-1][-1]
+        assert (last.topic, last.partition, last.key) == ("bank-account-state", 3, str(acct))
+        pub.ktable_progress()  # the account was born after recovery: the resident state grows, the three events fold onto it
+        assert json.loads(store.get_aggregate_bytes(str(acct))) == json.loads(last.value)
+        assert store.get_aggregate(str(acct)) == BankAccount(acct, "Jane Doe", "1234", 999.75)
+        assert store.get_aggregate(str(other)) == BankAccount(other, "Someone Else", "0000", 5.0)
+        assert GpuPersistentActor(bl, str(acct), store, pub).get_state() == BankAccount(acct, "Jane Doe", "1234", 999.75)
+    finally:
+        store.close()
