@@ -84,8 +84,15 @@ int32_t surge_ingest_counters(const surge_ingest* g, int64_t out[8]);
 /* Exposed for tests / other bindings. */
 uint32_t surge_crc32c(const uint8_t* data, int64_t len);          /* SSE4.2 CRC32 instruction when the CPU has it */
 uint32_t surge_crc32c_portable(const uint8_t* data, int64_t len); /* table walk; must always agree with the above */
-/* LZ4 frame -> bytes.  Returns the decompressed size, or a negative status. */
+/* LZ4 frame -> bytes.  Returns the decompressed size, or a negative status (-6: dst too small, -7: not a valid
+ * frame, which includes a wrong header checksum — kafka-clients rejects those for message format v2 as well). */
 int64_t surge_lz4_frame_decompress(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
+/* bytes -> LZ4 frame as kafka-clients writes it (version 01, block independence, 64 KiB blocks, header checksum).
+ * dst_cap must be at least surge_lz4_frame_bound(n); returns the frame size or a negative status. */
+int64_t surge_lz4_frame_bound(int64_t n);
+int64_t surge_lz4_frame_compress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t dst_cap);
+/* XXH32 (the frame's header checksum is its second byte over the descriptor). */
+uint32_t surge_xxh32(const uint8_t* data, int64_t len, uint32_t seed);
 
 #ifdef __cplusplus
 }

@@ -8,8 +8,11 @@
  *     ProducerRecord(stateTopic, partition, key = aggregateId, value = writeState(state).value | null)
  * framed as message-format-v2 record batches (KIP-98; the same framing include/surge_ingest.h decodes — kafka-clients
  * 3.2.3 is not vendored under /root/reference: parity unpinned, pinned on the format's own CRC-32C and on a round trip
- * through the independent decoder and the test-side writer).  Batches are written uncompressed and non-transactional
- * (producerId -1): a bulk snapshot is not part of any command's transaction.
+ * through the independent decoder and the test-side writer).  Batches are non-transactional (producerId -1: a bulk
+ * snapshot is not part of any command's transaction) and either uncompressed or — like the reference's producer,
+ * compression.type = lz4, modules/common/src/main/resources/reference.conf:112 — LZ4: the records section of a batch
+ * is one LZ4 frame as kafka-clients writes it (surge_lz4_frame_compress in surge_ingest.h; the tests decode it with
+ * liblz4 itself).
  *
  * Which aggregates get a record comes from surge_replay_snapshot_delta (include/surge_replay.h): kind[i] =
  * SURGE_SNAP_SKIP (nothing: state unchanged, PersistentActor.scala:212,257), SURGE_SNAP_VALUE, SURGE_SNAP_TOMBSTONE.
@@ -30,6 +33,11 @@ typedef struct surge_snapshot_writer surge_snapshot_writer;
 int32_t surge_snapshot_writer_create(int32_t n_partitions, int32_t max_records_per_batch, int64_t max_batch_bytes,
                                      surge_snapshot_writer** out);
 int32_t surge_snapshot_writer_destroy(surge_snapshot_writer* w);
+/* Codec of the batches closed from now on (Kafka attribute bits 0-2): NONE (default) or LZ4.  Call between batches
+ * (right after create, flush or reset). */
+#define SURGE_SNAPSHOT_CODEC_NONE 0
+#define SURGE_SNAPSHOT_CODEC_LZ4  3
+int32_t surge_snapshot_writer_set_compression(surge_snapshot_writer* w, int32_t codec);
 const char* surge_snapshot_writer_last_error(const surge_snapshot_writer* w);
 
 /* For every i in [0, n) with kind[i] != SURGE_SNAP_SKIP append one record to partition[i]:

@@ -15,6 +15,7 @@ from surge_amd.replay import ReplayEngine
 from surge_amd.snapshot import BulkSnapshotPublisher
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+compression = sys.argv[2] if len(sys.argv) > 2 else "none"  # "lz4": compress the record batches like the reference producer
 dev = torch.device("cuda:0")
 lens = synth.zipf_lengths(torch.arange(n, dtype=torch.int64, device=dev), 3, max_len=64)
 so, ev = synth.csr_log_device(lens, 3, mix=synth.C1_MIX)
@@ -23,7 +24,7 @@ with ReplayEngine() as eng:
     eng.load_csr(so, ev)
     eng.fold()
     t0 = time.perf_counter()
-    pub = BulkSnapshotPublisher(eng, keys, 64)
+    pub = BulkSnapshotPublisher(eng, keys, 64, compression=compression)
     setup_s = time.perf_counter() - t0
     t0 = time.perf_counter()
     full = pub.publish()

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
-SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_slots.hip", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "snapshot_writer.cpp")
+SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_slots.hip", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")
 HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
@@ -84,12 +84,16 @@ INGEST_EXPORTS = (
     "surge_crc32c",
     "surge_crc32c_portable",
     "surge_lz4_frame_decompress",
+    "surge_lz4_frame_bound",
+    "surge_lz4_frame_compress",
+    "surge_xxh32",
 )
 
 #: every symbol ``include/surge_snapshot.h`` declares
 SNAPSHOT_EXPORTS = (
     "surge_snapshot_writer_create",
     "surge_snapshot_writer_destroy",
+    "surge_snapshot_writer_set_compression",
     "surge_snapshot_writer_last_error",
     "surge_snapshot_writer_append",
     "surge_snapshot_writer_flush",
@@ -230,6 +234,9 @@ def load() -> ctypes.CDLL:
         "surge_crc32c": ([vp, i64], ctypes.c_uint32),
         "surge_crc32c_portable": ([vp, i64], ctypes.c_uint32),
         "surge_lz4_frame_decompress": ([vp, i64, vp, i64], i64),
+        "surge_lz4_frame_bound": ([i64], i64),
+        "surge_lz4_frame_compress": ([vp, i64, vp, i64], i64),
+        "surge_xxh32": ([vp, i64, ctypes.c_uint32], ctypes.c_uint32),
     })
     sig.update({
         "surge_snapshot_writer_create": ([i32, i32, i64, ctypes.POINTER(vp)], i32),
@@ -239,6 +246,7 @@ def load() -> ctypes.CDLL:
         "surge_snapshot_writer_flush": ([vp], i32),
         "surge_snapshot_writer_partition": ([vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
         "surge_snapshot_writer_reset": ([vp], i32),
+        "surge_snapshot_writer_set_compression": ([vp, i32], i32),
     })
     for name in EXPORTS + INGEST_EXPORTS + SNAPSHOT_EXPORTS:
         try:

@@ -325,10 +325,13 @@ int64_t surge_lz4_frame_decompress(const uint8_t* src, int64_t n, uint8_t* dst, 
   p++;  // BD: block maximum size, not needed to decode
   if ((flg >> 6) != 1) return SURGE_E_CORRUPT;  // version 01
   const bool block_checksum = flg & 0x10, content_size = flg & 0x08, content_checksum = flg & 0x04, dict_id = flg & 0x01;
+  const uint8_t* const descriptor = p - 2;
   if (content_size) p += 8;
   if (dict_id) p += 4;
-  p += 1;  // header checksum (xxh32 of the descriptor >> 8); not verified
-  if (p > end) return SURGE_E_CORRUPT;
+  if (p >= end) return SURGE_E_CORRUPT;
+  // header checksum: second byte of XXH32(descriptor); kafka-clients verifies it for message format v2
+  if (*p != (uint8_t)(surge_xxh32(descriptor, (int64_t)(p - descriptor), 0) >> 8)) return SURGE_E_CORRUPT;
+  p += 1;
   int64_t op = 0;
   while (true) {
     if (end - p < 4) return SURGE_E_CORRUPT;

@@ -57,6 +57,7 @@ struct surge_snapshot_writer {
   std::vector<PartitionLog> parts;
   int32_t max_records = 10000;
   int64_t max_bytes = 1 << 20;
+  int32_t codec = SURGE_SNAPSHOT_CODEC_NONE;
   std::string err;
 };
 
@@ -68,8 +69,14 @@ int32_t fail(surge_snapshot_writer* w, int32_t code, const std::string& m) {
   return code;
 }
 
-void close_batch(PartitionLog& p) {
+void close_batch(PartitionLog& p, int32_t codec) {
   if (p.open_records == 0) return;
+  if (codec == SURGE_SNAPSHOT_CODEC_LZ4) {  // the records section becomes ONE LZ4 frame (DefaultRecordBatch + KafkaLZ4BlockOutputStream)
+    std::vector<uint8_t> frame((size_t)surge_lz4_frame_bound((int64_t)p.open.size()));
+    const int64_t n = surge_lz4_frame_compress(p.open.data(), (int64_t)p.open.size(), frame.data(), (int64_t)frame.size());
+    frame.resize((size_t)n);
+    p.open.swap(frame);
+  }
   std::vector<uint8_t>& o = p.bytes;
   put_be(o, (uint64_t)p.base_offset, 8);
   put_be(o, (uint64_t)(kHeader - 12 + p.open.size()), 4);  // batchLength: everything after this field
@@ -78,7 +85,7 @@ void close_batch(PartitionLog& p) {
   const size_t crc_at = o.size();
   put_be(o, 0, 4);                                         // crc, patched below
   const size_t crc_from = o.size();
-  put_be(o, 0, 2);                                         // attributes: no compression, CreateTime, not transactional
+  put_be(o, (uint64_t)(codec & 7), 2);                     // attributes: codec in bits 0-2, CreateTime, not transactional
   put_be(o, (uint64_t)(p.open_records - 1), 4);            // lastOffsetDelta
   put_be(o, (uint64_t)p.base_ts, 8);
   put_be(o, (uint64_t)p.max_ts, 8);
@@ -113,6 +120,15 @@ int32_t surge_snapshot_writer_create(int32_t n_partitions, int32_t max_records_p
   if (max_records_per_batch > 0) w->max_records = max_records_per_batch;
   if (max_batch_bytes > 0) w->max_bytes = max_batch_bytes;
   *out = w;
+  return OK;
+}
+
+int32_t surge_snapshot_writer_set_compression(surge_snapshot_writer* w, int32_t codec) {
+  if (!w) return fail(nullptr, E_INVALID, "writer is NULL");
+  if (codec != SURGE_SNAPSHOT_CODEC_NONE && codec != SURGE_SNAPSHOT_CODEC_LZ4) return fail(w, E_INVALID, "codec must be NONE (0) or LZ4 (3)");
+  for (const PartitionLog& p : w->parts)
+    if (p.open_records != 0) return fail(w, E_INVALID, "flush before changing the codec (a batch has one codec)");
+  w->codec = codec;
   return OK;
 }
 
@@ -188,7 +204,7 @@ int32_t surge_snapshot_writer_append(surge_snapshot_writer* w, int64_t n, const 
         p.next_offset += 1;
         p.open_records += 1;
         p.n_records += 1;
-        if (p.open_records >= w->max_records || (int64_t)o.size() >= w->max_bytes) close_batch(p);
+        if (p.open_records >= w->max_records || (int64_t)o.size() >= w->max_bytes) close_batch(p, w->codec);
       }
     };
     unsigned hw = std::thread::hardware_concurrency();
@@ -225,7 +241,7 @@ int32_t surge_snapshot_writer_append(surge_snapshot_writer* w, int64_t n, const 
 int32_t surge_snapshot_writer_flush(surge_snapshot_writer* w) {
   if (!w) return fail(nullptr, E_INVALID, "writer is NULL");
   try {
-    for (PartitionLog& p : w->parts) close_batch(p);
+    for (PartitionLog& p : w->parts) close_batch(p, w->codec);
   } catch (const std::bad_alloc&) {
     return fail(w, E_NOMEM, "out of host memory while encoding");
   }

@@ -74,13 +74,21 @@ class RecordBatchWriter:
     """Kafka record batches (message format v2) of a state topic, one log per partition, through the C ABI of
     ``include/surge_snapshot.h`` (host C++; the same library decodes them again in ``include/surge_ingest.h``)."""
 
-    def __init__(self, n_partitions: int, max_records_per_batch: int = 0, max_batch_bytes: int = 0):
+    CODECS = {"none": 0, "lz4": 3}  # Kafka attribute bits 0-2; lz4 is the reference producer's setting (reference.conf:112)
+
+    def __init__(self, n_partitions: int, max_records_per_batch: int = 0, max_batch_bytes: int = 0, compression: str = "none"):
         self._lib = _native.load()
         self._h = ctypes.c_void_p()
         rc = self._lib.surge_snapshot_writer_create(n_partitions, max_records_per_batch, max_batch_bytes, ctypes.byref(self._h))
         if rc != 0:
             raise RuntimeError(f"surge_snapshot_writer_create: {rc}: {(self._lib.surge_snapshot_writer_last_error(None) or b'').decode()}")
         self.n_partitions = n_partitions
+        if compression != "none":
+            self.set_compression(compression)
+
+    def set_compression(self, compression: str) -> None:
+        """Codec of the batches closed from now on (call right after create, flush or reset)."""
+        self._check(self._lib.surge_snapshot_writer_set_compression(self._h, self.CODECS[compression]))
 
     def close(self):
         if self._h:
@@ -129,9 +137,11 @@ class BulkSnapshotPublisher:
 
     ``keys`` are the aggregate ids in dense-index order; ``template`` declares the model's serialized state."""
 
-    def __init__(self, engine, keys: Optional[Sequence[str]], n_partitions: int, template=None, device=None, tables=None):
+    def __init__(self, engine, keys: Optional[Sequence[str]], n_partitions: int, template=None, device=None, tables=None,
+                 compression: str = "none"):
         """``keys``: aggregate ids in dense-index order; or ``tables = (keys_utf8, key_off, keys_utf16, off16)`` as
-        tensors / arrays built without Python strings (large synthetic populations)."""
+        tensors / arrays built without Python strings (large synthetic populations).  ``compression``: "none" or "lz4"
+        (the reference producer's ``compression.type``)."""
         import torch
 
         from .encode import JsonTemplate, key_table_utf8
@@ -140,7 +150,7 @@ class BulkSnapshotPublisher:
         self.engine, self.n_partitions = engine, n_partitions
         self.template = template or JsonTemplate.counter()
         self.device = torch.device(device or f"cuda:{engine.device}")
-        self.writer = RecordBatchWriter(n_partitions)
+        self.writer = RecordBatchWriter(n_partitions, compression=compression)
         if tables is None:
             data, off = key_table_utf8(keys)
             u16, o16 = utf16_table(keys)

@@ -109,11 +109,18 @@ def lz4_block_compress(data: bytes) -> bytes:
     return bytes(out)
 
 
+def header_checksum(descriptor: bytes) -> int:
+    """HC of an LZ4 frame: second byte of XXH32(descriptor, seed 0) — from the third-party xxhash module."""
+    import xxhash
+
+    return (xxhash.xxh32(descriptor, seed=0).intdigest() >> 8) & 0xFF
+
+
 def lz4_frame(data: bytes, block_size: int = 65536, store_incompressible: bool = True, content_checksum: bool = False) -> bytes:
     """LZ4 frame: magic, FLG (version 01, block independence), BD (64 KiB), HC, blocks, EndMark."""
     flg = 0x60 | (0x04 if content_checksum else 0)
     out = bytearray(struct.pack("<I", 0x184D2204))
-    out += bytes([flg, 0x40, 0x00])  # HC is not verified by the decoder (xxh32 of the descriptor)
+    out += bytes([flg, 0x40, header_checksum(bytes([flg, 0x40]))])
     for s in range(0, len(data), block_size):
         chunk = data[s:s + block_size]
         comp = lz4_block_compress(chunk)

@@ -53,8 +53,25 @@ def test_crc32c_published_vectors_of_rfc_3720():
     assert len(read10) == 48 and crc(read10) == 0xD9963A56  # an iSCSI SCSI Read (10) command PDU
 
 
+def test_lz4_header_checksum_is_verified_like_kafka_clients_does_for_v2():
+    L = _native.load()
+    blk = bytes([0x50]) + b"hello"
+    body = struct.pack("<I", len(blk)) + blk + struct.pack("<I", 0)
+    good = struct.pack("<I", 0x184D2204) + bytes([0x60, 0x40, 0x82]) + body
+    assert lz4_decompress(good) == b"hello"
+    for hc in (0x00, 0x83):
+        bad = struct.pack("<I", 0x184D2204) + bytes([0x60, 0x40, hc]) + body
+        assert L.surge_lz4_frame_decompress(bad, len(bad), ctypes.create_string_buffer(64), 64) == -7
+    xxhash = pytest.importorskip("xxhash")  # third party: the product's XXH32 against the xxhash module
+    rng = np.random.default_rng(3)
+    for n in list(range(0, 40)) + [63, 64, 65, 1000, 4097]:
+        for seed in (0, 1, 0x9E3779B1):
+            data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+            assert L.surge_xxh32(data, n, seed) == xxhash.xxh32(data, seed=seed).intdigest(), (n, seed)
+
+
 def test_lz4_hand_assembled_sequences():
-    hdr = struct.pack("<I", 0x184D2204) + bytes([0x60, 0x40, 0x00])
+    hdr = struct.pack("<I", 0x184D2204) + bytes([0x60, 0x40, 0x82])  # HC 0x82 = (XXH32(60 40) >> 8) & 0xff, what every liblz4 frame with this descriptor carries
     # literals only: token 0x50 = 5 literals, no match
     blk = bytes([0x50]) + b"hello"
     assert lz4_decompress(hdr + struct.pack("<I", len(blk)) + blk + struct.pack("<I", 0)) == b"hello"
@@ -68,7 +85,8 @@ def test_lz4_hand_assembled_sequences():
     assert lz4_decompress(hdr + struct.pack("<I", len(blk)) + blk + struct.pack("<I", 0)) == lit
     # stored (uncompressed) block + content checksum flag
     raw = b"stored-block"
-    frame = struct.pack("<I", 0x184D2204) + bytes([0x64, 0x40, 0x00]) + struct.pack("<I", len(raw) | 0x80000000) + raw + struct.pack("<I", 0) + b"\0\0\0\0"
+    frame = (struct.pack("<I", 0x184D2204) + bytes([0x64, 0x40, kw.header_checksum(bytes([0x64, 0x40]))]) +
+             struct.pack("<I", len(raw) | 0x80000000) + raw + struct.pack("<I", 0) + b"\0\0\0\0")
     assert lz4_decompress(frame) == raw
 
 
@@ -76,7 +94,7 @@ def test_lz4_hand_assembled_sequences():
 def test_lz4_overlapping_matches_of_every_period(period):
     # a match whose offset is shorter than its length replicates the last `period` bytes: the decoder's three
     # copy regimes (offset >= length, 8 <= offset < length, offset < 8) must all produce the periodic extension
-    hdr = struct.pack("<I", 0x184D2204) + bytes([0x60, 0x40, 0x00])
+    hdr = struct.pack("<I", 0x184D2204) + bytes([0x60, 0x40, 0x82])  # HC 0x82 = (XXH32(60 40) >> 8) & 0xff, what every liblz4 frame with this descriptor carries
     seedb = bytes((37 * i + 11) & 0xFF for i in range(period))
     for ml in (4, 5, period, period + 1, 3 * period + 5, 300):
         if ml < 4:
@@ -293,8 +311,9 @@ def test_lz4_frame_with_a_content_size_field_sizes_the_first_attempt():
 
     data = b"\x00" * 300000
     body = kw.lz4_frame(data)
-    # same frame with FLG.content_size set and the 8-byte size after BD (the header checksum is not verified)
-    frame = body[:4] + bytes([body[4] | 0x08, body[5]]) + struct.pack("<Q", len(data)) + body[6:]
+    # same frame with FLG.content_size set and the 8-byte size after BD (the header checksum covers FLG, BD and the size)
+    desc = bytes([body[4] | 0x08, body[5]]) + struct.pack("<Q", len(data))
+    frame = body[:4] + desc + bytes([kw.header_checksum(desc)]) + body[7:]
     out = ctypes.create_string_buffer(len(data))
     assert _native.load().surge_lz4_frame_decompress(frame, len(frame), out, len(data)) == len(data)
     assert out.raw == data
@@ -473,3 +492,78 @@ def test_record_varints_written_by_the_protobuf_runtime_are_read_and_the_writers
         nh, pos = sv(pos)
         assert nh == 0 and pos == end
     assert pos == len(data)
+
+
+# ---- the product's LZ4 frame WRITER (state-topic batches compressed like the reference's producer) -------------------------
+def _product_lz4_frame(data: bytes) -> bytes:
+    L = _native.load()
+    cap = L.surge_lz4_frame_bound(len(data))
+    dst = ctypes.create_string_buffer(cap)
+    n = L.surge_lz4_frame_compress(data, len(data), dst, cap)
+    assert 0 < n <= cap, n
+    return dst.raw[:n]
+
+
+def _frame_payloads():
+    rng = np.random.default_rng(11)
+    yield "empty", b""
+    yield "one", b"x"
+    yield "twelve", b"abcabcabcabc"                       # shorter than MFLIMIT + 1: literals only
+    yield "thirteen", b"a" * 13                            # the first length at which a match may be emitted
+    yield "json", b"".join(b'{"aggregateId":"acct-%08d","count":%d,"version":%d}' % (i, i % 7, i) for i in range(30000))
+    yield "zeros", bytes(3 << 20)                          # long matches, many 64 KiB blocks
+    yield "random", rng.integers(0, 256, 200_000, dtype=np.uint8).tobytes()   # incompressible: stored blocks
+    yield "block_edge", bytes(rng.integers(0, 3, 65536 * 2 + 5, dtype=np.uint8))
+    yield "far_matches", (rng.integers(0, 256, 70_000, dtype=np.uint8).tobytes()) * 2   # repeats beyond the 64 KiB window of a block
+    for n in (65535, 65536, 65537):
+        yield f"ab{n}", (b"ab" * n)[:n]
+
+
+@pytest.mark.parametrize("name,data", list(_frame_payloads()), ids=[n for n, _ in _frame_payloads()])
+def test_lz4_frames_written_by_the_product_are_decoded_by_liblz4_and_by_the_product(name, data):
+    pa = pytest.importorskip("pyarrow")
+    if not pa.Codec.is_available("lz4"):
+        pytest.skip("this pyarrow build has no LZ4 frame codec")
+    frame = _product_lz4_frame(data)
+    assert frame[:7] == b"\x04\x22\x4d\x18\x60\x40\x82" and frame[-4:] == b"\0\0\0\0"   # kafka-clients' descriptor and EndMark
+    back = pa.decompress(frame, decompressed_size=len(data), codec="lz4", asbytes=True) if data else b""
+    assert back == data                                       # the reference LZ4 library accepts it
+    assert lz4_decompress(frame, cap=len(data) + 64) == data  # and so does the product's own reader
+    if name in ("json", "zeros") or name.startswith("ab"):
+        assert len(frame) < len(data) // 2, (name, len(frame), len(data))  # it does compress
+    L = _native.load()
+    assert L.surge_lz4_frame_compress(data, len(data), ctypes.create_string_buffer(8), 8) == -6  # too small a buffer is refused
+
+
+def test_lz4_compressed_state_topic_batches_round_trip_and_match_the_uncompressed_records():
+    from surge_amd.snapshot import RecordBatchWriter
+
+    rng = np.random.default_rng(2)
+    n = 5000
+    keys = [f"acct-{i:08d}".encode() for i in range(n)]
+    vals = [b'{"aggregateId":"acct-%08d","count":%d,"version":%d}' % (i, int(rng.integers(-5, 5)), i) for i in range(n)]
+    kind = np.where(rng.random(n) < 0.1, 2, 1).astype(np.uint8)  # some tombstones
+    part = rng.integers(0, 4, n).astype(np.int32)
+    key_off, val_off = np.cumsum([0] + [len(k) for k in keys]), np.cumsum([0] + [len(v) for v in vals])
+    out = {}
+    for codec in ("none", "lz4"):
+        with RecordBatchWriter(4, max_records_per_batch=700, compression=codec) as w:
+            w.append(kind, part, np.frombuffer(b"".join(keys), np.uint8), key_off, np.frombuffer(b"".join(vals), np.uint8), val_off,
+                     timestamp_ms=1700000000000)
+            out[codec] = [w.partition_bytes(p) for p in range(4)]
+    for p in range(4):
+        plain, n_plain, _ = out["none"][p]
+        packed, n_packed, _ = out["lz4"][p]
+        assert n_plain == n_packed and len(packed) < len(plain) // 2
+        assert packed[21 + 1] & 7 == 3  # attributes (after baseOffset, length, leaderEpoch, magic, crc): codec LZ4
+        decoded = []
+        for wire in (plain, packed):
+            with EventsTopicIngest() as g:
+                g.feed(wire)
+                decoded.append([(o, k, v) for o, _, k, v in g.drain_records()])
+        assert decoded[0] == decoded[1] and len(decoded[0]) == n_plain
+        want = [(keys[i], None if kind[i] == 2 else vals[i]) for i in range(n) if part[i] == p]
+        assert [(k, v) for _, k, v in decoded[1]] == want
+    with RecordBatchWriter(1) as w:
+        with pytest.raises(RuntimeError):
+            w.set_compression("lz4") if False else w._check(w._lib.surge_snapshot_writer_set_compression(w._h, 2))  # snappy: unsupported
