@@ -176,7 +176,7 @@ inline uint64_t hash_bytes(const uint8_t* p, size_t n) {
     n -= 8;
   }
   uint64_t v = 0;
-  std::memcpy(&v, p, n);
+  if (n > 0) std::memcpy(&v, p, n);  // an empty key in an empty arena has a null pointer
   h = (h ^ v) * 0xD6E8FEB86659FD93ull;
   return h ^ (h >> 29);
 }

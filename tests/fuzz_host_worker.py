@@ -1,0 +1,155 @@
+"""TEST INFRASTRUCTURE: mutation fuzzing of the host-side decoders / encoders (ingest.cpp, lz4_frame.cpp,
+snapshot_writer.cpp) built with AddressSanitizer + UBSan.  Run as a subprocess with LD_PRELOAD=libasan.so by
+tests/test_host_fuzz.py:  python fuzz_host_worker.py <libsurge_host_asan.so> <seconds> <seed>
+
+Bytes from a Kafka fetch are untrusted input: whatever they are, the decoder must answer with a status code — never read or
+write outside its buffers.  A sanitizer report aborts this process; the parent test shows it."""
+import ctypes
+import os
+import random
+import struct
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kafka_wire as kw  # noqa: E402
+
+lib = ctypes.CDLL(sys.argv[1])
+budget, seed = float(sys.argv[2]), int(sys.argv[3])
+rng = random.Random(seed)
+vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+lib.surge_ingest_create.argtypes = [i32, ctypes.POINTER(vp)]
+lib.surge_ingest_destroy.argtypes = [vp]
+lib.surge_ingest_feed.argtypes = [vp, ctypes.c_char_p, i64, ctypes.POINTER(i64)]
+lib.surge_ingest_ready.argtypes = [vp]
+lib.surge_ingest_ready.restype = i64
+lib.surge_ingest_drain_fixed16.argtypes = [vp, i64, vp, vp, vp, ctypes.POINTER(i64)]
+lib.surge_ingest_drain.argtypes = [vp, i64, vp, ctypes.POINTER(i64)]
+lib.surge_ingest_arena.argtypes = [vp]
+lib.surge_ingest_arena.restype = ctypes.POINTER(ctypes.c_uint8)
+
+
+class Rec(ctypes.Structure):  # surge_ingest_record
+    _fields_ = [("offset", i64), ("agg_idx", i64), ("key_off", i64), ("key_len", i32), ("value_len", i32), ("value_off", i64)]
+lib.surge_lz4_frame_decompress.argtypes = [ctypes.c_char_p, i64, ctypes.c_char_p, i64]
+lib.surge_lz4_frame_decompress.restype = i64
+lib.surge_lz4_frame_bound.argtypes = [i64]
+lib.surge_lz4_frame_bound.restype = i64
+lib.surge_lz4_frame_compress.argtypes = [ctypes.c_char_p, i64, ctypes.c_char_p, i64]
+lib.surge_lz4_frame_compress.restype = i64
+
+
+def valid_wire():
+    batches, off = [], rng.randrange(0, 1 << 40)
+    for _ in range(rng.randrange(1, 5)):
+        n = rng.randrange(1, 30)
+        recs = []
+        for i in range(n):
+            key = None if rng.random() < 0.05 else f"agg-{rng.randrange(40)}:{i}".encode()[: rng.randrange(0, 20)]
+            val = None if rng.random() < 0.05 else os.urandom(rng.choice([0, 1, 15, 16, 17, 64, 300]))
+            hdrs = [(b"h" * rng.randrange(0, 5), None if rng.random() < 0.3 else b"v" * rng.randrange(0, 9))] if rng.random() < 0.3 else []
+            recs.append((key, val, hdrs))
+        tx = rng.random() < 0.3
+        batches.append(kw.record_batch(off, recs, compression=rng.choice(["none", "lz4"]), transactional=tx, producer_id=7 if tx else -1))
+        off += n
+        if tx and rng.random() < 0.7:
+            batches.append(kw.control_batch(off, 7, rng.choice([kw.COMMIT, kw.ABORT])))
+            off += 1
+    return b"".join(batches)
+
+
+def mutate(b: bytes) -> bytes:
+    b = bytearray(b)
+    for _ in range(rng.randrange(1, 6)):
+        if not b:
+            break
+        kind = rng.randrange(7)
+        i = rng.randrange(len(b))
+        if kind == 0:
+            b[i] ^= 1 << rng.randrange(8)
+        elif kind == 1:
+            b[i] = rng.choice([0, 0x7F, 0x80, 0xFF])
+        elif kind == 2:
+            del b[i:i + rng.randrange(1, 40)]
+        elif kind == 3:
+            b[i:i] = os.urandom(rng.randrange(1, 20))
+        elif kind == 4:
+            b = b[: rng.randrange(len(b))]
+        elif kind == 5 and len(b) >= 4:
+            j = rng.randrange(len(b) - 3)
+            b[j:j + 4] = struct.pack(rng.choice(["<I", ">I"]), rng.choice([0, 1, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF, len(b)]))
+        else:
+            j = rng.randrange(len(b))
+            b[i:i] = b[j:j + rng.randrange(1, 64)]
+    return bytes(b)
+
+
+def fix_crc(b: bytes) -> bytes:
+    """Re-seal the first batch so mutations get past the CRC gate and reach the record parser / LZ4 decoder."""
+    if len(b) < 61:
+        return b
+    (blen,) = struct.unpack(">i", b[8:12])
+    end = 12 + blen
+    if blen < 49 or end > len(b):
+        return b
+    return b[:17] + struct.pack(">I", kw.crc32c(b[21:end])) + b[21:]
+
+
+def drain(h):
+    n = lib.surge_ingest_ready(h)
+    if n <= 0:
+        return
+    if rng.random() < 0.5:
+        idx, ev, off = (ctypes.c_int64 * n)(), (ctypes.c_uint8 * (16 * n))(), (ctypes.c_int64 * n)()
+        got = i64()
+        lib.surge_ingest_drain_fixed16(h, n, idx, ev, off, ctypes.byref(got))
+    else:
+        recs = (Rec * n)()
+        got = i64()
+        assert lib.surge_ingest_drain(h, n, recs, ctypes.byref(got)) == 0 and got.value <= n
+        arena = lib.surge_ingest_arena(h)
+        for r in recs[: got.value]:  # every span the decoder hands out must be readable (ASan checks the reads)
+            if r.key_len > 0:
+                _ = bytes(arena[r.key_off: r.key_off + r.key_len])
+            if r.value_len > 0:
+                _ = arena[r.value_off], arena[r.value_off + r.value_len - 1]
+
+
+t_end, rounds = time.time() + budget, 0
+while time.time() < t_end:
+    rounds += 1
+    wire = valid_wire()
+    data = wire if rng.random() < 0.15 else mutate(wire)
+    if rng.random() < 0.6:
+        data = fix_crc(data)
+    h = vp()
+    assert lib.surge_ingest_create(rng.randrange(2), ctypes.byref(h)) == 0
+    pos = 0
+    while pos < len(data):  # arbitrary fetch boundaries; a failing feed ends this stream
+        step = rng.randrange(1, 400)
+        chunk = data[pos:pos + step]
+        consumed = i64()
+        rc = lib.surge_ingest_feed(h, chunk, len(chunk), ctypes.byref(consumed))
+        assert 0 <= consumed.value <= len(chunk), (consumed.value, len(chunk))
+        if rc != 0:
+            break
+        pos += step
+        if rng.random() < 0.5:
+            drain(h)
+    drain(h)
+    lib.surge_ingest_destroy(h)
+    # LZ4 frames: liblz4-shaped ones from the product's own writer, mutated
+    raw = os.urandom(rng.randrange(0, 300)) + bytes(rng.randrange(0, 70000)) + b"abc" * rng.randrange(0, 3000)
+    cap = lib.surge_lz4_frame_bound(len(raw))
+    dst = ctypes.create_string_buffer(cap)
+    n = lib.surge_lz4_frame_compress(raw, len(raw), dst, cap)
+    assert n > 0
+    frame = dst.raw[:n]
+    out = ctypes.create_string_buffer(len(raw) + 16)
+    assert lib.surge_lz4_frame_decompress(frame, n, out, len(raw) + 16) == len(raw) and out.raw[: len(raw)] == raw
+    bad = mutate(frame)
+    small = rng.choice([0, 1, 100, len(raw) // 2 + 1, len(raw) + 16])
+    out2 = ctypes.create_string_buffer(max(small, 1))
+    r = lib.surge_lz4_frame_decompress(bad, len(bad), out2, small)
+    assert r <= small
+print(f"OK {rounds} rounds")

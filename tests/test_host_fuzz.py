@@ -1,0 +1,33 @@
+"""The host-side decoders take untrusted bytes (a Kafka fetch): mutation-fuzz them under AddressSanitizer + UBSan.
+Builds ingest.cpp / lz4_frame.cpp / snapshot_writer.cpp with g++ -fsanitize=address,undefined (plain C++: no HIP in those
+files) and drives the result from a subprocess that preloads libasan."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _asan_runtime():
+    try:
+        p = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_mutated_record_batches_and_lz4_frames_never_touch_memory_they_do_not_own(tmp_path, seed):
+    rt = _asan_runtime()
+    if rt is None:
+        pytest.skip("no libasan.so next to gcc")
+    lib = str(tmp_path / "libsurge_host_asan.so")
+    srcs = [os.path.join(ROOT, "surge_amd", "csrc", f) for f in ("ingest.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")]
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                    "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", lib, "-lpthread"], check=True, capture_output=True)
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
+    res = subprocess.run([sys.executable, os.path.join(HERE, "fuzz_host_worker.py"), lib, "6", str(seed)], capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0 and "OK " in res.stdout, (res.stdout[-1500:] + res.stderr[-6000:])
