@@ -93,11 +93,14 @@ class EventsTopicIngest:
         recs = np.zeros(n, dtype=RECORD_DTYPE)
         got = ctypes.c_int64(0)
         self._check(self._lib.surge_ingest_drain(self._h, n, recs.ctypes.data_as(ctypes.c_void_p), ctypes.byref(got)))
-        base = self._lib.surge_ingest_arena(self._h)
+        base = self._lib.surge_ingest_arena(self._h) or 0  # NULL while the arena is empty (only empty keys / values so far)
+
+        def span(off, ln):
+            return None if ln < 0 else (b"" if ln == 0 else ctypes.string_at(base + int(off), int(ln)))
+
         out = []
         for r in recs[: got.value]:
-            key = None if r["key_len"] < 0 else ctypes.string_at(base + int(r["key_off"]), int(r["key_len"]))
-            val = None if r["value_len"] < 0 else ctypes.string_at(base + int(r["value_off"]), int(r["value_len"]))
+            key, val = span(r["key_off"], r["key_len"]), span(r["value_off"], r["value_len"])
             out.append((int(r["offset"]), int(r["agg_idx"]), key, val))
         return out
 
