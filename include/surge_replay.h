@@ -220,9 +220,18 @@ typedef struct surge_replay_schema_v2 {
 #define SURGE_ALGO_SORTED 4 /* K2b: any CSR; segments counting-sorted by length at load time, persistent
                                waves walk groups of 64 similar-length segments, one lane per aggregate  */
 #define SURGE_ALGO_SLOTS 6 /* v2 handles only: sorted-rows transport + slot interpreter, one lane per aggregate */
-#define SURGE_ALGO_CHUNKED 5 /* K2c: like SORTED, but an aggregate longer than T events (default 256) is cut into
-                                2^k line-aligned chunks walked by adjacent lanes of one wave and stitched with
-                                shuffles: no wave ever walks more than ~T events alone (mid-size ragged logs) */
+#define SURGE_ALGO_CHUNKED 5 /* K2c: like SORTED, but an aggregate longer than T events (T ~ log bytes / 4 MB) is cut into
+                                independent line-aligned chunks, each a virtual row of its own, stitched left to right
+                                by a second, tiny kernel: no wave ever walks more than ~T events alone (mid-size
+                                ragged logs) */
+#define SURGE_ALGO_TILED 7 /* K2t: CHUNKED's virtual rows folded from a TILE-MAJOR COPY of the log the handle builds once
+                              per bound log (groups of 64 similar-length rows, each 8-event x 64-row subtile one
+                              contiguous 8 KiB run): every load instruction of the fold covers contiguous memory, the
+                              fold streams linearly.  Costs one extra copy of the log in device memory and one re-layout
+                              pass (about the time of four folds; surge_replay_layout_info reports it), so it pays when a
+                              bound log is folded more than once or is bound ahead of need: never chosen by
+                              SURGE_ALGO_AUTO, ask for it (surge_replay_prepare does the copy without folding).  Any
+                              CSR, v1 handles. */
 
 typedef struct surge_replay_stats_t {
   int64_t n_aggregates;
@@ -238,6 +247,21 @@ typedef struct surge_replay_stats_t {
   double  sum_fold_kernel_ms;  /* sum of the dominant kernel's HIP-event times since stats_reset  */
   int64_t timed_folds;         /* number of folds in that sum (at most 256 are kept)              */
 } surge_replay_stats_t;
+
+/* The per-log index the handle built for the last SORTED / CHUNKED / TILED fold (or surge_replay_prepare) and what
+ * building it cost: device time between HIP events on the handle's stream, paid once per bound log and never part of a
+ * fold's kernel time.  Replaces nothing in the reference — its restore consumer (SurgeStateStoreConsumer.scala:57-76)
+ * has no index; this is what "recovery happens once" costs here beside the fold itself. */
+typedef struct surge_replay_layout_info_t {
+  int32_t algo;              /* SURGE_ALGO_SORTED / _CHUNKED / _TILED, 0 = no index built for the bound log   */
+  int32_t chunk_events;      /* CHUNKED / TILED: aggregates longer than this were cut into chunks (T)          */
+  int64_t virtual_rows;      /* rows the lanes walk: aggregates, or aggregates + the extra chunks of cut ones   */
+  int64_t cut_aggregates;    /* aggregates cut into more than one chunk                                        */
+  int64_t tiled_bytes;       /* TILED: size of the tile-major copy of the log (0 otherwise)                     */
+  int64_t padding_events;    /* TILED: PAD events in that copy (rows rounded up to their group's longest)       */
+  double  index_build_ms;    /* length order / chunk table / tile index                                        */
+  double  relayout_ms;       /* TILED: the copy into tile-major order                                          */
+} surge_replay_layout_info_t;
 
 typedef struct surge_replay_handle surge_replay_handle;
 
@@ -283,6 +307,11 @@ int32_t surge_replay_bind_device_csr(surge_replay_handle* h, const int64_t* d_se
  * (CommandModels.scala:26).  Result stays device-resident.  Asynchronous on the
  * handle's stream. */
 int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo);
+/* Builds whatever per-log index `algo` needs for the bound log (length order, chunk table, tile-major copy) without
+ * folding, so a host can pay it when the log is bound rather than inside its first fold.  A later fold with the same
+ * algo reuses it.  Asynchronous except for two small device->host size reads. */
+int32_t surge_replay_prepare(surge_replay_handle* h, int32_t algo);
+int32_t surge_replay_layout_info(surge_replay_handle* h, surge_replay_layout_info_t* out);
 
 /* Streaming micro-batch (K3): for every group g,
  *   state[group_agg[g]] = events[group_off[g]..group_off[g+1]).foldLeft(state[group_agg[g]])(handleEvent)

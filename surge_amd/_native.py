@@ -11,14 +11,14 @@ import shutil
 import subprocess
 from typing import List, Optional
 
-from .schema import CSchema, CStats
+from .schema import CLayoutInfo, CSchema, CStats
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
-SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_slots.hip", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")
-HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
+SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip", "fold_slots.hip", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")
+HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "fold_chunk_device.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
 EXPORTS = (
@@ -32,6 +32,8 @@ EXPORTS = (
     "surge_replay_load_csr",
     "surge_replay_bind_device_csr",
     "surge_replay_fold",
+    "surge_replay_prepare",
+    "surge_replay_layout_info",
     "surge_replay_append_fold",
     "surge_replay_append_events",
     "surge_replay_append_events_device",
@@ -183,6 +185,8 @@ def load() -> ctypes.CDLL:
         "surge_replay_load_csr": ([vp, vp, i64, vp, i64, vp], i32),
         "surge_replay_bind_device_csr": ([vp, vp, i64, vp, i64, vp, vp], i32),
         "surge_replay_fold": ([vp, i32], i32),
+        "surge_replay_prepare": ([vp, i32], i32),
+        "surge_replay_layout_info": ([vp, ctypes.POINTER(CLayoutInfo)], i32),
         "surge_replay_append_fold": ([vp, vp, vp, i64, vp, i64], i32),
         "surge_replay_append_fold_device": ([vp, vp, vp, i64, vp, i64], i32),
         "surge_replay_append_events": ([vp, vp, vp, i64], i32),

@@ -80,10 +80,28 @@ struct surge_replay_handle {
   int64_t n_nz = 0;
   DevBuf perm, sort_hist, counter;  // SORTED: segments by descending length (built lazily, per bound log)
   bool perm_valid = false;
-  DevBuf v_start, v_len, v_info, v_seg, v_total;  // CHUNKED: the chunk table (built lazily, per bound log) ...
-  DevBuf v_side, r_slot0, r_c, r_out, v_ctr;       // ... the chunk summaries and the list of cut aggregates
-  int64_t n_vrows = 0, n_cut_rows = 0;
-  uint32_t chunk_T = 0;                            // the chunk target the table was built for (0 = none built)
+  // CHUNKED / TILED: the chunk table (built lazily, per bound log), the chunk summaries and the list of cut aggregates
+  struct ChunkIndex {
+    DevBuf v_start, v_len, v_info, v_seg, v_side, r_slot0, r_c, r_out;
+    int64_t n_vrows = 0, n_cut_rows = 0;
+    uint32_t T = 0;  // the chunk target the table was built for (0 = none built)
+    void release() {
+      DevBuf* b[] = {&v_start, &v_len, &v_info, &v_seg, &v_side, &r_slot0, &r_c, &r_out};
+      for (DevBuf* x : b) x->release();
+      n_vrows = n_cut_rows = 0;
+      T = 0;
+    }
+  };
+  ChunkIndex cidx;              // CHUNKED: rows tiled from their 128-byte lines in the CSR log
+  ChunkIndex tidx;              // TILED: rows copied to tile boundaries
+  DevBuf v_total, v_ctr;        // scratch of the chunk-table build
+  DevBuf t_tiles, t_gsub, t_gminlen;  // TILED: the tile-major copy of the log, per group first subtile / shortest row
+  int64_t t_n_sub = 0;          // subtiles (8 KiB each) of the tile-major copy
+  bool tiled_valid = false;
+  // one-off costs of the bound log's index (device time between HIP events), reported by surge_replay_layout_info
+  hipEvent_t ev_i0 = nullptr, ev_i1 = nullptr, ev_r0 = nullptr, ev_r1 = nullptr;
+  bool index_timed = false, relayout_timed = false;
+  int32_t index_algo = 0;
 
   // per-fold scratch
   DevBuf plan, batch_group_agg, batch_group_off, batch_events, poison_count, gather_idx, gather_out, scan_totals;
@@ -421,7 +439,7 @@ int32_t surge_replay_create(const surge_replay_schema* schema, int32_t device_id
     delete h;
     return fail(nullptr, SURGE_E_DEVICE, "hipSetDevice failed");
   }
-  hipEvent_t* evs[] = {&h->ev_total0, &h->ev_total1, &h->ev_h0, &h->ev_h1};
+  hipEvent_t* evs[] = {&h->ev_total0, &h->ev_total1, &h->ev_h0, &h->ev_h1, &h->ev_i0, &h->ev_i1, &h->ev_r0, &h->ev_r1};
   for (hipEvent_t* ev : evs) {
     e = hipEventCreate(ev);
     if (e != hipSuccess) {
@@ -474,11 +492,13 @@ int32_t surge_replay_destroy(surge_replay_handle* h) {
   h->comm = nullptr;
   if (h->pinned) (void)hipHostFree(h->pinned);
   h->pinned = nullptr;
-  DevBuf* bufs[] = {&h->gb_temp, &h->gb_u32, &h->gb_flags, &h->gb_agg_idx, &h->gb_events, &h->published, &h->gathered[0], &h->gathered[1], &h->v_side, &h->r_slot0, &h->r_c, &h->r_out, &h->v_ctr, &h->v_start, &h->v_len, &h->v_info, &h->v_seg, &h->v_total, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
+  h->cidx.release();
+  h->tidx.release();
+  DevBuf* bufs[] = {&h->gb_temp, &h->gb_u32, &h->gb_flags, &h->gb_agg_idx, &h->gb_events, &h->published, &h->gathered[0], &h->gathered[1], &h->v_ctr, &h->v_total, &h->t_tiles, &h->t_gsub, &h->t_gminlen, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
                     &h->nz_map, &h->block_counts, &h->plan, &h->batch_group_agg, &h->batch_group_off,
                     &h->batch_events, &h->poison_count, &h->gather_idx, &h->gather_out, &h->scan_totals};
   for (DevBuf* b : bufs) b->release();
-  hipEvent_t evs[] = {h->ev_total0, h->ev_total1, h->ev_h0, h->ev_h1};
+  hipEvent_t evs[] = {h->ev_total0, h->ev_total1, h->ev_h0, h->ev_h1, h->ev_i0, h->ev_i1, h->ev_r0, h->ev_r1};
   for (hipEvent_t ev : evs)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& pr : h->fold_events) {
@@ -519,7 +539,11 @@ int32_t surge_replay_bind_device_csr(surge_replay_handle* h, const int64_t* d_se
   DeviceGuard g(h->device);
   h->bound = false;
   h->perm_valid = false;
-  h->chunk_T = 0;
+  h->cidx.T = 0;
+  h->tidx.T = 0;
+  h->tiled_valid = false;
+  h->index_timed = h->relayout_timed = false;
+  h->index_algo = 0;
   h->d_seg_off = d_seg_off;
   h->d_events = (const uint4*)d_events;
   h->d_init = (const uint4*)d_init_state;
@@ -569,19 +593,34 @@ int32_t surge_replay_load_csr(surge_replay_handle* h, const int64_t* seg_off, in
                                       init_state ? h->own_init.ptr : nullptr, nullptr);
 }
 
-int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
-  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+}  // extern "C" (reopened below)
+
+// ---- which kernel folds the bound log, and the per-log index that kernel needs -------------------------------------
+namespace {
+
+struct FoldPlan {
+  int32_t use = SURGE_ALGO_FLAT;
+  bool uniform = false;
+  uint32_t chunk_T = 0;   // CHUNKED / TILED: aggregates longer than this are cut
+  int64_t span = 0;
+};
+
+int32_t plan_fold(surge_replay_handle* h, int32_t algo, FoldPlan& pl) {
   if (!h->bound) return fail(h, SURGE_E_STATE, "fold before load_csr/bind_device_csr");
   if (!h->log_valid) return fail(h, SURGE_E_STATE, "the resident state was grown past the bound log (surge_replay_grow): load a log again");
-  if (algo < SURGE_ALGO_AUTO || algo > SURGE_ALGO_SLOTS) return fail(h, SURGE_E_INVALID, "unknown algo");
+  if (algo < SURGE_ALGO_AUTO || algo > SURGE_ALGO_TILED) return fail(h, SURGE_E_INVALID, "unknown algo");
   if (h->v2 != (algo == SURGE_ALGO_SLOTS) && !(h->v2 && algo == SURGE_ALGO_AUTO))
     return fail(h, SURGE_E_UNSUPPORTED, h->v2 ? "a v2 slot schema folds with SURGE_ALGO_AUTO / SURGE_ALGO_SLOTS only"
                                                : "SURGE_ALGO_SLOTS needs a handle created with surge_replay_create_v2");
-  DeviceGuard g(h->device);
-  if (h->v2) return fold_slots_bound(h);
+  if (h->v2) {
+    pl.use = SURGE_ALGO_SLOTS;
+    return SURGE_OK;
+  }
   const int64_t span = h->an.last - h->an.first;
+  pl.span = span;
   const bool uniform = h->n_agg > 0 && !h->an.nonuniform && h->an.n_empty == 0 && h->an.len0 > 0 &&
                        (h->an.len0 % 16) == 0 && h->an.len0 < (1ll << 31) && h->an.first == 0;
+  pl.uniform = uniform;
   if ((algo == SURGE_ALGO_FIXED || algo == SURGE_ALGO_ROWS) && !uniform)
     return fail(h, SURGE_E_UNSUPPORTED, "ALGO_FIXED / ALGO_ROWS need equal segment lengths that are a multiple of 16");
   const bool rows_ok = uniform && h->an.len0 <= (1 << 24);
@@ -590,8 +629,8 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
   // with FIXED between 512 groups (FIXED 20-50 % faster) and 1024 groups (ROWS 10-18 % faster, L = 64..1024)
   const bool rows_auto = rows_ok && h->n_agg / kWave >= 1024;
   const bool sorted_ok = h->an.max_len < (1ll << 31);
-  if ((algo == SURGE_ALGO_SORTED || algo == SURGE_ALGO_CHUNKED) && !sorted_ok)
-    return fail(h, SURGE_E_UNSUPPORTED, "ALGO_SORTED / ALGO_CHUNKED need segments shorter than 2^31 events");
+  if ((algo == SURGE_ALGO_SORTED || algo == SURGE_ALGO_CHUNKED || algo == SURGE_ALGO_TILED) && !sorted_ok)
+    return fail(h, SURGE_E_UNSUPPORTED, "ALGO_SORTED / ALGO_CHUNKED / ALGO_TILED need segments shorter than 2^31 events");
   // Measured on MI355X (C3: 10 M aggregates, Zipf 1..4096): FLAT 16.2 ms (4.6 TB/s); SORTED (line-aligned
   // 256 B row pieces, 8 resident waves per CU) 12.1-12.7 ms (5.9-6.2 TB/s).  One lane per aggregate pays only when
   // rows are long enough to fill their 256-byte pieces (mean >= 64 events: at <= 32 events per aggregate the
@@ -614,18 +653,171 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
     chunk_T = chunk_T < 16u ? 16u : (chunk_T > 65528u ? 65528u : chunk_T);
     chunk_T &= ~7u;
   }
+  pl.chunk_T = chunk_T;
   const bool nothing_to_cut = (int64_t)chunk_T >= h->an.max_len + 7;
   // one lane per aggregate / chunk pays from ~1.5 GB of log and a mean of 64 events per aggregate (shorter aggregates
   // run 2-4x faster on the linear-stream FLAT kernel; at 0.2 M Zipf aggregates = 1.5 GB CHUNKED and FLAT tie)
   const bool lanes_auto = sorted_ok && mean_len >= 64.0 && (double)h->st.algorithmic_bytes >= 1.5e9;
   int32_t use = algo;
   if (algo == SURGE_ALGO_AUTO) {
+    // AUTO never picks TILED: the tile-major copy costs about four folds and doubles the log's footprint, which only a
+    // caller that replays the bound log repeatedly (or binds it long before it needs the states) wants to pay
     if (uniform)
       use = rows_auto ? SURGE_ALGO_ROWS : SURGE_ALGO_FIXED;
     else if (lanes_auto)
       use = nothing_to_cut ? SURGE_ALGO_SORTED : SURGE_ALGO_CHUNKED;
     else
       use = SURGE_ALGO_FLAT;
+  }
+  pl.use = use;
+  return SURGE_OK;
+}
+
+// chunk table of the kernel-facing CSR for chunk target T (align: rows tiled from their 128-byte lines — CHUNKED)
+int32_t build_chunk_index(surge_replay_handle* h, surge_replay_handle::ChunkIndex& ci, const int64_t* off, int64_t n_seg, uint32_t T,
+                          bool align) {
+  HIPCHK(h, h->sort_hist.reserve((size_t)kChunkBucketsHost * 8));
+  HIPCHK(h, h->v_total.reserve(8));
+  HIPCHK(h, h->v_ctr.reserve(32));
+  unsigned long long total = 0, ctr[4] = {0, 0, 0, 0};
+  HIPCHK(h, launch_chunk_count(off, n_seg, T, align, (unsigned long long*)h->sort_hist.ptr, (unsigned long long*)h->v_total.ptr,
+                               (unsigned long long*)h->v_ctr.ptr, h->stream));
+  HIPCHK(h, hipMemcpyAsync(ctr, h->v_ctr.ptr, 32, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(&total, h->v_total.ptr, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  ci.n_vrows = (int64_t)total;
+  ci.n_cut_rows = (int64_t)ctr[0];
+  HIPCHK(h, ci.v_start.reserve((size_t)ci.n_vrows * 8));
+  HIPCHK(h, ci.v_seg.reserve((size_t)ci.n_vrows * 8));
+  HIPCHK(h, ci.v_len.reserve((size_t)ci.n_vrows * 4));
+  HIPCHK(h, ci.v_info.reserve((size_t)ci.n_vrows * 4));
+  HIPCHK(h, ci.v_side.reserve((size_t)ctr[1] * 80));
+  HIPCHK(h, ci.r_slot0.reserve((size_t)ctr[0] * 8));
+  HIPCHK(h, ci.r_out.reserve((size_t)ctr[0] * 8));
+  HIPCHK(h, ci.r_c.reserve((size_t)ctr[0] * 4));
+  HIPCHK(h, launch_chunk_scatter(off, n_seg, h->an.n_empty > 0 ? (const int64_t*)h->nz_map.ptr : nullptr, T, align,
+                                 (unsigned long long*)h->sort_hist.ptr, (unsigned long long*)h->v_ctr.ptr, (int64_t*)ci.v_start.ptr,
+                                 (uint32_t*)ci.v_len.ptr, (uint32_t*)ci.v_info.ptr, (int64_t*)ci.v_seg.ptr, (int64_t*)ci.r_slot0.ptr,
+                                 (uint32_t*)ci.r_c.ptr, (int64_t*)ci.r_out.ptr, h->stream));
+  ci.T = T;
+  return SURGE_OK;
+}
+
+// Build (once per bound log) whatever index the chosen kernel needs: the length order (SORTED), the chunk table
+// (CHUNKED), the chunk table + the tile-major copy of the log (TILED).  Timed with HIP events; see
+// surge_replay_layout_info.
+int32_t ensure_index(surge_replay_handle* h, const FoldPlan& pl) {
+  if (h->n_agg <= 0 || pl.span <= 0) return SURGE_OK;
+  const int64_t* off = h->an.n_empty > 0 ? (const int64_t*)h->nz_off.ptr : h->d_seg_off;
+  const int64_t n_seg = h->an.n_empty > 0 ? h->n_nz : h->n_agg;
+  if (pl.use == SURGE_ALGO_SORTED && !h->perm_valid) {
+    HIPCHK(h, h->perm.reserve((size_t)n_seg * 8));
+    HIPCHK(h, h->sort_hist.reserve((size_t)kSortBucketsHost * 8));
+    HIPCHK(h, hipEventRecord(h->ev_i0, h->stream));
+    HIPCHK(h, launch_sort_by_length(off, n_seg, (unsigned long long*)h->sort_hist.ptr, (int64_t*)h->perm.ptr, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_i1, h->stream));
+    h->perm_valid = true;
+    h->index_timed = true;
+    h->relayout_timed = false;
+    h->index_algo = SURGE_ALGO_SORTED;
+  } else if (pl.use == SURGE_ALGO_CHUNKED && h->cidx.T != pl.chunk_T) {
+    HIPCHK(h, hipEventRecord(h->ev_i0, h->stream));
+    const int32_t rc = build_chunk_index(h, h->cidx, off, n_seg, pl.chunk_T, true);
+    if (rc != SURGE_OK) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_i1, h->stream));
+    h->index_timed = true;
+    h->relayout_timed = false;
+    h->index_algo = SURGE_ALGO_CHUNKED;
+  } else if (pl.use == SURGE_ALGO_TILED && (!h->tiled_valid || h->tidx.T != pl.chunk_T)) {
+    h->tiled_valid = false;
+    HIPCHK(h, hipEventRecord(h->ev_i0, h->stream));
+    const int32_t rc = build_chunk_index(h, h->tidx, off, n_seg, pl.chunk_T, false);
+    if (rc != SURGE_OK) return rc;
+    const int64_t n_groups = (h->tidx.n_vrows + kWave - 1) / kWave;
+    HIPCHK(h, h->t_gsub.reserve((size_t)(n_groups + 1) * 8));
+    HIPCHK(h, h->t_gminlen.reserve((size_t)(n_groups > 0 ? n_groups : 1) * 4));
+    HIPCHK(h, launch_tile_index((const uint32_t*)h->tidx.v_len.ptr, h->tidx.n_vrows, (int64_t*)h->t_gsub.ptr, (uint32_t*)h->t_gminlen.ptr,
+                                h->stream));
+    HIPCHK(h, launch_exclusive_scan_i64((int64_t*)h->t_gsub.ptr, n_groups, h->stream));
+    int64_t n_sub = 0;
+    HIPCHK(h, hipMemcpyAsync(&n_sub, (int64_t*)h->t_gsub.ptr + n_groups, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_i1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->t_n_sub = n_sub;
+    HIPCHK(h, h->t_tiles.reserve((size_t)n_sub * kTileSubBytes));
+    HIPCHK(h, hipEventRecord(h->ev_r0, h->stream));
+    HIPCHK(h, launch_relayout(h->d_events, (const int64_t*)h->tidx.v_start.ptr, (const uint32_t*)h->tidx.v_len.ptr, h->tidx.n_vrows,
+                              (const int64_t*)h->t_gsub.ptr, n_sub, (uint4*)h->t_tiles.ptr, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_r1, h->stream));
+    h->tiled_valid = true;
+    h->index_timed = h->relayout_timed = true;
+    h->index_algo = SURGE_ALGO_TILED;
+  }
+  return SURGE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t surge_replay_prepare(surge_replay_handle* h, int32_t algo) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  DeviceGuard g(h->device);
+  FoldPlan pl;
+  const int32_t rc = plan_fold(h, algo, pl);
+  if (rc != SURGE_OK) return rc;
+  if (h->v2) return SURGE_OK;  // the slot kernel's length order is built by its first fold
+  return ensure_index(h, pl);
+}
+
+int32_t surge_replay_layout_info(surge_replay_handle* h, surge_replay_layout_info_t* out) {
+  if (!h || !out) return fail(h, SURGE_E_INVALID, "NULL argument");
+  if (!h->bound) return fail(h, SURGE_E_STATE, "layout_info before load_csr/bind_device_csr");
+  DeviceGuard g(h->device);
+  std::memset(out, 0, sizeof(*out));
+  out->algo = h->index_algo;
+  if (h->index_algo == SURGE_ALGO_CHUNKED) {
+    out->virtual_rows = h->cidx.n_vrows;
+    out->cut_aggregates = h->cidx.n_cut_rows;
+    out->chunk_events = h->cidx.T;
+  } else if (h->index_algo == SURGE_ALGO_TILED) {
+    out->virtual_rows = h->tidx.n_vrows;
+    out->cut_aggregates = h->tidx.n_cut_rows;
+    out->chunk_events = h->tidx.T;
+    out->tiled_bytes = h->t_n_sub * kTileSubBytes;
+    out->padding_events = h->t_n_sub * (kTileSubBytes / 16) - (h->an.last - h->an.first);
+  } else if (h->index_algo == SURGE_ALGO_SORTED) {
+    out->virtual_rows = h->an.n_empty > 0 ? h->n_nz : h->n_agg;
+  }
+  if (h->index_timed) {
+    HIPCHK(h, hipEventSynchronize(h->ev_i1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev_i0, h->ev_i1));
+    out->index_build_ms = ms;
+  }
+  if (h->relayout_timed) {
+    HIPCHK(h, hipEventSynchronize(h->ev_r1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev_r0, h->ev_r1));
+    out->relayout_ms = ms;
+  }
+  return SURGE_OK;
+}
+
+int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  DeviceGuard g(h->device);
+  FoldPlan pl;
+  {
+    const int32_t rc = plan_fold(h, algo, pl);
+    if (rc != SURGE_OK) return rc;
+  }
+  if (h->v2) return fold_slots_bound(h);
+  const int64_t span = pl.span;
+  const int32_t use = pl.use;
+  {
+    const int32_t rc = ensure_index(h, pl);  // once per bound log (part of its index, like the empty-segment compaction)
+    if (rc != SURGE_OK) return rc;
   }
 
   FoldParams p;
@@ -683,12 +875,6 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       const int le = env_lane_events("SURGE_REPLAY_LE_SORTED", 16);
       const int64_t* off = h->an.n_empty > 0 ? (const int64_t*)h->nz_off.ptr : h->d_seg_off;
       const int64_t n_seg = h->an.n_empty > 0 ? h->n_nz : h->n_agg;
-      if (!h->perm_valid) {  // once per bound log (part of its index, like the empty-segment compaction)
-        HIPCHK(h, h->perm.reserve((size_t)n_seg * 8));
-        HIPCHK(h, h->sort_hist.reserve((size_t)kSortBucketsHost * 8));
-        HIPCHK(h, launch_sort_by_length(off, n_seg, (unsigned long long*)h->sort_hist.ptr, (int64_t*)h->perm.ptr, h->stream));
-        h->perm_valid = true;
-      }
       if (h->an.n_empty > 0) p.out_map = (const int64_t*)h->nz_map.ptr;
       p.seg_off = off;
       p.plan = (const int64_t*)h->perm.ptr;
@@ -710,41 +896,13 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       h->st.n_tasks = (int32_t)n_waves;
     } else if (use == SURGE_ALGO_CHUNKED) {
       const int le = env_lane_events("SURGE_REPLAY_LE_CHUNKED", 16) == 8 ? 8 : 16;
-      const int64_t* off = h->an.n_empty > 0 ? (const int64_t*)h->nz_off.ptr : h->d_seg_off;
-      const int64_t n_seg = h->an.n_empty > 0 ? h->n_nz : h->n_agg;
-      if (h->chunk_T != chunk_T) {  // once per bound log (part of its index, like the empty-segment compaction)
-        HIPCHK(h, h->sort_hist.reserve((size_t)kChunkBucketsHost * 8));
-        HIPCHK(h, h->v_total.reserve(8));
-        HIPCHK(h, h->v_ctr.reserve(32));
-        unsigned long long total = 0, ctr[4] = {0, 0, 0, 0};
-        HIPCHK(h, launch_chunk_count(off, n_seg, chunk_T, (unsigned long long*)h->sort_hist.ptr, (unsigned long long*)h->v_total.ptr,
-                                     (unsigned long long*)h->v_ctr.ptr, h->stream));
-        HIPCHK(h, hipMemcpyAsync(ctr, h->v_ctr.ptr, 32, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(&total, h->v_total.ptr, 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        h->n_vrows = (int64_t)total;
-        h->n_cut_rows = (int64_t)ctr[0];
-        HIPCHK(h, h->v_start.reserve((size_t)h->n_vrows * 8));
-        HIPCHK(h, h->v_seg.reserve((size_t)h->n_vrows * 8));
-        HIPCHK(h, h->v_len.reserve((size_t)h->n_vrows * 4));
-        HIPCHK(h, h->v_info.reserve((size_t)h->n_vrows * 4));
-        HIPCHK(h, h->v_side.reserve((size_t)ctr[1] * 80));
-        HIPCHK(h, h->r_slot0.reserve((size_t)ctr[0] * 8));
-        HIPCHK(h, h->r_out.reserve((size_t)ctr[0] * 8));
-        HIPCHK(h, h->r_c.reserve((size_t)ctr[0] * 4));
-        HIPCHK(h, launch_chunk_scatter(off, n_seg, h->an.n_empty > 0 ? (const int64_t*)h->nz_map.ptr : nullptr, chunk_T,
-                                       (unsigned long long*)h->sort_hist.ptr, (unsigned long long*)h->v_ctr.ptr,
-                                       (int64_t*)h->v_start.ptr, (uint32_t*)h->v_len.ptr, (uint32_t*)h->v_info.ptr,
-                                       (int64_t*)h->v_seg.ptr, (int64_t*)h->r_slot0.ptr, (uint32_t*)h->r_c.ptr,
-                                       (int64_t*)h->r_out.ptr, h->stream));
-        h->chunk_T = chunk_T;
-      }
+      const auto& ci = h->cidx;
       {
         const int32_t rcd = dispenser_begin(h, p);
         if (rcd != SURGE_OK) return rcd;
       }
-      p.n_seg = n_seg;
-      const int64_t groups = (h->n_vrows + kWave - 1) / kWave;
+      p.n_seg = h->an.n_empty > 0 ? h->n_nz : h->n_agg;
+      const int64_t groups = (ci.n_vrows + kWave - 1) / kWave;
       // resident waves per CU: 16 KiB tiles 8 (2 per SIMD, 8 x 18.7 KB of LDS), 8 KiB tiles 12 (3 per SIMD)
       const int64_t slots = (int64_t)h->n_cus * (le == 8 ? 12 : 8);
       const int64_t n_waves = groups < slots ? groups : slots;
@@ -752,9 +910,35 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       const int32_t rc = next_fold_events(h, &e0, &e1);
       if (rc != SURGE_OK) return rc;
       HIPCHK(h, hipEventRecord(e0, h->stream));  // the stitch kernel is timed with the fold: it is part of it
-      HIPCHK(h, launch_fold_chunked(p, (const int64_t*)h->v_start.ptr, (const uint32_t*)h->v_len.ptr, (const uint32_t*)h->v_info.ptr,
-                                    (const int64_t*)h->v_seg.ptr, h->n_vrows, (uint32_t*)h->v_side.ptr, (const int64_t*)h->r_slot0.ptr,
-                                    (const uint32_t*)h->r_c.ptr, (const int64_t*)h->r_out.ptr, h->n_cut_rows, n_waves, le, h->stream));
+      HIPCHK(h, launch_fold_chunked(p, (const int64_t*)ci.v_start.ptr, (const uint32_t*)ci.v_len.ptr, (const uint32_t*)ci.v_info.ptr,
+                                    (const int64_t*)ci.v_seg.ptr, ci.n_vrows, (uint32_t*)ci.v_side.ptr, (const int64_t*)ci.r_slot0.ptr,
+                                    (const uint32_t*)ci.r_c.ptr, (const int64_t*)ci.r_out.ptr, ci.n_cut_rows, n_waves, le, h->stream));
+      HIPCHK(h, hipEventRecord(e1, h->stream));
+      h->st.n_tasks = (int32_t)n_waves;
+    } else if (use == SURGE_ALGO_TILED) {
+      int subs = 2;  // subtiles (8 events per lane) per step
+      if (const char* v = std::getenv("SURGE_REPLAY_TILED_SUBS")) subs = std::atoi(v) == 1 ? 1 : 2;
+      const auto& ci = h->tidx;
+      {
+        const int32_t rcd = dispenser_begin(h, p);
+        if (rcd != SURGE_OK) return rcd;
+      }
+      p.n_seg = h->an.n_empty > 0 ? h->n_nz : h->n_agg;
+      const int64_t groups = (ci.n_vrows + kWave - 1) / kWave;
+      // resident waves per CU: 16 KiB steps 8 (2 per SIMD), 8 KiB steps 12 (3 per SIMD)
+      int64_t per_cu = subs == 1 ? 12 : 8;
+      if (const char* v = std::getenv("SURGE_REPLAY_TILED_WAVES")) per_cu = std::atoi(v) > 0 ? std::atoi(v) : per_cu;
+      const int64_t slots = (int64_t)h->n_cus * per_cu;
+      const int64_t n_waves = groups < slots ? groups : slots;
+      hipEvent_t e0, e1;
+      const int32_t rc = next_fold_events(h, &e0, &e1);
+      if (rc != SURGE_OK) return rc;
+      HIPCHK(h, hipEventRecord(e0, h->stream));  // the stitch kernel is timed with the fold: it is part of it
+      HIPCHK(h, launch_fold_tiled(p, (const uint4*)h->t_tiles.ptr, (const int64_t*)h->t_gsub.ptr, (const uint32_t*)h->t_gminlen.ptr,
+                                  (const uint32_t*)ci.v_len.ptr, (const uint32_t*)ci.v_info.ptr, (const int64_t*)ci.v_seg.ptr, ci.n_vrows,
+                                  (uint32_t*)ci.v_side.ptr, n_waves, subs, h->stream));
+      HIPCHK(h, launch_chunk_stitch(p, (const uint32_t*)ci.v_side.ptr, (const int64_t*)ci.r_slot0.ptr, (const uint32_t*)ci.r_c.ptr,
+                                    (const int64_t*)ci.r_out.ptr, ci.n_cut_rows, h->stream));
       HIPCHK(h, hipEventRecord(e1, h->stream));
       h->st.n_tasks = (int32_t)n_waves;
     } else if (h->an.n_empty > 0) {

@@ -36,7 +36,7 @@
 // any association and min/max/set are exact, so the result is bit-identical to the sequential fold.
 #include <type_traits>
 
-#include "fold_device.h"
+#include "fold_chunk_device.h"
 
 namespace surge {
 namespace {
@@ -46,12 +46,6 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int kChunkBuckets = 65536;  // chunk-length histogram: bucket = min(chunk length, 65535)
 
-constexpr uint32_t VI_RELATIVE = 1u;        // bit 0: chunk of a cut aggregate (walked relative to an unknown incoming state)
-constexpr int VI_PAD_SHIFT = 16;            // bits 16..18: null events in front of an aggregate's first event (line alignment)
-constexpr uint32_t VI_SIDE = 1u << 25;      // the chunk's summary goes to the side buffer (slot = v_dest), not to the state array
-constexpr uint32_t SIDE_DECIDED = 1u << 31; // in a side entry's S.fl: the chunk contained a deciding event
-constexpr int kSideDwords = 20;             // a side entry: P (10 dwords) then S (10 dwords)
-
 // chunks of an aggregate whose events span `span` slots from its 128-byte line start
 __host__ __device__ __forceinline__ uint32_t chunks_of(int64_t span, uint32_t T) {
   const int64_t c = (span + T - 1) / T;
@@ -59,12 +53,14 @@ __host__ __device__ __forceinline__ uint32_t chunks_of(int64_t span, uint32_t T)
 }
 
 // hist[chunk length] += chunks of every aggregate; ctr[0] += aggregates cut into several chunks, ctr[1] += their chunks
-__global__ void chunk_hist_kernel(const int64_t* __restrict__ off, int64_t n_seg, uint32_t T, unsigned long long* __restrict__ hist,
-                                  unsigned long long* __restrict__ ctr) {
+// (align: rows are tiled from the 128-byte line that holds their first event — what the CSR kernel wants; the tile-major
+// re-layout copies rows to tile boundaries anyway and passes align = false: no pad events)
+__global__ void chunk_hist_kernel(const int64_t* __restrict__ off, int64_t n_seg, uint32_t T, bool align,
+                                  unsigned long long* __restrict__ hist, unsigned long long* __restrict__ ctr) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_seg) return;
   const int64_t st = off[s], len = off[s + 1] - st;
-  const int64_t span = len + (st & 7);
+  const int64_t span = len + (align ? (st & 7) : 0);
   const uint32_t c = chunks_of(span, T);
   const int64_t cl = (span + c - 1) / c;
   atomicAdd(&hist[cl < kChunkBuckets - 1 ? cl : kChunkBuckets - 1], (unsigned long long)c);
@@ -98,14 +94,14 @@ __global__ void __launch_bounds__(1024) chunk_scan_kernel(unsigned long long* hi
 // chunks of one aggregate end up on unrelated lanes) and, if it is cut, register it for the stitch kernel
 __global__ void chunk_scatter_kernel(const int64_t* __restrict__ off, int64_t n_seg, const int64_t* __restrict__ out_map,
                                      unsigned long long* __restrict__ cursor, unsigned long long* __restrict__ ctr, uint32_t T,
-                                     int64_t* __restrict__ v_start, uint32_t* __restrict__ v_len, uint32_t* __restrict__ v_info,
+                                     bool align, int64_t* __restrict__ v_start, uint32_t* __restrict__ v_len, uint32_t* __restrict__ v_info,
                                      int64_t* __restrict__ v_dest, int64_t* __restrict__ r_slot0, uint32_t* __restrict__ r_c,
                                      int64_t* __restrict__ r_out) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_seg) return;
   const int64_t st = off[s], len = off[s + 1] - st;
-  const uint32_t pad = (uint32_t)(st & 7);
-  const int64_t base = st - pad;  // the 128-byte line that holds the first event
+  const uint32_t pad = align ? (uint32_t)(st & 7) : 0u;
+  const int64_t base = st - pad;  // the 128-byte line that holds the first event (align), or the first event itself
   const int64_t span = len + pad, end = st + len;
   const uint32_t c = chunks_of(span, T);
   const int64_t cl = (span + c - 1) / c;
@@ -133,78 +129,6 @@ __global__ void chunk_scatter_kernel(const int64_t* __restrict__ off, int64_t n_
   }
 }
 
-// walk of LE events that also watches for the lane's first "deciding" event (see the file comment); lanes with
-// undecM == 0 (an aggregate in one piece, or already decided) just walk
-template <int LE>
-__device__ __forceinline__ void walk_events_track(Acc& a, Acc& P, uint32_t& undecM, uint32_t& frozenM, uint32_t& corr,
-                                                  const uint4* ev, const uint32_t* tyc, const uint32_t* lds_tab,
-                                                  const FoldParams& p) {
-  uint4 tq0, tq1, tq2, tq3;
-  {
-    const uint4* te = (const uint4*)(lds_tab + tyc[0]);
-    tq0 = te[0]; tq1 = te[1]; tq2 = te[2]; tq3 = te[3];
-  }
-#pragma unroll
-  for (int j = 0; j < LE; ++j) {
-    uint4 nq0 = tq0, nq1 = tq1, nq2 = tq2, nq3 = tq3;
-    if (j + 1 < LE) {
-      const uint4* te = (const uint4*)(lds_tab + tyc[j + 1]);
-      nq0 = te[0]; nq1 = te[1]; nq2 = te[2]; nq3 = te[3];
-    }
-    // live (not ignored, not throwing) and not of class REQUIRE: from here on the state is Some or an absolute None
-    const uint32_t firstM = undecM & tq2.w & ~(frozenM | tq2.x);
-    if (__builtin_amdgcn_ballot_w64(firstM != 0u) != 0ull) {  // wave-uniform; taken once or twice per chunk
-      a.sum = (int64_t)((uint64_t)a.sum + corr);
-      corr = 0u;
-      const bool f = firstM != 0u;
-      P = select_acc(f, a, P);
-      a = select_acc(f, acc_identity(), a);
-      undecM = andn(undecM, firstM);
-    }
-    apply_event(a, frozenM, corr, tq0, tq1, tq2, tq3, ev[j].y, ev[j].z, ev[j].w, p);
-    tq0 = nq0; tq1 = nq1; tq2 = nq2; tq3 = nq3;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-__device__ __forceinline__ Acc acc_defaults(const FoldParams& p) {  // Some(defaults), absolute
-  Acc a;
-  a.count = p.d_count; a.version = p.d_version; a.sum = p.d_sum; a.bal = p.d_balance; a.mn = p.d_min; a.mx = p.d_max;
-  a.n = p.d_evcount;
-  a.fl = FL_PRESENT | SM_ALL;
-  return a;
-}
-
-// the state after a chunk whose incoming state is x (concrete): see the file comment
-__device__ __forceinline__ Acc resolve_chunk(const Acc& x, const Acc& P, const Acc& S, bool decided, const FoldParams& p) {
-  const Acc some = seq_acc(seq_acc(x, P), S);
-  const Acc none_dec = seq_acc(acc_defaults(p), S);
-  Acc none_und = x;
-  none_und.fl |= P.fl & FL_POISONED;
-  const bool xpres = (x.fl & FL_PRESENT) != 0u, xpois = (x.fl & FL_POISONED) != 0u;
-  Acc r = select_acc(xpres, some, select_acc(decided, none_dec, none_und));
-  return select_acc(xpois, x, r);  // an aggregate that threw ignores every later event
-}
-
-__device__ __forceinline__ void acc_to_words(const Acc& a, uint32_t* w) {
-  w[0] = (uint32_t)a.count; w[1] = (uint32_t)a.version; w[2] = (uint32_t)a.sum; w[3] = (uint32_t)((uint64_t)a.sum >> 32);
-  w[4] = (uint32_t)a.bal; w[5] = (uint32_t)(a.bal >> 32); w[6] = (uint32_t)a.mn; w[7] = (uint32_t)a.mx; w[8] = a.n; w[9] = a.fl;
-}
-__device__ __forceinline__ Acc acc_from_words(const uint32_t* w) {
-  Acc a;
-  a.count = (int32_t)w[0]; a.version = (int32_t)w[1]; a.sum = (int64_t)(((uint64_t)w[3] << 32) | w[2]);
-  a.bal = ((uint64_t)w[5] << 32) | w[4]; a.mn = (int32_t)w[6]; a.mx = (int32_t)w[7]; a.n = w[8]; a.fl = w[9];
-  return a;
-}
-__device__ __forceinline__ void store_side(uint32_t* side, int64_t slot, const Acc& P, const Acc& S) {
-  uint32_t w[kSideDwords];
-  acc_to_words(P, w);
-  acc_to_words(S, w + 10);
-  uint4* o = (uint4*)(side + slot * kSideDwords);  // 80-byte entries: 16-byte aligned
-#pragma unroll
-  for (int i = 0; i < 5; ++i) o[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-}
-
 // second kernel: one thread per cut aggregate composes its chunk summaries left to right onto the prior state
 __global__ void chunk_stitch_kernel(const FoldParams p, const uint32_t* __restrict__ side, const int64_t* __restrict__ r_slot0,
                                     const uint32_t* __restrict__ r_c, const int64_t* __restrict__ r_out, int64_t n_rows) {
@@ -227,15 +151,6 @@ __global__ void chunk_stitch_kernel(const FoldParams p, const uint32_t* __restri
   }
   store_state(p.out, oi, x);
 }
-
-struct ChunkTable {
-  const int64_t* v_start;  // first event slot of the virtual row (a multiple of 8 events: line aligned)
-  const uint32_t* v_len;   // event slots from there (pad included)
-  const uint32_t* v_info;  // VI_*
-  const int64_t* v_dest;   // aggregate index (state array) or side-buffer slot
-  int64_t n_vrows;
-  uint32_t* side;
-};
 
 // Register budget = resident waves: 2 per SIMD (<= 256 VGPRs) with 16 KiB tiles, 3 per SIMD (<= 168) with 8 KiB tiles.
 template <int LE>
@@ -396,25 +311,25 @@ fold_chunked_kernel(const FoldParams p, const ChunkTable t) {
 // Build the chunk table of a kernel-facing CSR (once per bound log).  d_hist: kChunkBuckets u64 scratch; d_total:
 // one u64; d_ctr: four u64.  Phase 1 (count) leaves the number of virtual rows in *d_total and {cut aggregates, their
 // chunks, 0, 0} in d_ctr; the host reads them, sizes the arrays and runs phase 2 (scatter).
-hipError_t launch_chunk_count(const int64_t* off, int64_t n_seg, uint32_t T, unsigned long long* d_hist,
+hipError_t launch_chunk_count(const int64_t* off, int64_t n_seg, uint32_t T, bool align, unsigned long long* d_hist,
                               unsigned long long* d_total, unsigned long long* d_ctr, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(d_hist, 0, (size_t)kChunkBuckets * 8, stream);
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(d_ctr, 0, 32, stream);
   if (e != hipSuccess) return e;
   if (n_seg > 0)
-    hipLaunchKernelGGL(chunk_hist_kernel, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, stream, off, n_seg, T, d_hist, d_ctr);
+    hipLaunchKernelGGL(chunk_hist_kernel, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, stream, off, n_seg, T, align, d_hist, d_ctr);
   hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, stream, d_hist, d_total);
   return hipGetLastError();
 }
 
-hipError_t launch_chunk_scatter(const int64_t* off, int64_t n_seg, const int64_t* out_map, uint32_t T,
+hipError_t launch_chunk_scatter(const int64_t* off, int64_t n_seg, const int64_t* out_map, uint32_t T, bool align,
                                 unsigned long long* d_cursor, unsigned long long* d_ctr, int64_t* v_start, uint32_t* v_len,
                                 uint32_t* v_info, int64_t* v_dest, int64_t* r_slot0, uint32_t* r_c, int64_t* r_out,
                                 hipStream_t stream) {
   if (n_seg <= 0) return hipSuccess;
   hipLaunchKernelGGL(chunk_scatter_kernel, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, stream, off, n_seg, out_map,
-                     d_cursor, d_ctr, T, v_start, v_len, v_info, v_dest, r_slot0, r_c, r_out);
+                     d_cursor, d_ctr, T, align, v_start, v_len, v_info, v_dest, r_slot0, r_c, r_out);
   return hipGetLastError();
 }
 
@@ -431,6 +346,14 @@ hipError_t launch_fold_chunked(const FoldParams& p, const int64_t* v_start, cons
     hipLaunchKernelGGL((fold_chunked_kernel<16>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxSorted), stream, p, t);
   if (n_cut > 0)
     hipLaunchKernelGGL(chunk_stitch_kernel, dim3((unsigned)((n_cut + 127) / 128)), dim3(128), 0, stream, p, side, r_slot0, r_c, r_out, n_cut);
+  return hipGetLastError();
+}
+
+// the stitch alone (the tile-major fold, fold_tiled.hip, leaves the same side entries)
+hipError_t launch_chunk_stitch(const FoldParams& p, const uint32_t* side, const int64_t* r_slot0, const uint32_t* r_c, const int64_t* r_out,
+                               int64_t n_cut, hipStream_t stream) {
+  if (n_cut <= 0) return hipSuccess;
+  hipLaunchKernelGGL(chunk_stitch_kernel, dim3((unsigned)((n_cut + 127) / 128)), dim3(128), 0, stream, p, side, r_slot0, r_c, r_out, n_cut);
   return hipGetLastError();
 }
 

@@ -55,18 +55,18 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t andn(uint32_t x, uint32_t m) { return bfi(m, 0u, x); }  // x & ~m in one v_bfi
 
 // One case of handleEvent applied to one evaluation path, as pure VALU mask arithmetic: every
-// "condition" is an all-ones / all-zero dword (table words q0..q3, see TW_* in replay_internal.h),
+// "condition" is an all-ones / all-zero dword (table words q0..q3, see TW_* in fold_layout.h),
 // selects are v_bfi_b32, nothing touches the scalar unit.  frozenM: events are being ignored
 // (the aggregate is poisoned).  validM: this event exists (tail of the last tile).
 __device__ __forceinline__ void apply_event(Acc& a, uint32_t& frozenM, uint32_t& corr, const uint4 q0, const uint4 q1,
-                                            const uint4 q2, const uint4 q3, uint32_t seq, uint32_t raw_lo,
+                                            const uint4 q2, const uint2 q3, uint32_t seq, uint32_t raw_lo,
                                             uint32_t raw_hi, const FoldParams& p) {
   const uint32_t ispM = andn(q2.x, frozenM);                            // throws (and is not ignored)
   const uint32_t goM = ~(frozenM | q2.x);
   const uint32_t presentM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 0, 1);
   const uint32_t delM = goM & q2.y;
-  const uint32_t appM = andn(goM, q2.y) & (presentM | q2.w);            // REQUIRE-class events skip None
-  const uint32_t rstM = appM & bfi(presentM, q3.x, ~0u);                // CREATE, or materialising from None
+  const uint32_t appM = andn(goM, q2.y) & (presentM | q2.z);            // REQUIRE-class events skip None
+  const uint32_t rstM = appM & bfi(presentM, q2.w, ~0u);                // CREATE, or materialising from None
   frozenM |= ispM;
 
   uint32_t fl = a.fl | (ispM & FL_POISONED);
@@ -105,8 +105,8 @@ __device__ __forceinline__ void apply_event(Acc& a, uint32_t& frozenM, uint32_t&
   const uint32_t mbalM = q1.z & appM;
   bal_lo = bfi(mbalM, raw_lo, bal_lo);
   bal_hi = bfi(mbalM, raw_hi, bal_hi);
-  mn = (uint32_t)min((int32_t)mn, (int32_t)bfi(q3.y & appM, arg, 0x7fffffffu));
-  mx = (uint32_t)max((int32_t)mx, (int32_t)bfi(q3.z & appM, arg, 0x80000000u));
+  mn = (uint32_t)min((int32_t)mn, (int32_t)bfi(q3.x & appM, arg, 0x7fffffffu));
+  mx = (uint32_t)max((int32_t)mx, (int32_t)bfi(q3.y & appM, arg, 0x80000000u));
   n += q1.w & appM;
   fl |= (msetM & SM_COUNT) | (mverM & SM_VERSION) | (mbalM & SM_BAL);
 
@@ -255,18 +255,20 @@ __device__ __forceinline__ void issue_tile_loads(const FoldParams& p, int64_t te
 template <int LE, bool HEADS, typename OnHead>
 __device__ __forceinline__ void walk_events(Acc& a, uint32_t& frozenM, uint32_t& corr, const uint4* ev, const uint32_t* tyc,
                                             uint32_t hb, const uint32_t* lds_tab, const FoldParams& p, OnHead on_head) {
-  uint4 tq0, tq1, tq2, tq3;
+  uint4 tq0, tq1, tq2;
+  uint2 tq3;
   {
     const uint4* te = (const uint4*)(lds_tab + tyc[0]);
-    tq0 = te[0]; tq1 = te[1]; tq2 = te[2]; tq3 = te[3];
+    tq0 = te[0]; tq1 = te[1]; tq2 = te[2]; tq3 = *(const uint2*)(te + 3);
   }
 #pragma unroll
   for (int j = 0; j < LE; ++j) {
-    uint4 nq0 = tq0, nq1 = tq1, nq2 = tq2, nq3 = tq3;
+    uint4 nq0 = tq0, nq1 = tq1, nq2 = tq2;
+    uint2 nq3 = tq3;
 #if !defined(SURGE_DBG_FIXED_TABLE)
     if (j + 1 < LE) {
       const uint4* te = (const uint4*)(lds_tab + tyc[j + 1]);
-      nq0 = te[0]; nq1 = te[1]; nq2 = te[2]; nq3 = te[3];
+      nq0 = te[0]; nq1 = te[1]; nq2 = te[2]; nq3 = *(const uint2*)(te + 3);
     }
 #endif
     if (HEADS && ((hb >> j) & 1u)) on_head(j);

@@ -712,6 +712,13 @@ hipError_t launch_fill_empty(const int64_t* off, int64_t n_seg, const uint4* ini
   return hipGetLastError();
 }
 
+// in-place exclusive scan of v[0..n) with the total appended at v[n] (single block: index-time use only)
+hipError_t launch_exclusive_scan_i64(int64_t* v, int64_t n, hipStream_t stream) {
+  if (n < 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, stream, v, n);
+  return hipGetLastError();
+}
+
 hipError_t launch_compact_nonempty(const int64_t* off, int64_t n_seg, int64_t* d_block_counts, int64_t* nz_off,
                                    int64_t* nz_map, hipStream_t stream) {
   if (n_seg <= 0) return hipSuccess;

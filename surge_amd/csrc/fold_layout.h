@@ -37,13 +37,18 @@ enum {
   TW_EVC = 7,      // event_count += this (0 / 1)
   TW_POISON = 8,   // handleEvent throws
   TW_DELETE = 9,   // result is None
-  TW_MATERIALIZES = 10,  // class MATERIALIZE or CREATE: result is always Some
-  TW_NOT_REQUIRE = 11,   // applies to None as well
-  TW_CREATE = 12,  // resets to defaults even when Some
-  TW_MIN = 13,
-  TW_MAX = 14,
-  TW_FLAGS = 15,   // presence pre-pass: bit0 poison, bit16 delete, bit1 materializes (OR-ed in at << j)
+  TW_NOT_REQUIRE = 10,  // applies to None as well
+  TW_CREATE = 11,  // resets to defaults even when Some
+  TW_MIN = 12,
+  TW_MAX = 13,
+  // Words [0, 14) are what the per-event walk reads (three ds_read_b128 + one ds_read_b64): every loaded register is
+  // used.  With a dead word inside a b128 the register allocator reuses its destination at once and hipcc has to put an
+  // s_waitcnt lgkmcnt(0) right behind the prefetch of the NEXT event's entry (write-after-write on an outstanding LDS
+  // load) — one exposed LDS round trip per event (round 3: visible in the ISA of every walk).
+  TW_MATERIALIZES = 14,  // flat kernel's presence pre-pass only: class MATERIALIZE or CREATE, the result is always Some
+  TW_FLAGS = 15,   // flat kernel's presence pre-pass only: bit0 poison, bit16 delete (OR-ed in at << j)
 };
+constexpr int kTableWalkWords = 14;
 constexpr int kTargetTasks = 16384;                       // enough tasks to fill the chip several times over
 
 struct FoldParams {

@@ -1,0 +1,269 @@
+// fold_tiled.hip — K2t "tile-major": the fold over a re-laid-out copy of the log in which every tile a wave fetches
+// is ONE contiguous run of memory.
+//
+// Why (measured in round 2): the lane-per-aggregate kernels over the CSR log (rows / sorted / chunked)
+// fetch, per tile, 64 separate row pieces of 128–256 bytes from 64 unrelated places of the log and top out at
+// 5.7–6.05 TB/s, while a LINEAR stream of the same LDS-DMA loads reaches 7.0–7.2 TB/s on the same chip.  The engine owns
+// the layout of a bound log (it builds the length order and the chunk table anyway), so it can also own the order of
+// the bytes: here the virtual rows of the chunk table (whole aggregates, or chunks of aggregates longer than T — exactly
+// fold_chunked.hip's) are copied ONCE into group-major / tile-major order:
+//
+//   group g   = 64 virtual rows of (almost) equal length, longest groups first (the chunk table's order)
+//   subtile c = events [8c, 8c+8) of each of the group's 64 rows: 64 x 8 x 16 B = 8 KiB, stored as the exact LDS image
+//               the walk wants (row of lane l at byte 128 l, its event j at slot j ^ key(l): the XOR swizzle that makes
+//               the later ds_read_b128 of "event j of lane l" bank-conflict free is applied by the re-layout, not by
+//               the loads)
+//   the subtiles of a group are consecutive, the groups are consecutive: a wave that owns group g streams
+//   [g_sub0[g], g_sub0[g+1]) x 8 KiB front to back with global_load_lds_dwordx4, every instruction one fully used,
+//   contiguous 1 KiB, every byte of the copy read exactly once per fold.
+//
+// Rows shorter than their group's longest are padded to it with PAD events (type 0xffffffff; never applied: the walk
+// masks them by the row length, and an unmasked one would poison its aggregate loudly rather than count as a NOOP).
+// Rows are sorted by length, so the padding is the rounding of each row to 8 events: < 1 % of the bytes on the
+// Zipf(1..4096) logs.  What a fold reads beyond the algorithmic bytes is that padding; the one-off cost is the copy
+// itself (read the CSR log once, write the tiled log once: reported by surge_replay_layout_info, never hidden in a
+// fold's time).
+//
+// Everything else — one lane per virtual row, concrete running state for whole aggregates, the P / S presence split
+// and the 80-byte side entries for chunks of cut aggregates, the stitch kernel, the self re-arming group dispenser, the
+// mask-arithmetic event walk — is fold_chunked.hip's (fold_chunk_device.h); results are bit-identical to the
+// sequential fold for the same reasons.
+#include <type_traits>
+
+#include "fold_chunk_device.h"
+
+namespace surge {
+namespace {
+
+constexpr int kSubEvents = 8;                       // events per lane in one subtile
+constexpr int kSubBytes = kWave * kSubEvents * 16;  // 8 KiB
+constexpr uint32_t kPadType = 0xffffffffu;
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+// one wave per group: subtiles of the group (from its longest row) and its shortest non-empty row
+__global__ void __launch_bounds__(256) tile_index_kernel(const uint32_t* __restrict__ v_len, int64_t n_vrows, int64_t n_groups,
+                                                         int64_t* __restrict__ g_sub, uint32_t* __restrict__ g_minlen) {
+  const int lane = threadIdx.x & 63;
+  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= n_groups) return;
+  const int64_t row = g * kWave + lane;
+  const uint32_t len = row < n_vrows ? v_len[row] : 0u;
+  uint32_t mx = len, mn = len ? len : 0xffffffffu;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64));
+  }
+  if (lane == 0) {
+    g_sub[g] = (int64_t)((mx + kSubEvents - 1) / kSubEvents);
+    g_minlen[g] = mn;
+  }
+}
+
+// The re-layout: one 256-thread block per subtile, two 16-byte slots per thread.  Output slot `pos` of a subtile
+// belongs to lane l = pos / 8 and holds its event j = (pos % 8) ^ key(l) — Geo<8>'s swizzle.  Writes are linear
+// (8 KiB per block); reads are 64 row pieces of 128 bytes.
+__global__ void __launch_bounds__(256) relayout_kernel(const uint4* __restrict__ events, const int64_t* __restrict__ v_start,
+                                                       const uint32_t* __restrict__ v_len, int64_t n_vrows,
+                                                       const int64_t* __restrict__ g_sub0, int64_t n_groups, int64_t n_sub_total,
+                                                       uint4* __restrict__ tiles) {
+  for (int64_t sub = blockIdx.x; sub < n_sub_total; sub += gridDim.x) {
+    // the group that owns this subtile: the last g with g_sub0[g] <= sub (block-uniform search)
+    int64_t lo = 0, hi = n_groups;
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (g_sub0[mid] <= sub) lo = mid; else hi = mid;
+    }
+    const int64_t g = lo;
+    const uint32_t e0 = (uint32_t)(sub - g_sub0[g]) * kSubEvents;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int pos = threadIdx.x + 256 * k;
+      const int l = pos >> 3;
+      const uint32_t j = (uint32_t)(pos & 7) ^ Geo<8>::key(l);
+      const int64_t row = g * kWave + l;
+      v4u v = {kPadType, 0u, 0u, 0u};
+      if (row < n_vrows) {
+        const uint32_t len = v_len[row];
+        if (e0 + j < len) v = __builtin_nontemporal_load((const v4u*)(events + v_start[row] + e0 + j));
+      }
+      __builtin_nontemporal_store(v, (v4u*)(tiles + sub * (kSubBytes / 16) + pos));
+    }
+  }
+}
+
+struct TileTable {
+  const uint4* tiles;        // the tile-major log
+  const int64_t* g_sub0;     // n_groups + 1: first subtile of every group
+  const uint32_t* g_minlen;  // shortest non-empty row of every group
+  const uint32_t* v_len;     // per virtual row: events
+  const uint32_t* v_info;    // VI_*
+  const int64_t* v_dest;     // aggregate index (state array) or side-buffer slot
+  int64_t n_vrows;
+  uint32_t* side;
+};
+
+// SUBS subtiles per step: 1 = 8 events per lane per step (8 KiB in flight per wave, 122 VGPRs: up to 4 waves per SIMD),
+// 2 = 16 events (16 KiB, 154 VGPRs: up to 3 waves per SIMD, 9 per CU by LDS).
+template <int SUBS>
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SUBS == 1 ? 4 : 2)))
+fold_tiled_kernel(const FoldParams p, const TileTable t) {
+  constexpr int LE = kSubEvents * SUBS;
+  constexpr int kLoads = SUBS * (kSubBytes / 1024);
+  __shared__ __attribute__((aligned(16))) char lds_ev[SUBS * kSubBytes];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_tab[kTableLdsDwords];
+  const int lane = threadIdx.x;
+  load_table<8>(p, lds_tab, lane);
+  const uint32_t ev_row = Geo<8>::ev_row(lane);  // my row inside a subtile; event j of the subtile at ev_row ^ (j * 16)
+  const int64_t n_groups = (t.n_vrows + kWave - 1) / kWave;
+
+  auto grab = [&]() -> int64_t {
+    unsigned long long g = 0;
+    if (lane == 0) g = atomicAdd(p.counter, 1ull);
+    return (int64_t)(((uint64_t)rl((uint32_t)(g >> 32), 0) << 32) | rl((uint32_t)g, 0));
+  };
+  struct Meta { int64_t dest; uint32_t len, info; };
+  auto load_meta = [&](int64_t g) -> Meta {
+    Meta m; m.dest = -1; m.len = 0u; m.info = 0u;
+    const int64_t idx = g * kWave + lane;
+    if (g < n_groups && idx < t.n_vrows) {
+      m.dest = t.v_dest[idx]; m.len = t.v_len[idx]; m.info = t.v_info[idx];
+    }
+    return m;
+  };
+  struct Shape { int64_t sub0; int n_sub; uint32_t minlen; };  // wave-uniform
+  auto load_shape = [&](int64_t g) -> Shape {  // every lane reads the same words; made scalar for the buffer descriptor
+    Shape s; s.sub0 = 0; s.n_sub = 0; s.minlen = 0u;
+    if (g < n_groups) {
+      const int64_t a = t.g_sub0[g], b = t.g_sub0[g + 1];
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)a >> 32));
+      s.sub0 = (int64_t)(((uint64_t)hi << 32) | lo);
+      s.n_sub = (int)__builtin_amdgcn_readfirstlane((uint32_t)(b - a));
+      s.minlen = __builtin_amdgcn_readfirstlane(t.g_minlen[g]);
+    }
+    return s;
+  };
+  // Step c of a group = its subtiles [SUBS c, SUBS c + SUBS): one linear run, fetched with buffer_load_dwordx4 ... lds
+  // (descriptor base = the step's first byte, lane offset 16 l, instruction q at scalar offset 1024 q).  MUBUF, not
+  // global_load_lds, on purpose: hipcc treats global_load_lds as a FLAT access that may touch LDS, and while one is
+  // outstanding (the next step's fetch is, during the whole walk) it forces EVERY s_waitcnt on LDS reads to
+  // lgkmcnt(0) — the one-event-ahead prefetch of op-table entries then waits for the entry it has just requested, an
+  // exposed LDS round trip per event.  With buffer loads the waits come out as the exact counts.
+  const int voff = lane * 16;
+  auto issue = [&](const Shape& s, int c) {
+    const char* base = (const char*)t.tiles + (s.sub0 + (int64_t)c * SUBS) * kSubBytes;  // wave-uniform
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    const int n = (SUBS == 2 && c * 2 + 1 >= s.n_sub) ? kLoads / 2 : kLoads;  // an odd last subtile: half a step
+#pragma unroll
+    for (int q = 0; q < kLoads; ++q)
+      if (q < n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds_ev + q * 1024), 16, voff, q * 1024, 0, kLoadAux);
+  };
+
+  int64_t g = grab();
+  Meta cur = load_meta(g);
+  Shape sh = load_shape(g);
+  if (g < n_groups) issue(sh, 0);
+  while (g < n_groups) {
+    const int64_t g_next = grab();
+    const Meta nxt = load_meta(g_next);  // in flight while this group is walked
+    const Shape sh_next = load_shape(g_next);
+    const int n_steps = (sh.n_sub + SUBS - 1) / SUBS;
+    const uint32_t minlen = sh.minlen;
+
+    const bool whole = (cur.info & VI_RELATIVE) == 0u;
+    // an aggregate in one piece starts from its known state, a chunk from "whatever comes in" (relative)
+    Acc a = whole ? ((p.init && cur.dest >= 0) ? load_state(p.init, cur.dest) : acc_none()) : acc_identity();
+    Acc P = acc_identity();
+    uint32_t undecM = whole ? 0u : ~0u;
+    uint32_t frozenM = whole ? (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 1, 1) : 0u;
+    uint32_t corr = 0u;
+    bool watching = __builtin_amdgcn_ballot_w64(!whole) != 0ull;
+    auto step = [&](int c, auto tracking) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      uint4 ev[LE];
+#pragma unroll
+      for (int j = 0; j < LE; ++j)
+        ev[j] = *(const uint4*)(lds_ev + (j >> 3) * kSubBytes + (ev_row ^ (uint32_t)((j & 7) * 16)));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (c + 1 < n_steps) {
+        issue(sh, c + 1);
+      } else if (g_next < n_groups) {
+        issue(sh_next, 0);  // the next group's first step is fetched while this group's last one is walked
+      }
+
+      uint32_t tyc[LE];
+      if ((uint32_t)(c + 1) * LE <= minlen) {
+#pragma unroll
+        for (int j = 0; j < LE; ++j) tyc[j] = (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride;
+      } else {
+        const int32_t rem = (int32_t)cur.len - c * LE;  // my remaining events (may be <= 0): the rest is padding
+#pragma unroll
+        for (int j = 0; j < LE; ++j) tyc[j] = j < rem ? (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride : (uint32_t)kNullEntryOff;
+      }
+      if constexpr (decltype(tracking)::value) {
+        walk_events_track<LE>(a, P, undecM, frozenM, corr, ev, tyc, lds_tab, p);
+        watching = __builtin_amdgcn_ballot_w64(undecM != 0u && frozenM == 0u) != 0ull;
+      } else {
+        walk_events<LE, false>(a, frozenM, corr, ev, tyc, 0u, lds_tab, p, [](int) {});
+      }
+    };
+    int c = 0;
+    for (; c < n_steps && watching; ++c) step(c, std::true_type{});
+    for (; c < n_steps; ++c) step(c, std::false_type{});
+    a.sum = (int64_t)((uint64_t)a.sum + corr);
+
+    if (cur.dest >= 0) {
+      if (cur.info & VI_SIDE) {
+        const bool empty = cur.len == 0u;
+        const bool undecided = undecM != 0u || empty;
+        const Acc Pw = empty ? acc_identity() : select_acc(undecided, a, P);
+        Acc Sw = select_acc(undecided, acc_identity(), a);
+        if (!undecided) Sw.fl |= SIDE_DECIDED;
+        store_side(t.side, cur.dest, Pw, Sw);
+      } else {
+        store_state(p.out, cur.dest, a);
+      }
+    }
+
+    g = g_next;
+    cur = nxt;
+    sh = sh_next;
+  }
+  dispenser_leave(p.counter, lane);
+}
+
+}  // namespace
+
+// g_sub[g] := subtiles of group g (n_groups entries; the caller scans them into offsets), g_minlen[g]
+hipError_t launch_tile_index(const uint32_t* v_len, int64_t n_vrows, int64_t* g_sub, uint32_t* g_minlen, hipStream_t stream) {
+  const int64_t n_groups = (n_vrows + kWave - 1) / kWave;
+  if (n_groups <= 0) return hipSuccess;
+  hipLaunchKernelGGL(tile_index_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, stream, v_len, n_vrows, n_groups, g_sub, g_minlen);
+  return hipGetLastError();
+}
+
+hipError_t launch_relayout(const uint4* events, const int64_t* v_start, const uint32_t* v_len, int64_t n_vrows, const int64_t* g_sub0,
+                           int64_t n_sub_total, uint4* tiles, hipStream_t stream) {
+  const int64_t n_groups = (n_vrows + kWave - 1) / kWave;
+  if (n_groups <= 0 || n_sub_total <= 0) return hipSuccess;
+  const int64_t blocks = n_sub_total < (1ll << 20) ? n_sub_total : (1ll << 20);
+  hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, events, v_start, v_len, n_vrows, g_sub0, n_groups,
+                     n_sub_total, tiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_fold_tiled(const FoldParams& p, const uint4* tiles, const int64_t* g_sub0, const uint32_t* g_minlen, const uint32_t* v_len,
+                             const uint32_t* v_info, const int64_t* v_dest, int64_t n_vrows, uint32_t* side, int64_t n_waves, int subs,
+                             hipStream_t stream) {
+  if (n_waves <= 0 || n_vrows <= 0) return hipSuccess;
+  TileTable t;
+  t.tiles = tiles; t.g_sub0 = g_sub0; t.g_minlen = g_minlen; t.v_len = v_len; t.v_info = v_info; t.v_dest = v_dest;
+  t.n_vrows = n_vrows; t.side = side;
+  if (subs == 1)
+    hipLaunchKernelGGL((fold_tiled_kernel<1>), dim3((unsigned)n_waves), dim3(kWave), 0, stream, p, t);
+  else
+    hipLaunchKernelGGL((fold_tiled_kernel<2>), dim3((unsigned)n_waves), dim3(kWave), 0, stream, p, t);
+  return hipGetLastError();
+}
+
+}  // namespace surge

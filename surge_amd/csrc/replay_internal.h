@@ -31,15 +31,27 @@ hipError_t launch_sort_by_length(const int64_t* off, int64_t n_seg, unsigned lon
                                  hipStream_t stream);
 // CHUNKED (fold_chunked.hip): chunk table of the kernel-facing CSR, then the fold over it + the stitch kernel
 constexpr int kChunkBucketsHost = 65536;
-hipError_t launch_chunk_count(const int64_t* off, int64_t n_seg, uint32_t T, unsigned long long* d_hist,
+hipError_t launch_chunk_count(const int64_t* off, int64_t n_seg, uint32_t T, bool align, unsigned long long* d_hist,
                               unsigned long long* d_total, unsigned long long* d_ctr, hipStream_t stream);
-hipError_t launch_chunk_scatter(const int64_t* off, int64_t n_seg, const int64_t* out_map, uint32_t T,
+hipError_t launch_chunk_scatter(const int64_t* off, int64_t n_seg, const int64_t* out_map, uint32_t T, bool align,
                                 unsigned long long* d_cursor, unsigned long long* d_ctr, int64_t* v_start, uint32_t* v_len,
                                 uint32_t* v_info, int64_t* v_dest, int64_t* r_slot0, uint32_t* r_c, int64_t* r_out,
                                 hipStream_t stream);
 hipError_t launch_fold_chunked(const FoldParams& p, const int64_t* v_start, const uint32_t* v_len, const uint32_t* v_info,
                                const int64_t* v_dest, int64_t n_vrows, uint32_t* side, const int64_t* r_slot0, const uint32_t* r_c,
                                const int64_t* r_out, int64_t n_cut, int64_t n_waves, int lane_events, hipStream_t stream);
+hipError_t launch_chunk_stitch(const FoldParams& p, const uint32_t* side, const int64_t* r_slot0, const uint32_t* r_c, const int64_t* r_out,
+                               int64_t n_cut, hipStream_t stream);
+// TILED (fold_tiled.hip): the chunk table's virtual rows copied once into group-major / tile-major order, then the fold
+// over that copy.  g_sub: n_groups + 1 int64 (subtiles per group, scanned in place into offsets by the caller).
+constexpr int kTileSubBytes = 8192;
+hipError_t launch_tile_index(const uint32_t* v_len, int64_t n_vrows, int64_t* g_sub, uint32_t* g_minlen, hipStream_t stream);
+hipError_t launch_relayout(const uint4* events, const int64_t* v_start, const uint32_t* v_len, int64_t n_vrows, const int64_t* g_sub0,
+                           int64_t n_sub_total, uint4* tiles, hipStream_t stream);
+hipError_t launch_fold_tiled(const FoldParams& p, const uint4* tiles, const int64_t* g_sub0, const uint32_t* g_minlen, const uint32_t* v_len,
+                             const uint32_t* v_info, const int64_t* v_dest, int64_t n_vrows, uint32_t* side, int64_t n_waves, int subs,
+                             hipStream_t stream);
+hipError_t launch_exclusive_scan_i64(int64_t* v, int64_t n, hipStream_t stream);
 hipError_t launch_plan(const int64_t* off, int64_t n_seg, int64_t task_events, int64_t n_tasks,
                        int64_t* plan, hipStream_t stream);
 hipError_t launch_analyze_csr(const int64_t* off, int64_t n_seg, CsrAnalysis* d_result, hipStream_t stream);

@@ -22,6 +22,7 @@ from .schema import (
     DEFAULT_ALGEBRA,
     EVENT_DTYPE,
     STATE_DTYPE,
+    CLayoutInfo,
     CSchema,
     CStats,
     EventAlgebra,
@@ -159,6 +160,16 @@ class ReplayEngine:
     # -- fold ------------------------------------------------------------------------------------
     def fold(self, algo: int = ALGO_AUTO) -> None:
         self._check(self._lib.surge_replay_fold(self._h, algo))
+
+    def prepare(self, algo: int = ALGO_AUTO) -> None:
+        """Build the per-log index ``algo`` needs (length order, chunk table, tile-major copy) without folding."""
+        self._check(self._lib.surge_replay_prepare(self._h, algo))
+
+    def layout_info(self) -> CLayoutInfo:
+        """The index built for the bound log and its one-off cost (``surge_replay_layout_info``)."""
+        info = CLayoutInfo()
+        self._check(self._lib.surge_replay_layout_info(self._h, ctypes.byref(info)))
+        return info
 
     def append_fold(self, group_agg, group_off, events) -> None:
         """Micro-batch re-fold onto the resident state (K3); see ``surge_replay_append_fold``."""

@@ -58,6 +58,7 @@ ALGO_FLAT = 2
 ALGO_ROWS = 3
 ALGO_SORTED = 4
 ALGO_CHUNKED = 5
+ALGO_TILED = 7
 
 INT32_MAX = 2**31 - 1
 INT32_MIN = -(2**31)
@@ -120,6 +121,21 @@ class CStats(ctypes.Structure):
         ("n_poisoned", ctypes.c_int64),
         ("sum_fold_kernel_ms", ctypes.c_double),
         ("timed_folds", ctypes.c_int64),
+    ]
+
+
+class CLayoutInfo(ctypes.Structure):
+    """``surge_replay_layout_info_t``: the per-log index of the last SORTED / CHUNKED / TILED fold and its one-off cost."""
+
+    _fields_ = [
+        ("algo", ctypes.c_int32),
+        ("chunk_events", ctypes.c_int32),
+        ("virtual_rows", ctypes.c_int64),
+        ("cut_aggregates", ctypes.c_int64),
+        ("tiled_bytes", ctypes.c_int64),
+        ("padding_events", ctypes.c_int64),
+        ("index_build_ms", ctypes.c_double),
+        ("relayout_ms", ctypes.c_double),
     ]
 
 

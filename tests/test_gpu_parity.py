@@ -72,7 +72,7 @@ def test_zipf_csr(seed, mix):
     got, st = gpu_fold(so, ev)
     assert st.last_algo == S.ALGO_FLAT  # 150 MB: below the ~1.5 GB where one lane per chunk starts to pay
     assert_same(got, exp, so)
-    for algo in (S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED):
+    for algo in (S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED, S.ALGO_TILED):
         got, st = gpu_fold(so, ev, algo=algo)
         assert st.last_algo == algo
         assert_same(got, exp, so)
@@ -135,7 +135,65 @@ def test_chunked_rows_resolve_presence_across_chunks(chunk_t, monkeypatch):
         got, st = gpu_fold(so, ev, prior, algo=S.ALGO_CHUNKED)
         assert st.last_algo == S.ALGO_CHUNKED
         assert_same(got, exp, so)
+        # K2t: the same chunks walked from the tile-major copy of the log (rows copied to tile boundaries, PAD events
+        # behind short rows), 8- and 16-event steps
+        for subs in ("1", "2"):
+            monkeypatch.setenv("SURGE_REPLAY_TILED_SUBS", subs)
+            got, st = gpu_fold(so, ev, prior, algo=S.ALGO_TILED)
+            assert st.last_algo == S.ALGO_TILED
+            assert_same(got, exp, so)
         got, _ = gpu_fold(so, ev, prior, algo=S.ALGO_FLAT)  # the flat kernel resolves presence its own way: same bytes
+        assert_same(got, exp, so)
+
+
+def test_tile_major_layout_prepare_reuse_and_rebind(monkeypatch):
+    # K2t: the handle copies the bound log once into tile-major order (surge_replay_prepare or the first TILED fold),
+    # later folds reuse the copy; a new bind drops it.  Covers: rows cut into chunks and not, empty segments, a prior
+    # snapshot, a last group of fewer than 64 rows, an odd number of 8-event subtiles, redirected output, repeated folds
+    # (the dispenser re-arms itself) and what surge_replay_layout_info reports.
+    monkeypatch.setenv("SURGE_REPLAY_CHUNK_T", "512")
+    rng = np.random.default_rng(5)
+    lens = (synth.zipf_lengths(np.arange(4000, dtype=np.int64), 11) * (rng.random(4000) < 0.93)).astype(np.int64)
+    lens[17] = 40_001  # cut into 79 chunks
+    so, ev = synth.csr_log(lens, 12, synth.STRESS_MIX)
+    prior = oracle.fold_csr(*synth.csr_log(rng.integers(0, 4, size=4000), 13, synth.STRESS_MIX))
+    exp = oracle.fold_csr(so, ev, prior)
+    n_events = int(so[-1])
+    with ReplayEngine() as eng:
+        eng.load_csr(so, ev, prior)
+        assert eng.layout_info().algo == 0
+        eng.prepare(S.ALGO_TILED)
+        info = eng.layout_info()
+        assert info.algo == S.ALGO_TILED and info.chunk_events == 512
+        assert info.cut_aggregates == int((lens > 512).sum())
+        assert info.virtual_rows == int(np.where(lens > 0, -(-lens // 512), 0).sum())
+        assert info.tiled_bytes % 8192 == 0 and info.tiled_bytes == 16 * (n_events + info.padding_events)
+        # rows are rounded up to 8 events and to their group's longest: a few percent here, < 1 % on the big logs
+        assert 0 <= info.padding_events < 0.25 * n_events
+        assert info.index_build_ms > 0 and info.relayout_ms > 0
+        for _ in range(3):
+            eng.fold(S.ALGO_TILED)
+            assert_same(eng.snapshot(), exp, so)
+        again = eng.layout_info()
+        assert (again.relayout_ms, again.tiled_bytes) == (info.relayout_ms, info.tiled_bytes)  # built once
+        eng.fold(S.ALGO_CHUNKED)  # the CSR kernels still work beside the copy
+        assert_same(eng.snapshot(), exp, so)
+        assert eng.layout_info().algo == S.ALGO_CHUNKED
+        eng.fold(S.ALGO_TILED)
+        assert_same(eng.snapshot(), exp, so)
+        # a different log on the same handle: the copy is rebuilt for it
+        so2, ev2 = synth.csr_log(rng.integers(0, 700, size=1000).astype(np.int64), 14, synth.STRESS_MIX)
+        eng.load_csr(so2, ev2)
+        assert eng.layout_info().algo == 0
+        eng.fold(S.ALGO_TILED)
+        assert_same(eng.snapshot(), oracle.fold_csr(so2, ev2), so2)
+    # uniform fan-in (config C2's shape) through the tile-major path, both step widths
+    so, ev = synth.fixed_log(5000, 256, seed=15)
+    exp = oracle.fold_csr(so, ev)
+    for subs in ("1", "2"):
+        monkeypatch.setenv("SURGE_REPLAY_TILED_SUBS", subs)
+        got, st = gpu_fold(so, ev, algo=S.ALGO_TILED)
+        assert st.last_algo == S.ALGO_TILED
         assert_same(got, exp, so)
 
 
@@ -145,7 +203,7 @@ def test_auto_picks_rows_for_large_uniform_logs_and_all_uniform_kernels_agree():
     got, st = gpu_fold(so, ev)
     assert st.last_algo == S.ALGO_ROWS
     assert_same(got, exp, so)
-    for algo in (S.ALGO_FIXED, S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED):
+    for algo in (S.ALGO_FIXED, S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED, S.ALGO_TILED):
         got, st = gpu_fold(so, ev, algo=algo)
         assert st.last_algo == algo
         assert_same(got, exp, so)
@@ -185,7 +243,7 @@ def test_csr_window_into_a_larger_events_buffer(lead, tail):
     so2 = so + lead
     exp = oracle.fold_csr(so, ev)
     assert oracle.fold_csr(so2, ev2).tobytes() == exp.tobytes()
-    for algo in (S.ALGO_AUTO, S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED):
+    for algo in (S.ALGO_AUTO, S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED, S.ALGO_TILED):
         got, _ = gpu_fold(so2, ev2, algo=algo)
         assert_same(got, exp, so)
     # a uniform log behind a lead cannot take the FIXED / ROWS fast paths, AUTO must still be right
@@ -254,7 +312,7 @@ def test_random_log_shapes_through_every_kernel(seed):
         if rng.random() < 0.5:
             prior = oracle.fold_csr(*synth.csr_log(rng.integers(0, 4, size=n), int(rng.integers(1, 1 << 30)), synth.STRESS_MIX))
         exp = oracle.fold_csr(so, ev, prior)
-        algos = [S.ALGO_AUTO, S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED] + ([S.ALGO_FIXED, S.ALGO_ROWS] if kind == 4 else [])
+        algos = [S.ALGO_AUTO, S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED, S.ALGO_TILED] + ([S.ALGO_FIXED, S.ALGO_ROWS] if kind == 4 else [])
         for algo in algos:
             got, _ = gpu_fold(so, ev, prior, algo=algo)
             assert got.tobytes() == exp.tobytes(), (seed, kind, n, algo)
