@@ -13,6 +13,12 @@ send/recv of the 40-byte wire form on the library's side stream), overlapped wit
 resident in HBM before the timed region.  ``--workload c2`` runs BASELINE config C2 (1 M aggregates x 256 events) instead;
 ``--workload c2-weak`` is round 1's weak-scaled C2-per-GPU run.
 
+The default algorithm for the Zipf log is the TILE-MAJOR fold (SURGE_ALGO_TILED: the handle copies the bound log once into
+group-major 8 KiB subtiles and every fold streams that copy linearly).  A recovery folds a log once, so what "once" costs
+is part of the line: ``one_shot`` carries the index build, the re-layout copy and the first (cold) fold, ``csr_direct`` the
+fold straight from the CSR log (no copy: SORTED / CHUNKED) measured in the same run.  ``python bench.py --gpus N`` with
+N > 1 and no torchrun environment starts its own ranks (torch.distributed.run on 127.0.0.1).
+
 Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant fold kernel against the 8 TB/s HBM peak using the
 algorithmic bytes 16*E + 8*(A+1) + 64*A and the kernel's HIP-event times measured inside the timed region on
 the launch stream (mean for ``achieved``; min / median / max reported).  ``traffic`` comes from the rocprofv3 PMC passes
@@ -40,20 +46,41 @@ ZIPF_SEED = 3
 C2_AGGREGATES, C2_EVENTS, C2_SEED = 1_000_000, 256, 2
 
 
+ALGO_NAMES = {"auto": 0, "fixed": 1, "flat": 2, "rows": 3, "sorted": 4, "chunked": 5, "tiled": 7}
+
+
 def kernel_name(S, algo):
     return {S.ALGO_FIXED: "fold_kernel<FIXED,16>", S.ALGO_FLAT: "fold_kernel<FLAT,16>", S.ALGO_ROWS: "fold_rows_kernel<8>",
-            S.ALGO_SORTED: "fold_sorted_kernel<16>", S.ALGO_CHUNKED: "fold_chunked_kernel<16> + chunk_stitch_kernel"}.get(algo, str(algo))
+            S.ALGO_SORTED: "fold_sorted_kernel<16>", S.ALGO_CHUNKED: "fold_chunked_kernel<16> + chunk_stitch_kernel",
+            S.ALGO_TILED: "fold_tiled_kernel<2> + chunk_stitch_kernel"}.get(algo, str(algo))
 
 
 def algo_name(S, algo):
-    return {S.ALGO_FIXED: "fixed", S.ALGO_FLAT: "flat", S.ALGO_ROWS: "rows", S.ALGO_SORTED: "sorted", S.ALGO_CHUNKED: "chunked"}.get(algo, str(algo))
+    return {S.ALGO_FIXED: "fixed", S.ALGO_FLAT: "flat", S.ALGO_ROWS: "rows", S.ALGO_SORTED: "sorted", S.ALGO_CHUNKED: "chunked",
+            S.ALGO_TILED: "tiled"}.get(algo, str(algo))
+
+
+def parse_algo(text):
+    if text is None:
+        return None
+    if text.lower() in ALGO_NAMES:
+        return ALGO_NAMES[text.lower()]
+    return int(text)
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def csrc_sha16():
     """Identity of the kernel sources a profile was taken with (profiles/traffic_manifest.json records it)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "surge_amd", "csrc")
-    for name in ("fold_layout.h", "fold_device.h", "fold_kernels.hip", "fold_chunked.hip"):  # what the fold kernels are built from
+    for name in ("fold_layout.h", "fold_device.h", "fold_chunk_device.h", "fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip"):  # what the fold kernels are built from
         h.update(name.encode())
         h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
@@ -142,7 +169,12 @@ def main():
                          "(strong-scaled); c2-weak: 1 M x 256 PER GPU (round 1's run)")
     ap.add_argument("--aggregates", type=int, default=None, help="global aggregate count (default 10 M for c4, 1 M for c2)")
     ap.add_argument("--events-per-aggregate", type=int, default=C2_EVENTS, help="c2 only")
-    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 fixed, 2 flat, 3 rows, 4 sorted, 5 chunked")
+    ap.add_argument("--algo", default=None,
+                    help="auto | fixed | flat | rows | sorted | chunked | tiled (or the SURGE_ALGO_* number); default: tiled for the "
+                         "Zipf log (c3 / c4), auto for c2")
+    ap.add_argument("--parity", default="full", choices=["full", "sample", "none"],
+                    help="N = 1: check the GPU states against the CPU restatement on the whole log (default), on the cpu_baseline "
+                         "sample only, or not at all")
     ap.add_argument("--gather", default="native", choices=["native", "torch", "none"],
                     help="N > 1 snapshot exchange: native = RCCL behind the C ABI (default), torch = torch.distributed, none = fold only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-time budget of the cpu_baseline leg")
@@ -157,12 +189,16 @@ def main():
     from surge_amd import synth
     from surge_amd.replay import ReplayEngine
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start one rank per GPU ourselves (what the driver's torchrun line does)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the replay engine has no CPU fallback")
@@ -188,6 +224,9 @@ def main():
 
     zipf = args.workload in ("c4", "c3")
     weak = args.workload == "c2-weak"
+    algo = parse_algo(args.algo)
+    if algo is None:
+        algo = S.ALGO_TILED if zipf else S.ALGO_AUTO
     L = args.events_per_aggregate
     n_global = args.aggregates or (N_AGGREGATES if zipf else C2_AGGREGATES)
     if weak:
@@ -246,12 +285,26 @@ def main():
     eng.load_csr(seg_off, events, None, bufs[0])
     fold_done = [torch.cuda.Event(), torch.cuda.Event()]
 
+    # ---- what happens ONCE per bound log: its index (length order / chunk table / tile-major copy) and the first,
+    # cold fold — a recovery is one fold, so these are reported beside the warm-replay rate, never inside it
+    torch.cuda.synchronize(dev)
+    t_p = time.perf_counter()
+    eng.prepare(algo)
+    eng.synchronize()
+    prepare_wall_ms = (time.perf_counter() - t_p) * 1e3
+    layout = eng.layout_info()
+    t_p = time.perf_counter()
+    eng.fold(algo)
+    eng.synchronize()
+    first_fold_wall_ms = (time.perf_counter() - t_p) * 1e3
+    first_fold_kernel_ms = eng.stats().last_fold_kernel_ms
+
     def step(i):
         slot = i & 1
         if gather is not None:
             gather.wait(slot, compute)  # the exchange that last read bufs[slot] must be finished
         eng.set_state_out(bufs[slot])
-        eng.fold(args.algo)
+        eng.fold(algo)
         if gather is not None:
             fold_done[slot].record(compute)
             gather.launch(slot, bufs[slot], fold_done[slot])
@@ -326,6 +379,37 @@ def main():
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
             cpu_baseline = run_cpu_baseline(args, seg_off, events, bufs[last])
+        one_shot = {
+            "index_algo": algo_name(S, layout.algo) if layout.algo else None,
+            "index_build_ms": layout.index_build_ms,
+            "relayout_ms": layout.relayout_ms,
+            "prepare_wall_ms": prepare_wall_ms,
+            "first_fold_kernel_ms": first_fold_kernel_ms,
+            "first_fold_wall_ms": first_fold_wall_ms,
+            "tile_major_copy_bytes": layout.tiled_bytes,
+            "padding_events": layout.padding_events,
+            "virtual_rows": layout.virtual_rows,
+            "cut_aggregates": layout.cut_aggregates,
+            "chunk_events": layout.chunk_events,
+            "note": "device time between HIP events (wall for *_wall_ms), rank 0; paid once per bound log, outside the timed region",
+        }
+        csr_direct = None
+        if world == 1 and st.last_algo == S.ALGO_TILED:
+            # the same log folded straight from CSR (no copy): what a one-shot recovery would run
+            eng.set_state_out(bufs[1 - last])
+            t_p = time.perf_counter()
+            eng.fold(S.ALGO_AUTO)
+            eng.synchronize()
+            csr_first_wall = (time.perf_counter() - t_p) * 1e3
+            csr_layout = eng.layout_info()
+            dt2, st2, tm2 = time_folds(eng, torch, dev, S.ALGO_AUTO, max(5, args.steps // 2), 1)
+            csr_direct = {"algo": algo_name(S, st2.last_algo), "kernel": kernel_name(S, st2.last_algo),
+                          "index_build_ms": csr_layout.index_build_ms, "first_fold_wall_ms_incl_index": csr_first_wall,
+                          "kernel_ms_min_median_max": [float(np.min(tm2)), float(np.median(tm2)), float(np.max(tm2))],
+                          "frac": st2.algorithmic_bytes / (float(np.mean(tm2)) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                          "events_per_sec": total_events / (float(np.mean(tm2)) * 1e-3),
+                          "states_equal_primary": bool(torch.equal(bufs[0], bufs[1]))}
+            eng.set_state_out(bufs[last])
         if zipf:
             wl = (f"C{'3' if world == 1 else '4'}: {n_global} aggregates, Zipf(1..4096) events each, CSR, 16 B events, 64 B state, "
                   f"ids acct-%08d sharded over {world} GPU(s) by partitionForKey(id, {N_PARTITIONS}) % {world}; log resident in HBM")
@@ -365,6 +449,8 @@ def main():
                 "exchange_hidden_fraction": None if not exchange else max(0.0, min(1.0, 1.0 - max(0.0, ms_per_step - fold_ms) / exchange)),
             },
             "roofline": roof,
+            "one_shot": one_shot,
+            "csr_direct": csr_direct,
             "cpu_baseline": cpu_baseline,
         }
         if world == 1 and zipf and not args.no_secondary:
@@ -416,6 +502,45 @@ def effective_cpus():
             pass
     eff = n if quota is None else max(1, min(n, int(quota + 0.999)))
     return eff, n, quota
+
+
+def full_log_parity(seg_off, events, gpu_states, threads, slice_events=1 << 28):
+    """EVERY aggregate of the HBM-resident log folded by the CPU restatement (oracle/, sequential per aggregate, aggregates
+    split over ``threads`` host threads) and compared byte for byte with the GPU's states.  The log is brought to the host
+    in slices of whole aggregates (~``slice_events`` events = 4 GiB each), so the host never holds more than one slice."""
+    import numpy as np
+    import torch
+
+    from oracle import oracle
+    from surge_amd import schema as S
+    from surge_amd import synth
+
+    t0 = time.perf_counter()
+    n = int(seg_off.numel()) - 1
+    total = int(seg_off[-1].item())
+    cuts = [0, n]
+    if total > slice_events:
+        targets = torch.arange(slice_events, total, slice_events, device=seg_off.device, dtype=seg_off.dtype)
+        cuts += [int(c) for c in torch.searchsorted(seg_off, targets).tolist()]
+    cuts = sorted(set(cuts))
+    bad, first_bad, checked_events, cpu_s = 0, None, 0, 0.0
+    for a0, a1 in zip(cuts[:-1], cuts[1:]):
+        e0, e1 = int(seg_off[a0].item()), int(seg_off[a1].item())
+        so = (seg_off[a0 : a1 + 1] - e0).cpu().numpy()
+        ev = synth.to_event_records(events[e0:e1])
+        t1 = time.perf_counter()
+        exp = oracle.fold_csr(so, ev, threads=threads)
+        cpu_s += time.perf_counter() - t1
+        got = gpu_states[a0:a1].cpu().numpy().view(S.STATE_DTYPE).reshape(-1)
+        if got.tobytes() != exp.tobytes():
+            diff = np.nonzero(got != exp)[0]
+            bad += int(diff.size)
+            if first_bad is None:
+                first_bad = a0 + int(diff[0])
+        checked_events += e1 - e0
+        del ev, exp, got
+    return {"aggregates_checked": n, "events_checked": checked_events, "mismatching_aggregates": bad, "first_mismatch": first_bad,
+            "slices": len(cuts) - 1, "seconds": time.perf_counter() - t0, "cpu_fold_seconds": cpu_s, "threads": threads}
 
 
 def run_cpu_baseline(args, seg_off, events, gpu_states):
@@ -470,11 +595,23 @@ def run_cpu_baseline(args, seg_off, events, gpu_states):
                     "GBps": (ev.nbytes + so.nbytes) / dt / 1e9}
     except Exception as exc:  # pragma: no cover
         pcie = {"error": str(exc)}
+    full = None
+    if args.parity == "full":
+        full = full_log_parity(seg_off, events, gpu_states, cores)
+    pcie_full = None
+    if isinstance(pcie, dict) and pcie.get("GBps"):
+        n_all = int(seg_off[-1].item())
+        pcie_full = {"seconds": (16 * n_all + 8 * (n_aggs + 1)) / (pcie["GBps"] * 1e9),
+                     "note": "the whole log handed over as host buffers at the H2D rate measured on the sample (extrapolated, not run: "
+                             "the log is generated on the device)"}
     return {
         "value": all_cores,
         "unit": "events/s",
         "cores": cores,
         "kind": "port",
+        "gpu_matches_cpu_full_log": None if full is None else full["mismatching_aggregates"] == 0,
+        "full_log_check": full,
+        "pcie_inclusive_full_log_estimate": pcie_full,
         "sample": f"first {sample_aggs} aggregates of the same log ({n_ev} events), "
                   f"C restatement of the fold, aggregates split over {cores} host threads "
                   f"({logical} logical CPUs visible, cgroup CPU quota {'none' if quota is None else round(quota, 2)})",

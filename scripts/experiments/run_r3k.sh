@@ -1,0 +1,3 @@
+mkdir -p gpurun_out/r3k
+SURGE_DBG_PROBE_TILES=1 MODES=0 HANDLES=6 SHAPE=z4m SUBS=2 WAVES=6 ROUNDS=3 FOLDS=10 timeout 600 python scripts/experiments/ab_modes.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r3k/ab.log
+cat gpurun_out/r3k/ab.log

@@ -749,6 +749,9 @@ int32_t ensure_index(surge_replay_handle* h, const FoldPlan& pl) {
     HIPCHK(h, launch_relayout(h->d_events, (const int64_t*)h->tidx.v_start.ptr, (const uint32_t*)h->tidx.v_len.ptr, h->tidx.n_vrows,
                               (const int64_t*)h->t_gsub.ptr, n_sub, (uint4*)h->t_tiles.ptr, h->stream));
     HIPCHK(h, hipEventRecord(h->ev_r1, h->stream));
+    if (std::getenv("SURGE_DBG_PRINT"))
+      std::fprintf(stderr, "[surge dbg] tiles %p (%lld subtiles) v_len %p v_info %p v_dest %p g_sub %p state %p events %p\n", h->t_tiles.ptr,
+                   (long long)n_sub, h->tidx.v_len.ptr, h->tidx.v_info.ptr, h->tidx.v_seg.ptr, h->t_gsub.ptr, (void*)h->d_state, (const void*)h->d_events);
     h->tiled_valid = true;
     h->index_timed = h->relayout_timed = true;
     h->index_algo = SURGE_ALGO_TILED;
@@ -916,7 +919,7 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       HIPCHK(h, hipEventRecord(e1, h->stream));
       h->st.n_tasks = (int32_t)n_waves;
     } else if (use == SURGE_ALGO_TILED) {
-      int subs = 2;  // subtiles (8 events per lane) per step
+      int subs = 2;  // subtiles (8 events per lane) per step: 16 KiB in flight per wave
       if (const char* v = std::getenv("SURGE_REPLAY_TILED_SUBS")) subs = std::atoi(v) == 1 ? 1 : 2;
       const auto& ci = h->tidx;
       {
@@ -925,8 +928,9 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       }
       p.n_seg = h->an.n_empty > 0 ? h->n_nz : h->n_agg;
       const int64_t groups = (ci.n_vrows + kWave - 1) / kWave;
-      // resident waves per CU: 16 KiB steps 8 (2 per SIMD), 8 KiB steps 12 (3 per SIMD)
-      int64_t per_cu = subs == 1 ? 12 : 8;
+      // resident waves per CU.  Measured (round 3, same handle, Zipf(1..4096) logs of 9 / 30 / 74 GB and config C2): with
+      // 16 KiB steps 6 waves per CU beat 8 and 9 by 0.3-7 % and 4 by 0-5 %; 8 KiB steps are 0.5-4 % behind at any count
+      int64_t per_cu = subs == 1 ? 8 : 6;
       if (const char* v = std::getenv("SURGE_REPLAY_TILED_WAVES")) per_cu = std::atoi(v) > 0 ? std::atoi(v) : per_cu;
       const int64_t slots = (int64_t)h->n_cus * per_cu;
       const int64_t n_waves = groups < slots ? groups : slots;
@@ -1638,6 +1642,10 @@ int32_t surge_replay_stream_probe(surge_replay_handle* h, const void* d_src, int
   if (n_bytes < 16 || (n_bytes & 15) || ((uintptr_t)d_src & 15)) return fail(h, SURGE_E_INVALID, "n_bytes/pointer must be 16-byte multiples");
   DeviceGuard g(h->device);
   HIPCHK(h, h->poison_count.reserve(8));
+  if (std::getenv("SURGE_DBG_PROBE_TILES") && h->tiled_valid) {  // experiments: stream the handle's own tile-major copy
+    d_src = h->t_tiles.ptr;
+    n_bytes = h->t_n_sub * (int64_t)kTileSubBytes;
+  }
   float best = 0.f;
   for (int variant = 0; variant < 3; ++variant) {  // plain / non-temporal register loads, LDS-DMA tile stream: report the fastest
     HIPCHK(h, hipEventRecord(h->ev_h0, h->stream));

@@ -221,6 +221,8 @@ fold_tiled_kernel(const FoldParams p, const TileTable t) {
         if (!undecided) Sw.fl |= SIDE_DECIDED;
         store_side(t.side, cur.dest, Pw, Sw);
       } else {
+        // (tried in round 3: transposing the wave's 64 states through LDS so that each 64-byte state leaves as one
+        // contiguous access, and writing them in group order — same handle, alternating folds: +-0.1 % and -0.5 %)
         store_state(p.out, cur.dest, a);
       }
     }

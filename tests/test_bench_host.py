@@ -71,3 +71,20 @@ def test_committed_profiles_describe_the_current_kernel_sources():
     stale = sorted({e["source"].split(" ")[0] for e in entries if e["csrc_sha16"] != sha})
     if stale:
         pytest.skip("kernel sources changed since these PMC passes were taken (bench.py reports traffic: null for them): " + ", ".join(stale))
+
+
+def test_algo_names_and_plain_multi_gpu_invocation_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun environment) must re-exec under torch.distributed.run — the way the driver
+    starts the N > 1 bench.  Without a GPU both ranks then stop at the no-CPU-fallback check, which is what shows they ran."""
+    import subprocess
+
+    import torch
+
+    assert bench.parse_algo("tiled") == 7 and bench.parse_algo("AUTO") == 0 and bench.parse_algo("5") == 5 and bench.parse_algo(None) is None
+    if torch.cuda.is_available():
+        pytest.skip("covered on the GPU by tests/test_bench_rehearsal.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert res.returncode != 0
+    assert res.stderr.count("bench.py needs a GPU") >= 2, res.stderr[-3000:]

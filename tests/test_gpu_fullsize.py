@@ -1,17 +1,22 @@
 """-m gpu: BASELINE.json's full-size configs, checked through size-independent properties.
 
 C2 = 1 M aggregates x 256 events (4.1 GB), C3 = 10 M aggregates with Zipf(1..4096) event counts
-(~4.6e9 events, ~74 GB, generated on the GPU).  The oracle cannot fold these in seconds, so beside
-oracle parity on slices the checks are: every kernel family agrees bit for bit on the whole log,
-replay is idempotent, and — for a Counter-only log, where the fold is linear — every field equals an
-independent torch segment reduction (prefix sums over the raw events).
+(~4.6e9 events, ~74 GB, generated on the GPU).  EVERY aggregate of C2, C3 and the C4 shard is folded by the CPU
+oracle too (the log is streamed to the host in 4 GiB slices of whole aggregates and folded on all host threads:
+bench.full_log_parity, ~1-2 min for the 74 GB log) and compared byte for byte; beside that: every kernel family agrees
+bit for bit on the whole log, replay is idempotent, and — for a Counter-only log, where the fold is linear — every
+field equals an independent torch segment reduction (prefix sums over the raw events).
 
 Set SURGE_TEST_C3_AGGREGATES to shrink C3 (default 10_000_000).
 """
 import os
+import sys
 
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (full_log_parity: the whole-log oracle check bench.py's cpu_baseline leg runs)
 
 from oracle import oracle
 from surge_amd import schema as S
@@ -38,6 +43,15 @@ def fold_all(so, ev, algos):
         eng.synchronize()
         assert torch.equal(buf, out[algos[0]])
     return out
+
+
+def whole_log_parity(states, so, ev):
+    cores, _, _ = bench.effective_cpus()
+    r = bench.full_log_parity(so, ev, states, cores)
+    print(f"full-log oracle parity: {r['aggregates_checked']} aggregates / {r['events_checked']} events in {r['seconds']:.1f} s "
+          f"({r['cpu_fold_seconds']:.1f} s of it the CPU fold on {r['threads']} threads, {r['slices']} slices)")
+    assert r["aggregates_checked"] == so.numel() - 1 and r["events_checked"] == int(so[-1]) - int(so[0])
+    assert r["mismatching_aggregates"] == 0, f"{r['mismatching_aggregates']} aggregates differ from the oracle, first {r['first_mismatch']}"
 
 
 def slice_parity(states, so, ev, a0, a1):
@@ -95,9 +109,10 @@ def check_counter_fields(states, so, ev, max_chunk_events=300_000_000):
 def test_c2_full_size_1m_aggregates_x_256_events():
     A, L = 1_000_000, 256
     so, ev = synth.fixed_log_device(A, L, 2, DEV)
-    res = fold_all(so, ev, [S.ALGO_ROWS, S.ALGO_FIXED, S.ALGO_FLAT, S.ALGO_SORTED])
-    for a in (S.ALGO_FIXED, S.ALGO_FLAT, S.ALGO_SORTED):
+    res = fold_all(so, ev, [S.ALGO_ROWS, S.ALGO_FIXED, S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_TILED])
+    for a in (S.ALGO_FIXED, S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_TILED):
         assert torch.equal(res[S.ALGO_ROWS], res[a]), f"algo {a} differs from rows on the full C2 log"
+    whole_log_parity(res[S.ALGO_ROWS], so, ev)
     slice_parity(res[S.ALGO_ROWS], so, ev, 0, 20_000)
     slice_parity(res[S.ALGO_ROWS], so, ev, A - 5_000, A)
     del res
@@ -113,9 +128,11 @@ def test_c3_full_size_10m_aggregates_zipf():
     lens = synth.zipf_lengths(torch.arange(A, dtype=torch.int64, device=DEV), 3)
     # C3 type mix: oracle slices + agreement between the linear-stream and the sorted-rows kernels
     so, ev = synth.csr_log_device(lens, 3)
-    res = fold_all(so, ev, [S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED])
+    res = fold_all(so, ev, [S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED, S.ALGO_TILED])
     assert torch.equal(res[S.ALGO_FLAT], res[S.ALGO_SORTED]), "flat and sorted-rows differ on the full C3 log"
     assert torch.equal(res[S.ALGO_FLAT], res[S.ALGO_CHUNKED]), "flat and chunked-rows differ on the full C3 log"
+    assert torch.equal(res[S.ALGO_FLAT], res[S.ALGO_TILED]), "flat and tile-major differ on the full C3 log"
+    whole_log_parity(res[S.ALGO_TILED], so, ev)  # all 10 M aggregates, all 4.6e9 events, byte for byte
     slice_parity(res[S.ALGO_FLAT], so, ev, 0, 4_000)
     slice_parity(res[S.ALGO_FLAT], so, ev, A - 3_000, A)
     slice_parity(res[S.ALGO_FLAT], so, ev, A // 2, A // 2 + 3_000)
@@ -144,8 +161,10 @@ def test_c4_shard_size_1_25m_aggregates_zipf_every_kernel_agrees():
     A = 1_250_000
     lens = synth.zipf_lengths(torch.arange(A, dtype=torch.int64, device=DEV), 3)
     so, ev = synth.csr_log_device(lens, 3, mix=synth.STRESS_MIX)  # tombstones, throws, REQUIRE runs across chunk cuts
-    res = fold_all(so, ev, [S.ALGO_CHUNKED, S.ALGO_FLAT, S.ALGO_SORTED])
+    res = fold_all(so, ev, [S.ALGO_CHUNKED, S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_TILED])
     assert torch.equal(res[S.ALGO_CHUNKED], res[S.ALGO_FLAT]) and torch.equal(res[S.ALGO_CHUNKED], res[S.ALGO_SORTED])
+    assert torch.equal(res[S.ALGO_CHUNKED], res[S.ALGO_TILED])
+    whole_log_parity(res[S.ALGO_TILED], so, ev)  # every aggregate of the shard, stress mix
     slice_parity(res[S.ALGO_CHUNKED], so, ev, 0, 6_000)
     slice_parity(res[S.ALGO_CHUNKED], so, ev, A - 4_000, A)
     with ReplayEngine() as eng:
