@@ -26,7 +26,8 @@ sys.path.insert(0, ROOT)
 
 
 def short_name(k):
-    for n in ("fold_rows_kernel", "fold_sorted_kernel", "fold_chunked_kernel", "chunk_stitch_kernel", "stream_probe", "plan_kernel"):
+    for n in ("fold_rows_kernel", "fold_sorted_kernel", "fold_chunked_kernel", "fold_tiled_kernel", "relayout_kernel", "fold_slots_kernel",
+              "chunk_stitch_kernel", "stream_probe", "plan_kernel"):
         if n in k:
             return n
     if "fold_kernel" in k:

@@ -623,8 +623,8 @@ int32_t plan_fold(surge_replay_handle* h, int32_t algo, FoldPlan& pl) {
   pl.uniform = uniform;
   if ((algo == SURGE_ALGO_FIXED || algo == SURGE_ALGO_ROWS) && !uniform)
     return fail(h, SURGE_E_UNSUPPORTED, "ALGO_FIXED / ALGO_ROWS need equal segment lengths that are a multiple of 16");
-  const bool rows_ok = uniform && h->an.len0 <= (1 << 24);
-  if (algo == SURGE_ALGO_ROWS && !rows_ok) return fail(h, SURGE_E_UNSUPPORTED, "ALGO_ROWS needs L <= 2^24");
+  const bool rows_ok = uniform && h->an.len0 <= (1 << 20);  // 64 rows x L x 16 B must fit a 31-bit buffer offset
+  if (algo == SURGE_ALGO_ROWS && !rows_ok) return fail(h, SURGE_E_UNSUPPORTED, "ALGO_ROWS needs L <= 2^20");
   // one lane per aggregate only pays when 64-aggregate groups alone can fill the chip: measured crossover
   // with FIXED between 512 groups (FIXED 20-50 % faster) and 1024 groups (ROWS 10-18 % faster, L = 64..1024)
   const bool rows_auto = rows_ok && h->n_agg / kWave >= 1024;

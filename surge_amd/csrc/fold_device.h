@@ -153,6 +153,12 @@ __device__ __forceinline__ Acc shfl_up_acc(const Acc& a, int d) {
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
+// a value every lane holds identically, moved to scalar registers (buffer descriptors need wave-uniform bases)
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 __device__ __forceinline__ Acc readlane_acc(const Acc& a, int lane) {
   Acc r;
   r.count = (int32_t)rl((uint32_t)a.count, lane); r.version = (int32_t)rl((uint32_t)a.version, lane);
@@ -230,22 +236,29 @@ __device__ __forceinline__ void load_table(const FoldParams& p, uint32_t* lds_ta
     lds_tab[(i / kTableWords == kTableEntries - 1 ? kNullEntryOff : (i / kTableWords) * kTableStride) + (i % kTableWords)] = src[i];
 }
 
+// One linear tile [te0, te0 + kTile) of the events buffer -> LDS, as buffer_load_dwordx4 ... lds: descriptor base = the
+// tile's first byte (wave-uniform), lane offset = the swizzled slot, instruction q at scalar offset 1024 q.  MUBUF rather
+// than global_load_lds on purpose: hipcc models global_load_lds as a FLAT access that may touch LDS, and while one is
+// outstanding (the next tile's fetch is, during the whole walk) it turns EVERY s_waitcnt in front of an LDS read into
+// lgkmcnt(0) — the one-event-ahead prefetch of op-table entries then waits for the entry it has just requested.  With
+// buffer loads the waits are the exact counts.  (The row kernels over the CSR log cannot do this: their lanes address
+// rows anywhere in a log of up to 2^38 bytes and a buffer offset has 32 bits; the tile-major kernel can.)
 template <int LE>
 __device__ __forceinline__ void issue_tile_loads(const FoldParams& p, int64_t te0, char* lds, const uint32_t* voff) {
   using G = Geo<LE>;
   const char* base = (const char*)(p.events + te0);  // wave-uniform
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
   if (te0 + G::kTile <= p.n_events) {
 #pragma unroll
     for (int q = 0; q < G::kLoads; ++q)
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + q * 1024 + voff[q % G::kClasses]), (lptr_t)(lds + q * 1024), 16, 0,
-                                       kLoadAux);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds + q * 1024), 16, (int)voff[q % G::kClasses], q * 1024, 0, kLoadAux);
   } else {  // the last tile of the buffer: clamp so nothing is read past the end
-    const int64_t last = (p.n_events - 1 - te0) * 16;
+    const int last = (int)((p.n_events - 1 - te0) * 16);
 #pragma unroll
     for (int q = 0; q < G::kLoads; ++q) {
-      int64_t off = (int64_t)(q * 1024 + voff[q % G::kClasses]);
+      int off = q * 1024 + (int)voff[q % G::kClasses];
       off = off < last ? off : last;
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(lds + q * 1024), 16, 0, kLoadAux);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds + q * 1024), 16, off, 0, 0, kLoadAux);
     }
   }
 }

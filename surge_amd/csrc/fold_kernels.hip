@@ -58,23 +58,28 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
     E0 = S0 * p.fixed_len;
     E1 = S1 * p.fixed_len;
   } else {
-    S0 = p.plan[task];
-    S1 = p.plan[task + 1];
+    S0 = uniform64(p.plan[task]);
+    S1 = uniform64(p.plan[task + 1]);
     if (S0 >= S1) return;
-    E0 = p.seg_off[S0];
-    E1 = p.seg_off[S1];
+    E0 = uniform64(p.seg_off[S0]);
+    E1 = uniform64(p.seg_off[S1]);
   }
   if (E1 <= E0) return;
+  // Tiles are cut from the 128-byte line that holds the task's first event: every 1 KiB load instruction then covers 8
+  // whole lines instead of straddling 9 (measured in round 2 on a 0.1 M-aggregate log: FETCH_SIZE 1.17 x the algorithmic
+  // bytes).  The `lead` events in front of E0 belong to the previous task's last segment: null events here.
+  const int lead = (int)(E0 & 7);
+  const int64_t Ea = E0 - lead;
 
   load_table<LE>(p, lds_tab, lane);
   if (MODE == MODE_FLAT && lane < G::kHeadWords) lds_hb[lane] = 0u;
 
-  const int n_tiles = (int)((E1 - E0 + G::kTile - 1) / G::kTile);
+  const int n_tiles = (int)((E1 - Ea + G::kTile - 1) / G::kTile);
   uint32_t voff[G::kClasses];
 #pragma unroll
   for (int k = 0; k < G::kClasses; ++k) voff[k] = ((uint32_t)(lane / LE) * LE + G::load_j(lane, k)) * 16u;
   const uint32_t ev_row = G::ev_row(lane);
-  issue_tile_loads<LE>(p, E0, lds_ev, voff);
+  issue_tile_loads<LE>(p, Ea, lds_ev, voff);
 
   // FLAT: head marking.  next_s = first segment whose start has not been marked yet.
   int64_t next_s = S0;
@@ -93,7 +98,7 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
       if (cnt < kWave) break;
     }
   };
-  if (MODE == MODE_FLAT) mark_heads(E0);
+  if (MODE == MODE_FLAT) mark_heads(Ea);
 
   // The running segment that enters the next tile; starts as "nothing" (a head, None).
   Acc carry = acc_none();
@@ -103,7 +108,7 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
   const uint64_t below = (1ull << lane) - 1ull;
 
   for (int tile = 0; tile < n_tiles; ++tile) {
-    const int64_t te0 = E0 + (int64_t)tile * G::kTile;
+    const int64_t te0 = Ea + (int64_t)tile * G::kTile;
 
     // tile `tile` has landed in LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -126,7 +131,7 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
       heads_in_tile = (int)rl((uint32_t)incl, 63);
     } else {
       const uint32_t L = (uint32_t)p.fixed_len;
-      const uint32_t e_rel = (uint32_t)(te0 - E0) + (uint32_t)lane * LE;
+      const uint32_t e_rel = (uint32_t)(te0 - E0) + (uint32_t)lane * LE;  // FIXED: L % 16 == 0, so lead == 0
       const uint32_t q = e_rel / L;
       const uint32_t r = e_rel - q * L;
       hb = (r == 0u && te0 + lane * LE < E1) ? 1u : 0u;
@@ -140,14 +145,15 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
     // LDS dword offset of each event's op-table entry.  Events past the end of the task (last tile
     // only) become the null event [17], an identity on every state, so nothing below needs a validity mask.
     uint32_t tyc[LE];
-    if (te0 + G::kTile <= E1) {
+    if (te0 + G::kTile <= E1 && (tile > 0 || lead == 0)) {
 #pragma unroll
       for (int j = 0; j < LE; ++j) tyc[j] = (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride;
     } else {
       const int64_t rem = E1 - (te0 + (int64_t)lane * LE);
+      const int skip = tile == 0 ? lead - lane * LE : 0;  // the lead events of the first tile sit in lane 0 (lead < 8 <= LE)
 #pragma unroll
       for (int j = 0; j < LE; ++j)
-        tyc[j] = (int64_t)j < rem ? (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride : (uint32_t)kNullEntryOff;
+        tyc[j] = (j >= skip && (int64_t)j < rem) ? (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride : (uint32_t)kNullEntryOff;
     }
 
     // ---- pass A: presence / poison only, bit-parallel ---------------------------------------------
@@ -306,22 +312,25 @@ __global__ void __launch_bounds__(kWave) fold_rows_kernel(const FoldParams p) {
   for (int k = 0; k < G::kClasses; ++k) voff[k] = ((uint32_t)(lane / LE) * L + G::load_j(lane, k)) * 16u;
   const uint32_t ev_row = G::ev_row(lane);
 
+  // buffer_load ... lds (see issue_tile_loads for why not global_load_lds): descriptor base = the group's first row at
+  // this tile's column, lane offset = its row (m / LE) and swizzled slot, instruction q at scalar offset RPL q rows
   auto issue = [&](int t) {
     const int g = t / chunks, c = t - g * chunks;
     const int64_t row0 = S0 + (int64_t)g * kWave;
     const char* base = (const char*)(p.events + (row0 * L + (int64_t)c * LE));  // wave-uniform
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
     if (row0 + kWave <= p.n_seg) {
 #pragma unroll
       for (int q = 0; q < G::kLoads; ++q)
-        __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)(G::kRowsPerLoad * q) * L * 16u + voff[q % G::kClasses]),
-                                         (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds_ev + q * 1024), 16, (int)voff[q % G::kClasses],
+                                                 (int)((uint32_t)(G::kRowsPerLoad * q) * L * 16u), 0, kLoadAux);
     } else {  // last group of the log: rows past the end re-read the last row (their lanes are idle)
 #pragma unroll
       for (int q = 0; q < G::kLoads; ++q) {
         int64_t row = row0 + G::kRowsPerLoad * q + lane / LE;
         row = row < p.n_seg ? row : p.n_seg - 1;
-        const uint4* src = p.events + (row * L + (int64_t)c * LE + G::load_j(lane, q % G::kClasses));
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
+        const int off = (int)(((row - row0) * L + G::load_j(lane, q % G::kClasses)) * 16);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds_ev + q * 1024), 16, off, 0, 0, kLoadAux);
       }
     }
   };
