@@ -20,8 +20,7 @@ oracle:
 demos: lib
 	gcc -std=c99 -Wall -Iinclude examples/c_host_demo.c $(LDDEMO) -o examples/c_host_demo
 	g++ -std=c++17 -Wall -Iinclude examples/cpp_host_demo.cpp $(LDDEMO) -o examples/cpp_host_demo
-	g++ -std=c++17 -Wall -Iinclude examples/cpp_persistence_demo.cpp $(LDDEMO) -o examples/cpp_persistence_demo
 
 clean:
-	rm -f $(LIB) examples/c_host_demo examples/cpp_host_demo examples/cpp_persistence_demo
+	rm -f $(LIB) examples/c_host_demo examples/cpp_host_demo
 	$(MAKE) -C oracle clean

@@ -19,8 +19,8 @@ from typing import Optional, Sequence, Union
 
 import numpy as np
 
-from .command import ReplayableCommandModel, SurgeCommandBusinessLogic
-from .core import (
+from surge_amd.command import ReplayableCommandModel, SurgeCommandBusinessLogic
+from surge_amd.core import (
     KafkaTopic,
     SerializedAggregate,
     SerializedMessage,
@@ -28,7 +28,7 @@ from .core import (
     SurgeEventReadFormatting,
     SurgeEventWriteFormatting,
 )
-from .schema import (
+from surge_amd.schema import (
     CLS_CREATE,
     CLS_MATERIALIZE,
     CLS_REQUIRE,

@@ -455,7 +455,7 @@ int32_t surge_replay_unpack_states(surge_replay_handle* h, const void* d_packed4
  *
  *   rank 0:  surge_replay_comm_unique_id(id)  -> hand the 128 bytes to every rank over any channel the host has
  *   all:     surge_replay_comm_init(h, rank, world, id)                       (collective, blocking)
- *   all:     surge_replay_comm_counts(h, n_local, counts[world], &max_count)  (collective; cached per n_local)
+ *   all:     surge_replay_comm_counts(h, n_local, counts[world], &max_count)  (collective, every call: all ranks or none)
  *   all:     surge_replay_allgather_snapshot(h, d_states, n_local, d_out, rows_per_rank, slot, mode)
  *              d_out[r * rows_per_rank + i] = state i of rank r (64 B); rows i >= counts[r] are None (zero).
  *              d_states NULL = the handle's resident state.  Asynchronous: runs on the handle's side stream after
@@ -479,6 +479,11 @@ int32_t surge_replay_comm_destroy(surge_replay_handle* h);
 /* library = path the RCCL symbols came from (owned by the library); version = ncclGetVersion */
 int32_t surge_replay_comm_info(surge_replay_handle* h, int32_t* rank, int32_t* world, int32_t* rccl_version,
                                const char** library);
+/* Exchanges the shard sizes: a COLLECTIVE on every call (8-byte all-gather + host sync) — every rank calls it or none does.
+ * An exchange (surge_replay_allgather_snapshot) reuses the sizes of the last exchange; a rank's very first exchange does
+ * the size exchange implicitly (every rank of a new communicator is in that state).  When ANY rank's n_local may have
+ * changed (surge_replay_grow, a new shard), every rank calls surge_replay_comm_counts again first: a rank that passes a
+ * different n_local to an exchange without it gets SURGE_E_STATE — it never starts a collective its peers are not in. */
 int32_t surge_replay_comm_counts(surge_replay_handle* h, int64_t n_local, int64_t* counts_out, int64_t* max_count_out);
 int32_t surge_replay_allgather_snapshot(surge_replay_handle* h, const void* d_states, int64_t n_local, void* d_out,
                                         int64_t rows_per_rank, int32_t slot, int32_t mode);

@@ -6,10 +6,10 @@
   event at a time, is the *semantic contract* (seam S3).
 * ``SurgeCommandBusinessLogic`` — ``.../command/SurgeCommandBusinessLogic.scala:8-14`` and
   ``modules/command-engine/core/src/main/scala/surge/core/commondsl/SurgeGenericBusinessLogicTrait.scala:16-64``.
-* ``BatchedAggregateCommandModel`` (``AsyncAggregateCommandModel``, :33-57), ``AggregateEventModel``
-  (``.../scaladsl/event/AggregateEventModel.scala:10-22``) and ``JavaAggregateCommandModel``
-  (``.../javadsl/command/CommandModels.scala:17-40``, over ``Optional``): the other model flavours that compile to the same
-  core ``handle`` / ``applyAsync`` pair.
+* ``BatchedAggregateCommandModel`` (``AsyncAggregateCommandModel``, :33-57) and ``AggregateEventModel``
+  (``.../scaladsl/event/AggregateEventModel.scala:10-22``): the batched flavours that compile to the same core
+  ``handle`` / ``applyAsync`` pair.  The Java DSL twin (``javadsl/.../CommandModels.scala:17-40``) is the
+  same fold over ``java.util.Optional`` — DSL sugar (out of scope): not mirrored.
 * ``ReplayableCommandModel`` — ADDITIVE.  ``handleEvent`` is arbitrary code and cannot run on a
   GPU: a model that wants GPU replay also declares its event algebra and the
   fixed-width encodings of its events and state.  ``tests/test_host_models.py`` checks that the
@@ -107,78 +107,6 @@ class AggregateEventModel(Generic[Agg, Evt]):
 
             def apply_async(self, ctx: SurgeContext, state, events):
                 return ctx.update_state(model.handle_events(state, list(events))).reply(lambda s: s)
-
-        return _Core()
-
-
-class Optional_(Generic[Agg]):
-    """``java.util.Optional`` as the Java DSL sees aggregates (``javadsl/.../CommandModels.scala:19``): ``empty()`` /
-    ``of(x)``, never ``None`` inside."""
-
-    __slots__ = ("_v",)
-
-    def __init__(self, value=None):
-        self._v = value
-
-    @staticmethod
-    def empty() -> "Optional_":
-        return Optional_(None)
-
-    @staticmethod
-    def of(value) -> "Optional_":
-        if value is None:
-            raise ValueError("Optional.of(null)")
-        return Optional_(value)
-
-    @staticmethod
-    def of_nullable(value) -> "Optional_":
-        return Optional_(value)
-
-    def is_present(self) -> bool:
-        return self._v is not None
-
-    def get(self):
-        if self._v is None:
-            raise LookupError("No value present")
-        return self._v
-
-    def or_else(self, other):
-        return other if self._v is None else self._v
-
-    def __eq__(self, other):
-        return isinstance(other, Optional_) and self._v == other._v
-
-    def __repr__(self):
-        return "Optional.empty" if self._v is None else f"Optional[{self._v!r}]"
-
-
-class JavaAggregateCommandModel(Generic[Agg, Cmd, Evt]):
-    """``surge.javadsl.command.AggregateCommandModel`` — ``modules/command-engine/javadsl/src/main/scala/surge/javadsl/command/
-    CommandModels.scala:17-40``: the same contract over ``java.util.Optional``; ``toCore`` folds
-    ``events.foldLeft(state.asJava)(handleEvent)`` (:24-26) and converts back (``.asScala``)."""
-
-    def process_command(self, aggregate: Optional_, command: Cmd) -> Sequence[Evt]:
-        raise NotImplementedError
-
-    def handle_event(self, aggregate: Optional_, event: Evt) -> Optional_:
-        raise NotImplementedError
-
-    def to_core(self) -> SurgeProcessingModel:
-        model = self
-
-        def new_state_from_events(events, state):
-            s = Optional_.of_nullable(state)
-            for e in events:  # newStateFromEvents, :24-26
-                s = model.handle_event(s, e)
-            return s.or_else(None)
-
-        class _Core(SurgeProcessingModel):
-            def handle(self, ctx: SurgeContext, state, msg):
-                events = list(model.process_command(Optional_.of_nullable(state), msg))
-                return ctx.persist_events(events).update_state(new_state_from_events(events, state)).reply(lambda s: s)
-
-            def apply_async(self, ctx: SurgeContext, state, events):
-                return ctx.update_state(new_state_from_events(list(events), state)).reply(lambda s: s)
 
         return _Core()
 

@@ -227,9 +227,20 @@ int32_t comm_info(const CommState* c, int32_t* rank, int32_t* world, int32_t* ve
   return SURGE_OK;
 }
 
-// counts[r] = states rank r contributes (exchanged once per n_local; synchronous)
-static int32_t exchange_counts(CommState* c, int64_t n_local, std::string* err) {
-  if (c->counts_for == n_local) return SURGE_OK;
+// counts[r] = states rank r contributes.  The exchange is a COLLECTIVE (all-gather + host sync), so whether it runs must
+// never depend on one rank's local state alone: it runs when the host asks for it on every rank (surge_replay_comm_counts:
+// force) and, implicitly, in a rank's very first exchange (no counts yet — every rank of a fresh communicator is in that
+// state).  A rank whose shard size differs from the one the cached counts were exchanged for gets SURGE_E_STATE instead of
+// starting a collective its peers are not in (shards can change unevenly: surge_replay_grow, append_* after a grow) —
+// round-2 review: a skipped / unskipped all-gather on one side only is an operation mismatch, i.e. a hang.
+static int32_t exchange_counts(CommState* c, int64_t n_local, bool force, std::string* err) {
+  if (!force) {
+    if (c->counts_for == n_local) return SURGE_OK;
+    if (c->counts_for >= 0)
+      return comm_fail(err, SURGE_E_STATE,
+                       "this rank's shard size changed since the shard sizes were exchanged (" + std::to_string(c->counts_for) + " -> " +
+                           std::to_string(n_local) + "): call surge_replay_comm_counts on EVERY rank before the next exchange");
+  }
   int64_t mine = n_local;
   COMM_HIP(hipMemcpyAsync((char*)c->d_counts + (size_t)c->rank * 8, &mine, 8, hipMemcpyHostToDevice, c->side));
   if (c->world > 1)
@@ -246,11 +257,11 @@ static int32_t exchange_counts(CommState* c, int64_t n_local, std::string* err) 
   return SURGE_OK;
 }
 
-int32_t comm_counts(CommState* c, int64_t n_local, int64_t* counts_out, int64_t* max_count_out, std::string* err) {
+int32_t comm_counts(CommState* c, int64_t n_local, int64_t* counts_out, int64_t* max_count_out, bool force, std::string* err) {
   if (c->local) {  // an in-process group learns its shard sizes in surge_replay_allgather
     if (c->counts_for < 0) return comm_fail(err, SURGE_E_STATE, "in-process group: shard sizes are set by surge_replay_allgather");
   } else {
-    const int32_t rc = exchange_counts(c, n_local, err);
+    const int32_t rc = exchange_counts(c, n_local, force, err);
     if (rc != SURGE_OK) return rc;
   }
   if (counts_out) std::memcpy(counts_out, c->counts.data(), (size_t)c->world * 8);
@@ -265,7 +276,7 @@ int32_t comm_allgather(CommState* c, hipStream_t compute, const void* d_states, 
   if (slot < 0 || slot > 1) return comm_fail(err, SURGE_E_INVALID, "slot must be 0 or 1");
   if (n_local < 0 || (n_local > 0 && !d_states) || !d_out) return comm_fail(err, SURGE_E_INVALID, "bad argument");
   if (c->local) return comm_fail(err, SURGE_E_STATE, "rank of an in-process group: exchange with surge_replay_allgather");
-  int32_t rc = exchange_counts(c, n_local, err);
+  int32_t rc = exchange_counts(c, n_local, false, err);
   if (rc != SURGE_OK) return rc;
   if (out_rows_per_rank < c->max_count)
     return comm_fail(err, SURGE_E_RANGE, "d_out holds fewer rows per rank than the largest shard (see surge_replay_comm_counts)");

@@ -1478,7 +1478,7 @@ int32_t surge_replay_comm_counts(surge_replay_handle* h, int64_t n_local, int64_
   if (n_local < 0) return fail(h, SURGE_E_INVALID, "negative size");
   DeviceGuard g(h->device);
   std::string err;
-  const int32_t rc = comm_counts(h->comm, n_local, counts_out, max_count_out, &err);
+  const int32_t rc = comm_counts(h->comm, n_local, counts_out, max_count_out, true, &err);
   return rc == SURGE_OK ? rc : fail(h, rc, err);
 }
 
@@ -1498,7 +1498,7 @@ int32_t surge_replay_allgather_snapshot(surge_replay_handle* h, const void* d_st
   std::string err;
   if (!d_out) {  // the handle keeps the gathered snapshot (hosts without device pointers)
     int64_t mx = 0;
-    const int32_t rc0 = comm_counts(h->comm, n_local, nullptr, &mx, &err);
+    const int32_t rc0 = comm_counts(h->comm, n_local, nullptr, &mx, false, &err);
     if (rc0 != SURGE_OK) return fail(h, rc0, err);
     rows_per_rank = mx;
     HIPCHK(h, hipStreamSynchronize(h->stream));  // a reallocation must not pull the buffer from under an earlier exchange

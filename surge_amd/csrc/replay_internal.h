@@ -96,7 +96,8 @@ int32_t comm_unique_id(uint8_t* id_out, std::string* err);
 int32_t comm_create(int device, int rank, int world, const uint8_t* id, CommState** out, std::string* err);
 void comm_destroy(CommState* c);
 int32_t comm_info(const CommState* c, int32_t* rank, int32_t* world, int32_t* version, const char** library);
-int32_t comm_counts(CommState* c, int64_t n_local, int64_t* counts_out, int64_t* max_count_out, std::string* err);
+// force: run the (collective) exchange even when counts for this n_local are cached — the public, documented-collective call
+int32_t comm_counts(CommState* c, int64_t n_local, int64_t* counts_out, int64_t* max_count_out, bool force, std::string* err);
 int32_t comm_allgather(CommState* c, hipStream_t compute, const void* d_states, int64_t n_local, void* d_out,
                        int64_t out_rows_per_rank, int slot, int mode, bool packed, std::string* err);
 int32_t comm_wait(CommState* c, hipStream_t compute, int slot, bool host, std::string* err);

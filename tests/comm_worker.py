@@ -31,6 +31,10 @@ def shard(rank, world, n_global=5000):
     return so, ev
 
 
+def n2_of(rank, world):
+    return (shard(rank, world)[0].shape[0] - 1) // 2
+
+
 def main():
     rank, world, d, device = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
     mode = int(sys.argv[5]) if len(sys.argv) > 5 else 0
@@ -84,6 +88,26 @@ def main():
         for r in range(world):
             so_r, ev_r = shard(r, world)
             exp = oracle.fold_csr(so_r, ev_r).view(np.uint8).reshape(-1, 64)[: int(c2[r])]
+            assert got[r, : exp.shape[0]].tobytes() == exp.tobytes() and not got[r, exp.shape[0]:].any()
+        # shard sizes that change on ONE rank only (round-2 review): rank 0 shrinks its contribution and asks for an exchange
+        # without the collective size exchange -> it must be refused locally (SURGE_E_STATE), not start an all-gather the
+        # other ranks are not in; after every rank has called comm_counts the exchange runs with the new sizes
+        n3 = n2 - 7 if rank == 0 else n2
+        if rank == 0:
+            try:
+                eng.allgather_snapshot(None, n3, out, mx2, 0, mode)
+                raise SystemExit("an exchange with a locally changed shard size was accepted")
+            except ReplayError as e:
+                assert e.status == -2 and "surge_replay_comm_counts" in str(e), e
+        c3, mx3 = eng.comm_counts(n3)
+        assert int(c3[0]) == n2_of(0, world) - 7 and all(int(c3[r]) == n2_of(r, world) for r in range(1, world)), c3
+        out = torch.zeros((world, mx3, 64), dtype=torch.uint8, device=dev)
+        eng.allgather_snapshot(None, n3, out, mx3, 1, mode)
+        eng.comm_wait(1, host_sync=True)
+        got = out.cpu().numpy()
+        for r in range(world):
+            so_r, ev_r = shard(r, world)
+            exp = oracle.fold_csr(so_r, ev_r).view(np.uint8).reshape(-1, 64)[: int(c3[r])]
             assert got[r, : exp.shape[0]].tobytes() == exp.tobytes() and not got[r, exp.shape[0]:].any()
         eng.comm_destroy()
     print(f"OK {rank} rccl={info['rccl_version']} lib={info['library']}", flush=True)

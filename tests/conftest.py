@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the reference's fixture models (Counter, BankAccount, the SDK sample) restated as plugin code: example models, not product
+if os.path.join(ROOT, "examples") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
 
 
 def pytest_configure(config):

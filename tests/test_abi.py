@@ -156,40 +156,6 @@ def test_cpp_host_mirror_serves_get_aggregate_bytes_from_the_gpu_fold(tmp_path):
     assert "ALL PASS" in res.stdout and res.stdout.count("PASS  ") == 11 and "FAIL" not in res.stdout
 
 
-def _build_cpp_persistence_demo(tmp_path):
-    import subprocess
-
-    exe = str(tmp_path / "cpp_persistence_demo")
-    lib_dir = os.path.join(ROOT, "surge_amd")
-    cmd = ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "cpp_persistence_demo.cpp"),
-           "-L" + lib_dir, "-lsurge_replay", "-Wl,-rpath," + lib_dir, "-L/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe]
-    subprocess.run(cmd, check=True, capture_output=True)
-    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-    return subprocess.run([exe], capture_output=True, text=True, env=env)
-
-
-def test_cpp_persistence_mirror_compiles_and_keeps_the_retry_and_in_flight_protocol(tmp_path):
-    """include/surge_persistence.hpp (R3 / R5 / R10 / R11 for a compiled-language host) builds warning-free; the parts
-    that need no GPU — in-flight tracking, KTableInitializationSupport's retry schedule — reproduce the reference's
-    numbers; the store itself fails loudly without a GPU."""
-    import torch
-
-    _native.build()
-    res = _build_cpp_persistence_demo(tmp_path)
-    assert "FAIL" not in res.stdout and res.stdout.count("PASS  ") >= 6, res.stdout + res.stderr
-    if torch.cuda.is_available():
-        assert res.returncode == 0, res.stdout + res.stderr
-    else:
-        assert res.returncode == 2 and "no CPU fallback" in res.stdout and "CPU CHECKS PASS" in res.stdout
-
-
-@pytest.mark.gpu
-def test_cpp_persistence_mirror_replays_the_persistent_actor_spec_on_the_gpu_store(tmp_path):
-    res = _build_cpp_persistence_demo(tmp_path)
-    assert res.returncode == 0, res.stdout + res.stderr
-    assert "ALL PASS" in res.stdout and res.stdout.count("PASS  ") == 19 and "FAIL" not in res.stdout
-
-
 def _build_jni_harness(tmp_path):
     import subprocess
 

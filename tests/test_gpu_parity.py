@@ -11,7 +11,7 @@ from golden_util import NAMES, load_golden
 from oracle import oracle
 from surge_amd import schema as S
 from surge_amd import synth
-from surge_amd.fixtures import BANK_ACCOUNT_ALGEBRA, COUNTER_ALGEBRA
+from fixture_models import BANK_ACCOUNT_ALGEBRA, COUNTER_ALGEBRA
 from surge_amd.replay import ReplayEngine, ReplayError
 
 pytestmark = pytest.mark.gpu
@@ -513,7 +513,7 @@ def test_gpu_json_encoder_matches_play_json_text_of_the_counter_fixture():
     import torch
 
     from surge_amd.encode import JsonTemplate, encode_states, key_table_utf8
-    from surge_amd.fixtures import CounterAggregateFormat, State
+    from fixture_models import CounterAggregateFormat, State
 
     n = 5000
     rng = np.random.default_rng(11)
@@ -637,7 +637,7 @@ def test_sdk_sample_model_replays_and_encodes_to_its_stored_protobuf_form():
     import torch
 
     from surge_amd.encode import JP_I32, JsonTemplate, encode_states, key_table_utf8
-    from surge_amd.fixtures import SDK_SAMPLE_MODEL, MoneyDeposited, SdkBankAccount, SdkEvent, SdkSampleCommandModel, sdk_sample_state_bytes
+    from fixture_models import SDK_SAMPLE_MODEL, MoneyDeposited, SdkBankAccount, SdkEvent, SdkSampleCommandModel, sdk_sample_state_bytes
 
     rng = np.random.default_rng(77)
     model = SdkSampleCommandModel()

@@ -1,6 +1,6 @@
 """The host mirror of the plugin surface: literal ``handleEvent`` code vs the declared event algebra.
 
-``handle_event`` in surge_amd/fixtures.py is a case-by-case restatement of the Scala fixtures; the
+``handle_event`` in examples/fixture_models.py is a case-by-case restatement of the Scala fixtures; the
 ``event_algebra`` beside it is what the kernels replay.  Folding random event sequences through
 both (Python ``foldLeft`` vs the descriptor-driven oracle) ties the declaration to the code the
 reference's own specs exercise.
@@ -14,7 +14,7 @@ import pytest
 from oracle import oracle
 from surge_amd import schema as S
 from surge_amd.core import SurgeContext
-from surge_amd.fixtures import (
+from fixture_models import (
     BankAccount, BankAccountCommandModel, BankAccountCreated, BankAccountUpdated, CounterBusinessLogic,
     CounterCommandModel, CountDecremented, CountIncremented, CreateAccount, CreateNoOpEvent, CreditAccount,
     DebitAccount, DoNothing, ExceptionThrowingEvent, Increment, NoOpEvent, State,
@@ -191,12 +191,12 @@ def test_formats_round_trip_and_match_oracle_json_text():
 
 
 # ---- the other model flavours that compile to the same core (R4) -----------------------------------
-def test_event_only_batched_and_java_models_fold_like_the_scala_command_model():
+def test_event_only_and_batched_models_fold_like_the_scala_command_model():
     import random
 
-    from surge_amd.command import AggregateEventModel, BatchedAggregateCommandModel, JavaAggregateCommandModel, Optional_
+    from surge_amd.command import AggregateEventModel, BatchedAggregateCommandModel
     from surge_amd.core import SurgeContext
-    from surge_amd.fixtures import CounterCommandModel, CountDecremented, CountIncremented, Increment, NoOpEvent, State
+    from fixture_models import CounterCommandModel, CountDecremented, CountIncremented, Increment, NoOpEvent, State
 
     scala = CounterCommandModel()
 
@@ -213,13 +213,6 @@ def test_event_only_batched_and_java_models_fold_like_the_scala_command_model():
         def handle_events(self, agg, events):
             return EventOnly().handle_events(agg, events)
 
-    class Java(JavaAggregateCommandModel):  # javadsl CommandModels.scala:17-40, over Optional
-        def process_command(self, agg, cmd):
-            return scala.process_command(agg.or_else(None), cmd)
-
-        def handle_event(self, agg, evt):
-            return Optional_.of_nullable(scala.handle_event(agg.or_else(None), evt))
-
     rng = random.Random(3)
     for _ in range(50):
         events = []
@@ -227,12 +220,11 @@ def test_event_only_batched_and_java_models_fold_like_the_scala_command_model():
             events.append(rng.choice([CountIncremented("a", rng.randrange(9), seq), CountDecremented("a", rng.randrange(9), seq), NoOpEvent("a", seq)]))
         start = rng.choice([None, State("a", 3, 3)])
         want = scala.to_core().apply_async(SurgeContext(state=start), start, events).state
-        for model in (EventOnly(), Batched(), Java()):
+        for model in (EventOnly(), Batched()):
             assert model.to_core().apply_async(SurgeContext(state=start), start, events).state == want
-    # commands: the batched and the Java model persist the same events and reach the same state; the event-only model refuses
-    for model in (Batched(), Java()):
+    # commands: the batched model persists the same events and reaches the same state; the event-only model refuses
+    for model in (Batched(),):
         ctx = model.to_core().handle(SurgeContext(state=State("a", 3, 3)), State("a", 3, 3), Increment("a"))
         assert ctx.state == State("a", 4, 4) and [e for e, _ in ctx.events] == [CountIncremented("a", 1, 4)]
     with pytest.raises(NotImplementedError):
         EventOnly().to_core().handle(SurgeContext(), None, Increment("a"))
-    assert Optional_.empty() == Optional_.of_nullable(None) and Optional_.of(5).get() == 5 and not Optional_.empty().is_present()

@@ -10,7 +10,7 @@ import pytest
 
 from oracle import oracle
 from surge_amd import schema as S
-from surge_amd.fixtures import BANK_ACCOUNT_ALGEBRA, BA_CREATED, BA_UPDATED, COUNTER_ALGEBRA, CT_DEC, CT_INC, CT_NOOP, CT_THROW
+from fixture_models import BANK_ACCOUNT_ALGEBRA, BA_CREATED, BA_UPDATED, COUNTER_ALGEBRA, CT_DEC, CT_INC, CT_NOOP, CT_THROW
 
 
 def counter_state(count, version, present=True):

@@ -5,7 +5,7 @@ import json
 
 import pytest
 
-from surge_amd.fixtures import (
+from fixture_models import (
     CounterBusinessLogic, CountIncremented, CreateExceptionThrowingEvent, CreateNoOpEvent, Decrement, DoNothing,
     ExceptionThrowingEvent, FailCommandProcessing, Increment, State,
 )
@@ -310,7 +310,7 @@ def test_bank_account_command_sequence_state_of_record_on_the_gpu():
 
     from surge_amd.command import SurgeCommandBusinessLogic
     from surge_amd.core import KafkaTopic
-    from surge_amd.fixtures import (
+    from fixture_models import (
         AccountDoesNotExistException, BankAccount, BankAccountCommandModel, BankAccountFormat, CreateAccount, CreditAccount,
         DebitAccount, InsufficientFundsException,
     )
@@ -337,7 +337,7 @@ def test_bank_account_command_sequence_state_of_record_on_the_gpu():
     store = GpuReplayStateStore(bl)
     try:
         other = uuid.UUID(int=99)
-        from surge_amd.fixtures import BankAccountCreated
+        from fixture_models import BankAccountCreated
 
         store.restore([BankAccountCreated(other, "Someone Else", "0000", 5.0)])
         pub = StatePublisher(store)

@@ -4,7 +4,7 @@ import uuid
 
 import pytest
 
-from surge_amd.fixtures import (
+from fixture_models import (
     BankAccountCommandModel, BankAccountCreated, BankAccountUpdated, BankAccountFormat, CounterBusinessLogic,
     CountDecremented, CountIncremented, ExceptionThrowingEvent, NoOpEvent, State,
 )
