@@ -464,13 +464,21 @@ def main():
 
 
 def run_secondary_c2(args, S, synth, ReplayEngine, torch, dev, local_rank):
-    """BASELINE config C2 (1 M aggregates x 256 events, uniform fan-in) on the same GPU, with its own roofline."""
+    """BASELINE config C2 (1 M aggregates x 256 events, uniform fan-in) on the same GPU, with its own roofline: the
+    tile-major fold (with its one-off layout cost) and, beside it, the fold straight from the CSR log (ROWS)."""
+    import numpy as np
+
     so, ev = synth.fixed_log_device(C2_AGGREGATES, C2_EVENTS, C2_SEED, dev)
     out = torch.zeros((C2_AGGREGATES, 64), dtype=torch.uint8, device=dev)
     with ReplayEngine(device=local_rank) as e2:
         e2.load_csr(so, ev, None, out)
         steps = 150  # ~0.7 ms each: a > 100 ms timed region
-        dt, st, times_ms = time_folds(e2, torch, dev, 0, steps, 5)
+        e2.prepare(S.ALGO_TILED)
+        e2.synchronize()
+        layout = e2.layout_info()
+        dt, st, times_ms = time_folds(e2, torch, dev, S.ALGO_TILED, steps, 5)
+        tiled_states = out.clone()
+        dt_csr, st_csr, times_csr = time_folds(e2, torch, dev, S.ALGO_AUTO, steps, 5)
         return {
             "config": {"workload": f"C2: {C2_AGGREGATES} aggregates x {C2_EVENTS} events, 16 B events, 64 B state, single GPU, log resident in HBM",
                        "algo": algo_name(S, st.last_algo), "wave_tasks": st.n_tasks},
@@ -480,6 +488,11 @@ def run_secondary_c2(args, S, synth, ReplayEngine, torch, dev, local_rank):
             "steps": steps,
             "ms_per_step": dt / steps * 1e3,
             "roofline": roofline_of(S, st, times_ms),
+            "one_shot": {"index_build_ms": layout.index_build_ms, "relayout_ms": layout.relayout_ms, "tile_major_copy_bytes": layout.tiled_bytes},
+            "csr_direct": {"algo": algo_name(S, st_csr.last_algo), "kernel": kernel_name(S, st_csr.last_algo), "ms_per_step": dt_csr / steps * 1e3,
+                           "kernel_ms_min_median_max": [float(np.min(times_csr)), float(np.median(times_csr)), float(np.max(times_csr))],
+                           "frac": st_csr.algorithmic_bytes / (float(np.mean(times_csr)) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                           "states_equal_primary": bool(torch.equal(tiled_states, out))},
         }
 
 

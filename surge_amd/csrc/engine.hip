@@ -95,7 +95,7 @@ struct surge_replay_handle {
   ChunkIndex cidx;              // CHUNKED: rows tiled from their 128-byte lines in the CSR log
   ChunkIndex tidx;              // TILED: rows copied to tile boundaries
   DevBuf v_total, v_ctr;        // scratch of the chunk-table build
-  DevBuf t_tiles, t_gsub, t_gminlen;  // TILED: the tile-major copy of the log, per group first subtile / shortest row
+  DevBuf t_tiles, t_gsub;  // TILED: the tile-major copy of the log, first subtile of every group
   int64_t t_n_sub = 0;          // subtiles (8 KiB each) of the tile-major copy
   bool tiled_valid = false;
   // one-off costs of the bound log's index (device time between HIP events), reported by surge_replay_layout_info
@@ -494,7 +494,7 @@ int32_t surge_replay_destroy(surge_replay_handle* h) {
   h->pinned = nullptr;
   h->cidx.release();
   h->tidx.release();
-  DevBuf* bufs[] = {&h->gb_temp, &h->gb_u32, &h->gb_flags, &h->gb_agg_idx, &h->gb_events, &h->published, &h->gathered[0], &h->gathered[1], &h->v_ctr, &h->v_total, &h->t_tiles, &h->t_gsub, &h->t_gminlen, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
+  DevBuf* bufs[] = {&h->gb_temp, &h->gb_u32, &h->gb_flags, &h->gb_agg_idx, &h->gb_events, &h->published, &h->gathered[0], &h->gathered[1], &h->v_ctr, &h->v_total, &h->t_tiles, &h->t_gsub, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
                     &h->nz_map, &h->block_counts, &h->plan, &h->batch_group_agg, &h->batch_group_off,
                     &h->batch_events, &h->poison_count, &h->gather_idx, &h->gather_out, &h->scan_totals};
   for (DevBuf* b : bufs) b->release();
@@ -735,9 +735,7 @@ int32_t ensure_index(surge_replay_handle* h, const FoldPlan& pl) {
     if (rc != SURGE_OK) return rc;
     const int64_t n_groups = (h->tidx.n_vrows + kWave - 1) / kWave;
     HIPCHK(h, h->t_gsub.reserve((size_t)(n_groups + 1) * 8));
-    HIPCHK(h, h->t_gminlen.reserve((size_t)(n_groups > 0 ? n_groups : 1) * 4));
-    HIPCHK(h, launch_tile_index((const uint32_t*)h->tidx.v_len.ptr, h->tidx.n_vrows, (int64_t*)h->t_gsub.ptr, (uint32_t*)h->t_gminlen.ptr,
-                                h->stream));
+    HIPCHK(h, launch_tile_index((const uint32_t*)h->tidx.v_len.ptr, h->tidx.n_vrows, (int64_t*)h->t_gsub.ptr, h->stream));
     HIPCHK(h, launch_exclusive_scan_i64((int64_t*)h->t_gsub.ptr, n_groups, h->stream));
     int64_t n_sub = 0;
     HIPCHK(h, hipMemcpyAsync(&n_sub, (int64_t*)h->t_gsub.ptr + n_groups, 8, hipMemcpyDeviceToHost, h->stream));
@@ -938,7 +936,7 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       const int32_t rc = next_fold_events(h, &e0, &e1);
       if (rc != SURGE_OK) return rc;
       HIPCHK(h, hipEventRecord(e0, h->stream));  // the stitch kernel is timed with the fold: it is part of it
-      HIPCHK(h, launch_fold_tiled(p, (const uint4*)h->t_tiles.ptr, (const int64_t*)h->t_gsub.ptr, (const uint32_t*)h->t_gminlen.ptr,
+      HIPCHK(h, launch_fold_tiled(p, (const uint4*)h->t_tiles.ptr, (const int64_t*)h->t_gsub.ptr,
                                   (const uint32_t*)ci.v_len.ptr, (const uint32_t*)ci.v_info.ptr, (const int64_t*)ci.v_seg.ptr, ci.n_vrows,
                                   (uint32_t*)ci.v_side.ptr, n_waves, subs, h->stream));
       HIPCHK(h, launch_chunk_stitch(p, (const uint32_t*)ci.v_side.ptr, (const int64_t*)ci.r_slot0.ptr, (const uint32_t*)ci.r_c.ptr,

@@ -23,7 +23,7 @@ __device__ __forceinline__ void walk_events_track(Acc& a, Acc& P, uint32_t& unde
   uint4 tq0, tq1, tq2;
   uint2 tq3;
   {
-    const uint4* te = (const uint4*)(lds_tab + tyc[0]);
+    const uint4* te = table_entry(lds_tab, tyc[0]);
     tq0 = te[0]; tq1 = te[1]; tq2 = te[2]; tq3 = *(const uint2*)(te + 3);
   }
 #pragma unroll
@@ -31,7 +31,7 @@ __device__ __forceinline__ void walk_events_track(Acc& a, Acc& P, uint32_t& unde
     uint4 nq0 = tq0, nq1 = tq1, nq2 = tq2;
     uint2 nq3 = tq3;
     if (j + 1 < LE) {
-      const uint4* te = (const uint4*)(lds_tab + tyc[j + 1]);
+      const uint4* te = table_entry(lds_tab, tyc[j + 1]);
       nq0 = te[0]; nq1 = te[1]; nq2 = te[2]; nq3 = *(const uint2*)(te + 3);
     }
     // live (not ignored, not throwing) and not of class REQUIRE: from here on the state is Some or an absolute None

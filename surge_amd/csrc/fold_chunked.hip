@@ -262,13 +262,13 @@ fold_chunked_kernel(const FoldParams p, const ChunkTable t) {
       uint32_t tyc[LE];
       if (c > 0 && (uint32_t)(c + 1) * LE <= minlen) {
 #pragma unroll
-        for (int j = 0; j < LE; ++j) tyc[j] = (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride;
+        for (int j = 0; j < LE; ++j) tyc[j] = type_off(ev[j].x);
       } else {
         const int32_t rem = (int32_t)cur.len - c * LE;   // my remaining events (may be <= 0)
         const int32_t skip = c == 0 ? (int32_t)pad : 0;  // events in front of my aggregate (its first chunk only)
 #pragma unroll
         for (int j = 0; j < LE; ++j)
-          tyc[j] = (j >= skip && j < rem) ? (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride : (uint32_t)kNullEntryOff;
+          tyc[j] = (j >= skip && j < rem) ? type_off(ev[j].x) : kNullEntryOffBytes;
       }
       if constexpr (decltype(tracking)::value) {
         walk_events_track<LE>(a, P, undecM, frozenM, corr, ev, tyc, lds_tab, p);

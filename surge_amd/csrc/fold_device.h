@@ -116,6 +116,57 @@ __device__ __forceinline__ void apply_event(Acc& a, uint32_t& frozenM, uint32_t&
   a.mn = (int32_t)mn; a.mx = (int32_t)mx; a.n = n; a.fl = fl;
 }
 
+// The same case of handleEvent for a lane whose running state is CONCRETE (it walks an aggregate from its known prior
+// state: the row kernels' whole aggregates): presence and "an event threw" live in two mask registers and none of the
+// transformer's absolute / relative bookkeeping (the SM_* bits) is kept — 7 VALU instructions fewer per event.  It did
+// not pay over the CSR log (round 2: the row-piece transport was the bound); over the tile-major log the walk's VALU
+// time is what stands between the kernel and the transport ceiling.
+__device__ __forceinline__ void apply_event_concrete(Acc& a, uint32_t& presentM, uint32_t& frozenM, uint32_t& corr, const uint4 q0,
+                                                     const uint4 q1, const uint4 q2, const uint2 q3, uint32_t seq, uint32_t raw_lo,
+                                                     uint32_t raw_hi, const FoldParams& p) {
+  const uint32_t goM = ~(frozenM | q2.x);
+  frozenM |= q2.x;                                                      // a throwing event freezes the aggregate
+  const uint32_t delM = goM & q2.y;
+  const uint32_t appM = andn(goM, q2.y) & (presentM | q2.z);            // REQUIRE-class events skip None
+  const uint32_t rstM = appM & (q2.w | ~presentM);                      // CREATE, or materialising from None
+  presentM = andn(presentM, delM) | rstM;
+
+  uint32_t count = bfi(rstM, (uint32_t)p.d_count, (uint32_t)a.count);
+  uint32_t version = bfi(rstM, (uint32_t)p.d_version, (uint32_t)a.version);
+  uint32_t sum_lo = bfi(rstM, (uint32_t)p.d_sum, (uint32_t)a.sum);
+  uint32_t sum_hi = bfi(rstM, (uint32_t)((uint64_t)p.d_sum >> 32), (uint32_t)((uint64_t)a.sum >> 32));
+  uint32_t bal_lo = bfi(rstM, (uint32_t)p.d_balance, (uint32_t)a.bal);
+  uint32_t bal_hi = bfi(rstM, (uint32_t)(p.d_balance >> 32), (uint32_t)(a.bal >> 32));
+  uint32_t mn = bfi(rstM, (uint32_t)p.d_min, (uint32_t)a.mn);
+  uint32_t mx = bfi(rstM, (uint32_t)p.d_max, (uint32_t)a.mx);
+  uint32_t n = bfi(rstM, p.d_evcount, a.n);
+  corr = andn(corr, rstM);
+
+  const uint32_t arg = raw_lo;
+  count += ((arg ^ q0.y) - q0.y) & (q0.x & appM);
+  count = bfi(q0.z & appM, arg, count);
+  version = bfi(q0.w & appM, seq, version);
+  {
+    const uint32_t m = q1.x & appM;
+    const uint32_t x = (arg ^ q1.y) & m;
+    const uint64_t sum = (((uint64_t)sum_hi << 32) | sum_lo) + (uint64_t)(int64_t)(int32_t)x;
+    sum_lo = (uint32_t)sum;
+    sum_hi = (uint32_t)(sum >> 32);
+    corr -= q1.y & m;
+  }
+  const uint32_t mbalM = q1.z & appM;
+  bal_lo = bfi(mbalM, raw_lo, bal_lo);
+  bal_hi = bfi(mbalM, raw_hi, bal_hi);
+  mn = (uint32_t)min((int32_t)mn, (int32_t)bfi(q3.x & appM, arg, 0x7fffffffu));
+  mx = (uint32_t)max((int32_t)mx, (int32_t)bfi(q3.y & appM, arg, 0x80000000u));
+  n += q1.w & appM;
+
+  a.count = (int32_t)count; a.version = (int32_t)version;
+  a.sum = (int64_t)(((uint64_t)sum_hi << 32) | sum_lo);
+  a.bal = ((uint64_t)bal_hi << 32) | bal_lo;
+  a.mn = (int32_t)mn; a.mx = (int32_t)mx; a.n = n;
+}
+
 // g after f.  Absolute fields of g win, relative ones combine with f's.  A poisoned f is only ever
 // followed (inside its segment) by lanes that ignored their events, i.e. by identity transformers,
 // so the fields need no special case; the presence bit then has to come from f.
@@ -229,6 +280,19 @@ struct Geo {
   }
 };
 
+// Op-table entries are addressed by BYTE offset into the LDS copy of the table (tyc[] below): an event's entry is
+// min(type, 16) * 80 bytes in — one v_min + one v_mul per event, no shift in front of the ds_read; the tile-major re-layout
+// stores that offset in place of the type word, so its fold spends nothing on it.
+constexpr uint32_t kTableStrideBytes = kTableStride * 4u;
+constexpr uint32_t kNullEntryOffBytes = kNullEntryOff * 4u;
+__device__ __forceinline__ uint32_t type_off(uint32_t ty) { return (ty < 16u ? ty : 16u) * kTableStrideBytes; }
+__device__ __forceinline__ const uint4* table_entry(const uint32_t* lds_tab, uint32_t off) {
+  return (const uint4*)((const char*)lds_tab + off);
+}
+__device__ __forceinline__ uint32_t table_word(const uint32_t* lds_tab, uint32_t off, int word) {
+  return *(const uint32_t*)((const char*)lds_tab + off + word * 4);
+}
+
 template <int LE>
 __device__ __forceinline__ void load_table(const FoldParams& p, uint32_t* lds_tab, int lane) {
   const uint32_t* src = &p.table[0][0];
@@ -271,7 +335,7 @@ __device__ __forceinline__ void walk_events(Acc& a, uint32_t& frozenM, uint32_t&
   uint4 tq0, tq1, tq2;
   uint2 tq3;
   {
-    const uint4* te = (const uint4*)(lds_tab + tyc[0]);
+    const uint4* te = table_entry(lds_tab, tyc[0]);
     tq0 = te[0]; tq1 = te[1]; tq2 = te[2]; tq3 = *(const uint2*)(te + 3);
   }
 #pragma unroll
@@ -280,7 +344,7 @@ __device__ __forceinline__ void walk_events(Acc& a, uint32_t& frozenM, uint32_t&
     uint2 nq3 = tq3;
 #if !defined(SURGE_DBG_FIXED_TABLE)
     if (j + 1 < LE) {
-      const uint4* te = (const uint4*)(lds_tab + tyc[j + 1]);
+      const uint4* te = table_entry(lds_tab, tyc[j + 1]);
       nq0 = te[0]; nq1 = te[1]; nq2 = te[2]; nq3 = *(const uint2*)(te + 3);
     }
 #endif
@@ -295,6 +359,30 @@ __device__ __forceinline__ void walk_events(Acc& a, uint32_t& frozenM, uint32_t&
   }
 }
 
+
+// The concrete-state walk (apply_event_concrete); a.fl is rebuilt from the two masks when the walk ends.
+template <int LE>
+__device__ __forceinline__ void walk_events_concrete(Acc& a, uint32_t& presentM, uint32_t& frozenM, uint32_t& corr, const uint4* ev,
+                                                     const uint32_t* tyc, const uint32_t* lds_tab, const FoldParams& p) {
+  uint4 tq0, tq1, tq2;
+  uint2 tq3;
+  {
+    const uint4* te = table_entry(lds_tab, tyc[0]);
+    tq0 = te[0]; tq1 = te[1]; tq2 = te[2]; tq3 = *(const uint2*)(te + 3);
+  }
+#pragma unroll
+  for (int j = 0; j < LE; ++j) {
+    uint4 nq0 = tq0, nq1 = tq1, nq2 = tq2;
+    uint2 nq3 = tq3;
+    if (j + 1 < LE) {
+      const uint4* te = table_entry(lds_tab, tyc[j + 1]);
+      nq0 = te[0]; nq1 = te[1]; nq2 = te[2]; nq3 = *(const uint2*)(te + 3);
+    }
+    apply_event_concrete(a, presentM, frozenM, corr, tq0, tq1, tq2, tq3, ev[j].y, ev[j].z, ev[j].w, p);
+    tq0 = nq0; tq1 = nq1; tq2 = nq2; tq3 = nq3;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 
 }  // namespace
 // Persistent kernels pull groups of 64 rows from an atomic ticket counter.  Every wave draws until its first ticket

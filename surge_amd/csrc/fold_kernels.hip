@@ -147,13 +147,13 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
     uint32_t tyc[LE];
     if (te0 + G::kTile <= E1 && (tile > 0 || lead == 0)) {
 #pragma unroll
-      for (int j = 0; j < LE; ++j) tyc[j] = (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride;
+      for (int j = 0; j < LE; ++j) tyc[j] = type_off(ev[j].x);
     } else {
       const int64_t rem = E1 - (te0 + (int64_t)lane * LE);
       const int skip = tile == 0 ? lead - lane * LE : 0;  // the lead events of the first tile sit in lane 0 (lead < 8 <= LE)
 #pragma unroll
       for (int j = 0; j < LE; ++j)
-        tyc[j] = (j >= skip && (int64_t)j < rem) ? (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride : (uint32_t)kNullEntryOff;
+        tyc[j] = (j >= skip && (int64_t)j < rem) ? type_off(ev[j].x) : kNullEntryOffBytes;
     }
 
     // ---- pass A: presence / poison only, bit-parallel ---------------------------------------------
@@ -165,8 +165,8 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
       uint32_t PD = 0u, Mb = 0u;
 #pragma unroll
       for (int j = 0; j < LE; ++j) {
-        PD |= lds_tab[tyc[j] + TW_FLAGS] << j;                 // bit j: throws ; bit 16+j: deletes
-        Mb |= lds_tab[tyc[j] + TW_MATERIALIZES] & (1u << j);
+        PD |= table_word(lds_tab, tyc[j], TW_FLAGS) << j;                 // bit j: throws ; bit 16+j: deletes
+        Mb |= table_word(lds_tab, tyc[j], TW_MATERIALIZES) & (1u << j);
       }
       has_head = hb != 0u;
       const uint32_t lo = has_head ? (31u - (uint32_t)__clz((int)hb)) : 0u;
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(kWave) fold_rows_kernel(const FoldParams p) {
 
     uint32_t tyc[LE];
 #pragma unroll
-    for (int j = 0; j < LE; ++j) tyc[j] = (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride;
+    for (int j = 0; j < LE; ++j) tyc[j] = type_off(ev[j].x);
     walk_events<LE, false>(a, frozenM, corr, ev, tyc, 0u, lds_tab, p, [](int) {});
     if (++c == chunks) {
       c = 0;
@@ -466,13 +466,13 @@ __global__ void __launch_bounds__(kWave) fold_sorted_kernel(const FoldParams p) 
       uint32_t tyc[LE];
       if (c > 0 && (uint32_t)(c + 1) * LE <= minlen) {
 #pragma unroll
-        for (int j = 0; j < LE; ++j) tyc[j] = (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride;
+        for (int j = 0; j < LE; ++j) tyc[j] = type_off(ev[j].x);
       } else {
         const int32_t rem = (int32_t)cur.len - c * LE;         // my remaining events (may be <= 0)
         const int32_t skip = c == 0 ? (int32_t)cur.pad : 0;   // events in front of my segment
 #pragma unroll
         for (int j = 0; j < LE; ++j)
-          tyc[j] = (j >= skip && j < rem) ? (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride : (uint32_t)kNullEntryOff;
+          tyc[j] = (j >= skip && j < rem) ? type_off(ev[j].x) : kNullEntryOffBytes;
       }
       walk_events<LE, false>(a, frozenM, corr, ev, tyc, 0u, lds_tab, p, [](int) {});
     }

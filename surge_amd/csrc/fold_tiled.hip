@@ -37,27 +37,19 @@ namespace {
 
 constexpr int kSubEvents = 8;                       // events per lane in one subtile
 constexpr int kSubBytes = kWave * kSubEvents * 16;  // 8 KiB
-constexpr uint32_t kPadType = 0xffffffffu;
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
-// one wave per group: subtiles of the group (from its longest row) and its shortest non-empty row
+// one wave per group: subtiles of the group (from its longest row)
 __global__ void __launch_bounds__(256) tile_index_kernel(const uint32_t* __restrict__ v_len, int64_t n_vrows, int64_t n_groups,
-                                                         int64_t* __restrict__ g_sub, uint32_t* __restrict__ g_minlen) {
+                                                         int64_t* __restrict__ g_sub) {
   const int lane = threadIdx.x & 63;
   const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (g >= n_groups) return;
   const int64_t row = g * kWave + lane;
-  const uint32_t len = row < n_vrows ? v_len[row] : 0u;
-  uint32_t mx = len, mn = len ? len : 0xffffffffu;
+  uint32_t mx = row < n_vrows ? v_len[row] : 0u;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
-    mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64));
-  }
-  if (lane == 0) {
-    g_sub[g] = (int64_t)((mx + kSubEvents - 1) / kSubEvents);
-    g_minlen[g] = mn;
-  }
+  for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+  if (lane == 0) g_sub[g] = (int64_t)((mx + kSubEvents - 1) / kSubEvents);
 }
 
 // The re-layout: one 256-thread block per subtile, two 16-byte slots per thread.  Output slot `pos` of a subtile
@@ -82,10 +74,13 @@ __global__ void __launch_bounds__(256) relayout_kernel(const uint4* __restrict__
       const int l = pos >> 3;
       const uint32_t j = (uint32_t)(pos & 7) ^ Geo<8>::key(l);
       const int64_t row = g * kWave + l;
-      v4u v = {kPadType, 0u, 0u, 0u};
+      v4u v = {kNullEntryOffBytes, 0u, 0u, 0u};  // PAD: the null entry of the op table (identity on every state)
       if (row < n_vrows) {
         const uint32_t len = v_len[row];
-        if (e0 + j < len) v = __builtin_nontemporal_load((const v4u*)(events + v_start[row] + e0 + j));
+        if (e0 + j < len) {
+          v = __builtin_nontemporal_load((const v4u*)(events + v_start[row] + e0 + j));
+          v.x = type_off(v.x);  // the type word becomes the byte offset of its op-table entry (unknown types: the poison entry)
+        }
       }
       __builtin_nontemporal_store(v, (v4u*)(tiles + sub * (kSubBytes / 16) + pos));
     }
@@ -95,7 +90,6 @@ __global__ void __launch_bounds__(256) relayout_kernel(const uint4* __restrict__
 struct TileTable {
   const uint4* tiles;        // the tile-major log
   const int64_t* g_sub0;     // n_groups + 1: first subtile of every group
-  const uint32_t* g_minlen;  // shortest non-empty row of every group
   const uint32_t* v_len;     // per virtual row: events
   const uint32_t* v_info;    // VI_*
   const int64_t* v_dest;     // aggregate index (state array) or side-buffer slot
@@ -103,10 +97,10 @@ struct TileTable {
   uint32_t* side;
 };
 
-// SUBS subtiles per step: 1 = 8 events per lane per step (8 KiB in flight per wave, 122 VGPRs: up to 4 waves per SIMD),
-// 2 = 16 events (16 KiB, 154 VGPRs: up to 3 waves per SIMD, 9 per CU by LDS).
+// SUBS subtiles per step: 1 = 8 events per lane per step (8 KiB in flight per wave, up to 4 waves per SIMD), 2 = 16 events
+// (16 KiB, up to 3 waves per SIMD).
 template <int SUBS>
-__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SUBS == 1 ? 4 : 2)))
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SUBS == 1 ? 3 : 2)))
 fold_tiled_kernel(const FoldParams p, const TileTable t) {
   constexpr int LE = kSubEvents * SUBS;
   constexpr int kLoads = SUBS * (kSubBytes / 1024);
@@ -131,24 +125,19 @@ fold_tiled_kernel(const FoldParams p, const TileTable t) {
     }
     return m;
   };
-  struct Shape { int64_t sub0; int n_sub; uint32_t minlen; };  // wave-uniform
+  struct Shape { int64_t sub0; int n_sub; };  // wave-uniform
   auto load_shape = [&](int64_t g) -> Shape {  // every lane reads the same words; made scalar for the buffer descriptor
-    Shape s; s.sub0 = 0; s.n_sub = 0; s.minlen = 0u;
+    Shape s; s.sub0 = 0; s.n_sub = 0;
     if (g < n_groups) {
       const int64_t a = t.g_sub0[g], b = t.g_sub0[g + 1];
-      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)a >> 32));
-      s.sub0 = (int64_t)(((uint64_t)hi << 32) | lo);
+      s.sub0 = uniform64(a);
       s.n_sub = (int)__builtin_amdgcn_readfirstlane((uint32_t)(b - a));
-      s.minlen = __builtin_amdgcn_readfirstlane(t.g_minlen[g]);
     }
     return s;
   };
   // Step c of a group = its subtiles [SUBS c, SUBS c + SUBS): one linear run, fetched with buffer_load_dwordx4 ... lds
-  // (descriptor base = the step's first byte, lane offset 16 l, instruction q at scalar offset 1024 q).  MUBUF, not
-  // global_load_lds, on purpose: hipcc treats global_load_lds as a FLAT access that may touch LDS, and while one is
-  // outstanding (the next step's fetch is, during the whole walk) it forces EVERY s_waitcnt on LDS reads to
-  // lgkmcnt(0) — the one-event-ahead prefetch of op-table entries then waits for the entry it has just requested, an
-  // exposed LDS round trip per event.  With buffer loads the waits come out as the exact counts.
+  // (descriptor base = the step's first byte, lane offset 16 l, instruction q at scalar offset 1024 q; MUBUF rather than
+  // global_load_lds for the exact lgkm waits it leaves in the walk: see issue_tile_loads in fold_device.h).
   const int voff = lane * 16;
   auto issue = [&](const Shape& s, int c) {
     const char* base = (const char*)t.tiles + (s.sub0 + (int64_t)c * SUBS) * kSubBytes;  // wave-uniform
@@ -168,62 +157,91 @@ fold_tiled_kernel(const FoldParams p, const TileTable t) {
     const Meta nxt = load_meta(g_next);  // in flight while this group is walked
     const Shape sh_next = load_shape(g_next);
     const int n_steps = (sh.n_sub + SUBS - 1) / SUBS;
-    const uint32_t minlen = sh.minlen;
+    const bool odd_tail = SUBS == 2 && (sh.n_sub & 1);  // the last step holds one subtile: its second half is stale
 
     const bool whole = (cur.info & VI_RELATIVE) == 0u;
     // an aggregate in one piece starts from its known state, a chunk from "whatever comes in" (relative)
     Acc a = whole ? ((p.init && cur.dest >= 0) ? load_state(p.init, cur.dest) : acc_none()) : acc_identity();
-    Acc P = acc_identity();
-    uint32_t undecM = whole ? 0u : ~0u;
     uint32_t frozenM = whole ? (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 1, 1) : 0u;
     uint32_t corr = 0u;
-    bool watching = __builtin_amdgcn_ballot_w64(!whole) != 0ull;
-    auto step = [&](int c, auto tracking) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      uint4 ev[LE];
-#pragma unroll
-      for (int j = 0; j < LE; ++j)
-        ev[j] = *(const uint4*)(lds_ev + (j >> 3) * kSubBytes + (ev_row ^ (uint32_t)((j & 7) * 16)));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const bool any_relative = __builtin_amdgcn_ballot_w64(!whole) != 0ull;  // wave-uniform
+
+    // one step: wait for it, pull my N events out of LDS, start the next fetch, walk.  The type word of an event in the
+    // tile-major log IS the byte offset of its op-table entry (PAD slots: the null entry), so there is no decode and no
+    // tail masking here.
+    auto fetch_next = [&](int c) {
       if (c + 1 < n_steps) {
         issue(sh, c + 1);
       } else if (g_next < n_groups) {
         issue(sh_next, 0);  // the next group's first step is fetched while this group's last one is walked
       }
-
-      uint32_t tyc[LE];
-      if ((uint32_t)(c + 1) * LE <= minlen) {
-#pragma unroll
-        for (int j = 0; j < LE; ++j) tyc[j] = (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride;
-      } else {
-        const int32_t rem = (int32_t)cur.len - c * LE;  // my remaining events (may be <= 0): the rest is padding
-#pragma unroll
-        for (int j = 0; j < LE; ++j) tyc[j] = j < rem ? (ev[j].x < 16u ? ev[j].x : 16u) * kTableStride : (uint32_t)kNullEntryOff;
-      }
-      if constexpr (decltype(tracking)::value) {
-        walk_events_track<LE>(a, P, undecM, frozenM, corr, ev, tyc, lds_tab, p);
-        watching = __builtin_amdgcn_ballot_w64(undecM != 0u && frozenM == 0u) != 0ull;
-      } else {
-        walk_events<LE, false>(a, frozenM, corr, ev, tyc, 0u, lds_tab, p, [](int) {});
-      }
     };
-    int c = 0;
-    for (; c < n_steps && watching; ++c) step(c, std::true_type{});
-    for (; c < n_steps; ++c) step(c, std::false_type{});
-    a.sum = (int64_t)((uint64_t)a.sum + corr);
+    auto read_events = [&](uint4* ev, auto n_tag) {
+      constexpr int N = decltype(n_tag)::value;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < N; ++j) ev[j] = *(const uint4*)(lds_ev + (j >> 3) * kSubBytes + (ev_row ^ (uint32_t)((j & 7) * 16)));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
 
-    if (cur.dest >= 0) {
-      if (cur.info & VI_SIDE) {
-        const bool empty = cur.len == 0u;
-        const bool undecided = undecM != 0u || empty;
-        const Acc Pw = empty ? acc_identity() : select_acc(undecided, a, P);
-        Acc Sw = select_acc(undecided, acc_identity(), a);
-        if (!undecided) Sw.fl |= SIDE_DECIDED;
-        store_side(t.side, cur.dest, Pw, Sw);
-      } else {
-        // (tried in round 3: transposing the wave's 64 states through LDS so that each 64-byte state leaves as one
-        // contiguous access, and writing them in group order — same handle, alternating folds: +-0.1 % and -0.5 %)
-        store_state(p.out, cur.dest, a);
+    if (!any_relative) {
+      // every lane walks a whole aggregate from its known state: the concrete walk (no transformer bookkeeping)
+      uint32_t presentM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 0, 1);
+      auto step = [&](int c, auto n_tag) {
+        constexpr int N = decltype(n_tag)::value;
+        uint4 ev[N];
+        read_events(ev, n_tag);
+        fetch_next(c);
+        uint32_t tyc[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) tyc[j] = ev[j].x;
+        walk_events_concrete<N>(a, presentM, frozenM, corr, ev, tyc, lds_tab, p);
+      };
+      const int full = odd_tail ? n_steps - 1 : n_steps;
+      for (int c = 0; c < full; ++c) step(c, std::integral_constant<int, LE>{});
+      if (odd_tail) step(n_steps - 1, std::integral_constant<int, kSubEvents>{});
+      a.sum = (int64_t)((uint64_t)a.sum + corr);
+      a.fl = (presentM & FL_PRESENT) | (frozenM & FL_POISONED);
+      if (cur.dest >= 0) store_state(p.out, cur.dest, a);
+    } else {
+      Acc P = acc_identity();
+      uint32_t undecM = whole ? 0u : ~0u;
+      bool watching = true;
+      auto step = [&](int c, auto n_tag, auto tracking) {
+        constexpr int N = decltype(n_tag)::value;
+        uint4 ev[N];
+        read_events(ev, n_tag);
+        fetch_next(c);
+        uint32_t tyc[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) tyc[j] = ev[j].x;
+        if constexpr (decltype(tracking)::value) {
+          walk_events_track<N>(a, P, undecM, frozenM, corr, ev, tyc, lds_tab, p);
+          watching = __builtin_amdgcn_ballot_w64(undecM != 0u && frozenM == 0u) != 0ull;
+        } else {
+          walk_events<N, false>(a, frozenM, corr, ev, tyc, 0u, lds_tab, p, [](int) {});
+        }
+      };
+      // Two loops, not one loop with a branch (fold_chunked.hip): the watching loop — usually the first step only —
+      // carries P and the deciding-event test; the plain loop is the transformer walk without it.
+      const int full = odd_tail ? n_steps - 1 : n_steps;
+      int c = 0;
+      for (; c < full && watching; ++c) step(c, std::integral_constant<int, LE>{}, std::true_type{});
+      for (; c < full; ++c) step(c, std::integral_constant<int, LE>{}, std::false_type{});
+      if (odd_tail) step(n_steps - 1, std::integral_constant<int, kSubEvents>{}, std::true_type{});
+      a.sum = (int64_t)((uint64_t)a.sum + corr);
+
+      if (cur.dest >= 0) {
+        if (cur.info & VI_SIDE) {
+          const bool empty = cur.len == 0u;
+          const bool undecided = undecM != 0u || empty;
+          const Acc Pw = empty ? acc_identity() : select_acc(undecided, a, P);
+          Acc Sw = select_acc(undecided, acc_identity(), a);
+          if (!undecided) Sw.fl |= SIDE_DECIDED;
+          store_side(t.side, cur.dest, Pw, Sw);
+        } else {
+          store_state(p.out, cur.dest, a);
+        }
       }
     }
 
@@ -236,11 +254,11 @@ fold_tiled_kernel(const FoldParams p, const TileTable t) {
 
 }  // namespace
 
-// g_sub[g] := subtiles of group g (n_groups entries; the caller scans them into offsets), g_minlen[g]
-hipError_t launch_tile_index(const uint32_t* v_len, int64_t n_vrows, int64_t* g_sub, uint32_t* g_minlen, hipStream_t stream) {
+// g_sub[g] := subtiles of group g (n_groups entries; the caller scans them into offsets)
+hipError_t launch_tile_index(const uint32_t* v_len, int64_t n_vrows, int64_t* g_sub, hipStream_t stream) {
   const int64_t n_groups = (n_vrows + kWave - 1) / kWave;
   if (n_groups <= 0) return hipSuccess;
-  hipLaunchKernelGGL(tile_index_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, stream, v_len, n_vrows, n_groups, g_sub, g_minlen);
+  hipLaunchKernelGGL(tile_index_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, stream, v_len, n_vrows, n_groups, g_sub);
   return hipGetLastError();
 }
 
@@ -254,12 +272,12 @@ hipError_t launch_relayout(const uint4* events, const int64_t* v_start, const ui
   return hipGetLastError();
 }
 
-hipError_t launch_fold_tiled(const FoldParams& p, const uint4* tiles, const int64_t* g_sub0, const uint32_t* g_minlen, const uint32_t* v_len,
+hipError_t launch_fold_tiled(const FoldParams& p, const uint4* tiles, const int64_t* g_sub0, const uint32_t* v_len,
                              const uint32_t* v_info, const int64_t* v_dest, int64_t n_vrows, uint32_t* side, int64_t n_waves, int subs,
                              hipStream_t stream) {
   if (n_waves <= 0 || n_vrows <= 0) return hipSuccess;
   TileTable t;
-  t.tiles = tiles; t.g_sub0 = g_sub0; t.g_minlen = g_minlen; t.v_len = v_len; t.v_info = v_info; t.v_dest = v_dest;
+  t.tiles = tiles; t.g_sub0 = g_sub0; t.v_len = v_len; t.v_info = v_info; t.v_dest = v_dest;
   t.n_vrows = n_vrows; t.side = side;
   if (subs == 1)
     hipLaunchKernelGGL((fold_tiled_kernel<1>), dim3((unsigned)n_waves), dim3(kWave), 0, stream, p, t);

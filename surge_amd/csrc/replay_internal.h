@@ -45,10 +45,10 @@ hipError_t launch_chunk_stitch(const FoldParams& p, const uint32_t* side, const 
 // TILED (fold_tiled.hip): the chunk table's virtual rows copied once into group-major / tile-major order, then the fold
 // over that copy.  g_sub: n_groups + 1 int64 (subtiles per group, scanned in place into offsets by the caller).
 constexpr int kTileSubBytes = 8192;
-hipError_t launch_tile_index(const uint32_t* v_len, int64_t n_vrows, int64_t* g_sub, uint32_t* g_minlen, hipStream_t stream);
+hipError_t launch_tile_index(const uint32_t* v_len, int64_t n_vrows, int64_t* g_sub, hipStream_t stream);
 hipError_t launch_relayout(const uint4* events, const int64_t* v_start, const uint32_t* v_len, int64_t n_vrows, const int64_t* g_sub0,
                            int64_t n_sub_total, uint4* tiles, hipStream_t stream);
-hipError_t launch_fold_tiled(const FoldParams& p, const uint4* tiles, const int64_t* g_sub0, const uint32_t* g_minlen, const uint32_t* v_len,
+hipError_t launch_fold_tiled(const FoldParams& p, const uint4* tiles, const int64_t* g_sub0, const uint32_t* v_len,
                              const uint32_t* v_info, const int64_t* v_dest, int64_t n_vrows, uint32_t* side, int64_t n_waves, int subs,
                              hipStream_t stream);
 hipError_t launch_exclusive_scan_i64(int64_t* v, int64_t n, hipStream_t stream);
