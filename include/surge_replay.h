@@ -281,6 +281,8 @@ const char* surge_replay_last_error(const surge_replay_handle* h);
 
 /* Launch all work of this handle on the given hipStream_t (NULL = default stream). */
 int32_t surge_replay_set_stream(surge_replay_handle* h, void* hip_stream);
+/* Waits for the handle's stream; also where a skipped device micro-batch (see surge_replay_append_events_device) is
+ * reported. */
 int32_t surge_replay_synchronize(surge_replay_handle* h);
 
 /* ---- load -------------------------------------------------------------------
@@ -325,7 +327,12 @@ int32_t surge_replay_append_fold(surge_replay_handle* h, const int64_t* group_ag
  * library groups them by aggregate ON THE DEVICE (stable radix sort of (index, position), head scan, gather;
  * order inside an aggregate is kept), then runs the same micro-batch fold.  This is the shape a consumer of
  * the events topic has after interning record keys "<aggregateId>:<seq>" (TestBoundedContext.scala:122-124).
- * Host buffers are staged through pinned memory; the _device variant takes device pointers. */
+ * Host buffers are staged through two pinned areas used in turn (the host fills one while the other is still being
+ * copied) and their indices are range-checked before anything is enqueued (SURGE_E_RANGE, batch not applied).
+ * The _device variant takes device pointers and NEVER waits for the device (v1 handles): group-by, plan and fold are
+ * enqueued back to back — the plan reads the group count where the group-by left it.  A device batch with an index out of
+ * range is skipped as a whole on the device (it folds nothing) and the skip is reported, once, as SURGE_E_RANGE by the
+ * next surge_replay_synchronize. */
 int32_t surge_replay_append_events(surge_replay_handle* h, const int64_t* agg_idx, const void* events,
                                    int64_t n_events);
 int32_t surge_replay_append_events_device(surge_replay_handle* h, const int64_t* d_agg_idx, const void* d_events,

@@ -116,8 +116,15 @@ struct surge_replay_handle {
 
   // append_events: device group-by scratch (stream_kernels.hip) and pinned H2D staging of host batches
   DevBuf gb_temp, gb_u32, gb_flags, gb_agg_idx, gb_events;
-  void* pinned = nullptr;  // hipHostMalloc'ed staging: agg_idx then events of one batch
-  size_t pinned_cap = 0;
+  // hipHostMalloc'ed staging of host batches (agg_idx then events), two areas used in turn: the host fills one while the
+  // copy engine still drains the other; ev_staged[k] = "the H2D copies out of area k are done"
+  void* pinned[2] = {nullptr, nullptr};
+  size_t pinned_cap[2] = {0, 0};
+  hipEvent_t ev_staged[2] = {nullptr, nullptr};
+  bool staged_busy[2] = {false, false};
+  int pinned_next = 0;
+  uint32_t* host_flags = nullptr;  // pinned: {groups, bad, skipped batches} of the last device group-by, copied back async
+  uint32_t skipped_seen = 0;       // skipped batches already reported to the host
 
   DevBuf published;                      // the last committed snapshot (surge_replay_snapshot_delta), n_agg x 64 B
   int64_t published_n = 0;
@@ -490,8 +497,14 @@ int32_t surge_replay_destroy(surge_replay_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->comm) comm_destroy(h->comm);
   h->comm = nullptr;
-  if (h->pinned) (void)hipHostFree(h->pinned);
-  h->pinned = nullptr;
+  for (int k = 0; k < 2; ++k) {
+    if (h->pinned[k]) (void)hipHostFree(h->pinned[k]);
+    h->pinned[k] = nullptr;
+    if (h->ev_staged[k]) (void)hipEventDestroy(h->ev_staged[k]);
+    h->ev_staged[k] = nullptr;
+  }
+  if (h->host_flags) (void)hipHostFree(h->host_flags);
+  h->host_flags = nullptr;
   h->cidx.release();
   h->tidx.release();
   DevBuf* bufs[] = {&h->gb_temp, &h->gb_u32, &h->gb_flags, &h->gb_agg_idx, &h->gb_events, &h->published, &h->gathered[0], &h->gathered[1], &h->v_ctr, &h->v_total, &h->t_tiles, &h->t_gsub, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
@@ -519,11 +532,22 @@ int32_t surge_replay_set_stream(surge_replay_handle* h, void* hip_stream) {
   return SURGE_OK;
 }
 
+// A micro-batch whose aggregate indices were out of range is skipped on the device (stream_kernels.hip) and reported
+// here, at the host's next synchronisation point, once.
+static int32_t report_skipped_batches(surge_replay_handle* h) {
+  if (!h->host_flags) return SURGE_OK;
+  const uint32_t skipped = h->host_flags[2];
+  if (skipped == h->skipped_seen) return SURGE_OK;
+  const uint32_t n = skipped - h->skipped_seen;
+  h->skipped_seen = skipped;
+  return fail(h, SURGE_E_RANGE, std::to_string(n) + " micro-batch(es) carried an aggregate index out of range and were skipped (agg_idx out of range)");
+}
+
 int32_t surge_replay_synchronize(surge_replay_handle* h) {
   if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
   DeviceGuard g(h->device);
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  return SURGE_OK;
+  return report_skipped_batches(h);
 }
 
 int32_t surge_replay_bind_device_csr(surge_replay_handle* h, const int64_t* d_seg_off, int64_t n_agg,
@@ -1052,20 +1076,64 @@ int32_t surge_replay_append_events_device(surge_replay_handle* h, const int64_t*
   HIPCHK(h, groupby_temp_bytes(n, bits, &temp));
   HIPCHK(h, h->gb_temp.reserve(temp));
   HIPCHK(h, h->gb_u32.reserve((size_t)n * 4 * 6));
-  HIPCHK(h, h->gb_flags.reserve(8));
+  HIPCHK(h, h->gb_flags.reserve(16));
   HIPCHK(h, h->batch_group_agg.reserve((size_t)n * 8));
   HIPCHK(h, h->batch_group_off.reserve((size_t)(n + 1) * 8));
   HIPCHK(h, h->batch_events.reserve((size_t)n * 16));
   uint32_t* u = (uint32_t*)h->gb_u32.ptr;
+  if (!h->host_flags) {
+    HIPCHK(h, hipHostMalloc((void**)&h->host_flags, 16, hipHostMallocDefault));
+    std::memset(h->host_flags, 0, 16);
+    HIPCHK(h, hipMemsetAsync(h->gb_flags.ptr, 0, 16, h->stream));  // the sticky "skipped batches" word starts at 0
+  }
   HIPCHK(h, launch_groupby(d_agg_idx, (const uint4*)d_events, n, h->n_agg, bits, h->gb_temp.ptr, temp, u, u + n, u + 2 * (size_t)n,
                            u + 3 * (size_t)n, u + 4 * (size_t)n, u + 5 * (size_t)n, (uint4*)h->batch_events.ptr,
                            (int64_t*)h->batch_group_agg.ptr, (int64_t*)h->batch_group_off.ptr, (uint32_t*)h->gb_flags.ptr, h->stream));
-  uint32_t flags[2] = {0, 0};
-  HIPCHK(h, hipMemcpyAsync(flags, h->gb_flags.ptr, 8, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));  // the fold's launch is sized by the number of groups
-  if (flags[1]) return fail(h, SURGE_E_RANGE, "agg_idx out of range");
-  return surge_replay_append_fold_device(h, (const int64_t*)h->batch_group_agg.ptr, (const int64_t*)h->batch_group_off.ptr,
-                                         (int64_t)flags[0], h->batch_events.ptr, n_events);
+  HIPCHK(h, hipMemcpyAsync(h->host_flags, h->gb_flags.ptr, 12, hipMemcpyDeviceToHost, h->stream));
+  if (h->v2) {
+    // the slot kernel's launch (length sort of the groups, one lane per group) is sized on the host: wait for the count
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int32_t rs = report_skipped_batches(h);
+    if (rs != SURGE_OK) return rs;
+    if (h->host_flags[0] == 0u) return SURGE_OK;
+    return surge_replay_append_fold_device(h, (const int64_t*)h->batch_group_agg.ptr, (const int64_t*)h->batch_group_off.ptr,
+                                           (int64_t)h->host_flags[0], h->batch_events.ptr, n_events);
+  }
+  // v1: no host round trip — the plan kernel reads the group count where the group-by left it, the fold's grid depends on
+  // the event count only, and a batch with a bad index has zero groups (reported at the next synchronisation point)
+  FoldParams p;
+  fill_params(h, p);
+  p.events = (const uint4*)h->batch_events.ptr;
+  p.n_events = n_events;
+  p.init = h->d_state;  // fold onto the resident state, in place
+  p.out = h->d_state;
+  p.out_map = (const int64_t*)h->batch_group_agg.ptr;
+  HIPCHK(h, hipEventRecord(h->ev_total0, h->stream));
+  {
+    const int le = env_lane_events("SURGE_REPLAY_LE_FLAT", 16);
+    const int64_t task_events = choose_task_events(n_events, le);
+    const int64_t n_tasks = (n_events + task_events - 1) / task_events;
+    HIPCHK(h, h->plan.reserve((size_t)(n_tasks + 1) * 8));
+    HIPCHK(h, launch_plan_dev((const int64_t*)h->batch_group_off.ptr, (const uint32_t*)h->gb_flags.ptr, task_events, n_tasks,
+                              (int64_t*)h->plan.ptr, h->stream));
+    p.seg_off = (const int64_t*)h->batch_group_off.ptr;
+    p.plan = (const int64_t*)h->plan.ptr;
+    p.n_seg = 0;  // FLAT takes its segments from the plan
+    hipEvent_t e0, e1;
+    const int32_t rc = next_fold_events(h, &e0, &e1);
+    if (rc != SURGE_OK) return rc;
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    HIPCHK(h, launch_fold_flat(p, n_tasks, le, h->stream));
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    h->st.n_tasks = (int32_t)n_tasks;
+  }
+  HIPCHK(h, hipEventRecord(h->ev_total1, h->stream));
+  h->timing_valid = true;
+  h->st.last_algo = SURGE_ALGO_FLAT;
+  h->st.n_folds += 1;
+  h->st.n_poisoned = -1;
+  h->fold_epoch.fetch_add(1);
+  return SURGE_OK;
 }
 
 int32_t surge_replay_append_events(surge_replay_handle* h, const int64_t* agg_idx, const void* events, int64_t n_events) {
@@ -1076,26 +1144,41 @@ int32_t surge_replay_append_events(surge_replay_handle* h, const int64_t* agg_id
   if (!agg_idx || !events) return fail(h, SURGE_E_INVALID, "NULL batch buffer");
   if (n_events > 0xffffffffll) return fail(h, SURGE_E_UNSUPPORTED, "micro-batches are limited to 2^32 - 1 events");
   DeviceGuard g(h->device);
-  // host buffers (pageable: a JNI direct buffer, a numpy array) go through one pinned staging area so the H2D copy
-  // runs at PCIe speed; grouping happens on the device
+  // the indices are on the host here: check them before anything is enqueued (immediate SURGE_E_RANGE, batch not applied)
+  for (int64_t i = 0; i < n_events; ++i)
+    if (agg_idx[i] < 0 || agg_idx[i] >= h->n_agg) return fail(h, SURGE_E_RANGE, "agg_idx out of range");
+  // Host buffers (pageable: a JNI direct buffer, a numpy array) go through pinned staging so the H2D copy runs at PCIe
+  // speed; two staging areas alternate, so filling the next batch overlaps the copy and the fold of the previous one and
+  // the host never waits for the whole stream (double-buffered H2D).  Grouping happens on the device.
   const size_t need = (size_t)n_events * 24;
-  if (need > h->pinned_cap) {
-    if (h->pinned) (void)hipHostFree(h->pinned);
-    h->pinned = nullptr;
-    h->pinned_cap = 0;
-    const size_t cap = need < (4u << 20) ? (4u << 20) : need + need / 2;
-    HIPCHK(h, hipHostMalloc(&h->pinned, cap, hipHostMallocDefault));
-    h->pinned_cap = cap;
+  const int k = h->pinned_next;
+  h->pinned_next ^= 1;
+  if (!h->ev_staged[k]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_staged[k], hipEventDisableTiming));
+  if (h->staged_busy[k]) {  // the copies out of this area (two batches ago) must be done before it is overwritten
+    HIPCHK(h, hipEventSynchronize(h->ev_staged[k]));
+    h->staged_busy[k] = false;
   }
+  if (need > h->pinned_cap[k]) {
+    if (h->pinned[k]) (void)hipHostFree(h->pinned[k]);
+    h->pinned[k] = nullptr;
+    h->pinned_cap[k] = 0;
+    const size_t cap = need < (4u << 20) ? (4u << 20) : need + need / 2;
+    HIPCHK(h, hipHostMalloc(&h->pinned[k], cap, hipHostMallocDefault));
+    h->pinned_cap[k] = cap;
+  }
+  // the device-side landing buffers are reused by every batch: stream order keeps a batch's copies behind the previous
+  // batch's kernels; growing them must wait for those kernels
+  if ((size_t)n_events * 8 > h->gb_agg_idx.cap || (size_t)n_events * 16 > h->gb_events.cap) HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, h->gb_agg_idx.reserve((size_t)n_events * 8));
   HIPCHK(h, h->gb_events.reserve((size_t)n_events * 16));
-  HIPCHK(h, hipStreamSynchronize(h->stream));  // the previous batch's copy out of the staging area is done
-  std::memcpy(h->pinned, agg_idx, (size_t)n_events * 8);
-  std::memcpy((char*)h->pinned + (size_t)n_events * 8, events, (size_t)n_events * 16);
+  std::memcpy(h->pinned[k], agg_idx, (size_t)n_events * 8);
+  std::memcpy((char*)h->pinned[k] + (size_t)n_events * 8, events, (size_t)n_events * 16);
   HIPCHK(h, hipEventRecord(h->ev_h0, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->gb_agg_idx.ptr, h->pinned, (size_t)n_events * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->gb_events.ptr, (char*)h->pinned + (size_t)n_events * 8, (size_t)n_events * 16, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->gb_agg_idx.ptr, h->pinned[k], (size_t)n_events * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->gb_events.ptr, (char*)h->pinned[k] + (size_t)n_events * 8, (size_t)n_events * 16, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipEventRecord(h->ev_h1, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_staged[k], h->stream));
+  h->staged_busy[k] = true;
   h->h2d_valid = true;
   return surge_replay_append_events_device(h, (const int64_t*)h->gb_agg_idx.ptr, h->gb_events.ptr, n_events);
 }

@@ -536,6 +536,23 @@ __global__ void plan_kernel(const int64_t* __restrict__ off, int64_t n_seg, int6
   plan[k] = lo;
 }
 
+// the same plan over a segment count that only the device knows yet (micro-batches: the group count the device group-by
+// has just produced — no host round trip between the group-by and the fold)
+__global__ void plan_dev_kernel(const int64_t* __restrict__ off, const uint32_t* __restrict__ d_n_seg, int64_t task_events,
+                                int64_t n_tasks, int64_t* __restrict__ plan) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > n_tasks) return;
+  const int64_t n_seg = (int64_t)d_n_seg[0];
+  if (k == n_tasks || n_seg == 0) { plan[k] = n_seg; return; }  // no segments: every task is empty
+  const int64_t target = off[0] + k * task_events;
+  int64_t lo = 0, hi = n_seg;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (off[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  plan[k] = lo;
+}
+
 __global__ void analyze_csr_kernel(const int64_t* __restrict__ off, int64_t n_seg, CsrAnalysis* res) {
   __shared__ unsigned long long s_empty;
   __shared__ long long s_max;
@@ -701,6 +718,13 @@ hipError_t launch_plan(const int64_t* off, int64_t n_seg, int64_t task_events, i
   const int64_t n = n_tasks + 1;
   hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, off, n_seg, task_events,
                      n_tasks, plan);
+  return hipGetLastError();
+}
+
+hipError_t launch_plan_dev(const int64_t* off, const uint32_t* d_n_seg, int64_t task_events, int64_t n_tasks, int64_t* plan,
+                           hipStream_t stream) {
+  const int64_t n = n_tasks + 1;
+  hipLaunchKernelGGL(plan_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, off, d_n_seg, task_events, n_tasks, plan);
   return hipGetLastError();
 }
 

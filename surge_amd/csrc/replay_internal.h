@@ -54,6 +54,8 @@ hipError_t launch_fold_tiled(const FoldParams& p, const uint4* tiles, const int6
 hipError_t launch_exclusive_scan_i64(int64_t* v, int64_t n, hipStream_t stream);
 hipError_t launch_plan(const int64_t* off, int64_t n_seg, int64_t task_events, int64_t n_tasks,
                        int64_t* plan, hipStream_t stream);
+hipError_t launch_plan_dev(const int64_t* off, const uint32_t* d_n_seg, int64_t task_events, int64_t n_tasks, int64_t* plan,
+                           hipStream_t stream);
 hipError_t launch_analyze_csr(const int64_t* off, int64_t n_seg, CsrAnalysis* d_result, hipStream_t stream);
 hipError_t launch_fill_empty(const int64_t* off, int64_t n_seg, const uint4* init, uint4* out,
                              hipStream_t stream);

@@ -46,7 +46,12 @@ __global__ void groupby_scatter_kernel(const uint32_t* __restrict__ keys, const 
   if (i == n - 1) {
     const uint32_t g = gid[i] + head[i];
     group_off[g] = (int64_t)n;
-    n_groups[0] = g;
+    // flags: [0] groups of this batch, [1] "an index of this batch was out of range", [2] batches skipped so far (sticky).
+    // A batch with a bad index is SKIPPED on the device (0 groups: the fold that follows touches nothing) — the host does
+    // not wait for the flag before it launches the fold; it learns about the skip at its next synchronisation point.
+    const bool bad = n_groups[1] != 0u;
+    n_groups[0] = bad ? 0u : g;
+    if (bad) atomicAdd(&n_groups[2], 1u);
   }
 }
 
@@ -65,7 +70,8 @@ hipError_t groupby_temp_bytes(uint32_t n, unsigned key_bits, size_t* bytes) {
   return hipSuccess;
 }
 
-// All buffers device: keys_a/keys_b/vals_a/vals_b/head/gid: n x u32 each; d_flags: {n_groups, bad} (2 x u32).
+// All buffers device: keys_a/keys_b/vals_a/vals_b/head/gid: n x u32 each; d_flags: {n_groups, bad, skipped batches} (3 x u32;
+// the third word is sticky: zeroed by the owner, never here).
 hipError_t launch_groupby(const int64_t* d_agg_idx, const uint4* d_events, uint32_t n, int64_t n_agg, unsigned key_bits, void* d_temp,
                           size_t temp_bytes, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* head,
                           uint32_t* gid, uint4* d_sorted_events, int64_t* d_group_agg, int64_t* d_group_off, uint32_t* d_flags,
