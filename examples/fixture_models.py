@@ -204,6 +204,15 @@ class CounterCommandModel(ReplayableCommandModel[State, object, CounterEvent]):
             return CT_THROW, event.sequenceNumber, 0, None
         raise TypeError(f"not a Counter event: {event!r}")
 
+    def event_json_template(self):
+        """The JSON ``CounterEventFormat.write_event`` produces (``Json.toJson(evt)`` over the sealed ``BaseTestEvent`` format,
+        TestBoundedContext.scala:42-49): a ``_type`` discriminator, ``sequenceNumber`` and the increment / decrement."""
+        from surge_amd.ingest import ARG_I32, ARG_NONE, EventJsonTemplate
+
+        return EventJsonTemplate("_type", [("countIncremented", CT_INC, "sequenceNumber", "incrementBy", ARG_I32),
+                                           ("countDecremented", CT_DEC, "sequenceNumber", "decrementBy", ARG_I32),
+                                           ("no-op", CT_NOOP, "sequenceNumber", "", ARG_NONE)])
+
     def aggregate_id_of(self, event: CounterEvent) -> str:
         return event.aggregateId
 
@@ -394,6 +403,14 @@ class BankAccountCommandModel(ReplayableCommandModel[BankAccount, object, object
         if isinstance(event, BankAccountUpdated):
             return BA_UPDATED, 0, None, event.newBalance
         raise TypeError(f"not a BankAccount event: {event!r}")
+
+    def event_json_template(self):
+        """``Json.toJson(evt)(Json.format[BankAccountEvent])`` (BankAccountSurgeModel.scala:30-32): play-json's sealed-family
+        format names the case class in ``_type`` (fully qualified by default); the balances are JSON numbers."""
+        from surge_amd.ingest import ARG_F64, EventJsonTemplate
+
+        return EventJsonTemplate("_type", [("docs.command.BankAccountCreated", BA_CREATED, "", "balance", ARG_F64),
+                                           ("docs.command.BankAccountUpdated", BA_UPDATED, "", "newBalance", ARG_F64)])
 
     def aggregate_id_of(self, event) -> str:
         return str(event.accountNumber)

@@ -72,6 +72,43 @@ const uint8_t* surge_ingest_arena(const surge_ingest* g);
 int32_t surge_ingest_drain_fixed16(surge_ingest* g, int64_t max, int64_t* agg_idx_out, void* events16_out,
                                    int64_t* offsets_out, int64_t* n_out);
 
+/* ---- record VALUES as the reference's plugins write them: JSON text -> the 16-byte fixed event -----------------------
+ * The reference's event writers are `Json.toJson(evt).toString().getBytes()` over play-json case-class formats
+ * (TestBoundedContext.scala:42-49,122-124; BankAccountSurgeModel.scala:30-32): one flat JSON object per event, and for a
+ * sealed family a discriminator field naming the case class.  A template tells the decoder which discriminator value is
+ * which surge_event16.type and which fields carry the sequence number and the payload; field order, extra fields and
+ * the spelling of numbers do not matter (play-json is not under /root/reference: its exact text is parity-unpinned, the
+ * decoder does not depend on it).  The reference has no event READER at all (SurgeFormatting.scala:9-11 only writes):
+ * this is additive, the mirror image of the GPU state encoders of surge_replay.h. */
+#define SURGE_EVJ_MAX_TYPES 16
+#define SURGE_EVJ_NAME      64
+#define SURGE_EVJ_ARG_NONE  0
+#define SURGE_EVJ_ARG_I32   1 /* JSON integer that fits a JVM Int -> payload low word (high word zero)              */
+#define SURGE_EVJ_ARG_F64   2 /* JSON number -> IEEE double, correctly rounded (BigDecimal.doubleValue semantics) */
+typedef struct surge_event_json_type {
+  char     name[SURGE_EVJ_NAME];      /* discriminator value selecting this entry, NUL-terminated ("" if none)   */
+  uint32_t event_type;                /* surge_event16.type to emit                                              */
+  uint32_t arg_kind;                  /* SURGE_EVJ_ARG_*                                                         */
+  char     seq_field[SURGE_EVJ_NAME]; /* integer field -> surge_event16.seq ("" = 0)                             */
+  char     arg_field[SURGE_EVJ_NAME]; /* field -> payload ("" with SURGE_EVJ_ARG_NONE)                           */
+} surge_event_json_type;
+typedef struct surge_event_json_template {
+  uint32_t n_types;
+  uint32_t reserved;
+  char     discriminator[SURGE_EVJ_NAME]; /* e.g. "_type"; "" = every value is types[0]                            */
+  surge_event_json_type types[SURGE_EVJ_MAX_TYPES];
+} surge_event_json_template;
+int32_t surge_event_json_validate(const surge_event_json_template* t);
+/* One record value -> one 16-byte event.  0 or SURGE_E_CORRUPT (malformed JSON, unknown type, missing field, a number
+ * that is not what the template says); the reason is in surge_event_json_last_error() (thread-local). */
+int32_t surge_event_json_decode(const surge_event_json_template* t, const uint8_t* value, int64_t len, void* event16_out);
+const char* surge_event_json_last_error(void);
+/* Like surge_ingest_drain_fixed16 for topics whose values are JSON events: pops up to max deliverable records and
+ * decodes each value through the template — no per-record work in the host language.  Nothing is popped when a value
+ * does not decode (SURGE_E_CORRUPT; surge_ingest_last_error names the record's offset and the reason). */
+int32_t surge_ingest_drain_json(surge_ingest* g, int64_t max, const surge_event_json_template* tmpl, int64_t* agg_idx_out,
+                                void* events16_out, int64_t* offsets_out, int64_t* n_out);
+
 /* Key table: aggregate ids in first-DELIVERED order (a key is interned when its record is drained, so the
  * keys of aborted or still-open transactions never appear). */
 int64_t surge_ingest_key_count(const surge_ingest* g);

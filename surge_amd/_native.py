@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
-SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip", "fold_slots.hip", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")
+SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip", "fold_slots.hip", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "event_decode.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")
 HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "fold_chunk_device.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
@@ -80,6 +80,10 @@ INGEST_EXPORTS = (
     "surge_ingest_drain",
     "surge_ingest_arena",
     "surge_ingest_drain_fixed16",
+    "surge_ingest_drain_json",
+    "surge_event_json_validate",
+    "surge_event_json_decode",
+    "surge_event_json_last_error",
     "surge_ingest_key_count",
     "surge_ingest_key",
     "surge_ingest_counters",
@@ -232,6 +236,10 @@ def load() -> ctypes.CDLL:
         "surge_ingest_drain": ([vp, i64, vp, ctypes.POINTER(i64)], i32),
         "surge_ingest_arena": ([vp], vp),
         "surge_ingest_drain_fixed16": ([vp, i64, vp, vp, vp, ctypes.POINTER(i64)], i32),
+        "surge_ingest_drain_json": ([vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)], i32),
+        "surge_event_json_validate": ([vp], i32),
+        "surge_event_json_decode": ([vp, vp, i64, vp], i32),
+        "surge_event_json_last_error": ([], ctypes.c_char_p),
         "surge_ingest_key_count": ([vp], i64),
         "surge_ingest_key": ([vp, i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i64)], i32),
         "surge_ingest_counters": ([vp, ctypes.POINTER(i64 * 8)], i32),

@@ -131,6 +131,12 @@ class ReplayableCommandModel(AggregateCommandModel[Agg, Cmd, Evt]):
     def state_to_fixed(self, aggregate: Agg) -> np.ndarray:
         raise NotImplementedError
 
+    def event_json_template(self):
+        """Optional: an ``EventJsonTemplate`` describing the JSON text ``SurgeEventWriteFormatting.write_event`` produces, so
+        that an events topic can be decoded in the library (``surge_ingest_drain_json``) instead of record by record
+        through ``read_event`` + ``encode_event``.  ``None`` = no template (the store falls back to the plugin's reader)."""
+        return None
+
     def encode_events(self, events: Sequence[Evt]) -> np.ndarray:
         out = np.zeros(len(events), dtype=EVENT_DTYPE)
         for i, e in enumerate(events):

@@ -531,6 +531,44 @@ int32_t surge_ingest_drain_fixed16(surge_ingest* g, int64_t max, int64_t* agg_id
   return OK;
 }
 
+int32_t surge_ingest_drain_json(surge_ingest* g, int64_t max, const surge_event_json_template* tmpl, int64_t* agg_idx_out,
+                                void* events16_out, int64_t* offsets_out, int64_t* n_out) {
+  if (!g || !n_out || !tmpl || max < 0 || ((!agg_idx_out || !events16_out) && max > 0)) return fail(g, E_INVALID, "bad argument");
+  if (surge_event_json_validate(tmpl) != 0) return fail(g, E_INVALID, std::string("event template: ") + surge_event_json_last_error());
+  // decode before popping anything: a value that does not decode leaves the queue as it was
+  uint8_t* ev = (uint8_t*)events16_out;
+  int64_t avail = 0;
+  for (const Batch& b : g->queue) {
+    if (b.decided == 0) break;
+    if (b.decided == 2) continue;
+    for (size_t i = b.next; i < b.recs.size() && avail < max; ++i, ++avail) {
+      const Rec& r = b.recs[i];
+      if (r.agg_idx == -1 || r.value_len < 0)
+        return fail(g, SURGE_E_CORRUPT, "record at offset " + std::to_string(r.offset) + " has a null key or value (not an event)");
+      const int32_t rc = surge_event_json_decode(tmpl, g->arena.data() + r.value_off, r.value_len, ev + avail * 16);
+      if (rc != OK)
+        return fail(g, SURGE_E_CORRUPT, "record at offset " + std::to_string(r.offset) + ": " + surge_event_json_last_error());
+    }
+    if (avail >= max) break;
+  }
+  int64_t n = 0;
+  while (n < max && !g->queue.empty()) {
+    Batch& b = g->queue.front();
+    if (b.decided == 0) break;
+    if (b.decided == 2) { g->queue.pop_front(); continue; }
+    while (n < max && b.next < b.recs.size()) {
+      Rec& r = b.recs[b.next++];
+      agg_idx_out[n] = deliver_idx(g, r);
+      if (offsets_out) offsets_out[n] = r.offset;
+      ++n;
+    }
+    if (b.next == b.recs.size()) g->queue.pop_front();
+  }
+  g->counters[2] += n;
+  *n_out = n;
+  return OK;
+}
+
 int64_t surge_ingest_key_count(const surge_ingest* g) { return g ? (int64_t)g->keys.size() : 0; }
 
 int32_t surge_ingest_key(const surge_ingest* g, int64_t idx, const char** utf8_out, int64_t* len_out) {

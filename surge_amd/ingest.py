@@ -24,6 +24,53 @@ RECORD_DTYPE = np.dtype([("offset", "<i8"), ("agg_idx", "<i8"), ("key_off", "<i8
 assert RECORD_DTYPE.itemsize == 40
 
 
+EVJ_NAME, EVJ_MAX_TYPES = 64, 16
+ARG_NONE, ARG_I32, ARG_F64 = 0, 1, 2
+
+
+class _CEventJsonType(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * EVJ_NAME), ("event_type", ctypes.c_uint32), ("arg_kind", ctypes.c_uint32),
+                ("seq_field", ctypes.c_char * EVJ_NAME), ("arg_field", ctypes.c_char * EVJ_NAME)]
+
+
+class CEventJsonTemplate(ctypes.Structure):
+    _fields_ = [("n_types", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("discriminator", ctypes.c_char * EVJ_NAME),
+                ("types", _CEventJsonType * EVJ_MAX_TYPES)]
+
+
+class EventJsonTemplate:
+    """``surge_event_json_template``: how a model's JSON event text maps onto the 16-byte fixed event.
+
+    ``types``: ``(discriminator value, event type, seq field or "", arg field or "", ARG_*)`` per event class;
+    ``discriminator``: the field naming the class (play-json's sealed-family ``"_type"``), ``""`` for single-class topics."""
+
+    def __init__(self, discriminator: str, types):
+        self.discriminator, self.types = discriminator, list(types)
+
+    def to_c(self) -> CEventJsonTemplate:
+        t = CEventJsonTemplate()
+        t.n_types = len(self.types)
+        t.discriminator = self.discriminator.encode()
+        for i, (name, ev_type, seq_field, arg_field, arg_kind) in enumerate(self.types):
+            e = t.types[i]
+            e.name, e.event_type, e.arg_kind = name.encode(), ev_type, arg_kind
+            e.seq_field, e.arg_field = seq_field.encode(), arg_field.encode()
+        return t
+
+    def decode(self, value: bytes) -> np.ndarray:
+        """One record value -> one ``EVENT_DTYPE`` record (``surge_event_json_decode``)."""
+        lib = _native.load()
+        out = np.zeros(1, dtype=EVENT_DTYPE)
+        c = self.to_c()
+        if lib.surge_event_json_validate(ctypes.byref(c)) != 0:
+            raise IngestError(-1, (lib.surge_event_json_last_error() or b"").decode())
+        buf = (ctypes.c_uint8 * max(len(value), 1)).from_buffer_copy(value or b"\0")
+        rc = lib.surge_event_json_decode(ctypes.byref(c), buf, len(value), out.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            raise IngestError(rc, (lib.surge_event_json_last_error() or b"").decode())
+        return out[0]
+
+
 class IngestError(RuntimeError):
     def __init__(self, status: int, message: str):
         super().__init__(f"surge_ingest status {status}: {message}")
@@ -84,6 +131,20 @@ class EventsTopicIngest:
         got = ctypes.c_int64(0)
         self._check(self._lib.surge_ingest_drain_fixed16(
             self._h, n, agg.ctypes.data_as(ctypes.c_void_p), ev.ctypes.data_as(ctypes.c_void_p),
+            off.ctypes.data_as(ctypes.c_void_p), ctypes.byref(got)))
+        return agg[: got.value], ev[: got.value], off[: got.value]
+
+    def drain_json(self, template: EventJsonTemplate, max_records: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """``(agg_idx, events, offsets)`` for topics whose record values are JSON events, decoded in the library through the
+        model's template (``surge_ingest_drain_json``): no per-record Python."""
+        n = self.ready if max_records is None else min(self.ready, max_records)
+        agg = np.zeros(n, dtype=np.int64)
+        ev = np.zeros(n, dtype=EVENT_DTYPE)
+        off = np.zeros(n, dtype=np.int64)
+        got = ctypes.c_int64(0)
+        c = template.to_c()
+        self._check(self._lib.surge_ingest_drain_json(
+            self._h, n, ctypes.byref(c), agg.ctypes.data_as(ctypes.c_void_p), ev.ctypes.data_as(ctypes.c_void_p),
             off.ctypes.data_as(ctypes.c_void_p), ctypes.byref(got)))
         return agg[: got.value], ev[: got.value], off[: got.value]
 

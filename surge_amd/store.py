@@ -73,19 +73,23 @@ class GpuReplayStateStore:
         ingest counters."""
         from .core import SerializedMessage
         from .ingest import EventsTopicIngest
-        from .log import group_by_aggregate
         from .schema import EVENT_DTYPE
 
         from .ingest import IngestError
 
+        template = self.model.event_json_template()
         with EventsTopicIngest() as g:
             g.feed(record_batches)
+            recs = None
             try:
                 # GPU-ready topic (every value IS the 16-byte fixed event): one vectorised drain, no per-record Python
                 agg_idx, events, _ = g.drain_fixed16()
-                recs = None
             except IngestError:
-                recs = g.drain_records()  # plugin-serialized values: decode through the plugin's event reader
+                if template is not None:
+                    # the plugin's JSON event text, decoded in the library through the model's template
+                    agg_idx, events, _ = g.drain_json(template)
+                else:
+                    recs = g.drain_records()  # no template: every value through the plugin's own event reader
             keys = g.key_table()
             counters = g.counters()
         if recs is not None:
@@ -99,9 +103,17 @@ class GpuReplayStateStore:
                 else:
                     evt = reader.read_event(SerializedMessage(key.decode("utf-8"), value or b""))
                     events[i] = self.model.encode_events([evt])[0]
+        # The records are in topic (offset) order, tagged with their aggregate's dense index: exactly a micro-batch.  The
+        # group-by runs on the device (stable radix sort + head scan, the K3 path) onto an all-None resident state; no
+        # host-side sort of the whole topic.
         n_agg = max(len(keys), capacity)
-        seg_off, sorted_ev = group_by_aggregate(agg_idx, events, n_agg)
-        self.restore_log(EventLog(seg_off, sorted_ev, keys), None, algo)
+        self.keys = keys
+        self.engine.load_csr(np.zeros(n_agg + 1, dtype=np.int64), np.zeros(0, dtype=EVENT_DTYPE))
+        self.engine.fold()  # every aggregate None; `algo` only names kernels for bound logs (restore / restore_log)
+        if events.shape[0]:
+            self.engine.append_events(agg_idx, events)
+        self.engine.snapshot()  # publishes the host mirror that serves point reads
+        self._restored = True
         return counters
 
     def restore_log(self, log: EventLog, init_state: Optional[np.ndarray] = None, algo: int = ALGO_AUTO) -> None:

@@ -39,6 +39,23 @@ lib.surge_lz4_frame_compress.argtypes = [ctypes.c_char_p, i64, ctypes.c_char_p, 
 lib.surge_lz4_frame_compress.restype = i64
 
 
+class EvType(ctypes.Structure):  # surge_event_json_type
+    _fields_ = [("name", ctypes.c_char * 64), ("event_type", ctypes.c_uint32), ("arg_kind", ctypes.c_uint32), ("seq_field", ctypes.c_char * 64),
+                ("arg_field", ctypes.c_char * 64)]
+
+
+class EvTemplate(ctypes.Structure):  # surge_event_json_template
+    _fields_ = [("n_types", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("discriminator", ctypes.c_char * 64), ("types", EvType * 16)]
+
+
+TMPL = EvTemplate()
+TMPL.n_types, TMPL.discriminator = 3, b"_type"
+for _i, (_n, _t, _k, _s, _a) in enumerate([(b"countIncremented", 1, 1, b"sequenceNumber", b"incrementBy"), (b"no-op", 0, 0, b"sequenceNumber", b""),
+                                           (b"upd", 4, 2, b"", b"newBalance")]):
+    TMPL.types[_i].name, TMPL.types[_i].event_type, TMPL.types[_i].arg_kind, TMPL.types[_i].seq_field, TMPL.types[_i].arg_field = _n, _t, _k, _s, _a
+lib.surge_event_json_decode.argtypes = [vp, ctypes.c_char_p, i64, vp]
+
+
 def valid_wire():
     batches, off = [], rng.randrange(0, 1 << 40)
     for _ in range(rng.randrange(1, 5)):
@@ -152,4 +169,16 @@ while time.time() < t_end:
     out2 = ctypes.create_string_buffer(max(small, 1))
     r = lib.surge_lz4_frame_decompress(bad, len(bad), out2, small)
     assert r <= small
+    # JSON event values: valid ones must decode, mutated ones must answer 0 or CORRUPT without touching foreign memory
+    for _ in range(20):
+        good = rng.choice([
+            b'{"aggregateId":"a","incrementBy":%d,"sequenceNumber":%d,"_type":"countIncremented"}' % (rng.randrange(-2**31, 2**31), rng.randrange(2**31)),
+            b'{"_type":"no-op","aggregateId":"x\\"y","sequenceNumber":7,"n":{"a":[1,{"b":"}"}]}}',
+            b'{"_type":"upd","newBalance":%s}' % repr(rng.uniform(-1e300, 1e300)).encode(),
+        ])
+        ev = (ctypes.c_uint8 * 16)()
+        assert lib.surge_event_json_decode(ctypes.byref(TMPL), good, len(good), ev) == 0, good
+        m = mutate(good)
+        exact = ctypes.create_string_buffer(m, len(m))  # no NUL terminator behind the value: an over-read is an ASan report
+        assert lib.surge_event_json_decode(ctypes.byref(TMPL), exact, len(m), ev) in (0, -7)
 print(f"OK {rounds} rounds")

@@ -75,7 +75,7 @@ def test_committed_profiles_describe_the_current_kernel_sources():
 
 def test_algo_names_and_plain_multi_gpu_invocation_starts_its_own_ranks():
     """`python bench.py --gpus 2` (no torchrun environment) must re-exec under torch.distributed.run — the way the driver
-    starts the N > 1 bench.  Without a GPU both ranks then stop at the no-CPU-fallback check, which is what shows they ran."""
+    starts the N > 1 bench.  Without a GPU the ranks then stop at the no-CPU-fallback check, which is what shows they ran."""
     import subprocess
 
     import torch
@@ -87,4 +87,5 @@ def test_algo_names_and_plain_multi_gpu_invocation_starts_its_own_ranks():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
     assert res.returncode != 0
-    assert res.stderr.count("bench.py needs a GPU") >= 2, res.stderr[-3000:]
+    # both ranks were started by torch.distributed.run (its failure report lists them); the first to reach the check stops the job
+    assert res.stderr.count("bench.py needs a GPU") >= 1 and "local_rank: 1" in res.stderr and "local_rank: 0" in res.stderr, res.stderr[-3000:]
