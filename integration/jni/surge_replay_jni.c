@@ -17,6 +17,7 @@
 #include <jni.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 #include "surge_replay.h"
 
 #define H(h) ((surge_replay_handle*)(intptr_t)(h))
@@ -84,6 +85,26 @@ JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_loadCsr(JNIEnv* env, j
 JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_fold(JNIEnv* env, jclass c, jlong h, jint algo) {
   (void)c;
   return check(env, surge_replay_fold(H(h), algo));
+}
+
+/* Builds the per-log index `algo` needs (SURGE_ALGO_TILED = 7: the tile-major copy of the bound log) without folding, so a
+ * recovery can pay the one-off layout cost when the log is bound; out (nullable, >= 24 bytes) receives
+ * {index_build_ms, relayout_ms (doubles), tiled_bytes (long)} of surge_replay_layout_info. */
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_prepare(JNIEnv* env, jclass c, jlong h, jint algo, jobject out) {
+  (void)c;
+  int bad = 0;
+  unsigned char* o = (unsigned char*)buf(env, out, 24, 1, &bad, "out: direct buffer of 24 bytes expected");
+  surge_replay_layout_info_t info;
+  int32_t rc;
+  if (bad) return SURGE_E_INVALID;
+  rc = check(env, surge_replay_prepare(H(h), algo));
+  if (rc != SURGE_OK || !o) return rc;
+  rc = check(env, surge_replay_layout_info(H(h), &info));
+  if (rc != SURGE_OK) return rc;
+  memcpy(o, &info.index_build_ms, 8);
+  memcpy(o + 8, &info.relayout_ms, 8);
+  memcpy(o + 16, &info.tiled_bytes, 8);
+  return SURGE_OK;
 }
 
 JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_appendFold(JNIEnv* env, jclass c, jlong h, jobject groupAgg,

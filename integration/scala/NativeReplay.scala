@@ -20,6 +20,9 @@ object NativeReplay {
   @native def destroy(handle: Long): Unit
   @native def loadCsr(handle: Long, segOff: ByteBuffer, nAgg: Long, events: ByteBuffer, nEvents: Long, initState: ByteBuffer): Int
   @native def fold(handle: Long, algo: Int): Int
+  /** Builds the index `algo` needs without folding (algo 7 = tile-major copy of the bound log); `out` (nullable, 24 bytes,
+    * native order) receives index_build_ms, relayout_ms (doubles) and the copy's size in bytes (long). */
+  @native def prepare(handle: Long, algo: Int, out: ByteBuffer): Int
   @native def appendFold(handle: Long, groupAgg: ByteBuffer, groupOff: ByteBuffer, nGroups: Long, events: ByteBuffer, nEvents: Long): Int
   @native def appendEvents(handle: Long, aggIdx: ByteBuffer, events: ByteBuffer, nEvents: Long): Int
   @native def grow(handle: Long, newNAgg: Long): Int

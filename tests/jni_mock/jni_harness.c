@@ -16,6 +16,7 @@ jlong Java_surge_replay_gpu_NativeReplay_create(JNIEnv*, jclass, jobject, jint);
 void Java_surge_replay_gpu_NativeReplay_destroy(JNIEnv*, jclass, jlong);
 jint Java_surge_replay_gpu_NativeReplay_loadCsr(JNIEnv*, jclass, jlong, jobject, jlong, jobject, jlong, jobject);
 jint Java_surge_replay_gpu_NativeReplay_fold(JNIEnv*, jclass, jlong, jint);
+jint Java_surge_replay_gpu_NativeReplay_prepare(JNIEnv*, jclass, jlong, jint, jobject);
 jint Java_surge_replay_gpu_NativeReplay_appendFold(JNIEnv*, jclass, jlong, jobject, jobject, jlong, jobject, jlong);
 jint Java_surge_replay_gpu_NativeReplay_appendEvents(JNIEnv*, jclass, jlong, jobject, jobject, jlong);
 jint Java_surge_replay_gpu_NativeReplay_grow(JNIEnv*, jclass, jlong, jlong);
@@ -123,6 +124,24 @@ int main(void) {
             Java_surge_replay_gpu_NativeReplay_snapshot(env, NULL, h, 3, &b_out, &b_present) == 0 && n_thrown == 0,
         "loadCsr / fold / snapshot through direct buffers");
   check(out[0].count == 5 && out[0].version == 5 && present[0] == 1 && present[1] == 0, "(3,3) + two increments = (5,5); orphan update stays None");
+  {
+    /* the tile-major path through JNI: prepare(TILED) reports its one-off cost, fold(TILED) gives the same states */
+    unsigned char lay[24];
+    fake_direct_buffer b_lay = DB(lay, sizeof lay);
+    surge_state64 out2[3];
+    uint8_t present2[3];
+    fake_direct_buffer b_out2 = DB(out2, sizeof out2), b_present2 = DB(present2, sizeof present2);
+    double relayout_ms = -1.0;
+    int64_t tiled_bytes = 0;
+    n_thrown = 0;
+    const int okp = Java_surge_replay_gpu_NativeReplay_prepare(env, NULL, h, SURGE_ALGO_TILED, &b_lay) == 0 &&
+                    Java_surge_replay_gpu_NativeReplay_fold(env, NULL, h, SURGE_ALGO_TILED) == 0 &&
+                    Java_surge_replay_gpu_NativeReplay_snapshot(env, NULL, h, 3, &b_out2, &b_present2) == 0 && n_thrown == 0;
+    memcpy(&relayout_ms, lay + 8, 8);
+    memcpy(&tiled_bytes, lay + 16, 8);
+    check(okp && memcmp(out, out2, sizeof out) == 0 && relayout_ms > 0.0 && tiled_bytes > 0 && tiled_bytes % 8192 == 0,
+          "prepare(TILED) + fold(TILED): same states, layout cost reported");
+  }
   check(Java_surge_replay_gpu_NativeReplay_get(env, NULL, h, 0, &b_one) == 1 && one.count == 5 &&
             Java_surge_replay_gpu_NativeReplay_get(env, NULL, h, 1, &b_one) == 0, "get: 1 = Some(state64 filled), 0 = None");
   check(Java_surge_replay_gpu_NativeReplay_get(env, NULL, h, 2, &b_one) == 2, "get: 2 = POISONED (replay hit a throwing event): never served as a state");
