@@ -80,7 +80,8 @@ def csrc_sha16():
     """Identity of the kernel sources a profile was taken with (profiles/traffic_manifest.json records it)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "surge_amd", "csrc")
-    for name in ("fold_layout.h", "fold_device.h", "fold_chunk_device.h", "fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip"):  # what the fold kernels are built from
+    for name in ("fold_layout.h", "fold_device.h", "fold_chunk_device.h", "fold_slots_device.h", "fold_kernels.hip", "fold_chunked.hip",
+                 "fold_tiled.hip"):  # what the fold kernels are built from
         h.update(name.encode())
         h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
@@ -164,10 +165,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c4", choices=["c4", "c3", "c2", "c2-weak", "c5"],
+    ap.add_argument("--workload", default="c4", choices=["c4", "c3", "c2", "c2-weak", "c5", "v2"],
                     help="c4 / c3 (default): the 10 M-aggregate Zipf log, strong-scaled over the GPUs; c2: 1 M x 256 fixed fan-in "
                          "(strong-scaled); c2-weak: 1 M x 256 PER GPU (round 1's run); c5: streaming micro-batches onto a resident "
-                         "state store with periodic state-topic snapshots (one GPU; a step = one micro-batch, default 600 steps)")
+                         "state store with periodic state-topic snapshots (one GPU; a step = one micro-batch, default 600 steps); "
+                         "v2: an ABI v2 slot schema (accumulating f64 ledger) over a 2 M-aggregate Zipf log, schema-specialised "
+                         "kernels vs the generic interpreter, CSR vs tile-major transport (one GPU)")
     ap.add_argument("--batch-events", type=int, default=100_000, help="c5: events per micro-batch")
     ap.add_argument("--snapshot-every", type=int, default=30, help="c5: publish a state-topic delta every N batches (0 = never)")
     ap.add_argument("--device-batches", action="store_true", help="c5: batches already in HBM (no staging / H2D)")
@@ -187,6 +190,9 @@ def main():
     args = ap.parse_args()
     if args.workload == "c5":
         print(json.dumps(run_c5(args)))
+        return
+    if args.workload == "v2":
+        print(json.dumps(run_v2(args)))
         return
 
     import numpy as np
@@ -656,6 +662,100 @@ def run_c5(args):
     pub.close()
     eng.close()
     return result
+
+
+def run_v2(args):
+    """ABI v2 (models the seven named v1 fields cannot express): an accumulating f64 ledger — IEEE double
+    ADD / SUB strictly in event order, a running Math.max, an Int transaction count, event_count — over a Zipf(1..4096)
+    log (default 2 M aggregates), one lane per aggregate.  Four timed variants of the SAME device code: compiled for the
+    schema by hiprtc at create time (what a host gets) or as the generic interpreter (SURGE_REPLAY_RTC=0), each over the
+    bound CSR log and over the tile-major copy.  `value` = the specialised kernels over the tile-major copy; every
+    variant's states are compared with the first one's, and that one with the sequential CPU oracle on the whole log."""
+    import numpy as np
+    import torch
+
+    from oracle import oracle
+    from surge_amd import schema as S
+    from surge_amd import synth
+    from surge_amd.replay import ReplayEngine
+    from surge_amd.schema import CLS_CREATE, CLS_REQUIRE, OP_ADD, OP_MAX, OP_SET, OP_SUB, SLOT_F64, SLOT_I32, SRC_ONE, SRC_PAYLOAD, Slot, SlotAlgebra
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the replay engine has no CPU fallback")
+    dev = torch.device("cuda:0")
+    ledger = SlotAlgebra(
+        slots=(Slot("balance", SLOT_F64, SRC_PAYLOAD), Slot("largest", SLOT_F64, SRC_PAYLOAD, default=float("-inf")), Slot("n", SLOT_I32, SRC_ONE)),
+        types=((CLS_CREATE, {"balance": OP_SET}), (CLS_REQUIRE, {"balance": OP_ADD, "largest": OP_MAX, "n": OP_ADD}),
+               (CLS_REQUIRE, {"balance": OP_SUB, "largest": OP_MAX, "n": OP_ADD})), count_events=True)
+    n = args.aggregates or 2_000_000
+    lens = synth.zipf_lengths(torch.arange(n, dtype=torch.int64, device=dev), ZIPF_SEED)
+    so = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=so[1:])
+    E = int(so[-1])
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    ty = torch.randint(0, 100, (E,), device=dev, generator=g)
+    ty = torch.where(ty < 3, 0, torch.where(ty < 55, 1, 2)).to(torch.int64)  # 3 % Opened, 52 % Credited, 45 % Debited
+    val = (torch.rand(E, device=dev, generator=g, dtype=torch.float64) * 1e6).view(torch.int64)
+    ev = torch.stack((ty | (torch.arange(E, device=dev) % 1000 + 1) << 32, val), dim=1)
+    del ty, val
+    K, W = args.steps, args.warmup
+    variants, first_states, info_spec, one_shot = {}, None, None, None
+    for build in ("specialised", "interpreter"):
+        os.environ["SURGE_REPLAY_RTC"] = "1" if build == "specialised" else "0"
+        with ReplayEngine(ledger) as eng:
+            info = eng.kernel_info()
+            if build == "specialised":
+                info_spec = info
+                if not info["specialised"]:
+                    raise SystemExit("the schema-specialised kernels are not available: " + info["detail"])
+            out = torch.zeros((n, 64), dtype=torch.uint8, device=dev)
+            eng.load_csr(so, ev, None, out)
+            for algo, label in ((S.ALGO_TILED, "tiled"), (S.ALGO_SLOTS, "csr")):
+                if algo == S.ALGO_TILED:
+                    eng.prepare(algo)
+                    lay = eng.layout_info()
+                    if one_shot is None:
+                        one_shot = {"index_build_ms": lay.index_build_ms, "relayout_ms": lay.relayout_ms, "tile_major_copy_bytes": lay.tiled_bytes,
+                                    "padding_events": lay.padding_events, "schema_compile_ms": info["compile_ms"]}
+                dt, st, times = time_folds(eng, torch, dev, algo, K, W)
+                states = out.clone()
+                if first_states is None:
+                    first_states = states
+                kms = float(np.mean(times))
+                variants[f"{build}/{label}"] = {
+                    "events_per_sec": E * K / dt, "kernel_ms": kms, "kernel_ms_min_median_max": [float(np.min(times)), float(np.median(times)), float(np.max(times))],
+                    "frac": st.algorithmic_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "states_equal_first_variant": bool(torch.equal(states, first_states))}
+                if build == "specialised" and label == "tiled":
+                    primary = (dt, st, times)
+    os.environ.pop("SURGE_REPLAY_RTC", None)
+    dt, st, times = primary
+    kms = float(np.mean(times))
+    cpu_baseline = None
+    if not args.no_cpu_baseline:
+        t0 = time.perf_counter()
+        so_h, ev_h = so.cpu().numpy(), ev.cpu().numpy().view(S.EVENT_DTYPE).reshape(-1)
+        exp = oracle.fold_csr_v2(so_h, ev_h, ledger)
+        cpu_s = time.perf_counter() - t0
+        parity = first_states.cpu().numpy().tobytes() == exp.tobytes()
+        cpu_baseline = {"value": E / cpu_s, "unit": "events/s", "cores": 1, "kind": "port",
+                        "sample": f"the whole log ({E} events, incl. the D2H copy), single-threaded C slot interpreter (oracle_fold_csr_v2)",
+                        "gpu_matches_cpu_full_log": bool(parity)}
+    return {
+        "metric": "events/sec replayed", "value": E * K / dt, "unit": "events/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64 add / sub / Math.max in event order + int32 add",
+        "data": "synthetic (Zipf(1..4096) ledger log generated on the device)",
+        "config": {"workload": f"ABI v2 ledger schema (f64 balance += / -= amount in event order, f64 largest = Math.max, i32 transactions, event_count) "
+                               f"over {n} aggregates, Zipf(1..4096) events each, one lane per aggregate; log resident in HBM",
+                   "aggregates": n, "events": E, "kernels": info_spec["detail"], "variants": variants},
+        "roofline": {"bound": "hbm", "achieved": st.algorithmic_bytes / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": st.algorithmic_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": pmc_traffic("surge_slots_tiled2", st.algorithmic_bytes)[0], "kernel": "surge_slots_tiled2",
+                     "kernel_note": "fold_slots_device.h compiled for the schema by hiprtc at surge_replay_create_v2",
+                     "kernel_ms": kms, "kernel_ms_min_median_max": [float(np.min(times)), float(np.median(times)), float(np.max(times))],
+                     "algorithmic_bytes": st.algorithmic_bytes, "timed_launches": int(len(times))},
+        "one_shot": one_shot,
+        "cpu_baseline": cpu_baseline,
+    }
 
 
 def effective_cpus():

@@ -143,7 +143,8 @@ typedef struct surge_replay_schema {
  * operation per slot.  A model with two counters and a Long version — which v1 cannot express — is three slots.
  *
  *   state (64 B): slot 0..3 at bytes 0, 8, 16, 24 | u32 event_count at 32 | u32 flags at 36 (as in v1) | slot 4..6 at 40, 48, 56
- *                 an I32 slot uses the low 4 bytes of its 8 (the rest stay zero); None is all-zero, as in v1
+ *                 an I32 slot uses the low 4 bytes of its 8 (the rest are zero — also in a prior snapshot handed to load /
+ *                 bind; a fold writes them as zero for every aggregate that has events); None is all-zero, as in v1
  *   slot i:  type  SURGE_SLOT_I32 / _I64 / _F64
  *            source of the operand x of every operation on it:
  *              SURGE_SRC_ARG      (int32) low half of the event payload   (incrementBy)
@@ -156,12 +157,18 @@ typedef struct surge_replay_schema {
  *                  ops[t] = 4 bits per slot, slot i in bits [4i, 4i+4): SURGE_OP_KEEP / ADD / SUB / SET / MIN / MAX
  *   integer ADD / SUB wrap like JVM Int / Long; F64 ADD / SUB are IEEE double operations applied STRICTLY in event
  *   order (the JVM fold's order; the library is built with -ffp-contract=off), so the result is bit-identical to the
- *   sequential fold — no tolerance needed; F64 MIN / MAX are `if (x < cur) x else cur` / `if (x > cur) x else cur`.
+ *   sequential fold — no tolerance needed.  F64 MIN / MAX are java.lang.Math.min(cur, x) / Math.max(cur, x) — what a JVM
+ *   model's `math.min` / `math.max` call — as the JDK's library source states them: a NaN on either side gives that NaN
+ *   (bits preserved), -0.0 orders below +0.0, otherwise `cur <= x ? cur : x` / `cur >= x ? cur : x`.  (HotSpot's
+ *   intrinsic may return a different NaN bit pattern than the library source; the value is NaN either way.)
  * Any mix of operations on one slot is allowed: v2 handles always fold with ONE lane per aggregate (or per
- * micro-batch group) walking its events in order — the sorted-rows transport with a slot interpreter
- * (fold_slots.hip) — so nothing has to be associative.  Everything else of the ABI (load / bind, fold, append_*, get,
- * gather, snapshot, grow, encoders, snapshot_delta, the exchange) works on v2 handles; surge_replay_fold accepts
- * SURGE_ALGO_AUTO only. */
+ * micro-batch group) walking its events in order (fold_slots.hip), so nothing has to be associative.  The kernels are
+ * COMPILED FOR THE SCHEMA when the handle is created (hiprtc, about a second the first time a process sees a schema;
+ * surge_replay_kernel_info): the walk then costs the schema's own arithmetic.  Without libhiprtc — or with
+ * SURGE_REPLAY_RTC=0 — the same device code runs as a generic interpreter (2-3x slower, same results).  Everything
+ * else of the ABI (load / bind, fold, append_*, get, gather, snapshot, grow, encoders, snapshot_delta, the exchange)
+ * works on v2 handles; surge_replay_fold accepts SURGE_ALGO_AUTO (= SURGE_ALGO_SLOTS: the bound CSR log through
+ * length-sorted row pieces) and SURGE_ALGO_TILED (the tile-major copy, rows never cut). */
 #define SURGE_REPLAY_ABI_VERSION_2 2u
 #define SURGE_MAX_SLOTS 7
 #define SURGE_SLOT_I32 1u
@@ -231,7 +238,7 @@ typedef struct surge_replay_schema_v2 {
                               pass (about the time of four folds; surge_replay_layout_info reports it), so it pays when a
                               bound log is folded more than once or is bound ahead of need: never chosen by
                               SURGE_ALGO_AUTO, ask for it (surge_replay_prepare does the copy without folding).  Any
-                              CSR, v1 handles. */
+                              CSR; v2 handles fold the same copy with whole aggregates as rows (nothing cut). */
 
 typedef struct surge_replay_stats_t {
   int64_t n_aggregates;
@@ -263,6 +270,15 @@ typedef struct surge_replay_layout_info_t {
   double  relayout_ms;       /* TILED: the copy into tile-major order                                          */
 } surge_replay_layout_info_t;
 
+/* Which build of the fold kernels a handle runs. */
+typedef struct surge_replay_kernel_info_t {
+  int32_t specialised;   /* 1: kernels compiled at create time for this handle's schema (v2 handles, hiprtc); 0: the
+                            ahead-of-time kernels (every v1 handle; v2: the generic slot interpreter)                 */
+  int32_t reserved;
+  double  compile_ms;    /* wall time of that compilation (shared by every handle of the process with the same schema) */
+  char    detail[240];   /* the libhiprtc that compiled them, or why the interpreter runs instead                      */
+} surge_replay_kernel_info_t;
+
 typedef struct surge_replay_handle surge_replay_handle;
 
 /* ---- lifecycle -------------------------------------------------------------- */
@@ -276,6 +292,11 @@ int32_t surge_replay_create(const surge_replay_schema* schema, int32_t device_id
                             surge_replay_handle** out);
 /* Same, for a v2 slot schema. */
 int32_t surge_replay_create_v2(const surge_replay_schema_v2* schema, int32_t device_id, surge_replay_handle** out);
+int32_t surge_replay_kernel_info(surge_replay_handle* h, surge_replay_kernel_info_t* out);
+/* The code object surge_replay_create_v2 would compile for `schema` on an `arch` device ("gfx950"): needs libhiprtc, no
+ * GPU.  code_out nullable (size query); *code_bytes is set either way.  For build-time checks of a model's schema. */
+int32_t surge_replay_compile_schema_v2(const surge_replay_schema_v2* schema, const char* arch, void* code_out, int64_t capacity,
+                                       int64_t* code_bytes);
 int32_t surge_replay_destroy(surge_replay_handle* h);
 const char* surge_replay_last_error(const surge_replay_handle* h);
 

@@ -217,8 +217,17 @@ static uint64_t slot_apply(const surge_slot_def* sd, uint32_t op, uint64_t cur, 
     switch (op) {
       case SURGE_OP_ADD: r = a + b; break;
       case SURGE_OP_SUB: r = a - b; break;
-      case SURGE_OP_MIN: return b < a ? x : cur;
-      default: return b > a ? x : cur; /* SURGE_OP_MAX */
+      /* java.lang.Math.min(a, b) / Math.max(a, b) as the JDK library source states them (what a Scala model's
+       * math.min / math.max calls): `if (a != a) return a;` then the signed-zero case, then `(a <= b) ? a : b` /
+       * `(a >= b) ? a : b` — so a NaN operand b is returned as is, and -0.0 orders below +0.0. */
+      case SURGE_OP_MIN:
+        if (a != a) return cur;
+        if (a == 0.0 && b == 0.0 && x == 0x8000000000000000ull) return x;
+        return (a <= b) ? cur : x;
+      default: /* SURGE_OP_MAX */
+        if (a != a) return cur;
+        if (a == 0.0 && b == 0.0 && cur == 0x8000000000000000ull) return x;
+        return (a >= b) ? cur : x;
     }
     memcpy(&bits, &r, 8);
     return bits;

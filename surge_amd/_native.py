@@ -11,20 +11,22 @@ import shutil
 import subprocess
 from typing import List, Optional
 
-from .schema import CLayoutInfo, CSchema, CStats
+from .schema import CKernelInfo, CLayoutInfo, CSchema, CStats
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
-SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip", "fold_slots.hip", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "event_decode.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")
-HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "fold_chunk_device.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
+SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip", "fold_slots.hip", "rtc.cpp", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "event_decode.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")
+HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "fold_chunk_device.h"), os.path.join(CSRC, "fold_slots_device.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
 EXPORTS = (
     "surge_replay_default_schema",
     "surge_replay_create",
     "surge_replay_create_v2",
+    "surge_replay_kernel_info",
+    "surge_replay_compile_schema_v2",
     "surge_replay_destroy",
     "surge_replay_last_error",
     "surge_replay_set_stream",
@@ -143,6 +145,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         "-ffp-contract=off",
         "-Wall",
         "-I" + INCLUDE,
+        "-I" + CSRC,  # rtc.cpp embeds the device headers with .incbin
     ]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     tmp = LIB_PATH + ".tmp"
@@ -182,6 +185,8 @@ def load() -> ctypes.CDLL:
         "surge_replay_default_schema": ([ctypes.POINTER(CSchema)], i32),
         "surge_replay_create": ([ctypes.POINTER(CSchema), i32, ctypes.POINTER(vp)], i32),
         "surge_replay_create_v2": ([vp, i32, ctypes.POINTER(vp)], i32),
+        "surge_replay_kernel_info": ([vp, ctypes.POINTER(CKernelInfo)], i32),
+        "surge_replay_compile_schema_v2": ([vp, ctypes.c_char_p, vp, i64, ctypes.POINTER(i64)], i32),
         "surge_replay_destroy": ([vp], i32),
         "surge_replay_last_error": ([vp], ctypes.c_char_p),
         "surge_replay_set_stream": ([vp, vp], i32),

@@ -61,6 +61,9 @@ struct surge_replay_handle {
   bool v2 = false;                     // ABI v2 slot schema: folds only through fold_slots.hip
   surge_replay_schema_v2 schema2{};
   alignas(16) unsigned char slot_params[kSlotParamsBytes] = {};
+  SlotKernels* spec = nullptr;         // v2: the kernels hiprtc compiled for this schema (process-wide cache); nullptr = interpreter
+  double spec_compile_ms = 0.0;
+  std::string spec_why;                // why the interpreter runs instead / which libhiprtc compiled the kernels
   std::string err;
   std::mutex err_mu;  // concurrent point readers may fail at the same time
 
@@ -349,9 +352,10 @@ int32_t run_slots(surge_replay_handle* h, FoldParams& p, const int64_t* off, int
   }
   p.n_seg = n_seg;
   const int64_t groups = (n_seg + kWave - 1) / kWave;
-  // the interpreter is VALU-bound and light on registers (93 VGPRs): 8 KiB tiles and as many resident waves as LDS allows
-  const int le = env_lane_events("SURGE_REPLAY_LE_SLOTS", 8) == 16 ? 16 : 8;
-  int64_t per_cu = le == 8 ? 14 : 8;
+  // the interpreter is VALU-bound and light on registers (93 VGPRs): 8 KiB tiles and as many resident waves as LDS
+  // allows; the schema-specialised kernels keep their tile in registers like the v1 sorted-rows kernel: 16 KiB tiles, 8 waves
+  const int le = env_lane_events("SURGE_REPLAY_LE_SLOTS", h->spec ? 16 : 8) == 16 ? 16 : 8;
+  int64_t per_cu = le == 8 ? (h->spec ? 12 : 14) : 8;
   if (const char* v = std::getenv("SURGE_REPLAY_SLOTS_WAVES")) per_cu = std::atoi(v) > 0 ? std::atoi(v) : per_cu;
   const int64_t slots = (int64_t)h->n_cus * per_cu;
   const int64_t n_waves = groups < slots ? groups : slots;
@@ -359,13 +363,17 @@ int32_t run_slots(surge_replay_handle* h, FoldParams& p, const int64_t* off, int
   const int32_t rc = next_fold_events(h, &e0, &e1);
   if (rc != SURGE_OK) return rc;
   HIPCHK(h, hipEventRecord(e0, h->stream));
-  HIPCHK(h, launch_fold_slots(p, *(const SlotParams*)h->slot_params, n_waves, le, h->stream));
+  HIPCHK(h, launch_fold_slots(p, *(const SlotParams*)h->slot_params, h->spec, n_waves, le, h->stream));
   HIPCHK(h, hipEventRecord(e1, h->stream));
   h->st.n_tasks = (int32_t)n_waves;
   return SURGE_OK;
 }
 
-int32_t fold_slots_bound(surge_replay_handle* h) {
+struct FoldPlan;
+int32_t ensure_index(surge_replay_handle* h, const FoldPlan& pl);
+int32_t run_slots_tiled(surge_replay_handle* h, FoldParams& p);
+
+int32_t fold_slots_bound(surge_replay_handle* h, bool tiled) {
   FoldParams p;
   std::memset(&p, 0, sizeof(p));
   p.events = h->d_events;
@@ -379,7 +387,8 @@ int32_t fold_slots_bound(surge_replay_handle* h) {
     if (h->an.max_len >= (1ll << 31)) return fail(h, SURGE_E_UNSUPPORTED, "segments must be shorter than 2^31 events");
     const bool nz = h->an.n_empty > 0;
     if (nz) p.out_map = (const int64_t*)h->nz_map.ptr;
-    const int32_t rc = run_slots(h, p, nz ? (const int64_t*)h->nz_off.ptr : h->d_seg_off, nz ? h->n_nz : h->n_agg, true);
+    const int32_t rc = tiled ? run_slots_tiled(h, p)
+                             : run_slots(h, p, nz ? (const int64_t*)h->nz_off.ptr : h->d_seg_off, nz ? h->n_nz : h->n_agg, true);
     if (rc != SURGE_OK) return rc;
   } else {
     hipEvent_t e0, e1;
@@ -391,7 +400,7 @@ int32_t fold_slots_bound(surge_replay_handle* h) {
   if (h->an.n_empty > 0 || span == 0) HIPCHK(h, launch_fill_empty(h->d_seg_off, h->n_agg, h->d_init, h->d_state, h->stream));
   HIPCHK(h, hipEventRecord(h->ev_total1, h->stream));
   h->timing_valid = true;
-  h->st.last_algo = SURGE_ALGO_SLOTS;
+  h->st.last_algo = tiled ? SURGE_ALGO_TILED : SURGE_ALGO_SLOTS;
   h->st.n_folds += 1;
   h->st.n_poisoned = -1;
   h->fold_epoch.fetch_add(1);
@@ -460,9 +469,7 @@ int32_t surge_replay_create(const surge_replay_schema* schema, int32_t device_id
   return SURGE_OK;
 }
 
-int32_t surge_replay_create_v2(const surge_replay_schema_v2* sc, int32_t device_id, surge_replay_handle** out) {
-  if (!out) return fail(nullptr, SURGE_E_INVALID, "out is NULL");
-  *out = nullptr;
+static int32_t validate_schema_v2(const surge_replay_schema_v2* sc) {
   if (!sc) return fail(nullptr, SURGE_E_INVALID, "schema is NULL");
   if (sc->abi_version != SURGE_REPLAY_ABI_VERSION_2) return fail(nullptr, SURGE_E_UNSUPPORTED, "schema.abi_version is not 2");
   if (sc->state_size != 64 || sc->event_size != 16) return fail(nullptr, SURGE_E_UNSUPPORTED, "only 64-byte states and 16-byte events are supported");
@@ -481,6 +488,16 @@ int32_t surge_replay_create_v2(const surge_replay_schema_v2* sc, int32_t device_
       if (i >= sc->n_slots && op != SURGE_OP_KEEP) return fail(nullptr, SURGE_E_INVALID, "operation on a slot the schema does not declare");
     }
   }
+  return SURGE_OK;
+}
+
+int32_t surge_replay_create_v2(const surge_replay_schema_v2* sc, int32_t device_id, surge_replay_handle** out) {
+  if (!out) return fail(nullptr, SURGE_E_INVALID, "out is NULL");
+  *out = nullptr;
+  {
+    const int32_t rcv = validate_schema_v2(sc);
+    if (rcv != SURGE_OK) return rcv;
+  }
   surge_replay_schema v1;
   surge_replay_default_schema(&v1);  // the handle's v1 half is inert; every fold of a v2 handle goes through the slot kernel
   const int32_t rc = surge_replay_create(&v1, device_id, out);
@@ -488,6 +505,14 @@ int32_t surge_replay_create_v2(const surge_replay_schema_v2* sc, int32_t device_
   (*out)->v2 = true;
   (*out)->schema2 = *sc;
   slot_params_from_schema(*sc, (SlotParams*)(*out)->slot_params);
+  {
+    // the schema never changes: compile the slot kernels for it (hiprtc, ~1 s the first time a process sees the schema);
+    // any failure leaves the generic interpreter in charge and is reported by surge_replay_kernel_info, not here
+    DeviceGuard g(device_id);
+    surge_replay_handle* h = *out;
+    slot_kernels_acquire(*sc, *(const SlotParams*)h->slot_params, device_id, &h->spec, &h->spec_compile_ms, &h->spec_why);
+    if (h->spec) h->spec_why = std::string("compiled by ") + rtc_library_path();
+  }
   return SURGE_OK;
 }
 
@@ -633,11 +658,16 @@ int32_t plan_fold(surge_replay_handle* h, int32_t algo, FoldPlan& pl) {
   if (!h->bound) return fail(h, SURGE_E_STATE, "fold before load_csr/bind_device_csr");
   if (!h->log_valid) return fail(h, SURGE_E_STATE, "the resident state was grown past the bound log (surge_replay_grow): load a log again");
   if (algo < SURGE_ALGO_AUTO || algo > SURGE_ALGO_TILED) return fail(h, SURGE_E_INVALID, "unknown algo");
-  if (h->v2 != (algo == SURGE_ALGO_SLOTS) && !(h->v2 && algo == SURGE_ALGO_AUTO))
-    return fail(h, SURGE_E_UNSUPPORTED, h->v2 ? "a v2 slot schema folds with SURGE_ALGO_AUTO / SURGE_ALGO_SLOTS only"
+  if (h->v2 != (algo == SURGE_ALGO_SLOTS) && !(h->v2 && (algo == SURGE_ALGO_AUTO || algo == SURGE_ALGO_TILED)))
+    return fail(h, SURGE_E_UNSUPPORTED, h->v2 ? "a v2 slot schema folds with SURGE_ALGO_AUTO / SURGE_ALGO_SLOTS / SURGE_ALGO_TILED only"
                                                : "SURGE_ALGO_SLOTS needs a handle created with surge_replay_create_v2");
   if (h->v2) {
-    pl.use = SURGE_ALGO_SLOTS;
+    // one lane per WHOLE aggregate whatever the transport: the tile-major copy is built with nothing cut
+    pl.use = algo == SURGE_ALGO_TILED ? SURGE_ALGO_TILED : SURGE_ALGO_SLOTS;
+    pl.span = h->an.last - h->an.first;
+    pl.chunk_T = 0x7ffffff8u;
+    if (pl.use == SURGE_ALGO_TILED && h->an.max_len >= (1ll << 31))
+      return fail(h, SURGE_E_UNSUPPORTED, "ALGO_SORTED / ALGO_CHUNKED / ALGO_TILED need segments shorter than 2^31 events");
     return SURGE_OK;
   }
   const int64_t span = h->an.last - h->an.first;
@@ -781,9 +811,69 @@ int32_t ensure_index(surge_replay_handle* h, const FoldPlan& pl) {
   return SURGE_OK;
 }
 
+// v2 over the tile-major copy (rows = whole aggregates, never cut): same launch shape as the v1 tiled fold
+int32_t run_slots_tiled(surge_replay_handle* h, FoldParams& p) {
+  int subs = 2;
+  if (const char* v = std::getenv("SURGE_REPLAY_TILED_SUBS")) subs = std::atoi(v) == 1 ? 1 : 2;
+  const auto& ci = h->tidx;
+  {
+    const int32_t rcd = dispenser_begin(h, p);
+    if (rcd != SURGE_OK) return rcd;
+  }
+  p.n_seg = h->an.n_empty > 0 ? h->n_nz : h->n_agg;
+  const int64_t groups = (ci.n_vrows + kWave - 1) / kWave;
+  int64_t per_cu = subs == 1 ? 8 : 6;
+  if (const char* v = std::getenv("SURGE_REPLAY_TILED_WAVES")) per_cu = std::atoi(v) > 0 ? std::atoi(v) : per_cu;
+  const int64_t slots = (int64_t)h->n_cus * per_cu;
+  const int64_t n_waves = groups < slots ? groups : slots;
+  TileTable t;
+  t.tiles = (const uint4*)h->t_tiles.ptr; t.g_sub0 = (const int64_t*)h->t_gsub.ptr; t.v_len = (const uint32_t*)ci.v_len.ptr;
+  t.v_info = (const uint32_t*)ci.v_info.ptr; t.v_dest = (const int64_t*)ci.v_seg.ptr; t.n_vrows = ci.n_vrows; t.side = nullptr;
+  hipEvent_t e0, e1;
+  const int32_t rc = next_fold_events(h, &e0, &e1);
+  if (rc != SURGE_OK) return rc;
+  HIPCHK(h, hipEventRecord(e0, h->stream));
+  HIPCHK(h, launch_fold_slots_tiled(p, *(const SlotParams*)h->slot_params, h->spec, t, n_waves, subs, h->stream));
+  HIPCHK(h, hipEventRecord(e1, h->stream));
+  h->st.n_tasks = (int32_t)n_waves;
+  return SURGE_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int32_t surge_replay_kernel_info(surge_replay_handle* h, surge_replay_kernel_info_t* out) {
+  if (!h || !out) return fail(h, SURGE_E_INVALID, "NULL argument");
+  std::memset(out, 0, sizeof(*out));
+  out->specialised = h->spec ? 1 : 0;
+  out->compile_ms = h->spec_compile_ms;
+  const std::string d = h->v2 ? h->spec_why : std::string("v1 schema: the ahead-of-time kernels interpret the op table");
+  std::snprintf(out->detail, sizeof(out->detail), "%s", d.c_str());
+  return SURGE_OK;
+}
+
+int32_t surge_replay_compile_schema_v2(const surge_replay_schema_v2* sc, const char* arch, void* code_out, int64_t capacity,
+                                       int64_t* code_bytes) {
+  if (!sc || !arch || !code_bytes) return fail(nullptr, SURGE_E_INVALID, "NULL argument");
+  *code_bytes = 0;
+  {
+    const int32_t rc = validate_schema_v2(sc);
+    if (rc != SURGE_OK) return rc;
+  }
+  alignas(16) unsigned char spb[kSlotParamsBytes] = {};
+  slot_params_from_schema(*sc, (SlotParams*)spb);
+  std::vector<char> code;
+  std::string log;
+  double ms = 0.0;
+  if (!rtc_compile(slots_spec_source(*(const SlotParams*)spb), arch, &code, &log, &ms)) return fail(nullptr, SURGE_E_UNSUPPORTED, log);
+  *code_bytes = (int64_t)code.size();
+  if (code_out) {
+    if (capacity < (int64_t)code.size()) return fail(nullptr, SURGE_E_INVALID, "code_out is too small (see *code_bytes)");
+    std::memcpy(code_out, code.data(), code.size());
+  }
+  return SURGE_OK;
+}
 
 int32_t surge_replay_prepare(surge_replay_handle* h, int32_t algo) {
   if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
@@ -791,7 +881,7 @@ int32_t surge_replay_prepare(surge_replay_handle* h, int32_t algo) {
   FoldPlan pl;
   const int32_t rc = plan_fold(h, algo, pl);
   if (rc != SURGE_OK) return rc;
-  if (h->v2) return SURGE_OK;  // the slot kernel's length order is built by its first fold
+  if (h->v2 && pl.use != SURGE_ALGO_TILED) return SURGE_OK;  // the slot kernel's length order is built by its first fold
   return ensure_index(h, pl);
 }
 
@@ -837,7 +927,13 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
     const int32_t rc = plan_fold(h, algo, pl);
     if (rc != SURGE_OK) return rc;
   }
-  if (h->v2) return fold_slots_bound(h);
+  if (h->v2) {
+    if (pl.use == SURGE_ALGO_TILED) {
+      const int32_t rc = ensure_index(h, pl);
+      if (rc != SURGE_OK) return rc;
+    }
+    return fold_slots_bound(h, pl.use == SURGE_ALGO_TILED);
+  }
   const int64_t span = pl.span;
   const int32_t use = pl.use;
   {

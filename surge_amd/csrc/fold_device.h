@@ -3,7 +3,11 @@
 // transformer composition, the LDS tile geometry and the per-lane event walk.  Everything here is
 // `static`/inline in an anonymous namespace: each translation unit gets its own copy.
 #pragma once
+#ifdef __HIPCC_RTC__  // run-time compiled kernels (fold_slots.hip): device code only, no host declarations
+#include "fold_layout.h"
+#else
 #include "replay_internal.h"
+#endif
 
 namespace surge {
 namespace {

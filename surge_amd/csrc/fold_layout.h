@@ -3,9 +3,22 @@
 // kernel sources to decide whether a committed rocprof traffic figure still describes the code).
 #pragma once
 
+// Also compiled at run time (hiprtc, fold_slots.hip's schema-specialised kernels): hiprtc has no system headers and
+// brings the HIP device runtime with it, so the includes are skipped there and the fixed-width types come from here.
+#ifdef __HIPCC_RTC__
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef short int16_t;
+typedef unsigned short uint16_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long int64_t;
+typedef unsigned long uint64_t;
+#else
 #include <stdint.h>
 
 #include <hip/hip_runtime.h>
+#endif
 
 namespace surge {
 
@@ -72,5 +85,18 @@ struct FoldParams {
   int32_t d_min, d_max;
   uint32_t d_evcount;
 };
+
+// The tile-major copy of a bound log (fold_tiled.hip builds it; fold_tiled.hip and the slot kernels fold it).
+struct TileTable {
+  const uint4* tiles;        // the tile-major log
+  const int64_t* g_sub0;     // n_groups + 1: first subtile of every group
+  const uint32_t* v_len;     // per virtual row: events
+  const uint32_t* v_info;    // VI_*
+  const int64_t* v_dest;     // aggregate index (state array) or side-buffer slot
+  int64_t n_vrows;
+  uint32_t* side;
+};
+constexpr int kSubEvents = 8;                       // events per lane in one subtile
+constexpr int kSubBytes = kWave * kSubEvents * 16;  // 8 KiB
 
 }  // namespace surge

@@ -1,238 +1,36 @@
-// fold_slots.hip — the fold for ABI v2 "slot" schemas (include/surge_replay.h): up to 7 typed 8-byte slots, one
-// operation per slot per event type, ANY mix of operations (ADD / SUB / SET / MIN / MAX, integer or IEEE double).
-//
-// The v1 kernels split aggregates across lanes and waves and therefore need every field to compose associatively; a
-// generic slot schema promises nothing of the sort (an f64 ADD is order-sensitive, ADD followed by MIN followed by ADD
-// on one slot has no closed form).  So this kernel never splits an aggregate: ONE lane walks ONE aggregate's events
-// (or one micro-batch group's) strictly in order with a concrete running state — the sorted-rows transport (length
-// sort at load time, persistent waves pulling groups of 64, LDS-DMA tiles with line-aligned row pieces) around a slot
-// interpreter.  That also makes f64 accumulation bit-identical to the JVM's sequential fold (no tolerance).
-//
-// Interpreter cost control: slot type, operand source and the SET of operations any event type ever applies to a slot
-// are wave-uniform (schema constants), so they are scalar branches; only the operation an individual event applies is
-// per lane (a 4-bit code from a 16-entry LDS table), resolved by selects among the candidates the schema allows.
-#include "fold_device.h"
+// fold_slots.hip — the fold of ABI v2 "slot" schemas (include/surge_replay.h): the kernels' device code lives in
+// fold_slots_device.h (read its header comment first); this file instantiates the GENERIC INTERPRETER ahead of time,
+// and builds, caches and launches the SCHEMA-SPECIALISED kernels that hiprtc compiles from the same source when a v2
+// handle is created (rtc.cpp).
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "fold_slots_device.h"
 
 namespace surge {
-
-struct SlotParams {
-  uint32_t n_slots;
-  uint32_t count_events;
-  uint32_t type[SURGE_MAX_SLOTS];
-  uint32_t source[SURGE_MAX_SLOTS];
-  uint32_t used_ops[SURGE_MAX_SLOTS];  // bit o set: some event type applies SURGE_OP_o to this slot
-  uint64_t def[SURGE_MAX_SLOTS];
-  uint32_t cls[SURGE_MAX_EVENT_TYPES + 2];  // [16] unknown type: throws; [17] null (padding) event
-  uint32_t ops[SURGE_MAX_EVENT_TYPES + 2];
-};
 
 static_assert(sizeof(SlotParams) <= kSlotParamsBytes, "grow kSlotParamsBytes");
 
 namespace {
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-constexpr uint32_t CLS_NULL = 1u << 31;  // the padding event: identity on every state
-
-struct SlotState {
-  uint64_t s[SURGE_MAX_SLOTS];
-  uint32_t evc, fl;
-};
-
-__device__ __forceinline__ SlotState slots_none() {
-  SlotState st;
-#pragma unroll
-  for (int i = 0; i < SURGE_MAX_SLOTS; ++i) st.s[i] = 0ull;
-  st.evc = 0u;
-  st.fl = 0u;
-  return st;
-}
-
-__device__ __forceinline__ SlotState slots_load(const uint4* in, int64_t idx) {
-  const uint64_t* w = (const uint64_t*)(in + idx * 4);
-  SlotState st;
-  st.s[0] = w[0]; st.s[1] = w[1]; st.s[2] = w[2]; st.s[3] = w[3];
-  const uint64_t m = w[4];
-  st.evc = (uint32_t)m;
-  st.fl = (uint32_t)(m >> 32) & (FL_PRESENT | FL_POISONED);
-  st.s[4] = w[5]; st.s[5] = w[6]; st.s[6] = w[7];
-  return st;
-}
-
-__device__ __forceinline__ void slots_store(uint4* out, int64_t idx, const SlotState& st) {
-  const bool pr = (st.fl & FL_PRESENT) != 0u;  // None is canonically all-zero (plus, possibly, the POISONED flag)
-  uint4* o = out + idx * 4;
-  auto lo = [&](int i) { return pr ? (uint32_t)st.s[i] : 0u; };
-  auto hi = [&](int i) { return pr ? (uint32_t)(st.s[i] >> 32) : 0u; };
-  o[0] = make_uint4(lo(0), hi(0), lo(1), hi(1));
-  o[1] = make_uint4(lo(2), hi(2), lo(3), hi(3));
-  o[2] = make_uint4(pr ? st.evc : 0u, st.fl & (FL_PRESENT | FL_POISONED), lo(4), hi(4));
-  o[3] = make_uint4(lo(5), hi(5), lo(6), hi(6));
-}
-
-// one handleEvent step on a concrete state.  cls / ops: the event type's table words (per lane).
-__device__ __forceinline__ void slots_apply(SlotState& st, bool& frozen, uint32_t cls, uint32_t ops, uint32_t seq, uint32_t raw_lo,
-                                            uint32_t raw_hi, const SlotParams& p) {
-  const bool is_null = (cls & CLS_NULL) != 0u;
-  const bool live = !frozen && !is_null;
-  const bool throws = live && (cls & SURGE_D_POISON);
-  frozen = frozen || throws;
-  if (throws) st.fl |= FL_POISONED;
-  const uint32_t c = cls & SURGE_CLS_MASK;
-  const bool go = live && !throws;
-  const bool present = (st.fl & FL_PRESENT) != 0u;
-  const bool del = go && c == SURGE_CLS_DELETE;
-  const bool app = go && c != SURGE_CLS_DELETE && (present || c != SURGE_CLS_REQUIRE);  // REQUIRE-class events skip None
-  const bool rst = app && (c == SURGE_CLS_CREATE || !present);                          // CREATE, or materialising from None
-  if (del) st.fl &= ~FL_PRESENT;
-  if (app) st.fl |= FL_PRESENT;
-  if (rst) st.evc = 0u;
-  if (app && p.count_events) st.evc += 1u;
-#pragma unroll
-  for (int i = 0; i < SURGE_MAX_SLOTS; ++i) {
-    if (i >= (int)p.n_slots) break;  // wave-uniform
-    uint64_t cur = rst ? p.def[i] : st.s[i];
-    const uint32_t ty = p.type[i], src = p.source[i], used = p.used_ops[i];  // wave-uniform
-    const uint32_t op = (ops >> (4 * i)) & 15u;                              // per lane
-    // the operand, in the slot's own type
-    uint64_t x;
-    if (ty == SURGE_SLOT_F64) {
-      double d;
-      if (src == SURGE_SRC_PAYLOAD) d = __longlong_as_double((long long)(((uint64_t)raw_hi << 32) | raw_lo));
-      else if (src == SURGE_SRC_ONE) d = 1.0;
-      else d = (double)(int32_t)(src == SURGE_SRC_SEQ ? seq : raw_lo);
-      x = (uint64_t)__double_as_longlong(d);
-    } else {
-      int64_t v;
-      if (src == SURGE_SRC_PAYLOAD) v = (int64_t)(((uint64_t)raw_hi << 32) | raw_lo);
-      else if (src == SURGE_SRC_ONE) v = 1;
-      else v = (int64_t)(int32_t)(src == SURGE_SRC_SEQ ? seq : raw_lo);
-      x = ty == SURGE_SLOT_I32 ? (uint64_t)(uint32_t)v : (uint64_t)v;
-    }
-    uint64_t r = cur;
-    if (ty == SURGE_SLOT_F64) {
-      const double a = __longlong_as_double((long long)cur), b = __longlong_as_double((long long)x);
-      if (used & (1u << SURGE_OP_ADD)) r = op == SURGE_OP_ADD ? (uint64_t)__double_as_longlong(a + b) : r;
-      if (used & (1u << SURGE_OP_SUB)) r = op == SURGE_OP_SUB ? (uint64_t)__double_as_longlong(a - b) : r;
-      if (used & (1u << SURGE_OP_MIN)) r = (op == SURGE_OP_MIN && b < a) ? x : r;
-      if (used & (1u << SURGE_OP_MAX)) r = (op == SURGE_OP_MAX && b > a) ? x : r;
-    } else if (ty == SURGE_SLOT_I64) {
-      if (used & (1u << SURGE_OP_ADD)) r = op == SURGE_OP_ADD ? cur + x : r;
-      if (used & (1u << SURGE_OP_SUB)) r = op == SURGE_OP_SUB ? cur - x : r;
-      if (used & (1u << SURGE_OP_MIN)) r = (op == SURGE_OP_MIN && (int64_t)x < (int64_t)cur) ? x : r;
-      if (used & (1u << SURGE_OP_MAX)) r = (op == SURGE_OP_MAX && (int64_t)x > (int64_t)cur) ? x : r;
-    } else {
-      const uint32_t a = (uint32_t)cur, b = (uint32_t)x;
-      uint32_t q = a;
-      if (used & (1u << SURGE_OP_ADD)) q = op == SURGE_OP_ADD ? a + b : q;
-      if (used & (1u << SURGE_OP_SUB)) q = op == SURGE_OP_SUB ? a - b : q;
-      if (used & (1u << SURGE_OP_MIN)) q = (op == SURGE_OP_MIN && (int32_t)b < (int32_t)a) ? b : q;
-      if (used & (1u << SURGE_OP_MAX)) q = (op == SURGE_OP_MAX && (int32_t)b > (int32_t)a) ? b : q;
-      r = (uint64_t)q;
-    }
-    if (used & (1u << SURGE_OP_SET)) r = op == SURGE_OP_SET ? x : r;
-    st.s[i] = app ? r : st.s[i];
-  }
-}
-
 template <int LE>
 __global__ void __launch_bounds__(kWave) fold_slots_kernel(const FoldParams p, const SlotParams sp) {
-  using G = Geo<LE>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* lds_ev = smem;
-  int64_t* lds_rs = (int64_t*)(smem + G::kTileBytes);
-  uint32_t* lds_len = (uint32_t*)(smem + G::kTileBytes + kWave * 8);
-  uint32_t* lds_cls = (uint32_t*)(smem + G::kTileBytes + G::kAuxSorted);  // 18 class words then 18 op words
-  uint32_t* lds_ops = lds_cls + SURGE_MAX_EVENT_TYPES + 2;
-  const int lane = threadIdx.x;
-  if (lane < SURGE_MAX_EVENT_TYPES + 2) {
-    lds_cls[lane] = sp.cls[lane];
-    lds_ops[lane] = sp.ops[lane];
-  }
-  const uint32_t ev_row = G::ev_row(lane);
-  const int64_t n_groups = (p.n_seg + kWave - 1) / kWave;
-  const int64_t* perm = p.plan;
+  const SlotSchema sc{sp};
+  fold_slots_csr_body<LE>(p, sc, smem);
+}
 
-  auto grab = [&]() -> int64_t {
-    unsigned long long g = 0;
-    if (lane == 0) g = atomicAdd(p.counter, 1ull);
-    return (int64_t)(((uint64_t)rl((uint32_t)(g >> 32), 0) << 32) | rl((uint32_t)g, 0));
-  };
-  struct Meta { int64_t s, start; uint32_t len, pad; };
-  auto load_meta = [&](int64_t g) -> Meta {
-    Meta m; m.s = -1; m.start = 0; m.len = 0u; m.pad = 0u;
-    const int64_t idx = g * kWave + lane;
-    if (g < n_groups && idx < p.n_seg) {
-      m.s = perm[idx];
-      const int64_t st = p.seg_off[m.s];
-      m.pad = (uint32_t)(st & 7);
-      m.start = st - m.pad;  // tiled from the 128-byte line that holds the first event (as the sorted-rows kernel)
-      m.len = (uint32_t)(p.seg_off[m.s + 1] - st) + m.pad;
-    }
-    return m;
-  };
-
-  int64_t g = grab();
-  Meta cur = load_meta(g);
-  while (g < n_groups) {
-    const int64_t g_next = grab();
-    const Meta nxt = load_meta(g_next);
-    uint32_t maxlen = cur.len, minlen = cur.s >= 0 ? cur.len : 0xffffffffu;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, d, 64));
-      minlen = min(minlen, (uint32_t)__shfl_xor((int)minlen, d, 64));
-    }
-    const int n_tiles = (int)((maxlen + LE - 1) / LE);
-    lds_rs[lane] = cur.start;
-    lds_len[lane] = cur.len;
-    auto issue = [&](int c) {
-#pragma unroll
-      for (int q = 0; q < G::kLoads; ++q) {  // never read past a row's own events
-        const int r = G::kRowsPerLoad * q + lane / LE;
-        const uint32_t rlen = lds_len[r];
-        uint32_t j = (uint32_t)c * LE + G::load_j(lane, q % G::kClasses);
-        const uint32_t lastj = rlen ? rlen - 1u : 0u;
-        j = j < lastj ? j : lastj;
-        __builtin_amdgcn_global_load_lds((gptr_t)(p.events + (lds_rs[r] + j)), (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
-      }
-    };
-    const int64_t oi = cur.s >= 0 ? (p.out_map ? p.out_map[cur.s] : cur.s) : -1;
-    SlotState st = (p.init && oi >= 0) ? slots_load(p.init, oi) : slots_none();
-    bool frozen = (st.fl & FL_POISONED) != 0u;
-    issue(0);
-    for (int c = 0; c < n_tiles; ++c) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      // The interpreter is a ROLLED loop over my LE events, each read from LDS when its turn comes (one ahead): unrolling
-      // 16 events x 7 slots x 3 value types made ~190 KB of code, far beyond the instruction cache, and holding the tile in
-      // registers to free the buffer early cost a 45-select chain per event.  So, unlike the v1 kernels, the next tile is
-      // fetched AFTER this one is walked — the interpreter is VALU-bound, the other resident waves cover the latency.
-      const int32_t rem = (int32_t)cur.len - c * LE;
-      const int32_t skip = c == 0 ? (int32_t)cur.pad : 0;
-      uint4 e_n = *(const uint4*)(lds_ev + ev_row);
-      uint32_t t_n = (0 >= skip && 0 < rem) ? (e_n.x < 16u ? e_n.x : 16u) : 17u;
-      uint32_t cls_n = lds_cls[t_n], ops_n = lds_ops[t_n];
-#pragma unroll 2
-      for (int j = 0; j < LE; ++j) {
-        const uint4 e = e_n;
-        const uint32_t cls = cls_n, ops = ops_n;
-        if (j + 1 < LE) {
-          e_n = *(const uint4*)(lds_ev + (ev_row ^ (uint32_t)((j + 1) * 16)));
-          t_n = (j + 1 >= skip && j + 1 < rem) ? (e_n.x < 16u ? e_n.x : 16u) : 17u;
-          cls_n = lds_cls[t_n];
-          ops_n = lds_ops[t_n];
-        }
-        slots_apply(st, frozen, cls, ops, e.y, e.z, e.w, sp);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (c + 1 < n_tiles) issue(c + 1);
-    }
-    if (oi >= 0) slots_store(p.out, oi, st);
-    g = g_next;
-    cur = nxt;
-  }
-  dispenser_leave(p.counter, lane);
+template <int SUBS>
+__global__ void __launch_bounds__(kWave) fold_slots_tiled_kernel(const FoldParams p, const TileTable t, const SlotParams sp) {
+  __shared__ __attribute__((aligned(16))) char lds_ev[SUBS * kSubBytes];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_tab[kTableLdsDwords];
+  const SlotSchema sc{sp};
+  fold_slots_tiled_body<SUBS>(p, t, sc, lds_ev, lds_tab);
 }
 
 }  // namespace
@@ -254,18 +52,195 @@ void slot_params_from_schema(const surge_replay_schema_v2& sc, SlotParams* out) 
   for (uint32_t t = 0; t < sc.n_types && t < SURGE_MAX_EVENT_TYPES; ++t) {
     p.cls[t] = sc.cls[t] & (SURGE_CLS_MASK | SURGE_D_POISON);
     p.ops[t] = sc.ops[t];
-    for (uint32_t i = 0; i < sc.n_slots; ++i) p.used_ops[i] |= 1u << ((sc.ops[t] >> (4 * i)) & 15u);
+    const bool applies = !(p.cls[t] & SURGE_D_POISON) && (p.cls[t] & SURGE_CLS_MASK) != SURGE_CLS_DELETE;
+    for (uint32_t i = 0; i < sc.n_slots; ++i)
+      if (applies) p.used_ops[i] |= 1u << ((sc.ops[t] >> (4 * i)) & 15u);
   }
-  p.cls[SURGE_MAX_EVENT_TYPES + 1] = 1u << 31;  // [17]: the null event
+  p.cls[SURGE_MAX_EVENT_TYPES + 1] = CLS_NULL;  // [17]: the null event
   *out = p;
 }
 
-hipError_t launch_fold_slots(const FoldParams& p, const SlotParams& sp, int64_t n_waves, int lane_events, hipStream_t stream) {
+// ---- the schema-specialised build ---------------------------------------------------------------------------------
+struct SlotKernels {
+  hipModule_t module = nullptr;
+  hipFunction_t csr8 = nullptr, csr16 = nullptr, tiled1 = nullptr, tiled2 = nullptr;
+  int device = 0;
+  double compile_ms = 0.0;
+};
+
+// The program handed to hiprtc: the ABI constants the device code names, the schema as SURGE_SPEC_* macros (ternary
+// chains over an index that is a constant after unrolling), the shared device header, four extern "C" entry points.
+std::string slots_spec_source(const SlotParams& sp) {
+  std::string s;
+  char b[256];
+  auto def = [&](const char* name, unsigned long long v, const char* suffix) {
+    std::snprintf(b, sizeof b, "#define %s %llu%s\n", name, v, suffix);
+    s += b;
+  };
+#define SURGE_EMIT(name) def(#name, (unsigned long long)(name), "u")
+  SURGE_EMIT(SURGE_MAX_SLOTS);
+  SURGE_EMIT(SURGE_MAX_EVENT_TYPES);
+  SURGE_EMIT(SURGE_CLS_MATERIALIZE); SURGE_EMIT(SURGE_CLS_REQUIRE); SURGE_EMIT(SURGE_CLS_CREATE); SURGE_EMIT(SURGE_CLS_DELETE);
+  SURGE_EMIT(SURGE_CLS_MASK); SURGE_EMIT(SURGE_D_POISON);
+  SURGE_EMIT(SURGE_SLOT_I32); SURGE_EMIT(SURGE_SLOT_I64); SURGE_EMIT(SURGE_SLOT_F64);
+  SURGE_EMIT(SURGE_SRC_ARG); SURGE_EMIT(SURGE_SRC_SEQ); SURGE_EMIT(SURGE_SRC_PAYLOAD); SURGE_EMIT(SURGE_SRC_ONE);
+  SURGE_EMIT(SURGE_OP_KEEP); SURGE_EMIT(SURGE_OP_ADD); SURGE_EMIT(SURGE_OP_SUB); SURGE_EMIT(SURGE_OP_SET); SURGE_EMIT(SURGE_OP_MIN);
+  SURGE_EMIT(SURGE_OP_MAX);
+#undef SURGE_EMIT
+  // MAX_SLOTS / MAX_EVENT_TYPES size arrays: they must be plain ints
+  s += "#undef SURGE_MAX_SLOTS\n#undef SURGE_MAX_EVENT_TYPES\n";
+  def("SURGE_MAX_SLOTS", SURGE_MAX_SLOTS, "");
+  def("SURGE_MAX_EVENT_TYPES", SURGE_MAX_EVENT_TYPES, "");
+  s += "#define SURGE_SLOTS_SPEC 1\n";
+  def("SURGE_SPEC_N_SLOTS", sp.n_slots, "u");
+  def("SURGE_SPEC_COUNT_EVENTS", sp.count_events, "u");
+  auto chain = [&](const char* name, int n, auto value, const char* suffix) {
+    s += std::string("#define ") + name + "(i) (";
+    for (int i = 0; i < n; ++i) {
+      std::snprintf(b, sizeof b, "(i) == %d ? %llu%s : ", i, (unsigned long long)value(i), suffix);
+      s += b;
+    }
+    s += std::string("0") + suffix + ")\n";
+  };
+  chain("SURGE_SPEC_TYPE", SURGE_MAX_SLOTS, [&](int i) { return sp.type[i]; }, "u");
+  chain("SURGE_SPEC_SOURCE", SURGE_MAX_SLOTS, [&](int i) { return sp.source[i]; }, "u");
+  chain("SURGE_SPEC_USED", SURGE_MAX_SLOTS, [&](int i) { return sp.used_ops[i]; }, "u");
+  chain("SURGE_SPEC_DEF", SURGE_MAX_SLOTS, [&](int i) { return sp.def[i]; }, "ul");
+  chain("SURGE_SPEC_CLS", SURGE_MAX_EVENT_TYPES + 2, [&](int t) { return sp.cls[t]; }, "u");
+  chain("SURGE_SPEC_OPS", SURGE_MAX_EVENT_TYPES + 2, [&](int t) { return sp.ops[t]; }, "u");
+  s += R"SRC(
+#include "fold_slots_device.h"
+using namespace surge;
+extern "C" __global__ void __launch_bounds__(64) surge_slots_csr8(const FoldParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  fold_slots_csr_body<8>(p, SlotSchema{}, smem);
+}
+extern "C" __global__ void __launch_bounds__(64) surge_slots_csr16(const FoldParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  fold_slots_csr_body<16>(p, SlotSchema{}, smem);
+}
+extern "C" __global__ void __launch_bounds__(64) surge_slots_tiled1(const FoldParams p, const TileTable t) {
+  __shared__ __attribute__((aligned(16))) char lds_ev[kSubBytes];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_tab[kTableLdsDwords];
+  fold_slots_tiled_body<1>(p, t, SlotSchema{}, lds_ev, lds_tab);
+}
+extern "C" __global__ void __launch_bounds__(64) surge_slots_tiled2(const FoldParams p, const TileTable t) {
+  __shared__ __attribute__((aligned(16))) char lds_ev[2 * kSubBytes];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_tab[kTableLdsDwords];
+  fold_slots_tiled_body<2>(p, t, SlotSchema{}, lds_ev, lds_tab);
+}
+)SRC";
+  return s;
+}
+
+namespace {
+
+std::mutex g_spec_mu;
+// key: device + the SlotParams bytes (everything the generated source depends on); entries live as long as the process
+// (a handful of schemas per host; a module is a few tens of KB)
+std::map<std::string, std::unique_ptr<SlotKernels>> g_spec_cache;
+std::map<std::string, std::string> g_spec_failed;  // key -> why (never retried: the answer will not change)
+
+}  // namespace
+
+void slot_kernels_acquire(const surge_replay_schema_v2& sc, const SlotParams& sp, int device, SlotKernels** out, double* compile_ms,
+                          std::string* why) {
+  (void)sc;
+  *out = nullptr;
+  *compile_ms = 0.0;
+  if (const char* v = std::getenv("SURGE_REPLAY_RTC")) {
+    if (std::atoi(v) == 0) {
+      *why = "disabled by SURGE_REPLAY_RTC=0";
+      return;
+    }
+  }
+  std::string key((const char*)&sp, sizeof(sp));
+  key += "@" + std::to_string(device);
+  std::lock_guard<std::mutex> lk(g_spec_mu);
+  auto hit = g_spec_cache.find(key);
+  if (hit != g_spec_cache.end()) {
+    *out = hit->second.get();
+    *compile_ms = hit->second->compile_ms;
+    return;
+  }
+  auto miss = g_spec_failed.find(key);
+  if (miss != g_spec_failed.end()) {
+    *why = miss->second;
+    return;
+  }
+  auto give_up = [&](const std::string& m) {
+    g_spec_failed[key] = m;
+    *why = m;
+  };
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return give_up("hipGetDeviceProperties failed");
+  std::string arch = prop.gcnArchName;  // "gfx950:sramecc+:xnack-"
+  const size_t colon = arch.find(':');
+  if (colon != std::string::npos) arch.resize(colon);
+  std::vector<char> code;
+  std::string log;
+  double ms = 0.0;
+  if (!rtc_compile(slots_spec_source(sp), arch.c_str(), &code, &log, &ms)) return give_up(log);
+  auto k = std::make_unique<SlotKernels>();
+  k->device = device;
+  k->compile_ms = ms;
+  hipError_t e = hipModuleLoadData(&k->module, code.data());
+  if (e != hipSuccess) return give_up(std::string("hipModuleLoadData: ") + hipGetErrorString(e));
+  struct { hipFunction_t* f; const char* name; int lds; } fns[] = {
+      {&k->csr8, "surge_slots_csr8", Geo<8>::lds_bytes(Geo<8>::kAuxSorted)},
+      {&k->csr16, "surge_slots_csr16", Geo<16>::lds_bytes(Geo<16>::kAuxSorted)},
+      {&k->tiled1, "surge_slots_tiled1", 0},
+      {&k->tiled2, "surge_slots_tiled2", 0}};
+  for (auto& f : fns) {
+    e = hipModuleGetFunction(f.f, k->module, f.name);
+    if (e != hipSuccess) {
+      (void)hipModuleUnload(k->module);
+      return give_up(std::string("hipModuleGetFunction(") + f.name + "): " + hipGetErrorString(e));
+    }
+  }
+  *compile_ms = ms;
+  *out = k.get();
+  g_spec_cache[key] = std::move(k);
+}
+
+namespace {
+
+hipError_t launch_module_kernel(hipFunction_t f, unsigned grid, unsigned lds, hipStream_t stream, void* args, size_t args_bytes) {
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &args_bytes, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(f, grid, 1, 1, kWave, 1, 1, lds, stream, nullptr, config);
+}
+
+}  // namespace
+
+hipError_t launch_fold_slots(const FoldParams& p, const SlotParams& sp, const SlotKernels* spec, int64_t n_waves, int lane_events,
+                             hipStream_t stream) {
   if (n_waves <= 0) return hipSuccess;
+  const unsigned lds = lane_events == 8 ? Geo<8>::lds_bytes(Geo<8>::kAuxSorted) : Geo<16>::lds_bytes(Geo<16>::kAuxSorted);
+  if (spec) {
+    FoldParams args = p;
+    return launch_module_kernel(lane_events == 8 ? spec->csr8 : spec->csr16, (unsigned)n_waves, lds, stream, &args, sizeof(args));
+  }
   if (lane_events == 8)
-    hipLaunchKernelGGL((fold_slots_kernel<8>), dim3((unsigned)n_waves), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxSorted), stream, p, sp);
+    hipLaunchKernelGGL((fold_slots_kernel<8>), dim3((unsigned)n_waves), dim3(kWave), lds, stream, p, sp);
   else
-    hipLaunchKernelGGL((fold_slots_kernel<16>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxSorted), stream, p, sp);
+    hipLaunchKernelGGL((fold_slots_kernel<16>), dim3((unsigned)n_waves), dim3(kWave), lds, stream, p, sp);
+  return hipGetLastError();
+}
+
+hipError_t launch_fold_slots_tiled(const FoldParams& p, const SlotParams& sp, const SlotKernels* spec, const TileTable& t, int64_t n_waves,
+                                   int subs, hipStream_t stream) {
+  if (n_waves <= 0 || t.n_vrows <= 0) return hipSuccess;
+  if (spec) {
+    struct Args { FoldParams p; TileTable t; } args;  // the kernel-argument segment: both structs are 8-byte aligned
+    static_assert(sizeof(FoldParams) % 8 == 0, "TileTable must follow FoldParams without padding");
+    args.p = p;
+    args.t = t;
+    return launch_module_kernel(subs == 1 ? spec->tiled1 : spec->tiled2, (unsigned)n_waves, 0, stream, &args, sizeof(args));
+  }
+  if (subs == 1)
+    hipLaunchKernelGGL((fold_slots_tiled_kernel<1>), dim3((unsigned)n_waves), dim3(kWave), 0, stream, p, t, sp);
+  else
+    hipLaunchKernelGGL((fold_slots_tiled_kernel<2>), dim3((unsigned)n_waves), dim3(kWave), 0, stream, p, t, sp);
   return hipGetLastError();
 }
 

@@ -35,8 +35,6 @@
 namespace surge {
 namespace {
 
-constexpr int kSubEvents = 8;                       // events per lane in one subtile
-constexpr int kSubBytes = kWave * kSubEvents * 16;  // 8 KiB
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 // one wave per group: subtiles of the group (from its longest row)
@@ -86,16 +84,6 @@ __global__ void __launch_bounds__(256) relayout_kernel(const uint4* __restrict__
     }
   }
 }
-
-struct TileTable {
-  const uint4* tiles;        // the tile-major log
-  const int64_t* g_sub0;     // n_groups + 1: first subtile of every group
-  const uint32_t* v_len;     // per virtual row: events
-  const uint32_t* v_info;    // VI_*
-  const int64_t* v_dest;     // aggregate index (state array) or side-buffer slot
-  int64_t n_vrows;
-  uint32_t* side;
-};
 
 // SUBS subtiles per step: 1 = 8 events per lane per step (8 KiB in flight per wave, up to 4 waves per SIMD), 2 = 16 events
 // (16 KiB, up to 3 waves per SIMD).

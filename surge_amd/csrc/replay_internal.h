@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/surge_replay.h"
 #include "fold_layout.h"
@@ -75,9 +76,21 @@ hipError_t launch_snapshot_delta(const uint4* states, uint4* published, int64_t 
 
 // ---- fold_slots.hip: the fold of ABI v2 slot schemas ------------------------------------------------------------
 struct SlotParams;
+struct SlotKernels;
 constexpr size_t kSlotParamsBytes = 512;  // >= sizeof(SlotParams): the engine keeps it as opaque storage
 void slot_params_from_schema(const surge_replay_schema_v2& sc, SlotParams* out);
-hipError_t launch_fold_slots(const FoldParams& p, const SlotParams& sp, int64_t n_waves, int lane_events, hipStream_t stream);
+hipError_t launch_fold_slots(const FoldParams& p, const SlotParams& sp, const SlotKernels* spec, int64_t n_waves, int lane_events,
+                             hipStream_t stream);
+// Schema-specialised build of the slot kernels (hiprtc; rtc.cpp + fold_slots.hip).  A SlotKernels object is shared by
+// every handle of the process with the same schema on the same device; nullptr = the interpreter.
+bool rtc_compile(const std::string& source, const char* arch, std::vector<char>* code, std::string* log, double* ms);
+const char* rtc_library_path();
+std::string slots_spec_source(const SlotParams& sp);  // the program handed to hiprtc for this schema
+// never fails the caller: on any problem *out stays nullptr and *why says what happened
+void slot_kernels_acquire(const surge_replay_schema_v2& sc, const SlotParams& sp, int device, SlotKernels** out, double* compile_ms,
+                          std::string* why);
+hipError_t launch_fold_slots_tiled(const FoldParams& p, const SlotParams& sp, const SlotKernels* spec, const TileTable& t, int64_t n_waves,
+                                   int subs, hipStream_t stream);
 // unpack == false: in = n x 64 B, out = n x 40 B; unpack == true: in = n x 40 B, out = n x 64 B
 hipError_t launch_pack_states(const void* in, int64_t n, void* out, bool unpack, hipStream_t stream);
 hipError_t launch_gather_states(const uint4* states, const int64_t* idx, int64_t n, uint4* out, hipStream_t stream);

@@ -1,0 +1,157 @@
+// rtc.cpp — run-time compilation of schema-specialised kernels (host side, no HIP runtime calls here).
+//
+// The ABI v2 slot fold is an interpreter when compiled ahead of time: slot types, operand sources and the operations a
+// schema uses are kernel arguments.  A handle's schema never changes, so surge_replay_create_v2 compiles the same
+// device source (fold_slots_device.h, embedded below byte for byte) once more with the schema as constants:
+// hiprtc -> a gfx950 code object -> hipModuleLoadData (fold_slots.hip).  libhiprtc is dlopen'ed on first use — hosts
+// without it keep the interpreter (surge_replay_kernel_info says which one a handle runs).
+#include <dlfcn.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+
+// The device sources, embedded at build time (the assembler's .incbin finds them through -I surge_amd/csrc).  hipcc
+// compiles this file as HIP too: the blobs belong to the host pass only.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SURGE_EMBED(sym, file) extern "C" const char sym[];
+#else
+#define SURGE_EMBED(sym, file)                                                                                         \
+  __asm__(".pushsection .rodata\n.balign 16\n.hidden " #sym "\n.global " #sym "\n" #sym ":\n.incbin \"" file "\"\n.byte 0\n" \
+          ".popsection\n");                                                                                            \
+  extern "C" const char sym[];
+#endif
+SURGE_EMBED(surge_src_fold_layout_h, "fold_layout.h")
+SURGE_EMBED(surge_src_fold_device_h, "fold_device.h")
+SURGE_EMBED(surge_src_fold_slots_device_h, "fold_slots_device.h")
+
+namespace surge {
+namespace {
+
+typedef struct _hiprtcProgram* hiprtcProgram;
+struct RtcApi {
+  void* lib = nullptr;
+  std::string path, why;
+  int (*CreateProgram)(hiprtcProgram*, const char*, const char*, int, const char* const*, const char* const*) = nullptr;
+  int (*CompileProgram)(hiprtcProgram, int, const char* const*) = nullptr;
+  int (*GetProgramLogSize)(hiprtcProgram, size_t*) = nullptr;
+  int (*GetProgramLog)(hiprtcProgram, char*) = nullptr;
+  int (*GetCodeSize)(hiprtcProgram, size_t*) = nullptr;
+  int (*GetCode)(hiprtcProgram, char*) = nullptr;
+  int (*DestroyProgram)(hiprtcProgram*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+
+std::mutex g_rtc_mu;
+RtcApi g_rtc;
+bool g_rtc_tried = false;
+
+// libhiprtc: SURGE_HIPRTC_LIBRARY, then the copy that sits beside the HIP runtime this process already uses (PyTorch
+// ships its own pair), then the loader's search path, then /opt/rocm.
+bool load_rtc_locked() {
+  if (g_rtc_tried) return g_rtc.lib != nullptr;
+  g_rtc_tried = true;
+  std::vector<std::string> cands;
+  if (const char* v = std::getenv("SURGE_HIPRTC_LIBRARY")) cands.push_back(v);
+  {
+    Dl_info info;
+    void* hip_fn = dlsym(RTLD_DEFAULT, "hipGetDeviceCount");
+    if (hip_fn && dladdr(hip_fn, &info) && info.dli_fname) {
+      std::string dir = info.dli_fname;
+      const size_t slash = dir.rfind('/');
+      if (slash != std::string::npos) cands.push_back(dir.substr(0, slash + 1) + "libhiprtc.so");
+    }
+  }
+  cands.push_back("libhiprtc.so");
+  cands.push_back("/opt/rocm/lib/libhiprtc.so");
+  for (const std::string& c : cands) {
+    void* lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!lib) {
+      g_rtc.why += c + ": " + (dlerror() ? dlerror() : "?") + "; ";
+      continue;
+    }
+    RtcApi a;
+    a.lib = lib;
+    a.path = c;
+    bool ok = true;
+    auto sym = [&](const char* n) -> void* {
+      void* p = dlsym(lib, n);
+      if (!p) ok = false;
+      return p;
+    };
+    a.CreateProgram = (decltype(a.CreateProgram))sym("hiprtcCreateProgram");
+    a.CompileProgram = (decltype(a.CompileProgram))sym("hiprtcCompileProgram");
+    a.GetProgramLogSize = (decltype(a.GetProgramLogSize))sym("hiprtcGetProgramLogSize");
+    a.GetProgramLog = (decltype(a.GetProgramLog))sym("hiprtcGetProgramLog");
+    a.GetCodeSize = (decltype(a.GetCodeSize))sym("hiprtcGetCodeSize");
+    a.GetCode = (decltype(a.GetCode))sym("hiprtcGetCode");
+    a.DestroyProgram = (decltype(a.DestroyProgram))sym("hiprtcDestroyProgram");
+    a.GetErrorString = (decltype(a.GetErrorString))sym("hiprtcGetErrorString");
+    if (!ok) {
+      g_rtc.why += c + ": missing hiprtc symbols; ";
+      dlclose(lib);
+      continue;
+    }
+    const std::string why = g_rtc.why;
+    g_rtc = a;
+    g_rtc.why = why;
+    return true;
+  }
+  return false;
+}
+
+}  // namespace
+
+// Compile `source` (which #includes the embedded headers by their file names) for `arch`.  Returns false with *log set
+// on any failure.  ms: wall time of the compilation.
+bool rtc_compile(const std::string& source, const char* arch, std::vector<char>* code, std::string* log, double* ms) {
+  std::lock_guard<std::mutex> lk(g_rtc_mu);
+  if (!load_rtc_locked()) {
+    *log = "libhiprtc not available: " + g_rtc.why;
+    return false;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  const char* headers[] = {surge_src_fold_layout_h, surge_src_fold_device_h, surge_src_fold_slots_device_h};
+  const char* names[] = {"fold_layout.h", "fold_device.h", "fold_slots_device.h"};
+  hiprtcProgram prog = nullptr;
+  int rc = g_rtc.CreateProgram(&prog, source.c_str(), "surge_slots_spec.hip", 3, headers, names);
+  if (rc != 0) {
+    *log = std::string("hiprtcCreateProgram: ") + g_rtc.GetErrorString(rc);
+    return false;
+  }
+  const std::string arch_opt = std::string("--offload-arch=") + arch;
+  // -ffp-contract=off: an f64 ADD must round exactly like the JVM's (no fused multiply-add anywhere near it)
+  const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
+  rc = g_rtc.CompileProgram(prog, 4, opts);
+  size_t ls = 0;
+  if (g_rtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
+    log->assign(ls, '\0');
+    g_rtc.GetProgramLog(prog, &(*log)[0]);
+    while (!log->empty() && log->back() == '\0') log->pop_back();
+  }
+  bool ok = rc == 0;
+  if (!ok) *log = std::string("hiprtcCompileProgram: ") + g_rtc.GetErrorString(rc) + "\n" + *log;
+  if (ok) {
+    size_t cs = 0;
+    ok = g_rtc.GetCodeSize(prog, &cs) == 0 && cs > 0;
+    if (ok) {
+      code->resize(cs);
+      ok = g_rtc.GetCode(prog, code->data()) == 0;
+    }
+    if (!ok) *log = "hiprtcGetCode failed";
+  }
+  g_rtc.DestroyProgram(&prog);
+  *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return ok;
+}
+
+const char* rtc_library_path() {
+  std::lock_guard<std::mutex> lk(g_rtc_mu);
+  return g_rtc.lib ? g_rtc.path.c_str() : "";
+}
+
+}  // namespace surge

@@ -22,6 +22,7 @@ from .schema import (
     DEFAULT_ALGEBRA,
     EVENT_DTYPE,
     STATE_DTYPE,
+    CKernelInfo,
     CLayoutInfo,
     CSchema,
     CStats,
@@ -170,6 +171,13 @@ class ReplayEngine:
         info = CLayoutInfo()
         self._check(self._lib.surge_replay_layout_info(self._h, ctypes.byref(info)))
         return info
+
+    def kernel_info(self) -> dict:
+        """Which build of the fold kernels this handle runs (``surge_replay_kernel_info``): v2 handles run kernels
+        compiled for their schema at create time when libhiprtc is present."""
+        info = CKernelInfo()
+        self._check(self._lib.surge_replay_kernel_info(self._h, ctypes.byref(info)))
+        return {"specialised": bool(info.specialised), "compile_ms": float(info.compile_ms), "detail": info.detail.decode(errors="replace")}
 
     def append_fold(self, group_agg, group_off, events) -> None:
         """Micro-batch re-fold onto the resident state (K3); see ``surge_replay_append_fold``."""

@@ -139,6 +139,17 @@ class CLayoutInfo(ctypes.Structure):
     ]
 
 
+class CKernelInfo(ctypes.Structure):
+    """``surge_replay_kernel_info_t``: which build of the fold kernels a handle runs."""
+
+    _fields_ = [
+        ("specialised", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("compile_ms", ctypes.c_double),
+        ("detail", ctypes.c_char * 240),
+    ]
+
+
 assert ctypes.sizeof(CState64) == STATE_SIZE
 assert ctypes.sizeof(CSchema) == 16 + 4 * MAX_EVENT_TYPES + STATE_SIZE
 
