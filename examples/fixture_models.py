@@ -431,20 +431,16 @@ class BankAccountCommandModel(ReplayableCommandModel[BankAccount, object, object
 class BankAccountFormat(SurgeAggregateFormatting[BankAccount]):
     """``BankAccountSurgeModel`` formats (``.../docs/command/BankAccountSurgeModel.scala:22-32``).
 
-    play-json's text for ``Double`` is parity-unpinned: compare parsed values.
+    ``balance`` is written as play-json 2.9.2 writes a Scala ``Double`` (shortest round-trip digits through
+    ``BigDecimal``: ``100.0`` -> ``100``; ``surge_amd/csrc/f64_text.h``), the same conversion the GPU encoder runs.
     """
 
     def write_state(self, agg: BankAccount) -> SerializedAggregate:
-        text = json.dumps(
-            {
-                "accountNumber": str(agg.accountNumber),
-                "accountOwner": agg.accountOwner,
-                "securityCode": agg.securityCode,
-                "balance": agg.balance,
-            },
-            separators=(",", ":"),
-            ensure_ascii=False,
-        )
+        from surge_amd.encode import play_json_double
+
+        q = lambda v: json.dumps(v, ensure_ascii=False)  # noqa: E731  Jackson's default string escaping
+        text = (f'{{"accountNumber":{q(str(agg.accountNumber))},"accountOwner":{q(agg.accountOwner)},'
+                f'"securityCode":{q(agg.securityCode)},"balance":{play_json_double(agg.balance)}}}')
         return SerializedAggregate(text.encode("utf-8"), {"aggregate_id": str(agg.accountNumber)})
 
     def read_state(self, data: bytes) -> Optional[BankAccount]:

@@ -398,18 +398,37 @@ int32_t surge_replay_device_state(surge_replay_handle* h, void** d_states, int64
  * (TestBoundedContext.scala:15-16,127-129) = LITERAL KEY LITERAL I32@0 LITERAL I32@4 LITERAL.
  * KEY is the aggregate id as a JSON string with Jackson's default escaping.  Absent (None) and poisoned
  * aggregates get zero bytes (out_off[a+1] == out_off[a]): the caller writes a tombstone / nothing.
- * Doubles are not supported (play-json's number text is parity-unpinned). */
+ * A Double field (BankAccount.balance, BankAccountSurgeModel.scala:26-28) is written as play-json 2.9.2 writes a Scala
+ * Double: the shortest decimal digits that round back to it (java.lang.Double.toString's contract) formatted by
+ * java.math.BigDecimal's rules after stripTrailingZeros — 100.0 -> 100, 0.1 -> 0.1, 1.5E20 -> 1.5E+20, 1.0E-7 -> 1E-7,
+ * -0.0 -> 0 (surge_amd/csrc/f64_text.h states the rule and its sources).  NaN / infinities are not JSON numbers — the
+ * reference's writeState throws: such an aggregate gets zero bytes and the call returns SURGE_E_UNSUPPORTED after
+ * encoding everything else (the output is valid; last_error carries the count).
+ * The model's immutable string fields that never enter the fold (BankAccount.accountOwner / securityCode, set once by
+ * the creating event) are served from up to SURGE_JSON_STRING_COLUMNS side string tables on the device. */
 #define SURGE_JP_LITERAL 0u /* bytes literals[lit_off .. lit_off + lit_len)          */
 #define SURGE_JP_KEY     1u /* "<aggregate id>" escaped                               */
 #define SURGE_JP_I32     2u /* decimal int32 at state byte offset field_offset        */
 #define SURGE_JP_U32     3u
 #define SURGE_JP_I64     4u
+#define SURGE_JP_F64     5u /* play-json Double text of the f64 at state byte offset field_offset */
+#define SURGE_JP_STR     6u /* "<side string column field_offset of this aggregate>" escaped (surge_replay_set_encode_strings) */
 #define SURGE_JSON_MAX_PARTS 16
+#define SURGE_JSON_STRING_COLUMNS 4
 typedef struct surge_json_template {
   uint32_t n_parts;
   struct { uint32_t kind, field_offset, lit_off, lit_len; } part[SURGE_JSON_MAX_PARTS];
   uint8_t literals[256];
 } surge_json_template;
+
+/* Side string column `column` (0 .. SURGE_JSON_STRING_COLUMNS-1) for SURGE_JP_STR parts: aggregate a's string is
+ * d_utf8[d_off[a] .. d_off[a+1]) (n_agg + 1 offsets; device pointers that stay valid while encoders run; NULL removes it). */
+int32_t surge_replay_set_encode_strings(surge_replay_handle* h, int32_t column, const uint8_t* d_utf8, const int64_t* d_off);
+
+/* The Double text above on the host: returns its length (0 for NaN / infinity), at most 26 bytes written to out when
+ * capacity allows; _many formats n values back to back (out_off: n + 1 offsets, nullable) and returns the total. */
+int32_t surge_format_f64_json(uint64_t f64_bits, uint8_t* out, int32_t capacity);
+int64_t surge_format_f64_json_many(const uint64_t* f64_bits, int64_t n, uint8_t* out, int64_t capacity, int64_t* out_off);
 
 /* d_keys_utf8 / d_key_off (n_agg + 1 entries): the key table on the device.  Two passes: lengths ->
  * exclusive scan into d_out_off (n_agg + 1) -> bytes into d_out.  *total_bytes_out (host) receives the

@@ -189,3 +189,53 @@ def counter_state_json(aggregate_id: str, count: int, version: int) -> bytes:
     if n < 0:
         raise RuntimeError("oracle_counter_state_json: buffer too small")
     return buf.raw[:n]
+
+
+def play_json_double_text(x: float) -> str:
+    """The JSON text play-json 2.9.2 writes for a Scala ``Double`` — oracle-side restatement, independent of the
+    product's Ryu implementation (``surge_amd/csrc/f64_text.h`` states the rule and its sources):
+
+    * digits = ``java.lang.Double.toString``'s: the shortest decimal that rounds back to ``x`` (Python's ``repr`` is David
+      Gay's shortest round-trip conversion — the third-party pin for the digits), except that a ONE-digit shortest
+      decimal is replaced by the closest TWO-digit decimal that rounds back (exact rational arithmetic below);
+    * ``JsNumber(BigDecimal(...))`` -> ``stripTrailingZeros`` -> ``toPlainString`` inside (1E-10, 1E20), else
+      ``toString`` -> re-read -> ``BigDecimal.toString``.
+    ``""`` for NaN / infinities (``new BigDecimal("NaN")`` throws: the reference's ``writeState`` fails)."""
+    from fractions import Fraction
+
+    if x != x or x in (float("inf"), float("-inf")):
+        return ""
+    if x == 0:
+        return "0"
+    mant, _, ex = repr(abs(x)).partition("e")
+    ip, _, fp = mant.partition(".")
+    digits = (ip + fp).lstrip("0")
+    e_last = (int(ex) if ex else 0) - len(fp)  # exponent of the last digit
+    stripped = digits.rstrip("0")
+    e_last += len(digits) - len(stripped)
+    digits = stripped
+    if len(digits) == 1:
+        exact = Fraction(abs(x))
+        k = e_last - 1  # two-digit decimals around x are multiples of 10^k with x / 10^k in [10, 100)
+        while exact / Fraction(10) ** k >= 100:
+            k += 1
+        while exact / Fraction(10) ** k < 10:
+            k -= 1
+        unit = Fraction(10) ** k
+        q = exact / unit
+        lo = q.numerator // q.denominator
+        cands = sorted((abs(exact - c * unit), c % 2, c) for c in (lo, lo + 1) if float(c * unit) == abs(x))
+        c = cands[0][2]
+        digits, e_last = str(c), k
+        stripped = digits.rstrip("0")
+        e_last += len(digits) - len(stripped)
+        digits = stripped
+    n = len(digits)
+    a = e_last + n - 1  # adjusted exponent
+    if a >= 20 or a < -6:
+        s = digits[0] + ("." + digits[1:] if n > 1 else "") + "E" + ("-" if a < 0 else "+") + str(abs(a))
+    elif a >= 0:
+        s = digits[: a + 1].ljust(a + 1, "0") + ("." + digits[a + 1:] if n > a + 1 else "")
+    else:
+        s = "0." + "0" * (-a - 1) + digits
+    return ("-" if x < 0 else "") + s

@@ -17,8 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
-SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip", "fold_slots.hip", "rtc.cpp", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "event_decode.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")
-HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "fold_chunk_device.h"), os.path.join(CSRC, "fold_slots_device.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
+SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip", "fold_slots.hip", "rtc.cpp", "f64_text.cpp", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "event_decode.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")
+HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "fold_chunk_device.h"), os.path.join(CSRC, "fold_slots_device.h"), os.path.join(CSRC, "f64_text.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
 EXPORTS = (
@@ -46,6 +46,9 @@ EXPORTS = (
     "surge_replay_device_state",
     "surge_replay_snapshot_delta",
     "surge_replay_set_encode_filter",
+    "surge_replay_set_encode_strings",
+    "surge_format_f64_json",
+    "surge_format_f64_json_many",
     "surge_replay_encode_json",
     "surge_replay_encode_protobuf_state",
     "surge_replay_pack_states",
@@ -206,6 +209,9 @@ def load() -> ctypes.CDLL:
         "surge_replay_device_state": ([vp, ctypes.POINTER(vp), ctypes.POINTER(i64)], i32),
         "surge_replay_snapshot_delta": ([vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64), i32], i32),
         "surge_replay_set_encode_filter": ([vp, vp], i32),
+        "surge_replay_set_encode_strings": ([vp, i32, vp, vp], i32),
+        "surge_format_f64_json": ([ctypes.c_uint64, vp, i32], i32),
+        "surge_format_f64_json_many": ([vp, i64, vp, i64, vp], i64),
         "surge_replay_encode_json": ([vp, vp, vp, vp, vp, i64, vp, ctypes.POINTER(i64)], i32),
         "surge_replay_encode_protobuf_state": ([vp, vp, vp, vp, vp, i64, vp, ctypes.POINTER(i64)], i32),
         "surge_replay_pack_states": ([vp, vp, i64, vp, vp], i32),

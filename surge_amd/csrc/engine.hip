@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "replay_internal.h"
+#include "f64_text.h"
 
 using namespace surge;
 
@@ -132,6 +133,8 @@ struct surge_replay_handle {
   DevBuf published;                      // the last committed snapshot (surge_replay_snapshot_delta), n_agg x 64 B
   int64_t published_n = 0;
   const uint8_t* encode_filter = nullptr;  // surge_replay_set_encode_filter
+  JsonSide json_side{};                  // Double-text tables (device copy, made on first use), side string columns
+  DevBuf f64_tables, nan_count;
 
   CommState* comm = nullptr;  // the snapshot exchange (comm.hip), created by surge_replay_comm_init
   DevBuf gathered[2];         // handle-owned output of allgather_snapshot(d_out = NULL), per slot
@@ -532,7 +535,7 @@ int32_t surge_replay_destroy(surge_replay_handle* h) {
   h->host_flags = nullptr;
   h->cidx.release();
   h->tidx.release();
-  DevBuf* bufs[] = {&h->gb_temp, &h->gb_u32, &h->gb_flags, &h->gb_agg_idx, &h->gb_events, &h->published, &h->gathered[0], &h->gathered[1], &h->v_ctr, &h->v_total, &h->t_tiles, &h->t_gsub, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
+  DevBuf* bufs[] = {&h->gb_temp, &h->gb_u32, &h->gb_flags, &h->gb_agg_idx, &h->gb_events, &h->published, &h->gathered[0], &h->gathered[1], &h->f64_tables, &h->nan_count, &h->v_ctr, &h->v_total, &h->t_tiles, &h->t_gsub, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
                     &h->nz_map, &h->block_counts, &h->plan, &h->batch_group_agg, &h->batch_group_off,
                     &h->batch_events, &h->poison_count, &h->gather_idx, &h->gather_out, &h->scan_totals};
   for (DevBuf* b : bufs) b->release();
@@ -1361,21 +1364,41 @@ static int32_t encode_states(surge_replay_handle* h, const surge_json_template* 
   if (!h->bound || h->st.n_folds == 0) return fail(h, SURGE_E_STATE, "encode_json before fold");
   if (!tmpl || !d_key_off || !d_out_off || !total_bytes_out) return fail(h, SURGE_E_INVALID, "NULL argument");
   if (tmpl->n_parts == 0 || tmpl->n_parts > SURGE_JSON_MAX_PARTS) return fail(h, SURGE_E_INVALID, "template.n_parts out of range");
+  bool uses_f64 = false;
   for (uint32_t i = 0; i < tmpl->n_parts; ++i) {
     const auto& pt = tmpl->part[i];
-    if (pt.kind > SURGE_JP_I64) return fail(h, SURGE_E_UNSUPPORTED, "unknown template part kind");
+    if (pt.kind > SURGE_JP_STR) return fail(h, SURGE_E_UNSUPPORTED, "unknown template part kind");
     if (pt.kind == SURGE_JP_LITERAL && (pt.lit_off > 256 || pt.lit_len > 256 - pt.lit_off)) return fail(h, SURGE_E_INVALID, "literal out of range");
-    if (pt.kind >= SURGE_JP_I32 && pt.field_offset + (pt.kind == SURGE_JP_I64 ? 8u : 4u) > 64u) return fail(h, SURGE_E_INVALID, "field outside the 64-byte state");
+    if (pt.kind == SURGE_JP_STR) {
+      if (pt.field_offset >= SURGE_JSON_STRING_COLUMNS || !h->json_side.str_off[pt.field_offset])
+        return fail(h, SURGE_E_INVALID, "SURGE_JP_STR names a string column that was not set (surge_replay_set_encode_strings)");
+    } else if (pt.kind >= SURGE_JP_I32) {
+      const uint32_t width = (pt.kind == SURGE_JP_I64 || pt.kind == SURGE_JP_F64) ? 8u : 4u;
+      if (pt.field_offset + width > 64u || pt.field_offset % width) return fail(h, SURGE_E_INVALID, "field outside the 64-byte state or misaligned");
+    }
+    uses_f64 = uses_f64 || pt.kind == SURGE_JP_F64;
   }
   *total_bytes_out = 0;
   if (h->n_agg == 0) return SURGE_OK;
   DeviceGuard g(h->device);
+  if (uses_f64 && !h->json_side.f64) {  // the power-of-5 tables of the Double text: one 10.7 KB copy per handle
+    HIPCHK(h, h->f64_tables.reserve(sizeof(F64Tables)));
+    HIPCHK(h, hipMemcpy(h->f64_tables.ptr, f64_tables_host(), sizeof(F64Tables), hipMemcpyHostToDevice));
+    h->json_side.f64 = (const F64Tables*)h->f64_tables.ptr;
+  }
+  if (!h->json_side.not_a_number) {
+    HIPCHK(h, h->nan_count.reserve(8));
+    h->json_side.not_a_number = (unsigned long long*)h->nan_count.ptr;
+  }
+  HIPCHK(h, hipMemsetAsync(h->nan_count.ptr, 0, 8, h->stream));
   const int64_t nb = (h->n_agg + 1023) / 1024;
   HIPCHK(h, h->scan_totals.reserve((size_t)(nb + 1) * 8));
   HIPCHK(h, launch_json_encode(*tmpl, h->d_state, h->n_agg, d_keys_utf8, d_key_off, d_out_off, (int64_t*)h->scan_totals.ptr,
-                               d_out, false, envelope, h->encode_filter, h->stream));
+                               d_out, false, envelope, h->encode_filter, h->json_side, h->stream));
   int64_t total = 0;
+  unsigned long long not_numbers = 0;
   HIPCHK(h, hipMemcpyAsync(&total, (int64_t*)h->scan_totals.ptr + nb, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(&not_numbers, h->nan_count.ptr, 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpyAsync(d_out_off + h->n_agg, &total, 8, hipMemcpyHostToDevice, h->stream));
   *total_bytes_out = total;
@@ -1385,8 +1408,19 @@ static int32_t encode_states(surge_replay_handle* h, const surge_json_template* 
   }
   if (total > 0 && !d_out) return fail(h, SURGE_E_INVALID, "d_out is NULL");
   HIPCHK(h, launch_json_encode(*tmpl, h->d_state, h->n_agg, d_keys_utf8, d_key_off, d_out_off, (int64_t*)h->scan_totals.ptr,
-                               d_out, true, envelope, h->encode_filter, h->stream));
+                               d_out, true, envelope, h->encode_filter, h->json_side, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (not_numbers)
+    return fail(h, SURGE_E_UNSUPPORTED, std::to_string(not_numbers) + " aggregate(s) hold a NaN / infinite Double: no JSON number exists (the "
+                                        "reference's writeState throws); they were encoded as zero bytes, everything else is valid");
+  return SURGE_OK;
+}
+
+int32_t surge_replay_set_encode_strings(surge_replay_handle* h, int32_t column, const uint8_t* d_utf8, const int64_t* d_off) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (column < 0 || column >= SURGE_JSON_STRING_COLUMNS) return fail(h, SURGE_E_INVALID, "string column out of range");
+  h->json_side.str[column] = d_utf8;
+  h->json_side.str_off[column] = d_off;
   return SURGE_OK;
 }
 

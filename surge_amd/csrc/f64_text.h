@@ -6,9 +6,12 @@
 // here from its published sources:
 //   1. Writes.DoubleWrites: JsNumber(BigDecimal(d)) = new java.math.BigDecimal(java.lang.Double.toString(d)) under
 //      MathContext.DECIMAL128, i.e. the decimal digits of Double.toString — the SHORTEST decimal that rounds back to d,
-//      the closest one when several are equally short (the JDK's specification; JDK >= 19 implements exactly that, older
-//      JDKs print one digit too many for a small set of values — JDK-4511638 — which is outside what can be pinned
-//      without the JVM that wrote the topic).  NaN / infinities have no BigDecimal: the reference throws.
+//      the closest one when several are equally short, and — Double.toString always prints a fraction digit — when the
+//      shortest has ONE digit, the closest of the TWO-digit decimals that round back (java.lang.Double.toString's
+//      specification since JDK 19; it only changes the value for a few hundred subnormals: Double.MIN_VALUE is 4.9E-324,
+//      not 5E-324).  JDK >= 19 implements exactly that; older JDKs print one digit too many for a small set of values
+//      (JDK-4511638), which is outside what can be pinned without the JVM that wrote the topic.  NaN / infinities have
+//      no BigDecimal: the reference throws.
 //   2. JsValueSerializer (play-json JacksonJson.scala): stripped = v.stripTrailingZeros; 1E-10 < |v| < 1E20 ?
 //      stripped.toPlainString : stripped.toString; the text is re-read as a BigDecimal (or BigInteger when it has no '.'
 //      / 'E') and Jackson writes that number's toString.
@@ -41,7 +44,7 @@ struct F64Tables {
 const F64Tables* f64_tables_host();  // f64_text.cpp: built on first use
 
 #if defined(__HIPCC__)
-#define SURGE_HD __host__ __device__ __forceinline__
+#define SURGE_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define SURGE_HD inline
 #endif
@@ -51,14 +54,9 @@ SURGE_HD uint32_t ryu_log10pow2(int32_t e) { return ((uint32_t)e * 78913u) >> 18
 SURGE_HD uint32_t ryu_log10pow5(int32_t e) { return ((uint32_t)e * 732923u) >> 20; }                   // floor(log10(5^e)), 0 <= e <= 2620
 
 SURGE_HD uint64_t ryu_umul128(uint64_t a, uint64_t b, uint64_t* hi) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  *hi = __umul64hi(a, b);
-  return a * b;
-#else
-  const unsigned __int128 p = (unsigned __int128)a * b;
+  const unsigned __int128 p = (unsigned __int128)a * b;  // host: one mul; gfx950: 32-bit partial products (v_mad_u64_u32)
   *hi = (uint64_t)(p >> 64);
   return (uint64_t)p;
-#endif
 }
 
 // (m * mul) >> j for a 128-bit mul = {low, high}, 64 < j < 128; m has at most 55 bits
@@ -197,6 +195,24 @@ SURGE_HD int f64_play_json_text(uint64_t bits, const F64Tables* tb, uint8_t* out
   uint64_t digits;
   int32_t e10;
   ryu_shortest(mant, expo, tb, &digits, &e10);
+  if (digits < 10u && expo == 0u && mant <= 1000u) {
+    // A one-digit shortest decimal: Double.toString prints the closest TWO-digit decimal instead.  For normal doubles
+    // that is the same number (d.0: the rounding interval is far narrower than the spacing of two-digit decimals); only
+    // the smallest subnormals have room for another one.  x = mant * 2^-1074 = mant * 4.9406564584124654...e-324: a
+    // double product decides the two digits for every mant <= 1000 (no product comes within 1e-4 of a rounding
+    // midpoint; tests/test_f64_text.py checks all of them against exact rational arithmetic).
+    const double v = (double)mant * 4.9406564584124654;  // x * 1e324
+    double scaled = v;
+    int32_t e = -324;                                     // exponent of the units digit of `scaled`
+    if (v < 10.0) { scaled = v * 10.0; e = -325; }
+    else if (v >= 1000.0) { scaled = v / 100.0; e = -322; }
+    else if (v >= 100.0) { scaled = v / 10.0; e = -323; }
+    uint64_t two = (uint64_t)(scaled + 0.5);
+    if (two == 100u) { two = 10u; ++e; }
+    digits = two;
+    e10 = e;
+    if (digits % 10u == 0u) { digits /= 10u; ++e10; }
+  }
   uint8_t d[20];
   int n = 0;
   for (uint64_t v = digits; v != 0ull; v /= 10u) d[n++] = (uint8_t)('0' + (int)(v % 10u));  // least significant first

@@ -67,9 +67,16 @@ hipError_t launch_compact_nonempty(const int64_t* off, int64_t n_seg, int64_t* d
 hipError_t launch_partition_hash(const uint16_t* utf16, const int64_t* str_off, int64_t n,
                                  int32_t n_partitions, int32_t* part_out, bool up_to_colon, hipStream_t stream);
 hipError_t launch_stream_probe(const uint4* src, int64_t n_vec, uint32_t* sink, int variant, hipStream_t stream);
+struct F64Tables;
+struct JsonSide {
+  const F64Tables* f64;                              // device copy of the Double-text tables (f64_text.h); needed by SURGE_JP_F64
+  const uint8_t* str[SURGE_JSON_STRING_COLUMNS];     // side string columns (SURGE_JP_STR), UTF-8
+  const int64_t* str_off[SURGE_JSON_STRING_COLUMNS];
+  unsigned long long* not_a_number;                  // += aggregates skipped because a Double of theirs is NaN / infinite
+};
 hipError_t launch_json_encode(const surge_json_template& tmpl, const uint4* states, int64_t n, const uint8_t* keys,
                               const int64_t* key_off, int64_t* d_len_off, int64_t* d_totals, uint8_t* out, bool write_pass,
-                              uint32_t envelope, const uint8_t* filter, hipStream_t stream);
+                              uint32_t envelope, const uint8_t* filter, const JsonSide& side, hipStream_t stream);
 // kind[a] in SURGE_SNAP_*; d_counts: two u64 {values, tombstones}; commit: published := states where kind != SKIP
 hipError_t launch_snapshot_delta(const uint4* states, uint4* published, int64_t n, uint8_t* kind, unsigned long long* d_counts,
                                  bool commit, bool full64, hipStream_t stream);

@@ -2,6 +2,7 @@
 // (N3), the snapshot delta (N2), the 40-byte wire form of the exchange, bulk point reads, and the HBM stream probes the
 // bench calibrates against.  Split from fold_kernels.hip so that the fold kernels' sources (what a committed rocprof
 // traffic figure describes) change only when a fold kernel changes.
+#include "f64_text.h"
 #include "fold_device.h"
 
 namespace surge {
@@ -101,7 +102,15 @@ struct JsonTemplateDev {
       lit_len[SURGE_JSON_MAX_PARTS];
   uint8_t literals[256];
   const uint8_t* filter;  // nullable: per-aggregate SURGE_SNAP_* kinds; only SURGE_SNAP_VALUE aggregates are encoded
+  JsonSide side;          // power-of-5 tables of the Double text, side string columns, the "not a JSON number" counter
 };
+
+// an aggregate whose template names a Double that is NaN / infinite has no JSON text (the reference's writeState throws)
+__device__ __forceinline__ bool json_all_finite(const JsonTemplateDev& t, const uint8_t* st) {
+  for (uint32_t i = 0; i < t.n_parts; ++i)
+    if (t.kind[i] == SURGE_JP_F64 && ((*(const uint64_t*)(st + t.field_offset[i]) >> 52) & 0x7ffull) == 0x7ffull) return false;
+  return true;
+}
 
 __device__ __forceinline__ int dec_len_u64(uint64_t v) {
   int n = 1;
@@ -161,6 +170,12 @@ __device__ __forceinline__ int64_t json_text_len(const JsonTemplateDev& t, const
     } else if (k == SURGE_JP_KEY) {
       len += 2;
       for (int64_t b = key_off[a]; b < key_off[a + 1]; ++b) len += json_escaped_len(keys[b]);
+    } else if (k == SURGE_JP_STR) {
+      const uint32_t c = t.field_offset[i];
+      len += 2;
+      for (int64_t b = t.side.str_off[c][a]; b < t.side.str_off[c][a + 1]; ++b) len += json_escaped_len(t.side.str[c][b]);
+    } else if (k == SURGE_JP_F64) {
+      len += f64_play_json_text(*(const uint64_t*)(st + t.field_offset[i]), t.side.f64, nullptr);
     } else {
       bool neg; uint64_t mag;
       json_int_value(st, k, t.field_offset[i], &neg, &mag);
@@ -200,7 +215,11 @@ __global__ void __launch_bounds__(kJsonBlock) json_encode_kernel(const JsonTempl
   const bool live = a < n;
   const uint8_t* st = (const uint8_t*)(states + (live ? a : 0) * 4);
   const uint32_t fl = *(const uint32_t*)(st + 36);
-  const bool emit = live && (fl & FL_PRESENT) && !(fl & FL_POISONED) && (!t.filter || t.filter[a] == SURGE_SNAP_VALUE);
+  bool emit = live && (fl & FL_PRESENT) && !(fl & FL_POISONED) && (!t.filter || t.filter[a] == SURGE_SNAP_VALUE);
+  if (emit && !json_all_finite(t, st)) {
+    emit = false;
+    if (!WRITE) atomicAdd(t.side.not_a_number, 1ull);
+  }
   if (!WRITE) {
     if (!live) return;
     int64_t len = 0;
@@ -241,6 +260,13 @@ __global__ void __launch_bounds__(kJsonBlock) json_encode_kernel(const JsonTempl
         *o++ = '"';
         for (int64_t b = key_off[a]; b < key_off[a + 1]; ++b) o = json_put_escaped(o, keys[b]);
         *o++ = '"';
+      } else if (k == SURGE_JP_STR) {
+        const uint32_t c = t.field_offset[i];
+        *o++ = '"';
+        for (int64_t b = t.side.str_off[c][a]; b < t.side.str_off[c][a + 1]; ++b) o = json_put_escaped(o, t.side.str[c][b]);
+        *o++ = '"';
+      } else if (k == SURGE_JP_F64) {
+        o += f64_play_json_text(*(const uint64_t*)(st + t.field_offset[i]), t.side.f64, o);
       } else {
         bool neg; uint64_t mag;
         json_int_value(st, k, t.field_offset[i], &neg, &mag);
@@ -410,12 +436,13 @@ hipError_t launch_stream_probe(const uint4* src, int64_t n_vec, uint32_t* sink, 
 // d_len_off: n + 1 entries; d_totals: ceil(n / 1024) + 1 entries of scratch
 hipError_t launch_json_encode(const surge_json_template& tmpl, const uint4* states, int64_t n, const uint8_t* keys,
                               const int64_t* key_off, int64_t* d_len_off, int64_t* d_totals, uint8_t* out, bool write_pass,
-                              uint32_t envelope, const uint8_t* filter, hipStream_t stream) {
+                              uint32_t envelope, const uint8_t* filter, const JsonSide& side, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   JsonTemplateDev t;
   t.n_parts = tmpl.n_parts;
   t.envelope = envelope;
   t.filter = filter;
+  t.side = side;
   for (uint32_t i = 0; i < SURGE_JSON_MAX_PARTS; ++i) {
     t.kind[i] = tmpl.part[i].kind; t.field_offset[i] = tmpl.part[i].field_offset;
     t.lit_off[i] = tmpl.part[i].lit_off; t.lit_len[i] = tmpl.part[i].lit_len;

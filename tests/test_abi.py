@@ -12,7 +12,7 @@ from surge_amd.schema import CSchema, DEFAULT_ALGEBRA
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols(name="surge_replay.h", prefix="surge_replay_"):
+def header_symbols(name="surge_replay.h", prefix="surge_(?:replay|format)_"):
     text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]*)\s*\(", text)))

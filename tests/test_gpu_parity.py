@@ -2,6 +2,8 @@
 
 Bit-exact is the bar: all state fields are integers or bit-copied f64 payloads.
 """
+import ctypes
+import json
 import os
 
 import numpy as np
@@ -596,6 +598,71 @@ def test_gpu_json_encoder_matches_play_json_text_of_the_counter_fixture():
         else:
             assert text == b""  # None => tombstone, poisoned => nothing
     assert 0 < n_emitted < n
+
+
+@pytest.mark.gpu
+def test_gpu_json_encoder_writes_bank_account_states_with_play_json_double_text():
+    # R14 / N3: Json.toJson(BankAccount).toString() (BankAccountSurgeModel.scala:26-28) from the device, byte for byte:
+    # the Double as play-json 2.9.2 writes it, owner / security code from side string columns
+    import uuid
+
+    import torch
+
+    from surge_amd.encode import JsonTemplate, encode_states, key_table_utf8
+    from surge_amd.replay import ReplayError
+    from fixture_models import BANK_ACCOUNT_ALGEBRA, BA_CREATED, BA_UPDATED, BankAccount, BankAccountFormat
+
+    n = 20000
+    rng = np.random.default_rng(21)
+    keys = [str(uuid.UUID(int=int(x))) for x in rng.integers(0, 1 << 62, size=n)]
+    owners = [f"Owner {i} \"q\" ünï" if i % 97 == 0 else f"Jane Doe {i}" for i in range(n)]
+    codes = ["" if i % 50 == 0 else f"{i % 10000:04d}" for i in range(n)]
+    # one Created (+ for half of them an Updated) per account; balances of every magnitude, cents, integers, special values
+    two = rng.random(n) < 0.5
+    lens = 1 + two.astype(np.int64)
+    so = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=so[1:])
+    ev = np.zeros(int(so[-1]), dtype=S.EVENT_DTYPE)
+    ev["type"][so[:-1]] = BA_CREATED
+    ev["type"][so[:-1][two] + 1] = BA_UPDATED
+    kinds = rng.integers(0, 6, size=ev.shape[0])
+    vals = np.select([kinds == 0, kinds == 1, kinds == 2, kinds == 3, kinds == 4],
+                     [np.round(rng.random(ev.shape[0]) * 1e7) / 100, rng.integers(-10 ** 6, 10 ** 6, size=ev.shape[0]).astype(np.float64),
+                      rng.random(ev.shape[0]) * 10.0 ** rng.integers(-12, 25, size=ev.shape[0]), rng.standard_normal(ev.shape[0]) * 1e3,
+                      rng.choice([0.0, -0.0, 1e20, 1e-7, 5e-324, 1.7976931348623157e308, 0.1 + 0.2, 1e21, 100.0], size=ev.shape[0])],
+                     default=rng.integers(0, 0x7FF0000000000000, size=ev.shape[0], dtype=np.uint64).view(np.float64))
+    ev["raw"] = vals.view(np.uint64)
+    bad = rng.choice(ev.shape[0], size=25, replace=False)
+    ev["raw"][bad] = rng.choice(np.array([0x7FF8000000000000, 0x7FF0000000000000, 0xFFF0000000000000], dtype=np.uint64), size=25)
+    fmt = BankAccountFormat()
+    with ReplayEngine(BANK_ACCOUNT_ALGEBRA) as eng:
+        eng.load_csr(so, ev)
+        eng.fold()
+        states = eng.snapshot()
+        data, off = key_table_utf8(keys)
+        cols = [tuple(torch.from_numpy(x).cuda() for x in key_table_utf8(col)) for col in (owners, codes)]
+        nonfinite = ~np.isfinite(states["balance"])
+        assert 0 < nonfinite.sum() <= 25
+        with pytest.raises(ReplayError, match="NaN / infinite"):  # reported, after everything else was encoded ...
+            encode_states(eng, JsonTemplate.bank_account(), torch.from_numpy(data).cuda(), torch.from_numpy(off).cuda(), strings=cols)
+        # ... so encode again with those aggregates filtered out (what a publisher that already knows them would do)
+        kind = torch.from_numpy(np.where(nonfinite, 0, 1).astype(np.uint8)).cuda()
+        eng._check(eng._lib.surge_replay_set_encode_filter(eng._h, ctypes.c_void_p(kind.data_ptr())))
+        d_out, d_off = encode_states(eng, JsonTemplate.bank_account(), torch.from_numpy(data).cuda(), torch.from_numpy(off).cuda(), strings=cols)
+        eng._check(eng._lib.surge_replay_set_encode_filter(eng._h, None))
+        out, offs = d_out.cpu().numpy().tobytes(), d_off.cpu().numpy()
+    for a in range(n):
+        text = out[offs[a]:offs[a + 1]]
+        if nonfinite[a]:
+            assert text == b""
+            continue
+        bal = float(states[a]["balance"])
+        # the oracle-side restatement (repr digits + BigDecimal rules), then the host plugin's writeState
+        exp = (f'{{"accountNumber":"{keys[a]}","accountOwner":{json.dumps(owners[a], ensure_ascii=False)},'
+               f'"securityCode":"{codes[a]}","balance":{oracle.play_json_double_text(bal)}}}').encode("utf-8")
+        assert text == exp, (a, text, exp)
+        assert text == fmt.write_state(BankAccount(uuid.UUID(keys[a]), owners[a], codes[a], bal)).value
+        assert float(json.loads(text)["balance"]) == bal  # and it reads back as the same Double
 
 
 @pytest.mark.gpu
