@@ -464,6 +464,11 @@ int32_t surge_replay_encode_protobuf_state(surge_replay_handle* h, const surge_j
 int32_t surge_replay_snapshot_delta(surge_replay_handle* h, uint8_t* d_kind_out, int64_t* n_values_out, int64_t* n_tombstones_out,
                                     int32_t commit);
 int32_t surge_replay_set_encode_filter(surge_replay_handle* h, const uint8_t* d_kind);
+/* The second half of a two-step publish: surge_replay_snapshot_delta(commit = 0) -> encode -> produce -> and only once the
+ * records are safely out (the reference treats a state as published when the producer acknowledged it) make the states
+ * of the aggregates d_kind reports (the array that delta call filled) the new baseline.  No fold / append may run on the
+ * handle between the two calls. */
+int32_t surge_replay_snapshot_commit(surge_replay_handle* h, const uint8_t* d_kind);
 
 /* ---- shard map (R15) --------------------------------------------------------------
  * surge_replay_partition_hash:  part_out[i] = abs(MurmurHash3.stringHash(str_i) % n_partitions)

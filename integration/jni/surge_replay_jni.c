@@ -49,6 +49,15 @@ static void* buf(JNIEnv* env, jobject b, int64_t need, int nullable, int* bad, c
   return NULL;
 }
 
+/* string offsets handed over by the JVM: non-negative and non-decreasing, so strOff[n] bounds every string */
+static int offsets_ok(const int64_t* so, int64_t n) {
+  int64_t i;
+  if (so[0] < 0) return 0;
+  for (i = 0; i < n; ++i)
+    if (so[i + 1] < so[i]) return 0;
+  return 1;
+}
+
 JNIEXPORT jlong JNICALL Java_surge_replay_gpu_NativeReplay_create(JNIEnv* env, jclass c, jobject schemaBuf, jint device) {
   surge_replay_handle* h = NULL;
   surge_replay_schema sc;
@@ -74,11 +83,14 @@ JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_loadCsr(JNIEnv* env, j
                                                                     jlong nAgg, jobject events, jlong nEvents,
                                                                     jobject initState) {
   int bad = 0;
-  const int64_t* so = (const int64_t*)buf(env, segOff, (nAgg + 1) * 8, 0, &bad, "segOff: direct buffer of (nAgg + 1) longs expected");
-  const void* ev = buf(env, events, nEvents * 16, nEvents == 0, &bad, "events: direct buffer of nEvents x 16 bytes expected");
-  const void* in = buf(env, initState, nAgg * 64, 1, &bad, "initState: direct buffer of nAgg x 64 bytes expected");
+  const int64_t* so;
+  const void *ev, *in;
   (void)c;
-  if (bad || nAgg < 0 || nEvents < 0) return SURGE_E_INVALID;
+  if (nAgg < 0 || nEvents < 0) return SURGE_E_INVALID;
+  so = (const int64_t*)buf(env, segOff, (nAgg + 1) * 8, 0, &bad, "segOff: direct buffer of (nAgg + 1) longs expected");
+  ev = buf(env, events, nEvents * 16, nEvents == 0, &bad, "events: direct buffer of nEvents x 16 bytes expected");
+  in = buf(env, initState, nAgg * 64, 1, &bad, "initState: direct buffer of nAgg x 64 bytes expected");
+  if (bad) return SURGE_E_INVALID;
   return check(env, surge_replay_load_csr(H(h), so, nAgg, ev, nEvents, in));
 }
 
@@ -164,10 +176,13 @@ JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_get(JNIEnv* env, jclas
 JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_gather(JNIEnv* env, jclass c, jlong h, jobject aggIdx, jlong n,
                                                                    jobject states) {
   int bad = 0;
-  const int64_t* ai = (const int64_t*)buf(env, aggIdx, n * 8, n == 0, &bad, "aggIdx: direct buffer of n longs expected");
-  void* st = buf(env, states, n * 64, n == 0, &bad, "states: direct buffer of n x 64 bytes expected");
+  const int64_t* ai;
+  void* st;
   (void)c;
-  if (bad || n < 0) return SURGE_E_INVALID;
+  if (n < 0) return SURGE_E_INVALID;
+  ai = (const int64_t*)buf(env, aggIdx, n * 8, n == 0, &bad, "aggIdx: direct buffer of n longs expected");
+  st = buf(env, states, n * 64, n == 0, &bad, "states: direct buffer of n x 64 bytes expected");
+  if (bad) return SURGE_E_INVALID;
   return check(env, surge_replay_gather(H(h), ai, n, st));
 }
 
@@ -176,11 +191,20 @@ JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_partitionHash(JNIEnv* 
                                                                           jobject strOff, jlong n, jint nPartitions,
                                                                           jobject partOut) {
   int bad = 0;
-  const int64_t* so = (const int64_t*)buf(env, strOff, (n + 1) * 8, 0, &bad, "strOff: direct buffer of (n + 1) longs expected");
-  const uint16_t* u = (const uint16_t*)buf(env, utf16, bad ? -1 : so[n] * 2, 1, &bad, "utf16: direct buffer of strOff[n] chars expected");
-  int32_t* po = (int32_t*)buf(env, partOut, n * 4, 0, &bad, "partOut: direct buffer of n ints expected");
+  const int64_t* so;
+  const uint16_t* u;
+  int32_t* po;
   (void)c;
-  if (bad || n < 0) return SURGE_E_INVALID;
+  if (n < 0) return SURGE_E_INVALID; /* before any size is derived from it */
+  so = (const int64_t*)buf(env, strOff, (n + 1) * 8, 0, &bad, "strOff: direct buffer of (n + 1) longs expected");
+  if (!bad && !offsets_ok(so, n)) {
+    jclass ex = (*env)->FindClass(env, "java/lang/IllegalArgumentException");
+    if (ex) (*env)->ThrowNew(env, ex, "strOff: offsets must start at >= 0 and never decrease");
+    return SURGE_E_INVALID;
+  }
+  u = (const uint16_t*)buf(env, utf16, bad ? -1 : so[n] * 2, 1, &bad, "utf16: direct buffer of strOff[n] chars expected");
+  po = (int32_t*)buf(env, partOut, n * 4, 0, &bad, "partOut: direct buffer of n ints expected");
+  if (bad) return SURGE_E_INVALID;
   return check(env, surge_replay_partition_hash(u, so, n, nPartitions, po));
 }
 
@@ -189,11 +213,20 @@ JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_partitionHashUpToColon
                                                                                    jobject strOff, jlong n, jint nPartitions,
                                                                                    jobject partOut) {
   int bad = 0;
-  const int64_t* so = (const int64_t*)buf(env, strOff, (n + 1) * 8, 0, &bad, "strOff: direct buffer of (n + 1) longs expected");
-  const uint16_t* u = (const uint16_t*)buf(env, utf16, bad ? -1 : so[n] * 2, 1, &bad, "utf16: direct buffer of strOff[n] chars expected");
-  int32_t* po = (int32_t*)buf(env, partOut, n * 4, 0, &bad, "partOut: direct buffer of n ints expected");
+  const int64_t* so;
+  const uint16_t* u;
+  int32_t* po;
   (void)c;
-  if (bad || n < 0) return SURGE_E_INVALID;
+  if (n < 0) return SURGE_E_INVALID; /* before any size is derived from it */
+  so = (const int64_t*)buf(env, strOff, (n + 1) * 8, 0, &bad, "strOff: direct buffer of (n + 1) longs expected");
+  if (!bad && !offsets_ok(so, n)) {
+    jclass ex = (*env)->FindClass(env, "java/lang/IllegalArgumentException");
+    if (ex) (*env)->ThrowNew(env, ex, "strOff: offsets must start at >= 0 and never decrease");
+    return SURGE_E_INVALID;
+  }
+  u = (const uint16_t*)buf(env, utf16, bad ? -1 : so[n] * 2, 1, &bad, "utf16: direct buffer of strOff[n] chars expected");
+  po = (int32_t*)buf(env, partOut, n * 4, 0, &bad, "partOut: direct buffer of n ints expected");
+  if (bad) return SURGE_E_INVALID;
   return check(env, surge_replay_partition_hash_up_to_colon(u, so, n, nPartitions, po));
 }
 

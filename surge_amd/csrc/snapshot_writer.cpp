@@ -221,14 +221,25 @@ int32_t surge_snapshot_writer_append(surge_snapshot_writer* w, int64_t n, const 
       auto worker = [&]() {
         try {
           for (int32_t p = next.fetch_add(1); p < P; p = next.fetch_add(1)) encode_partition(p);
-        } catch (const std::bad_alloc&) {
+        } catch (...) {  // bad_alloc, length_error ...: nothing may leave a thread (std::terminate would take the JVM down)
           oom = true;
+          next = P;  // the other workers stop at their next draw
         }
       };
       std::vector<std::thread> th;
-      for (int t = 0; t < n_threads; ++t) th.emplace_back(worker);
+      bool started_all = true;
+      try {
+        th.reserve((size_t)n_threads);
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(worker);
+      } catch (...) {  // std::system_error: the threads that did start finish the work (or the caller's thread does)
+        started_all = false;
+      }
+      if (!started_all && th.empty()) worker();
       for (std::thread& t : th) t.join();
-      if (oom) return fail(w, E_NOMEM, "out of host memory while encoding");
+      if (oom) {
+        // partitions are left partially appended: the writer must be reset before it is used again
+        return fail(w, E_NOMEM, "out of host memory while encoding (call surge_snapshot_writer_reset before appending again)");
+      }
     }
   } catch (const std::bad_alloc&) {
     return fail(w, E_NOMEM, "out of host memory while encoding");

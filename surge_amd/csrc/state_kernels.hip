@@ -489,6 +489,12 @@ hipError_t launch_snapshot_delta(const uint4* states, uint4* published, int64_t 
   return hipGetLastError();
 }
 
+hipError_t launch_snapshot_commit(const uint4* states, uint4* published, int64_t n, const uint8_t* kind, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(snapshot_commit_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, stream, states, published, n, kind);
+  return hipGetLastError();
+}
+
 hipError_t launch_count_poisoned(const uint4* states, int64_t n, unsigned long long* d_count, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess || n <= 0) return e;

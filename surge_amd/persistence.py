@@ -53,6 +53,14 @@ class ACKError:
 
 
 @dataclass(frozen=True)
+class ACKRejection:
+    """``PersistentActor.ACKRejection(rejection)`` (:60-62): the command was rejected by the model (``ctx.reject``) —
+    distinct from ``ACKError``, nothing is published, the state is untouched."""
+
+    rejection: object
+
+
+@dataclass(frozen=True)
 class EventRecord:
     topic: str
     key: str
@@ -197,7 +205,7 @@ class GpuPersistentActor(Generic[Agg]):
         try:
             ctx = self.core.handle(SurgeContext(state=self.state, default_event_topic=self.business_logic.events_topic), self.state, message)
             if ctx.is_rejected:
-                return ACKError(RuntimeError(f"rejected: {ctx.rejection!r}"))
+                return ACKRejection(ctx.rejection)
             events = [e for e, _ in ctx.events]
             is_something_new = bool(events) or bool(ctx.records) or (self.state != ctx.state)
             records: List[object] = [] if self.business_logic.publish_state_only else list(self._serialize_events(ctx.events))

@@ -173,7 +173,12 @@ class BulkSnapshotPublisher:
         self.writer.close()
 
     def publish(self, commit: bool = True, timestamp_ms: Optional[int] = None) -> Dict[int, bytes]:
-        """Record batches (per partition) for everything that changed since the last committed publish."""
+        """Record batches (per partition) for everything that changed since the last committed publish.
+
+        The baseline moves only AFTER the batches exist (delta with commit = 0, encode, copy, frame, then
+        ``surge_replay_snapshot_commit``): a failure anywhere on the way leaves the changed aggregates unpublished, to be
+        emitted again by the next call.  ``commit=False`` defers that last step to ``commit_published()`` — call it when
+        the producer acknowledged the records (the reference's notion of "published")."""
         import torch
 
         from .encode import encode_states
@@ -186,7 +191,8 @@ class BulkSnapshotPublisher:
         t0 = time.perf_counter()
         d_kind = torch.zeros(n, dtype=torch.uint8, device=self.device)
         nv, nt = ctypes.c_int64(), ctypes.c_int64()
-        eng._check(lib.surge_replay_snapshot_delta(eng._h, ctypes.c_void_p(d_kind.data_ptr()), ctypes.byref(nv), ctypes.byref(nt), 1 if commit else 0))
+        eng._check(lib.surge_replay_snapshot_delta(eng._h, ctypes.c_void_p(d_kind.data_ptr()), ctypes.byref(nv), ctypes.byref(nt), 0))
+        self._pending_kind = None
         eng._check(lib.surge_replay_set_encode_filter(eng._h, ctypes.c_void_p(d_kind.data_ptr())))
         try:
             d_out, d_off = encode_states(eng, self.template, self.d_keys, self.d_key_off, capacity_hint=max(64, 96 * nv.value + int(self.d_keys.numel())))
@@ -203,10 +209,21 @@ class BulkSnapshotPublisher:
             data, nrec, _ = self.writer.partition_bytes(p)
             if nrec:
                 out[p] = data
+        self._pending_kind = d_kind
+        if commit:
+            self.commit_published()
         t3 = time.perf_counter()
         self.timings = {"gpu_delta_and_encode_ms": (t1 - t0) * 1e3, "d2h_ms": (t2 - t1) * 1e3, "record_batches_ms": (t3 - t2) * 1e3,
                         "values": nv.value, "tombstones": nt.value, "text_bytes": int(text.nbytes)}
         return out
+
+    def commit_published(self) -> None:
+        """Make what the last ``publish`` reported the new baseline (``surge_replay_snapshot_commit``)."""
+        if getattr(self, "_pending_kind", None) is None:
+            return
+        eng = self.engine
+        eng._check(_native.load().surge_replay_snapshot_commit(eng._h, ctypes.c_void_p(self._pending_kind.data_ptr())))
+        self._pending_kind = None
 
 
 def compact(records: Iterable[StateRecord]) -> Dict[str, Optional[bytes]]:

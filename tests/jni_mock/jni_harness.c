@@ -90,6 +90,17 @@ int main(void) {
     n_thrown = 0;
     rc = Java_surge_replay_gpu_NativeReplay_partitionHash(env, NULL, &b_heap, &b_off, 3, 1000003, &b_part);
     check(rc == SURGE_E_INVALID && n_thrown == 1, "a heap (non-direct) buffer -> IllegalArgumentException");
+    /* sizes and offsets the JVM hands over are checked before anything is derived from them */
+    n_thrown = 0;
+    rc = Java_surge_replay_gpu_NativeReplay_partitionHash(env, NULL, &b_utf16, &b_off, -1, 1000003, &b_part);
+    check(rc == SURGE_E_INVALID, "a negative count is refused before any buffer size is computed from it");
+    {
+      const int64_t bad_off[] = {0, 3, 1, 4};
+      fake_direct_buffer b_bad = DB(bad_off, sizeof(bad_off));
+      n_thrown = 0;
+      rc = Java_surge_replay_gpu_NativeReplay_partitionHashUpToColon(env, NULL, &b_utf16, &b_bad, 3, 1000003, &b_part);
+      check(rc == SURGE_E_INVALID && n_thrown == 1, "decreasing string offsets -> IllegalArgumentException");
+    }
   }
 
   n_thrown = 0;

@@ -82,6 +82,30 @@ def test_initialization_retries_then_succeeds_or_fails_like_ktable_initializatio
     assert actor.get_state() is None
 
 
+def test_a_rejected_command_is_an_ackrejection_not_an_ackerror_and_publishes_nothing():
+    """PersistentActor.handle: `if (ctx.isRejected) ACKRejection(ctx.rejection)` (PersistentActor.scala:60-62, :205-207) —
+    a reply type of its own, the state untouched, nothing handed to the producer."""
+    from surge_amd.core import SurgeProcessingModel
+    from surge_amd.persistence import ACKRejection
+
+    bl = CounterBusinessLogic()
+    fmt = bl.aggregate_write_formatting()
+    store = _FakeStore({"x": fmt.write_state(State("x", 3, 3)).value})
+    pub = StatePublisher(store)
+    published = []
+    pub.publish = lambda *a, **k: published.append(a)
+    actor = GpuPersistentActor(bl, "x", store, pub)
+
+    class Rejecting(SurgeProcessingModel):
+        def handle(self, ctx, state, msg):
+            return ctx.reject({"reason": "insufficient funds", "command": msg})
+
+    actor.core = Rejecting()
+    r = actor.process_message("withdraw 10")
+    assert r == ACKRejection({"reason": "insufficient funds", "command": "withdraw 10"}) and not isinstance(r, ACKError)
+    assert published == [] and actor.get_state() == State("x", 3, 3)
+
+
 # ---- GPU: the spec's scenarios, state of record on the GPU store ----------------------------------------------------
 def _context(base_events):
     from surge_amd.store import GpuReplayStateStore
