@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
-SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip", "fold_slots.hip", "rtc.cpp", "f64_text.cpp", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "event_decode.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")
+SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip", "fold_slots.hip", "index_kernels.hip", "rtc.cpp", "f64_text.cpp", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "event_decode.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")
 HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "fold_chunk_device.h"), os.path.join(CSRC, "fold_slots_device.h"), os.path.join(CSRC, "f64_text.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)

@@ -82,7 +82,10 @@ struct surge_replay_handle {
   CsrAnalysis an{};
   DevBuf d_analysis, nz_off, nz_map, block_counts;
   int64_t n_nz = 0;
-  DevBuf perm, sort_hist, counter;  // SORTED: segments by descending length (built lazily, per bound log)
+  DevBuf perm, counter;  // SORTED: segments by descending length (built lazily, per bound log)
+  // scratch of the index builds (index_kernels.hip): rocPRIM temp, sort keys / values, the chunk table's counts and its
+  // rows in aggregate order; released once the bound log's index stands
+  DevBuf ix_temp, ix_keys_a, ix_keys_b, ix_vals_a, ix_vals_b, ix_cnt, ix_u_start, ix_u_len, ix_u_info, ix_u_dest;
   bool perm_valid = false;
   // CHUNKED / TILED: the chunk table (built lazily, per bound log), the chunk summaries and the list of cut aggregates
   struct ChunkIndex {
@@ -98,7 +101,6 @@ struct surge_replay_handle {
   };
   ChunkIndex cidx;              // CHUNKED: rows tiled from their 128-byte lines in the CSR log
   ChunkIndex tidx;              // TILED: rows copied to tile boundaries
-  DevBuf v_total, v_ctr;        // scratch of the chunk-table build
   DevBuf t_tiles, t_gsub;  // TILED: the tile-major copy of the log, first subtile of every group
   int64_t t_n_sub = 0;          // subtiles (8 KiB each) of the tile-major copy
   bool tiled_valid = false;
@@ -339,12 +341,39 @@ int32_t dispenser_begin(surge_replay_handle* h, FoldParams& p) {
   return SURGE_OK;
 }
 
+// scratch for ordering n rows by length (vals_b only when the caller does not supply its own output)
+int32_t index_scratch(surge_replay_handle* h, int64_t n, bool need_vals_b, IndexScratch* sc) {
+  size_t tb = 0;
+  HIPCHK(h, index_temp_bytes(n, &tb));
+  const size_t rows = (size_t)(n > 0 ? n : 1);
+  HIPCHK(h, h->ix_temp.reserve(tb));
+  HIPCHK(h, h->ix_keys_a.reserve(rows * 4));
+  HIPCHK(h, h->ix_keys_b.reserve(rows * 4));
+  HIPCHK(h, h->ix_vals_a.reserve(rows * 8));
+  if (need_vals_b) HIPCHK(h, h->ix_vals_b.reserve(rows * 8));
+  sc->temp = h->ix_temp.ptr;
+  sc->temp_bytes = tb;
+  sc->keys_a = (uint32_t*)h->ix_keys_a.ptr;
+  sc->keys_b = (uint32_t*)h->ix_keys_b.ptr;
+  sc->vals_a = (int64_t*)h->ix_vals_a.ptr;
+  sc->vals_b = (int64_t*)h->ix_vals_b.ptr;
+  return SURGE_OK;
+}
+
+// a bound log's index stands: give the build scratch back (a 10 M-aggregate log's is ~0.6 GB); micro-batch sorts keep theirs
+void index_scratch_release(surge_replay_handle* h) {
+  DevBuf* b[] = {&h->ix_temp, &h->ix_keys_a, &h->ix_keys_b, &h->ix_vals_a, &h->ix_vals_b, &h->ix_cnt, &h->ix_u_start, &h->ix_u_len, &h->ix_u_info, &h->ix_u_dest};
+  for (DevBuf* x : b) x->release();
+}
+
 // v2: length-sort the kernel-facing segments (once per bound log / per micro-batch), then one lane per segment
 int32_t run_slots(surge_replay_handle* h, FoldParams& p, const int64_t* off, int64_t n_seg, bool cache_perm) {
   if (!cache_perm || !h->perm_valid) {
     HIPCHK(h, h->perm.reserve((size_t)(n_seg > 0 ? n_seg : 1) * 8));
-    HIPCHK(h, h->sort_hist.reserve((size_t)kSortBucketsHost * 8));
-    HIPCHK(h, launch_sort_by_length(off, n_seg, (unsigned long long*)h->sort_hist.ptr, (int64_t*)h->perm.ptr, h->stream));
+    IndexScratch sc;
+    const int32_t rcs = index_scratch(h, n_seg, false, &sc);
+    if (rcs != SURGE_OK) return rcs;
+    HIPCHK(h, launch_sort_by_length(off, n_seg, sc, (int64_t*)h->perm.ptr, h->stream));
     h->perm_valid = cache_perm;
   }
   p.seg_off = off;
@@ -535,7 +564,7 @@ int32_t surge_replay_destroy(surge_replay_handle* h) {
   h->host_flags = nullptr;
   h->cidx.release();
   h->tidx.release();
-  DevBuf* bufs[] = {&h->gb_temp, &h->gb_u32, &h->gb_flags, &h->gb_agg_idx, &h->gb_events, &h->published, &h->gathered[0], &h->gathered[1], &h->f64_tables, &h->nan_count, &h->v_ctr, &h->v_total, &h->t_tiles, &h->t_gsub, &h->perm, &h->sort_hist, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
+  DevBuf* bufs[] = {&h->gb_temp, &h->gb_u32, &h->gb_flags, &h->gb_agg_idx, &h->gb_events, &h->published, &h->gathered[0], &h->gathered[1], &h->f64_tables, &h->nan_count, &h->ix_temp, &h->ix_keys_a, &h->ix_keys_b, &h->ix_vals_a, &h->ix_vals_b, &h->ix_cnt, &h->ix_u_start, &h->ix_u_len, &h->ix_u_info, &h->ix_u_dest, &h->t_tiles, &h->t_gsub, &h->perm, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
                     &h->nz_map, &h->block_counts, &h->plan, &h->batch_group_agg, &h->batch_group_off,
                     &h->batch_events, &h->poison_count, &h->gather_idx, &h->gather_out, &h->scan_totals};
   for (DevBuf* b : bufs) b->release();
@@ -733,29 +762,40 @@ int32_t plan_fold(surge_replay_handle* h, int32_t algo, FoldPlan& pl) {
 // chunk table of the kernel-facing CSR for chunk target T (align: rows tiled from their 128-byte lines — CHUNKED)
 int32_t build_chunk_index(surge_replay_handle* h, surge_replay_handle::ChunkIndex& ci, const int64_t* off, int64_t n_seg, uint32_t T,
                           bool align) {
-  HIPCHK(h, h->sort_hist.reserve((size_t)kChunkBucketsHost * 8));
-  HIPCHK(h, h->v_total.reserve(8));
-  HIPCHK(h, h->v_ctr.reserve(32));
-  unsigned long long total = 0, ctr[4] = {0, 0, 0, 0};
-  HIPCHK(h, launch_chunk_count(off, n_seg, T, align, (unsigned long long*)h->sort_hist.ptr, (unsigned long long*)h->v_total.ptr,
-                               (unsigned long long*)h->v_ctr.ptr, h->stream));
-  HIPCHK(h, hipMemcpyAsync(ctr, h->v_ctr.ptr, 32, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(&total, h->v_total.ptr, 8, hipMemcpyDeviceToHost, h->stream));
+  IndexScratch sc;
+  {
+    const int32_t rcs = index_scratch(h, n_seg + 1, true, &sc);
+    if (rcs != SURGE_OK) return rcs;
+  }
+  HIPCHK(h, h->ix_cnt.reserve((size_t)(n_seg + 1) * 3 * 8));
+  int64_t* cnt = (int64_t*)h->ix_cnt.ptr;
+  HIPCHK(h, launch_chunk_count(off, n_seg, T, align, cnt, sc, h->stream));
+  int64_t totals[3] = {0, 0, 0};  // virtual rows, cut aggregates, side slots
+  for (int k = 0; k < 3; ++k)
+    HIPCHK(h, hipMemcpyAsync(&totals[k], cnt + (int64_t)k * (n_seg + 1) + n_seg, 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  ci.n_vrows = (int64_t)total;
-  ci.n_cut_rows = (int64_t)ctr[0];
+  ci.n_vrows = totals[0];
+  ci.n_cut_rows = totals[1];
   HIPCHK(h, ci.v_start.reserve((size_t)ci.n_vrows * 8));
   HIPCHK(h, ci.v_seg.reserve((size_t)ci.n_vrows * 8));
   HIPCHK(h, ci.v_len.reserve((size_t)ci.n_vrows * 4));
   HIPCHK(h, ci.v_info.reserve((size_t)ci.n_vrows * 4));
-  HIPCHK(h, ci.v_side.reserve((size_t)ctr[1] * 80));
-  HIPCHK(h, ci.r_slot0.reserve((size_t)ctr[0] * 8));
-  HIPCHK(h, ci.r_out.reserve((size_t)ctr[0] * 8));
-  HIPCHK(h, ci.r_c.reserve((size_t)ctr[0] * 4));
-  HIPCHK(h, launch_chunk_scatter(off, n_seg, h->an.n_empty > 0 ? (const int64_t*)h->nz_map.ptr : nullptr, T, align,
-                                 (unsigned long long*)h->sort_hist.ptr, (unsigned long long*)h->v_ctr.ptr, (int64_t*)ci.v_start.ptr,
-                                 (uint32_t*)ci.v_len.ptr, (uint32_t*)ci.v_info.ptr, (int64_t*)ci.v_seg.ptr, (int64_t*)ci.r_slot0.ptr,
-                                 (uint32_t*)ci.r_c.ptr, (int64_t*)ci.r_out.ptr, h->stream));
+  HIPCHK(h, ci.v_side.reserve((size_t)totals[2] * 80));
+  HIPCHK(h, ci.r_slot0.reserve((size_t)totals[1] * 8));
+  HIPCHK(h, ci.r_out.reserve((size_t)totals[1] * 8));
+  HIPCHK(h, ci.r_c.reserve((size_t)totals[1] * 4));
+  {
+    const int32_t rcs = index_scratch(h, ci.n_vrows, true, &sc);  // the rows (>= aggregates) are what gets sorted
+    if (rcs != SURGE_OK) return rcs;
+  }
+  HIPCHK(h, h->ix_u_start.reserve((size_t)ci.n_vrows * 8));
+  HIPCHK(h, h->ix_u_dest.reserve((size_t)ci.n_vrows * 8));
+  HIPCHK(h, h->ix_u_len.reserve((size_t)ci.n_vrows * 4));
+  HIPCHK(h, h->ix_u_info.reserve((size_t)ci.n_vrows * 4));
+  HIPCHK(h, launch_chunk_table(off, n_seg, h->an.n_empty > 0 ? (const int64_t*)h->nz_map.ptr : nullptr, T, align, cnt, ci.n_vrows, sc,
+                               (int64_t*)h->ix_u_start.ptr, (uint32_t*)h->ix_u_len.ptr, (uint32_t*)h->ix_u_info.ptr, (int64_t*)h->ix_u_dest.ptr,
+                               (int64_t*)ci.v_start.ptr, (uint32_t*)ci.v_len.ptr, (uint32_t*)ci.v_info.ptr, (int64_t*)ci.v_seg.ptr,
+                               (int64_t*)ci.r_slot0.ptr, (uint32_t*)ci.r_c.ptr, (int64_t*)ci.r_out.ptr, h->stream));
   ci.T = T;
   return SURGE_OK;
 }
@@ -769,9 +809,11 @@ int32_t ensure_index(surge_replay_handle* h, const FoldPlan& pl) {
   const int64_t n_seg = h->an.n_empty > 0 ? h->n_nz : h->n_agg;
   if (pl.use == SURGE_ALGO_SORTED && !h->perm_valid) {
     HIPCHK(h, h->perm.reserve((size_t)n_seg * 8));
-    HIPCHK(h, h->sort_hist.reserve((size_t)kSortBucketsHost * 8));
+    IndexScratch sc;
+    const int32_t rcs = index_scratch(h, n_seg, false, &sc);
+    if (rcs != SURGE_OK) return rcs;
     HIPCHK(h, hipEventRecord(h->ev_i0, h->stream));
-    HIPCHK(h, launch_sort_by_length(off, n_seg, (unsigned long long*)h->sort_hist.ptr, (int64_t*)h->perm.ptr, h->stream));
+    HIPCHK(h, launch_sort_by_length(off, n_seg, sc, (int64_t*)h->perm.ptr, h->stream));
     HIPCHK(h, hipEventRecord(h->ev_i1, h->stream));
     h->perm_valid = true;
     h->index_timed = true;
@@ -810,7 +852,10 @@ int32_t ensure_index(surge_replay_handle* h, const FoldPlan& pl) {
     h->tiled_valid = true;
     h->index_timed = h->relayout_timed = true;
     h->index_algo = SURGE_ALGO_TILED;
+  } else {
+    return SURGE_OK;  // nothing was built
   }
+  index_scratch_release(h);  // (hipFree waits for the build's kernels)
   return SURGE_OK;
 }
 

@@ -44,91 +44,6 @@ namespace {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int kChunkBuckets = 65536;  // chunk-length histogram: bucket = min(chunk length, 65535)
-
-// chunks of an aggregate whose events span `span` slots from its 128-byte line start
-__host__ __device__ __forceinline__ uint32_t chunks_of(int64_t span, uint32_t T) {
-  const int64_t c = (span + T - 1) / T;
-  return (uint32_t)(c < 1 ? 1 : c);
-}
-
-// hist[chunk length] += chunks of every aggregate; ctr[0] += aggregates cut into several chunks, ctr[1] += their chunks
-// (align: rows are tiled from the 128-byte line that holds their first event — what the CSR kernel wants; the tile-major
-// re-layout copies rows to tile boundaries anyway and passes align = false: no pad events)
-__global__ void chunk_hist_kernel(const int64_t* __restrict__ off, int64_t n_seg, uint32_t T, bool align,
-                                  unsigned long long* __restrict__ hist, unsigned long long* __restrict__ ctr) {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_seg) return;
-  const int64_t st = off[s], len = off[s + 1] - st;
-  const int64_t span = len + (align ? (st & 7) : 0);
-  const uint32_t c = chunks_of(span, T);
-  const int64_t cl = (span + c - 1) / c;
-  atomicAdd(&hist[cl < kChunkBuckets - 1 ? cl : kChunkBuckets - 1], (unsigned long long)c);
-  if (c > 1) {
-    atomicAdd(&ctr[0], 1ull);
-    atomicAdd(&ctr[1], (unsigned long long)c);
-  }
-}
-
-// single block: hist[b] := number of virtual rows in buckets > b (longest first); total[0] := number of virtual rows
-__global__ void __launch_bounds__(1024) chunk_scan_kernel(unsigned long long* hist, unsigned long long* total) {
-  __shared__ unsigned long long part[1024];
-  const int tid = threadIdx.x;
-  const int per = kChunkBuckets / 1024;
-  const int hi = kChunkBuckets - 1 - tid * per;  // thread 0 owns the longest buckets
-  unsigned long long sum = 0;
-  for (int k = 0; k < per; ++k) sum += hist[hi - k];
-  part[tid] = sum;
-  __syncthreads();
-  if (tid == 0) {
-    unsigned long long run = 0;
-    for (int i = 0; i < 1024; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
-    total[0] = run;
-  }
-  __syncthreads();
-  unsigned long long run = part[tid];
-  for (int k = 0; k < per; ++k) { const unsigned long long v = hist[hi - k]; hist[hi - k] = run; run += v; }
-}
-
-// one thread per aggregate: describe its chunks as virtual rows (each claims one slot of its length bucket, so the
-// chunks of one aggregate end up on unrelated lanes) and, if it is cut, register it for the stitch kernel
-__global__ void chunk_scatter_kernel(const int64_t* __restrict__ off, int64_t n_seg, const int64_t* __restrict__ out_map,
-                                     unsigned long long* __restrict__ cursor, unsigned long long* __restrict__ ctr, uint32_t T,
-                                     bool align, int64_t* __restrict__ v_start, uint32_t* __restrict__ v_len, uint32_t* __restrict__ v_info,
-                                     int64_t* __restrict__ v_dest, int64_t* __restrict__ r_slot0, uint32_t* __restrict__ r_c,
-                                     int64_t* __restrict__ r_out) {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_seg) return;
-  const int64_t st = off[s], len = off[s + 1] - st;
-  const uint32_t pad = align ? (uint32_t)(st & 7) : 0u;
-  const int64_t base = st - pad;  // the 128-byte line that holds the first event (align), or the first event itself
-  const int64_t span = len + pad, end = st + len;
-  const uint32_t c = chunks_of(span, T);
-  const int64_t cl = (span + c - 1) / c;
-  const int64_t b = cl < kChunkBuckets - 1 ? cl : kChunkBuckets - 1;
-  const int64_t oi = out_map ? out_map[s] : s;
-  int64_t slot0 = 0;
-  if (c > 1) {
-    const unsigned long long r = atomicAdd(&ctr[2], 1ull);
-    slot0 = (int64_t)atomicAdd(&ctr[3], (unsigned long long)c);
-    r_slot0[r] = slot0; r_c[r] = c; r_out[r] = oi;
-  }
-  // chunk k = [base + floor8(k span / c), base + floor8((k+1) span / c)): boundaries on whole lines, lengths within 8
-  // events of each other
-  for (uint32_t k = 0; k < c; ++k) {
-    const int64_t lo = base + (((int64_t)k * span / c) & ~7ll);
-    const int64_t hiE = k + 1 == c ? end : base + (((int64_t)(k + 1) * span / c) & ~7ll);
-    const bool empty = hiE <= lo;  // cannot happen while T >= 16 (span / c >= 8); kept as a guard
-    const unsigned long long pos = atomicAdd(&cursor[b], 1ull);
-    v_start[pos] = empty ? 0 : lo;  // an empty chunk still "reads" (clamped, ignored): keep it in bounds
-    v_len[pos] = empty ? 0u : (uint32_t)(hiE - lo);
-    // every chunk of a cut aggregate is walked relative, chunk 0 included: the stitch kernel starts from the
-    // aggregate's prior state; an aggregate in one piece is walked concretely and stores its own state
-    v_info[pos] = (c > 1 ? (VI_RELATIVE | VI_SIDE) : 0u) | ((k == 0 ? pad : 0u) << VI_PAD_SHIFT);
-    v_dest[pos] = c > 1 ? slot0 + k : oi;
-  }
-}
-
 // second kernel: one thread per cut aggregate composes its chunk summaries left to right onto the prior state
 __global__ void chunk_stitch_kernel(const FoldParams p, const uint32_t* __restrict__ side, const int64_t* __restrict__ r_slot0,
                                     const uint32_t* __restrict__ r_c, const int64_t* __restrict__ r_out, int64_t n_rows) {
@@ -307,31 +222,6 @@ fold_chunked_kernel(const FoldParams p, const ChunkTable t) {
 }
 
 }  // namespace
-
-// Build the chunk table of a kernel-facing CSR (once per bound log).  d_hist: kChunkBuckets u64 scratch; d_total:
-// one u64; d_ctr: four u64.  Phase 1 (count) leaves the number of virtual rows in *d_total and {cut aggregates, their
-// chunks, 0, 0} in d_ctr; the host reads them, sizes the arrays and runs phase 2 (scatter).
-hipError_t launch_chunk_count(const int64_t* off, int64_t n_seg, uint32_t T, bool align, unsigned long long* d_hist,
-                              unsigned long long* d_total, unsigned long long* d_ctr, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(d_hist, 0, (size_t)kChunkBuckets * 8, stream);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(d_ctr, 0, 32, stream);
-  if (e != hipSuccess) return e;
-  if (n_seg > 0)
-    hipLaunchKernelGGL(chunk_hist_kernel, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, stream, off, n_seg, T, align, d_hist, d_ctr);
-  hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, stream, d_hist, d_total);
-  return hipGetLastError();
-}
-
-hipError_t launch_chunk_scatter(const int64_t* off, int64_t n_seg, const int64_t* out_map, uint32_t T, bool align,
-                                unsigned long long* d_cursor, unsigned long long* d_ctr, int64_t* v_start, uint32_t* v_len,
-                                uint32_t* v_info, int64_t* v_dest, int64_t* r_slot0, uint32_t* r_c, int64_t* r_out,
-                                hipStream_t stream) {
-  if (n_seg <= 0) return hipSuccess;
-  hipLaunchKernelGGL(chunk_scatter_kernel, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, stream, off, n_seg, out_map,
-                     d_cursor, d_ctr, T, align, v_start, v_len, v_info, v_dest, r_slot0, r_c, r_out);
-  return hipGetLastError();
-}
 
 // the fold over the chunk table + the stitch of the cut aggregates
 hipError_t launch_fold_chunked(const FoldParams& p, const int64_t* v_start, const uint32_t* v_len, const uint32_t* v_info,

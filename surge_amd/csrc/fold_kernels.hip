@@ -372,7 +372,6 @@ __global__ void __launch_bounds__(kWave) fold_rows_kernel(const FoldParams p) {
 // equal, so the 64 lanes walk their own segments in lockstep exactly like the uniform rows kernel:
 // concrete running state, no presence pre-pass, no scan.  A lane whose segment ends early pads with the
 // null event.  Row pieces are LE*16 bytes at arbitrary 16 B-aligned addresses.
-constexpr int kSortBuckets = 65536;  // bucket = min(length, 65535); longer segments share the last one
 
 template <int LE>
 __global__ void __launch_bounds__(kWave) fold_sorted_kernel(const FoldParams p) {
@@ -483,42 +482,6 @@ __global__ void __launch_bounds__(kWave) fold_sorted_kernel(const FoldParams p) 
     cur = nxt;
   }
   dispenser_leave(p.counter, lane);
-}
-
-// load-time counting sort of the kernel-facing segments by length, longest first
-__global__ void sort_hist_kernel(const int64_t* __restrict__ off, int64_t n_seg, unsigned long long* __restrict__ hist) {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_seg) return;
-  const int64_t len = off[s + 1] - off[s];
-  atomicAdd(&hist[len < kSortBuckets - 1 ? len : kSortBuckets - 1], 1ull);
-}
-
-// single block: hist[b] := number of segments in buckets > b (descending exclusive scan)
-__global__ void __launch_bounds__(1024) sort_scan_kernel(unsigned long long* hist) {
-  __shared__ unsigned long long part[1024];
-  const int tid = threadIdx.x;
-  const int per = kSortBuckets / 1024;
-  const int hi = kSortBuckets - 1 - tid * per;  // thread 0 owns the longest buckets
-  unsigned long long sum = 0;
-  for (int k = 0; k < per; ++k) sum += hist[hi - k];
-  part[tid] = sum;
-  __syncthreads();
-  if (tid == 0) {
-    unsigned long long run = 0;
-    for (int i = 0; i < 1024; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
-  }
-  __syncthreads();
-  unsigned long long run = part[tid];
-  for (int k = 0; k < per; ++k) { const unsigned long long v = hist[hi - k]; hist[hi - k] = run; run += v; }
-}
-
-__global__ void sort_scatter_kernel(const int64_t* __restrict__ off, int64_t n_seg, unsigned long long* __restrict__ cursor,
-                                    int64_t* __restrict__ perm) {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_seg) return;
-  const int64_t len = off[s + 1] - off[s];
-  const unsigned long long pos = atomicAdd(&cursor[len < kSortBuckets - 1 ? len : kSortBuckets - 1], 1ull);
-  perm[pos] = s;
 }
 
 // ---- plan: task k owns segments [lower_bound(off, off[0] + k*T), lower_bound(off, off[0] + (k+1)*T)) ----
@@ -688,19 +651,6 @@ hipError_t launch_fold_sorted(const FoldParams& p, int64_t n_waves, int lane_eve
     hipLaunchKernelGGL((fold_sorted_kernel<32>), dim3((unsigned)n_waves), dim3(kWave), Geo<32>::lds_bytes(Geo<32>::kAuxSorted), stream, p);
   else
     hipLaunchKernelGGL((fold_sorted_kernel<16>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxSorted), stream, p);
-  return hipGetLastError();
-}
-
-// perm (n_seg int64) := kernel-facing segment ids sorted by length, longest first.  d_hist: kSortBuckets u64 scratch.
-hipError_t launch_sort_by_length(const int64_t* off, int64_t n_seg, unsigned long long* d_hist, int64_t* perm,
-                                 hipStream_t stream) {
-  if (n_seg <= 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(d_hist, 0, (size_t)kSortBuckets * 8, stream);
-  if (e != hipSuccess) return e;
-  const unsigned blocks = (unsigned)((n_seg + 255) / 256);
-  hipLaunchKernelGGL(sort_hist_kernel, dim3(blocks), dim3(256), 0, stream, off, n_seg, d_hist);
-  hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, stream, d_hist);
-  hipLaunchKernelGGL(sort_scatter_kernel, dim3(blocks), dim3(256), 0, stream, off, n_seg, d_hist, perm);
   return hipGetLastError();
 }
 

@@ -27,17 +27,22 @@ hipError_t launch_fold_fixed(const FoldParams& p, int64_t n_tasks, int lane_even
 hipError_t launch_fold_flat(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream);
 hipError_t launch_fold_rows(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream);
 hipError_t launch_fold_sorted(const FoldParams& p, int64_t n_waves, int lane_events, hipStream_t stream);
-constexpr int kSortBucketsHost = 65536;
-hipError_t launch_sort_by_length(const int64_t* off, int64_t n_seg, unsigned long long* d_hist, int64_t* perm,
-                                 hipStream_t stream);
-// CHUNKED (fold_chunked.hip): chunk table of the kernel-facing CSR, then the fold over it + the stitch kernel
-constexpr int kChunkBucketsHost = 65536;
-hipError_t launch_chunk_count(const int64_t* off, int64_t n_seg, uint32_t T, bool align, unsigned long long* d_hist,
-                              unsigned long long* d_total, unsigned long long* d_ctr, hipStream_t stream);
-hipError_t launch_chunk_scatter(const int64_t* off, int64_t n_seg, const int64_t* out_map, uint32_t T, bool align,
-                                unsigned long long* d_cursor, unsigned long long* d_ctr, int64_t* v_start, uint32_t* v_len,
-                                uint32_t* v_info, int64_t* v_dest, int64_t* r_slot0, uint32_t* r_c, int64_t* r_out,
-                                hipStream_t stream);
+// ---- index_kernels.hip: the per-log indexes (length order, chunk table), built with rocPRIM sorts / scans -----------
+struct IndexScratch {  // engine-owned device scratch, sized for the rows being ordered
+  void* temp;          // rocPRIM temporary storage
+  size_t temp_bytes;
+  uint32_t *keys_a, *keys_b;  // n x u32 each
+  int64_t *vals_a, *vals_b;   // n x i64 each (launch_sort_by_length writes its result to `perm` instead of vals_b)
+};
+hipError_t index_temp_bytes(int64_t n, size_t* bytes);
+hipError_t launch_sort_by_length(const int64_t* off, int64_t n_seg, const IndexScratch& sc, int64_t* perm, hipStream_t stream);
+// CHUNKED / TILED: the chunk table of the kernel-facing CSR.  cnt: 3 x (n_seg + 1) int64.
+hipError_t launch_chunk_count(const int64_t* off, int64_t n_seg, uint32_t T, bool align, int64_t* cnt, const IndexScratch& sc,
+                              hipStream_t stream);
+hipError_t launch_chunk_table(const int64_t* off, int64_t n_seg, const int64_t* out_map, uint32_t T, bool align, const int64_t* cnt,
+                              int64_t n_vrows, const IndexScratch& sc, int64_t* u_start, uint32_t* u_len, uint32_t* u_info, int64_t* u_dest,
+                              int64_t* v_start, uint32_t* v_len, uint32_t* v_info, int64_t* v_dest, int64_t* r_slot0, uint32_t* r_c,
+                              int64_t* r_out, hipStream_t stream);
 hipError_t launch_fold_chunked(const FoldParams& p, const int64_t* v_start, const uint32_t* v_len, const uint32_t* v_info,
                                const int64_t* v_dest, int64_t n_vrows, uint32_t* side, const int64_t* r_slot0, const uint32_t* r_c,
                                const int64_t* r_out, int64_t n_cut, int64_t n_waves, int lane_events, hipStream_t stream);
