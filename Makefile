@@ -3,8 +3,8 @@
 HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 LIB     := surge_amd/libsurge_replay.so
-SRC     := surge_amd/csrc/fold_kernels.hip surge_amd/csrc/fold_chunked.hip surge_amd/csrc/fold_tiled.hip surge_amd/csrc/fold_slots.hip surge_amd/csrc/index_kernels.hip surge_amd/csrc/rtc.cpp surge_amd/csrc/f64_text.cpp surge_amd/csrc/state_kernels.hip surge_amd/csrc/stream_kernels.hip surge_amd/csrc/engine.hip surge_amd/csrc/comm.hip surge_amd/csrc/ingest.cpp surge_amd/csrc/event_decode.cpp surge_amd/csrc/lz4_frame.cpp surge_amd/csrc/snapshot_writer.cpp
-HDR     := include/surge_replay.h include/surge_ingest.h include/surge_snapshot.h surge_amd/csrc/replay_internal.h surge_amd/csrc/fold_layout.h surge_amd/csrc/fold_device.h surge_amd/csrc/fold_chunk_device.h surge_amd/csrc/fold_slots_device.h surge_amd/csrc/f64_text.h
+SRC     := surge_amd/csrc/fold_kernels.hip surge_amd/csrc/fold_chunked.hip surge_amd/csrc/fold_tiled.hip surge_amd/csrc/fold_slots.hip surge_amd/csrc/index_kernels.hip surge_amd/csrc/ingest_kernels.hip surge_amd/csrc/rtc.cpp surge_amd/csrc/f64_text.cpp surge_amd/csrc/state_kernels.hip surge_amd/csrc/stream_kernels.hip surge_amd/csrc/engine.hip surge_amd/csrc/comm.hip surge_amd/csrc/ingest.cpp surge_amd/csrc/event_decode.cpp surge_amd/csrc/lz4_frame.cpp surge_amd/csrc/snapshot_writer.cpp
+HDR     := include/surge_replay.h include/surge_ingest.h include/surge_snapshot.h surge_amd/csrc/replay_internal.h surge_amd/csrc/fold_layout.h surge_amd/csrc/fold_device.h surge_amd/csrc/fold_chunk_device.h surge_amd/csrc/fold_slots_device.h surge_amd/csrc/f64_text.h surge_amd/csrc/f64_parse.h
 LDDEMO  := -Lsurge_amd -lsurge_replay -Wl,-rpath,$(CURDIR)/surge_amd -L/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib
 
 .PHONY: all lib oracle demos clean

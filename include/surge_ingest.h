@@ -1,8 +1,8 @@
 /*
  * surge_ingest.h — C ABI of the events-topic ingest: the step immediately BEFORE
- * the fold.  Host-side, no GPU: Kafka record batches of one partition of the events topic in, records
- * in offset order with their aggregate index out (ready for surge_replay_load_csr /
- * surge_replay_append_events).
+ * the fold.  Kafka record batches of one partition of the events topic in, records in offset order with
+ * their aggregate index out (ready for surge_replay_load_csr / surge_replay_append_events): entirely on
+ * the host, or — "device decode" below — framed on the host and decoded on the GPU.
  *
  * What it restates (third party, NOT vendored under /root/reference: org.apache.kafka:kafka-clients 3.2.3,
  * message format v2 / KIP-98; LZ4 frame format — "parity unpinned"):
@@ -32,7 +32,7 @@ extern "C" {
 #define SURGE_INGEST_READ_UNCOMMITTED 0
 #define SURGE_INGEST_READ_COMMITTED   1
 
-/* status codes are surge_replay.h's: 0 OK, -1 INVALID, -2 STATE, -4 NOMEM, -5 UNSUPPORTED; plus: */
+/* status codes are surge_replay.h's: 0 OK, -1 INVALID, -2 STATE, -3 DEVICE, -4 NOMEM, -5 UNSUPPORTED; plus: */
 #define SURGE_E_CORRUPT (-7) /* bad magic / CRC mismatch / malformed varint / bad LZ4 stream */
 
 typedef struct surge_ingest surge_ingest;
@@ -103,11 +103,62 @@ int32_t surge_event_json_validate(const surge_event_json_template* t);
  * that is not what the template says); the reason is in surge_event_json_last_error() (thread-local). */
 int32_t surge_event_json_decode(const surge_event_json_template* t, const uint8_t* value, int64_t len, void* event16_out);
 const char* surge_event_json_last_error(void);
+/* A JSON number -> the bits of the nearest IEEE double, ties to even (what BigDecimal(text).doubleValue gives play-json):
+ * the Eisel-Lemire algorithm (surge_amd/csrc/f64_parse.h — the same code decodes Doubles on the device), with strtod
+ * for the values it reports as undecidable.  0: decided by the fast path; 1: decided by strtod; SURGE_E_CORRUPT: not a
+ * JSON number. */
+int32_t surge_parse_f64_json(const uint8_t* text, int64_t len, uint64_t* bits_out);
 /* Like surge_ingest_drain_fixed16 for topics whose values are JSON events: pops up to max deliverable records and
  * decodes each value through the template — no per-record work in the host language.  Nothing is popped when a value
  * does not decode (SURGE_E_CORRUPT; surge_ingest_last_error names the record's offset and the reason). */
 int32_t surge_ingest_drain_json(surge_ingest* g, int64_t max, const surge_event_json_template* tmpl, int64_t* agg_idx_out,
                                 void* events16_out, int64_t* offsets_out, int64_t* n_out);
+
+/* ---- device decode (N1 on the GPU) ---------------------------------------------------------------------------------------
+ * Per-record work — parsing the varint-framed records, interning the aggregate ids, decoding the event values — is what
+ * the host decoder above spends its time on (about 90 ns per record and thread for 16-byte values, 640 ns for JSON), in
+ * front of a fold that takes 3 ps per event.  In FRAMES mode the host keeps only what is sequential and cheap per byte —
+ * walking the 61-byte batch headers, the CRC-32C, read_committed, LZ4 — and hands the records SECTIONS of the
+ * deliverable batches over as they are; a surge_device_decoder turns them into device-resident (aggregate index,
+ * 16-byte event, offset) arrays and a device key table: what surge_replay_append_events_device / a CSR build take.
+ *   g = surge_ingest_create(isolation | SURGE_INGEST_FRAMES, ..)   feed as usual
+ *   surge_ingest_drain_sections(g, ..)  ->  surge_device_decoder_push(d, surge_ingest_arena(g), sections, n)
+ * Same results as surge_ingest_drain_fixed16 / _json on the same bytes (tests/test_ingest_gpu.py): same records in the
+ * same order, aggregate ids numbered in first-delivered order, flush records skipped, the same values rejected. */
+#define SURGE_INGEST_FRAMES 0x100 /* OR into surge_ingest_create's isolation_level */
+typedef struct surge_batch_section {
+  int64_t byte_off;    /* the batch's records section inside the arena (surge_ingest_arena)            */
+  int64_t byte_len;
+  int64_t base_offset; /* Kafka offset of the batch's first record                                     */
+  int32_t n_records;
+  int32_t reserved;
+} surge_batch_section;
+/* Pops up to max deliverable batches (committed / non-transactional, before any open transaction), in offset order.
+ * Spans stay valid until the next feed / destroy.  SURGE_E_STATE on a decoder that was not created in FRAMES mode. */
+int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge_batch_section* out, int64_t* n_out);
+
+typedef struct surge_device_decoder surge_device_decoder;
+/* tmpl == NULL: record values are 16-byte surge_event16; otherwise the reference's JSON event text, decoded by the
+ * template with surge_event_json_decode's rules (Doubles correctly rounded on the device — f64_parse.h — the rare value
+ * its fast path cannot decide is re-parsed on the host).  hip_stream: the stream the decoder works on (NULL = default). */
+int32_t surge_device_decoder_create(int32_t device_id, void* hip_stream, const surge_event_json_template* tmpl, surge_device_decoder** out);
+int32_t surge_device_decoder_destroy(surge_device_decoder* d);
+const char* surge_device_decoder_last_error(const surge_device_decoder* d);
+/* Decodes the sections (spans of `bytes`, a HOST buffer) and APPENDS their records to the device-resident result.  A
+ * record that does not decode fails the whole push (SURGE_E_CORRUPT, the message names the record's offset): nothing of
+ * the push is appended.  Synchronous. */
+int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes, const surge_batch_section* sections, int64_t n_sections);
+/* Everything appended since the last clear: device arrays of n_records entries (valid until the next push / clear). */
+int32_t surge_device_decoder_result(surge_device_decoder* d, int64_t* n_records, const int64_t** d_agg_idx, const void** d_events16,
+                                    const int64_t** d_offsets, int64_t* n_keys);
+int32_t surge_device_decoder_clear(surge_device_decoder* d); /* drops the records, keeps the key table */
+/* The key table (aggregate ids in first-delivered order): to the host (NULL / NULL = size query), or where it lives on
+ * the device (n_keys + 1 offsets; what the GPU state encoders and K4 take). */
+int32_t surge_device_decoder_keys(surge_device_decoder* d, uint8_t* utf8_out, int64_t utf8_capacity, int64_t* key_off_out, int64_t* n_keys_out,
+                                  int64_t* utf8_bytes_out);
+int32_t surge_device_decoder_key_table(surge_device_decoder* d, const uint8_t** d_utf8, const int64_t** d_key_off);
+/* [0] records seen, [1] delivered, [2] flush records skipped, [3] Double values re-parsed on the host */
+int32_t surge_device_decoder_counters(const surge_device_decoder* d, int64_t out[4]);
 
 /* Key table: aggregate ids in first-DELIVERED order (a key is interned when its record is drained, so the
  * keys of aborted or still-open transactions never appear). */

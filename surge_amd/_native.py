@@ -17,8 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
-SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip", "fold_slots.hip", "index_kernels.hip", "rtc.cpp", "f64_text.cpp", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "event_decode.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")
-HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "fold_chunk_device.h"), os.path.join(CSRC, "fold_slots_device.h"), os.path.join(CSRC, "f64_text.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
+SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip", "fold_slots.hip", "index_kernels.hip", "ingest_kernels.hip", "rtc.cpp", "f64_text.cpp", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "event_decode.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")
+HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "fold_chunk_device.h"), os.path.join(CSRC, "fold_slots_device.h"), os.path.join(CSRC, "f64_text.h"), os.path.join(CSRC, "f64_parse.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
 EXPORTS = (
@@ -87,9 +87,20 @@ INGEST_EXPORTS = (
     "surge_ingest_arena",
     "surge_ingest_drain_fixed16",
     "surge_ingest_drain_json",
+    "surge_ingest_drain_sections",
+    "surge_device_decoder_create",
+    "surge_device_decoder_destroy",
+    "surge_device_decoder_last_error",
+    "surge_device_decoder_push",
+    "surge_device_decoder_result",
+    "surge_device_decoder_clear",
+    "surge_device_decoder_keys",
+    "surge_device_decoder_key_table",
+    "surge_device_decoder_counters",
     "surge_event_json_validate",
     "surge_event_json_decode",
     "surge_event_json_last_error",
+    "surge_parse_f64_json",
     "surge_ingest_key_count",
     "surge_ingest_key",
     "surge_ingest_counters",
@@ -250,9 +261,20 @@ def load() -> ctypes.CDLL:
         "surge_ingest_arena": ([vp], vp),
         "surge_ingest_drain_fixed16": ([vp, i64, vp, vp, vp, ctypes.POINTER(i64)], i32),
         "surge_ingest_drain_json": ([vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)], i32),
+        "surge_ingest_drain_sections": ([vp, i64, vp, ctypes.POINTER(i64)], i32),
+        "surge_device_decoder_create": ([i32, vp, vp, ctypes.POINTER(vp)], i32),
+        "surge_device_decoder_destroy": ([vp], i32),
+        "surge_device_decoder_last_error": ([vp], ctypes.c_char_p),
+        "surge_device_decoder_push": ([vp, vp, vp, i64], i32),
+        "surge_device_decoder_result": ([vp, ctypes.POINTER(i64), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64)], i32),
+        "surge_device_decoder_clear": ([vp], i32),
+        "surge_device_decoder_keys": ([vp, vp, i64, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
+        "surge_device_decoder_key_table": ([vp, ctypes.POINTER(vp), ctypes.POINTER(vp)], i32),
+        "surge_device_decoder_counters": ([vp, ctypes.POINTER(i64 * 4)], i32),
         "surge_event_json_validate": ([vp], i32),
         "surge_event_json_decode": ([vp, vp, i64, vp], i32),
         "surge_event_json_last_error": ([], ctypes.c_char_p),
+        "surge_parse_f64_json": ([vp, i64, ctypes.POINTER(ctypes.c_uint64)], i32),
         "surge_ingest_key_count": ([vp], i64),
         "surge_ingest_key": ([vp, i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i64)], i32),
         "surge_ingest_counters": ([vp, ctypes.POINTER(i64 * 8)], i32),

@@ -9,8 +9,8 @@
 // ("_type") naming the case class.  The decoder does not depend on field order or on fields it is not told about: it
 // scans the top-level object once, remembers the discriminator string and every numeric field, then builds the event from
 // the template entry the discriminator selects.  Numbers: an I32 payload / the sequence number must be a JSON integer
-// that fits an Int (anything else is reported, not truncated); an F64 payload is converted with strtod, which rounds
-// correctly like the JVM's BigDecimal.doubleValue that play-json reads Doubles with.
+// that fits an Int (anything else is reported, not truncated); an F64 payload is converted by
+// surge_parse_f64_json (f64_parse.h), correctly rounded like the JVM's BigDecimal.doubleValue that play-json reads Doubles with.
 //
 // play-json itself is not under /root/reference (com.typesafe.play:play-json 2.9.2): its exact text — where it puts the
 // discriminator, how it spells a Double — is parity-unpinned; being order- and spelling-agnostic is what
@@ -129,15 +129,11 @@ int parse_i32(const uint8_t* s, int len, int32_t* out) {
 }
 
 bool parse_f64(const uint8_t* s, int len, double* out) {
-  if (len <= 0 || len >= 400) return false;
-  char buf[400];
-  std::memcpy(buf, s, (size_t)len);
-  buf[len] = 0;
-  char* endp = nullptr;
-  errno = 0;
-  const double v = std::strtod(buf, &endp);  // correctly rounded (glibc), like BigDecimal.doubleValue
-  if (endp != buf + len) return false;
-  *out = v;
+  // the library's own correctly rounded parser (Eisel-Lemire, strtod where that cannot decide): the code the device
+  // decoder runs, so host and device agree on every value by construction — and both with BigDecimal.doubleValue
+  uint64_t bits = 0;
+  if (surge_parse_f64_json(s, len, &bits) < 0) return false;
+  std::memcpy(out, &bits, 8);
   return true;
 }
 

@@ -1,7 +1,9 @@
 // f64_text.cpp — the power-of-5 tables of f64_text.h, computed once with exact integer arithmetic, and the host entry
 // point of the Double -> JSON text conversion (the device copy of the tables is made by engine.hip).
 #include "f64_text.h"
+#include "f64_parse.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -98,7 +100,45 @@ void build_tables() {
   }
 }
 
+// The Eisel-Lemire table (f64_parse.h), as the algorithm's published generator script defines it:
+//   q >= 0: 5^q shifted left until bit 127 is set, truncated to 128 bits;
+//   q <  0: c = floor(2^b / 5^-q) + 1 with b = z + 127 for q >= -27 and b = 2 z + 128 below (z = bits of 5^-q, i.e. the
+//           smallest z with 2^z >= 5^-q), truncated to its top 128 bits.
+F64ParseTable g_parse;
+std::once_flag g_parse_once;
+
+void build_parse_table() {
+  auto store = [](int q, const Nat& v) {
+    uint64_t w[2];
+    window128(v, bit_length(v) - 128, w);  // top 128 bits (shifted left when shorter)
+    g_parse.p5[2 * (q - kPow10Min)] = w[1];
+    g_parse.p5[2 * (q - kPow10Min) + 1] = w[0];
+  };
+  Nat p{1u};
+  for (int q = 0; q <= kPow10Max; ++q) {
+    store(q, p);
+    mul_small(p, 5u);
+  }
+  p = Nat{5u};
+  for (int q = -1; q >= kPow10Min; --q) {
+    int z = bit_length(p);                       // 2^(z-1) <= p < 2^z; p is never a power of two, so this is the script's z
+    const int b = q >= -27 ? z + 127 : 2 * z + 128;
+    Nat c = div_pow2(b, p);
+    for (size_t l = 0;; ++l) {                   // + 1
+      if (l == c.size()) { c.push_back(1u); break; }
+      if (++c[l] != 0u) break;
+    }
+    store(q, c);
+    mul_small(p, 5u);
+  }
+}
+
 }  // namespace
+
+const F64ParseTable* f64_parse_table_host() {
+  std::call_once(g_parse_once, build_parse_table);
+  return &g_parse;
+}
 
 const F64Tables* f64_tables_host() {
   std::call_once(g_once, build_tables);
@@ -112,6 +152,26 @@ extern "C" int32_t surge_format_f64_json(uint64_t bits, uint8_t* out, int32_t ca
   const int n = surge::f64_play_json_text(bits, surge::f64_tables_host(), tmp);
   if (out && capacity >= n) std::memcpy(out, tmp, (size_t)n);
   return n;
+}
+
+// JSON number -> double bits.  0 = OK; 1 = the fast algorithm cannot decide (more than 19 digits, or one of its rare
+// ambiguous products): *bits_out is then the exact result computed with strtod — the status only tells tests which path
+// ran; SURGE_E_CORRUPT (-7) = not a JSON number.
+extern "C" int32_t surge_parse_f64_json(const uint8_t* text, int64_t len, uint64_t* bits_out) {
+  if (!text || !bits_out || len <= 0 || len >= 400) return -7;
+  const int rc = surge::f64_parse_json_number(text, (int)len, surge::f64_parse_table_host(), bits_out);
+  if (rc == surge::F64_PARSE_MALFORMED) return -7;
+  if (rc == surge::F64_PARSE_AMBIGUOUS) {
+    char buf[400];
+    std::memcpy(buf, text, (size_t)len);
+    buf[len] = 0;
+    char* endp = nullptr;
+    const double v = std::strtod(buf, &endp);
+    if (endp != buf + len) return -7;
+    std::memcpy(bits_out, &v, 8);
+    return 1;
+  }
+  return 0;
 }
 
 extern "C" int64_t surge_format_f64_json_many(const uint64_t* bits, int64_t n, uint8_t* out, int64_t capacity, int64_t* out_off) {

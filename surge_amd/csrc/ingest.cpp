@@ -27,6 +27,9 @@ struct Batch {
   int decided = 1;  // 0 pending (open transaction), 1 committed / non-transactional, 2 aborted
   std::vector<Rec> recs;
   size_t next = 0;  // first record not yet drained
+  // FRAMES mode (device decode): the batch's records section, verbatim, inside the arena
+  int64_t sect_off = -1, sect_len = 0, base_offset = 0;
+  int32_t count = 0;
 };
 
 struct CrcTables {
@@ -147,6 +150,7 @@ int lz4_block(const uint8_t* ip, const uint8_t* iend, uint8_t* dst, int64_t* op_
 
 struct surge_ingest {
   int isolation = SURGE_INGEST_READ_COMMITTED;
+  bool frames = false;  // SURGE_INGEST_FRAMES: records are not parsed here, their sections go to a surge_device_decoder
   std::string err;
   std::vector<uint8_t> arena;
   std::deque<Batch> queue;
@@ -226,7 +230,7 @@ int64_t ready_count(const surge_ingest* g) {
   int64_t n = 0;
   for (const Batch& b : g->queue) {
     if (b.decided == 0) break;  // an open transaction: nothing behind it is stable yet
-    if (b.decided == 1) n += (int64_t)(b.recs.size() - b.next);
+    if (b.decided == 1) n += b.sect_off >= 0 ? (int64_t)b.count : (int64_t)(b.recs.size() - b.next);
   }
   return n;
 }
@@ -359,11 +363,14 @@ int64_t surge_lz4_frame_decompress(const uint8_t* src, int64_t n, uint8_t* dst, 
 int32_t surge_ingest_create(int32_t isolation_level, surge_ingest** out) {
   if (!out) return fail(nullptr, E_INVALID, "out is NULL");
   *out = nullptr;
+  const bool frames = (isolation_level & SURGE_INGEST_FRAMES) != 0;
+  isolation_level &= ~SURGE_INGEST_FRAMES;
   if (isolation_level != SURGE_INGEST_READ_UNCOMMITTED && isolation_level != SURGE_INGEST_READ_COMMITTED)
     return fail(nullptr, E_INVALID, "unknown isolation level");
   surge_ingest* g = new (std::nothrow) surge_ingest();
   if (!g) return fail(nullptr, E_NOMEM, "out of host memory");
   g->isolation = isolation_level;
+  g->frames = frames;
   *out = g;
   return OK;
 }
@@ -442,10 +449,20 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
       b.producer_id = producer_id;
       b.transactional = transactional;
       int control_type = -1;
-      const int32_t rc = parse_records(g, b, recs, recs_len, count, base_offset, control, &control_type);
-      if (rc != OK) {
-        if (consumed_out) *consumed_out = pos;
-        return rc;
+      if (g->frames && !control) {
+        // device decode: the records section travels as it is (the device chains and parses the records)
+        b.sect_off = (int64_t)g->arena.size();
+        b.sect_len = recs_len;
+        b.base_offset = base_offset;
+        b.count = count;
+        g->arena.insert(g->arena.end(), recs, recs + recs_len);
+        g->counters[1] += count;
+      } else {
+        const int32_t rc = parse_records(g, b, recs, recs_len, count, base_offset, control, &control_type);
+        if (rc != OK) {
+          if (consumed_out) *consumed_out = pos;
+          return rc;
+        }
       }
       g->counters[0] += 1;
       if (control) {
@@ -454,12 +471,12 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
           for (Batch& qb : g->queue)
             if (qb.decided == 0 && qb.producer_id == producer_id) {
               qb.decided = control_type == 1 ? 1 : 2;
-              if (control_type == 0) g->counters[3] += (int64_t)qb.recs.size();
+              if (control_type == 0) g->counters[3] += qb.sect_off >= 0 ? (int64_t)qb.count : (int64_t)qb.recs.size();
             }
         }
       } else {
         b.decided = (transactional && g->isolation == SURGE_INGEST_READ_COMMITTED) ? 0 : 1;
-        if (!b.recs.empty()) g->queue.push_back(std::move(b));
+        if (!b.recs.empty() || b.count > 0) g->queue.push_back(std::move(b));
       }
       pos += 12 + batch_len;
     }
@@ -478,6 +495,7 @@ int64_t surge_ingest_ready(const surge_ingest* g) { return g ? ready_count(g) : 
 
 int32_t surge_ingest_drain(surge_ingest* g, int64_t max, surge_ingest_record* out, int64_t* n_out) {
   if (!g || !n_out || max < 0 || (!out && max > 0)) return fail(g, E_INVALID, "bad argument");
+  if (g->frames) return fail(g, -2, "this decoder frames batches for a surge_device_decoder (SURGE_INGEST_FRAMES): use surge_ingest_drain_sections");
   int64_t n = 0;
   while (n < max && !g->queue.empty()) {
     Batch& b = g->queue.front();
@@ -502,6 +520,7 @@ int32_t surge_ingest_drain_fixed16(surge_ingest* g, int64_t max, int64_t* agg_id
                                    int64_t* offsets_out, int64_t* n_out) {
   if (!g || !n_out || max < 0 || ((!agg_idx_out || !events16_out) && max > 0)) return fail(g, E_INVALID, "bad argument");
   // validate before popping anything
+  if (g->frames) return fail(g, -2, "this decoder frames batches for a surge_device_decoder (SURGE_INGEST_FRAMES): use surge_ingest_drain_sections");
   int64_t avail = 0;
   for (const Batch& b : g->queue) {
     if (b.decided == 0) break;
@@ -534,6 +553,7 @@ int32_t surge_ingest_drain_fixed16(surge_ingest* g, int64_t max, int64_t* agg_id
 int32_t surge_ingest_drain_json(surge_ingest* g, int64_t max, const surge_event_json_template* tmpl, int64_t* agg_idx_out,
                                 void* events16_out, int64_t* offsets_out, int64_t* n_out) {
   if (!g || !n_out || !tmpl || max < 0 || ((!agg_idx_out || !events16_out) && max > 0)) return fail(g, E_INVALID, "bad argument");
+  if (g->frames) return fail(g, -2, "this decoder frames batches for a surge_device_decoder (SURGE_INGEST_FRAMES): use surge_ingest_drain_sections");
   if (surge_event_json_validate(tmpl) != 0) return fail(g, E_INVALID, std::string("event template: ") + surge_event_json_last_error());
   // decode before popping anything: a value that does not decode leaves the queue as it was
   uint8_t* ev = (uint8_t*)events16_out;
@@ -565,6 +585,29 @@ int32_t surge_ingest_drain_json(surge_ingest* g, int64_t max, const surge_event_
     if (b.next == b.recs.size()) g->queue.pop_front();
   }
   g->counters[2] += n;
+  *n_out = n;
+  return OK;
+}
+
+int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge_batch_section* out, int64_t* n_out) {
+  if (!g || !n_out || max_sections < 0 || (!out && max_sections > 0)) return fail(g, E_INVALID, "bad argument");
+  if (!g->frames) return fail(g, -2, "surge_ingest_drain_sections needs a decoder created with SURGE_INGEST_FRAMES");
+  int64_t n = 0, recs = 0;
+  while (n < max_sections && !g->queue.empty()) {
+    Batch& b = g->queue.front();
+    if (b.decided == 0) break;  // an open transaction: nothing behind it is stable yet
+    if (b.decided == 1) {
+      out[n].byte_off = b.sect_off;
+      out[n].byte_len = b.sect_len;
+      out[n].base_offset = b.base_offset;
+      out[n].n_records = b.count;
+      out[n].reserved = 0;
+      recs += b.count;
+      ++n;
+    }
+    g->queue.pop_front();
+  }
+  g->counters[2] += recs;  // handed to the device decoder (its own counters tell flush records from events)
   *n_out = n;
   return OK;
 }

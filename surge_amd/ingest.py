@@ -18,6 +18,10 @@ from .log import KeyTable
 from .schema import EVENT_DTYPE
 
 READ_UNCOMMITTED, READ_COMMITTED = 0, 1
+FRAMES = 0x100  # SURGE_INGEST_FRAMES: frame on the host, decode the records on the GPU (DeviceDecoder)
+
+SECTION_DTYPE = np.dtype([("byte_off", "<i8"), ("byte_len", "<i8"), ("base_offset", "<i8"), ("n_records", "<i4"), ("reserved", "<i4")])
+assert SECTION_DTYPE.itemsize == 32
 
 RECORD_DTYPE = np.dtype([("offset", "<i8"), ("agg_idx", "<i8"), ("key_off", "<i8"), ("key_len", "<i4"),
                          ("value_len", "<i4"), ("value_off", "<i8")])
@@ -78,10 +82,11 @@ class IngestError(RuntimeError):
 
 
 class EventsTopicIngest:
-    def __init__(self, isolation_level: int = READ_COMMITTED):
+    def __init__(self, isolation_level: int = READ_COMMITTED, frames: bool = False):
         self._lib = _native.load()
         self._h = ctypes.c_void_p()
-        rc = self._lib.surge_ingest_create(isolation_level, ctypes.byref(self._h))
+        self.frames = frames
+        rc = self._lib.surge_ingest_create(isolation_level | (FRAMES if frames else 0), ctypes.byref(self._h))
         if rc != 0:
             raise IngestError(rc, (self._lib.surge_ingest_last_error(None) or b"").decode())
         self._tail = b""
@@ -122,6 +127,14 @@ class EventsTopicIngest:
         names = ["batches", "records_decoded", "records_delivered", "records_aborted", "control_batches",
                  "flush_records_skipped", "bytes_decompressed", "open_transactions"]
         return dict(zip(names, [int(x) for x in c]))
+
+    def drain_sections(self, max_sections: int = 1 << 30) -> Tuple[np.ndarray, int]:
+        """FRAMES mode: the records sections of the deliverable batches (``SECTION_DTYPE`` records whose spans point into
+        the arena) and the arena's address — what ``DeviceDecoder.push`` takes."""
+        out = np.zeros(min(max_sections, max(self.ready, 1)), dtype=SECTION_DTYPE)  # ready counts records: an upper bound
+        got = ctypes.c_int64(0)
+        self._check(self._lib.surge_ingest_drain_sections(self._h, out.shape[0], out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(got)))
+        return out[: got.value], int(self._lib.surge_ingest_arena(self._h) or 0)
 
     def drain_fixed16(self, max_records: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         n = self.ready if max_records is None else min(self.ready, max_records)
@@ -173,3 +186,82 @@ class EventsTopicIngest:
             self._check(self._lib.surge_ingest_key(self._h, i, ctypes.byref(p), ctypes.byref(ln)))
             kt.intern(ctypes.string_at(p, ln.value).decode("utf-8"))
         return kt
+
+
+class DeviceDecoder:
+    """``surge_device_decoder``: records sections (host bytes) -> device-resident ``(agg_idx, events, offsets)`` and a
+    device key table.  ``template=None``: record values are 16-byte events; otherwise the model's ``EventJsonTemplate``."""
+
+    def __init__(self, template: Optional[EventJsonTemplate] = None, device: int = 0, stream=None):
+        self._lib = _native.load()
+        self._h = ctypes.c_void_p()
+        self.device = device
+        c = template.to_c() if template is not None else None
+        rc = self._lib.surge_device_decoder_create(device, stream, ctypes.byref(c) if c is not None else None, ctypes.byref(self._h))
+        if rc != 0:
+            raise IngestError(rc, (self._lib.surge_device_decoder_last_error(None) or b"").decode())
+
+    def close(self):
+        if self._h:
+            self._lib.surge_device_decoder_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise IngestError(rc, (self._lib.surge_device_decoder_last_error(self._h) or b"").decode())
+
+    def push(self, sections: np.ndarray, arena_address: int) -> None:
+        sections = np.ascontiguousarray(sections, dtype=SECTION_DTYPE)
+        self._check(self._lib.surge_device_decoder_push(self._h, ctypes.c_void_p(arena_address), sections.ctypes.data_as(ctypes.c_void_p),
+                                                        sections.shape[0]))
+
+    def push_from(self, ingest: EventsTopicIngest) -> int:
+        """Everything ``ingest`` (created with ``frames=True``) can deliver now; returns the number of batches."""
+        sections, arena = ingest.drain_sections()
+        if sections.shape[0]:
+            self.push(sections, arena)
+        return int(sections.shape[0])
+
+    def result(self):
+        """``(agg_idx, events, offsets)`` as CUDA tensors viewing the decoder's arrays (valid until the next push / clear)
+        and the number of keys so far."""
+        import torch
+
+        n, nk = ctypes.c_int64(), ctypes.c_int64()
+        pa, pe, po = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        self._check(self._lib.surge_device_decoder_result(self._h, ctypes.byref(n), ctypes.byref(pa), ctypes.byref(pe), ctypes.byref(po), ctypes.byref(nk)))
+        dev = torch.device("cuda", self.device)
+        if n.value == 0:
+            z = torch.zeros(0, dtype=torch.int64, device=dev)
+            return z, torch.zeros((0, 2), dtype=torch.int64, device=dev), z.clone(), nk.value
+
+        def view(ptr, count, cols):
+            iface = {"shape": (count, cols) if cols > 1 else (count,), "typestr": "<i8", "data": (ptr.value, False), "version": 2}
+            holder = type("_Span", (), {"__cuda_array_interface__": iface})()
+            return torch.as_tensor(holder, device=dev)
+
+        return view(pa, n.value, 1), view(pe, n.value, 2), view(po, n.value, 1), nk.value
+
+    def clear(self) -> None:
+        self._check(self._lib.surge_device_decoder_clear(self._h))
+
+    def keys(self) -> List[str]:
+        n, nb = ctypes.c_int64(), ctypes.c_int64()
+        self._check(self._lib.surge_device_decoder_keys(self._h, None, 0, None, ctypes.byref(n), ctypes.byref(nb)))
+        data = np.zeros(max(nb.value, 1), np.uint8)
+        off = np.zeros(n.value + 1, np.int64)
+        self._check(self._lib.surge_device_decoder_keys(self._h, data.ctypes.data_as(ctypes.c_void_p), data.shape[0], off.ctypes.data_as(ctypes.c_void_p),
+                                                        ctypes.byref(n), ctypes.byref(nb)))
+        raw = data.tobytes()
+        return [raw[off[i]:off[i + 1]].decode("utf-8") for i in range(n.value)]
+
+    def counters(self) -> dict:
+        c = (ctypes.c_int64 * 4)()
+        self._lib.surge_device_decoder_counters(self._h, ctypes.byref(c))
+        return dict(zip(["records_seen", "records_delivered", "flush_records_skipped", "doubles_parsed_on_host"], [int(x) for x in c]))

@@ -1,0 +1,321 @@
+"""N1 on the device (include/surge_ingest.h, "device decode"): the host frames the record batches (headers, CRC-32C,
+read_committed, LZ4), the GPU parses the records, interns the aggregate ids and decodes the event values.  Held to the
+HOST decoder of the same library on the same wire bytes (which the CPU suite holds to the independent test-side writer,
+liblz4, the protobuf runtime's varints ...): same records in the same order, same aggregate numbering, same key table,
+same events — and, through the fold, to the oracle."""
+import json
+import os
+import random
+import struct
+import uuid
+
+import numpy as np
+import pytest
+
+import kafka_wire as kw
+from fixture_models import (BA_CREATED, BA_UPDATED, BankAccountCommandModel, BankAccountCreated, BankAccountUpdated, CounterBusinessLogic,
+                            CountDecremented, CountIncremented, NoOpEvent)
+from oracle import oracle
+from surge_amd import schema as S
+from surge_amd.ingest import READ_COMMITTED, READ_UNCOMMITTED, DeviceDecoder, EventJsonTemplate, EventsTopicIngest, IngestError
+
+
+def counter_event(ty, seq, arg):
+    e = np.zeros(1, dtype=S.EVENT_DTYPE)
+    e["type"], e["seq"], e["raw"] = ty, seq, np.uint64(np.uint32(np.int32(arg)))
+    return e.tobytes()
+
+
+# ---- CPU: the framing mode of the host decoder ----------------------------------------------------------------------
+def test_frames_mode_hands_out_the_records_sections_of_deliverable_batches_only():
+    ev = lambda seq: counter_event(S.EVT_INC, seq, 1)
+    b0 = kw.record_batch(0, [(b"a:1", ev(1))], transactional=True, producer_id=7)
+    b1 = kw.record_batch(1, [(b"b:1", ev(1)), (b"b:2", ev(2))], transactional=True, producer_id=9, compression="lz4")
+    b2 = kw.record_batch(3, [(b"c:1", ev(1)), (b"", b"")])
+    with EventsTopicIngest(READ_COMMITTED, frames=True) as g:
+        g.feed(b0 + b1 + b2 + kw.control_batch(5, 9, kw.ABORT))
+        assert g.ready == 0  # producer 7's transaction is still open: nothing behind it is stable
+        with pytest.raises(IngestError):
+            g.drain_fixed16()  # a framing decoder does not parse records
+        g.feed(kw.control_batch(6, 7, kw.COMMIT))
+        sections, arena = g.drain_sections()
+        assert [(int(s["base_offset"]), int(s["n_records"])) for s in sections] == [(0, 1), (3, 2)]  # the aborted batch is gone
+        import ctypes
+
+        # a section is the batch's records section, verbatim (uncompressed)
+        want = kw.record(0, b"a:1", ev(1))
+        assert ctypes.string_at(arena + int(sections[0]["byte_off"]), int(sections[0]["byte_len"])) == want
+        c = g.counters()
+        assert c["records_aborted"] == 2 and c["control_batches"] == 2 and c["records_delivered"] == 3
+    with EventsTopicIngest(READ_COMMITTED) as g, pytest.raises(IngestError):
+        g.drain_sections()
+
+
+def test_the_host_f64_parser_is_correctly_rounded():
+    """surge_parse_f64_json = Eisel-Lemire (the code the device runs) + strtod for what it cannot decide: against
+    Python's float(), which is correctly rounded — shortest-round-trip spellings, arbitrary digit strings, ties, the
+    subnormal / overflow edges."""
+    import ctypes
+
+    from surge_amd import _native
+
+    lib = _native.load()
+    rng = np.random.default_rng(3)
+    rnd = random.Random(3)
+
+    def parse(txt):
+        b = ctypes.c_uint64()
+        rc = lib.surge_parse_f64_json(txt.encode(), len(txt), ctypes.byref(b))
+        return rc, b.value
+
+    texts = [repr(float(x)) for x in rng.integers(0, 0x7FF0000000000000, size=30000, dtype=np.uint64).view(np.float64)]
+    texts += [repr(float(x)) for x in rng.random(30000) * 1e6]
+    for _ in range(30000):
+        nd = rnd.randint(1, 19)
+        ds = "".join(rnd.choice("0123456789") for _ in range(nd))
+        texts.append(f"{ds}e{rnd.randint(-345, 310)}")
+        pos = rnd.randint(0, nd)
+        texts.append((ds[:pos] or "0") + "." + (ds[pos:] or "0"))
+    for e in range(-345, 312):
+        texts += [f"1e{e}", f"9.999999999999999e{e}", f"1.0000000000000002E{e}"]
+    texts += ["0", "-0", "0.0", "2.2250738585072011e-308", "2.2250738585072014e-308", "4.9e-324", "2.4703282292062327e-324",
+              "2.4703282292062328e-324", "1.7976931348623157e308", "1.7976931348623159e308", "9007199254740993", "9007199254740992.5",
+              "1e400", "-1e-400"]
+    texts += [f"{rnd.randint(2 ** 52, 2 ** 53 - 1)}.5" for _ in range(2000)]  # exactly between two doubles: ties to even
+    slow = 0
+    for t in texts:
+        rc, b = parse(t)
+        assert rc in (0, 1) and b == int(np.float64(float(t)).view(np.uint64)), (t, rc)
+        slow += rc
+    assert slow == 0  # all of these have at most 19 digits: the fast path decided every one
+    rc, b = parse("0.1000000000000000055511151231257827021181583404541015625")  # 55 digits: decided by strtod
+    assert rc == 1 and b == int(np.float64(0.1).view(np.uint64))
+    for t in ["", "abc", "1.", ".5", "1e", "--1", "1.5.2", "0x10"]:
+        assert parse(t)[0] == -7
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------------
+def both_decoders(wire, template=None, isolation=READ_COMMITTED, chunks=None):
+    """The same wire bytes through the host decoder and through host framing + the device decoder."""
+    with EventsTopicIngest(isolation) as g:
+        g.feed(wire)
+        host = g.drain_json(template) if template is not None else g.drain_fixed16()
+        host_keys = g.key_table().keys
+    with EventsTopicIngest(isolation, frames=True) as g, DeviceDecoder(template) as d:
+        if chunks is None:
+            g.feed(wire)
+            d.push_from(g)
+        else:  # several feeds / pushes: the key table and the result grow across pushes
+            pos = 0
+            for c in chunks:
+                g.feed(wire[pos:pos + c])
+                pos += c
+                d.push_from(g)
+            g.feed(wire[pos:])
+            d.push_from(g)
+        agg, ev, off, n_keys = d.result()
+        dev = (agg.cpu().numpy(), ev.cpu().numpy().view(S.EVENT_DTYPE).reshape(-1), off.cpu().numpy())
+        dev_keys = d.keys()
+        counters = d.counters()
+    assert n_keys == len(dev_keys)
+    return host, host_keys, dev, dev_keys, counters
+
+
+@pytest.mark.gpu
+def test_device_decoder_equals_the_host_decoder_on_fixed16_topics_with_transactions_lz4_headers_and_flush_records():
+    rng = random.Random(11)
+    batches, off = [], 0
+    pid = 100
+    for b in range(120):
+        n = rng.randrange(1, 40)
+        rs = []
+        for j in range(n):
+            if rng.random() < 0.03:
+                rs.append((b"", b"", []))  # the producer's flush record
+                continue
+            agg = f"acct-{rng.randrange(300):05d}" if rng.random() < 0.9 else "ünï-✓-" + "x" * rng.randrange(0, 40)
+            hdrs = [(b"aggregate_id", agg.encode())] if rng.random() < 0.3 else []
+            rs.append((f"{agg}:{rng.randrange(10 ** 6)}".encode(), counter_event(rng.choice([0, 1, 2]), off + j, rng.randrange(-50, 50)), hdrs))
+        txn = rng.random() < 0.5
+        batches.append(kw.record_batch(off, rs, compression=rng.choice(["none", "lz4"]), transactional=txn, producer_id=pid if txn else -1))
+        off += n
+        if txn:
+            batches.append(kw.control_batch(off, pid, kw.COMMIT if rng.random() < 0.8 else kw.ABORT))
+            off += 1
+            pid += 1
+    wire = b"".join(batches)
+    for chunks in (None, [len(wire) // 3, len(wire) // 3]):
+        host, host_keys, dev, dev_keys, counters = both_decoders(wire, chunks=chunks)
+        assert dev_keys == host_keys
+        for h, g in zip(host, dev):
+            assert h.shape == g.shape and h.tobytes() == g.tobytes()
+        assert counters["records_delivered"] == host[0].shape[0] and counters["flush_records_skipped"] > 0
+
+
+@pytest.mark.gpu
+def test_device_decoder_key_interning_across_table_growth_prefix_ids_and_many_pushes():
+    rng = random.Random(5)
+    ids = [f"agg-{i}" for i in range(20000)] + ["a" * k for k in range(1, 801)] + [""]
+    seq = ids * 3
+    rng.shuffle(seq)
+    wire, off = [], 0
+    for s0 in range(0, len(seq), 700):
+        chunk = seq[s0:s0 + 700]
+        wire.append(kw.record_batch(off, [(f"{a}:{j}".encode(), counter_event(1, j, 1)) for j, a in enumerate(chunk)]))
+        off += len(chunk)
+    wire = b"".join(wire)
+    host, host_keys, dev, dev_keys, _ = both_decoders(wire, chunks=[len(wire) // 7] * 6)
+    assert dev_keys == host_keys == list(dict.fromkeys(seq))  # first-delivered order, every id once, prefixes distinct
+    assert host[0].tobytes() == dev[0].tobytes() and host[2].tobytes() == dev[2].tobytes()
+
+
+@pytest.mark.gpu
+def test_device_decoder_decodes_play_json_counter_and_bank_account_events_like_the_host_decoder():
+    rng = random.Random(7)
+    bl = CounterBusinessLogic()
+    model, fmt = bl.command_model(), bl.event_write_formatting()
+    recs = []
+    for i in range(6000):
+        agg = f"agg-{rng.randrange(400)}"
+        e = rng.choice([CountIncremented(agg, rng.randrange(-2 ** 31, 2 ** 31), i + 1), CountDecremented(agg, rng.randrange(0, 1000), i + 1), NoOpEvent(agg, i + 1)])
+        m = fmt.write_event(e)
+        recs.append((m.key.encode(), m.value))
+    wire = b"".join(kw.record_batch(s, recs[s:s + 500], compression="lz4" if s % 1000 else "none") for s in range(0, len(recs), 500))
+    host, host_keys, dev, dev_keys, _ = both_decoders(wire, model.event_json_template())
+    assert dev_keys == host_keys
+    for h, g in zip(host, dev):
+        assert h.tobytes() == g.tobytes()
+
+    # BankAccount: Doubles as play-json writes them (and a few spellings it never writes), field order shuffled, extra
+    # fields, nested values to skip
+    ba = BankAccountCommandModel()
+    tmpl = ba.event_json_template()
+    from surge_amd.encode import play_json_double
+
+    nprng = np.random.default_rng(9)
+    recs = []
+    vals = np.concatenate([np.round(nprng.random(3000) * 1e7) / 100, nprng.random(2000) * 10.0 ** nprng.integers(-12, 25, size=2000),
+                           nprng.integers(0, 0x7FF0000000000000, size=2000, dtype=np.uint64).view(np.float64),
+                           np.array([0.0, 5e-324, 1.7976931348623157e308, 0.1 + 0.2, 1e21, 100.0, 1e-7])])
+    for i, v in enumerate(vals):
+        acct = str(uuid.UUID(int=rng.randrange(1 << 100) % 500 + 1))
+        text = play_json_double(float(v))
+        if i % 3 == 0:
+            fields = [('"accountNumber"', f'"{acct}"'), ('"accountOwner"', '"Jane \\"J\\" Doe"'), ('"securityCode"', '"1234"'), ('"balance"', text),
+                      ('"_type"', '"docs.command.BankAccountCreated"')]
+        else:
+            fields = [('"_type"', '"docs.command.BankAccountUpdated"'), ('"accountNumber"', f'"{acct}"'), ('"newBalance"', text),
+                      ('"audit"', '{"by":["x",{"y":"}"}],"n":null,"ok":true}')]
+        if i % 5 == 0:
+            rng.shuffle(fields)
+        value = ("{" + ",".join(f"{k}:{v2}" for k, v2 in fields) + "}").encode()
+        recs.append((f"{acct}:{i}".encode(), value))
+    recs.append((b"long:1", b'{"_type":"docs.command.BankAccountUpdated","newBalance":0.1000000000000000055511151231257827021181583404541015625}'))
+    recs.append((b"long:2", b'{"_type":"docs.command.BankAccountUpdated","newBalance":-12345678901234567890123.5E-3}'))
+    wire = b"".join(kw.record_batch(s, recs[s:s + 400]) for s in range(0, len(recs), 400))
+    host, host_keys, dev, dev_keys, counters = both_decoders(wire, tmpl)
+    assert dev_keys == host_keys and counters["doubles_parsed_on_host"] == 2  # the two > 19-digit spellings
+    for h, g in zip(host, dev):
+        assert h.tobytes() == g.tobytes()
+    got = dev[1]["raw"][: len(vals)].view(np.float64)
+    assert got.tobytes() == vals.astype(np.float64).tobytes()  # text -> double is the inverse of double -> text, bit for bit
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bad,why", [
+    (b'{"_type":"docs.command.Nope","newBalance":1}', "event type"),
+    (b'{"_type":"docs.command.BankAccountUpdated"}', "field"),
+    (b'{"_type":"docs.command.BankAccountUpdated","newBalance":"12"}', "field"),
+    (b'{"_type":"docs.command.BankAccountUpdated","newBalance":1', "JSON"),
+    (b'[1,2]', "JSON"),
+])
+def test_device_decoder_rejects_what_the_host_decoder_rejects_and_names_the_offset(bad, why):
+    tmpl = BankAccountCommandModel().event_json_template()
+    good = b'{"_type":"docs.command.BankAccountUpdated","newBalance":1.5}'
+    wire = kw.record_batch(40, [(b"a:1", good), (b"b:1", bad), (b"c:1", good)])
+    with EventsTopicIngest() as g:
+        g.feed(wire)
+        with pytest.raises(IngestError):
+            g.drain_json(tmpl)
+    with EventsTopicIngest(frames=True) as g, DeviceDecoder(tmpl) as d:
+        g.feed(wire)
+        with pytest.raises(IngestError) as ei:
+            d.push_from(g)
+        assert ei.value.status == -7 and "offset 41" in str(ei.value) and why in str(ei.value)
+        assert d.result()[0].shape[0] == 0  # nothing of the failing push was appended
+    # fixed-16 topics: wrong value size, null value, a record whose length runs past the batch
+    with EventsTopicIngest(frames=True) as g, DeviceDecoder() as d:
+        g.feed(kw.record_batch(0, [(b"k:1", b"not sixteen bytes")]))
+        with pytest.raises(IngestError, match="16-byte"):
+            d.push_from(g)
+        g.feed(kw.record_batch(1, [(b"k:1", None)]))
+        with pytest.raises(IngestError, match="null"):
+            d.push_from(g)
+        sec = np.zeros(1, dtype=[("byte_off", "<i8"), ("byte_len", "<i8"), ("base_offset", "<i8"), ("n_records", "<i4"), ("reserved", "<i4")])
+        body = np.frombuffer(kw.record(0, b"k:1", counter_event(1, 1, 1))[:-3], dtype=np.uint8).copy()  # truncated record
+        sec["byte_len"], sec["n_records"] = body.shape[0], 1
+        with pytest.raises(IngestError, match="malformed"):
+            d.push(sec, body.ctypes.data)
+
+
+@pytest.mark.gpu
+def test_events_topic_bytes_to_states_without_the_host_touching_a_record():
+    """Kafka bytes -> host framing -> device decode -> device group-by + fold (K3) -> states, against the oracle's fold of
+    the published events; the GPU state encoder takes the decoder's DEVICE key table as it is."""
+    import torch
+
+    from surge_amd.encode import JsonTemplate, encode_states
+    from surge_amd.replay import ReplayEngine
+
+    rng = random.Random(21)
+    bl = CounterBusinessLogic()
+    model, fmt = bl.command_model(), bl.event_write_formatting()
+    published, recs = {}, []
+    seqs = {}
+    for i in range(30000):
+        agg = f"agg-{int(rng.paretovariate(1.2)) % 2000}"
+        seqs[agg] = seqs.get(agg, 0) + 1
+        e = rng.choice([CountIncremented(agg, rng.randrange(1, 9), seqs[agg]), CountDecremented(agg, rng.randrange(1, 9), seqs[agg]), NoOpEvent(agg, seqs[agg])])
+        m = fmt.write_event(e)
+        recs.append((m.key.encode(), m.value))
+        published.setdefault(agg, []).append(e)
+    wire = b"".join(kw.record_batch(s, recs[s:s + 600], compression="lz4") for s in range(0, len(recs), 600))
+    with EventsTopicIngest(frames=True) as g, DeviceDecoder(model.event_json_template()) as d, ReplayEngine(model.event_algebra()) as eng:
+        pos, n_agg = 0, 0
+        eng.load_csr(np.zeros(1, np.int64), np.zeros(0, dtype=S.EVENT_DTYPE))  # an empty store to grow
+        eng.fold()
+        while pos < len(wire):  # fetch by fetch: decode on the device, fold onto the resident state
+            g.feed(wire[pos:pos + 200_000])
+            pos += 200_000
+            if d.push_from(g) == 0:
+                continue
+            agg, ev, _, n_keys = d.result()
+            if n_keys > n_agg:
+                eng.grow(n_keys)
+                n_agg = n_keys
+            eng.append_events(agg, ev)
+            eng.synchronize()
+            d.clear()
+        states = eng.snapshot()
+        keys = d.keys()
+        assert sorted(keys) == sorted(published)
+        for a, key in enumerate(keys):
+            evs = model.encode_events(published[key])
+            off = np.array([0, evs.shape[0]], np.int64)
+            assert states[a].tobytes() == oracle.fold_csr(off, evs, None, model.event_algebra())[0].tobytes(), key
+        # the decoder's device key table feeds the GPU state encoder directly
+        import ctypes
+
+        pk, po = ctypes.c_void_p(), ctypes.c_void_p()
+        assert d._lib.surge_device_decoder_key_table(d._h, ctypes.byref(pk), ctypes.byref(po)) == 0
+        n_bytes = sum(len(k.encode()) for k in keys)
+
+        def view(ptr, count, typ):
+            iface = {"shape": (count,), "typestr": typ, "data": (ptr.value, False), "version": 2}
+            return torch.as_tensor(type("_S", (), {"__cuda_array_interface__": iface})(), device="cuda")
+
+        d_out, d_off = encode_states(eng, JsonTemplate.counter(), view(pk, n_bytes, "|u1"), view(po, len(keys) + 1, "<i8"))
+        out, offs = d_out.cpu().numpy().tobytes(), d_off.cpu().numpy()
+        for a in (0, len(keys) // 2, len(keys) - 1):
+            o = json.loads(out[offs[a]:offs[a + 1]])
+            assert o["aggregateId"] == keys[a] and o["count"] == int(states[a]["count"])
