@@ -68,16 +68,42 @@ class GpuReplayStateStore:
         """Recover from the raw bytes of one events-topic partition (Kafka record batches v2, lz4 or none,
         ``read_committed``): ingest (``include/surge_ingest.h``) -> CSR pack -> GPU fold.
 
-        Record values that are exactly 16 bytes are taken as fixed-width events; anything else goes through
-        the plugin's ``SurgeEventReadFormatting.read_event`` and the model's ``encode_event``.  Returns the
-        ingest counters."""
+        Record values that are exactly 16 bytes are taken as fixed-width events; the plugin's JSON event text is decoded
+        through the model's ``event_json_template``.  Both go the device way: the host only frames the batches (headers,
+        CRC, transactions, LZ4), the GPU parses the records, interns the aggregate ids, decodes the values and groups
+        them (``surge_device_decoder`` + the K3 group-by) — no per-record work in any host language.  A model without a
+        template falls back to the host decoder and the plugin's ``SurgeEventReadFormatting.read_event`` per record.
+        Returns the ingest counters."""
         from .core import SerializedMessage
-        from .ingest import EventsTopicIngest
+        from .ingest import DeviceDecoder, EventsTopicIngest, IngestError
+        from .log import KeyTable
         from .schema import EVENT_DTYPE
 
-        from .ingest import IngestError
-
         template = self.model.event_json_template()
+        with EventsTopicIngest(frames=True) as g:
+            g.feed(record_batches)
+            sections, arena = g.drain_sections()
+            counters = g.counters()
+            kind = _sniff_value_kind(sections, arena)  # "fixed16", "json" or None (no deliverable record)
+            if kind == "fixed16" or (kind == "json" and template is not None) or kind is None:
+                with DeviceDecoder(template if kind == "json" else None, device=self.engine.device) as d:
+                    if sections.shape[0]:
+                        d.push(sections, arena)
+                    agg_idx, events, _, n_keys = d.result()
+                    keys = KeyTable()
+                    for k in d.keys():
+                        keys.intern(k)
+                    n_agg = max(len(keys), capacity)
+                    self.keys = keys
+                    self.engine.load_csr(np.zeros(n_agg + 1, dtype=np.int64), np.zeros(0, dtype=EVENT_DTYPE))
+                    self.engine.fold()  # every aggregate None
+                    if agg_idx.shape[0]:
+                        self.engine.append_events(agg_idx, events)  # device arrays straight into the device group-by
+                        self.engine.synchronize()
+                    counters.update(d.counters())
+                self.engine.snapshot()  # publishes the host mirror that serves point reads
+                self._restored = True
+                return counters
         with EventsTopicIngest() as g:
             g.feed(record_batches)
             recs = None
@@ -230,3 +256,42 @@ class GpuReplayPersistencePlugin:
 
     def create_supplier(self, store_name: str) -> GpuReplayKeyValueStore:
         return GpuReplayKeyValueStore(store_name, self.recovered)
+
+
+def _sniff_value_kind(sections, arena_address: int):
+    """What the first deliverable record's value looks like — a 16-byte fixed event or JSON text: decides which device
+    decoder a topic gets (a topic is written by one plugin: its values are all of one kind; a value that is not fails the
+    push loudly)."""
+    import ctypes
+
+    def varlong(buf, pos):
+        v, shift = 0, 0
+        while True:
+            b = buf[pos]
+            pos += 1
+            v |= (b & 0x7F) << shift
+            if not b & 0x80:
+                break
+            shift += 7
+        return (v >> 1) ^ -(v & 1), pos
+
+    for s in sections:
+        buf = ctypes.string_at(arena_address + int(s["byte_off"]), min(int(s["byte_len"]), 4096))
+        pos = 0
+        try:
+            for _ in range(int(s["n_records"])):
+                rlen, pos = varlong(buf, pos)  # record length
+                end = pos + rlen
+                pos += 1                       # attributes
+                _, pos = varlong(buf, pos)     # timestampDelta
+                _, pos = varlong(buf, pos)     # offsetDelta
+                klen, pos = varlong(buf, pos)
+                pos += max(klen, 0)
+                vlen, pos = varlong(buf, pos)
+                if klen == 0 and vlen == 0:    # the producer's flush record: look at the next one
+                    pos = end
+                    continue
+                return "fixed16" if vlen == 16 and buf[pos:pos + 1] != b"{" else "json"
+        except IndexError:
+            return "json"
+    return None
