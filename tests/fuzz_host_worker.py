@@ -54,6 +54,9 @@ for _i, (_n, _t, _k, _s, _a) in enumerate([(b"countIncremented", 1, 1, b"sequenc
                                            (b"upd", 4, 2, b"", b"newBalance")]):
     TMPL.types[_i].name, TMPL.types[_i].event_type, TMPL.types[_i].arg_kind, TMPL.types[_i].seq_field, TMPL.types[_i].arg_field = _n, _t, _k, _s, _a
 lib.surge_event_json_decode.argtypes = [vp, ctypes.c_char_p, i64, vp]
+lib.surge_parse_f64_json.argtypes = [ctypes.c_char_p, i64, ctypes.POINTER(ctypes.c_uint64)]
+lib.surge_format_f64_json.argtypes = [ctypes.c_uint64, ctypes.c_char_p, ctypes.c_int32]
+lib.surge_ingest_drain_sections.argtypes = [vp, i64, vp, ctypes.POINTER(i64)]
 
 
 def valid_wire():
@@ -181,4 +184,30 @@ while time.time() < t_end:
         m = mutate(good)
         exact = ctypes.create_string_buffer(m, len(m))  # no NUL terminator behind the value: an over-read is an ASan report
         assert lib.surge_event_json_decode(ctypes.byref(TMPL), exact, len(m), ev) in (0, -7)
+    # numbers: text -> double (Eisel-Lemire + strtod) and double -> play-json text (Ryu), exact-size buffers
+    for _ in range(40):
+        num = rng.choice([repr(rng.uniform(-1e300, 1e300)), "%de%d" % (rng.randrange(10 ** 19), rng.randrange(-400, 400)),
+                          "0." + "0" * rng.randrange(0, 30) + str(rng.randrange(10 ** 25)), "1e-400", "-0.0"]).encode()
+        bits = ctypes.c_uint64()
+        assert lib.surge_parse_f64_json(ctypes.create_string_buffer(num, len(num)), len(num), ctypes.byref(bits)) in (0, 1), num
+        m = mutate(num)
+        assert lib.surge_parse_f64_json(ctypes.create_string_buffer(m, len(m)), len(m), ctypes.byref(bits)) in (0, 1, -7)
+        out = ctypes.create_string_buffer(26)
+        n = lib.surge_format_f64_json(ctypes.c_uint64(rng.getrandbits(64)), out, 26)
+        assert 0 <= n <= 26
+    # the framing mode of the decoder (device decode): sections must lie inside the arena, whatever was fed
+    hf = vp()
+    assert lib.surge_ingest_create(1 | 0x100, ctypes.byref(hf)) == 0
+    wire2 = mutate(valid_wire()) if rng.random() < 0.7 else valid_wire()
+    consumed2 = i64()
+    lib.surge_ingest_feed(hf, wire2, len(wire2), ctypes.byref(consumed2))
+    secs = (i64 * (4 * 64))()
+    n_sec = i64()
+    assert lib.surge_ingest_drain_sections(hf, 64, secs, ctypes.byref(n_sec)) == 0
+    for k in range(n_sec.value):
+        byte_off, byte_len = secs[4 * k], secs[4 * k + 1]
+        assert byte_off >= 0 and byte_len >= 0
+        if byte_len:
+            ctypes.string_at(ctypes.addressof(lib.surge_ingest_arena(hf).contents) + byte_off, byte_len)  # readable end to end (ASan checks)
+    lib.surge_ingest_destroy(hf)
 print(f"OK {rounds} rounds")

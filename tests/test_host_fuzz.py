@@ -1,5 +1,5 @@
 """The host-side decoders take untrusted bytes (a Kafka fetch): mutation-fuzz them under AddressSanitizer + UBSan.
-Builds ingest.cpp / event_decode.cpp / lz4_frame.cpp / snapshot_writer.cpp with g++ -fsanitize=address,undefined (plain C++: no HIP in those
+Builds ingest.cpp / event_decode.cpp / f64_text.cpp / lz4_frame.cpp / snapshot_writer.cpp with g++ -fsanitize=address,undefined (plain C++: no HIP in those
 files) and drives the result from a subprocess that preloads libasan."""
 import os
 import subprocess
@@ -25,7 +25,7 @@ def test_mutated_record_batches_and_lz4_frames_never_touch_memory_they_do_not_ow
     if rt is None:
         pytest.skip("no libasan.so next to gcc")
     lib = str(tmp_path / "libsurge_host_asan.so")
-    srcs = [os.path.join(ROOT, "surge_amd", "csrc", f) for f in ("ingest.cpp", "event_decode.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")]
+    srcs = [os.path.join(ROOT, "surge_amd", "csrc", f) for f in ("ingest.cpp", "event_decode.cpp", "f64_text.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")]
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
                     "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", lib, "-lpthread"], check=True, capture_output=True)
     env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
@@ -37,7 +37,7 @@ def test_multithreaded_snapshot_writer_is_race_free_under_thread_sanitizer(tmp_p
     """The writer frames partitions on up to 16 host threads (plain and LZ4): tests/cpp/tsan_snapshot_writer.cpp appends
     2 x 200 k records over 64 partitions under -fsanitize=thread and decodes every partition again with the product's reader."""
     exe = str(tmp_path / "tsan_snapshot_writer")
-    srcs = [os.path.join(HERE, "cpp", "tsan_snapshot_writer.cpp")] + [os.path.join(ROOT, "surge_amd", "csrc", f) for f in ("snapshot_writer.cpp", "lz4_frame.cpp", "ingest.cpp", "event_decode.cpp")]
+    srcs = [os.path.join(HERE, "cpp", "tsan_snapshot_writer.cpp")] + [os.path.join(ROOT, "surge_amd", "csrc", f) for f in ("snapshot_writer.cpp", "lz4_frame.cpp", "ingest.cpp", "event_decode.cpp", "f64_text.cpp")]
     build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I" + os.path.join(ROOT, "include")] + srcs + ["-lpthread", "-o", exe],
                            capture_output=True, text=True)
     if build.returncode != 0 and "tsan" in (build.stderr or "").lower():
