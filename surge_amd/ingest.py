@@ -108,9 +108,10 @@ class EventsTopicIngest:
 
     def feed(self, data: bytes) -> int:
         """Decode whole batches; a trailing partial batch is kept and completed by the next call."""
-        buf = self._tail + bytes(data)
+        buf = self._tail + bytes(data) if self._tail else (data if isinstance(data, bytes) else bytes(data))
         consumed = ctypes.c_int64(0)
-        arr = (ctypes.c_uint8 * len(buf)).from_buffer_copy(buf) if buf else None
+        # a bytes object is handed over in place (the library copies what it keeps): no per-feed copy of the fetch
+        arr = ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p) if buf else None
         rc = self._lib.surge_ingest_feed(self._h, arr, len(buf), ctypes.byref(consumed))
         # also on failure: batches decoded before the failing one ARE queued and must not be fed again
         self._tail = buf[consumed.value:]
