@@ -148,10 +148,22 @@ const char* surge_device_decoder_last_error(const surge_device_decoder* d);
  * record that does not decode fails the whole push (SURGE_E_CORRUPT, the message names the record's offset): nothing of
  * the push is appended.  Synchronous. */
 int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes, const surge_batch_section* sections, int64_t n_sections);
+/* The same for records that arrive already framed — what a JVM's KafkaConsumer hands over (ConsumerRecord key / value
+ * bytes and offset): record i's key is keys[key_off[i] .. key_off[i+1]), its value values[value_off[i] .. value_off[i+1]),
+ * offsets nullable (then 0, 1, 2 ..).  A record with an empty key AND an empty value is the producer's flush record and
+ * is skipped, as in the wire path. */
+int32_t surge_device_decoder_push_records(surge_device_decoder* d, const uint8_t* keys, const int64_t* key_off, const uint8_t* values,
+                                          const int64_t* value_off, const int64_t* offsets, int64_t n);
 /* Everything appended since the last clear: device arrays of n_records entries (valid until the next push / clear). */
 int32_t surge_device_decoder_result(surge_device_decoder* d, int64_t* n_records, const int64_t** d_agg_idx, const void** d_events16,
                                     const int64_t** d_offsets, int64_t* n_keys);
 int32_t surge_device_decoder_clear(surge_device_decoder* d); /* drops the records, keeps the key table */
+/* Folds everything decoded since the last clear onto the replay handle's resident state and clears it: grows the
+ * state for aggregate ids seen for the first time (surge_replay_grow), device group-by + fold
+ * (surge_replay_append_events_device), synchronises.  The handle must hold a bound / restored state (an empty one will
+ * do: load a CSR of zero aggregates and fold).  *n_events_out / *n_keys_out (nullable): what was folded / the key count. */
+struct surge_replay_handle;
+int32_t surge_replay_append_decoded(struct surge_replay_handle* h, surge_device_decoder* d, int64_t* n_events_out, int64_t* n_keys_out);
 /* The key table (aggregate ids in first-delivered order): to the host (NULL / NULL = size query), or where it lives on
  * the device (n_keys + 1 offsets; what the GPU state encoders and K4 take). */
 int32_t surge_device_decoder_keys(surge_device_decoder* d, uint8_t* utf8_out, int64_t utf8_capacity, int64_t* key_off_out, int64_t* n_keys_out,

@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <string.h>
 #include "surge_replay.h"
+#include "surge_ingest.h"
 
 #define H(h) ((surge_replay_handle*)(intptr_t)(h))
 
@@ -297,4 +298,91 @@ JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_gatheredRead(JNIEnv* e
   (void)c;
   if (bad || nRows < 0) return SURGE_E_INVALID;
   return check(env, surge_replay_gathered_read(H(h), slot, rank, firstRow, nRows, st));
+}
+
+/* ---- device decode (include/surge_ingest.h): ConsumerRecords in bulk -> resident state, no per-record JVM work ----
+ * The JVM copies the key / value bytes of a poll into direct buffers (System.arraycopy) and crosses JNI twice per poll:
+ * decoderPushRecords (parse keys, intern aggregate ids, decode the event values — 16-byte events or the plugin's
+ * play-json text through the template — on the GPU) and appendDecoded (grow + device group-by + fold). */
+#define D(d) ((surge_device_decoder*)(intptr_t)(d))
+
+static jint check_dec(JNIEnv* env, int32_t rc) {
+  if (rc != SURGE_OK) {
+    jclass ex = (*env)->FindClass(env, "java/io/IOException");
+    const char* msg = surge_device_decoder_last_error(NULL);
+    if (ex) (*env)->ThrowNew(env, ex, msg && msg[0] ? msg : "surge_device_decoder call failed");
+  }
+  return rc;
+}
+
+/* templateBuf: a surge_event_json_template (native layout) or null for topics whose values are 16-byte events */
+JNIEXPORT jlong JNICALL Java_surge_replay_gpu_NativeReplay_decoderCreate(JNIEnv* env, jclass c, jobject templateBuf, jint device) {
+  surge_device_decoder* d = NULL;
+  int bad = 0;
+  const void* t = buf(env, templateBuf, (int64_t)sizeof(surge_event_json_template), 1, &bad,
+                      "template: direct buffer of sizeof(surge_event_json_template) bytes expected");
+  (void)c;
+  if (bad) return 0;
+  check_dec(env, surge_device_decoder_create(device, NULL, (const surge_event_json_template*)t, &d));
+  return (jlong)(intptr_t)d;
+}
+
+JNIEXPORT void JNICALL Java_surge_replay_gpu_NativeReplay_decoderDestroy(JNIEnv* env, jclass c, jlong d) {
+  (void)env; (void)c;
+  surge_device_decoder_destroy(D(d));
+}
+
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_decoderPushRecords(JNIEnv* env, jclass c, jlong d, jobject keys, jobject keyOff,
+                                                                               jobject values, jobject valueOff, jobject offsets, jlong n) {
+  int bad = 0;
+  const int64_t *ko, *vo, *of;
+  const uint8_t *k, *v;
+  (void)c;
+  if (n < 0) return SURGE_E_INVALID;
+  ko = (const int64_t*)buf(env, keyOff, (n + 1) * 8, 0, &bad, "keyOff: direct buffer of (n + 1) longs expected");
+  vo = (const int64_t*)buf(env, valueOff, (n + 1) * 8, 0, &bad, "valueOff: direct buffer of (n + 1) longs expected");
+  if (!bad && (!offsets_ok(ko, n) || !offsets_ok(vo, n))) {
+    jclass ex = (*env)->FindClass(env, "java/lang/IllegalArgumentException");
+    if (ex) (*env)->ThrowNew(env, ex, "keyOff / valueOff: offsets must start at >= 0 and never decrease");
+    return SURGE_E_INVALID;
+  }
+  k = (const uint8_t*)buf(env, keys, bad ? -1 : ko[n], 1, &bad, "keys: direct buffer of keyOff[n] bytes expected");
+  v = (const uint8_t*)buf(env, values, bad ? -1 : vo[n], 1, &bad, "values: direct buffer of valueOff[n] bytes expected");
+  of = (const int64_t*)buf(env, offsets, n * 8, 1, &bad, "offsets: direct buffer of n longs expected");
+  if (bad) return SURGE_E_INVALID;
+  return check_dec(env, surge_device_decoder_push_records(D(d), k, ko, v, vo, of, n));
+}
+
+/* out (nullable, 16 bytes): {events folded, keys known} */
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_appendDecoded(JNIEnv* env, jclass c, jlong h, jlong d, jobject out) {
+  int bad = 0;
+  int64_t* o = (int64_t*)buf(env, out, 16, 1, &bad, "out: direct buffer of 16 bytes expected");
+  int64_t n_events = 0, n_keys = 0;
+  int32_t rc;
+  (void)c;
+  if (bad) return SURGE_E_INVALID;
+  rc = check_dec(env, surge_replay_append_decoded(H(h), D(d), &n_events, &n_keys));
+  if (o) { o[0] = n_events; o[1] = n_keys; }
+  return rc;
+}
+
+/* The key table: utf8Out / keyOffOut nullable (size query); counts (16 bytes) receives {keys, utf8 bytes} */
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_decoderKeys(JNIEnv* env, jclass c, jlong d, jobject utf8Out, jobject keyOffOut,
+                                                                        jobject counts) {
+  int bad = 0;
+  int64_t n_keys = 0, n_bytes = 0;
+  int64_t* cn = (int64_t*)buf(env, counts, 16, 0, &bad, "counts: direct buffer of 16 bytes expected");
+  uint8_t* u;
+  int64_t* ko;
+  int32_t rc;
+  (void)c;
+  if (bad) return SURGE_E_INVALID;
+  rc = check_dec(env, surge_device_decoder_keys(D(d), NULL, 0, NULL, &n_keys, &n_bytes));
+  if (rc != SURGE_OK) return rc;
+  cn[0] = n_keys; cn[1] = n_bytes;
+  if (!utf8Out && !keyOffOut) return SURGE_OK;
+  u = (uint8_t*)buf(env, utf8Out, n_bytes, n_bytes == 0, &bad, "utf8Out: direct buffer of counts[1] bytes expected");
+  ko = (int64_t*)buf(env, keyOffOut, (n_keys + 1) * 8, 0, &bad, "keyOffOut: direct buffer of (counts[0] + 1) longs expected");
+  if (bad) return SURGE_E_INVALID;
+  return check_dec(env, surge_device_decoder_keys(D(d), u, n_bytes, ko, &n_keys, &n_bytes));
 }

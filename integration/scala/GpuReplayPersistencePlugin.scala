@@ -181,6 +181,70 @@ object GpuReplayRecovery {
   }
 }
 
+/** The same recovery with NO per-record JVM work: every poll of the events-topic consumer (key / value byte arrays, as a
+ *  ByteArrayDeserializer hands them over, read_committed) is copied into direct buffers and pushed to a device decoder —
+ *  key parsing, aggregate-id interning, event decoding (16-byte events, or the plugin's play-json text through
+ *  `eventTemplate`: include/surge_ingest.h surge_event_json_template) and the group-by + fold all run on the GPU; the JVM
+ *  crosses JNI twice per poll.  Replaces the HashMap / ArrayList loop of `recover` above for topics of any size. */
+object GpuReplayBulkRecovery {
+  final class Session(model: ReplayableModel[_, _], device: Int, eventTemplate: ByteBuffer) extends AutoCloseable {
+    NativeReplay.ensureLoaded()
+    private val handle = NativeReplay.create(model.schema, device)
+    private val decoder = NativeReplay.decoderCreate(eventTemplate, device)
+    locally { // an empty resident state to grow: zero aggregates, folded
+      val segOff = ByteBuffer.allocateDirect(8).order(ByteOrder.LITTLE_ENDIAN)
+      segOff.putLong(0, 0L)
+      NativeReplay.loadCsr(handle, segOff, 0L, null, 0L, null)
+      NativeReplay.fold(handle, 0)
+    }
+
+    /** One poll: records in offset order per partition. */
+    def push(records: IndexedSeq[(Array[Byte], Array[Byte], Long)]): Unit = if (records.nonEmpty) {
+      val n = records.size
+      val keyBytes = records.iterator.map(r => if (r._1 eq null) 0L else r._1.length.toLong).sum
+      val valBytes = records.iterator.map(r => if (r._2 eq null) 0L else r._2.length.toLong).sum
+      val keys = ByteBuffer.allocateDirect(math.max(1L, keyBytes).toInt)
+      val values = ByteBuffer.allocateDirect(math.max(1L, valBytes).toInt)
+      val keyOff = ByteBuffer.allocateDirect((n + 1) * 8).order(ByteOrder.LITTLE_ENDIAN)
+      val valOff = ByteBuffer.allocateDirect((n + 1) * 8).order(ByteOrder.LITTLE_ENDIAN)
+      val offsets = ByteBuffer.allocateDirect(n * 8).order(ByteOrder.LITTLE_ENDIAN)
+      keyOff.putLong(0L); valOff.putLong(0L)
+      records.foreach { case (k, v, o) =>
+        if (k ne null) keys.put(k)
+        if (v ne null) values.put(v)
+        keyOff.putLong(keys.position().toLong); valOff.putLong(values.position().toLong); offsets.putLong(o)
+      }
+      NativeReplay.decoderPushRecords(decoder, keys, keyOff, values, valOff, offsets, n.toLong)
+      NativeReplay.appendDecoded(handle, decoder, null)
+    }
+
+    /** End of the topic: publish the host mirror that serves the 32 concurrent readers and hand over the store. */
+    def finish(): RecoveredSnapshot = {
+      val counts = ByteBuffer.allocateDirect(16).order(ByteOrder.LITTLE_ENDIAN)
+      NativeReplay.decoderKeys(decoder, null, null, counts)
+      val nKeys = counts.getLong(0)
+      val utf8 = ByteBuffer.allocateDirect(math.max(1L, counts.getLong(8)).toInt)
+      val keyOff = ByteBuffer.allocateDirect(((nKeys + 1) * 8).toInt).order(ByteOrder.LITTLE_ENDIAN)
+      NativeReplay.decoderKeys(decoder, utf8, keyOff, counts)
+      val keyIndex = new util.HashMap[String, java.lang.Long]()
+      var i = 0L
+      while (i < nKeys) {
+        val a = keyOff.getLong((i * 8).toInt).toInt
+        val b = keyOff.getLong(((i + 1) * 8).toInt).toInt
+        val bytes = new Array[Byte](b - a)
+        utf8.position(a); utf8.get(bytes)
+        keyIndex.put(new String(bytes, java.nio.charset.StandardCharsets.UTF_8), java.lang.Long.valueOf(i))
+        i += 1
+      }
+      NativeReplay.snapshot(handle, nKeys, null, null)
+      NativeReplay.decoderDestroy(decoder)
+      new RecoveredSnapshot(handle, keyIndex, model)
+    }
+
+    override def close(): Unit = { NativeReplay.decoderDestroy(decoder); NativeReplay.destroy(handle) }
+  }
+}
+
 /** One JVM that owns every GPU of the node (one RecoveredSnapshot per device): after the shards are folded, every device
  *  gets every shard's final states — the path's single exchange step (SURVEY §8e) — without RCCL or a rendezvous:
  *  surge_replay_allgather moves the shards with peer copies over xGMI.  Shard r = the state-topic partitions p with

@@ -39,6 +39,19 @@ object NativeReplay {
   @native def allgatherSnapshot(handle: Long, nLocal: Long, slot: Int, mode: Int): Int
   @native def allgatherGroup(handles: ByteBuffer, n: Int, slot: Int): Int
   @native def gatheredRead(handle: Long, slot: Int, rank: Int, firstRow: Long, nRows: Long, states: ByteBuffer): Int
+
+  // ---- device decode (include/surge_ingest.h): a poll's ConsumerRecords in bulk, no per-record JVM work ----
+  /** template: a surge_event_json_template in native layout (how the plugin's JSON event text maps onto the 16-byte event),
+    * or null when the record values already are 16-byte events. */
+  @native def decoderCreate(template: ByteBuffer, device: Int): Long
+  @native def decoderDestroy(decoder: Long): Unit
+  /** keys / values: the records' bytes back to back; keyOff / valueOff: n + 1 offsets; offsets: n Kafka offsets (nullable). */
+  @native def decoderPushRecords(decoder: Long, keys: ByteBuffer, keyOff: ByteBuffer, values: ByteBuffer, valueOff: ByteBuffer,
+                                 offsets: ByteBuffer, n: Long): Int
+  /** grow + device group-by + fold of everything pushed since the last call; out (nullable, 16 bytes): events folded, keys known. */
+  @native def appendDecoded(handle: Long, decoder: Long, out: ByteBuffer): Int
+  /** counts (16 bytes): keys, UTF-8 bytes; utf8Out / keyOffOut nullable for a size query. */
+  @native def decoderKeys(decoder: Long, utf8Out: ByteBuffer, keyOffOut: ByteBuffer, counts: ByteBuffer): Int
 }
 
 final class GpuReplayUnavailableException(msg: String, cause: Throwable) extends RuntimeException(msg, cause)

@@ -92,8 +92,10 @@ INGEST_EXPORTS = (
     "surge_device_decoder_destroy",
     "surge_device_decoder_last_error",
     "surge_device_decoder_push",
+    "surge_device_decoder_push_records",
     "surge_device_decoder_result",
     "surge_device_decoder_clear",
+    "surge_replay_append_decoded",
     "surge_device_decoder_keys",
     "surge_device_decoder_key_table",
     "surge_device_decoder_counters",
@@ -266,8 +268,10 @@ def load() -> ctypes.CDLL:
         "surge_device_decoder_destroy": ([vp], i32),
         "surge_device_decoder_last_error": ([vp], ctypes.c_char_p),
         "surge_device_decoder_push": ([vp, vp, vp, i64], i32),
+        "surge_device_decoder_push_records": ([vp, vp, vp, vp, vp, vp, i64], i32),
         "surge_device_decoder_result": ([vp, ctypes.POINTER(i64), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64)], i32),
         "surge_device_decoder_clear": ([vp], i32),
+        "surge_replay_append_decoded": ([vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
         "surge_device_decoder_keys": ([vp, vp, i64, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
         "surge_device_decoder_key_table": ([vp, ctypes.POINTER(vp), ctypes.POINTER(vp)], i32),
         "surge_device_decoder_counters": ([vp, ctypes.POINTER(i64 * 4)], i32),

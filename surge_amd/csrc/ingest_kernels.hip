@@ -176,6 +176,32 @@ __global__ void parse_kernel(const uint8_t* __restrict__ bytes, const Section* _
   meta[i] = m;
 }
 
+// records that arrive already framed (a JVM's ConsumerRecords: key bytes, value bytes, offset per record): the bytes buffer
+// holds the keys first, the values from `val_base` on
+__global__ void records_meta_kernel(const uint8_t* __restrict__ bytes, const int64_t* __restrict__ key_off, const int64_t* __restrict__ val_off,
+                                    const int64_t* __restrict__ offsets, int64_t val_base, int64_t n_rec, RecMeta* __restrict__ meta, ErrorCell* err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rec) return;
+  RecMeta m;
+  const int64_t k0 = key_off[i], k1 = key_off[i + 1], v0 = val_off[i], v1 = val_off[i + 1];
+  m.key_off = k0; m.val_off = val_base + v0; m.offset = offsets ? offsets[i] : i; m.hash = 0; m.key_len = 0; m.val_len = 0; m.slot = 0;
+  if (k1 < k0 || v1 < v0 || k1 - k0 >= (1ll << 31) || v1 - v0 >= (1ll << 31)) {
+    m.status = RS_MALFORMED;
+  } else if (k1 == k0 && v1 == v0) {
+    m.status = RS_SKIP;  // the producer's flush record
+  } else {
+    const uint8_t* key = bytes + k0;
+    int n = 0;
+    while (n < (int)(k1 - k0) && key[n] != (uint8_t)':') ++n;
+    m.key_len = n;
+    m.val_len = (int32_t)(v1 - v0);
+    m.hash = hash_key(key, n);
+    m.status = RS_OK;
+  }
+  if (m.status >= RS_NULL) report(err, i, m.status);
+  meta[i] = m;
+}
+
 struct Table {
   unsigned long long* hash;  // 0 = empty
   uint32_t* key_id;          // 0xffffffff = not assigned yet (inserted by the push in flight)
@@ -632,40 +658,14 @@ int32_t surge_device_decoder_destroy(surge_device_decoder* d) {
   return OK;
 }
 
-int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes, const surge_batch_section* sections, int64_t n_sections) {
-  if (!d) return dfail(nullptr, E_INVALID, "decoder is NULL");
-  if (n_sections < 0 || (n_sections > 0 && (!bytes || !sections))) return dfail(d, E_INVALID, "bad argument");
-  if (n_sections == 0) return OK;
-  // the span of the arena this push needs, and every batch's first record index
-  int64_t lo = INT64_MAX, hi = 0, n_rec = 0;
-  std::vector<Section> secs;
-  try {
-    secs.resize((size_t)n_sections);
-  } catch (const std::bad_alloc&) {
-    return dfail(d, E_NOMEM, "out of host memory");
-  }
-  for (int64_t s = 0; s < n_sections; ++s) {
-    const surge_batch_section& in = sections[s];
-    if (in.byte_off < 0 || in.byte_len < 0 || in.n_records < 0) return dfail(d, E_INVALID, "negative section field");
-    lo = in.byte_off < lo ? in.byte_off : lo;
-    hi = in.byte_off + in.byte_len > hi ? in.byte_off + in.byte_len : hi;
-    secs[(size_t)s] = Section{in.byte_off, in.byte_len, in.base_offset, in.n_records, 0, n_rec};
-    n_rec += in.n_records;
-  }
-  if (n_rec == 0) return OK;
-  if (n_rec >= (1ll << 32) - 1) return dfail(d, E_UNSUPPORTED, "more than 2^32 - 2 records in one push: push fewer sections at a time");
-  for (Section& s : secs) s.byte_off -= lo;
-  const int64_t n_bytes = hi - lo;
-  int prev = 0;
-  (void)hipGetDevice(&prev);
-  struct Restore { int dev; ~Restore() { (void)hipSetDevice(dev); } } restore{prev};
-  DCHK(d, hipSetDevice(d->device));
+}  // extern "C" (reopened below)
+
+namespace {
+
+// scratch of one push and a fresh error cell; the hash table sized for n_rec more keys
+int32_t begin_push(surge_device_decoder* d, int64_t n_rec) {
   hipStream_t st = d->stream;
   const size_t R = (size_t)n_rec;
-  DCHK(d, d->d_bytes.reserve((size_t)n_bytes + 16, false, st));
-  DCHK(d, d->d_sections.reserve(sizeof(Section) * (size_t)n_sections, false, st));
-  DCHK(d, d->rec_pos.reserve(R * 8, false, st));
-  DCHK(d, d->rec_end.reserve(R * 8, false, st));
   DCHK(d, d->meta.reserve(R * sizeof(RecMeta), false, st));
   DCHK(d, d->new_slots.reserve(R * 4, false, st));
   DCHK(d, d->agg_tmp.reserve(R * 8, false, st));
@@ -673,32 +673,20 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
   DCHK(d, d->keep.reserve(R * 4, false, st));
   DCHK(d, d->keep_pos.reserve(R * 4, false, st));
   DCHK(d, d->f64_list.reserve(R * 4, false, st));
-  // H2D through pinned staging (the caller's arena is pageable); one copy per push
-  if ((size_t)n_bytes > d->pinned_cap) {
-    if (d->pinned) (void)hipHostFree(d->pinned);
-    d->pinned = nullptr;
-    d->pinned_cap = 0;
-    DCHK(d, hipHostMalloc(&d->pinned, (size_t)n_bytes, hipHostMallocDefault));
-    d->pinned_cap = (size_t)n_bytes;
-  }
-  std::memcpy(d->pinned, bytes + lo, (size_t)n_bytes);
-  DCHK(d, hipMemcpyAsync(d->d_bytes.p, d->pinned, (size_t)n_bytes, hipMemcpyHostToDevice, st));
-  DCHK(d, hipMemcpyAsync(d->d_sections.p, secs.data(), sizeof(Section) * (size_t)n_sections, hipMemcpyHostToDevice, st));
   ErrorCell zero{~0ull, 0u, 0u};
   DCHK(d, hipMemcpyAsync(d->d_err.p, &zero, sizeof(zero), hipMemcpyHostToDevice, st));
-  {
-    const int32_t rc = ensure_table(d, n_rec);
-    if (rc != OK) return rc;
-  }
+  return ensure_table(d, n_rec);
+}
+
+// everything behind the per-record metadata: interning, value decode, compaction, append.  host_bytes: the host copy of
+// d_bytes (the exact re-parse of the rare Double the device cannot decide reads the value there).
+int32_t finish_push(surge_device_decoder* d, int64_t n_rec, const uint8_t* host_bytes) {
+  hipStream_t st = d->stream;
+  const size_t R = (size_t)n_rec;
   const uint8_t* dby = (const uint8_t*)d->d_bytes.p;
-  const Section* dsec = (const Section*)d->d_sections.p;
   ErrorCell* derr = (ErrorCell*)d->d_err.p;
   RecMeta* dmeta = (RecMeta*)d->meta.p;
   const unsigned rb = (unsigned)((n_rec + 255) / 256);
-  hipLaunchKernelGGL(chain_kernel, dim3((unsigned)((n_sections + 63) / 64)), dim3(64), 0, st, dby, dsec, n_sections, (int64_t*)d->rec_pos.p,
-                     (int64_t*)d->rec_end.p, derr);
-  hipLaunchKernelGGL(parse_kernel, dim3(rb), dim3(256), 0, st, dby, dsec, n_sections, (const int64_t*)d->rec_pos.p, (const int64_t*)d->rec_end.p,
-                     n_rec, dmeta, derr);
   hipLaunchKernelGGL(probe_kernel, dim3(rb), dim3(256), 0, st, dmeta, n_rec, table_of(d), (uint32_t*)d->new_slots.p, derr);
   ErrorCell ec;
   DCHK(d, hipMemcpyAsync(&ec, derr, sizeof(ec), hipMemcpyDeviceToHost, st));
@@ -787,7 +775,7 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
       DCHK(d, hipMemcpy(&m, dmeta + i, sizeof(m), hipMemcpyDeviceToHost));
       DCHK(d, hipMemcpy(&pos, (uint32_t*)d->keep_pos.p + i, 4, hipMemcpyDeviceToHost));
       uint8_t ev[16];
-      if (surge_event_json_decode(&tmpl, bytes + lo + m.val_off, m.val_len, ev) != 0)
+      if (surge_event_json_decode(&tmpl, host_bytes + m.val_off, m.val_len, ev) != 0)
         return dfail(d, SURGE_E_CORRUPT, "record at offset " + std::to_string(m.offset) + ": " + surge_event_json_last_error());
       DCHK(d, hipMemcpy((uint8_t*)d->r_ev.p + (size_t)(d->n_records + pos) * 16, ev, 16, hipMemcpyHostToDevice));
     }
@@ -800,6 +788,119 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
   return OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes, const surge_batch_section* sections, int64_t n_sections) {
+  if (!d) return dfail(nullptr, E_INVALID, "decoder is NULL");
+  if (n_sections < 0 || (n_sections > 0 && (!bytes || !sections))) return dfail(d, E_INVALID, "bad argument");
+  if (n_sections == 0) return OK;
+  // the span of the arena this push needs, and every batch's first record index
+  int64_t lo = INT64_MAX, hi = 0, n_rec = 0;
+  std::vector<Section> secs;
+  try {
+    secs.resize((size_t)n_sections);
+  } catch (const std::bad_alloc&) {
+    return dfail(d, E_NOMEM, "out of host memory");
+  }
+  for (int64_t s = 0; s < n_sections; ++s) {
+    const surge_batch_section& in = sections[s];
+    if (in.byte_off < 0 || in.byte_len < 0 || in.n_records < 0) return dfail(d, E_INVALID, "negative section field");
+    lo = in.byte_off < lo ? in.byte_off : lo;
+    hi = in.byte_off + in.byte_len > hi ? in.byte_off + in.byte_len : hi;
+    secs[(size_t)s] = Section{in.byte_off, in.byte_len, in.base_offset, in.n_records, 0, n_rec};
+    n_rec += in.n_records;
+  }
+  if (n_rec == 0) return OK;
+  if (n_rec >= (1ll << 32) - 1) return dfail(d, E_UNSUPPORTED, "more than 2^32 - 2 records in one push: push fewer sections at a time");
+  for (Section& s : secs) s.byte_off -= lo;
+  const int64_t n_bytes = hi - lo;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  struct Restore { int dev; ~Restore() { (void)hipSetDevice(dev); } } restore{prev};
+  DCHK(d, hipSetDevice(d->device));
+  hipStream_t st = d->stream;
+  const size_t R = (size_t)n_rec;
+  DCHK(d, d->d_bytes.reserve((size_t)n_bytes + 16, false, st));
+  DCHK(d, d->d_sections.reserve(sizeof(Section) * (size_t)n_sections, false, st));
+  DCHK(d, d->rec_pos.reserve(R * 8, false, st));
+  DCHK(d, d->rec_end.reserve(R * 8, false, st));
+  {
+    const int32_t rc = begin_push(d, n_rec);
+    if (rc != OK) return rc;
+  }
+  // H2D through pinned staging (the caller's arena is pageable); one copy per push
+  if ((size_t)n_bytes > d->pinned_cap) {
+    if (d->pinned) (void)hipHostFree(d->pinned);
+    d->pinned = nullptr;
+    d->pinned_cap = 0;
+    DCHK(d, hipHostMalloc(&d->pinned, (size_t)n_bytes, hipHostMallocDefault));
+    d->pinned_cap = (size_t)n_bytes;
+  }
+  std::memcpy(d->pinned, bytes + lo, (size_t)n_bytes);
+  DCHK(d, hipMemcpyAsync(d->d_bytes.p, d->pinned, (size_t)n_bytes, hipMemcpyHostToDevice, st));
+  DCHK(d, hipMemcpyAsync(d->d_sections.p, secs.data(), sizeof(Section) * (size_t)n_sections, hipMemcpyHostToDevice, st));
+  const uint8_t* dby = (const uint8_t*)d->d_bytes.p;
+  const Section* dsec = (const Section*)d->d_sections.p;
+  ErrorCell* derr = (ErrorCell*)d->d_err.p;
+  RecMeta* dmeta = (RecMeta*)d->meta.p;
+  const unsigned rb = (unsigned)((n_rec + 255) / 256);
+  hipLaunchKernelGGL(chain_kernel, dim3((unsigned)((n_sections + 63) / 64)), dim3(64), 0, st, dby, dsec, n_sections, (int64_t*)d->rec_pos.p,
+                     (int64_t*)d->rec_end.p, derr);
+  hipLaunchKernelGGL(parse_kernel, dim3(rb), dim3(256), 0, st, dby, dsec, n_sections, (const int64_t*)d->rec_pos.p, (const int64_t*)d->rec_end.p,
+                     n_rec, dmeta, derr);
+  return finish_push(d, n_rec, bytes + lo);
+}
+
+int32_t surge_device_decoder_push_records(surge_device_decoder* d, const uint8_t* keys, const int64_t* key_off, const uint8_t* values,
+                                          const int64_t* value_off, const int64_t* offsets, int64_t n) {
+  if (!d) return dfail(nullptr, E_INVALID, "decoder is NULL");
+  if (n < 0 || (n > 0 && (!key_off || !value_off))) return dfail(d, E_INVALID, "bad argument");
+  if (n == 0) return OK;
+  if (n >= (1ll << 32) - 1) return dfail(d, E_UNSUPPORTED, "more than 2^32 - 2 records in one push");
+  const int64_t kb = key_off[n] - key_off[0], vb = value_off[n] - value_off[0];
+  if (kb < 0 || vb < 0 || (kb > 0 && !keys) || (vb > 0 && !values)) return dfail(d, E_INVALID, "bad key / value spans");
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  struct Restore { int dev; ~Restore() { (void)hipSetDevice(dev); } } restore{prev};
+  DCHK(d, hipSetDevice(d->device));
+  hipStream_t st = d->stream;
+  const size_t n_bytes = (size_t)(kb + vb), off_bytes = (size_t)(n + 1) * 8;
+  const size_t stage = n_bytes + 2 * off_bytes + (offsets ? (size_t)n * 8 : 0) + 64;
+  DCHK(d, d->d_bytes.reserve(n_bytes + 16, false, st));
+  DCHK(d, d->rec_pos.reserve(off_bytes, false, st));  // reused as the device copies of key_off / value_off / offsets
+  DCHK(d, d->rec_end.reserve(off_bytes, false, st));
+  DCHK(d, d->d_sections.reserve((size_t)n * 8 + 8, false, st));
+  {
+    const int32_t rc = begin_push(d, n);
+    if (rc != OK) return rc;
+  }
+  if (stage > d->pinned_cap) {
+    if (d->pinned) (void)hipHostFree(d->pinned);
+    d->pinned = nullptr;
+    d->pinned_cap = 0;
+    DCHK(d, hipHostMalloc(&d->pinned, stage, hipHostMallocDefault));
+    d->pinned_cap = stage;
+  }
+  // pinned staging: [keys][values][key_off (rebased)][value_off (rebased)][offsets]
+  uint8_t* pin = (uint8_t*)d->pinned;
+  if (kb) std::memcpy(pin, keys + key_off[0], (size_t)kb);
+  if (vb) std::memcpy(pin + kb, values + value_off[0], (size_t)vb);
+  int64_t* p_ko = (int64_t*)(pin + ((n_bytes + 7) & ~(size_t)7));
+  int64_t* p_vo = p_ko + (n + 1);
+  int64_t* p_of = p_vo + (n + 1);
+  for (int64_t i = 0; i <= n; ++i) { p_ko[i] = key_off[i] - key_off[0]; p_vo[i] = value_off[i] - value_off[0]; }
+  if (offsets) std::memcpy(p_of, offsets, (size_t)n * 8);
+  if (n_bytes) DCHK(d, hipMemcpyAsync(d->d_bytes.p, pin, n_bytes, hipMemcpyHostToDevice, st));
+  DCHK(d, hipMemcpyAsync(d->rec_pos.p, p_ko, off_bytes, hipMemcpyHostToDevice, st));
+  DCHK(d, hipMemcpyAsync(d->rec_end.p, p_vo, off_bytes, hipMemcpyHostToDevice, st));
+  if (offsets) DCHK(d, hipMemcpyAsync(d->d_sections.p, p_of, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(records_meta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)d->d_bytes.p, (const int64_t*)d->rec_pos.p,
+                     (const int64_t*)d->rec_end.p, offsets ? (const int64_t*)d->d_sections.p : nullptr, kb, n, (RecMeta*)d->meta.p, (ErrorCell*)d->d_err.p);
+  return finish_push(d, n, pin);
+}
+
 int32_t surge_device_decoder_result(surge_device_decoder* d, int64_t* n_records, const int64_t** d_agg_idx, const void** d_events16,
                                     const int64_t** d_offsets, int64_t* n_keys) {
   if (!d) return dfail(nullptr, E_INVALID, "decoder is NULL");
@@ -808,6 +909,37 @@ int32_t surge_device_decoder_result(surge_device_decoder* d, int64_t* n_records,
   if (d_events16) *d_events16 = d->r_ev.p;
   if (d_offsets) *d_offsets = (const int64_t*)d->r_off.p;
   if (n_keys) *n_keys = d->n_keys;
+  return OK;
+}
+
+// result -> resident state: the composition a host would otherwise spell out (grow for the new keys, device group-by +
+// fold, clear), behind one call so a JVM needs a single JNI crossing per poll
+int32_t surge_replay_append_decoded(surge_replay_handle* h, surge_device_decoder* d, int64_t* n_events_out, int64_t* n_keys_out) {
+  if (!h || !d) return dfail(d, E_INVALID, "NULL argument");
+  if (n_events_out) *n_events_out = d->n_records;
+  if (n_keys_out) *n_keys_out = d->n_keys;
+  void* d_states = nullptr;
+  int64_t n_agg = 0;
+  int32_t rc = surge_replay_device_state(h, &d_states, &n_agg);
+  if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
+  if (d->n_keys > n_agg) {
+    rc = surge_replay_grow(h, d->n_keys);
+    if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
+  }
+  if (d->n_records > 0) {
+    // the decoder's arrays are written on its stream and read on the handle's: make the hand-over explicit
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(d->device);
+    const hipError_t e = hipStreamSynchronize(d->stream);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) return dfail(d, E_DEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    rc = surge_replay_append_events_device(h, (const int64_t*)d->r_agg.p, d->r_ev.p, d->n_records);
+    if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
+    rc = surge_replay_synchronize(h);  // the arrays are reused by the next push
+    if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
+  }
+  d->n_records = 0;
   return OK;
 }
 

@@ -222,6 +222,22 @@ class DeviceDecoder:
         self._check(self._lib.surge_device_decoder_push(self._h, ctypes.c_void_p(arena_address), sections.ctypes.data_as(ctypes.c_void_p),
                                                         sections.shape[0]))
 
+    def push_records(self, keys: List[bytes], values: List[bytes], offsets=None) -> None:
+        """Records that are already framed (a consumer's key / value byte arrays), in bulk."""
+        def table(items):
+            off = np.zeros(len(items) + 1, dtype=np.int64)
+            if items:
+                np.cumsum([len(x) for x in items], out=off[1:])
+            data = np.frombuffer(b"".join(items), dtype=np.uint8) if off[-1] else np.zeros(1, np.uint8)
+            return data, off
+
+        kd, ko = table(keys)
+        vd, vo = table(values)
+        of = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.int64)
+        self._check(self._lib.surge_device_decoder_push_records(
+            self._h, kd.ctypes.data_as(ctypes.c_void_p), ko.ctypes.data_as(ctypes.c_void_p), vd.ctypes.data_as(ctypes.c_void_p),
+            vo.ctypes.data_as(ctypes.c_void_p), of.ctypes.data_as(ctypes.c_void_p) if of is not None else None, len(keys)))
+
     def push_from(self, ingest: EventsTopicIngest) -> int:
         """Everything ``ingest`` (created with ``frames=True``) can deliver now; returns the number of batches."""
         sections, arena = ingest.drain_sections()

@@ -11,6 +11,7 @@
 #include <string.h>
 #include <jni.h>
 #include "surge_replay.h"
+#include "surge_ingest.h"
 
 jlong Java_surge_replay_gpu_NativeReplay_create(JNIEnv*, jclass, jobject, jint);
 void Java_surge_replay_gpu_NativeReplay_destroy(JNIEnv*, jclass, jlong);
@@ -32,6 +33,11 @@ jlong Java_surge_replay_gpu_NativeReplay_commCounts(JNIEnv*, jclass, jlong, jlon
 jint Java_surge_replay_gpu_NativeReplay_allgatherSnapshot(JNIEnv*, jclass, jlong, jlong, jint, jint);
 jint Java_surge_replay_gpu_NativeReplay_allgatherGroup(JNIEnv*, jclass, jobject, jint, jint);
 jint Java_surge_replay_gpu_NativeReplay_gatheredRead(JNIEnv*, jclass, jlong, jint, jint, jlong, jlong, jobject);
+jlong Java_surge_replay_gpu_NativeReplay_decoderCreate(JNIEnv*, jclass, jobject, jint);
+void Java_surge_replay_gpu_NativeReplay_decoderDestroy(JNIEnv*, jclass, jlong);
+jint Java_surge_replay_gpu_NativeReplay_decoderPushRecords(JNIEnv*, jclass, jlong, jobject, jobject, jobject, jobject, jobject, jlong);
+jint Java_surge_replay_gpu_NativeReplay_appendDecoded(JNIEnv*, jclass, jlong, jlong, jobject);
+jint Java_surge_replay_gpu_NativeReplay_decoderKeys(JNIEnv*, jclass, jlong, jobject, jobject, jobject);
 
 typedef struct { void* address; jlong capacity; } fake_direct_buffer;
 #define DB(ptr, bytes) { (void*)(ptr), (jlong)(bytes) }
@@ -233,6 +239,58 @@ int main(void) {
     check(ok2 && n_thrown == 0 && g[0].count == 21 && g[1].count == 22 && !(g[2].flags & SURGE_STATE_PRESENT) && !(g[3].flags & SURGE_STATE_PRESENT),
           "allgatherGroup: two handles in one process, each reads the other's shard; short shard padded with None");
     if (h2) Java_surge_replay_gpu_NativeReplay_destroy(env, NULL, h2);
+  }
+  {
+    /* device decode through JNI: a poll of the Counter fixture's play-json events (TestBoundedContext.scala:122-124) as key /
+     * value byte arrays -> decoderPushRecords -> appendDecoded onto an empty store -> (count, version) of agg-1 = (2 - 5, 3) */
+    surge_event_json_template t;
+    const char* keys = "agg-1:1agg-2:1agg-1:2agg-1:3";
+    const char* vals = "{\"aggregateId\":\"agg-1\",\"incrementBy\":1,\"sequenceNumber\":1,\"_type\":\"countIncremented\"}"
+                       "{\"_type\":\"countIncremented\",\"aggregateId\":\"agg-2\",\"incrementBy\":7,\"sequenceNumber\":1}"
+                       "{\"aggregateId\":\"agg-1\",\"incrementBy\":1,\"sequenceNumber\":2,\"_type\":\"countIncremented\"}"
+                       "{\"aggregateId\":\"agg-1\",\"decrementBy\":5,\"sequenceNumber\":3,\"_type\":\"countDecremented\"}";
+    const char* v0 = vals;
+    int64_t key_off[5] = {0, 7, 14, 21, 28}, val_off[5], offs[4] = {10, 11, 12, 13}, out2[2] = {0, 0}, counts[2] = {0, 0}, koff[3] = {0, 0, 0};
+    char utf8[16];
+    int i;
+    surge_state64 got;
+    memset(&t, 0, sizeof(t));
+    t.n_types = 2;
+    strcpy(t.discriminator, "_type");
+    strcpy(t.types[0].name, "countIncremented"); t.types[0].event_type = SURGE_EVT_INC; t.types[0].arg_kind = SURGE_EVJ_ARG_I32;
+    strcpy(t.types[0].seq_field, "sequenceNumber"); strcpy(t.types[0].arg_field, "incrementBy");
+    strcpy(t.types[1].name, "countDecremented"); t.types[1].event_type = SURGE_EVT_DEC; t.types[1].arg_kind = SURGE_EVJ_ARG_I32;
+    strcpy(t.types[1].seq_field, "sequenceNumber"); strcpy(t.types[1].arg_field, "decrementBy");
+    val_off[0] = 0;
+    for (i = 0; i < 4; ++i) { const char* e = strchr(v0 + val_off[i], '}'); val_off[i + 1] = (int64_t)(e - v0) + 1; }
+    {
+      fake_direct_buffer b_t = DB(&t, sizeof(t)), b_k = DB(keys, 28), b_ko = DB(key_off, sizeof(key_off)), b_v = DB(vals, val_off[4]),
+                         b_vo = DB(val_off, sizeof(val_off)), b_of = DB(offs, sizeof(offs)), b_o2 = DB(out2, sizeof(out2)),
+                         b_cn = DB(counts, sizeof(counts)), b_u = DB(utf8, sizeof(utf8)), b_kf = DB(koff, sizeof(koff)), b_st = DB(&got, sizeof(got));
+      int64_t zero_off[1] = {0};
+      fake_direct_buffer b_z = DB(zero_off, sizeof(zero_off));
+      jlong hd, dec;
+      n_thrown = 0;
+      hd = Java_surge_replay_gpu_NativeReplay_create(env, NULL, NULL, 0);
+      dec = Java_surge_replay_gpu_NativeReplay_decoderCreate(env, NULL, &b_t, 0);
+      check(hd != 0 && dec != 0 && Java_surge_replay_gpu_NativeReplay_loadCsr(env, NULL, hd, &b_z, 0, NULL, 0, NULL) == 0 &&
+                Java_surge_replay_gpu_NativeReplay_fold(env, NULL, hd, 0) == 0 &&
+                Java_surge_replay_gpu_NativeReplay_decoderPushRecords(env, NULL, dec, &b_k, &b_ko, &b_v, &b_vo, &b_of, 4) == 0 &&
+                Java_surge_replay_gpu_NativeReplay_appendDecoded(env, NULL, hd, dec, &b_o2) == 0 && out2[0] == 4 && out2[1] == 2 && n_thrown == 0,
+            "decoderCreate / decoderPushRecords / appendDecoded: a poll of play-json Counter events folded on the device");
+      check(Java_surge_replay_gpu_NativeReplay_get(env, NULL, hd, 0, &b_st) == 1 && got.count == -3 && got.version == 3 &&
+                Java_surge_replay_gpu_NativeReplay_get(env, NULL, hd, 1, &b_st) == 1 && got.count == 7 && got.version == 1,
+            "states after the poll: agg-1 = (1 + 1 - 5, 3), agg-2 = (7, 1)");
+      check(Java_surge_replay_gpu_NativeReplay_decoderKeys(env, NULL, dec, &b_u, &b_kf, &b_cn) == 0 && counts[0] == 2 && counts[1] == 10 &&
+                memcmp(utf8, "agg-1agg-2", 10) == 0 && koff[1] == 5 && koff[2] == 10,
+            "decoderKeys: aggregate ids in first-delivered order");
+      n_thrown = 0;
+      val_off[2] = val_off[1] - 3; /* offsets that decrease: refused before the C ABI sees them */
+      check(Java_surge_replay_gpu_NativeReplay_decoderPushRecords(env, NULL, dec, &b_k, &b_ko, &b_v, &b_vo, &b_of, 4) == SURGE_E_INVALID && n_thrown == 1,
+            "decreasing value offsets -> IllegalArgumentException");
+      Java_surge_replay_gpu_NativeReplay_decoderDestroy(env, NULL, dec);
+      Java_surge_replay_gpu_NativeReplay_destroy(env, NULL, hd);
+    }
   }
   Java_surge_replay_gpu_NativeReplay_destroy(env, NULL, h);
   printf("%s\n", fails ? "FAILED" : "ALL PASS");

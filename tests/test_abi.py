@@ -35,7 +35,7 @@ def test_exports_match_the_header():
 
 def test_ingest_exports_match_their_header():
     lib = _native.load()
-    declared = header_symbols("surge_ingest.h", "surge_(?:ingest|event_json|crc32c|lz4|xxh32|device_decoder|parse_f64)")
+    declared = header_symbols("surge_ingest.h", "surge_(?:ingest|event_json|crc32c|lz4|xxh32|device_decoder|parse_f64|replay_append_decoded)")
     assert declared == sorted(_native.INGEST_EXPORTS)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in surge_ingest.h but not exported"
@@ -187,7 +187,7 @@ def test_jni_shim_compiles_and_turns_a_missing_gpu_into_an_ioexception(tmp_path)
 def test_jni_shim_replays_the_reference_known_answers_through_direct_buffers(tmp_path):
     res = _build_jni_harness(tmp_path)
     assert res.returncode == 0, res.stdout + res.stderr
-    assert "ALL PASS" in res.stdout and res.stdout.count("PASS  ") == 20 and "FAIL" not in res.stdout
+    assert "ALL PASS" in res.stdout and res.stdout.count("PASS  ") == 24 and "FAIL" not in res.stdout
 
 
 def test_the_fake_jnienv_harness_drives_every_jni_export():

@@ -70,3 +70,29 @@ def test_eight_rank_bench_rehearsal_has_the_shape_of_config_c4(tmp_path):
     assert "C4:" in cfg["workload"] and "% 8" in cfg["workload"] and "C ABI" in cfg["exchange"]
     # shards by partitionForKey(id, 64) % 8 are balanced to a few percent at this size
     assert max(cfg["per_rank_events"]) < 1.15 * min(cfg["per_rank_events"])
+
+
+def run_single(args):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=600, cwd=ROOT,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_workload_v2_reports_four_variants_of_the_same_device_code_and_full_log_parity():
+    d = run_single(["--workload", "v2", "--aggregates", "30000", "--steps", "3", "--warmup", "1"])
+    v = d["config"]["variants"]
+    assert set(v) == {"specialised/tiled", "specialised/csr", "interpreter/tiled", "interpreter/csr"}
+    assert all(x["states_equal_first_variant"] for x in v.values()) and d["cpu_baseline"]["gpu_matches_cpu_full_log"] is True
+    assert d["roofline"]["kernel"] == "surge_slots_tiled2" and d["one_shot"]["schema_compile_ms"] >= 0 and "hiprtc" in d["config"]["kernels"]
+
+
+@pytest.mark.gpu
+def test_bench_workload_e2e_goes_from_topic_bytes_to_states_and_checks_them():
+    d = run_single(["--workload", "e2e", "--batch-events", "20000", "--steps", "3", "--warmup", "1"])
+    cfg = d["config"]
+    assert cfg["fetch_records"] == 20000 and cfg["decoder_counters"]["records_delivered"] == 20000 * 4 and cfg["aggregates_seen"] > 1000
+    assert d["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_decoded_events"] is True and d["value"] > 0

@@ -185,6 +185,30 @@ def test_device_decoder_decodes_play_json_counter_and_bank_account_events_like_t
     assert dev_keys == host_keys
     for h, g in zip(host, dev):
         assert h.tobytes() == g.tobytes()
+    # the same records already framed (a JVM consumer's key / value arrays): surge_device_decoder_push_records, in two
+    # polls, then folded onto a store with surge_replay_append_decoded
+    import ctypes
+
+    from surge_amd.replay import ReplayEngine
+
+    with DeviceDecoder(model.event_json_template()) as d, ReplayEngine(model.event_algebra()) as eng:
+        eng.load_csr(np.zeros(1, np.int64), np.zeros(0, dtype=S.EVENT_DTYPE))
+        eng.fold()
+        half = len(recs) // 2
+        d.push_records([k for k, _ in recs[:half]] + [b""], [v for _, v in recs[:half]] + [b""], list(range(half + 1)))  # + a flush record
+        d.push_records([k for k, _ in recs[half:]], [v for _, v in recs[half:]], list(range(half, len(recs))))
+        agg, ev, off, n_keys = d.result()
+        assert d.keys() == host_keys and agg.cpu().numpy().tobytes() == host[0].tobytes()
+        assert ev.cpu().numpy().view(S.EVENT_DTYPE).reshape(-1).tobytes() == host[1].tobytes() and off.cpu().numpy().tobytes() == host[2].tobytes()
+        assert d.counters()["flush_records_skipped"] == 1
+        n_ev, n_k = ctypes.c_int64(), ctypes.c_int64()
+        assert d._lib.surge_replay_append_decoded(eng._h, d._h, ctypes.byref(n_ev), ctypes.byref(n_k)) == 0
+        assert (n_ev.value, n_k.value) == (len(recs), len(host_keys)) and d.result()[0].shape[0] == 0
+        eng.n_agg = n_k.value
+        order = np.argsort(host[0], kind="stable")
+        so = np.zeros(n_k.value + 1, np.int64)
+        np.cumsum(np.bincount(host[0], minlength=n_k.value), out=so[1:])
+        assert eng.snapshot().tobytes() == oracle.fold_csr(so, host[1][order], None, model.event_algebra()).tobytes()
 
     # BankAccount: Doubles as play-json writes them (and a few spellings it never writes), field order shuffled, extra
     # fields, nested values to skip
