@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--batch-events", type=int, default=100_000, help="c5: events per micro-batch")
     ap.add_argument("--snapshot-every", type=int, default=30, help="c5: publish a state-topic delta every N batches (0 = never)")
     ap.add_argument("--device-batches", action="store_true", help="c5: batches already in HBM (no staging / H2D)")
+    ap.add_argument("--codec", default="lz4", choices=["lz4", "none"], help="e2e: compression of the record batches (the reference's producer: lz4)")
     ap.add_argument("--aggregates", type=int, default=None, help="global aggregate count (default 10 M for c4, 1 M for c2)")
     ap.add_argument("--events-per-aggregate", type=int, default=C2_EVENTS, help="c2 only")
     ap.add_argument("--algo", default=None,
@@ -766,8 +767,9 @@ def run_v2(args):
 def run_e2e(args):
     """From the bytes Kafka hands over to recovered states (SURVEY §8f N1 in front of R2): record batches (message format
     v2, 500 records each, the Counter fixture's play-json event text as the reference writes it: TestBoundedContext.scala:
-    122-124) -> host framing (headers, CRC-32C, read_committed; ONE host thread) -> surge_device_decoder (records, key
-    interning, JSON -> 16-byte events, on the GPU) -> device group-by + fold onto the resident state (K3).  A step = one
+    122-124; lz4-compressed like the reference's producer, reference.conf:112, frames written by liblz4) -> host framing
+    (headers, CRC-32C, read_committed; ONE host thread) -> surge_device_decoder (LZ4 blocks, records, key interning,
+    JSON -> 16-byte events, on the GPU) -> device group-by + fold onto the resident state (K3).  A step = one
     fetch of --batch-events records (default 1 M); `value` = events/s over K fetches incl. everything between the bytes
     and the states.  The same bytes through the library's host decoder beside it; the states after the run are compared
     with the oracle's fold of the decoded events, aggregate by aggregate."""
@@ -804,7 +806,12 @@ def run_e2e(args):
             e = [CountIncremented(agg, int(rng.integers(0, 1000)), i + 1), CountDecremented(agg, int(rng.integers(0, 1000)), i + 1), NoOpEvent(agg, i + 1)][i % 3]
             m = fmt.write_event(e)
             recs.append((m.key.encode(), m.value))
-        protos.append(bytearray(kw.record_batch(0, recs)))
+        if args.codec == "lz4":  # frames written by liblz4 itself (as bundled by Apache Arrow), one 64 KiB-block frame per batch
+            import pyarrow as pa
+
+            protos.append(bytearray(kw.record_batch(0, recs, compression="lz4", compressor=lambda raw: pa.Codec("lz4").compress(raw, asbytes=True))))
+        else:
+            protos.append(bytearray(kw.record_batch(0, recs)))
     offset = [0]
 
     def fetch():
@@ -819,7 +826,7 @@ def run_e2e(args):
     fetches = [fetch() for _ in range(W + K)]
     wire_bytes = sum(len(f) for f in fetches[W:])
     lat, host_ms, dev_ms = [], [], []
-    with EventsTopicIngest(frames=True) as g, DeviceDecoder(tmpl) as d, ReplayEngine(model.event_algebra()) as eng:
+    with EventsTopicIngest(frames=True, device_lz4=True) as g, DeviceDecoder(tmpl) as d, ReplayEngine(model.event_algebra()) as eng:
         eng.load_csr(np.zeros(1, np.int64), np.zeros(0, dtype=S.EVENT_DTYPE))
         eng.fold()
         n_agg = 0
@@ -872,7 +879,8 @@ def run_e2e(args):
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "bytes -> int32 events -> int32/int64 adds", "data": "synthetic (Counter fixture events as play-json text in Kafka record batches v2, built on the host)",
         "config": {"workload": f"E2E: events-topic bytes -> states; fetches of {n_fetch} records ({PER}-record batches, play-json Counter events, "
-                               f"uncompressed), host framing on ONE thread, records / key interning / JSON decode / group-by / fold on the GPU",
+                               f"compression {args.codec}), host framing on ONE thread (headers, CRC-32C, transactions), LZ4 / records / key interning / JSON decode / "
+                               f"group-by / fold on the GPU",
                    "fetch_records": n_fetch, "wire_bytes_per_record": wire_bytes / n_events, "aggregates_seen": int(n_agg),
                    "fetch_ms": {"p50": float(np.percentile(lat, 50)), "max": float(np.max(lat))},
                    "host_framing_ms_per_fetch": float(np.mean(host_ms)), "device_decode_groupby_fold_ms_per_fetch": float(np.mean(dev_ms)),

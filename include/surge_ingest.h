@@ -125,13 +125,16 @@ int32_t surge_ingest_drain_json(surge_ingest* g, int64_t max, const surge_event_
  *   surge_ingest_drain_sections(g, ..)  ->  surge_device_decoder_push(d, surge_ingest_arena(g), sections, n)
  * Same results as surge_ingest_drain_fixed16 / _json on the same bytes (tests/test_ingest_gpu.py): same records in the
  * same order, aggregate ids numbered in first-delivered order, flush records skipped, the same values rejected. */
-#define SURGE_INGEST_FRAMES 0x100 /* OR into surge_ingest_create's isolation_level */
+#define SURGE_INGEST_FRAMES     0x100 /* OR into surge_ingest_create's isolation_level */
+#define SURGE_INGEST_DEVICE_LZ4 0x200 /* FRAMES, and lz4 batches keep their LZ4 frame: the device decoder decodes the blocks on the
+                                         GPU (one wave per 64 KiB block, assembled in LDS); frames kafka-clients would not write —
+                                         blocks above 64 KiB, dependent blocks — it decompresses on the host                       */
 typedef struct surge_batch_section {
   int64_t byte_off;    /* the batch's records section inside the arena (surge_ingest_arena)            */
   int64_t byte_len;
   int64_t base_offset; /* Kafka offset of the batch's first record                                     */
   int32_t n_records;
-  int32_t reserved;
+  int32_t codec;       /* 0: the records themselves; 3: one LZ4 frame that holds them (SURGE_INGEST_DEVICE_LZ4)  */
 } surge_batch_section;
 /* Pops up to max deliverable batches (committed / non-transactional, before any open transaction), in offset order.
  * Spans stay valid until the next feed / destroy.  SURGE_E_STATE on a decoder that was not created in FRAMES mode. */

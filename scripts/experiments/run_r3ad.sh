@@ -1,0 +1,12 @@
+mkdir -p gpurun_out/r3ad
+timeout 400 python -m pytest tests/test_ingest_gpu.py tests/test_abi.py -x -q -m gpu > gpurun_out/r3ad/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r3ad/pytest.log
+grep -v amdgpu.ids gpurun_out/r3ad/pytest.log | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -30
+timeout 300 python scripts/ingest_gpu_bench.py 8000 > gpurun_out/r3ad/ingest_gpu.json 2> gpurun_out/r3ad/ingest_gpu.err; echo "ingest rc=$?"; tail -3 gpurun_out/r3ad/ingest_gpu.err
+python -c "
+import json; d=json.load(open('gpurun_out/r3ad/ingest_gpu.json'))
+for k,v in d.items():
+    if isinstance(v,dict):
+        print(k, 'host', round(v['host_decoder']['records_per_sec']/1e6,1))
+        for l in v:
+            if l.startswith('framing'): print('   ', l, round(v[l]['records_per_sec']/1e6,1), 'framing_s', round(v[l]['host_framing_s'],3), 'push_s', round(v[l]['device_push_s'],3), v[l]['equal_to_host_decoder'])
+"

@@ -29,7 +29,7 @@ struct Batch {
   size_t next = 0;  // first record not yet drained
   // FRAMES mode (device decode): the batch's records section, verbatim, inside the arena
   int64_t sect_off = -1, sect_len = 0, base_offset = 0;
-  int32_t count = 0;
+  int32_t count = 0, sect_codec = 0;
 };
 
 struct CrcTables {
@@ -195,6 +195,7 @@ int lz4_block(const uint8_t* ip, const uint8_t* iend, uint8_t* dst, int64_t* op_
 struct surge_ingest {
   int isolation = SURGE_INGEST_READ_COMMITTED;
   bool frames = false;  // SURGE_INGEST_FRAMES: records are not parsed here, their sections go to a surge_device_decoder
+  bool device_lz4 = false;  // SURGE_INGEST_DEVICE_LZ4: ... and LZ4 frames stay compressed (the device decoder undoes them)
   std::string err;
   std::vector<uint8_t> arena;
   std::deque<Batch> queue;
@@ -407,14 +408,16 @@ int64_t surge_lz4_frame_decompress(const uint8_t* src, int64_t n, uint8_t* dst, 
 int32_t surge_ingest_create(int32_t isolation_level, surge_ingest** out) {
   if (!out) return fail(nullptr, E_INVALID, "out is NULL");
   *out = nullptr;
-  const bool frames = (isolation_level & SURGE_INGEST_FRAMES) != 0;
-  isolation_level &= ~SURGE_INGEST_FRAMES;
+  const bool frames = (isolation_level & (SURGE_INGEST_FRAMES | SURGE_INGEST_DEVICE_LZ4)) != 0;
+  const bool device_lz4 = (isolation_level & SURGE_INGEST_DEVICE_LZ4) != 0;
+  isolation_level &= ~(SURGE_INGEST_FRAMES | SURGE_INGEST_DEVICE_LZ4);
   if (isolation_level != SURGE_INGEST_READ_UNCOMMITTED && isolation_level != SURGE_INGEST_READ_COMMITTED)
     return fail(nullptr, E_INVALID, "unknown isolation level");
   surge_ingest* g = new (std::nothrow) surge_ingest();
   if (!g) return fail(nullptr, E_NOMEM, "out of host memory");
   g->isolation = isolation_level;
   g->frames = frames;
+  g->device_lz4 = device_lz4;
   *out = g;
   return OK;
 }
@@ -465,7 +468,10 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
       const bool transactional = attrs & 0x10, control = attrs & 0x20;
       const uint8_t* recs = r.p;
       int64_t recs_len = r.end - r.p;
-      if (codec == 3) {
+      int sect_codec = 0;
+      if (codec == 3 && g->device_lz4 && !control) {
+        sect_codec = 3;  // the frame travels as it is: the device decoder walks its blocks and decodes them on the GPU
+      } else if (codec == 3) {
         // first guess: the frame's content-size field when the producer wrote one, else 8x (Kafka's LZ4 output
         // stream omits it); a too-small guess comes back as -6 (out of space) and is grown, never as "corrupt"
         int64_t cap = recs_len * 8 + 1024;
@@ -499,6 +505,7 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
         b.sect_len = recs_len;
         b.base_offset = base_offset;
         b.count = count;
+        b.sect_codec = sect_codec;
         g->arena.insert(g->arena.end(), recs, recs + recs_len);
         g->counters[1] += count;
       } else {
@@ -645,7 +652,7 @@ int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge
       out[n].byte_len = b.sect_len;
       out[n].base_offset = b.base_offset;
       out[n].n_records = b.count;
-      out[n].reserved = 0;
+      out[n].codec = b.sect_codec;
       recs += b.count;
       ++n;
     }

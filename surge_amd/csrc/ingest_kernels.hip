@@ -69,6 +69,8 @@ struct Section {  // = surge_batch_section + the batch's first record index in t
 struct ErrorCell {
   unsigned long long first_bad;  // min over (record index << 8 | status)
   unsigned int n_new, n_f64_host;
+  unsigned int lz4_bad;          // the first section whose LZ4 frame did not decode (~0 = none)
+  unsigned int pad;
 };
 
 struct Reader {
@@ -91,6 +93,105 @@ struct Reader {
 
 __device__ __forceinline__ void report(ErrorCell* err, int64_t rec, uint32_t status) {
   atomicMin(&err->first_bad, ((unsigned long long)rec << 8) | status);
+}
+
+// ---- LZ4 (the reference's producer publishes lz4: reference.conf:112) ------------------------------------------------
+// A record batch's records section is ONE LZ4 frame; kafka-clients writes it with independent blocks of at most 64 KiB
+// (KafkaLZ4BlockOutputStream's default), so every block but a frame's last decompresses to exactly 64 KiB and block k
+// of a frame lands at k x 64 KiB of the frame's output.  The host walks the frame header and the block size words
+// (nothing per byte); one WAVE decodes one block: the token / length / offset bytes are wave-uniform (every lane reads
+// the same byte: one broadcast load), literal runs and matches are copied by the 64 lanes together, an overlapping
+// match (offset < length: the period IS the data) as out[op + i] = out[op - offset + i % offset].  The block is
+// assembled in LDS — lanes read what other lanes wrote a sequence ago, which global memory does not promise inside a
+// wave — and leaves as whole 16-byte stores.
+constexpr int kLz4BlockMax = 65536;
+struct Lz4Block {
+  int64_t src_off;   // in the staged bytes
+  int64_t dst_off;   // in the decompressed area
+  int32_t src_len;   // bit 31: stored uncompressed
+  int32_t section;   // the section this block belongs to
+  int32_t last;      // the frame's last block: sets the section's length
+  int32_t index;     // k: this block's number inside its frame
+};
+
+__global__ void __launch_bounds__(64) lz4_block_kernel(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ out_base, const Lz4Block* __restrict__ blocks,
+                                                       int64_t n_blocks, Section* __restrict__ sections, ErrorCell* err) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lz4_out[];
+  const int lane = threadIdx.x;
+  for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+    const Lz4Block blk = blocks[b];
+    const uint8_t* in = bytes + blk.src_off;
+    const int32_t n_in = blk.src_len & 0x7fffffff;
+    int32_t op = 0;
+    bool ok = true;
+    if (blk.src_len < 0) {  // stored
+      ok = n_in <= kLz4BlockMax;
+      if (ok) {
+        for (int i = lane; i < n_in; i += 64) lz4_out[i] = in[i];
+        op = n_in;
+      }
+    } else {
+      int32_t ip = 0;
+      while (ip < n_in) {
+        const uint32_t token = __builtin_amdgcn_readfirstlane((uint32_t)in[ip++]);
+        int32_t lit = (int32_t)(token >> 4);
+        if (lit == 15) {
+          uint32_t x;
+          do {
+            if (ip >= n_in) { ok = false; break; }
+            x = __builtin_amdgcn_readfirstlane((uint32_t)in[ip++]);
+            lit += (int32_t)x;
+          } while (x == 255u && lit < (1 << 24));
+        }
+        if (!ok || lit > n_in - ip || lit > kLz4BlockMax - op) { ok = false; break; }
+        for (int i = lane; i < lit; i += 64) lz4_out[op + i] = in[ip + i];
+        ip += lit;
+        op += lit;
+        if (ip >= n_in) break;  // the last sequence carries literals only
+        if (n_in - ip < 2) { ok = false; break; }
+        const int32_t offset = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)in[ip] | ((uint32_t)in[ip + 1] << 8));
+        ip += 2;
+        if (offset == 0 || offset > op) { ok = false; break; }
+        int32_t ml = (int32_t)(token & 15u);
+        if (ml == 15) {
+          uint32_t x;
+          do {
+            if (ip >= n_in) { ok = false; break; }
+            x = __builtin_amdgcn_readfirstlane((uint32_t)in[ip++]);
+            ml += (int32_t)x;
+          } while (x == 255u && ml < (1 << 24));
+        }
+        ml += 4;
+        if (!ok || ml > kLz4BlockMax - op) { ok = false; break; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the literals (and earlier matches) are in LDS before they are read back
+        __builtin_amdgcn_wave_barrier();
+        const uint8_t* src = lz4_out + op - offset;
+        if (offset >= ml) {
+          for (int i = lane; i < ml; i += 64) lz4_out[op + i] = src[i];
+        } else {
+          for (int i = lane; i < ml; i += 64) lz4_out[op + i] = src[i % offset];
+        }
+        op += ml;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    // every block of a frame but its last is exactly full (that is how block k's place is known before it is decoded)
+    if (ok && !blk.last && op != kLz4BlockMax) ok = false;
+    if (!ok) {
+      if (lane == 0) atomicMin(&err->lz4_bad, (unsigned int)blk.section);
+      op = 0;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    uint8_t* dst = out_base + blk.dst_off;  // 16-byte aligned: dst_off is a multiple of 64 KiB from an aligned base
+    const int n16 = op >> 4;
+    for (int i = lane; i < n16; i += 64) ((uint4*)dst)[i] = ((const uint4*)lz4_out)[i];
+    for (int i = (n16 << 4) + lane; i < op; i += 64) dst[i] = lz4_out[i];
+    if (blk.last && lane == 0) sections[blk.section].byte_len = ok ? (int64_t)blk.index * kLz4BlockMax + op : 0;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 __global__ void chain_kernel(const uint8_t* __restrict__ bytes, const Section* __restrict__ sections, int64_t n_sections,
@@ -538,6 +639,7 @@ struct surge_device_decoder {
   std::string err;
   Buf d_tmpl, d_ptab, d_err;
   // per push
+  Buf lz4_blocks;
   Buf d_bytes, d_sections, rec_pos, rec_end, meta, new_slots, sort_k_a, sort_k_b, sort_v_b, lens, agg_tmp, ev_tmp, keep, keep_pos, f64_list, temp;
   void* pinned = nullptr;
   size_t pinned_cap = 0;
@@ -648,7 +750,7 @@ int32_t surge_device_decoder_destroy(surge_device_decoder* d) {
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  Buf* bufs[] = {&d->d_tmpl, &d->d_ptab, &d->d_err, &d->d_bytes, &d->d_sections, &d->rec_pos, &d->rec_end, &d->meta, &d->new_slots, &d->sort_k_a,
+  Buf* bufs[] = {&d->lz4_blocks, &d->d_tmpl, &d->d_ptab, &d->d_err, &d->d_bytes, &d->d_sections, &d->rec_pos, &d->rec_end, &d->meta, &d->new_slots, &d->sort_k_a,
                  &d->sort_k_b, &d->sort_v_b, &d->lens, &d->agg_tmp, &d->ev_tmp, &d->keep, &d->keep_pos, &d->f64_list, &d->temp, &d->t_hash,
                  &d->t_key_id, &d->t_first, &d->arena, &d->key_off, &d->key_hash, &d->r_agg, &d->r_ev, &d->r_off};
   for (Buf* b : bufs) b->release();
@@ -673,14 +775,13 @@ int32_t begin_push(surge_device_decoder* d, int64_t n_rec) {
   DCHK(d, d->keep.reserve(R * 4, false, st));
   DCHK(d, d->keep_pos.reserve(R * 4, false, st));
   DCHK(d, d->f64_list.reserve(R * 4, false, st));
-  ErrorCell zero{~0ull, 0u, 0u};
+  ErrorCell zero{~0ull, 0u, 0u, ~0u, 0u};
   DCHK(d, hipMemcpyAsync(d->d_err.p, &zero, sizeof(zero), hipMemcpyHostToDevice, st));
   return ensure_table(d, n_rec);
 }
 
-// everything behind the per-record metadata: interning, value decode, compaction, append.  host_bytes: the host copy of
-// d_bytes (the exact re-parse of the rare Double the device cannot decide reads the value there).
-int32_t finish_push(surge_device_decoder* d, int64_t n_rec, const uint8_t* host_bytes) {
+// everything behind the per-record metadata: interning, value decode, compaction, append
+int32_t finish_push(surge_device_decoder* d, int64_t n_rec) {
   hipStream_t st = d->stream;
   const size_t R = (size_t)n_rec;
   const uint8_t* dby = (const uint8_t*)d->d_bytes.p;
@@ -691,6 +792,8 @@ int32_t finish_push(surge_device_decoder* d, int64_t n_rec, const uint8_t* host_
   ErrorCell ec;
   DCHK(d, hipMemcpyAsync(&ec, derr, sizeof(ec), hipMemcpyDeviceToHost, st));
   DCHK(d, hipStreamSynchronize(st));
+  if (ec.lz4_bad != ~0u)
+    return dfail(d, SURGE_E_CORRUPT, "bad LZ4 frame in section " + std::to_string(ec.lz4_bad) + " of the push (malformed sequence, or a block that is not 64 KiB where it must be)");
   const uint32_t n_new = ec.n_new;
   if (n_new > 0) {
     // new keys in first-delivered order
@@ -775,7 +878,9 @@ int32_t finish_push(surge_device_decoder* d, int64_t n_rec, const uint8_t* host_
       DCHK(d, hipMemcpy(&m, dmeta + i, sizeof(m), hipMemcpyDeviceToHost));
       DCHK(d, hipMemcpy(&pos, (uint32_t*)d->keep_pos.p + i, 4, hipMemcpyDeviceToHost));
       uint8_t ev[16];
-      if (surge_event_json_decode(&tmpl, host_bytes + m.val_off, m.val_len, ev) != 0)
+      std::vector<uint8_t> value((size_t)m.val_len + 1);
+      DCHK(d, hipMemcpy(value.data(), dby + m.val_off, (size_t)m.val_len, hipMemcpyDeviceToHost));  // (an LZ4 section exists decompressed on the device only)
+      if (surge_event_json_decode(&tmpl, value.data(), m.val_len, ev) != 0)
         return dfail(d, SURGE_E_CORRUPT, "record at offset " + std::to_string(m.offset) + ": " + surge_event_json_last_error());
       DCHK(d, hipMemcpy((uint8_t*)d->r_ev.p + (size_t)(d->n_records + pos) * 16, ev, 16, hipMemcpyHostToDevice));
     }
@@ -815,14 +920,84 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
   if (n_rec == 0) return OK;
   if (n_rec >= (1ll << 32) - 1) return dfail(d, E_UNSUPPORTED, "more than 2^32 - 2 records in one push: push fewer sections at a time");
   for (Section& s : secs) s.byte_off -= lo;
-  const int64_t n_bytes = hi - lo;
+  const int64_t n_raw = hi - lo;
+  // LZ4 sections (codec 3: the batch's records section is still one LZ4 frame): the host reads the frame header and the
+  // block size words, the device decodes the blocks.  Frames it cannot take block by block (blocks larger than 64 KiB,
+  // dependent blocks) are decompressed here, on the host, and travel as plain bytes behind the raw span.
+  std::vector<Lz4Block> blocks;
+  std::vector<uint8_t> extra;
+  int64_t area = 0;  // bytes of the device-side decompressed area handed out so far (multiples of 64 KiB)
+  try {
+    for (int64_t s = 0; s < n_sections; ++s) {
+      if (sections[s].codec != 3 || sections[s].n_records == 0) continue;
+      Section& sec = secs[(size_t)s];
+      const uint8_t* f = bytes + sections[s].byte_off;
+      const int64_t fl = sections[s].byte_len;
+      bool device_ok = fl >= 7 && f[0] == 0x04 && f[1] == 0x22 && f[2] == 0x4D && f[3] == 0x18 && (f[4] >> 6) == 1 && (f[4] & 0x20) &&
+                       ((f[5] >> 4) & 7) == 4;
+      int64_t p = 6;
+      if (device_ok) {
+        if (f[4] & 0x08) p += 8;  // content size
+        if (f[4] & 0x01) p += 4;  // dictionary id
+        device_ok = p < fl && f[p] == (uint8_t)(surge_xxh32(f + 4, p - 4, 0) >> 8);
+        ++p;
+      }
+      const size_t first_block = blocks.size();
+      int32_t k = 0;
+      while (device_ok) {
+        if (fl - p < 4) { device_ok = false; break; }
+        const uint32_t bs = (uint32_t)f[p] | ((uint32_t)f[p + 1] << 8) | ((uint32_t)f[p + 2] << 16) | ((uint32_t)f[p + 3] << 24);
+        p += 4;
+        if (bs == 0) break;  // EndMark
+        const uint32_t size = bs & 0x7fffffffu;
+        if ((int64_t)size > fl - p || size > (1u << 30)) { device_ok = false; break; }
+        Lz4Block b;
+        b.src_off = sec.byte_off + p;
+        b.dst_off = area + (int64_t)k * kLz4BlockMax;
+        b.src_len = (int32_t)size | (int32_t)(bs & 0x80000000u);
+        b.section = (int32_t)s;
+        b.last = 0;
+        b.index = k++;
+        blocks.push_back(b);
+        p += size;
+        if (f[4] & 0x10) p += 4;  // block checksum (not verified: the batch CRC already covers these bytes)
+      }
+      if (device_ok && k > 0) {
+        blocks.back().last = 1;
+        sec.byte_off = -1 - area;  // resolved below, once the raw span's final size is known
+        sec.byte_len = 0;          // set by the kernel that decodes the frame's last block
+        area += (int64_t)k * kLz4BlockMax;
+      } else {
+        blocks.resize(first_block);
+        int64_t cap = fl * 8 + 1024, got;
+        const size_t at = extra.size();
+        while (true) {
+          extra.resize(at + (size_t)cap);
+          got = surge_lz4_frame_decompress(f, fl, extra.data() + at, cap);
+          if (got != -6) break;
+          cap *= 4;
+          if (cap > (1ll << 31)) return dfail(d, SURGE_E_CORRUPT, "LZ4 batch expands beyond 2 GiB");
+        }
+        if (got < 0) return dfail(d, SURGE_E_CORRUPT, "bad LZ4 frame in the section at base offset " + std::to_string(sections[s].base_offset));
+        extra.resize(at + (size_t)got);
+        sec.byte_off = n_raw + (int64_t)at;
+        sec.byte_len = got;
+      }
+    }
+  } catch (const std::bad_alloc&) {
+    return dfail(d, E_NOMEM, "out of host memory");
+  }
+  const int64_t n_bytes = n_raw + (int64_t)extra.size();              // what is staged and copied
+  const int64_t area_base = (n_bytes + 15) & ~15ll;                    // where the device-decompressed frames start
+  for (Section& s : secs)
+    if (s.byte_off < 0) s.byte_off = area_base + (-1 - s.byte_off);
   int prev = 0;
   (void)hipGetDevice(&prev);
   struct Restore { int dev; ~Restore() { (void)hipSetDevice(dev); } } restore{prev};
   DCHK(d, hipSetDevice(d->device));
   hipStream_t st = d->stream;
   const size_t R = (size_t)n_rec;
-  DCHK(d, d->d_bytes.reserve((size_t)n_bytes + 16, false, st));
+  DCHK(d, d->d_bytes.reserve((size_t)(area_base + area) + 16, false, st));
   DCHK(d, d->d_sections.reserve(sizeof(Section) * (size_t)n_sections, false, st));
   DCHK(d, d->rec_pos.reserve(R * 8, false, st));
   DCHK(d, d->rec_end.reserve(R * 8, false, st));
@@ -838,19 +1013,28 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
     DCHK(d, hipHostMalloc(&d->pinned, (size_t)n_bytes, hipHostMallocDefault));
     d->pinned_cap = (size_t)n_bytes;
   }
-  std::memcpy(d->pinned, bytes + lo, (size_t)n_bytes);
+  std::memcpy(d->pinned, bytes + lo, (size_t)n_raw);
+  if (!extra.empty()) std::memcpy((uint8_t*)d->pinned + n_raw, extra.data(), extra.size());
   DCHK(d, hipMemcpyAsync(d->d_bytes.p, d->pinned, (size_t)n_bytes, hipMemcpyHostToDevice, st));
   DCHK(d, hipMemcpyAsync(d->d_sections.p, secs.data(), sizeof(Section) * (size_t)n_sections, hipMemcpyHostToDevice, st));
   const uint8_t* dby = (const uint8_t*)d->d_bytes.p;
-  const Section* dsec = (const Section*)d->d_sections.p;
+  Section* dsec = (Section*)d->d_sections.p;
   ErrorCell* derr = (ErrorCell*)d->d_err.p;
   RecMeta* dmeta = (RecMeta*)d->meta.p;
+  if (!blocks.empty()) {
+    DCHK(d, d->lz4_blocks.reserve(blocks.size() * sizeof(Lz4Block), false, st));
+    DCHK(d, hipMemcpyAsync(d->lz4_blocks.p, blocks.data(), blocks.size() * sizeof(Lz4Block), hipMemcpyHostToDevice, st));
+    const unsigned grid = (unsigned)(blocks.size() < 4096 ? blocks.size() : 4096);
+    hipLaunchKernelGGL(lz4_block_kernel, dim3(grid), dim3(64), kLz4BlockMax, st, dby, (uint8_t*)d->d_bytes.p + area_base, (const Lz4Block*)d->lz4_blocks.p,
+                       (int64_t)blocks.size(), dsec, derr);
+    DCHK(d, hipStreamSynchronize(st));  // `blocks` (host) may go out of scope; errors are read with the rest below
+  }
   const unsigned rb = (unsigned)((n_rec + 255) / 256);
-  hipLaunchKernelGGL(chain_kernel, dim3((unsigned)((n_sections + 63) / 64)), dim3(64), 0, st, dby, dsec, n_sections, (int64_t*)d->rec_pos.p,
+  hipLaunchKernelGGL(chain_kernel, dim3((unsigned)((n_sections + 63) / 64)), dim3(64), 0, st, dby, (const Section*)dsec, n_sections, (int64_t*)d->rec_pos.p,
                      (int64_t*)d->rec_end.p, derr);
-  hipLaunchKernelGGL(parse_kernel, dim3(rb), dim3(256), 0, st, dby, dsec, n_sections, (const int64_t*)d->rec_pos.p, (const int64_t*)d->rec_end.p,
+  hipLaunchKernelGGL(parse_kernel, dim3(rb), dim3(256), 0, st, dby, (const Section*)dsec, n_sections, (const int64_t*)d->rec_pos.p, (const int64_t*)d->rec_end.p,
                      n_rec, dmeta, derr);
-  return finish_push(d, n_rec, bytes + lo);
+  return finish_push(d, n_rec);
 }
 
 int32_t surge_device_decoder_push_records(surge_device_decoder* d, const uint8_t* keys, const int64_t* key_off, const uint8_t* values,
@@ -898,7 +1082,7 @@ int32_t surge_device_decoder_push_records(surge_device_decoder* d, const uint8_t
   if (offsets) DCHK(d, hipMemcpyAsync(d->d_sections.p, p_of, (size_t)n * 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(records_meta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)d->d_bytes.p, (const int64_t*)d->rec_pos.p,
                      (const int64_t*)d->rec_end.p, offsets ? (const int64_t*)d->d_sections.p : nullptr, kb, n, (RecMeta*)d->meta.p, (ErrorCell*)d->d_err.p);
-  return finish_push(d, n, pin);
+  return finish_push(d, n);
 }
 
 int32_t surge_device_decoder_result(surge_device_decoder* d, int64_t* n_records, const int64_t** d_agg_idx, const void** d_events16,

@@ -19,8 +19,9 @@ from .schema import EVENT_DTYPE
 
 READ_UNCOMMITTED, READ_COMMITTED = 0, 1
 FRAMES = 0x100  # SURGE_INGEST_FRAMES: frame on the host, decode the records on the GPU (DeviceDecoder)
+DEVICE_LZ4 = 0x200  # SURGE_INGEST_DEVICE_LZ4: ... and leave LZ4 frames for the GPU as well
 
-SECTION_DTYPE = np.dtype([("byte_off", "<i8"), ("byte_len", "<i8"), ("base_offset", "<i8"), ("n_records", "<i4"), ("reserved", "<i4")])
+SECTION_DTYPE = np.dtype([("byte_off", "<i8"), ("byte_len", "<i8"), ("base_offset", "<i8"), ("n_records", "<i4"), ("codec", "<i4")])
 assert SECTION_DTYPE.itemsize == 32
 
 RECORD_DTYPE = np.dtype([("offset", "<i8"), ("agg_idx", "<i8"), ("key_off", "<i8"), ("key_len", "<i4"),
@@ -82,11 +83,11 @@ class IngestError(RuntimeError):
 
 
 class EventsTopicIngest:
-    def __init__(self, isolation_level: int = READ_COMMITTED, frames: bool = False):
+    def __init__(self, isolation_level: int = READ_COMMITTED, frames: bool = False, device_lz4: bool = False):
         self._lib = _native.load()
         self._h = ctypes.c_void_p()
         self.frames = frames
-        rc = self._lib.surge_ingest_create(isolation_level | (FRAMES if frames else 0), ctypes.byref(self._h))
+        rc = self._lib.surge_ingest_create(isolation_level | (FRAMES if frames else 0) | (DEVICE_LZ4 if device_lz4 else 0), ctypes.byref(self._h))
         if rc != 0:
             raise IngestError(rc, (self._lib.surge_ingest_last_error(None) or b"").decode())
         self._tail = b""

@@ -80,7 +80,7 @@ class GpuReplayStateStore:
         from .schema import EVENT_DTYPE
 
         template = self.model.event_json_template()
-        with EventsTopicIngest(frames=True) as g:
+        with EventsTopicIngest(frames=True, device_lz4=True) as g:
             g.feed(record_batches)
             sections, arena = g.drain_sections()
             counters = g.counters()
@@ -275,8 +275,19 @@ def _sniff_value_kind(sections, arena_address: int):
             shift += 7
         return (v >> 1) ^ -(v & 1), pos
 
+    from . import _native
+
     for s in sections:
-        buf = ctypes.string_at(arena_address + int(s["byte_off"]), min(int(s["byte_len"]), 4096))
+        if int(s["codec"]) == 3:  # still an LZ4 frame (decoded on the GPU): look into it with the library's host decoder
+            frame = ctypes.string_at(arena_address + int(s["byte_off"]), int(s["byte_len"]))
+            cap = max(1 << 16, 64 * len(frame))
+            out = ctypes.create_string_buffer(cap)
+            got = _native.load().surge_lz4_frame_decompress(frame, len(frame), out, cap)
+            if got < 0:
+                return "json"  # too large to peek into, or damaged: the decoder will say which
+            buf = out.raw[: min(got, 4096)]
+        else:
+            buf = ctypes.string_at(arena_address + int(s["byte_off"]), min(int(s["byte_len"]), 4096))
         pos = 0
         try:
             for _ in range(int(s["n_records"])):
