@@ -852,8 +852,8 @@ def run_e2e(args):
                 lat.append((t2 - t0) * 1e3)
                 host_ms.append((t1 - t0) * 1e3)
                 dev_ms.append((t2 - t1) * 1e3)
-            all_agg.append(agg.cpu().numpy().copy())
-            all_ev.append(ev.cpu().numpy().view(S.EVENT_DTYPE).reshape(-1).copy())
+            all_agg.append(agg.clone())  # kept on the device for the parity check after the timed region
+            all_ev.append(ev.clone())
             d.clear()
         torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t_begin
@@ -861,7 +861,8 @@ def run_e2e(args):
         counters = d.counters()
     n_events = n_fetch * K
     # parity: the oracle folds the decoded events grouped by aggregate (stable: topic order inside an aggregate)
-    agg_all, ev_all = np.concatenate(all_agg), np.concatenate(all_ev)
+    agg_all = np.concatenate([a.cpu().numpy() for a in all_agg])
+    ev_all = np.concatenate([e.cpu().numpy().view(S.EVENT_DTYPE).reshape(-1) for e in all_ev])
     order = np.argsort(agg_all, kind="stable")
     off = np.zeros(n_agg + 1, np.int64)
     np.cumsum(np.bincount(agg_all, minlength=n_agg), out=off[1:])

@@ -140,7 +140,14 @@ typedef struct surge_batch_section {
  * Spans stay valid until the next feed / destroy.  SURGE_E_STATE on a decoder that was not created in FRAMES mode. */
 int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge_batch_section* out, int64_t* n_out);
 
+/* Where the arena's memory comes from (before the first feed; NULL / NULL = malloc / free).  surge_ingest_use_pinned_arena
+ * makes it page-locked host memory of the HIP runtime: a device decoder then copies the sections to the GPU straight out
+ * of the arena (no staging copy).  SURGE_E_DEVICE without a usable HIP runtime. */
+int32_t surge_ingest_set_allocator(surge_ingest* g, void* (*alloc)(size_t), void (*release)(void*));
+int32_t surge_ingest_use_pinned_arena(surge_ingest* g);
+
 typedef struct surge_device_decoder surge_device_decoder;
+/* (One decoder serves one consumer thread at a time: calls on the same decoder must not overlap.) */
 /* tmpl == NULL: record values are 16-byte surge_event16; otherwise the reference's JSON event text, decoded by the
  * template with surge_event_json_decode's rules (Doubles correctly rounded on the device — f64_parse.h — the rare value
  * its fast path cannot decide is re-parsed on the host).  hip_stream: the stream the decoder works on (NULL = default). */

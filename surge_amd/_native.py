@@ -88,6 +88,8 @@ INGEST_EXPORTS = (
     "surge_ingest_drain_fixed16",
     "surge_ingest_drain_json",
     "surge_ingest_drain_sections",
+    "surge_ingest_set_allocator",
+    "surge_ingest_use_pinned_arena",
     "surge_device_decoder_create",
     "surge_device_decoder_destroy",
     "surge_device_decoder_last_error",
@@ -264,6 +266,8 @@ def load() -> ctypes.CDLL:
         "surge_ingest_drain_fixed16": ([vp, i64, vp, vp, vp, ctypes.POINTER(i64)], i32),
         "surge_ingest_drain_json": ([vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)], i32),
         "surge_ingest_drain_sections": ([vp, i64, vp, ctypes.POINTER(i64)], i32),
+        "surge_ingest_set_allocator": ([vp, vp, vp], i32),
+        "surge_ingest_use_pinned_arena": ([vp], i32),
         "surge_device_decoder_create": ([i32, vp, vp, ctypes.POINTER(vp)], i32),
         "surge_device_decoder_destroy": ([vp], i32),
         "surge_device_decoder_last_error": ([vp], ctypes.c_char_p),

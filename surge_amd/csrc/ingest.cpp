@@ -2,6 +2,7 @@
 // Kafka RecordBatch v2 + LZ4 frame + read_committed, restated from the published formats (kafka-clients
 // 3.2.3 is not vendored under /root/reference: parity unpinned, see include/surge_ingest.h).
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <new>
@@ -192,12 +193,49 @@ int lz4_block(const uint8_t* ip, const uint8_t* iend, uint8_t* dst, int64_t* op_
 
 }  // namespace
 
+// The byte arena records / sections are copied into: a growable buffer whose memory comes from a pluggable allocator, so
+// that a device decoder can have it PAGE-LOCKED (surge_ingest_set_allocator: its H2D copy then reads the arena in place
+// instead of staging it through a pinned buffer of its own).
+struct Arena {
+  uint8_t* p = nullptr;
+  size_t n = 0, cap = 0;
+  void* (*alloc)(size_t) = nullptr;
+  void (*release)(void*) = nullptr;
+  Arena() = default;
+  Arena(const Arena&) = delete;
+  Arena& operator=(const Arena&) = delete;
+  ~Arena() { drop(); }
+  void drop() {
+    if (p) (release ? release : std::free)(p);
+    p = nullptr;
+    n = cap = 0;
+  }
+  size_t size() const { return n; }
+  const uint8_t* data() const { return p; }
+  uint8_t* data() { return p; }
+  void clear() { n = 0; }
+  void append(const uint8_t* src, size_t len) {
+    if (n + len > cap) {
+      size_t want = cap ? cap * 2 : (size_t)1 << 16;
+      while (want < n + len) want *= 2;
+      uint8_t* fresh = (uint8_t*)(alloc ? alloc(want) : std::malloc(want));
+      if (!fresh) throw std::bad_alloc();
+      if (n) std::memcpy(fresh, p, n);
+      if (p) (release ? release : std::free)(p);
+      p = fresh;
+      cap = want;
+    }
+    if (len) std::memcpy(p + n, src, len);
+    n += len;
+  }
+};
+
 struct surge_ingest {
   int isolation = SURGE_INGEST_READ_COMMITTED;
   bool frames = false;  // SURGE_INGEST_FRAMES: records are not parsed here, their sections go to a surge_device_decoder
   bool device_lz4 = false;  // SURGE_INGEST_DEVICE_LZ4: ... and LZ4 frames stay compressed (the device decoder undoes them)
   std::string err;
-  std::vector<uint8_t> arena;
+  Arena arena;
   std::deque<Batch> queue;
   std::vector<std::string> keys;   // aggregate ids in first-seen order
   std::vector<uint64_t> key_hash;  // their hashes
@@ -325,9 +363,9 @@ int32_t parse_records(surge_ingest* g, Batch& b, const uint8_t* data, int64_t le
     rec.key_len = (int32_t)klen;
     rec.value_len = (int32_t)vlen;
     rec.key_off = (int64_t)g->arena.size();
-    if (klen > 0) g->arena.insert(g->arena.end(), key, key + klen);
+    if (klen > 0) g->arena.append(key, (size_t)klen);
     rec.value_off = (int64_t)g->arena.size();
-    if (vlen > 0) g->arena.insert(g->arena.end(), val, val + vlen);
+    if (vlen > 0) g->arena.append(val, (size_t)vlen);
     rec.agg_idx = klen >= 0 ? -2 : -1;  // -2: interned when the record is DELIVERED (drain): the keys of aborted or
                                         // still-open transactions never enter the key table
     b.recs.push_back(rec);
@@ -506,7 +544,7 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
         b.base_offset = base_offset;
         b.count = count;
         b.sect_codec = sect_codec;
-        g->arena.insert(g->arena.end(), recs, recs + recs_len);
+        g->arena.append(recs, (size_t)recs_len);
         g->counters[1] += count;
       } else {
         const int32_t rc = parse_records(g, b, recs, recs_len, count, base_offset, control, &control_type);
@@ -566,6 +604,14 @@ int32_t surge_ingest_drain(surge_ingest* g, int64_t max, surge_ingest_record* ou
 }
 
 const uint8_t* surge_ingest_arena(const surge_ingest* g) { return g ? g->arena.data() : nullptr; }
+
+int32_t surge_ingest_set_allocator(surge_ingest* g, void* (*alloc)(size_t), void (*release)(void*)) {
+  if (!g || !alloc != !release) return fail(g, E_INVALID, "bad argument");
+  if (g->arena.cap) return fail(g, -2, "surge_ingest_set_allocator after the first feed");
+  g->arena.alloc = alloc;
+  g->arena.release = release;
+  return OK;
+}
 
 int32_t surge_ingest_drain_fixed16(surge_ingest* g, int64_t max, int64_t* agg_idx_out, void* events16_out,
                                    int64_t* offsets_out, int64_t* n_out) {

@@ -704,6 +704,18 @@ int32_t ensure_table(surge_device_decoder* d, int64_t extra) {
 
 extern "C" {
 
+static void* pinned_alloc(size_t n) {
+  void* p = nullptr;
+  return hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+static void pinned_release(void* p) { (void)hipHostFree(p); }
+
+int32_t surge_ingest_use_pinned_arena(surge_ingest* g) {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return dfail(nullptr, E_DEVICE, "no usable HIP device: the arena stays in pageable memory");
+  return surge_ingest_set_allocator(g, pinned_alloc, pinned_release);
+}
+
 const char* surge_device_decoder_last_error(const surge_device_decoder* d) { return d ? d->err.c_str() : g_dec_err.c_str(); }
 
 int32_t surge_device_decoder_create(int32_t device_id, void* hip_stream, const surge_event_json_template* tmpl, surge_device_decoder** out) {
@@ -792,8 +804,6 @@ int32_t finish_push(surge_device_decoder* d, int64_t n_rec) {
   ErrorCell ec;
   DCHK(d, hipMemcpyAsync(&ec, derr, sizeof(ec), hipMemcpyDeviceToHost, st));
   DCHK(d, hipStreamSynchronize(st));
-  if (ec.lz4_bad != ~0u)
-    return dfail(d, SURGE_E_CORRUPT, "bad LZ4 frame in section " + std::to_string(ec.lz4_bad) + " of the push (malformed sequence, or a block that is not 64 KiB where it must be)");
   const uint32_t n_new = ec.n_new;
   if (n_new > 0) {
     // new keys in first-delivered order
@@ -1005,17 +1015,30 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
     const int32_t rc = begin_push(d, n_rec);
     if (rc != OK) return rc;
   }
-  // H2D through pinned staging (the caller's arena is pageable); one copy per push
-  if ((size_t)n_bytes > d->pinned_cap) {
+  // H2D: straight out of the caller's arena when that is page-locked (surge_ingest_use_pinned_arena), else through the
+  // decoder's own pinned staging (one extra host copy per push)
+  hipPointerAttribute_t attr;
+  const bool in_place = hipPointerGetAttributes(&attr, bytes + lo) == hipSuccess && attr.type == hipMemoryTypeHost;
+  (void)hipGetLastError();  // a pageable pointer makes hipPointerGetAttributes fail: not an error of this call
+  const size_t staged = in_place ? extra.size() : (size_t)n_bytes;
+  if (staged > d->pinned_cap) {
     if (d->pinned) (void)hipHostFree(d->pinned);
     d->pinned = nullptr;
     d->pinned_cap = 0;
-    DCHK(d, hipHostMalloc(&d->pinned, (size_t)n_bytes, hipHostMallocDefault));
-    d->pinned_cap = (size_t)n_bytes;
+    DCHK(d, hipHostMalloc(&d->pinned, staged, hipHostMallocDefault));
+    d->pinned_cap = staged;
   }
-  std::memcpy(d->pinned, bytes + lo, (size_t)n_raw);
-  if (!extra.empty()) std::memcpy((uint8_t*)d->pinned + n_raw, extra.data(), extra.size());
-  DCHK(d, hipMemcpyAsync(d->d_bytes.p, d->pinned, (size_t)n_bytes, hipMemcpyHostToDevice, st));
+  if (in_place) {
+    DCHK(d, hipMemcpyAsync(d->d_bytes.p, bytes + lo, (size_t)n_raw, hipMemcpyHostToDevice, st));
+    if (!extra.empty()) {
+      std::memcpy(d->pinned, extra.data(), extra.size());
+      DCHK(d, hipMemcpyAsync((uint8_t*)d->d_bytes.p + n_raw, d->pinned, extra.size(), hipMemcpyHostToDevice, st));
+    }
+  } else {
+    std::memcpy(d->pinned, bytes + lo, (size_t)n_raw);
+    if (!extra.empty()) std::memcpy((uint8_t*)d->pinned + n_raw, extra.data(), extra.size());
+    DCHK(d, hipMemcpyAsync(d->d_bytes.p, d->pinned, (size_t)n_bytes, hipMemcpyHostToDevice, st));
+  }
   DCHK(d, hipMemcpyAsync(d->d_sections.p, secs.data(), sizeof(Section) * (size_t)n_sections, hipMemcpyHostToDevice, st));
   const uint8_t* dby = (const uint8_t*)d->d_bytes.p;
   Section* dsec = (Section*)d->d_sections.p;
@@ -1027,7 +1050,14 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
     const unsigned grid = (unsigned)(blocks.size() < 4096 ? blocks.size() : 4096);
     hipLaunchKernelGGL(lz4_block_kernel, dim3(grid), dim3(64), kLz4BlockMax, st, dby, (uint8_t*)d->d_bytes.p + area_base, (const Lz4Block*)d->lz4_blocks.p,
                        (int64_t)blocks.size(), dsec, derr);
-    DCHK(d, hipStreamSynchronize(st));  // `blocks` (host) may go out of scope; errors are read with the rest below
+    // a frame that does not decode fails the push HERE, before any key of the push is interned (`blocks` is host memory:
+    // the copy has to be done before it goes out of scope anyway)
+    ErrorCell lz;
+    DCHK(d, hipMemcpyAsync(&lz, derr, sizeof(lz), hipMemcpyDeviceToHost, st));
+    DCHK(d, hipStreamSynchronize(st));
+    if (lz.lz4_bad != ~0u)
+      return dfail(d, SURGE_E_CORRUPT, "bad LZ4 frame in the batch at base offset " + std::to_string(sections[lz.lz4_bad].base_offset) +
+                                       " (malformed sequence, or a block that is not 64 KiB where it must be)");
   }
   const unsigned rb = (unsigned)((n_rec + 255) / 256);
   hipLaunchKernelGGL(chain_kernel, dim3((unsigned)((n_sections + 63) / 64)), dim3(64), 0, st, dby, (const Section*)dsec, n_sections, (int64_t*)d->rec_pos.p,

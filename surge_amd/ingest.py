@@ -90,6 +90,9 @@ class EventsTopicIngest:
         rc = self._lib.surge_ingest_create(isolation_level | (FRAMES if frames else 0) | (DEVICE_LZ4 if device_lz4 else 0), ctypes.byref(self._h))
         if rc != 0:
             raise IngestError(rc, (self._lib.surge_ingest_last_error(None) or b"").decode())
+        if frames or device_lz4:
+            # page-locked arena when a GPU is there: the device decoder copies out of it in place (a pageable arena works too)
+            self._lib.surge_ingest_use_pinned_arena(self._h)
         self._tail = b""
 
     def close(self):
