@@ -131,25 +131,57 @@ __global__ void __launch_bounds__(64) lz4_block_kernel(const uint8_t* __restrict
         op = n_in;
       }
     } else {
-      int32_t ip = 0;
+      // The compressed stream is read through a 256-byte WINDOW held in registers (lane l: bytes [4l, 4l + 4) from
+      // `wbase`): control bytes come out of it with v_readlane, short literal runs with one shuffle — no global load on the
+      // path from one sequence to the next, only a refill every ~250 consumed bytes.  (First version: token, length
+      // bytes and offset were three dependent global loads per sequence, 2-3 us each way: 1.6 ms per 57 KB block.)
+      int32_t ip = 0, wbase = 0;
+      uint32_t win = 0;
+      auto refill = [&](int32_t at) {
+        wbase = at;
+        const int32_t pos = at + 4 * lane;
+        uint32_t v = 0;
+        if (pos + 4 <= n_in) {
+          v = (uint32_t)in[pos] | ((uint32_t)in[pos + 1] << 8) | ((uint32_t)in[pos + 2] << 16) | ((uint32_t)in[pos + 3] << 24);
+        } else {
+          for (int k = 0; k < 4; ++k)
+            if (pos + k < n_in) v |= (uint32_t)in[pos + k] << (8 * k);
+        }
+        win = v;
+      };
+      auto byte_at = [&](int32_t at) -> uint32_t {  // `at` is wave-uniform
+        if (at - wbase >= 256 || at < wbase) refill(at);
+        const int32_t idx = at - wbase;
+        const uint32_t word = __builtin_amdgcn_readlane(win, __builtin_amdgcn_readfirstlane(idx >> 2));
+        return (word >> ((idx & 3) * 8)) & 0xffu;
+      };
+      refill(0);
       while (ip < n_in) {
-        const uint32_t token = __builtin_amdgcn_readfirstlane((uint32_t)in[ip++]);
+        const uint32_t token = byte_at(ip++);
         int32_t lit = (int32_t)(token >> 4);
         if (lit == 15) {
           uint32_t x;
           do {
             if (ip >= n_in) { ok = false; break; }
-            x = __builtin_amdgcn_readfirstlane((uint32_t)in[ip++]);
+            x = byte_at(ip++);
             lit += (int32_t)x;
           } while (x == 255u && lit < (1 << 24));
         }
         if (!ok || lit > n_in - ip || lit > kLz4BlockMax - op) { ok = false; break; }
-        for (int i = lane; i < lit; i += 64) lz4_out[op + i] = in[ip + i];
+        if (lit > 0) {
+          if (lit <= 64 && ip >= wbase && ip + lit - wbase <= 256) {  // the whole run is in the window
+            const int32_t idx = ip - wbase + lane;
+            const uint32_t word = (uint32_t)__shfl((int)win, (idx >> 2) & 63, 64);
+            if (lane < lit) lz4_out[op + lane] = (uint8_t)(word >> ((idx & 3) * 8));
+          } else {
+            for (int i = lane; i < lit; i += 64) lz4_out[op + i] = in[ip + i];
+          }
+        }
         ip += lit;
         op += lit;
         if (ip >= n_in) break;  // the last sequence carries literals only
         if (n_in - ip < 2) { ok = false; break; }
-        const int32_t offset = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)in[ip] | ((uint32_t)in[ip + 1] << 8));
+        const int32_t offset = (int32_t)(byte_at(ip) | (byte_at(ip + 1) << 8));
         ip += 2;
         if (offset == 0 || offset > op) { ok = false; break; }
         int32_t ml = (int32_t)(token & 15u);
@@ -157,14 +189,13 @@ __global__ void __launch_bounds__(64) lz4_block_kernel(const uint8_t* __restrict
           uint32_t x;
           do {
             if (ip >= n_in) { ok = false; break; }
-            x = __builtin_amdgcn_readfirstlane((uint32_t)in[ip++]);
+            x = byte_at(ip++);
             ml += (int32_t)x;
           } while (x == 255u && ml < (1 << 24));
         }
         ml += 4;
         if (!ok || ml > kLz4BlockMax - op) { ok = false; break; }
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the literals (and earlier matches) are in LDS before they are read back
-        __builtin_amdgcn_wave_barrier();
+        // (LDS operations of one wave execute in order: a read sees every earlier write of any lane of this wave)
         const uint8_t* src = lz4_out + op - offset;
         if (offset >= ml) {
           for (int i = lane; i < ml; i += 64) lz4_out[op + i] = src[i];
@@ -172,8 +203,6 @@ __global__ void __launch_bounds__(64) lz4_block_kernel(const uint8_t* __restrict
           for (int i = lane; i < ml; i += 64) lz4_out[op + i] = src[i % offset];
         }
         op += ml;
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
       }
     }
     // every block of a frame but its last is exactly full (that is how block k's place is known before it is decoded)
