@@ -48,6 +48,13 @@ const char* surge_snapshot_writer_last_error(const surge_snapshot_writer* w);
 int32_t surge_snapshot_writer_append(surge_snapshot_writer* w, int64_t n, const uint8_t* kind, const int32_t* partition,
                                      const uint8_t* keys_utf8, const int64_t* key_off, const uint8_t* values,
                                      const int64_t* val_off, int64_t timestamp_ms);
+/* The same for a COMPACT list of records: record r belongs to aggregate agg_idx[r] (< n_aggregates); kind[r] and
+ * val_off[r .. r+1] are per record, partition[] and key_off[] stay the per-aggregate tables.  What a publisher uses when
+ * few of many aggregates changed: nothing of size n_aggregates is scanned or copied (BulkSnapshotPublisher compacts
+ * the delta on the device). */
+int32_t surge_snapshot_writer_append_indexed(surge_snapshot_writer* w, int64_t n, const int64_t* agg_idx, int64_t n_aggregates, const uint8_t* kind,
+                                             const int32_t* partition, const uint8_t* keys_utf8, const int64_t* key_off, const uint8_t* values,
+                                             const int64_t* val_off, int64_t timestamp_ms);
 
 /* Closes the open batch of every partition (call before reading the bytes). */
 int32_t surge_snapshot_writer_flush(surge_snapshot_writer* w);

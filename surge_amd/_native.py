@@ -123,6 +123,7 @@ SNAPSHOT_EXPORTS = (
     "surge_snapshot_writer_set_compression",
     "surge_snapshot_writer_last_error",
     "surge_snapshot_writer_append",
+    "surge_snapshot_writer_append_indexed",
     "surge_snapshot_writer_flush",
     "surge_snapshot_writer_partition",
     "surge_snapshot_writer_reset",
@@ -298,6 +299,7 @@ def load() -> ctypes.CDLL:
         "surge_snapshot_writer_destroy": ([vp], i32),
         "surge_snapshot_writer_last_error": ([vp], ctypes.c_char_p),
         "surge_snapshot_writer_append": ([vp, i64, vp, vp, vp, vp, vp, vp, i64], i32),
+        "surge_snapshot_writer_append_indexed": ([vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64], i32),
         "surge_snapshot_writer_flush": ([vp], i32),
         "surge_snapshot_writer_partition": ([vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
         "surge_snapshot_writer_reset": ([vp], i32),

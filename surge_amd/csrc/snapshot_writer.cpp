@@ -139,13 +139,16 @@ int32_t surge_snapshot_writer_destroy(surge_snapshot_writer* w) {
 
 const char* surge_snapshot_writer_last_error(const surge_snapshot_writer* w) { return w ? w->err.c_str() : g_err.c_str(); }
 
-int32_t surge_snapshot_writer_append(surge_snapshot_writer* w, int64_t n, const uint8_t* kind, const int32_t* partition,
-                                     const uint8_t* keys_utf8, const int64_t* key_off, const uint8_t* values,
-                                     const int64_t* val_off, int64_t timestamp_ms) {
+// record r of the call: aggregate a = idx ? idx[r] : r; kind[r] and val_off[r] are per RECORD, partition[a] and key_off[a]
+// per AGGREGATE (for idx == NULL the two numberings coincide)
+static int32_t append_core(surge_snapshot_writer* w, int64_t n, const int64_t* idx, int64_t n_agg, const uint8_t* kind, const int32_t* partition,
+                           const uint8_t* keys_utf8, const int64_t* key_off, const uint8_t* values, const int64_t* val_off,
+                           int64_t timestamp_ms) {
   if (!w) return fail(nullptr, E_INVALID, "writer is NULL");
   if (n < 0) return fail(w, E_INVALID, "negative size");
   if (n == 0) return OK;
   if (!partition || !key_off) return fail(w, E_INVALID, "NULL buffer");
+  auto agg = [&](int64_t r) { return idx ? idx[r] : r; };
   const int32_t P = (int32_t)w->parts.size();
   try {
     // pass 1 (validation + a counting sort of the published indices by partition): partitions are independent logs,
@@ -155,9 +158,11 @@ int32_t surge_snapshot_writer_append(surge_snapshot_writer* w, int64_t n, const 
       const uint8_t k = kind ? kind[i] : (uint8_t)SURGE_SNAP_VALUE;
       if (k == SURGE_SNAP_SKIP) continue;
       if (k != SURGE_SNAP_VALUE && k != SURGE_SNAP_TOMBSTONE) return fail(w, E_INVALID, "unknown record kind");
-      const int32_t pi = partition[i];
+      const int64_t a = agg(i);
+      if (idx && (a < 0 || a >= n_agg)) return fail(w, E_RANGE, "aggregate index out of range");
+      const int32_t pi = partition[a];
       if (pi < 0 || pi >= P) return fail(w, E_RANGE, "partition out of range");
-      const int64_t klen = key_off[i + 1] - key_off[i];
+      const int64_t klen = key_off[a + 1] - key_off[a];
       if (klen < 0 || (klen > 0 && !keys_utf8)) return fail(w, E_INVALID, "bad key span");
       if (k == SURGE_SNAP_VALUE) {
         if (!val_off) return fail(w, E_INVALID, "values expected");
@@ -173,14 +178,15 @@ int32_t surge_snapshot_writer_append(surge_snapshot_writer* w, int64_t n, const 
     {
       std::vector<int64_t> cur(start.begin(), start.end() - 1);
       for (int64_t i = 0; i < n; ++i)
-        if (!kind || kind[i] != SURGE_SNAP_SKIP) order[(size_t)cur[(size_t)partition[i]]++] = i;
+        if (!kind || kind[i] != SURGE_SNAP_SKIP) order[(size_t)cur[(size_t)partition[agg(i)]]++] = i;
     }
     auto encode_partition = [&](int32_t pi) {
       PartitionLog& p = w->parts[(size_t)pi];
       for (int64_t r = start[(size_t)pi]; r < start[(size_t)pi + 1]; ++r) {
         const int64_t i = order[(size_t)r];
         const uint8_t k = kind ? kind[i] : (uint8_t)SURGE_SNAP_VALUE;
-        const int64_t klen = key_off[i + 1] - key_off[i];
+        const int64_t a = agg(i);
+        const int64_t klen = key_off[a + 1] - key_off[a];
         const int64_t vlen = k == SURGE_SNAP_VALUE ? val_off[i + 1] - val_off[i] : -1;
         if (p.open_records == 0) {
           p.base_offset = p.next_offset;
@@ -197,7 +203,7 @@ int32_t surge_snapshot_writer_append(surge_snapshot_writer* w, int64_t n, const 
         put_varlong(o, ts_delta);
         put_varlong(o, off_delta);
         put_varlong(o, klen);
-        if (klen > 0) o.insert(o.end(), keys_utf8 + key_off[i], keys_utf8 + key_off[i + 1]);
+        if (klen > 0) o.insert(o.end(), keys_utf8 + key_off[a], keys_utf8 + key_off[a + 1]);
         put_varlong(o, vlen);
         if (vlen > 0) o.insert(o.end(), values + val_off[i], values + val_off[i + 1]);
         put_varlong(o, 0);
@@ -247,6 +253,19 @@ int32_t surge_snapshot_writer_append(surge_snapshot_writer* w, int64_t n, const 
     return fail(w, E_NOMEM, "could not start an encoder thread");
   }
   return OK;
+}
+
+int32_t surge_snapshot_writer_append(surge_snapshot_writer* w, int64_t n, const uint8_t* kind, const int32_t* partition,
+                                     const uint8_t* keys_utf8, const int64_t* key_off, const uint8_t* values,
+                                     const int64_t* val_off, int64_t timestamp_ms) {
+  return append_core(w, n, nullptr, n, kind, partition, keys_utf8, key_off, values, val_off, timestamp_ms);
+}
+
+int32_t surge_snapshot_writer_append_indexed(surge_snapshot_writer* w, int64_t n, const int64_t* agg_idx, int64_t n_aggregates, const uint8_t* kind,
+                                             const int32_t* partition, const uint8_t* keys_utf8, const int64_t* key_off, const uint8_t* values,
+                                             const int64_t* val_off, int64_t timestamp_ms) {
+  if (n > 0 && !agg_idx) return fail(w, E_INVALID, "agg_idx is NULL");
+  return append_core(w, n, agg_idx, n_aggregates, kind, partition, keys_utf8, key_off, values, val_off, timestamp_ms);
 }
 
 int32_t surge_snapshot_writer_flush(surge_snapshot_writer* w) {

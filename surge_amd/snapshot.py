@@ -116,6 +116,16 @@ class RecordBatchWriter:
             self._h, n, ptr(kind), ptr(partition), ptr(keys_utf8), ptr(key_off), ptr(values), ptr(val_off),
             int(time.time() * 1000) if timestamp_ms is None else int(timestamp_ms)))
 
+    def append_indexed(self, agg_idx, kind, partition, keys_utf8, key_off, values, val_off, timestamp_ms: Optional[int] = None) -> None:
+        """Compact form: record r is aggregate ``agg_idx[r]``; ``kind`` / ``val_off`` per record, ``partition`` / ``key_off`` per aggregate."""
+        p = lambda a, dt: None if a is None else np.ascontiguousarray(a, dtype=dt)  # noqa: E731
+        agg_idx, kind, partition = p(agg_idx, np.int64), p(kind, np.uint8), p(partition, np.int32)
+        keys_utf8, key_off, values, val_off = p(keys_utf8, np.uint8), p(key_off, np.int64), p(values, np.uint8), p(val_off, np.int64)
+        ptr = lambda a: None if a is None or a.size == 0 else a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        self._check(self._lib.surge_snapshot_writer_append_indexed(
+            self._h, agg_idx.shape[0], ptr(agg_idx), partition.shape[0], ptr(kind), ptr(partition), ptr(keys_utf8), ptr(key_off), ptr(values), ptr(val_off),
+            int(time.time() * 1000) if timestamp_ms is None else int(timestamp_ms)))
+
     def partition_bytes(self, partition: int) -> Tuple[bytes, int, int]:
         """``(record batches, records, next offset)`` of one partition's log (flushes the open batches)."""
         self._check(self._lib.surge_snapshot_writer_flush(self._h))
@@ -200,10 +210,15 @@ class BulkSnapshotPublisher:
             eng._check(lib.surge_replay_set_encode_filter(eng._h, None))
         torch.cuda.synchronize(self.device)
         t1 = time.perf_counter()
-        kind, text, off = d_kind.cpu().numpy(), d_out.cpu().numpy(), d_off.cpu().numpy()
+        # compact on the device: only what changed crosses PCIe and is walked by the writer (the encoder wrote text for
+        # VALUE aggregates only, so the text is already contiguous and the selected offsets are its record boundaries)
+        sel = torch.nonzero(d_kind).squeeze(1)
+        kind = d_kind[sel].cpu().numpy()
+        off = torch.cat((d_off[sel], d_off[n:n + 1])).cpu().numpy()
+        text, sel_h = d_out.cpu().numpy(), sel.cpu().numpy()
         t2 = time.perf_counter()
         self.writer.reset()
-        self.writer.append(kind, self.partitions[:n], self.h_keys, self.h_key_off[: n + 1], text, off, timestamp_ms)
+        self.writer.append_indexed(sel_h, kind, self.partitions[:n], self.h_keys, self.h_key_off[: n + 1], text, off, timestamp_ms)
         out = {}
         for p in range(self.n_partitions):
             data, nrec, _ = self.writer.partition_bytes(p)
