@@ -588,6 +588,10 @@ def run_c5(args):
     for i in range(K):
         submit(W + i)
         if every > 0 and (i + 1) % every == 0:
+            # Synchronous on purpose: the batches here come back to back (30 of them take 10 ms, not the 3 s they stand for),
+            # so there is nothing to hide a background framing behind — publish_async (framing on a worker thread while the
+            # store keeps folding) measured 68 ms per cycle here against 48 ms, the worker competing with this loop for the
+            # box's 16 cores.  In a real 3 s interval it is the other way round.
             ts = time.perf_counter()
             out = pub.publish()
             snap_ms.append((time.perf_counter() - ts) * 1e3)

@@ -469,6 +469,11 @@ int32_t surge_replay_set_encode_filter(surge_replay_handle* h, const uint8_t* d_
  * of the aggregates d_kind reports (the array that delta call filled) the new baseline.  No fold / append may run on the
  * handle between the two calls. */
 int32_t surge_replay_snapshot_commit(surge_replay_handle* h, const uint8_t* d_kind);
+/* The other way round, for a publisher that frames and produces in the background while the store keeps folding: it
+ * commits with the delta (commit = 1: the baseline is exactly what was encoded) and, should the records not make it out,
+ * calls this with the same d_kind — the reported aggregates then differ from their baseline again and the next delta
+ * re-emits them (at-least-once, like a producer retry). */
+int32_t surge_replay_snapshot_invalidate(surge_replay_handle* h, const uint8_t* d_kind);
 
 /* ---- shard map (R15) --------------------------------------------------------------
  * surge_replay_partition_hash:  part_out[i] = abs(MurmurHash3.stringHash(str_i) % n_partitions)

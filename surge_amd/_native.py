@@ -46,6 +46,7 @@ EXPORTS = (
     "surge_replay_device_state",
     "surge_replay_snapshot_delta",
     "surge_replay_snapshot_commit",
+    "surge_replay_snapshot_invalidate",
     "surge_replay_set_encode_filter",
     "surge_replay_set_encode_strings",
     "surge_format_f64_json",
@@ -227,6 +228,7 @@ def load() -> ctypes.CDLL:
         "surge_replay_snapshot_delta": ([vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64), i32], i32),
         "surge_replay_set_encode_filter": ([vp, vp], i32),
         "surge_replay_snapshot_commit": ([vp, vp], i32),
+        "surge_replay_snapshot_invalidate": ([vp, vp], i32),
         "surge_replay_set_encode_strings": ([vp, i32, vp, vp], i32),
         "surge_format_f64_json": ([ctypes.c_uint64, vp, i32], i32),
         "surge_format_f64_json_many": ([vp, i64, vp, i64, vp], i64),

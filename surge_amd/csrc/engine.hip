@@ -1524,6 +1524,16 @@ int32_t surge_replay_snapshot_commit(surge_replay_handle* h, const uint8_t* d_ki
   return SURGE_OK;
 }
 
+int32_t surge_replay_snapshot_invalidate(surge_replay_handle* h, const uint8_t* d_kind) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->bound || h->published_n < h->n_agg) return fail(h, SURGE_E_STATE, "snapshot_invalidate without a preceding snapshot_delta");
+  if (!d_kind && h->n_agg > 0) return fail(h, SURGE_E_INVALID, "d_kind is NULL");
+  DeviceGuard g(h->device);
+  HIPCHK(h, launch_snapshot_invalidate((uint4*)h->published.ptr, h->n_agg, d_kind, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SURGE_OK;
+}
+
 int32_t surge_replay_set_encode_filter(surge_replay_handle* h, const uint8_t* d_kind) {
   if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
   h->encode_filter = d_kind;

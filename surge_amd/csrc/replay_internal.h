@@ -83,6 +83,7 @@ hipError_t launch_json_encode(const surge_json_template& tmpl, const uint4* stat
                               const int64_t* key_off, int64_t* d_len_off, int64_t* d_totals, uint8_t* out, bool write_pass,
                               uint32_t envelope, const uint8_t* filter, const JsonSide& side, hipStream_t stream);
 // kind[a] in SURGE_SNAP_*; d_counts: two u64 {values, tombstones}; commit: published := states where kind != SKIP
+hipError_t launch_snapshot_invalidate(uint4* published, int64_t n, const uint8_t* kind, hipStream_t stream);
 hipError_t launch_snapshot_commit(const uint4* states, uint4* published, int64_t n, const uint8_t* kind, hipStream_t stream);
 hipError_t launch_snapshot_delta(const uint4* states, uint4* published, int64_t n, uint8_t* kind, unsigned long long* d_counts,
                                  bool commit, bool full64, hipStream_t stream);

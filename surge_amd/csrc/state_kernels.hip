@@ -395,6 +395,14 @@ __global__ void snapshot_commit_kernel(const uint4* __restrict__ states, uint4* 
   if (kind[i >> 2] != SURGE_SNAP_SKIP) published[i] = states[i];
 }
 
+// a publish that failed AFTER its baseline was committed: make the reported aggregates differ from anything a fold can
+// produce (flags word all ones), so the next delta reports them again
+__global__ void snapshot_invalidate_kernel(uint4* __restrict__ published, int64_t n, const uint8_t* __restrict__ kind) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16 B quarter of a state per thread
+  if (i >= n * 4) return;
+  if (kind[i >> 2] != SURGE_SNAP_SKIP) published[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+}
+
 __global__ void count_poisoned_kernel(const uint4* __restrict__ states, int64_t n, unsigned long long* count) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool p = s < n && (states[s * 4 + 2].y & FL_POISONED);
@@ -486,6 +494,12 @@ hipError_t launch_snapshot_delta(const uint4* states, uint4* published, int64_t 
     hipLaunchKernelGGL(snapshot_delta_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, states, published, n, kind, d_counts);
   if (commit)
     hipLaunchKernelGGL(snapshot_commit_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, stream, states, published, n, kind);
+  return hipGetLastError();
+}
+
+hipError_t launch_snapshot_invalidate(uint4* published, int64_t n, const uint8_t* kind, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(snapshot_invalidate_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, stream, published, n, kind);
   return hipGetLastError();
 }
 

@@ -232,6 +232,65 @@ class BulkSnapshotPublisher:
                         "values": nv.value, "tombstones": nt.value, "text_bytes": int(text.nbytes)}
         return out
 
+    def publish_async(self, timestamp_ms: Optional[int] = None) -> "PendingPublish":
+        """The same publish with the host framing in the BACKGROUND, so that the store keeps folding micro-batches meanwhile:
+        the GPU part (delta, encode, compaction, device -> host copy) runs now and commits the baseline — it is exactly what
+        was encoded —; the record batches are framed on a worker thread.  ``result()`` of the returned handle gives them;
+        should the framing fail, the baseline of the reported aggregates is invalidated (``surge_replay_snapshot_invalidate``)
+        and the next publish emits them again.  One publish may be pending at a time (a second call waits for the first)."""
+        import threading
+
+        import torch
+
+        from .encode import encode_states
+
+        prev = getattr(self, "_pending_publish", None)
+        if prev is not None:
+            prev.wait()
+        eng = self.engine
+        n = eng.n_agg
+        if n > len(self.partitions):
+            raise ValueError("the resident state has aggregates the publisher has no key for: rebuild it with the current key table")
+        lib = _native.load()
+        t0 = time.perf_counter()
+        d_kind = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        nv, nt = ctypes.c_int64(), ctypes.c_int64()
+        eng._check(lib.surge_replay_snapshot_delta(eng._h, ctypes.c_void_p(d_kind.data_ptr()), ctypes.byref(nv), ctypes.byref(nt), 1))
+        eng._check(lib.surge_replay_set_encode_filter(eng._h, ctypes.c_void_p(d_kind.data_ptr())))
+        try:
+            d_out, d_off = encode_states(eng, self.template, self.d_keys, self.d_key_off, capacity_hint=max(64, 96 * nv.value + int(self.d_keys.numel())))
+        except Exception:
+            eng._check(lib.surge_replay_set_encode_filter(eng._h, None))
+            eng._check(lib.surge_replay_snapshot_invalidate(eng._h, ctypes.c_void_p(d_kind.data_ptr())))
+            raise
+        eng._check(lib.surge_replay_set_encode_filter(eng._h, None))
+        sel = torch.nonzero(d_kind).squeeze(1)
+        kind = d_kind[sel].cpu().numpy()
+        off = torch.cat((d_off[sel], d_off[n:n + 1])).cpu().numpy()
+        text, sel_h = d_out.cpu().numpy(), sel.cpu().numpy()
+        pending = PendingPublish(self, d_kind, {"gpu_and_copy_ms": (time.perf_counter() - t0) * 1e3, "values": nv.value, "tombstones": nt.value,
+                                                "text_bytes": int(text.nbytes)})
+
+        def frame():
+            try:
+                t1 = time.perf_counter()
+                self.writer.reset()
+                self.writer.append_indexed(sel_h, kind, self.partitions[:n], self.h_keys, self.h_key_off[: n + 1], text, off, timestamp_ms)
+                out = {}
+                for p in range(self.n_partitions):
+                    data, nrec, _ = self.writer.partition_bytes(p)
+                    if nrec:
+                        out[p] = data
+                pending.timings["record_batches_ms"] = (time.perf_counter() - t1) * 1e3
+                pending._out = out
+            except BaseException as exc:  # noqa: BLE001  (handed to result())
+                pending._exc = exc
+
+        pending._thread = threading.Thread(target=frame, name="surge-snapshot-framing", daemon=True)
+        pending._thread.start()
+        self._pending_publish = pending
+        return pending
+
     def commit_published(self) -> None:
         """Make what the last ``publish`` reported the new baseline (``surge_replay_snapshot_commit``)."""
         if getattr(self, "_pending_kind", None) is None:
@@ -239,6 +298,32 @@ class BulkSnapshotPublisher:
         eng = self.engine
         eng._check(_native.load().surge_replay_snapshot_commit(eng._h, ctypes.c_void_p(self._pending_kind.data_ptr())))
         self._pending_kind = None
+
+
+class PendingPublish:
+    """A ``publish_async`` whose record batches are being framed on a worker thread."""
+
+    def __init__(self, publisher: "BulkSnapshotPublisher", d_kind, timings: dict):
+        self._publisher, self._d_kind, self.timings = publisher, d_kind, timings
+        self._thread = None
+        self._out: Optional[Dict[int, bytes]] = None
+        self._exc: Optional[BaseException] = None
+        self._settled = False
+
+    def wait(self) -> None:
+        if self._thread is not None:
+            self._thread.join()
+        if self._exc is not None and not self._settled:
+            eng = self._publisher.engine  # the records never existed: their baseline must not stand
+            eng._check(_native.load().surge_replay_snapshot_invalidate(eng._h, ctypes.c_void_p(self._d_kind.data_ptr())))
+        self._settled = True
+        self._d_kind = None
+
+    def result(self) -> Dict[int, bytes]:
+        self.wait()
+        if self._exc is not None:
+            raise self._exc
+        return self._out
 
 
 def compact(records: Iterable[StateRecord]) -> Dict[str, Optional[bytes]]:

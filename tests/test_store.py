@@ -358,5 +358,32 @@ def test_bulk_snapshot_publish_emits_only_what_changed_as_kafka_record_batches()
             assert got == expected(s2, s1)
             assert any(v is None for v in got.values()) and 0 < len(got) <= 40
             assert pub.timings["values"] + pub.timings["tombstones"] == len(got)
+            # the same publish with its framing in the background while the store keeps folding: what is published is the
+            # state AT THE DELTA, the batch folded meanwhile shows up in the next snapshot — nothing lost, nothing twice
+            touched2 = rng.choice(n, size=60, replace=False)
+            be2 = S.make_events([S.EVT_INC] * 60, rng.integers(2000, 3000, size=60), rng.integers(1, 9, size=60))
+            eng.append_events(touched2.astype(np.int64), be2)
+            off2 = np.zeros(n + 1, np.int64); np.cumsum(np.bincount(touched2, minlength=n), out=off2[1:])
+            s3 = oracle.fold_csr(off2, be2[np.argsort(touched2, kind="stable")], s2)
+            pending = pub.publish_async()
+            touched3 = rng.choice(n, size=50, replace=False)
+            be3 = S.make_events([S.EVT_DEC] * 50, rng.integers(3000, 4000, size=50), rng.integers(1, 9, size=50))
+            eng.append_events(touched3.astype(np.int64), be3)  # folds while the worker thread frames
+            off3 = np.zeros(n + 1, np.int64); np.cumsum(np.bincount(touched3, minlength=n), out=off3[1:])
+            s4 = oracle.fold_csr(off3, be3[np.argsort(touched3, kind="stable")], s3)
+            assert decode(pending.result()) == expected(s3, s2)
+            assert decode(pub.publish_async().result()) == expected(s4, s3)
+            # a framing failure after the baseline was committed: the aggregates are reported again by the next publish
+            touched4 = rng.choice(n, size=30, replace=False)
+            be4 = S.make_events([S.EVT_INC] * 30, rng.integers(4000, 5000, size=30), rng.integers(1, 9, size=30))
+            eng.append_events(touched4.astype(np.int64), be4)
+            off4 = np.zeros(n + 1, np.int64); np.cumsum(np.bincount(touched4, minlength=n), out=off4[1:])
+            s5 = oracle.fold_csr(off4, be4[np.argsort(touched4, kind="stable")], s4)
+            real_append = pub.writer.append_indexed
+            pub.writer.append_indexed = lambda *a, **k: (_ for _ in ()).throw(MemoryError("framing failed"))
+            with pytest.raises(MemoryError):
+                pub.publish_async().result()
+            pub.writer.append_indexed = real_append
+            assert decode(pub.publish()) == expected(s5, s4)
         finally:
             pub.close()
