@@ -770,7 +770,7 @@ def run_v2(args):
 
 def run_e2e(args):
     """From the bytes Kafka hands over to recovered states (SURVEY §8f N1 in front of R2): record batches (message format
-    v2, 500 records each, the Counter fixture's play-json event text as the reference writes it: TestBoundedContext.scala:
+    v2, 16 KiB = 140 records each like the reference producer's, the Counter fixture's play-json event text as the reference writes it: TestBoundedContext.scala:
     122-124; lz4-compressed like the reference's producer, reference.conf:112, frames written by liblz4) -> host framing
     (headers, CRC-32C, read_committed; ONE host thread) -> surge_device_decoder (LZ4 blocks, records, key interning,
     JSON -> 16-byte events, on the GPU) -> device group-by + fold onto the resident state (K3).  A step = one
@@ -794,7 +794,7 @@ def run_e2e(args):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the replay engine has no CPU fallback")
     dev = torch.device("cuda:0")
-    PER = 500
+    PER = 140  # ~16 KiB of play-json Counter events: where the reference's producer closes a batch (kafka.publisher.batch-size = 16384)
     n_fetch = max(PER, (args.batch_events if args.batch_events != 100_000 else 1_000_000) // PER * PER)
     K = args.steps if args.steps != 20 else 8
     W = min(args.warmup, 2)

@@ -1,7 +1,7 @@
 mkdir -p gpurun_out/r3af
 timeout 400 python -m pytest tests/test_ingest_gpu.py tests/test_store.py tests/test_event_decode.py -x -q -m gpu > gpurun_out/r3af/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r3af/pytest.log
 grep -v amdgpu.ids gpurun_out/r3af/pytest.log | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -12
-timeout 300 python scripts/ingest_gpu_bench.py 8000 > gpurun_out/r3af/ingest_gpu.json 2> gpurun_out/r3af/ingest_gpu.err; echo "ingest rc=$?"; tail -3 gpurun_out/r3af/ingest_gpu.err
+timeout 300 python scripts/ingest_gpu_bench.py 4000000 > gpurun_out/r3af/ingest_gpu.json 2> gpurun_out/r3af/ingest_gpu.err; echo "ingest rc=$?"; tail -3 gpurun_out/r3af/ingest_gpu.err
 python -c "
 import json; d=json.load(open('gpurun_out/r3af/ingest_gpu.json'))
 for k,v in d.items():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Events-topic bytes -> (aggregate index, 16-byte event) arrays: the host decoder (one partition thread) against host framing
 + the device decoder, on the same wire bytes.  Counter fixture events as play-json text, and the same records with 16-byte
-values; uncompressed and LZ4 batches of 500 records.   python scripts/ingest_gpu_bench.py [n_batches]   (needs a GPU)"""
+values; uncompressed and LZ4 batches of 16 KiB (the reference producer's batch size).   python scripts/ingest_gpu_bench.py [records]   (needs a GPU)"""
 import json
 import os
 import struct
@@ -19,14 +19,18 @@ import kafka_wire as kw
 from fixture_models import CounterBusinessLogic, CountDecremented, CountIncremented, NoOpEvent
 from surge_amd.ingest import DeviceDecoder, EventsTopicIngest
 
-n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 8000
-PER = 500
+n_records = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+# records per batch: what the reference's producer packs into one batch — it closes a batch at 16 KiB of records
+# (kafka.publisher.batch-size = 16384, reference.conf:115): ~140 play-json Counter events, ~400 16-byte ones
+PER_BY_MODE = {"json": 140, "fixed16": 400}
 rng = np.random.default_rng(1)
 bl = CounterBusinessLogic()
 model, fmt = bl.command_model(), bl.event_write_formatting()
 tmpl = model.event_json_template()
-res = {"records": n_batches * PER, "batch_records": PER}
+res = {"records_per_case": n_records, "batch_records": PER_BY_MODE}
 for mode in ("json", "fixed16"):
+    PER = PER_BY_MODE[mode]
+    n_batches = n_records // PER
     for codec in ("none", "lz4"):
         protos = []
         for b in range(16):

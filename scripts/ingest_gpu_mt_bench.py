@@ -24,7 +24,7 @@ from fixture_models import CounterBusinessLogic, CountDecremented, CountIncremen
 from surge_amd.ingest import DeviceDecoder, EventsTopicIngest
 
 n_fetch_per_thread = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-PER, BATCHES = 500, 2000  # a fetch = 1 M records
+PER, BATCHES = 140, 7142  # a fetch = 1 M records in 16 KiB batches (kafka.publisher.batch-size = 16384, reference.conf:115)
 bl = CounterBusinessLogic()
 model, fmt = bl.command_model(), bl.event_write_formatting()
 tmpl = model.event_json_template()

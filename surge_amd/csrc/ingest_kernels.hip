@@ -114,64 +114,136 @@ struct Lz4Block {
   int32_t index;     // k: this block's number inside its frame
 };
 
+// The compressed stream is read through a 256-byte WINDOW held in registers (lane l: bytes [4l, 4l + 4) from `wbase`):
+// control bytes come out of it with v_readlane, short literal runs with one shuffle — no global load on the path from
+// one sequence to the next, only a refill every ~250 consumed bytes.  (First version: token, length bytes and offset
+// were three dependent global loads per sequence.)
+struct Lz4Window {
+  const uint8_t* in;
+  int32_t n_in, wbase;
+  uint32_t win;
+  int lane;
+  __device__ void refill(int32_t at) {
+    wbase = at;
+    const int32_t pos = at + 4 * lane;
+    uint32_t v = 0;
+    if (pos + 4 <= n_in) {
+      v = (uint32_t)in[pos] | ((uint32_t)in[pos + 1] << 8) | ((uint32_t)in[pos + 2] << 16) | ((uint32_t)in[pos + 3] << 24);
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (pos + k < n_in) v |= (uint32_t)in[pos + k] << (8 * k);
+    }
+    win = v;
+  }
+  __device__ uint32_t byte_at(int32_t at) {  // `at` is wave-uniform
+    if (at - wbase >= 256 || at < wbase) refill(at);
+    const int32_t idx = at - wbase;
+    const uint32_t word = __builtin_amdgcn_readlane(win, __builtin_amdgcn_readfirstlane(idx >> 2));
+    return (word >> ((idx & 3) * 8)) & 0xffu;
+  }
+  // one sequence's header at ip: literal length, then (after the literals) offset and match length; false = malformed
+  __device__ bool literal_length(int32_t& ip, uint32_t& token, int32_t& lit) {
+    token = byte_at(ip++);
+    lit = (int32_t)(token >> 4);
+    if (lit == 15) {
+      uint32_t x;
+      do {
+        if (ip >= n_in) return false;
+        x = byte_at(ip++);
+        lit += (int32_t)x;
+      } while (x == 255u && lit < (1 << 24));
+    }
+    return lit <= n_in - ip;
+  }
+  __device__ bool match(int32_t& ip, uint32_t token, int32_t& offset, int32_t& ml) {
+    if (n_in - ip < 2) return false;
+    offset = (int32_t)(byte_at(ip) | (byte_at(ip + 1) << 8));
+    ip += 2;
+    ml = (int32_t)(token & 15u);
+    if (ml == 15) {
+      uint32_t x;
+      do {
+        if (ip >= n_in) return false;
+        x = byte_at(ip++);
+        ml += (int32_t)x;
+      } while (x == 255u && ml < (1 << 24));
+    }
+    ml += 4;
+    return offset != 0;
+  }
+};
+
+// Pass 1: what every block decompresses to (a walk over the sequence headers only: no LDS, many waves per CU), so that
+// pass 2 can give a block the LDS it needs and not 64 KiB — the reference's producer closes a batch at 16 KiB
+// (kafka.publisher.batch-size = 16384, reference.conf:115): its blocks need a quarter of that, and four times as many
+// waves fit a CU.  sizes[b] = decompressed bytes, or -1 for a malformed block.
+__global__ void __launch_bounds__(64) lz4_size_kernel(const uint8_t* __restrict__ bytes, const Lz4Block* __restrict__ blocks, int64_t n_blocks,
+                                                      int32_t* __restrict__ sizes) {
+  const int64_t b = blockIdx.x;
+  if (b >= n_blocks) return;
+  const Lz4Block blk = blocks[b];
+  const int32_t n_in = blk.src_len & 0x7fffffff;
+  int32_t op = 0;
+  bool ok = true;
+  if (blk.src_len < 0) {
+    op = n_in;
+  } else {
+    Lz4Window w{bytes + blk.src_off, n_in, 0, 0u, (int)threadIdx.x};
+    w.refill(0);
+    int32_t ip = 0;
+    while (ip < n_in) {
+      uint32_t token;
+      int32_t lit, offset, ml;
+      if (!w.literal_length(ip, token, lit)) { ok = false; break; }
+      ip += lit;
+      op += lit;
+      if (op > kLz4BlockMax) { ok = false; break; }
+      if (ip >= n_in) break;
+      if (!w.match(ip, token, offset, ml) || offset > op) { ok = false; break; }
+      op += ml;
+      if (op > kLz4BlockMax) { ok = false; break; }
+    }
+  }
+  if (ok && !blk.last && op != kLz4BlockMax) ok = false;  // every block of a frame but its last is exactly full
+  if (threadIdx.x == 0) sizes[b] = ok ? op : -1;
+}
+
+// Pass 2: the blocks whose size is in (size_lo, size_hi] (size_hi = this launch's dynamic LDS)
 __global__ void __launch_bounds__(64) lz4_block_kernel(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ out_base, const Lz4Block* __restrict__ blocks,
-                                                       int64_t n_blocks, Section* __restrict__ sections, ErrorCell* err) {
+                                                       int64_t n_blocks, const int32_t* __restrict__ sizes, int32_t size_lo, int32_t size_hi,
+                                                       Section* __restrict__ sections, ErrorCell* err) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lz4_out[];
   const int lane = threadIdx.x;
   for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+    const int32_t want = sizes[b];
+    if (want < 0) {  // reported once, by the launch of the smallest class
+      if (size_lo < 0 && lane == 0) {
+        atomicMin(&err->lz4_bad, (unsigned int)blocks[b].section);
+        if (blocks[b].last) sections[blocks[b].section].byte_len = 0;
+      }
+      continue;
+    }
+    if (want <= size_lo || want > size_hi) continue;
     const Lz4Block blk = blocks[b];
     const uint8_t* in = bytes + blk.src_off;
     const int32_t n_in = blk.src_len & 0x7fffffff;
     int32_t op = 0;
-    bool ok = true;
     if (blk.src_len < 0) {  // stored
-      ok = n_in <= kLz4BlockMax;
-      if (ok) {
-        for (int i = lane; i < n_in; i += 64) lz4_out[i] = in[i];
-        op = n_in;
-      }
+      for (int i = lane; i < n_in; i += 64) lz4_out[i] = in[i];
+      op = n_in;
     } else {
-      // The compressed stream is read through a 256-byte WINDOW held in registers (lane l: bytes [4l, 4l + 4) from
-      // `wbase`): control bytes come out of it with v_readlane, short literal runs with one shuffle — no global load on the
-      // path from one sequence to the next, only a refill every ~250 consumed bytes.  (First version: token, length
-      // bytes and offset were three dependent global loads per sequence, 2-3 us each way: 1.6 ms per 57 KB block.)
-      int32_t ip = 0, wbase = 0;
-      uint32_t win = 0;
-      auto refill = [&](int32_t at) {
-        wbase = at;
-        const int32_t pos = at + 4 * lane;
-        uint32_t v = 0;
-        if (pos + 4 <= n_in) {
-          v = (uint32_t)in[pos] | ((uint32_t)in[pos + 1] << 8) | ((uint32_t)in[pos + 2] << 16) | ((uint32_t)in[pos + 3] << 24);
-        } else {
-          for (int k = 0; k < 4; ++k)
-            if (pos + k < n_in) v |= (uint32_t)in[pos + k] << (8 * k);
-        }
-        win = v;
-      };
-      auto byte_at = [&](int32_t at) -> uint32_t {  // `at` is wave-uniform
-        if (at - wbase >= 256 || at < wbase) refill(at);
-        const int32_t idx = at - wbase;
-        const uint32_t word = __builtin_amdgcn_readlane(win, __builtin_amdgcn_readfirstlane(idx >> 2));
-        return (word >> ((idx & 3) * 8)) & 0xffu;
-      };
-      refill(0);
+      // pass 1 walked exactly these headers and bounded everything: no checks here
+      Lz4Window w{in, n_in, 0, 0u, lane};
+      w.refill(0);
+      int32_t ip = 0;
       while (ip < n_in) {
-        const uint32_t token = byte_at(ip++);
-        int32_t lit = (int32_t)(token >> 4);
-        if (lit == 15) {
-          uint32_t x;
-          do {
-            if (ip >= n_in) { ok = false; break; }
-            x = byte_at(ip++);
-            lit += (int32_t)x;
-          } while (x == 255u && lit < (1 << 24));
-        }
-        if (!ok || lit > n_in - ip || lit > kLz4BlockMax - op) { ok = false; break; }
+        uint32_t token;
+        int32_t lit, offset, ml;
+        (void)w.literal_length(ip, token, lit);
         if (lit > 0) {
-          if (lit <= 64 && ip >= wbase && ip + lit - wbase <= 256) {  // the whole run is in the window
-            const int32_t idx = ip - wbase + lane;
-            const uint32_t word = (uint32_t)__shfl((int)win, (idx >> 2) & 63, 64);
+          if (lit <= 64 && ip >= w.wbase && ip + lit - w.wbase <= 256) {  // the whole run is in the window
+            const int32_t idx = ip - w.wbase + lane;
+            const uint32_t word = (uint32_t)__shfl((int)w.win, (idx >> 2) & 63, 64);
             if (lane < lit) lz4_out[op + lane] = (uint8_t)(word >> ((idx & 3) * 8));
           } else {
             for (int i = lane; i < lit; i += 64) lz4_out[op + i] = in[ip + i];
@@ -180,45 +252,23 @@ __global__ void __launch_bounds__(64) lz4_block_kernel(const uint8_t* __restrict
         ip += lit;
         op += lit;
         if (ip >= n_in) break;  // the last sequence carries literals only
-        if (n_in - ip < 2) { ok = false; break; }
-        const int32_t offset = (int32_t)(byte_at(ip) | (byte_at(ip + 1) << 8));
-        ip += 2;
-        if (offset == 0 || offset > op) { ok = false; break; }
-        int32_t ml = (int32_t)(token & 15u);
-        if (ml == 15) {
-          uint32_t x;
-          do {
-            if (ip >= n_in) { ok = false; break; }
-            x = byte_at(ip++);
-            ml += (int32_t)x;
-          } while (x == 255u && ml < (1 << 24));
-        }
-        ml += 4;
-        if (!ok || ml > kLz4BlockMax - op) { ok = false; break; }
+        (void)w.match(ip, token, offset, ml);
         // (LDS operations of one wave execute in order: a read sees every earlier write of any lane of this wave)
         const uint8_t* src = lz4_out + op - offset;
         if (offset >= ml) {
           for (int i = lane; i < ml; i += 64) lz4_out[op + i] = src[i];
-        } else {
+        } else {  // the period IS the data
           for (int i = lane; i < ml; i += 64) lz4_out[op + i] = src[i % offset];
         }
         op += ml;
       }
     }
-    // every block of a frame but its last is exactly full (that is how block k's place is known before it is decoded)
-    if (ok && !blk.last && op != kLz4BlockMax) ok = false;
-    if (!ok) {
-      if (lane == 0) atomicMin(&err->lz4_bad, (unsigned int)blk.section);
-      op = 0;
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
     uint8_t* dst = out_base + blk.dst_off;  // 16-byte aligned: dst_off is a multiple of 64 KiB from an aligned base
     const int n16 = op >> 4;
     for (int i = lane; i < n16; i += 64) ((uint4*)dst)[i] = ((const uint4*)lz4_out)[i];
     for (int i = (n16 << 4) + lane; i < op; i += 64) dst[i] = lz4_out[i];
-    if (blk.last && lane == 0) sections[blk.section].byte_len = ok ? (int64_t)blk.index * kLz4BlockMax + op : 0;
-    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (blk.last && lane == 0) sections[blk.section].byte_len = (int64_t)blk.index * kLz4BlockMax + op;
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // the copy-out has read the LDS before the next block overwrites it
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -668,7 +718,7 @@ struct surge_device_decoder {
   std::string err;
   Buf d_tmpl, d_ptab, d_err;
   // per push
-  Buf lz4_blocks;
+  Buf lz4_blocks, lz4_sizes;
   Buf d_bytes, d_sections, rec_pos, rec_end, meta, new_slots, sort_k_a, sort_k_b, sort_v_b, lens, agg_tmp, ev_tmp, keep, keep_pos, f64_list, temp;
   void* pinned = nullptr;
   size_t pinned_cap = 0;
@@ -791,7 +841,7 @@ int32_t surge_device_decoder_destroy(surge_device_decoder* d) {
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  Buf* bufs[] = {&d->lz4_blocks, &d->d_tmpl, &d->d_ptab, &d->d_err, &d->d_bytes, &d->d_sections, &d->rec_pos, &d->rec_end, &d->meta, &d->new_slots, &d->sort_k_a,
+  Buf* bufs[] = {&d->lz4_blocks, &d->lz4_sizes, &d->d_tmpl, &d->d_ptab, &d->d_err, &d->d_bytes, &d->d_sections, &d->rec_pos, &d->rec_end, &d->meta, &d->new_slots, &d->sort_k_a,
                  &d->sort_k_b, &d->sort_v_b, &d->lens, &d->agg_tmp, &d->ev_tmp, &d->keep, &d->keep_pos, &d->f64_list, &d->temp, &d->t_hash,
                  &d->t_key_id, &d->t_first, &d->arena, &d->key_off, &d->key_hash, &d->r_agg, &d->r_ev, &d->r_off};
   for (Buf* b : bufs) b->release();
@@ -1076,9 +1126,14 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
   if (!blocks.empty()) {
     DCHK(d, d->lz4_blocks.reserve(blocks.size() * sizeof(Lz4Block), false, st));
     DCHK(d, hipMemcpyAsync(d->lz4_blocks.p, blocks.data(), blocks.size() * sizeof(Lz4Block), hipMemcpyHostToDevice, st));
-    const unsigned grid = (unsigned)(blocks.size() < 4096 ? blocks.size() : 4096);
-    hipLaunchKernelGGL(lz4_block_kernel, dim3(grid), dim3(64), kLz4BlockMax, st, dby, (uint8_t*)d->d_bytes.p + area_base, (const Lz4Block*)d->lz4_blocks.p,
-                       (int64_t)blocks.size(), dsec, derr);
+    DCHK(d, d->lz4_sizes.reserve(blocks.size() * 4, false, st));
+    const int64_t nb = (int64_t)blocks.size();
+    hipLaunchKernelGGL(lz4_size_kernel, dim3((unsigned)nb), dim3(64), 0, st, dby, (const Lz4Block*)d->lz4_blocks.p, nb, (int32_t*)d->lz4_sizes.p);
+    const unsigned grid = (unsigned)(nb < 8192 ? nb : 8192);
+    const int32_t classes[4] = {-1, 16384, 32768, kLz4BlockMax};  // LDS per wave of the three launches: 16 / 32 / 64 KiB
+    for (int c = 0; c < 3; ++c)
+      hipLaunchKernelGGL(lz4_block_kernel, dim3(grid), dim3(64), (size_t)classes[c + 1], st, dby, (uint8_t*)d->d_bytes.p + area_base,
+                         (const Lz4Block*)d->lz4_blocks.p, nb, (const int32_t*)d->lz4_sizes.p, classes[c], classes[c + 1], dsec, derr);
     // a frame that does not decode fails the push HERE, before any key of the push is interned (`blocks` is host memory:
     // the copy has to be done before it goes out of scope anyway)
     ErrorCell lz;
