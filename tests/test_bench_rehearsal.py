@@ -92,7 +92,8 @@ def test_bench_workload_v2_reports_four_variants_of_the_same_device_code_and_ful
 
 @pytest.mark.gpu
 def test_bench_workload_e2e_goes_from_topic_bytes_to_states_and_checks_them():
-    d = run_single(["--workload", "e2e", "--batch-events", "20000", "--steps", "3", "--warmup", "1"])
+    n = 140 * 143  # whole 16 KiB batches of 140 play-json records (bench.py cuts a fetch to a multiple of the batch)
+    d = run_single(["--workload", "e2e", "--batch-events", str(n), "--steps", "3", "--warmup", "1"])
     cfg = d["config"]
-    assert cfg["fetch_records"] == 20000 and cfg["decoder_counters"]["records_delivered"] == 20000 * 4 and cfg["aggregates_seen"] > 1000
+    assert cfg["fetch_records"] == n and cfg["decoder_counters"]["records_delivered"] == n * 4 and cfg["aggregates_seen"] > 1000
     assert d["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_decoded_events"] is True and d["value"] > 0
