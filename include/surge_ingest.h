@@ -137,7 +137,12 @@ typedef struct surge_batch_section {
   int32_t codec;       /* 0: the records themselves; 3: one LZ4 frame that holds them (SURGE_INGEST_DEVICE_LZ4)  */
 } surge_batch_section;
 /* Pops up to max deliverable batches (committed / non-transactional, before any open transaction), in offset order.
- * Spans stay valid until the next feed / destroy.  SURGE_E_STATE on a decoder that was not created in FRAMES mode. */
+ * SURGE_E_STATE on a decoder that was not created in FRAMES mode.
+ * Lifetime of the spans: a FRAMES decoder alternates between two arenas, one per feed, so the sections handed out here
+ * (and the address surge_ingest_arena returned right after this drain) stay valid THROUGH the next feed and until the
+ * feed after it — one thread can frame fetch i + 1 (feed, drain_sections, surge_ingest_arena) while another thread's
+ * surge_device_decoder_push still reads fetch i.  The handle itself is for one thread at a time; what the second thread
+ * touches is only the arena memory.  Batches still queued at a feed (open transactions) move to the new arena with it. */
 int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge_batch_section* out, int64_t* n_out);
 
 /* Where the arena's memory comes from (before the first feed; NULL / NULL = malloc / free).  surge_ingest_use_pinned_arena

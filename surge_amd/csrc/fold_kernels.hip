@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
 #pragma unroll
   for (int k = 0; k < G::kClasses; ++k) voff[k] = ((uint32_t)(lane / LE) * LE + G::load_j(lane, k)) * 16u;
   const uint32_t ev_row = G::ev_row(lane);
-  issue_tile_loads<LE>(p, Ea, lds_ev, voff);
+  issue_tile_loads<LE>(p, Ea, E1, lds_ev, voff);
 
   // FLAT: head marking.  next_s = first segment whose start has not been marked yet.
   int64_t next_s = S0;
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
     // all my reads of the event buffer are done: it can take the next tile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (MODE == MODE_FLAT && lane < G::kHeadWords) lds_hb[lane] = 0u;
-    if (tile + 1 < n_tiles) issue_tile_loads<LE>(p, te0 + G::kTile, lds_ev, voff);
+    if (tile + 1 < n_tiles) issue_tile_loads<LE>(p, te0 + G::kTile, E1, lds_ev, voff);
 
     // LDS dword offset of each event's op-table entry.  Events past the end of the task (last tile
     // only) become the null event [17], an identity on every state, so nothing below needs a validity mask.

@@ -235,7 +235,13 @@ struct surge_ingest {
   bool frames = false;  // SURGE_INGEST_FRAMES: records are not parsed here, their sections go to a surge_device_decoder
   bool device_lz4 = false;  // SURGE_INGEST_DEVICE_LZ4: ... and LZ4 frames stay compressed (the device decoder undoes them)
   std::string err;
-  Arena arena;
+  // FRAMES mode alternates between two arenas, one per feed: the sections a drain handed out stay where they are while
+  // the NEXT feed fills the other arena, so one thread can frame fetch i + 1 while a device decoder reads fetch i.
+  // The other modes only ever use the first.
+  Arena arenas[2];
+  int cur = 0;
+  Arena& arena_now() { return arenas[cur]; }
+  const Arena& arena_now() const { return arenas[cur]; }
   std::deque<Batch> queue;
   std::vector<std::string> keys;   // aggregate ids in first-seen order
   std::vector<uint64_t> key_hash;  // their hashes
@@ -304,7 +310,7 @@ int64_t intern(surge_ingest* g, const uint8_t* key, int32_t len) {
 
 // dense aggregate index of a record that is being delivered
 inline int64_t deliver_idx(surge_ingest* g, Rec& r) {
-  if (r.agg_idx == -2) r.agg_idx = intern(g, g->arena.data() + r.key_off, r.key_len);
+  if (r.agg_idx == -2) r.agg_idx = intern(g, g->arena_now().data() + r.key_off, r.key_len);
   return r.agg_idx;
 }
 
@@ -362,10 +368,10 @@ int32_t parse_records(surge_ingest* g, Batch& b, const uint8_t* data, int64_t le
     rec.offset = base_offset + offset_delta;
     rec.key_len = (int32_t)klen;
     rec.value_len = (int32_t)vlen;
-    rec.key_off = (int64_t)g->arena.size();
-    if (klen > 0) g->arena.append(key, (size_t)klen);
-    rec.value_off = (int64_t)g->arena.size();
-    if (vlen > 0) g->arena.append(val, (size_t)vlen);
+    rec.key_off = (int64_t)g->arena_now().size();
+    if (klen > 0) g->arena_now().append(key, (size_t)klen);
+    rec.value_off = (int64_t)g->arena_now().size();
+    if (vlen > 0) g->arena_now().append(val, (size_t)vlen);
     rec.agg_idx = klen >= 0 ? -2 : -1;  // -2: interned when the record is DELIVERED (drain): the keys of aborted or
                                         // still-open transactions never enter the key table
     b.recs.push_back(rec);
@@ -471,7 +477,26 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
   if (!g) return fail(nullptr, E_INVALID, "handle is NULL");
   if (len < 0 || (!data && len > 0)) return fail(g, E_INVALID, "bad buffer");
   if (consumed_out) *consumed_out = 0;
-  if (g->queue.empty()) g->arena.clear();  // spans handed out by the last drain are released here
+  if (g->frames) {
+    // switch arenas: the sections still queued (open transactions, undrained batches) move along, the ones the last
+    // drain handed out stay untouched in the arena this feed leaves behind (valid until the feed after this one)
+    try {
+      Arena& next = g->arenas[g->cur ^ 1];
+      const Arena& prev = g->arenas[g->cur];
+      next.clear();
+      for (Batch& qb : g->queue) {
+        if (qb.sect_off < 0) continue;
+        const int64_t at = (int64_t)next.size();
+        next.append(prev.data() + qb.sect_off, (size_t)qb.sect_len);
+        qb.sect_off = at;
+      }
+      g->cur ^= 1;
+    } catch (const std::bad_alloc&) {
+      return fail(g, E_NOMEM, "out of host memory while decoding");
+    }
+  } else if (g->queue.empty()) {
+    g->arena_now().clear();  // spans handed out by the last drain are released here
+  }
   int64_t pos = 0;
   // A failure in batch k leaves batches 0..k-1 of this buffer decoded and queued: report them as consumed so a
   // caller that retries (or skips the bad batch) never feeds them twice.
@@ -539,12 +564,12 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
       int control_type = -1;
       if (g->frames && !control) {
         // device decode: the records section travels as it is (the device chains and parses the records)
-        b.sect_off = (int64_t)g->arena.size();
+        b.sect_off = (int64_t)g->arena_now().size();
         b.sect_len = recs_len;
         b.base_offset = base_offset;
         b.count = count;
         b.sect_codec = sect_codec;
-        g->arena.append(recs, (size_t)recs_len);
+        g->arena_now().append(recs, (size_t)recs_len);
         g->counters[1] += count;
       } else {
         const int32_t rc = parse_records(g, b, recs, recs_len, count, base_offset, control, &control_type);
@@ -603,13 +628,15 @@ int32_t surge_ingest_drain(surge_ingest* g, int64_t max, surge_ingest_record* ou
   return OK;
 }
 
-const uint8_t* surge_ingest_arena(const surge_ingest* g) { return g ? g->arena.data() : nullptr; }
+const uint8_t* surge_ingest_arena(const surge_ingest* g) { return g ? g->arena_now().data() : nullptr; }
 
 int32_t surge_ingest_set_allocator(surge_ingest* g, void* (*alloc)(size_t), void (*release)(void*)) {
   if (!g || !alloc != !release) return fail(g, E_INVALID, "bad argument");
-  if (g->arena.cap) return fail(g, -2, "surge_ingest_set_allocator after the first feed");
-  g->arena.alloc = alloc;
-  g->arena.release = release;
+  if (g->arenas[0].cap || g->arenas[1].cap) return fail(g, -2, "surge_ingest_set_allocator after the first feed");
+  for (Arena& a : g->arenas) {
+    a.alloc = alloc;
+    a.release = release;
+  }
   return OK;
 }
 
@@ -636,7 +663,7 @@ int32_t surge_ingest_drain_fixed16(surge_ingest* g, int64_t max, int64_t* agg_id
     while (n < max && b.next < b.recs.size()) {
       Rec& r = b.recs[b.next++];
       agg_idx_out[n] = deliver_idx(g, r);
-      std::memcpy(ev + n * 16, g->arena.data() + r.value_off, 16);
+      std::memcpy(ev + n * 16, g->arena_now().data() + r.value_off, 16);
       if (offsets_out) offsets_out[n] = r.offset;
       ++n;
     }
@@ -662,7 +689,7 @@ int32_t surge_ingest_drain_json(surge_ingest* g, int64_t max, const surge_event_
       const Rec& r = b.recs[i];
       if (r.agg_idx == -1 || r.value_len < 0)
         return fail(g, SURGE_E_CORRUPT, "record at offset " + std::to_string(r.offset) + " has a null key or value (not an event)");
-      const int32_t rc = surge_event_json_decode(tmpl, g->arena.data() + r.value_off, r.value_len, ev + avail * 16);
+      const int32_t rc = surge_event_json_decode(tmpl, g->arena_now().data() + r.value_off, r.value_len, ev + avail * 16);
       if (rc != OK)
         return fail(g, SURGE_E_CORRUPT, "record at offset " + std::to_string(r.offset) + ": " + surge_event_json_last_error());
     }

@@ -193,6 +193,94 @@ class EventsTopicIngest:
         return kt
 
 
+class FramedFetches:
+    """Frames a sequence of fetches ONE FETCH AHEAD of whoever consumes them: a worker thread runs the host stage
+    (``feed`` = batch headers, CRC-32C, ``read_committed`` — and the fetch itself, when ``fetches`` is a generator that
+    polls) while the caller's thread keeps the device busy with the previous fetch (``DeviceDecoder.push`` + the
+    fold).  One ``EventsTopicIngest`` in FRAMES mode does all the framing, so transactions and partial batches carry
+    from fetch to fetch; its two alternating arenas (``surge_ingest_drain_sections`` in ``surge_ingest.h``) are what
+    makes the overlap safe: the sections of fetch i stay where they are while fetch i + 1 is framed, and fetch i + 2 is
+    not started before the consumer has asked for fetch i + 1 (= is done with fetch i).
+
+    Iterating yields ``(sections, arena_address)`` per fetch, in order.  ``overlap=False`` frames inline (same results,
+    one thread)."""
+
+    def __init__(self, fetches, isolation_level: int = READ_COMMITTED, device_lz4: bool = True, overlap: bool = True):
+        import queue
+        import threading
+
+        self._g = EventsTopicIngest(isolation_level, frames=True, device_lz4=device_lz4)
+        self._fetches = iter(fetches)
+        self._overlap = overlap
+        self.framing_seconds: List[float] = []
+        self._q: "queue.Queue" = queue.Queue()
+        self._slots = threading.Semaphore(2)  # framed fetches alive at once: the one being read + the one being framed
+        self._stop = False
+        self._held = 0
+        self._thread = threading.Thread(target=self._run, name="surge-framing", daemon=True) if overlap else None
+        if self._thread:
+            self._thread.start()
+
+    def _frame(self, data):
+        import time
+
+        t0 = time.perf_counter()
+        self._g.feed(data)
+        item = self._g.drain_sections()
+        self.framing_seconds.append(time.perf_counter() - t0)
+        return item
+
+    def _run(self):
+        try:
+            for data in self._fetches:
+                self._slots.acquire()
+                if self._stop:
+                    break
+                self._q.put(self._frame(data))
+        except BaseException as e:  # handed to the consumer, which re-raises it in its own thread
+            self._q.put(e)
+        finally:
+            self._q.put(None)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if not self._overlap:
+            return self._frame(next(self._fetches))
+        if self._held:  # the consumer is done with the fetch it got last time: its arena may be framed into again
+            self._held -= 1
+            self._slots.release()
+        item = self._q.get()
+        if item is None:
+            self._q.put(None)
+            raise StopIteration
+        if isinstance(item, BaseException):
+            self._q.put(None)
+            raise item
+        self._held += 1
+        return item
+
+    def counters(self) -> dict:
+        """The ingest counters; call it when the iteration has ended (the handle belongs to the framing thread)."""
+        return self._g.counters()
+
+    def close(self):
+        self._stop = True
+        if self._thread:
+            self._slots.release()
+            self._slots.release()
+            self._thread.join()
+            self._thread = None
+        self._g.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 class DeviceDecoder:
     """``surge_device_decoder``: records sections (host bytes) -> device-resident ``(agg_idx, events, offsets)`` and a
     device key table.  ``template=None``: record values are 16-byte events; otherwise the model's ``EventJsonTemplate``."""

@@ -80,30 +80,10 @@ class GpuReplayStateStore:
         from .schema import EVENT_DTYPE
 
         template = self.model.event_json_template()
-        with EventsTopicIngest(frames=True, device_lz4=True) as g:
-            g.feed(record_batches)
-            sections, arena = g.drain_sections()
-            counters = g.counters()
-            kind = _sniff_value_kind(sections, arena)  # "fixed16", "json" or None (no deliverable record)
-            if kind == "fixed16" or (kind == "json" and template is not None) or kind is None:
-                with DeviceDecoder(template if kind == "json" else None, device=self.engine.device) as d:
-                    if sections.shape[0]:
-                        d.push(sections, arena)
-                    agg_idx, events, _, n_keys = d.result()
-                    keys = KeyTable()
-                    for k in d.keys():
-                        keys.intern(k)
-                    n_agg = max(len(keys), capacity)
-                    self.keys = keys
-                    self.engine.load_csr(np.zeros(n_agg + 1, dtype=np.int64), np.zeros(0, dtype=EVENT_DTYPE))
-                    self.engine.fold()  # every aggregate None
-                    if agg_idx.shape[0]:
-                        self.engine.append_events(agg_idx, events)  # device arrays straight into the device group-by
-                        self.engine.synchronize()
-                    counters.update(d.counters())
-                self.engine.snapshot()  # publishes the host mirror that serves point reads
-                self._restored = True
-                return counters
+        try:
+            return self.restore_from_fetches([record_batches], capacity=capacity, overlap=False)
+        except _NotDeviceDecodable:
+            pass  # JSON values and a model without a template: the host decoder + the plugin's reader below
         with EventsTopicIngest() as g:
             g.feed(record_batches)
             recs = None
@@ -138,6 +118,63 @@ class GpuReplayStateStore:
         self.engine.fold()  # every aggregate None; `algo` only names kernels for bound logs (restore / restore_log)
         if events.shape[0]:
             self.engine.append_events(agg_idx, events)
+        self.engine.snapshot()  # publishes the host mirror that serves point reads
+        self._restored = True
+        return counters
+
+    def restore_from_fetches(self, fetches, capacity: int = 0, overlap: bool = True) -> dict:
+        """Recover from the events topic as a consumer receives it: ``fetches`` yields the record-batch bytes of one
+        partition, fetch by fetch, in offset order (a list, or a generator that polls).  The host frames fetch i + 1
+        (headers, CRC-32C, transactions — ``FramedFetches``) while the GPU decodes, groups and folds fetch i
+        (``surge_device_decoder`` -> the K3 group-by -> the fold onto the resident state), so neither waits for the
+        other; the resident state and the device key table grow as new aggregates appear.  What
+        ``SurgeStateStoreConsumer.scala:33-46,57-76`` does record by record through Kafka Streams' restore.
+        Needs values the device decoder reads (16-byte fixed events, or JSON with the model's
+        ``event_json_template``); returns the ingest + decoder counters."""
+        from .ingest import DeviceDecoder, FramedFetches
+        from .log import KeyTable
+        from .schema import EVENT_DTYPE
+
+        template = self.model.event_json_template()
+        d = None
+        n_agg = -1
+        try:
+            with FramedFetches(fetches, overlap=overlap) as framed:
+                for sections, arena in framed:
+                    if not sections.shape[0]:
+                        continue
+                    if d is None:
+                        kind = _sniff_value_kind(sections, arena)  # "fixed16", "json" or None (no deliverable record)
+                        if kind == "json" and template is None:
+                            raise _NotDeviceDecodable("JSON event values need the model's event_json_template")
+                        d = DeviceDecoder(template if kind == "json" else None, device=self.engine.device)
+                    if n_agg < 0:
+                        n_agg = capacity
+                        self.engine.load_csr(np.zeros(n_agg + 1, dtype=np.int64), np.zeros(0, dtype=EVENT_DTYPE))
+                        self.engine.fold()  # every aggregate None
+                    d.push(sections, arena)
+                    agg_idx, events, _, n_keys = d.result()
+                    if n_keys > n_agg:
+                        self.engine.grow(n_keys)
+                        n_agg = n_keys
+                    if agg_idx.shape[0]:
+                        self.engine.append_events(agg_idx, events)  # device arrays straight into the device group-by
+                        self.engine.synchronize()  # the arrays are the decoder's: done with them before the next push
+                    d.clear()
+                counters = framed.counters()
+            if n_agg < 0:  # nothing deliverable in the whole topic
+                n_agg = capacity
+                self.engine.load_csr(np.zeros(n_agg + 1, dtype=np.int64), np.zeros(0, dtype=EVENT_DTYPE))
+                self.engine.fold()
+            keys = KeyTable()
+            if d is not None:
+                for k in d.keys():
+                    keys.intern(k)
+                counters.update(d.counters())
+            self.keys = keys
+        finally:
+            if d is not None:
+                d.close()
         self.engine.snapshot()  # publishes the host mirror that serves point reads
         self._restored = True
         return counters
@@ -256,6 +293,10 @@ class GpuReplayPersistencePlugin:
 
     def create_supplier(self, store_name: str) -> GpuReplayKeyValueStore:
         return GpuReplayKeyValueStore(store_name, self.recovered)
+
+
+class _NotDeviceDecodable(ValueError):
+    """The topic's values are not something the device decoder reads (JSON text, and the model has no template)."""
 
 
 def _sniff_value_kind(sections, arena_address: int):

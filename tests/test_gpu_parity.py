@@ -288,6 +288,28 @@ def test_segment_boundaries_on_every_tile_alignment():
         assert_same(got, oracle.fold_csr(so, ev), so)
 
 
+@pytest.mark.parametrize("target_tasks,le", [(3, 16), (7, 16), (40, 16), (7, 8), (1000, 8)])
+def test_flat_tasks_of_several_tiles_fetch_only_their_own_pieces_of_the_last_tile(target_tasks, le, monkeypatch):
+    """A FLAT / FIXED task's last tile is fetched only up to the task's end (whole 1 KiB pieces; fold_device.h,
+    issue_tile_loads): tasks of 1 ... 60 tiles whose ends fall on every kind of offset inside a tile — with the events of the
+    NEXT task right behind them in memory — must still give the oracle's bytes, on None and on a prior snapshot."""
+    monkeypatch.setenv("SURGE_REPLAY_TARGET_TASKS", str(target_tasks))
+    monkeypatch.setenv("SURGE_REPLAY_LE_FLAT", str(le))
+    monkeypatch.setenv("SURGE_REPLAY_LE_FIXED", str(le))
+    rng = np.random.default_rng(77 + target_tasks)
+    for lens in (rng.integers(0, 900, size=400), rng.integers(1, 40, size=9000), np.array([1, 63, 64, 65, 1000, 1023, 1024, 1025, 3000, 7, 20000, 1] * 6),
+                 np.where(rng.random(3000) < 0.5, 1, rng.integers(1, 200, size=3000))):
+        so, ev = synth.csr_log(lens.astype(np.int64), int(rng.integers(1, 1 << 30)), synth.STRESS_MIX)
+        prior = oracle.fold_csr(*synth.csr_log(rng.integers(0, 4, size=lens.shape[0]), 5, synth.STRESS_MIX))
+        for init in (None, prior):
+            got, st = gpu_fold(so, ev, init, algo=S.ALGO_FLAT)
+            assert st.n_tasks >= min(target_tasks, 2) - 1
+            assert_same(got, oracle.fold_csr(so, ev, init), so)
+    so, ev = synth.fixed_log(517, 48, seed=9, mix=synth.STRESS_MIX)  # FIXED: 24 816 events, tasks end inside a tile
+    got, _ = gpu_fold(so, ev, algo=S.ALGO_FIXED)
+    assert_same(got, oracle.fold_csr(so, ev), so)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SURGE_TEST_FUZZ_SEEDS", "6"))))
 def test_random_log_shapes_through_every_kernel(seed):
     # shape fuzz: segment-length distributions that stress different paths (all short, a few giants, runs of

@@ -567,3 +567,80 @@ def test_lz4_compressed_state_topic_batches_round_trip_and_match_the_uncompresse
     with RecordBatchWriter(1) as w:
         with pytest.raises(RuntimeError):
             w.set_compression("lz4") if False else w._check(w._lib.surge_snapshot_writer_set_compression(w._h, 2))  # snappy: unsupported
+
+
+def _section_bytes(sections, arena):
+    return [ctypes.string_at(arena + int(s["byte_off"]), int(s["byte_len"])) for s in sections]
+
+
+def test_frames_mode_alternates_two_arenas_so_the_next_feed_leaves_the_drained_sections_alone():
+    """What lets one thread frame fetch i + 1 while a device decoder still reads fetch i (surge_ingest.h,
+    surge_ingest_drain_sections): a drained section stays byte-identical, at the same address, through the NEXT feed — and
+    batches that are still queued at a feed (an open transaction) travel to the new arena."""
+    ev = lambda seq: counter_event(S.EVT_INC, seq, seq)
+    batch = lambda off, key, n, **kw_: kw.record_batch(off, [(key, ev(off + i + 1)) for i in range(n)], **kw_)
+    a, b, c = batch(0, b"a:1", 300), batch(300, b"b:1", 200), batch(500, b"c:1", 5000)
+    with EventsTopicIngest(frames=True) as g:
+        g.feed(a)
+        sa, arena_a = g.drain_sections()
+        assert _section_bytes(sa, arena_a) == [a[61:]]
+        g.feed(b)  # fills the other arena
+        sb, arena_b = g.drain_sections()
+        assert arena_b != arena_a and _section_bytes(sa, arena_a) == [a[61:]] and _section_bytes(sb, arena_b) == [b[61:]]
+        g.feed(c)  # back in the first arena (grown for the larger fetch): b's spans are the ones that survive now
+        sc, arena_c = g.drain_sections()
+        assert _section_bytes(sb, arena_b) == [b[61:]] and _section_bytes(sc, arena_c) == [c[61:]]
+        # an open transaction is carried from arena to arena until its marker arrives
+        t = batch(5500, b"t:1", 40, transactional=True, producer_id=3)
+        g.feed(t)
+        assert g.drain_sections()[0].shape[0] == 0
+        g.feed(batch(5540, b"d:1", 10))  # behind the open transaction: not deliverable either
+        assert g.drain_sections()[0].shape[0] == 0 and g.counters()["open_transactions"] == 1
+        g.feed(kw.control_batch(5550, 3, kw.COMMIT))
+        st, arena_t = g.drain_sections()
+        assert [int(s["base_offset"]) for s in st] == [5500, 5540]
+        assert _section_bytes(st, arena_t) == [t[61:], batch(5540, b"d:1", 10)[61:]]
+
+
+def test_framed_fetches_yield_the_same_sections_one_fetch_ahead_as_inline():
+    from surge_amd.ingest import FramedFetches
+
+    ev = lambda seq: counter_event(S.EVT_INC, seq, seq)
+    rnd = random.Random(5)
+    fetches, off = [], 0
+    for f in range(12):
+        parts = []
+        for b in range(rnd.randrange(1, 6)):
+            n = rnd.randrange(1, 400)
+            parts.append(kw.record_batch(off, [(b"k%d:%d" % (rnd.randrange(50), i), ev(off + i + 1)) for i in range(n)],
+                                         compression=rnd.choice(["none", "lz4"])))
+            off += n
+        fetches.append(b"".join(parts))
+    # a fetch that cuts a batch in two: the tail is completed by the next fetch
+    cut = len(fetches[3]) - 37
+    fetches[3], fetches[4] = fetches[3][:cut], fetches[3][cut:] + fetches[4]
+
+    def collect(overlap, slow_consumer):
+        import time
+
+        got = []
+        with FramedFetches(iter(fetches), device_lz4=True, overlap=overlap) as framed:
+            for sections, arena in framed:
+                if slow_consumer:
+                    time.sleep(0.01)  # the framing thread runs ahead; the spans must still be intact afterwards
+                got.append([(int(s["base_offset"]), int(s["n_records"]), int(s["codec"]), b) for s, b in zip(sections, _section_bytes(sections, arena))])
+            c = framed.counters()
+        return got, c
+
+    inline, c0 = collect(False, False)
+    ahead, c1 = collect(True, True)
+    assert inline == ahead and c0 == c1 and sum(len(x) for x in inline) == c0["batches"] and len(inline) == len(fetches)
+
+    def failing():
+        yield fetches[0]
+        yield b"\x00" * 80  # not a record batch
+    with FramedFetches(failing(), overlap=True) as framed:
+        it = iter(framed)
+        next(it)
+        with pytest.raises(IngestError):
+            next(it)

@@ -240,6 +240,53 @@ def test_recovery_from_raw_events_topic_bytes():
         store.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [False, True])
+def test_recovery_fetch_by_fetch_equals_recovery_from_the_whole_partition(overlap):
+    """restore_from_fetches: the host frames fetch i + 1 while the GPU decodes / groups / folds fetch i; transactions
+    that span fetches, a batch cut by a fetch boundary and aggregates that first appear late all end in the same store
+    as one restore_from_topic over the concatenated bytes."""
+    import random
+
+    import kafka_wire as kw
+    from surge_amd.store import GpuReplayStateStore
+
+    bl = CounterBusinessLogic()
+    fmt = bl.event_write_formatting()
+    rnd = random.Random(11)
+    seq = {}
+    wire, off = [], 0
+    for flush in range(60):
+        events = []
+        for _ in range(rnd.randrange(1, 120)):
+            agg = "agg-%d" % rnd.randrange(40 + 25 * flush)  # the id space keeps growing: new aggregates in every fetch
+            seq[agg] = seq.get(agg, 0) + 1
+            events.append(rnd.choice([CountIncremented(agg, rnd.randrange(100), seq[agg]), CountDecremented(agg, rnd.randrange(100), seq[agg]),
+                                      NoOpEvent(agg, seq[agg])]))
+        msgs = [fmt.write_event(e) for e in events]
+        txn = flush % 3 == 0
+        wire.append(kw.record_batch(off, [(m.key.encode(), m.value) for m in msgs], compression=rnd.choice(["none", "lz4"]), transactional=txn, producer_id=5))
+        off += len(msgs)
+        if txn:
+            wire.append(kw.control_batch(off, 5, kw.ABORT if flush % 9 == 0 else kw.COMMIT))
+            off += 1
+    whole = b"".join(wire)
+    # fetch boundaries wherever they fall: inside batches, between a transaction's batch and its marker, ...
+    cuts = sorted(rnd.sample(range(1, len(whole)), 9))
+    fetches = [whole[a:b] for a, b in zip([0] + cuts, cuts + [len(whole)])]
+    one, many = GpuReplayStateStore(bl), GpuReplayStateStore(bl)
+    try:
+        c_one = one.restore_from_topic(whole)
+        c_many = many.restore_from_fetches(iter(fetches), overlap=overlap)
+        assert c_one == c_many and c_one["records_aborted"] > 0
+        assert one.keys.keys == many.keys.keys and len(one.keys.keys) > 500
+        for k in one.keys.keys:
+            assert one.get_aggregate_bytes(k) == many.get_aggregate_bytes(k)
+    finally:
+        one.close()
+        many.close()
+
+
 # ---- round-2 regressions (ADVICE.md: aggregates that first appear after recovery) ------------------------------
 def test_pack_batch_rejects_an_over_capacity_batch_without_interning_anything():
     from surge_amd.log import KeyTable, pack_batch
