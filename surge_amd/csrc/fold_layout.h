@@ -62,7 +62,8 @@ enum {
   TW_FLAGS = 15,   // flat kernel's presence pre-pass only: bit0 poison, bit16 delete (OR-ed in at << j)
 };
 constexpr int kTableWalkWords = 14;
-constexpr int kTargetTasks = 16384;                       // enough tasks to fill the chip several times over
+constexpr int kTargetTasks = 8192;                        // enough tasks to fill the chip (2048 resident waves) four times over; 16384
+                                                          // cost 3-13 % on logs below 1 GB: per-task start-up (plan, offsets, op table, first tile)
 
 struct FoldParams {
   const uint4* events;      // 16 B records
