@@ -177,6 +177,7 @@ def main():
     ap.add_argument("--snapshot-every", type=int, default=30, help="c5: publish a state-topic delta every N batches (0 = never)")
     ap.add_argument("--device-batches", action="store_true", help="c5: batches already in HBM (no staging / H2D)")
     ap.add_argument("--codec", default="lz4", choices=["lz4", "none"], help="e2e: compression of the record batches (the reference's producer: lz4)")
+    ap.add_argument("--host-framing", action="store_true", help="c5: frame the state-topic record batches with the host writer instead of the device framer")
     ap.add_argument("--serial-framing", action="store_true", help="e2e: frame each fetch and then run its device stage, one after the other (default: the host frames one fetch ahead on a second thread)")
     ap.add_argument("--aggregates", type=int, default=None, help="global aggregate count (default 10 M for c4, 1 M for c2)")
     ap.add_argument("--events-per-aggregate", type=int, default=C2_EVENTS, help="c2 only")
@@ -554,8 +555,9 @@ def run_c5(args):
     recovered = eng.snapshot()
     ids = torch.arange(A, dtype=torch.int64, device=dev)
     u16, o16 = id_table_utf16(ids)
-    pub = BulkSnapshotPublisher(eng, None, N_PARTITIONS, tables=(u16.to(torch.uint8), o16.clone(), u16, o16))
+    pub = BulkSnapshotPublisher(eng, None, N_PARTITIONS, tables=(u16.to(torch.uint8), o16.clone(), u16, o16), device_framing=not args.host_framing)
     pub.publish()  # the full snapshot after recovery: the baseline of the deltas
+    snap_parts = []
 
     rng = np.random.default_rng(7)
     cdf = synth.zipf_cdf(4096)
@@ -589,13 +591,13 @@ def run_c5(args):
     for i in range(K):
         submit(W + i)
         if every > 0 and (i + 1) % every == 0:
-            # Synchronous on purpose: the batches here come back to back (30 of them take 10 ms, not the 3 s they stand for),
-            # so there is nothing to hide a background framing behind — publish_async (framing on a worker thread while the
-            # store keeps folding) measured 68 ms per cycle here against 48 ms, the worker competing with this loop for the
-            # box's 16 cores.  In a real 3 s interval it is the other way round.
+            # Synchronous: the record batches are framed on the device (DeviceFramer), the host adds the batches' CRCs — a
+            # few milliseconds, nothing worth a worker thread.  (--host-framing: the C++ writer on up to 16 host threads,
+            # the publish of rounds 2 and 3 until the framer existed: 48-52 ms per snapshot.)
             ts = time.perf_counter()
             out = pub.publish()
             snap_ms.append((time.perf_counter() - ts) * 1e3)
+            snap_parts.append({k: v for k, v in pub.timings.items() if k.endswith("_ms")})
             touched.append(int(pub.timings["values"] + pub.timings["tombstones"]))
             snap_bytes.append(sum(len(x) for x in out.values()))
     eng.synchronize()
@@ -660,6 +662,8 @@ def run_c5(args):
             "ingest_only_events_per_sec_synced_per_batch": ingest_only,
             "batch_latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)), "max": float(lat.max())},
             "snapshot_ms": {"mean": float(np.mean(snap_ms)) if snap_ms else None, "max": float(np.max(snap_ms)) if snap_ms else None, "n": len(snap_ms)},
+            "snapshot_framing": "host (surge_snapshot_writer, C++ threads)" if args.host_framing else "device (surge_device_framer) + host CRC-32C",
+            "snapshot_parts_ms_mean": {k: float(np.mean([x[k] for x in snap_parts])) for k in (snap_parts[0] if snap_parts else {})},
             "snapshot_published_aggregates_mean": float(np.mean(touched)) if touched else None,
             "snapshot_record_batch_bytes_mean": float(np.mean(snap_bytes)) if snap_bytes else None,
             "groups_per_batch_mean": groups,

@@ -67,6 +67,37 @@ int32_t surge_snapshot_writer_partition(const surge_snapshot_writer* w, int32_t 
 /* Drops the bytes, keeps each partition's next offset (the log continues). */
 int32_t surge_snapshot_writer_reset(surge_snapshot_writer* w);
 
+/* ---- the same record batches, framed on the GPU ---------------------------------------------------------------------
+ * A bulk publish whose inputs are already in device memory — the delta's kind[] (surge_replay_snapshot_delta), the
+ * encoder's text and offsets (surge_replay_encode_states with the delta as filter), the key table, the partition of every
+ * aggregate — needs nothing from the host but the CRC-32C of the finished batches: the device selects the changed
+ * aggregates, orders them by partition (stable: aggregate index order inside a partition, like the writer above), cuts
+ * the batches by the same rule (a batch closes with the record that brings it to max_records or max_bytes) and writes
+ * every record and header where it goes; one copy brings the bytes to page-locked host memory, where the batches get
+ * their CRCs.  BYTE-IDENTICAL to surge_snapshot_writer_append + _flush on the same input (uncompressed batches;
+ * tests/test_frame_gpu.py).  What it is for: the state-topic side of KafkaProducerActorImpl's publish
+ * (modules/command-engine/core/src/main/scala/surge/internal/kafka/KafkaProducerActorImpl.scala:421-453) when a whole
+ * commit interval's worth of changed aggregates is published at once (config C5). */
+typedef struct surge_device_framer surge_device_framer;
+/* hip_stream: the stream the inputs are produced on (NULL = the default stream).  max_records_per_batch <= 2^20;
+ * 0 = the writer's defaults (10000 records, 1 MiB).  SURGE_E_DEVICE without a usable GPU: there is no CPU fallback
+ * (surge_snapshot_writer_* is the host path). */
+int32_t surge_device_framer_create(int32_t device_id, void* hip_stream, int32_t n_partitions, int32_t max_records_per_batch,
+                                   int64_t max_batch_bytes, surge_device_framer** out);
+int32_t surge_device_framer_destroy(surge_device_framer* f);
+const char* surge_device_framer_last_error(const surge_device_framer* f);
+/* One publish.  Device inputs, all indexed by aggregate: d_kind[n] (SURGE_SNAP_SKIP / VALUE / TOMBSTONE), d_partition[n],
+ * d_key_off[n + 1] into d_keys_utf8, d_val_off[n + 1] into d_values (read for VALUE aggregates only; the filtered
+ * encoder's output as it is).  Outputs: *bytes_out = the record batches of all partitions, partition after partition, in
+ * host memory owned by the framer (valid until its next call); (*part_byte_off_out)[p .. p+1] = partition p's span in
+ * it (n_partitions + 1 entries).  Each partition's log continues where the framer's previous call left it
+ * (surge_device_framer_next_offsets).  Synchronous.  On an error nothing is advanced. */
+int32_t surge_device_framer_frame(surge_device_framer* f, int64_t n_aggregates, const uint8_t* d_kind, const int32_t* d_partition,
+                                  const uint8_t* d_keys_utf8, const int64_t* d_key_off, const uint8_t* d_values, const int64_t* d_val_off,
+                                  int64_t timestamp_ms, const uint8_t** bytes_out, const int64_t** part_byte_off_out, int64_t* n_records_out,
+                                  int64_t* n_batches_out);
+int32_t surge_device_framer_next_offsets(const surge_device_framer* f, int64_t* out /* n_partitions */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
-SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip", "fold_slots.hip", "index_kernels.hip", "ingest_kernels.hip", "rtc.cpp", "f64_text.cpp", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "event_decode.cpp", "lz4_frame.cpp", "snapshot_writer.cpp")
+SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip", "fold_slots.hip", "index_kernels.hip", "ingest_kernels.hip", "rtc.cpp", "f64_text.cpp", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "event_decode.cpp", "lz4_frame.cpp", "snapshot_writer.cpp", "frame_kernels.hip")
 HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "fold_chunk_device.h"), os.path.join(CSRC, "fold_slots_device.h"), os.path.join(CSRC, "f64_text.h"), os.path.join(CSRC, "f64_parse.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
@@ -128,6 +128,11 @@ SNAPSHOT_EXPORTS = (
     "surge_snapshot_writer_flush",
     "surge_snapshot_writer_partition",
     "surge_snapshot_writer_reset",
+    "surge_device_framer_create",
+    "surge_device_framer_destroy",
+    "surge_device_framer_last_error",
+    "surge_device_framer_frame",
+    "surge_device_framer_next_offsets",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -306,6 +311,11 @@ def load() -> ctypes.CDLL:
         "surge_snapshot_writer_partition": ([vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
         "surge_snapshot_writer_reset": ([vp], i32),
         "surge_snapshot_writer_set_compression": ([vp, i32], i32),
+        "surge_device_framer_create": ([i32, vp, i32, i32, i64, ctypes.POINTER(vp)], i32),
+        "surge_device_framer_destroy": ([vp], i32),
+        "surge_device_framer_last_error": ([vp], ctypes.c_char_p),
+        "surge_device_framer_frame": ([vp, i64, vp, vp, vp, vp, vp, vp, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
+        "surge_device_framer_next_offsets": ([vp, vp], i32),
     })
     for name in EXPORTS + INGEST_EXPORTS + SNAPSHOT_EXPORTS:
         try:

@@ -137,18 +137,74 @@ class RecordBatchWriter:
         self._check(self._lib.surge_snapshot_writer_reset(self._h))
 
 
+class DeviceFramer:
+    """Record batches of a bulk publish framed ON THE GPU (``surge_device_framer_*`` in ``include/surge_snapshot.h``): the
+    inputs are the device arrays a publish already has (the delta's kinds, the encoder's text + offsets, the key table,
+    the partitions); the output is byte-identical to ``RecordBatchWriter.append`` + flush on the same input
+    (uncompressed batches).  Needs a GPU."""
+
+    def __init__(self, n_partitions: int, device: int = 0, max_records_per_batch: int = 0, max_batch_bytes: int = 0):
+        self._lib = _native.load()
+        self._h = ctypes.c_void_p()
+        self.n_partitions = n_partitions
+        rc = self._lib.surge_device_framer_create(device, None, n_partitions, max_records_per_batch, max_batch_bytes, ctypes.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(f"surge_device_framer_create: {rc}: {(self._lib.surge_device_framer_last_error(None) or b'').decode()}")
+        self.records = self.batches = 0
+
+    def close(self):
+        if self._h:
+            self._lib.surge_device_framer_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def frame(self, d_kind, d_partition, d_keys, d_key_off, d_values, d_val_off, timestamp_ms: Optional[int] = None) -> Dict[int, memoryview]:
+        """``{partition: record batches}`` for the aggregates with ``kind != SKIP``; CUDA tensors in (all per aggregate),
+        zero-copy views of the framer's page-locked buffer out — valid until the next call (``bytes(v)`` to keep one)."""
+        n = int(d_kind.numel())
+        if int(d_partition.numel()) < n or int(d_key_off.numel()) < n + 1 or (d_val_off is not None and int(d_val_off.numel()) < n + 1):
+            raise ValueError("partition / key_off / val_off are shorter than kind")
+        ptr = lambda t: None if t is None or int(t.numel()) == 0 else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        data, offs = ctypes.c_void_p(), ctypes.c_void_p()
+        nrec, nbat = ctypes.c_int64(), ctypes.c_int64()
+        rc = self._lib.surge_device_framer_frame(self._h, n, ptr(d_kind), ptr(d_partition), ptr(d_keys), ptr(d_key_off), ptr(d_values), ptr(d_val_off),
+                                                 int(time.time() * 1000) if timestamp_ms is None else int(timestamp_ms),
+                                                 ctypes.byref(data), ctypes.byref(offs), ctypes.byref(nrec), ctypes.byref(nbat))
+        if rc != 0:
+            raise RuntimeError(f"surge_device_framer_frame: {rc}: {(self._lib.surge_device_framer_last_error(self._h) or b'').decode()}")
+        self.records, self.batches = nrec.value, nbat.value
+        off = np.ctypeslib.as_array(ctypes.cast(offs, ctypes.POINTER(ctypes.c_int64)), shape=(self.n_partitions + 1,)).copy()
+        total = int(off[-1])
+        if total == 0:
+            return {}
+        whole = memoryview((ctypes.c_uint8 * total).from_address(data.value)).cast("B")
+        return {p: whole[int(off[p]):int(off[p + 1])] for p in range(self.n_partitions) if off[p + 1] > off[p]}
+
+    def next_offsets(self) -> np.ndarray:
+        out = np.zeros(self.n_partitions, dtype=np.int64)
+        self._lib.surge_device_framer_next_offsets(self._h, out.ctypes.data_as(ctypes.c_void_p))
+        return out
+
+
 class BulkSnapshotPublisher:
     """State-topic record batches straight from the GPU-resident states, no per-aggregate host work (N2 x N3):
 
         delta kernel (what changed since the last publish: PersistentActor.scala:212,257)
           -> GPU encoder restricted to the changed Some aggregates (writeState text; N3)
           -> K4 partitions of the aggregate ids (once per key table)
-          -> one D2H of {kinds, text, offsets} -> RecordBatch v2 encoder (C++; N2) -> bytes per partition.
+          -> uncompressed batches: DeviceFramer (records + headers written on the GPU, one D2H, CRC-32C on the host)
+             lz4 batches: one D2H of {kinds, text, offsets} -> RecordBatch v2 encoder (C++; N2)
+          -> bytes per partition (device framing: views of a page-locked buffer, valid until the next publish).
 
     ``keys`` are the aggregate ids in dense-index order; ``template`` declares the model's serialized state."""
 
     def __init__(self, engine, keys: Optional[Sequence[str]], n_partitions: int, template=None, device=None, tables=None,
-                 compression: str = "none"):
+                 compression: str = "none", device_framing: bool = True):
         """``keys``: aggregate ids in dense-index order; or ``tables = (keys_utf8, key_off, keys_utf16, off16)`` as
         tensors / arrays built without Python strings (large synthetic populations).  ``compression``: "none" or "lz4"
         (the reference producer's ``compression.type``)."""
@@ -177,10 +233,16 @@ class BulkSnapshotPublisher:
             engine.partition_hash_device(as_t(u16), as_t(o16), n_partitions, d_part, up_to_colon=True)
             engine.synchronize()
         self.partitions = d_part.cpu().numpy()
+        self.d_part = d_part
+        # uncompressed batches are framed on the device (DeviceFramer: byte-identical to the host writer); lz4 batches
+        # go through the host writer, whose compressor it is
+        self.framer = DeviceFramer(n_partitions, device=self.device.index or 0) if compression == "none" and device_framing else None
         self.timings: Dict[str, float] = {}
 
     def close(self):
         self.writer.close()
+        if self.framer is not None:
+            self.framer.close()
 
     def publish(self, commit: bool = True, timestamp_ms: Optional[int] = None) -> Dict[int, bytes]:
         """Record batches (per partition) for everything that changed since the last committed publish.
@@ -210,6 +272,16 @@ class BulkSnapshotPublisher:
             eng._check(lib.surge_replay_set_encode_filter(eng._h, None))
         torch.cuda.synchronize(self.device)
         t1 = time.perf_counter()
+        if self.framer is not None:
+            # the records and batch headers are written on the device; the host only adds the batches' CRCs
+            out = self.framer.frame(d_kind, self.d_part, self.d_keys, self.d_key_off, d_out, d_off, timestamp_ms)
+            self._pending_kind = d_kind
+            if commit:
+                self.commit_published()
+            t3 = time.perf_counter()
+            self.timings = {"gpu_delta_and_encode_ms": (t1 - t0) * 1e3, "device_framing_copy_crc_ms": (t3 - t1) * 1e3, "values": nv.value,
+                            "tombstones": nt.value, "text_bytes": int(d_off[n].item()), "batches": self.framer.batches}
+            return out
         # compact on the device: only what changed crosses PCIe and is walked by the writer (the encoder wrote text for
         # VALUE aggregates only, so the text is already contiguous and the selected offsets are its record boundaries)
         sel = torch.nonzero(d_kind).squeeze(1)
@@ -247,6 +319,13 @@ class BulkSnapshotPublisher:
         prev = getattr(self, "_pending_publish", None)
         if prev is not None:
             prev.wait()
+        if self.framer is not None:
+            # device framing leaves the host a few milliseconds of CRCs: nothing worth a thread, and one log of offsets
+            out = self.publish(commit=True, timestamp_ms=timestamp_ms)
+            pending = PendingPublish(self, None, dict(self.timings))
+            pending._out = {p: bytes(v) for p, v in out.items()}  # outlives the framer's buffer, like the writer's bytes
+            self._pending_publish = pending
+            return pending
         eng = self.engine
         n = eng.n_agg
         if n > len(self.partitions):

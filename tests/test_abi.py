@@ -43,7 +43,7 @@ def test_ingest_exports_match_their_header():
 
 def test_snapshot_writer_exports_match_their_header():
     lib = _native.load()
-    declared = header_symbols("surge_snapshot.h", "surge_snapshot_writer")
+    declared = header_symbols("surge_snapshot.h", "surge_(?:snapshot_writer|device_framer)")
     assert declared == sorted(_native.SNAPSHOT_EXPORTS)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in surge_snapshot.h but not exported"
@@ -201,3 +201,14 @@ def test_the_fake_jnienv_harness_drives_every_jni_export():
     for name in exports:
         assert harness.count(f"Java_surge_replay_gpu_NativeReplay_{name}(env") >= 1, f"{name} is never called by the harness"
         assert re.search(rf"@native def {name}\(", scala), f"{name} has no @native declaration in NativeReplay.scala"
+
+
+def test_device_framer_fails_loudly_without_a_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU; the no-device path is covered on the build container")
+    from surge_amd.snapshot import DeviceFramer
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        DeviceFramer(4)

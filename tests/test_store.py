@@ -344,7 +344,8 @@ def test_new_aggregates_after_recovery_grow_the_resident_state():
 
 
 @pytest.mark.gpu
-def test_bulk_snapshot_publish_emits_only_what_changed_as_kafka_record_batches():
+@pytest.mark.parametrize("device_framing", [True, False])
+def test_bulk_snapshot_publish_emits_only_what_changed_as_kafka_record_batches(device_framing):
     # N2 x N3 on the device path: delta kernel -> GPU JSON encoder (filtered) -> K4 partitions -> RecordBatch v2 bytes,
     # decoded again by the product's ingest.  "Nothing published when the state did not change" (PersistentActor.scala:212,257).
     import numpy as np
@@ -387,7 +388,8 @@ def test_bulk_snapshot_publish_emits_only_what_changed_as_kafka_record_batches()
     with ReplayEngine() as eng:
         eng.load_csr(so, ev)
         eng.fold()
-        pub = BulkSnapshotPublisher(eng, keys, n_part)
+        pub = BulkSnapshotPublisher(eng, keys, n_part, device_framing=device_framing)
+        assert (pub.framer is not None) == device_framing
         try:
             s1 = oracle.fold_csr(so, ev)
             got = decode(pub.publish())
@@ -426,11 +428,13 @@ def test_bulk_snapshot_publish_emits_only_what_changed_as_kafka_record_batches()
             eng.append_events(touched4.astype(np.int64), be4)
             off4 = np.zeros(n + 1, np.int64); np.cumsum(np.bincount(touched4, minlength=n), out=off4[1:])
             s5 = oracle.fold_csr(off4, be4[np.argsort(touched4, kind="stable")], s4)
-            real_append = pub.writer.append_indexed
-            pub.writer.append_indexed = lambda *a, **k: (_ for _ in ()).throw(MemoryError("framing failed"))
+            target = pub.framer if device_framing else pub.writer
+            method = "frame" if device_framing else "append_indexed"
+            real = getattr(target, method)
+            setattr(target, method, lambda *a, **k: (_ for _ in ()).throw(MemoryError("framing failed")))
             with pytest.raises(MemoryError):
                 pub.publish_async().result()
-            pub.writer.append_indexed = real_append
+            setattr(target, method, real)
             assert decode(pub.publish()) == expected(s5, s4)
         finally:
             pub.close()
