@@ -7,10 +7,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def make_input(rng, n, n_part, key_max, val_max, p_skip=0.5, p_tomb=0.1):
-    kind = rng.choice([0, 1, 2], size=n, p=[p_skip, 1 - p_skip - p_tomb, p_tomb]).astype(np.uint8)
+def make_input(rng, n, n_part, key_max, val_max, p_skip=0.5, p_tomb=0.1, key_min=0):
+    p_tomb = min(p_tomb, 1 - p_skip)
+    kind = rng.choice([0, 1, 2], size=n, p=[p_skip, max(0.0, 1 - p_skip - p_tomb), p_tomb]).astype(np.uint8)
     part = rng.integers(0, n_part, size=n).astype(np.int32)
-    klen = rng.integers(0, key_max + 1, size=n)
+    klen = rng.integers(key_min, key_max + 1, size=n)
     vlen = np.where(kind == 1, rng.integers(0, val_max + 1, size=n), 0)  # the filtered encoder writes text for VALUE aggregates only
     key_off = np.zeros(n + 1, np.int64); np.cumsum(klen, out=key_off[1:])
     val_off = np.zeros(n + 1, np.int64); np.cumsum(vlen, out=val_off[1:])
@@ -72,7 +73,7 @@ def test_device_framer_output_is_read_back_by_the_ingest_and_rejects_bad_input()
 
     rng = np.random.default_rng(3)
     n, n_part = 3000, 5
-    inp = make_input(rng, n, n_part, 9, 70, p_skip=0.3)
+    inp = make_input(rng, n, n_part, 9, 70, p_skip=0.3, key_min=1)  # (the reader treats a record without a key as a flush record)
     kind, part, keys, key_off, vals, val_off = inp
     with DeviceFramer(n_part) as f:
         got = device_frames(f, inp, 123)
