@@ -58,7 +58,7 @@ for mode in ("json", "fixed16"):
         variants = [("framing_plus_device_decoder", False)] + ([("framing_plus_device_decoder_lz4_on_device", True)] if codec == "lz4" else [])
         for label, device_lz4 in variants:
           with EventsTopicIngest(frames=True, device_lz4=device_lz4) as g, DeviceDecoder(tmpl if mode == "json" else None) as d:
-            for rep in range(2):  # the second pass runs with warm buffers and a populated key table
+            for rep in range(3):  # the last pass runs with warm buffers (both of the framer's arenas) and a populated key table
                 d.clear()
                 t0 = time.perf_counter()
                 g.feed(wire)

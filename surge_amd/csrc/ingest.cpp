@@ -240,6 +240,7 @@ struct surge_ingest {
   // The other modes only ever use the first.
   Arena arenas[2];
   int cur = 0;
+  bool handed_out = false;  // a drain has handed out spans of arenas[cur] since the last switch
   Arena& arena_now() { return arenas[cur]; }
   const Arena& arena_now() const { return arenas[cur]; }
   std::deque<Batch> queue;
@@ -477,9 +478,10 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
   if (!g) return fail(nullptr, E_INVALID, "handle is NULL");
   if (len < 0 || (!data && len > 0)) return fail(g, E_INVALID, "bad buffer");
   if (consumed_out) *consumed_out = 0;
-  if (g->frames) {
+  if (g->frames && g->handed_out) {
     // switch arenas: the sections still queued (open transactions, undrained batches) move along, the ones the last
-    // drain handed out stay untouched in the arena this feed leaves behind (valid until the feed after this one)
+    // drain handed out stay untouched in the arena this feed leaves behind (valid until the feed after this one).  A feed
+    // that follows no drain keeps appending where the last one stopped: nothing is copied.
     try {
       Arena& next = g->arenas[g->cur ^ 1];
       const Arena& prev = g->arenas[g->cur];
@@ -491,11 +493,13 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
         qb.sect_off = at;
       }
       g->cur ^= 1;
+      g->handed_out = false;
     } catch (const std::bad_alloc&) {
       return fail(g, E_NOMEM, "out of host memory while decoding");
     }
   } else if (g->queue.empty()) {
-    g->arena_now().clear();  // spans handed out by the last drain are released here
+    // nothing queued and (FRAMES: no span of this arena handed out since the switch) nothing to keep: start over
+    g->arena_now().clear();
   }
   int64_t pos = 0;
   // A failure in batch k leaves batches 0..k-1 of this buffer decoded and queued: report them as consumed so a
@@ -732,6 +736,7 @@ int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge
     g->queue.pop_front();
   }
   g->counters[2] += recs;  // handed to the device decoder (its own counters tell flush records from events)
+  if (n > 0) g->handed_out = true;
   *n_out = n;
   return OK;
 }

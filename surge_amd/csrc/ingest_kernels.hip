@@ -173,73 +173,46 @@ struct Lz4Window {
   }
 };
 
-// Pass 1: what every block decompresses to (a walk over the sequence headers only: no LDS, many waves per CU), so that
-// pass 2 can give a block the LDS it needs and not 64 KiB — the reference's producer closes a batch at 16 KiB
-// (kafka.publisher.batch-size = 16384, reference.conf:115): its blocks need a quarter of that, and four times as many
-// waves fit a CU.  sizes[b] = decompressed bytes, or -1 for a malformed block.
-__global__ void __launch_bounds__(64) lz4_size_kernel(const uint8_t* __restrict__ bytes, const Lz4Block* __restrict__ blocks, int64_t n_blocks,
-                                                      int32_t* __restrict__ sizes) {
-  const int64_t b = blockIdx.x;
-  if (b >= n_blocks) return;
-  const Lz4Block blk = blocks[b];
-  const int32_t n_in = blk.src_len & 0x7fffffff;
-  int32_t op = 0;
-  bool ok = true;
-  if (blk.src_len < 0) {
-    op = n_in;
-  } else {
-    Lz4Window w{bytes + blk.src_off, n_in, 0, 0u, (int)threadIdx.x};
-    w.refill(0);
-    int32_t ip = 0;
-    while (ip < n_in) {
-      uint32_t token;
-      int32_t lit, offset, ml;
-      if (!w.literal_length(ip, token, lit)) { ok = false; break; }
-      ip += lit;
-      op += lit;
-      if (op > kLz4BlockMax) { ok = false; break; }
-      if (ip >= n_in) break;
-      if (!w.match(ip, token, offset, ml) || offset > op) { ok = false; break; }
-      op += ml;
-      if (op > kLz4BlockMax) { ok = false; break; }
-    }
-  }
-  if (ok && !blk.last && op != kLz4BlockMax) ok = false;  // every block of a frame but its last is exactly full
-  if (threadIdx.x == 0) sizes[b] = ok ? op : -1;
-}
-
-// Pass 2: the blocks whose size is in (size_lo, size_hi] (size_hi = this launch's dynamic LDS)
+// One launch per LDS size class (16 / 32 / 64 KiB per wave), smallest first.  Nothing tells what a block decompresses to
+// but decoding it — the reference's producer closes a batch at 16 KiB (kafka.publisher.batch-size = 16384,
+// reference.conf:115), so its blocks need a quarter of the 64 KiB a block may take, and four times as many waves fit a CU
+// — so a block is TRIED in the smallest class its compressed size does not already rule out, every write bounded by the
+// class's LDS; a block that outgrows it is left for the next class (state[b] = -(class + 2)) and decoded again there from
+// its start.  (Rounds before: a separate first pass walked every block's sequence headers for its size — 1.3 ms of the
+// 5.8 ms a 1 M-record fetch spends on the device; the retry costs a producer of large batches up to a quarter of a
+// block, the 16 KiB producer nothing.)   state[b]: >= 0 decoded (its size), -1 malformed, -2 / -3 waiting for class 1 / 2.
 __global__ void __launch_bounds__(64) lz4_block_kernel(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ out_base, const Lz4Block* __restrict__ blocks,
-                                                       int64_t n_blocks, const int32_t* __restrict__ sizes, int32_t size_lo, int32_t size_hi,
+                                                       int64_t n_blocks, int32_t* __restrict__ state, int32_t cls, int32_t cap,
                                                        Section* __restrict__ sections, ErrorCell* err) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lz4_out[];
   const int lane = threadIdx.x;
   for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-    const int32_t want = sizes[b];
-    if (want < 0) {  // reported once, by the launch of the smallest class
-      if (size_lo < 0 && lane == 0) {
-        atomicMin(&err->lz4_bad, (unsigned int)blocks[b].section);
-        if (blocks[b].last) sections[blocks[b].section].byte_len = 0;
-      }
-      continue;
-    }
-    if (want <= size_lo || want > size_hi) continue;
+    if (cls > 0 && state[b] != -(cls + 1)) continue;
     const Lz4Block blk = blocks[b];
     const uint8_t* in = bytes + blk.src_off;
     const int32_t n_in = blk.src_len & 0x7fffffff;
     int32_t op = 0;
-    if (blk.src_len < 0) {  // stored
-      for (int i = lane; i < n_in; i += 64) lz4_out[i] = in[i];
-      op = n_in;
+    bool ok = true, grow = false;
+    if (!blk.last && cap < kLz4BlockMax) {  // every block of a frame but its last holds exactly 64 KiB
+      grow = true;
+    } else if (blk.src_len < 0) {  // stored
+      if (n_in > cap) {
+        grow = true;
+      } else {
+        for (int i = lane; i < n_in; i += 64) lz4_out[i] = in[i];
+        op = n_in;
+      }
+    } else if (n_in > cap + (cap >> 7) + 64) {  // a compressed block is never much longer than what it holds
+      grow = true;
     } else {
-      // pass 1 walked exactly these headers and bounded everything: no checks here
       Lz4Window w{in, n_in, 0, 0u, lane};
       w.refill(0);
       int32_t ip = 0;
       while (ip < n_in) {
         uint32_t token;
         int32_t lit, offset, ml;
-        (void)w.literal_length(ip, token, lit);
+        if (!w.literal_length(ip, token, lit)) { ok = false; break; }
+        if (lit > cap - op) { grow = true; break; }
         if (lit > 0) {
           if (lit <= 64 && ip >= w.wbase && ip + lit - w.wbase <= 256) {  // the whole run is in the window
             const int32_t idx = ip - w.wbase + lane;
@@ -252,7 +225,8 @@ __global__ void __launch_bounds__(64) lz4_block_kernel(const uint8_t* __restrict
         ip += lit;
         op += lit;
         if (ip >= n_in) break;  // the last sequence carries literals only
-        (void)w.match(ip, token, offset, ml);
+        if (!w.match(ip, token, offset, ml) || offset > op) { ok = false; break; }
+        if (ml > cap - op) { grow = true; break; }
         // (LDS operations of one wave execute in order: a read sees every earlier write of any lane of this wave)
         const uint8_t* src = lz4_out + op - offset;
         if (offset >= ml) {
@@ -263,11 +237,26 @@ __global__ void __launch_bounds__(64) lz4_block_kernel(const uint8_t* __restrict
         op += ml;
       }
     }
-    uint8_t* dst = out_base + blk.dst_off;  // 16-byte aligned: dst_off is a multiple of 64 KiB from an aligned base
-    const int n16 = op >> 4;
-    for (int i = lane; i < n16; i += 64) ((uint4*)dst)[i] = ((const uint4*)lz4_out)[i];
-    for (int i = (n16 << 4) + lane; i < op; i += 64) dst[i] = lz4_out[i];
-    if (blk.last && lane == 0) sections[blk.section].byte_len = (int64_t)blk.index * kLz4BlockMax + op;
+    if (grow && cap >= kLz4BlockMax) { grow = false; ok = false; }   // larger than a block may be
+    if (ok && !grow && !blk.last && op != kLz4BlockMax) ok = false;  // every block of a frame but its last is exactly full
+    if (grow) {
+      if (lane == 0) state[b] = -(cls + 2);
+    } else if (!ok) {
+      if (lane == 0) {
+        state[b] = -1;
+        atomicMin(&err->lz4_bad, (unsigned int)blk.section);
+        if (blk.last) sections[blk.section].byte_len = 0;
+      }
+    } else {
+      uint8_t* dst = out_base + blk.dst_off;  // 16-byte aligned: dst_off is a multiple of 64 KiB from an aligned base
+      const int n16 = op >> 4;
+      for (int i = lane; i < n16; i += 64) ((uint4*)dst)[i] = ((const uint4*)lz4_out)[i];
+      for (int i = (n16 << 4) + lane; i < op; i += 64) dst[i] = lz4_out[i];
+      if (lane == 0) {
+        state[b] = op;
+        if (blk.last) sections[blk.section].byte_len = (int64_t)blk.index * kLz4BlockMax + op;
+      }
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // the copy-out has read the LDS before the next block overwrites it
     __builtin_amdgcn_wave_barrier();
   }
@@ -1128,12 +1117,11 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
     DCHK(d, hipMemcpyAsync(d->lz4_blocks.p, blocks.data(), blocks.size() * sizeof(Lz4Block), hipMemcpyHostToDevice, st));
     DCHK(d, d->lz4_sizes.reserve(blocks.size() * 4, false, st));
     const int64_t nb = (int64_t)blocks.size();
-    hipLaunchKernelGGL(lz4_size_kernel, dim3((unsigned)nb), dim3(64), 0, st, dby, (const Lz4Block*)d->lz4_blocks.p, nb, (int32_t*)d->lz4_sizes.p);
     const unsigned grid = (unsigned)(nb < 8192 ? nb : 8192);
-    const int32_t classes[4] = {-1, 16384, 32768, kLz4BlockMax};  // LDS per wave of the three launches: 16 / 32 / 64 KiB
+    const int32_t caps[3] = {16384, 32768, kLz4BlockMax};  // LDS per wave of the three launches
     for (int c = 0; c < 3; ++c)
-      hipLaunchKernelGGL(lz4_block_kernel, dim3(grid), dim3(64), (size_t)classes[c + 1], st, dby, (uint8_t*)d->d_bytes.p + area_base,
-                         (const Lz4Block*)d->lz4_blocks.p, nb, (const int32_t*)d->lz4_sizes.p, classes[c], classes[c + 1], dsec, derr);
+      hipLaunchKernelGGL(lz4_block_kernel, dim3(grid), dim3(64), (size_t)caps[c], st, dby, (uint8_t*)d->d_bytes.p + area_base,
+                         (const Lz4Block*)d->lz4_blocks.p, nb, (int32_t*)d->lz4_sizes.p, c, caps[c], dsec, derr);
     // a frame that does not decode fails the push HERE, before any key of the push is interned (`blocks` is host memory:
     // the copy has to be done before it goes out of scope anyway)
     ErrorCell lz;
