@@ -620,29 +620,57 @@ __device__ uint32_t decode_json_event(const surge_event_json_template* t, const 
   return status;
 }
 
-__global__ void resolve_kernel(RecMeta* __restrict__ meta, int64_t n_rec, const uint8_t* __restrict__ bytes, Table t,
-                               const uint8_t* __restrict__ arena, const int64_t* __restrict__ key_off, const surge_event_json_template* tmpl,
-                               const surge::F64ParseTable* ptab, int64_t* __restrict__ agg_tmp, uint4* __restrict__ ev_tmp,
-                               uint32_t* __restrict__ keep, uint32_t* __restrict__ f64_host_list, ErrorCell* err) {
+// One thread per record.  The records of a block lie next to each other in the staged bytes (a section's records are
+// contiguous), so the block first copies the span that holds its keys and values into LDS with 16-byte loads and every
+// thread then walks its JSON text there: the walk is a chain of dependent single-byte reads, and an LDS read answers in
+// a tenth of the time a global one does (1.3 ms -> see DESIGN N1 per 1 M records).  A span that does not fit (records
+// handed over as separate key / value arrays, very long values) is read in place.
+constexpr int kResolveStage = 40960;
+__global__ void __launch_bounds__(256) resolve_kernel(RecMeta* __restrict__ meta, int64_t n_rec, const uint8_t* __restrict__ bytes, Table t,
+                                                      const uint8_t* __restrict__ arena, const int64_t* __restrict__ key_off,
+                                                      const surge_event_json_template* tmpl, const surge::F64ParseTable* ptab,
+                                                      int64_t* __restrict__ agg_tmp, uint4* __restrict__ ev_tmp, uint32_t* __restrict__ keep,
+                                                      uint32_t* __restrict__ f64_host_list, ErrorCell* err) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+  __shared__ unsigned long long s_lo, s_hi;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  RecMeta m;
+  m.status = RS_MALFORMED;
+  if (i < n_rec) m = meta[i];
+  const bool live = i < n_rec && m.status == RS_OK;
+  if (threadIdx.x == 0) { s_lo = ~0ull; s_hi = 0ull; }
+  __syncthreads();
+  if (live) {
+    const int64_t v1 = m.val_off + (m.val_len > 0 ? m.val_len : 0), k1 = m.key_off + (m.key_len > 0 ? m.key_len : 0);
+    atomicMin(&s_lo, (unsigned long long)(m.key_off < m.val_off ? m.key_off : m.val_off));
+    atomicMax(&s_hi, (unsigned long long)(v1 > k1 ? v1 : k1));
+  }
+  __syncthreads();
+  const unsigned long long lo = s_lo & ~15ull, hi = s_hi;
+  const bool staged = hi > lo && hi - lo <= (unsigned long long)kResolveStage;  // block-uniform
+  if (staged) {
+    const int n16 = (int)((hi - lo + 15) >> 4);  // the staged bytes buffer ends 16 bytes after its last byte
+    for (int c = threadIdx.x; c < n16; c += blockDim.x) ((uint4*)stage)[c] = *(const uint4*)(bytes + lo + 16ull * (unsigned)c);
+    __syncthreads();
+  }
   if (i >= n_rec) return;
-  RecMeta m = meta[i];
   uint32_t k = 0;
-  if (m.status == RS_OK) {
+  if (live) {
+    const uint8_t* kp = staged ? (const uint8_t*)stage + (m.key_off - (int64_t)lo) : bytes + m.key_off;
+    const uint8_t* vp = staged ? (const uint8_t*)stage + (m.val_off - (int64_t)lo) : bytes + m.val_off;
     const uint32_t id = t.key_id[m.slot];
     const int64_t a0 = key_off[id], a1 = key_off[id + 1];
     bool same = a1 - a0 == m.key_len;
-    for (int b = 0; same && b < m.key_len; ++b) same = arena[a0 + b] == bytes[m.key_off + b];
+    for (int b = 0; same && b < m.key_len; ++b) same = arena[a0 + b] == kp[b];
     uint4 e = make_uint4(0, 0, 0, 0);
     uint32_t st = RS_OK;
     if (!same) {
       st = RS_COLLISION;
     } else if (tmpl) {
-      st = decode_json_event(tmpl, ptab, bytes + m.val_off, m.val_len, &e);
+      st = decode_json_event(tmpl, ptab, vp, m.val_len, &e);
     } else if (m.val_len == 16) {
-      const uint8_t* v = bytes + m.val_off;
       uint32_t w[4];
-      for (int q = 0; q < 4; ++q) w[q] = (uint32_t)v[4 * q] | ((uint32_t)v[4 * q + 1] << 8) | ((uint32_t)v[4 * q + 2] << 16) | ((uint32_t)v[4 * q + 3] << 24);
+      for (int q = 0; q < 4; ++q) w[q] = (uint32_t)vp[4 * q] | ((uint32_t)vp[4 * q + 1] << 8) | ((uint32_t)vp[4 * q + 2] << 16) | ((uint32_t)vp[4 * q + 3] << 24);
       e = make_uint4(w[0], w[1], w[2], w[3]);
     } else {
       st = RS_SIZE;
@@ -906,7 +934,7 @@ int32_t finish_push(surge_device_decoder* d, int64_t n_rec) {
     d->n_keys += n_new;
     d->arena_bytes += new_bytes;
   }
-  hipLaunchKernelGGL(resolve_kernel, dim3(rb), dim3(256), 0, st, dmeta, n_rec, dby, table_of(d), (const uint8_t*)d->arena.p, (const int64_t*)d->key_off.p,
+  hipLaunchKernelGGL(resolve_kernel, dim3(rb), dim3(256), (size_t)kResolveStage, st, dmeta, n_rec, dby, table_of(d), (const uint8_t*)d->arena.p, (const int64_t*)d->key_off.p,
                      d->json ? (const surge_event_json_template*)d->d_tmpl.p : nullptr, (const surge::F64ParseTable*)d->d_ptab.p,
                      (int64_t*)d->agg_tmp.p, (uint4*)d->ev_tmp.p, (uint32_t*)d->keep.p, (uint32_t*)d->f64_list.p, derr);
   // the first-record marks of this push's new slots are spent
