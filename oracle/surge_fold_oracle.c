@@ -16,7 +16,12 @@
  *     (oracle_murmur3_x86_32 below is assembled from the same primitives) and against scikit-learn's
  *     bundled reference MurmurHash3_x86_32 on random inputs; what remains unpinned is stringHash's
  *     framing (seed, char-pair order, char count) — tools/MurmurPin.scala;
- *   - play-json 2.9.2 number/text formatting used by TestBoundedContext.scala:127-133.
+ *   - play-json 2.9.2 number/text formatting used by TestBoundedContext.scala:127-133 and (Doubles)
+ *     BankAccountSurgeModel.scala:22-32 — restated in oracle.py (play_json_double_text) from the published pieces:
+ *     java.lang.Double.toString's shortest digits (JDK >= 19; pinned here against Python's repr, the same shortest
+ *     round-trip digits, on tens of thousands of random doubles plus subnormal / boundary cases), BigDecimal.valueOf +
+ *     stripTrailingZeros + toPlainString / toString switch as play-json's JsNumber writer applies them; the product's
+ *     GPU and host formatters are checked against THAT (tests/test_f64_text.py), no JVM-produced text exists here.
  *
  * Everything here is written as a literal, sequential, one-event-at-a-time
  * reading of the Scala code it cites — deliberately NOT the transformer-monoid
