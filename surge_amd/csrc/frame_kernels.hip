@@ -69,6 +69,18 @@ __device__ inline uint8_t* put_varint(uint8_t* p, int64_t x) {
   return p;
 }
 
+// a record's key / value, 8 bytes at a time: neither end is aligned, which global memory on gfx9+ does not ask for (the
+// byte loop this replaces made the write kernel 1.9 ms of an 85 MB publish)
+__device__ inline void copy_bytes(uint8_t* dst, const uint8_t* src, int64_t n) {
+  int64_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t v;
+    __builtin_memcpy(&v, src + i, 8);
+    __builtin_memcpy(dst + i, &v, 8);
+  }
+  for (; i < n; ++i) dst[i] = src[i];
+}
+
 __device__ inline void put_be(uint8_t* p, uint64_t x, int n) {
   for (int i = 0; i < n; ++i) p[i] = (uint8_t)(x >> (8 * (n - 1 - i)));
 }
@@ -197,12 +209,12 @@ __global__ void frame_write_kernel(const Batch* __restrict__ batches, int64_t n_
   p = put_varint(p, d);
   const int64_t k0 = key_off[a], klen = key_off[a + 1] - k0;
   p = put_varint(p, klen);
-  for (int64_t i = 0; i < klen; ++i) p[i] = keys_utf8[k0 + i];
+  copy_bytes(p, keys_utf8 + k0, klen);
   p += klen;
   if (kind[a] == SURGE_SNAP_VALUE) {
     const int64_t v0 = val_off[a], vlen = val_off[a + 1] - v0;
     p = put_varint(p, vlen);
-    for (int64_t i = 0; i < vlen; ++i) p[i] = values[v0 + i];
+    copy_bytes(p, values + v0, vlen);
     p += vlen;
   } else {
     p = put_varint(p, -1);  // null value: a tombstone

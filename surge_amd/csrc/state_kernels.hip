@@ -362,26 +362,41 @@ __global__ void gather_states_kernel(const uint4* __restrict__ states, const int
 // snapshot delta: kind[a] = what the state topic needs for aggregate a relative to the last committed snapshot
 // ("publish only if the state changed", PersistentActor.scala:212,257): unchanged or poisoned -> SKIP, Some -> VALUE,
 // Some -> None -> TOMBSTONE.  counts[0] += values, counts[1] += tombstones.
+// Four lanes per aggregate, one 16-byte quarter of the state each: every load instruction of a wave covers 1 KiB of
+// contiguous memory (one thread per aggregate read its 48 bytes at a 64-byte stride: 1.9 ms for 10 M aggregates where the
+// 1.28 GB it compares stream in 0.3 ms), the quartet agrees through one ballot, and the counters get one atomic per wave
+// of a grid-stride launch instead of one per 64 aggregates.
 template <bool FULL64>
-__global__ void snapshot_delta_kernel(const uint4* __restrict__ states, const uint4* __restrict__ published, int64_t n,
-                                      uint8_t* __restrict__ kind, unsigned long long* __restrict__ counts) {
-  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t k = SURGE_SNAP_SKIP;
-  if (a < n) {
-    const uint4 s0 = states[a * 4], s1 = states[a * 4 + 1], s2 = states[a * 4 + 2];
-    const uint4 p0 = published[a * 4], p1 = published[a * 4 + 1], p2 = published[a * 4 + 2];
-    bool same = s0.x == p0.x && s0.y == p0.y && s0.z == p0.z && s0.w == p0.w && s1.x == p1.x && s1.y == p1.y && s1.z == p1.z &&
-                s1.w == p1.w && s2.x == p2.x && s2.y == p2.y;  // v1: bytes 0..39 carry the state (the tail is always zero)
-    if (FULL64) {  // v2 slot schemas use all 64 bytes
-      const uint4 s3 = states[a * 4 + 3], p3 = published[a * 4 + 3];
-      same = same && s2.z == p2.z && s2.w == p2.w && s3.x == p3.x && s3.y == p3.y && s3.z == p3.z && s3.w == p3.w;
+__global__ void __launch_bounds__(256) snapshot_delta_kernel(const uint4* __restrict__ states, const uint4* __restrict__ published, int64_t n,
+                                                             uint8_t* __restrict__ kind, unsigned long long* __restrict__ counts) {
+  const int lane = threadIdx.x & 63, quad = lane & ~3, part = lane & 3;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;  // a multiple of 4: a lane keeps its quarter
+  uint32_t nv = 0, nt = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * 4; i += stride) {
+    const uint4 s = states[i], p = published[i];
+    bool differs;
+    if (part < 2) {
+      differs = s.x != p.x || s.y != p.y || s.z != p.z || s.w != p.w;
+    } else if (part == 2) {  // v1: bytes 0..39 carry the state (the tail is always zero); v2 slot schemas use all 64 bytes
+      differs = s.x != p.x || s.y != p.y || (FULL64 && (s.z != p.z || s.w != p.w));
+    } else {
+      differs = FULL64 && (s.x != p.x || s.y != p.y || s.z != p.z || s.w != p.w);
     }
-    const bool poisoned = (s2.y & FL_POISONED) != 0u;
-    if (!same && !poisoned) k = (s2.y & FL_PRESENT) ? SURGE_SNAP_VALUE : SURGE_SNAP_TOMBSTONE;
-    kind[a] = (uint8_t)k;
+    const unsigned long long d = __ballot(differs);
+    const uint32_t flags = (uint32_t)__shfl((int)s.y, quad + 2, 64);  // the flags word lives in the third quarter
+    if (part == 0) {
+      uint32_t k = SURGE_SNAP_SKIP;
+      if (((d >> quad) & 0xFull) != 0ull && !(flags & FL_POISONED)) k = (flags & FL_PRESENT) ? SURGE_SNAP_VALUE : SURGE_SNAP_TOMBSTONE;
+      kind[i >> 2] = (uint8_t)k;
+      nv += k == SURGE_SNAP_VALUE;
+      nt += k == SURGE_SNAP_TOMBSTONE;
+    }
   }
-  const int nv = __popcll(__ballot(k == SURGE_SNAP_VALUE)), nt = __popcll(__ballot(k == SURGE_SNAP_TOMBSTONE));
-  if ((threadIdx.x & 63) == 0) {
+  for (int o = 32; o > 0; o >>= 1) {
+    nv += (uint32_t)__shfl_down((int)nv, o, 64);
+    nt += (uint32_t)__shfl_down((int)nt, o, 64);
+  }
+  if (lane == 0) {
     if (nv) atomicAdd(&counts[0], (unsigned long long)nv);
     if (nt) atomicAdd(&counts[1], (unsigned long long)nt);
   }
@@ -488,10 +503,12 @@ hipError_t launch_snapshot_delta(const uint4* states, uint4* published, int64_t 
                                  bool commit, bool full64, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(d_counts, 0, 16, stream);
   if (e != hipSuccess || n <= 0) return e;
+  const int64_t want = (n * 4 + 255) / 256;
+  const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
   if (full64)
-    hipLaunchKernelGGL(snapshot_delta_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, states, published, n, kind, d_counts);
+    hipLaunchKernelGGL(snapshot_delta_kernel<true>, dim3(grid), dim3(256), 0, stream, states, published, n, kind, d_counts);
   else
-    hipLaunchKernelGGL(snapshot_delta_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, states, published, n, kind, d_counts);
+    hipLaunchKernelGGL(snapshot_delta_kernel<false>, dim3(grid), dim3(256), 0, stream, states, published, n, kind, d_counts);
   if (commit)
     hipLaunchKernelGGL(snapshot_commit_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, stream, states, published, n, kind);
   return hipGetLastError();

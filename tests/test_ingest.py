@@ -644,3 +644,28 @@ def test_framed_fetches_yield_the_same_sections_one_fetch_ahead_as_inline():
         next(it)
         with pytest.raises(IngestError):
             next(it)
+
+
+def test_framed_fetches_can_be_abandoned_midway_without_hanging():
+    import threading
+    import time
+
+    from surge_amd.ingest import FramedFetches
+
+    ev = lambda seq: counter_event(S.EVT_INC, seq, seq)
+    fetches = [kw.record_batch(10 * i, [(b"k:%d" % j, ev(10 * i + j + 1)) for j in range(10)]) for i in range(50)]
+    done = []
+
+    def consume():
+        with FramedFetches(iter(fetches)) as framed:
+            for n, (sections, arena) in enumerate(framed):
+                assert _section_bytes(sections, arena) == [fetches[n][61:]]
+                if n == 2:
+                    break  # the framing thread is waiting for a free arena: close() has to release it
+        done.append(True)
+
+    t = threading.Thread(target=consume, daemon=True)
+    t0 = time.time()
+    t.start()
+    t.join(timeout=20)
+    assert done == [True] and time.time() - t0 < 20
