@@ -88,8 +88,9 @@ __device__ inline void put_be(uint8_t* p, uint64_t x, int n) {
 // per selected record r (aggregate sel[r]): its partition and the size of its body without the offsetDelta; bad[0] is
 // set when a partition is out of range, a span is negative or a kind is unknown
 __global__ void frame_size_kernel(const int64_t* __restrict__ sel, int64_t n_sel, const uint8_t* __restrict__ kind, const int32_t* __restrict__ part,
-                                  int32_t n_part, const int64_t* __restrict__ key_off, const int64_t* __restrict__ val_off,
-                                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ base, uint32_t* __restrict__ bad) {
+                                  int32_t n_part, const int64_t* __restrict__ key_off, const int64_t* __restrict__ val_off, bool have_keys,
+                                  bool have_values, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ base,
+                                  uint32_t* __restrict__ bad) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_sel) return;
   const int64_t a = sel[r];
@@ -99,7 +100,7 @@ __global__ void frame_size_kernel(const int64_t* __restrict__ sel, int64_t n_sel
   const int64_t klen = key_off[a + 1] - key_off[a];
   const int64_t vlen = value && val_off ? val_off[a + 1] - val_off[a] : -1;
   if ((!value && k != SURGE_SNAP_TOMBSTONE) || p < 0 || p >= n_part || klen < 0 || (value && (!val_off || vlen < 0)) || klen > (1 << 28) ||
-      vlen > (1 << 28))
+      vlen > (1 << 28) || (klen > 0 && !have_keys) || (vlen > 0 && !have_values))
     atomicOr(bad, 1u);
   keys[r] = (uint32_t)(p < 0 ? 0 : p);
   vals[r] = (uint32_t)r;
@@ -397,7 +398,7 @@ int32_t surge_device_framer_frame(surge_device_framer* f, int64_t n_aggregates, 
   FCHK(f, f->pbytes.reserve((size_t)(P + 1) * 8));
   FCHK(f, f->d_next.reserve((size_t)P * 8));
   hipLaunchKernelGGL(frame_size_kernel, dim3(grid(n_sel)), dim3(256), 0, st, (const int64_t*)f->sel.p, n_sel, d_kind, d_partition, P, d_key_off, d_val_off,
-                     (uint32_t*)f->keys_a.p, (uint32_t*)f->vals_a.p, (uint32_t*)f->base.p, (uint32_t*)f->bad.p);
+                     d_keys_utf8 != nullptr, d_values != nullptr, (uint32_t*)f->keys_a.p, (uint32_t*)f->vals_a.p, (uint32_t*)f->base.p, (uint32_t*)f->bad.p);
   FCHK(f, rocprim::radix_sort_pairs(f->temp.p, tb_sort, (const uint32_t*)f->keys_a.p, (uint32_t*)f->keys_b.p, (const uint32_t*)f->vals_a.p,
                                     (uint32_t*)f->vals_b.p, (size_t)n_sel, 0u, bits, st));
   const uint32_t* order = (const uint32_t*)f->vals_b.p;
@@ -436,7 +437,7 @@ int32_t surge_device_framer_frame(surge_device_framer* f, int64_t n_aggregates, 
   FCHK(f, hipStreamSynchronize(st));
   if (bad) {
     std::fill(f->part_byte_off.begin(), f->part_byte_off.end(), 0);
-    return ffail(f, E_RANGE, "a changed aggregate has an unknown kind, a partition outside [0, n_partitions) or a negative key / value span");
+    return ffail(f, E_RANGE, "a changed aggregate has an unknown kind, a partition outside [0, n_partitions), a negative key / value span, or bytes in a table that was passed as NULL");
   }
   const int64_t n_batches = totals[0], n_bytes = totals[1];
   FCHK(f, f->batches.reserve((size_t)n_batches * sizeof(Batch)));

@@ -196,18 +196,30 @@ while time.time() < t_end:
         n = lib.surge_format_f64_json(ctypes.c_uint64(rng.getrandbits(64)), out, 26)
         assert 0 <= n <= 26
     # the framing mode of the decoder (device decode): sections must lie inside the arena, whatever was fed
+    # Several fetches through one framer: what a drain handed out must stay readable, unchanged, THROUGH the next feed (the
+    # two arenas alternate; transactions left open by one fetch travel to the next arena) — a freed or overwritten arena is
+    # an ASan report / a changed byte here.
     hf = vp()
     assert lib.surge_ingest_create(1 | 0x100, ctypes.byref(hf)) == 0
-    wire2 = mutate(valid_wire()) if rng.random() < 0.7 else valid_wire()
-    consumed2 = i64()
-    lib.surge_ingest_feed(hf, wire2, len(wire2), ctypes.byref(consumed2))
-    secs = (i64 * (4 * 64))()
-    n_sec = i64()
-    assert lib.surge_ingest_drain_sections(hf, 64, secs, ctypes.byref(n_sec)) == 0
-    for k in range(n_sec.value):
-        byte_off, byte_len = secs[4 * k], secs[4 * k + 1]
-        assert byte_off >= 0 and byte_len >= 0
-        if byte_len:
-            ctypes.string_at(ctypes.addressof(lib.surge_ingest_arena(hf).contents) + byte_off, byte_len)  # readable end to end (ASan checks)
+    held = []  # (address, bytes) of the sections of the previous drain
+    for fetch in range(rng.randrange(1, 6)):
+        wire2 = mutate(valid_wire()) if rng.random() < 0.5 else valid_wire()
+        consumed2 = i64()
+        lib.surge_ingest_feed(hf, wire2, len(wire2), ctypes.byref(consumed2))
+        for addr, data in held:
+            assert ctypes.string_at(addr, len(data)) == data
+        if rng.random() < 0.25:
+            continue  # a feed that is followed by no drain: the next feed keeps appending (and may grow) the same arena
+        secs = (i64 * (4 * 64))()
+        n_sec = i64()
+        assert lib.surge_ingest_drain_sections(hf, 64, secs, ctypes.byref(n_sec)) == 0
+        if n_sec.value:
+            held = []
+        for k in range(n_sec.value):
+            byte_off, byte_len = secs[4 * k], secs[4 * k + 1]
+            assert byte_off >= 0 and byte_len >= 0
+            if byte_len:
+                addr = ctypes.addressof(lib.surge_ingest_arena(hf).contents) + byte_off
+                held.append((addr, ctypes.string_at(addr, byte_len)))  # readable end to end (ASan checks)
     lib.surge_ingest_destroy(hf)
 print(f"OK {rounds} rounds")
