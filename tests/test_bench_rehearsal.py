@@ -97,3 +97,17 @@ def test_bench_workload_e2e_goes_from_topic_bytes_to_states_and_checks_them():
     cfg = d["config"]
     assert cfg["fetch_records"] == n and cfg["decoder_counters"]["records_delivered"] == n * 4 and cfg["aggregates_seen"] > 1000
     assert d["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_decoded_events"] is True and d["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--host-framing"], ["--device-batches"]])
+def test_bench_workload_c5_streams_micro_batches_publishes_deltas_and_checks_the_whole_run(extra):
+    """BASELINE config 5 as the driver can start it, at a small size: micro-batches onto the resident state, a state-topic
+    delta every 10 batches (framed on the device, or by the host writer), the resident state after the run equal to the
+    oracle's replay of the same batches."""
+    d = run_single(["--workload", "c5", "--aggregates", "50000", "--batch-events", "5000", "--steps", "40", "--warmup", "3", "--snapshot-every", "10"] + extra)
+    cfg = d["config"]
+    assert cfg["snapshot_ms"]["n"] == 4 and cfg["snapshot_published_aggregates_mean"] > 1000 and cfg["snapshot_record_batch_bytes_mean"] > 50_000
+    assert cfg["snapshot_framing"].startswith("host" if "--host-framing" in extra else "device")
+    assert ("device_framing_copy_crc_ms" in cfg["snapshot_parts_ms_mean"]) == ("--host-framing" not in extra)
+    assert d["cpu_baseline"]["gpu_matches_cpu_full_run"] is True and d["value"] > 0 and d["roofline"]["kernel"].startswith("fold_kernel<FLAT")
