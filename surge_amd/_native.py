@@ -83,6 +83,7 @@ INGEST_EXPORTS = (
     "surge_ingest_destroy",
     "surge_ingest_last_error",
     "surge_ingest_feed",
+    "surge_ingest_set_threads",
     "surge_ingest_ready",
     "surge_ingest_drain",
     "surge_ingest_arena",
@@ -268,6 +269,7 @@ def load() -> ctypes.CDLL:
         "surge_ingest_destroy": ([vp], i32),
         "surge_ingest_last_error": ([vp], ctypes.c_char_p),
         "surge_ingest_feed": ([vp, vp, i64, ctypes.POINTER(i64)], i32),
+        "surge_ingest_set_threads": ([vp, i32], i32),
         "surge_ingest_ready": ([vp], i64),
         "surge_ingest_drain": ([vp, i64, vp, ctypes.POINTER(i64)], i32),
         "surge_ingest_arena": ([vp], vp),

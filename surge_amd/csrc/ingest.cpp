@@ -7,6 +7,8 @@
 #include <deque>
 #include <new>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/surge_ingest.h"
@@ -241,6 +243,7 @@ struct surge_ingest {
   Arena arenas[2];
   int cur = 0;
   bool handed_out = false;  // a drain has handed out spans of arenas[cur] since the last switch
+  int crc_threads = 1;      // surge_ingest_set_threads: host threads that verify the batches' CRC-32C of one feed
   Arena& arena_now() { return arenas[cur]; }
   const Arena& arena_now() const { return arenas[cur]; }
   std::deque<Batch> queue;
@@ -474,6 +477,49 @@ int32_t surge_ingest_destroy(surge_ingest* g) {
 
 const char* surge_ingest_last_error(const surge_ingest* g) { return g ? g->err.c_str() : g_err.c_str(); }
 
+namespace {
+
+// The whole batches at the front of data[0, len), found the way surge_ingest_feed's walk finds them (it stops where this
+// stops: a batchLength below the header size, a cut batch, a magic other than 2), and for each whether its CRC-32C holds.
+void verify_crcs_in_parallel(const uint8_t* data, int64_t len, int n_threads, std::vector<uint8_t>* ok) {
+  struct Span { const uint8_t* from; int64_t n; uint32_t crc; };
+  std::vector<Span> spans;
+  int64_t pos = 0;
+  while (len - pos >= 12) {
+    const uint8_t* h = data + pos;
+    const int32_t batch_len = (int32_t)(((uint32_t)h[8] << 24) | ((uint32_t)h[9] << 16) | ((uint32_t)h[10] << 8) | h[11]);
+    if (batch_len < 49 || len - pos - 12 < batch_len) break;
+    if (h[16] != 2) break;
+    const uint32_t crc = ((uint32_t)h[17] << 24) | ((uint32_t)h[18] << 16) | ((uint32_t)h[19] << 8) | h[20];
+    spans.push_back(Span{h + 21, (int64_t)batch_len - 9, crc});  // attributes .. end of the batch
+    pos += 12 + (int64_t)batch_len;
+  }
+  ok->assign(spans.size(), 0);
+  if (spans.empty()) return;
+  (void)surge_crc32c((const uint8_t*)"", 0);  // initialise the dispatch / tables before threads race for them
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    constexpr size_t kGrab = 32;
+    for (size_t b = next.fetch_add(kGrab); b < spans.size(); b = next.fetch_add(kGrab))
+      for (size_t k = b; k < spans.size() && k < b + kGrab; ++k) (*ok)[k] = surge_crc32c(spans[k].from, spans[k].n) == spans[k].crc;
+  };
+  std::vector<std::thread> th;
+  try {
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(work);
+  } catch (...) {  // the threads that did start, and this one, do the work
+  }
+  work();
+  for (std::thread& t : th) t.join();
+}
+
+}  // namespace
+
+int32_t surge_ingest_set_threads(surge_ingest* g, int32_t n_threads) {
+  if (!g || n_threads < 1 || n_threads > 64) return fail(g, E_INVALID, "threads must be in 1 .. 64");
+  g->crc_threads = n_threads;
+  return OK;
+}
+
 int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int64_t* consumed_out) {
   if (!g) return fail(nullptr, E_INVALID, "handle is NULL");
   if (len < 0 || (!data && len > 0)) return fail(g, E_INVALID, "bad buffer");
@@ -502,6 +548,18 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
     g->arena_now().clear();
   }
   int64_t pos = 0;
+  // With more than one CRC thread the batches' checksums are verified up front, in parallel (a batch's CRC depends on
+  // nothing but its own bytes; the walk below then looks the verdicts up in order, so what is reported, and when, is
+  // exactly what the one-thread walk reports).
+  std::vector<uint8_t> crc_ok;
+  if (g->crc_threads > 1 && len >= (1 << 20)) {
+    try {
+      verify_crcs_in_parallel(data, len, g->crc_threads, &crc_ok);
+    } catch (...) {  // no memory / no thread: the walk computes the CRCs itself
+      crc_ok.clear();
+    }
+  }
+  size_t batch_no = 0;
   // A failure in batch k leaves batches 0..k-1 of this buffer decoded and queued: report them as consumed so a
   // caller that retries (or skips the bad batch) never feeds them twice.
   auto bail = [&](int32_t code, const char* msg) {
@@ -521,7 +579,9 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
       const uint8_t magic = r.u8();
       if (magic != 2) return bail(E_UNSUPPORTED, "only message format v2 (magic 2) is supported");
       const uint32_t crc = (uint32_t)r.i32();
-      if (surge_crc32c(r.p, r.end - r.p) != crc) return bail(SURGE_E_CORRUPT, "record batch CRC-32C mismatch");
+      const bool crc_good = batch_no < crc_ok.size() ? crc_ok[batch_no] != 0 : surge_crc32c(r.p, r.end - r.p) == crc;
+      ++batch_no;
+      if (!crc_good) return bail(SURGE_E_CORRUPT, "record batch CRC-32C mismatch");
       const int16_t attrs = r.i16();
       (void)r.i32();  // lastOffsetDelta
       (void)r.i64();  // baseTimestamp

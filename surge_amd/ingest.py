@@ -83,7 +83,7 @@ class IngestError(RuntimeError):
 
 
 class EventsTopicIngest:
-    def __init__(self, isolation_level: int = READ_COMMITTED, frames: bool = False, device_lz4: bool = False):
+    def __init__(self, isolation_level: int = READ_COMMITTED, frames: bool = False, device_lz4: bool = False, threads: int = 1):
         self._lib = _native.load()
         self._h = ctypes.c_void_p()
         self.frames = frames
@@ -93,6 +93,8 @@ class EventsTopicIngest:
         if frames or device_lz4:
             # page-locked arena when a GPU is there: the device decoder copies out of it in place (a pageable arena works too)
             self._lib.surge_ingest_use_pinned_arena(self._h)
+        if threads != 1:  # host threads verifying the batches' CRC-32C of one feed (surge_ingest_set_threads)
+            self._check(self._lib.surge_ingest_set_threads(self._h, int(threads)))
         self._tail = b""
 
     def close(self):
@@ -205,11 +207,11 @@ class FramedFetches:
     Iterating yields ``(sections, arena_address)`` per fetch, in order.  ``overlap=False`` frames inline (same results,
     one thread)."""
 
-    def __init__(self, fetches, isolation_level: int = READ_COMMITTED, device_lz4: bool = True, overlap: bool = True):
+    def __init__(self, fetches, isolation_level: int = READ_COMMITTED, device_lz4: bool = True, overlap: bool = True, threads: int = 1):
         import queue
         import threading
 
-        self._g = EventsTopicIngest(isolation_level, frames=True, device_lz4=device_lz4)
+        self._g = EventsTopicIngest(isolation_level, frames=True, device_lz4=device_lz4, threads=threads)
         self._fetches = iter(fetches)
         self._overlap = overlap
         self.framing_seconds: List[float] = []

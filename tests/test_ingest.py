@@ -669,3 +669,54 @@ def test_framed_fetches_can_be_abandoned_midway_without_hanging():
     t.start()
     t.join(timeout=20)
     assert done == [True] and time.time() - t0 < 20
+
+
+@pytest.mark.parametrize("frames", [False, True])
+def test_crc_threads_give_the_same_records_counters_and_errors_as_one_thread(frames):
+    """surge_ingest_set_threads: the batches' CRCs of a feed are verified up front on several threads; everything the feed
+    reports — records, counters, WHICH batch fails and how many bytes count as consumed — is what one thread reports."""
+    rnd = random.Random(21)
+    ev = lambda seq: counter_event(S.EVT_INC, seq, seq)
+    batches, off = [], 0
+    for b in range(1500):
+        n = rnd.randrange(1, 60)
+        tx = b % 7 == 0
+        batches.append(kw.record_batch(off, [(b"k%d:%d" % (rnd.randrange(500), i), ev(off + i + 1)) for i in range(n)],
+                                       compression=rnd.choice(["none", "lz4"]), transactional=tx, producer_id=4))
+        off += n
+        if tx:
+            batches.append(kw.control_batch(off, 4, kw.ABORT if b % 21 == 0 else kw.COMMIT))
+            off += 1
+    good = b"".join(batches)
+    assert len(good) > (1 << 20)  # below 1 MiB a feed does not bother with threads
+    cut = good[: len(good) - 13]  # a fetch that ends inside a batch
+    k = 700
+    at = sum(len(x) for x in batches[:k])
+    bad_crc = bytearray(good); bad_crc[at + 70] ^= 0x10             # a payload byte of batch k: its CRC no longer holds
+    bad_magic = bytearray(good); bad_magic[at + 16] = 1             # batch k claims message format v1
+    bad_len = bytearray(good); bad_len[at + 8:at + 12] = b"\x00\x00\x00\x05"  # batchLength below the header size
+
+    def run(wire, threads):
+        with EventsTopicIngest(frames=frames, threads=threads) as g:
+            err = None
+            consumed = 0
+            try:
+                consumed = g.feed(bytes(wire))
+            except IngestError as e:
+                err = (e.status, str(e))
+                consumed = len(wire) - len(g._tail)
+            if frames:
+                sections, arena = g.drain_sections()
+                got = [(int(x["base_offset"]), int(x["n_records"]), int(x["codec"]), b) for x, b in zip(sections, _section_bytes(sections, arena))]
+            else:
+                got = g.drain_records()
+            return err, consumed, got, g.counters()
+
+    for wire in (good, cut, bad_crc, bad_magic, bad_len):
+        one = run(wire, 1)
+        for threads in (2, 5):
+            assert run(wire, threads) == one
+    assert run(bad_crc, 4)[0][0] == -7 and run(bad_crc, 4)[1] == at  # the bytes of the good batches before it count as consumed
+    with EventsTopicIngest() as g:
+        with pytest.raises(IngestError):
+            g._check(g._lib.surge_ingest_set_threads(g._h, 0))
