@@ -182,7 +182,23 @@ static int32_t append_core(surge_snapshot_writer* w, int64_t n, const int64_t* i
     }
     auto encode_partition = [&](int32_t pi) {
       PartitionLog& p = w->parts[(size_t)pi];
-      for (int64_t r = start[(size_t)pi]; r < start[(size_t)pi + 1]; ++r) {
+      const int64_t r_end = start[(size_t)pi + 1];
+      constexpr int64_t kAhead = 12;  // a partition's records are scattered over the key / value tables: ask for them early
+      for (int64_t r = start[(size_t)pi]; r < r_end; ++r) {
+        if (r + 2 * kAhead < r_end) {  // ... and, before that, the table entries that say where they are
+          const int64_t j2 = order[(size_t)(r + 2 * kAhead)];
+          __builtin_prefetch(key_off + agg(j2));
+          if (val_off) __builtin_prefetch(val_off + j2);
+        }
+        if (r + kAhead < r_end) {
+          const int64_t j = order[(size_t)(r + kAhead)];
+          const int64_t aj = agg(j);
+          if (keys_utf8) __builtin_prefetch(keys_utf8 + key_off[aj]);
+          if (values && val_off && (!kind || kind[j] == SURGE_SNAP_VALUE)) {
+            __builtin_prefetch(values + val_off[j]);
+            __builtin_prefetch(values + val_off[j] + 64);
+          }
+        }
         const int64_t i = order[(size_t)r];
         const uint8_t k = kind ? kind[i] : (uint8_t)SURGE_SNAP_VALUE;
         const int64_t a = agg(i);
