@@ -777,10 +777,12 @@ def run_e2e(args):
     """From the bytes Kafka hands over to recovered states (SURVEY §8f N1 in front of R2): record batches (message format
     v2, 16 KiB = 140 records each like the reference producer's, the Counter fixture's play-json event text as the reference writes it: TestBoundedContext.scala:
     122-124; lz4-compressed like the reference's producer, reference.conf:112, frames written by liblz4) -> host framing
-    (headers, CRC-32C, read_committed; ONE host thread) -> surge_device_decoder (LZ4 blocks, records, key interning,
-    JSON -> 16-byte events, on the GPU) -> device group-by + fold onto the resident state (K3).  A step = one
-    fetch of --batch-events records (default 1 M); `value` = events/s over K fetches incl. everything between the bytes
-    and the states.  The same bytes through the library's host decoder beside it; the states after the run are compared
+    (headers, CRC-32C, read_committed; ONE host thread, running one fetch ahead of the device stage on its own thread:
+    surge_amd.ingest.FramedFetches; --serial-framing puts the two stages one after the other) -> surge_device_decoder
+    (LZ4 blocks, records, key interning, JSON -> 16-byte events, on the GPU) -> device group-by + fold onto the resident
+    state (K3).  A step = one fetch of --batch-events records (default 1 M); `value` = events/s over K fetches incl.
+    everything between the bytes and the states, timed from the completed fold of the last warm-up fetch to the completed
+    fold of the last timed one.  The same bytes through the library's host decoder beside it; the states after the run are compared
     with the oracle's fold of the decoded events, aggregate by aggregate."""
     import struct
 
