@@ -75,8 +75,7 @@ class GpuReplayStateStore:
         template falls back to the host decoder and the plugin's ``SurgeEventReadFormatting.read_event`` per record.
         Returns the ingest counters."""
         from .core import SerializedMessage
-        from .ingest import DeviceDecoder, EventsTopicIngest, IngestError
-        from .log import KeyTable
+        from .ingest import EventsTopicIngest, IngestError
         from .schema import EVENT_DTYPE
 
         template = self.model.event_json_template()
