@@ -466,13 +466,16 @@ int32_t surge_replay_snapshot_delta(surge_replay_handle* h, uint8_t* d_kind_out,
 int32_t surge_replay_set_encode_filter(surge_replay_handle* h, const uint8_t* d_kind);
 /* The second half of a two-step publish: surge_replay_snapshot_delta(commit = 0) -> encode -> produce -> and only once the
  * records are safely out (the reference treats a state as published when the producer acknowledged it) make the states
- * of the aggregates d_kind reports (the array that delta call filled) the new baseline.  No fold / append may run on the
- * handle between the two calls. */
+ * of the aggregates d_kind reports (the array that delta call filled) the new baseline.  No fold / append / grow may run
+ * on the handle between the two calls: the commit copies the states as they are NOW, so it is refused with SURGE_E_STATE
+ * when the handle's fold epoch or aggregate count moved since that delta (take a new delta).  A publisher that wants the
+ * store to keep folding while its records travel uses commit = 1 + surge_replay_snapshot_invalidate instead. */
 int32_t surge_replay_snapshot_commit(surge_replay_handle* h, const uint8_t* d_kind);
 /* The other way round, for a publisher that frames and produces in the background while the store keeps folding: it
  * commits with the delta (commit = 1: the baseline is exactly what was encoded) and, should the records not make it out,
  * calls this with the same d_kind — the reported aggregates then differ from their baseline again and the next delta
- * re-emits them (at-least-once, like a producer retry). */
+ * re-emits them (at-least-once, like a producer retry).  d_kind is read up to the aggregate count of that delta call;
+ * folds, appends and grows in between are fine. */
 int32_t surge_replay_snapshot_invalidate(surge_replay_handle* h, const uint8_t* d_kind);
 
 /* ---- shard map (R15) --------------------------------------------------------------

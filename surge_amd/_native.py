@@ -17,7 +17,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(_HERE, "libsurge_replay.so")
-SOURCES = ("fold_kernels.hip", "fold_chunked.hip", "fold_tiled.hip", "fold_slots.hip", "index_kernels.hip", "ingest_kernels.hip", "rtc.cpp", "f64_text.cpp", "state_kernels.hip", "stream_kernels.hip", "engine.hip", "comm.hip", "ingest.cpp", "event_decode.cpp", "lz4_frame.cpp", "snapshot_writer.cpp", "frame_kernels.hip")
+def _read_sources() -> tuple:
+    """The translation units, from ``csrc/SOURCES`` — the one list the Makefile reads too (tests/test_abi.py)."""
+    with open(os.path.join(CSRC, "SOURCES")) as f:
+        return tuple(ln.strip() for ln in f if ln.strip() and not ln.startswith("#"))
+
+
+SOURCES = _read_sources()
 HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "fold_chunk_device.h"), os.path.join(CSRC, "fold_slots_device.h"), os.path.join(CSRC, "f64_text.h"), os.path.join(CSRC, "f64_parse.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
@@ -158,30 +164,50 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall")
+OBJ_DIR = os.path.join(_HERE, "build")
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 in-tree (the .so travels with the repo snapshot)."""
+    """Compile the HIP sources for gfx950 in-tree (the .so travels with the repo snapshot).
+
+    One object per translation unit under ``surge_amd/build/`` (compiled side by side, only the ones older than their
+    source or any header), then one link: the flags and the source list (``csrc/SOURCES``) are the Makefile's.
+    """
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [
-        _hipcc(),
-        "--offload-arch=gfx950",
-        "-O3",
-        "-std=c++17",
-        "-fPIC",
-        "-shared",
-        "-ffp-contract=off",
-        "-Wall",
-        "-I" + INCLUDE,
-        "-I" + CSRC,  # rtc.cpp embeds the device headers with .incbin
-    ]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    from concurrent.futures import ThreadPoolExecutor
+
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    newest_header = max(os.path.getmtime(h) for h in HEADERS)
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, src + ".o")
+        path = os.path.join(CSRC, src)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), newest_header):
+            jobs.append((path, obj))
+
+    def compile_one(job):
+        path, obj = job
+        # -I csrc: rtc.cpp embeds the device headers with .incbin
+        cmd = [hipcc, *FLAGS, "-I" + INCLUDE, "-I" + CSRC, "-c", path, "-o", obj + ".tmp"]
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode == 0:
+            os.replace(obj + ".tmp", obj)
+        return path, proc
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
+        for path, proc in pool.map(compile_one, jobs):
+            if proc.returncode != 0:
+                raise NativeLibraryError(f"hipcc failed on {path}:\n" + proc.stdout + proc.stderr)
+            if verbose and (proc.stdout or proc.stderr):
+                print(proc.stdout + proc.stderr)
     tmp = LIB_PATH + ".tmp"
-    cmd += ["-o", tmp]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(OBJ_DIR, s + ".o") for s in SOURCES] + ["-o", tmp]
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise NativeLibraryError("hipcc failed:\n" + proc.stdout + proc.stderr)
-    if verbose and (proc.stdout or proc.stderr):
-        print(proc.stdout + proc.stderr)
+        raise NativeLibraryError("link failed:\n" + proc.stdout + proc.stderr)
     os.replace(tmp, LIB_PATH)
     return LIB_PATH
 

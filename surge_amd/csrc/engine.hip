@@ -147,6 +147,7 @@ struct surge_replay_handle {
   std::shared_mutex mu;  // readers share it against the published mirror; snapshot / device reads take it exclusively
   std::vector<uint8_t> mirror;
   std::atomic<int64_t> fold_epoch{0};
+  int64_t delta_epoch = -1, delta_n = -1;  // fold epoch / aggregate count the last snapshot_delta's kinds describe
   int64_t mirror_epoch = -1;
 };
 
@@ -1516,6 +1517,8 @@ int32_t surge_replay_snapshot_delta(surge_replay_handle* h, uint8_t* d_kind_out,
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (n_values_out) *n_values_out = (int64_t)c[0];
   if (n_tombstones_out) *n_tombstones_out = (int64_t)c[1];
+  h->delta_epoch = h->fold_epoch.load();
+  h->delta_n = h->n_agg;
   return SURGE_OK;
 }
 
@@ -1523,6 +1526,11 @@ int32_t surge_replay_snapshot_commit(surge_replay_handle* h, const uint8_t* d_ki
   if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
   if (!h->bound || h->published_n < h->n_agg) return fail(h, SURGE_E_STATE, "snapshot_commit without a preceding snapshot_delta");
   if (!d_kind && h->n_agg > 0) return fail(h, SURGE_E_INVALID, "d_kind is NULL");
+  // the commit copies the CURRENT states of the reported aggregates into the baseline: after a fold / append / grow they
+  // are no longer the states that were encoded, and a newer state would count as published without ever being emitted
+  if (h->delta_epoch != h->fold_epoch.load() || h->delta_n != h->n_agg)
+    return fail(h, SURGE_E_STATE, "snapshot_commit: the resident state changed since the snapshot_delta whose kinds these are "
+                                  "(fold / append / grow in between); take a new delta");
   DeviceGuard g(h->device);
   HIPCHK(h, launch_snapshot_commit(h->d_state, (uint4*)h->published.ptr, h->n_agg, d_kind, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1531,10 +1539,12 @@ int32_t surge_replay_snapshot_commit(surge_replay_handle* h, const uint8_t* d_ki
 
 int32_t surge_replay_snapshot_invalidate(surge_replay_handle* h, const uint8_t* d_kind) {
   if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
-  if (!h->bound || h->published_n < h->n_agg) return fail(h, SURGE_E_STATE, "snapshot_invalidate without a preceding snapshot_delta");
-  if (!d_kind && h->n_agg > 0) return fail(h, SURGE_E_INVALID, "d_kind is NULL");
+  if (!h->bound || h->delta_n < 0 || h->published_n < h->delta_n) return fail(h, SURGE_E_STATE, "snapshot_invalidate without a preceding snapshot_delta");
+  if (!d_kind && h->delta_n > 0) return fail(h, SURGE_E_INVALID, "d_kind is NULL");
   DeviceGuard g(h->device);
-  HIPCHK(h, launch_snapshot_invalidate((uint4*)h->published.ptr, h->n_agg, d_kind, h->stream));
+  // d_kind holds delta_n entries: the store may have grown (and folded) since; the aggregates added later have no
+  // baseline to invalidate, and invalidating an older aggregate only makes the next delta report it again
+  HIPCHK(h, launch_snapshot_invalidate((uint4*)h->published.ptr, h->delta_n, d_kind, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return SURGE_OK;
 }

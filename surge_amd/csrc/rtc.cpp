@@ -63,15 +63,20 @@ bool load_rtc_locked() {
     if (hip_fn && dladdr(hip_fn, &info) && info.dli_fname) {
       std::string dir = info.dli_fname;
       const size_t slash = dir.rfind('/');
-      if (slash != std::string::npos) cands.push_back(dir.substr(0, slash + 1) + "libhiprtc.so");
+      if (slash != std::string::npos) {
+        cands.push_back(dir.substr(0, slash + 1) + "libhiprtc.so");
+        for (const char* v : {"7", "6"}) cands.push_back(dir.substr(0, slash + 1) + "libhiprtc.so." + v);
+      }
     }
   }
-  cands.push_back("libhiprtc.so");
-  cands.push_back("/opt/rocm/lib/libhiprtc.so");
+  // runtime-only ROCm installs ship the versioned soname without the development symlink
+  for (const char* n : {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6"}) cands.push_back(n);
+  for (const char* n : {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6"}) cands.push_back(std::string("/opt/rocm/lib/") + n);
   for (const std::string& c : cands) {
     void* lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!lib) {
-      g_rtc.why += c + ": " + (dlerror() ? dlerror() : "?") + "; ";
+      const char* e = dlerror();  // once: a second call returns NULL (the first one cleared the error)
+      g_rtc.why += c + ": " + (e ? e : "?") + "; ";
       continue;
     }
     RtcApi a;

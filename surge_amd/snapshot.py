@@ -371,7 +371,12 @@ class BulkSnapshotPublisher:
         return pending
 
     def commit_published(self) -> None:
-        """Make what the last ``publish`` reported the new baseline (``surge_replay_snapshot_commit``)."""
+        """Make what the last ``publish(commit=False)`` reported the new baseline (``surge_replay_snapshot_commit``).
+
+        The commit copies the aggregates' states as they are *now*, so nothing may fold, append or grow on the engine
+        between that ``publish`` and this call: the library refuses with ``SURGE_E_STATE`` (``ReplayError``) if it did
+        — publish again.  A publisher that wants the store to keep folding while the producer acknowledges uses
+        ``publish_async`` (baseline = exactly what was encoded, invalidated if the records never make it out)."""
         if getattr(self, "_pending_kind", None) is None:
             return
         eng = self.engine

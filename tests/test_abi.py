@@ -49,6 +49,48 @@ def test_snapshot_writer_exports_match_their_header():
         assert hasattr(lib, name), f"{name} declared in surge_snapshot.h but not exported"
 
 
+def test_make_lib_builds_the_same_library_as_the_python_build(tmp_path):
+    """`make lib` is the recipe INTEGRATION.md gives JNI / C / C++ hosts.  It reads the same source list as
+    _native.build() (surge_amd/csrc/SOURCES) and its output exports every symbol the three headers declare."""
+    import shutil
+    import subprocess
+
+    if shutil.which("make") is None or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("make / hipcc not present")
+    mk = open(os.path.join(ROOT, "Makefile")).read()
+    assert "surge_amd/csrc/SOURCES" in mk and re.search(r"^SRC\s*:=.*SOURCES", mk, re.M), "the Makefile must take its sources from csrc/SOURCES"
+    for src in _native.SOURCES:
+        assert os.path.exists(os.path.join(_native.CSRC, src))
+    lib = str(tmp_path / "libsurge_replay_make.so")
+    res = subprocess.run(["make", "-j8", "lib", "LIB=" + lib, "OBJ=" + str(tmp_path / "obj")], cwd=ROOT, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    nm = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (surge_[a-z0-9_]+)", nm))
+    missing = [n for n in _native.EXPORTS + _native.INGEST_EXPORTS + _native.SNAPSHOT_EXPORTS if n not in exported]
+    assert not missing, f"`make lib` output lacks {missing}"
+
+
+def test_a_libhiprtc_candidate_that_fails_to_load_does_not_take_the_process_down():
+    """ADVICE r3 (high): a dlopen failure used to call dlerror() twice and build a std::string from NULL.  A process with
+    a wrong SURGE_HIPRTC_LIBRARY must survive the failed candidate and go on to the next one."""
+    import subprocess
+    import sys
+
+    code = (
+        "import ctypes\n"
+        "from surge_amd import _native\n"
+        "lib = _native.load()\n"
+        "from tests.test_slots import LEDGER\n"
+        "sc = LEDGER.to_c(); n = ctypes.c_int64(0)\n"
+        "rc = lib.surge_replay_compile_schema_v2(ctypes.byref(sc), b'gfx950', None, 0, ctypes.byref(n))\n"
+        "print('RC', rc, n.value)\n"
+    )
+    env = dict(os.environ, SURGE_HIPRTC_LIBRARY="/nonexistent/libhiprtc.so")
+    res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr  # 139 = the segfault
+    assert "RC 0 " in res.stdout or "RC -" in res.stdout, res.stdout + res.stderr
+
+
 def test_default_schema_matches_python_mirror():
     lib = _native.load()
     s = CSchema()

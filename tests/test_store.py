@@ -436,5 +436,31 @@ def test_bulk_snapshot_publish_emits_only_what_changed_as_kafka_record_batches(d
                 pub.publish_async().result()
             setattr(target, method, real)
             assert decode(pub.publish()) == expected(s5, s4)
+            # a deferred commit: a fold between publish(commit=False) and commit_published() is refused — the
+            # commit would copy the NEWER states into the baseline and they would never be emitted — and nothing is lost:
+            # the next publish reports the aggregates of both batches with their current states
+            from surge_amd.replay import ReplayError
+
+            touched5 = rng.choice(n, size=30, replace=False)
+            be5 = S.make_events([S.EVT_INC] * 30, rng.integers(5000, 6000, size=30), rng.integers(1, 9, size=30))
+            eng.append_events(touched5.astype(np.int64), be5)
+            off5 = np.zeros(n + 1, np.int64); np.cumsum(np.bincount(touched5, minlength=n), out=off5[1:])
+            s6 = oracle.fold_csr(off5, be5[np.argsort(touched5, kind="stable")], s5)
+            assert decode(pub.publish(commit=False)) == expected(s6, s5)
+            touched6 = rng.choice(n, size=30, replace=False)
+            be6 = S.make_events([S.EVT_INC] * 30, rng.integers(6000, 7000, size=30), rng.integers(1, 9, size=30))
+            eng.append_events(touched6.astype(np.int64), be6)
+            off6 = np.zeros(n + 1, np.int64); np.cumsum(np.bincount(touched6, minlength=n), out=off6[1:])
+            s7 = oracle.fold_csr(off6, be6[np.argsort(touched6, kind="stable")], s6)
+            with pytest.raises(ReplayError) as ei:
+                pub.commit_published()
+            assert ei.value.status == -2 and "changed since" in str(ei.value)  # SURGE_E_STATE
+            assert decode(pub.publish()) == expected(s7, s5)
+            # and the undisturbed deferred commit still works
+            eng.append_events(touched5.astype(np.int64), be5)
+            s8 = oracle.fold_csr(off5, be5[np.argsort(touched5, kind="stable")], s7)
+            assert decode(pub.publish(commit=False)) == expected(s8, s7)
+            pub.commit_published()
+            assert decode(pub.publish()) == {}
         finally:
             pub.close()
