@@ -191,6 +191,12 @@ int32_t surge_device_decoder_keys(surge_device_decoder* d, uint8_t* utf8_out, in
 int32_t surge_device_decoder_key_table(surge_device_decoder* d, const uint8_t** d_utf8, const int64_t** d_key_off);
 /* [0] records seen, [1] delivered, [2] flush records skipped, [3] Double values re-parsed on the host */
 int32_t surge_device_decoder_counters(const surge_device_decoder* d, int64_t out[4]);
+/* [0..3] the counters above, [4] re-seeds of the key table's hash function — two different aggregate ids with the same
+ * 64-bit hash are detected (every record's key is compared byte for byte with the key its slot stands for) and handled:
+ * nothing of the push is committed, the table gets another hash function (every known key re-hashed from the key arena) and
+ * the push runs again; after four functions in a row the push fails with SURGE_E_UNSUPPORTED — [5] slots of the key table,
+ * [6] pushes that delivered, [7] the hash function in use (0 = the first). */
+int32_t surge_device_decoder_stats(const surge_device_decoder* d, int64_t out[8]);
 
 /* Key table: aggregate ids in first-DELIVERED order (a key is interned when its record is drained, so the
  * keys of aborted or still-open transactions never appear). */

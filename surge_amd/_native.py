@@ -109,6 +109,7 @@ INGEST_EXPORTS = (
     "surge_device_decoder_keys",
     "surge_device_decoder_key_table",
     "surge_device_decoder_counters",
+    "surge_device_decoder_stats",
     "surge_event_json_validate",
     "surge_event_json_decode",
     "surge_event_json_last_error",
@@ -315,6 +316,7 @@ def load() -> ctypes.CDLL:
         "surge_device_decoder_keys": ([vp, vp, i64, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
         "surge_device_decoder_key_table": ([vp, ctypes.POINTER(vp), ctypes.POINTER(vp)], i32),
         "surge_device_decoder_counters": ([vp, ctypes.POINTER(i64 * 4)], i32),
+        "surge_device_decoder_stats": ([vp, ctypes.POINTER(i64 * 8)], i32),
         "surge_event_json_validate": ([vp], i32),
         "surge_event_json_decode": ([vp, vp, i64, vp], i32),
         "surge_event_json_last_error": ([], ctypes.c_char_p),

@@ -68,27 +68,9 @@ struct Section {  // = surge_batch_section + the batch's first record index in t
 
 struct ErrorCell {
   unsigned long long first_bad;  // min over (record index << 8 | status)
-  unsigned int n_new, n_f64_host;
+  unsigned int reserved, n_f64_host;
   unsigned int lz4_bad;          // the first section whose LZ4 frame did not decode (~0 = none)
   unsigned int pad;
-};
-
-struct Reader {
-  const uint8_t* p;
-  const uint8_t* end;
-  bool ok;
-  __device__ int64_t varlong() {
-    uint64_t v = 0;
-    int shift = 0;
-    while (true) {
-      if (p >= end || shift > 63) { ok = false; return 0; }
-      const uint8_t b = *p++;
-      v |= (uint64_t)(b & 0x7f) << shift;
-      if (!(b & 0x80)) break;
-      shift += 7;
-    }
-    return (int64_t)(v >> 1) ^ -(int64_t)(v & 1);
-  }
 };
 
 __device__ __forceinline__ void report(ErrorCell* err, int64_t rec, uint32_t status) {
@@ -112,6 +94,7 @@ struct Lz4Block {
   int32_t section;   // the section this block belongs to
   int32_t last;      // the frame's last block: sets the section's length
   int32_t index;     // k: this block's number inside its frame
+  int64_t seq_off;   // first entry of this block in the sequence table (two-pass decode); -1: the one-pass kernel takes it
 };
 
 // The compressed stream is read through a 256-byte WINDOW held in registers (lane l: bytes [4l, 4l + 4) from `wbase`):
@@ -189,6 +172,7 @@ __global__ void __launch_bounds__(64) lz4_block_kernel(const uint8_t* __restrict
   for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
     if (cls > 0 && state[b] != -(cls + 1)) continue;
     const Lz4Block blk = blocks[b];
+    if (blk.seq_off >= 0) continue;  // decoded in two passes (lz4_parse_kernel / lz4_exec_kernel)
     const uint8_t* in = bytes + blk.src_off;
     const int32_t n_in = blk.src_len & 0x7fffffff;
     int32_t op = 0;
@@ -262,184 +246,279 @@ __global__ void __launch_bounds__(64) lz4_block_kernel(const uint8_t* __restrict
   }
 }
 
-__global__ void chain_kernel(const uint8_t* __restrict__ bytes, const Section* __restrict__ sections, int64_t n_sections,
-                             int64_t* __restrict__ rec_pos, int64_t* __restrict__ rec_end, ErrorCell* err) {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_sections) return;
-  const Section sec = sections[s];
-  Reader r{bytes + sec.byte_off, bytes + sec.byte_off + sec.byte_len, true};
-  for (int32_t i = 0; i < sec.n_records; ++i) {
-    const int64_t len = r.varlong();
-    const int64_t at = r.p - bytes;
-    if (!r.ok || len < 0 || r.end - r.p < len) {
-      // everything from here to the end of the batch is unreadable: mark the rest empty and report the first
-      for (int32_t k = i; k < sec.n_records; ++k) { rec_pos[sec.rec_first + k] = -1; rec_end[sec.rec_first + k] = -1; }
-      report(err, sec.rec_first + i, RS_MALFORMED);
-      return;
+// ---- LZ4 in two passes (round 4) ---------------------------------------------------------------------------------------
+// What the counters said about the one-pass kernel above (profiles/r04_e2e_r3sources_summary.txt: 1 M records = 7142
+// blocks of ~16 KiB, ~1050 sequences each — play-json text compresses into sequences of 1.4 literal and 13.5 match bytes):
+// 108 k SCALAR instructions per block — the sequence headers are wave-uniform, so every length / offset / bounds step is
+// SALU work that 63 of 64 lanes only wait for — against 20 k VALU and 3 k LDS instructions; 2.4 ms per fetch, bound by the
+// one scalar pipe of a CU.  Two things are serial in an LZ4 block — finding where the next sequence starts, and a match
+// reading what an earlier match wrote — and neither needs a wave per sequence:
+//   pass 1  lz4_parse_kernel   ONE LANE per block (64 blocks per wave) walks its block's sequence headers: a 16-byte
+//           unaligned load at the sequence's first byte holds the token, up to 12 literal bytes, the offset and one length
+//           byte — the whole header of all but a fraction of a percent of the sequences — so a step is one load and ~50
+//           branch-free VALU instructions for 64 blocks at once.  It writes an 8-byte entry per sequence {position,
+//           literal length, match length, offset}, stores the literal bytes where they belong in the decompressed area
+//           (they come from the compressed stream, never from earlier output), and validates what the one-pass decoder
+//           validates, so the block's exact decompressed size — the section's length and the LDS class of pass 2 — is
+//           known before a match is copied.
+//   pass 2  lz4_exec_kernel    one WAVE per block, in a launch with exactly the LDS its size needs: the block's image
+//           (literals in place) is loaded into LDS; per 64 entries the lanes expand their matches into a byte map
+//           (map[p] = the position byte p copies from; identity for literals), then the map is applied 64 output bytes at
+//           a time, lane per byte: one gather when no byte of the window reads another byte of the same window, else once
+//           more per byte that does (a chain inside a window cannot be longer).  ~5 instructions per sequence instead of
+//           ~140, and the serial chain is per 64 bytes of output instead of per sequence.  Overlapping matches (offset <
+//           length: the period IS the data), matches above 256 bytes and groups that span more than the map holds take
+//           the sequence-by-sequence loop.
+// Blocks whose compressed size is 64 KiB or more (a compressor that expands instead of storing) keep the one-pass kernel.
+struct Lz4Work {
+  int32_t* state;      // per block: >= 0 decoded (its size), -1 malformed
+  int32_t* n_seq;      // per block: entries written
+  uint2* seq;          // the sequence table
+  int32_t* cls_count;  // [kLz4Classes + 1]: blocks per LDS class; the last is "stored" (no LDS: copied as they are)
+  int32_t* cls_list;   // [kLz4Classes + 1][n_blocks]
+};
+constexpr int kLz4Classes = 6;
+constexpr int kLz4Map = 4096;  // bytes of output one group's map may span (a power of two)
+__device__ __constant__ int32_t kLz4ClassCap[kLz4Classes] = {8192, 16384, 24576, 32768, 49152, 65536};
+static const int32_t kLz4ClassCapHost[kLz4Classes] = {8192, 16384, 24576, 32768, 49152, 65536};
+
+struct __attribute__((packed)) Unaligned16 { uint64_t lo, hi; };
+
+// bits [b, b + 64) of the 128-bit little-endian window hi:lo, b in [0, 128)
+__device__ __forceinline__ uint64_t window_bits(uint64_t lo, uint64_t hi, int b) {
+  const uint64_t low = (lo >> (b & 63)) | ((hi << 1) << (63 - (b & 63)));
+  return b < 64 ? low : hi >> (b & 63);
+}
+
+// one sequence of the block, byte by byte (the block's last sequence, literal runs above 12 bytes, lengths continued over
+// several bytes, the block's edge): false = malformed
+__device__ bool lz4_slow_sequence(const uint8_t* __restrict__ in, int32_t n_in, uint8_t* __restrict__ dst, int32_t& ip, int32_t& op, uint2* __restrict__ out,
+                                  int32_t& ns) {
+  const uint32_t token = in[ip++];
+  int32_t lit = (int32_t)(token >> 4);
+  if (lit == 15) {
+    uint32_t x;
+    do {
+      if (ip >= n_in) return false;
+      x = in[ip++];
+      lit += (int32_t)x;
+    } while (x == 255u && lit < (1 << 24));
+  }
+  if (lit > n_in - ip || lit > kLz4BlockMax - op) return false;  // (n_in < 64 KiB: a length always fits 16 bits)
+  for (int32_t j = 0; j < lit; ++j) dst[op + j] = in[ip + j];
+  ip += lit;
+  if (ip >= n_in) {  // the last sequence carries literals only
+    out[ns++] = make_uint2((uint32_t)op | ((uint32_t)lit << 16), 0u);
+    op += lit;
+    return true;
+  }
+  if (n_in - ip < 2) return false;
+  const int32_t offset = (int32_t)in[ip] | ((int32_t)in[ip + 1] << 8);
+  ip += 2;
+  int32_t ml = (int32_t)(token & 15u);
+  if (ml == 15) {
+    uint32_t x;
+    do {
+      if (ip >= n_in) return false;
+      x = in[ip++];
+      ml += (int32_t)x;
+    } while (x == 255u && ml < (1 << 24));
+  }
+  ml += 4;
+  const int32_t D = op + lit;
+  // offset <= D and offset >= 1 make D >= 1, so a match that fits the block is at most 65535 long
+  if (offset == 0 || offset > D || ml > kLz4BlockMax - D) return false;
+  out[ns++] = make_uint2((uint32_t)op | ((uint32_t)lit << 16), (uint32_t)ml | ((uint32_t)offset << 16));
+  op = D + ml;
+  return true;
+}
+
+__global__ void __launch_bounds__(64) lz4_parse_kernel(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ out_base, const Lz4Block* __restrict__ blocks,
+                                                       int32_t n_blocks, Lz4Work w, Section* __restrict__ sections, ErrorCell* err) {
+  const int32_t b = (int32_t)(blockIdx.x * 64u + threadIdx.x);
+  if (b >= n_blocks) return;
+  const Lz4Block blk = blocks[b];
+  if (blk.seq_off < 0) return;  // the one-pass kernel's
+  const uint8_t* __restrict__ in = bytes + blk.src_off;
+  uint8_t* __restrict__ dst = out_base + blk.dst_off;
+  const int32_t n_in = blk.src_len & 0x7fffffff;
+  int32_t op = 0, ns = 0;
+  bool ok = true;
+  int32_t cls = kLz4Classes;  // stored
+  if (blk.src_len < 0) {
+    op = n_in;
+    ok = n_in <= kLz4BlockMax;
+  } else {
+    uint2* __restrict__ out = w.seq + blk.seq_off;
+    int32_t ip = 0;
+    while (ip < n_in) {
+      // (the staged bytes end 16 bytes after their last byte: the load may run past the block, never past the buffer)
+      Unaligned16 win;
+      __builtin_memcpy(&win, in + ip, 16);
+      const uint32_t token = (uint32_t)win.lo & 0xffu;
+      const int32_t lit = (int32_t)(token >> 4), mlc = (int32_t)(token & 15u);
+      const int32_t need = 3 + lit + (mlc == 15 ? 1 : 0);
+      const uint32_t tail = (uint32_t)window_bits(win.lo, win.hi, 8 * (1 + lit));  // offset (16 bits), then the length byte
+      bool fast = lit <= 12 && need <= n_in - ip && op + 16 <= kLz4BlockMax && !(mlc == 15 && ((tail >> 16) & 0xffu) == 255u);
+      // (need < n_in - ip would also do: a sequence that ends the block exactly still carries its match; the last,
+      // literal-only sequence has no room for an offset and takes the slow path)
+      if (fast) {
+        if (lit > 0) {  // 16 bytes where the literals go: what follows them is overwritten by the match / the next literals
+          Unaligned16 lits;
+          lits.lo = (win.lo >> 8) | (win.hi << 56);
+          lits.hi = win.hi >> 8;
+          __builtin_memcpy(dst + op, &lits, 16);
+        }
+        const int32_t offset = (int32_t)(tail & 0xffffu);
+        const int32_t ml = mlc + 4 + (mlc == 15 ? (int32_t)((tail >> 16) & 0xffu) : 0);
+        const int32_t D = op + lit;
+        if (offset == 0 || offset > D || ml > kLz4BlockMax - D) { ok = false; break; }
+        out[ns++] = make_uint2((uint32_t)op | ((uint32_t)lit << 16), (uint32_t)ml | ((uint32_t)offset << 16));
+        ip += need;
+        op = D + ml;
+      } else if (!lz4_slow_sequence(in, n_in, dst, ip, op, out, ns)) {
+        ok = false;
+        break;
+      }
     }
-    rec_pos[sec.rec_first + i] = at;
-    rec_end[sec.rec_first + i] = at + len;
-    r.p += len;
+    cls = 0;
+    while (cls < kLz4Classes - 1 && op > kLz4ClassCap[cls]) ++cls;
+  }
+  if (ok && !blk.last && op != kLz4BlockMax) ok = false;  // every block of a frame but its last is exactly full
+  w.n_seq[b] = ns;
+  if (!ok) {
+    w.state[b] = -1;
+    atomicMin(&err->lz4_bad, (unsigned int)blk.section);
+    if (blk.last) sections[blk.section].byte_len = 0;
+    return;
+  }
+  w.state[b] = op;
+  if (blk.last) sections[blk.section].byte_len = (int64_t)blk.index * kLz4BlockMax + op;
+  if (op > 0) w.cls_list[(int64_t)cls * n_blocks + atomicAdd(&w.cls_count[cls], 1)] = b;
+}
+
+// cls == kLz4Classes: stored blocks (launched without LDS).  LDS: the block's image (the class's capacity + 64 bytes
+// that a masked-off lane may address), then the byte map (kLz4Map 16-bit positions).
+__global__ void __launch_bounds__(64) lz4_exec_kernel(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ out_base, const Lz4Block* __restrict__ blocks,
+                                                      int32_t n_blocks, Lz4Work w, int32_t cls, int32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lz4_out[];
+  uint16_t* const map = (uint16_t*)(lz4_out + cap + 64);
+  const int lane = threadIdx.x;
+  const int32_t count = w.cls_count[cls];
+  for (int32_t k = (int32_t)blockIdx.x; k < count; k += (int32_t)gridDim.x) {
+    const int32_t b = w.cls_list[(int64_t)cls * n_blocks + k];
+    const Lz4Block blk = blocks[b];
+    uint8_t* __restrict__ dst = out_base + blk.dst_off;  // 16-byte aligned: dst_off is a multiple of 64 KiB from an aligned base
+    const int32_t size = w.state[b];
+    if (cls == kLz4Classes) {  // stored: the bytes as they are
+      const uint8_t* __restrict__ in = bytes + blk.src_off;
+      for (int i = lane; i < size; i += 64) dst[i] = in[i];
+      continue;
+    }
+    // the image with the literals the first pass put in place
+    const int n16 = (size + 15) >> 4;
+    for (int i = lane; i < n16; i += 64) ((uint4*)lz4_out)[i] = ((const uint4*)dst)[i];
+    const int32_t n = w.n_seq[b];
+    const uint2* __restrict__ sq = w.seq + blk.seq_off;
+    uint2 e_next = lane < n ? sq[lane] : make_uint2(0u, 0u);
+    for (int32_t g = 0; g < n; g += 64) {
+      const uint2 e = e_next;
+      if (g + 64 < n) e_next = g + 64 + lane < n ? sq[g + 64 + lane] : make_uint2(0u, 0u);  // in flight during this group
+      const int32_t cnt = n - g < 64 ? n - g : 64;
+      const int32_t op = (int32_t)(e.x & 0xffffu), lit = (int32_t)(e.x >> 16), M = (int32_t)(e.y & 0xffffu), O = (int32_t)(e.y >> 16);
+      const int32_t D = op + lit, end = D + M;
+      const int32_t g0 = __builtin_amdgcn_readfirstlane(op), g1 = __builtin_amdgcn_readlane(end, cnt - 1);
+      const bool mapped = g1 - g0 <= kLz4Map && !__any(lane < cnt && M > 0 && (O < M || M > 256));
+      if (mapped) {
+        // (LDS operations of one wave execute in order: a read sees every earlier write of any lane of this wave)
+        for (int32_t p = g0 + lane; p < g1; p += 64) map[p & (kLz4Map - 1)] = (uint16_t)p;
+        const int32_t m_lane = lane < cnt ? M : 0;
+        for (int32_t i = 0; __any(i < m_lane); ++i)
+          if (i < m_lane) map[(D + i) & (kLz4Map - 1)] = (uint16_t)(D - O + i);
+        for (int32_t p = g0; p < g1; p += 64) {
+          const int32_t pos = p + lane;
+          const bool act = pos < g1;
+          const int32_t src = act ? (int32_t)map[pos & (kLz4Map - 1)] : pos;
+          // bytes of this window that copy from this window: a chain of them is at most that many long
+          const unsigned long long dep = __ballot(act && src >= p && src != pos);
+          const int n_it = dep ? __builtin_popcountll(dep) + 1 : 1;
+          for (int it = 0; it < n_it; ++it) {
+            const uint8_t v = lz4_out[src];
+            if (act) lz4_out[pos] = v;
+          }
+        }
+      } else {
+        // sequence by sequence, strictly in order
+        for (int32_t s = 0; s < cnt; ++s) {
+          const int32_t Ms = __builtin_amdgcn_readlane(M, s);
+          if (Ms == 0) continue;  // the block's last sequence
+          const int32_t Os = __builtin_amdgcn_readlane(O, s), Ds = __builtin_amdgcn_readlane(D, s);
+          const uint8_t* src = lz4_out + Ds - Os;
+          if (Os >= Ms || Os >= 64) {  // chunks of 64 bytes never read what the same instruction writes
+            for (int32_t i = lane; i < Ms; i += 64) lz4_out[Ds + i] = src[i];
+          } else {                     // the period IS the data
+            for (int32_t i = lane; i < Ms; i += 64) lz4_out[Ds + i] = src[i % Os];
+          }
+        }
+      }
+    }
+    const int f16 = size >> 4;
+    for (int i = lane; i < f16; i += 64) ((uint4*)dst)[i] = ((const uint4*)lz4_out)[i];
+    for (int i = (f16 << 4) + lane; i < size; i += 64) dst[i] = lz4_out[i];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // the copy-out has read the LDS before the next block overwrites it
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
-__device__ __forceinline__ uint64_t hash_key(const uint8_t* p, int n) {
-  uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+// ---- records: chain, parse, decode (round 4: one workgroup per batch, out of LDS) -----------------------------------------
+// Round 3 ran three kernels over the decompressed bytes in global memory — chain (one thread per batch walking its
+// records' length varints), parse (one thread per record), resolve (one thread per record walking the JSON text byte by
+// byte) — every step a dependent single-byte load: 1.45 ms per 1 M records, almost all of it waiting (SQ_WAIT_ANY 3/4 of
+// the wave cycles; the LDS staging resolve_kernel had never fired on lz4 topics: a block's 256 records came from two
+// batches whose decompressed bytes lie 64 KiB apart).  Now one workgroup owns one batch: it copies the batch's records
+// section into LDS with 16-byte loads, one thread walks the length varints there (the only sequential step, now at LDS
+// latency), then every thread parses its record and decodes its value from LDS.  A section that does not fit the LDS of
+// its launch is read in place (same code, global pointers).
+typedef const __attribute__((address_space(3))) uint8_t* lds_ptr_t;
+
+template <typename P>
+struct ReaderT {
+  P p;
+  P end;
+  bool ok;
+  __device__ int64_t varlong() {
+    uint64_t v = 0;
+    int shift = 0;
+    while (true) {
+      if (p >= end || shift > 63) { ok = false; return 0; }
+      const uint8_t b = *p++;
+      v |= (uint64_t)(b & 0x7f) << shift;
+      if (!(b & 0x80)) break;
+      shift += 7;
+    }
+    return (int64_t)(v >> 1) ^ -(int64_t)(v & 1);
+  }
+};
+
+// 64-bit hash of an aggregate id under the table's seed (a re-seed follows a detected collision); 0 marks an empty slot
+template <typename P>
+__device__ __forceinline__ uint64_t hash_key(P p, int n, uint64_t seed) {
+  uint64_t h = (0x9E3779B97F4A7C15ull ^ (uint64_t)n) + seed * 0xC2B2AE3D27D4EB4Full;
   for (int i = 0; i < n; ++i) h = (h ^ p[i]) * 0x100000001B3ull;
   h ^= h >> 29;
   h *= 0xD6E8FEB86659FD93ull;
   h ^= h >> 32;
-  return h == 0ull ? 1ull : h;  // 0 marks an empty slot
-}
-
-// section of record i: the last section with rec_first <= i (records of a section are contiguous)
-__device__ __forceinline__ int64_t section_of(const Section* sections, int64_t n_sections, int64_t i) {
-  int64_t lo = 0, hi = n_sections;
-  while (hi - lo > 1) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (sections[mid].rec_first <= i) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
-__global__ void parse_kernel(const uint8_t* __restrict__ bytes, const Section* __restrict__ sections, int64_t n_sections,
-                             const int64_t* __restrict__ rec_pos, const int64_t* __restrict__ rec_end, int64_t n_rec, RecMeta* __restrict__ meta,
-                             ErrorCell* err) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_rec) return;
-  RecMeta m;
-  m.key_off = m.val_off = m.offset = 0; m.hash = 0; m.key_len = m.val_len = 0; m.slot = 0; m.status = RS_MALFORMED;
-  const int64_t at = rec_pos[i];
-  if (at >= 0) {
-    Reader q{bytes + at, bytes + rec_end[i], true};
-    if (q.p < q.end) ++q.p; else q.ok = false;  // attributes
-    (void)q.varlong();                            // timestampDelta
-    const int64_t offset_delta = q.varlong();
-    const int64_t klen = q.varlong();
-    const uint8_t* key = q.p;
-    if (q.ok && klen > 0) { if (q.end - q.p >= klen) q.p += klen; else q.ok = false; }
-    const int64_t vlen = q.ok ? q.varlong() : 0;
-    const uint8_t* val = q.p;
-    if (q.ok && vlen > 0) { if (q.end - q.p >= vlen) q.p += vlen; else q.ok = false; }
-    // (headers follow; the chain already knows where the record ends)
-    if (q.ok && klen >= -1 && vlen >= -1 && klen < (1ll << 31) && vlen < (1ll << 31)) {
-      const Section& sec = sections[section_of(sections, n_sections, i)];
-      m.offset = sec.base_offset + offset_delta;
-      if (klen == 0 && vlen == 0) {
-        m.status = RS_SKIP;  // KafkaProducerActorImpl.scala:322-329
-      } else if (klen < 0 || vlen < 0) {
-        m.status = RS_NULL;
-      } else {
-        int n = 0;
-        while (n < (int)klen && key[n] != (uint8_t)':') ++n;  // PartitionStringUpToColon (KafkaPartitioner.scala:38-42)
-        m.key_off = key - bytes;
-        m.key_len = n;
-        m.val_off = val - bytes;
-        m.val_len = (int32_t)vlen;
-        m.hash = hash_key(key, n);
-        m.status = RS_OK;
-      }
-    }
-  }
-  if (m.status >= RS_NULL) report(err, i, m.status);
-  meta[i] = m;
-}
-
-// records that arrive already framed (a JVM's ConsumerRecords: key bytes, value bytes, offset per record): the bytes buffer
-// holds the keys first, the values from `val_base` on
-__global__ void records_meta_kernel(const uint8_t* __restrict__ bytes, const int64_t* __restrict__ key_off, const int64_t* __restrict__ val_off,
-                                    const int64_t* __restrict__ offsets, int64_t val_base, int64_t n_rec, RecMeta* __restrict__ meta, ErrorCell* err) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_rec) return;
-  RecMeta m;
-  const int64_t k0 = key_off[i], k1 = key_off[i + 1], v0 = val_off[i], v1 = val_off[i + 1];
-  m.key_off = k0; m.val_off = val_base + v0; m.offset = offsets ? offsets[i] : i; m.hash = 0; m.key_len = 0; m.val_len = 0; m.slot = 0;
-  if (k1 < k0 || v1 < v0 || k1 - k0 >= (1ll << 31) || v1 - v0 >= (1ll << 31)) {
-    m.status = RS_MALFORMED;
-  } else if (k1 == k0 && v1 == v0) {
-    m.status = RS_SKIP;  // the producer's flush record
-  } else {
-    const uint8_t* key = bytes + k0;
-    int n = 0;
-    while (n < (int)(k1 - k0) && key[n] != (uint8_t)':') ++n;
-    m.key_len = n;
-    m.val_len = (int32_t)(v1 - v0);
-    m.hash = hash_key(key, n);
-    m.status = RS_OK;
-  }
-  if (m.status >= RS_NULL) report(err, i, m.status);
-  meta[i] = m;
-}
-
-struct Table {
-  unsigned long long* hash;  // 0 = empty
-  uint32_t* key_id;          // 0xffffffff = not assigned yet (inserted by the push in flight)
-  uint32_t* first_rec;       // of a slot inserted by the push in flight: its first record
-  uint64_t mask;
-};
-
-__global__ void probe_kernel(RecMeta* __restrict__ meta, int64_t n_rec, Table t, uint32_t* __restrict__ new_slots, ErrorCell* err) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_rec) return;
-  if (meta[i].status != RS_OK) return;
-  const unsigned long long h = meta[i].hash;
-  uint64_t s = h & t.mask;
-  while (true) {
-    const unsigned long long old = atomicCAS(&t.hash[s], 0ull, h);
-    if (old == 0ull) {  // inserted: this push discovers the key
-      new_slots[atomicAdd(&err->n_new, 1u)] = (uint32_t)s;
-      break;
-    }
-    if (old == h) break;
-    s = (s + 1) & t.mask;
-  }
-  meta[i].slot = (uint32_t)s;
-  if (t.key_id[s] == 0xffffffffu) atomicMin(&t.first_rec[s], (uint32_t)i);
-}
-
-__global__ void newkey_keys_kernel(const uint32_t* __restrict__ new_slots, uint32_t n_new, Table t, uint32_t* __restrict__ sort_keys) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n_new) sort_keys[k] = t.first_rec[new_slots[k]];
-}
-
-// after the sort: slot k (in first-record order) gets id n_keys + k; lens[k] = its key length (scanned into arena offsets)
-__global__ void newkey_len_kernel(const uint32_t* __restrict__ first_sorted, uint32_t n_new, const RecMeta* __restrict__ meta,
-                                  int64_t* __restrict__ lens) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n_new) lens[k] = meta[first_sorted[k]].key_len;
-  if (k == n_new) lens[k] = 0;
-}
-
-__global__ void newkey_assign_kernel(const uint32_t* __restrict__ first_sorted, const uint32_t* __restrict__ slot_sorted, uint32_t n_new,
-                                     const RecMeta* __restrict__ meta, const uint8_t* __restrict__ bytes, const int64_t* __restrict__ lens_scanned,
-                                     int64_t n_keys, int64_t arena_base, Table t, uint8_t* __restrict__ arena, int64_t* __restrict__ key_off,
-                                     unsigned long long* __restrict__ key_hash) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_new) return;
-  const RecMeta m = meta[first_sorted[k]];
-  const int64_t dst = arena_base + lens_scanned[k];
-  for (int b = 0; b < m.key_len; ++b) arena[dst + b] = bytes[m.key_off + b];
-  const int64_t id = n_keys + k;
-  key_off[id + 1] = dst + m.key_len;
-  key_hash[id] = m.hash;
-  t.key_id[slot_sorted[k]] = (uint32_t)id;
-}
-
-__global__ void rehash_kernel(const unsigned long long* __restrict__ key_hash, int64_t n_keys, Table t) {
-  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= n_keys) return;
-  const unsigned long long h = key_hash[id];
-  uint64_t s = h & t.mask;
-  while (atomicCAS(&t.hash[s], 0ull, h) != 0ull) s = (s + 1) & t.mask;  // distinct keys, distinct (verified) hashes
-  t.key_id[s] = (uint32_t)id;
+  if (seed >> 63) h &= 0xffull;  // test hook (SURGE_INGEST_DEBUG_WEAK_HASH): collisions guaranteed until the first re-seed
+  return h == 0ull ? 1ull : h;
 }
 
 // ---- event values ------------------------------------------------------------------------------------------------------
-struct JsonScan {
-  const uint8_t* p;
-  const uint8_t* end;
+template <typename P>
+struct JsonScanT {
+  P p;
+  P end;
   __device__ void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p; }
-  __device__ bool string(const uint8_t** s, int* len, bool* escaped) {
+  __device__ bool string(P* s, int* len, bool* escaped) {
     if (p >= end || *p != '"') return false;
     ++p;
     *s = p;
@@ -457,7 +536,7 @@ struct JsonScan {
     ++p;
     return true;
   }
-  __device__ bool number(const uint8_t** s, int* len) {
+  __device__ bool number(P* s, int* len) {
     *s = p;
     if (p < end && (*p == '-' || *p == '+')) ++p;
     bool digits = false;
@@ -471,7 +550,7 @@ struct JsonScan {
   __device__ bool skip_value() {
     ws();
     if (p >= end) return false;
-    const uint8_t* s; int l; bool e;
+    P s; int l; bool e;
     if (*p == '"') return string(&s, &l, &e);
     if (*p == '{' || *p == '[') {
       int depth = 0;
@@ -497,73 +576,39 @@ struct JsonScan {
   }
 };
 
-__device__ __forceinline__ bool name_is(const char* want, const uint8_t* got, int got_len) {
-  int n = 0;
-  while (n < SURGE_EVJ_NAME && want[n]) ++n;
-  if (n != got_len) return false;
-  for (int i = 0; i < n; ++i)
+template <typename P>
+__device__ __forceinline__ bool name_is(const char* want, int want_len, P got, int got_len) {
+  if (want_len != got_len) return false;
+  for (int i = 0; i < want_len; ++i)
     if ((uint8_t)want[i] != got[i]) return false;
   return true;
 }
 
-struct Found {
-  const uint8_t* s;
-  int len;
-  bool is_num, is_str, escaped;
+// The template as the kernels use it: the distinct field names the decoder has to look for, with their lengths, and per
+// event type which of them carry its sequence number / argument — so ONE pass over the object finds everything (round 3
+// walked the text twice: once for the discriminator, once for the fields of the type it selected).
+constexpr int kEvjNames = 1 + 2 * SURGE_EVJ_MAX_TYPES;
+struct EvjDevice {
+  uint32_t n_types, n_names;                  // names[0] is the discriminator ("" when the template has none)
+  char names[kEvjNames][SURGE_EVJ_NAME];
+  uint8_t name_len[kEvjNames];
+  char type_name[SURGE_EVJ_MAX_TYPES][SURGE_EVJ_NAME];
+  uint8_t type_name_len[SURGE_EVJ_MAX_TYPES];
+  uint8_t seq_name[SURGE_EVJ_MAX_TYPES], arg_name[SURGE_EVJ_MAX_TYPES];  // index into names, 0xff = none
+  uint32_t event_type[SURGE_EVJ_MAX_TYPES], arg_kind[SURGE_EVJ_MAX_TYPES];
 };
 
-// One pass over the top-level object, looking for the fields named a / b (either may be NULL) exactly as the host
-// decoder's lookups do on duplicated names: FIRST_NUMERIC = the first field of that name that is a number (find_num),
-// otherwise the last field of that name whatever it is (the discriminator loop).  Returns false on malformed JSON.
-template <bool FIRST_NUMERIC>
-__device__ bool scan_object(const uint8_t* v, int len, const char* name_a, Found* fa, const char* name_b, Found* fb) {
-  JsonScan sc{v, v + len};
-  if (fa) fa->s = nullptr;
-  if (fb) fb->s = nullptr;
-  sc.ws();
-  if (sc.p >= sc.end || *sc.p != '{') return false;
-  ++sc.p;
-  sc.ws();
-  if (sc.p < sc.end && *sc.p == '}') {
-    ++sc.p;
-  } else {
-    int n_fields = 0;
-    for (;;) {
-      sc.ws();
-      const uint8_t* key; int key_len; bool esc = false;
-      if (!sc.string(&key, &key_len, &esc)) return false;
-      sc.ws();
-      if (sc.p >= sc.end || *sc.p != ':') return false;
-      ++sc.p;
-      sc.ws();
-      if (sc.p >= sc.end) return false;
-      Found cur;
-      cur.s = nullptr; cur.len = 0; cur.is_num = cur.is_str = cur.escaped = false;
-      if (*sc.p == '"') {
-        if (!sc.string(&cur.s, &cur.len, &cur.escaped)) return false;
-        cur.is_str = true;
-      } else if (*sc.p == '-' || (*sc.p >= '0' && *sc.p <= '9')) {
-        if (!sc.number(&cur.s, &cur.len)) return false;
-        cur.is_num = true;
-      } else if (!sc.skip_value()) {
-        return false;
-      }
-      if (!esc && n_fields < 24) {  // the host decoder remembers 24 fields and ignores names with escapes
-        ++n_fields;
-        if (fa && name_a && name_is(name_a, key, key_len) && (FIRST_NUMERIC ? (cur.is_num && !(fa->s && fa->is_num)) : true)) *fa = cur;
-        if (fb && name_b && name_is(name_b, key, key_len) && (FIRST_NUMERIC ? (cur.is_num && !(fb->s && fb->is_num)) : true)) *fb = cur;
-      }
-      sc.ws();
-      if (sc.p < sc.end && *sc.p == ',') { ++sc.p; continue; }
-      if (sc.p < sc.end && *sc.p == '}') { ++sc.p; break; }
-      return false;
-    }
-  }
-  sc.ws();
-  return sc.p == sc.end;
-}
+template <typename P>
+struct FoundT {
+  P s;
+  int len;
+  bool present, is_num, is_str, escaped;
+};
 
-__device__ int parse_i32(const uint8_t* s, int len, int32_t* out) {  // 0 ok, else not an Int
+constexpr int kEvjTrack = 8;  // numeric field names tracked in registers; templates with more use the generic lookup below
+
+template <typename P>
+__device__ int parse_i32(P s, int len, int32_t* out) {  // 0 ok, else not an Int
   if (len <= 0 || len > 11) return 1;
   int i = 0;
   bool neg = false;
@@ -580,126 +625,403 @@ __device__ int parse_i32(const uint8_t* s, int len, int32_t* out) {  // 0 ok, el
   return 0;
 }
 
-// the rules of surge_event_json_decode (event_decode.cpp), on the device
-__device__ uint32_t decode_json_event(const surge_event_json_template* t, const surge::F64ParseTable* ptab, const uint8_t* v, int len, uint4* out) {
-  const surge_event_json_type* ty = nullptr;
-  if (t->discriminator[0] == 0) {
-    ty = &t->types[0];
-    if (!scan_object<false>(v, len, nullptr, nullptr, nullptr, nullptr)) return RS_JSON;
+// the rules of surge_event_json_decode (event_decode.cpp), on the device, in one pass over the object: the discriminator
+// is the LAST field of its name among the first 24 fields with unescaped names, a sequence / argument field the FIRST
+// numeric field of its name among them
+template <typename P>
+__device__ uint32_t decode_json_event(const EvjDevice* __restrict__ t, const surge::F64ParseTable* ptab, P v, int len, uint4* out) {
+  JsonScanT<P> sc{v, v + len};
+  FoundT<P> disc;
+  disc.present = false; disc.is_num = disc.is_str = disc.escaped = false; disc.len = 0; disc.s = v;
+  P num_s[kEvjTrack];
+  int num_len[kEvjTrack];
+#pragma unroll
+  for (int j = 0; j < kEvjTrack; ++j) { num_s[j] = v; num_len[j] = -1; }
+  const int n_names = (int)t->n_names;
+  sc.ws();
+  if (sc.p >= sc.end || *sc.p != '{') return RS_JSON;
+  ++sc.p;
+  sc.ws();
+  if (sc.p < sc.end && *sc.p == '}') {
+    ++sc.p;
   } else {
-    Found d;
-    if (!scan_object<false>(v, len, t->discriminator, &d, nullptr, nullptr)) return RS_JSON;
-    if (!d.s || !d.is_str) return RS_FIELD;
-    for (uint32_t i = 0; i < t->n_types && !ty; ++i)
-      if (!d.escaped && name_is(t->types[i].name, d.s, d.len)) ty = &t->types[i];
-    if (!ty) return RS_TYPE;
+    int n_fields = 0;
+    for (;;) {
+      sc.ws();
+      P key; int key_len; bool esc = false;
+      if (!sc.string(&key, &key_len, &esc)) return RS_JSON;
+      sc.ws();
+      if (sc.p >= sc.end || *sc.p != ':') return RS_JSON;
+      ++sc.p;
+      sc.ws();
+      if (sc.p >= sc.end) return RS_JSON;
+      FoundT<P> cur;
+      cur.s = sc.p; cur.len = 0; cur.present = true; cur.is_num = cur.is_str = cur.escaped = false;
+      if (*sc.p == '"') {
+        if (!sc.string(&cur.s, &cur.len, &cur.escaped)) return RS_JSON;
+        cur.is_str = true;
+      } else if (*sc.p == '-' || (*sc.p >= '0' && *sc.p <= '9')) {
+        if (!sc.number(&cur.s, &cur.len)) return RS_JSON;
+        cur.is_num = true;
+      } else if (!sc.skip_value()) {
+        return RS_JSON;
+      }
+      if (!esc && n_fields < 24) {  // the host decoder remembers 24 fields and ignores names with escapes
+        ++n_fields;
+        if (t->name_len[0] && name_is(t->names[0], t->name_len[0], key, key_len)) disc = cur;
+        if (cur.is_num) {
+#pragma unroll
+          for (int j = 0; j < kEvjTrack; ++j)
+            if (j + 1 < n_names && num_len[j] < 0 && name_is(t->names[j + 1], t->name_len[j + 1], key, key_len)) { num_s[j] = cur.s; num_len[j] = cur.len; }
+        }
+      }
+      sc.ws();
+      if (sc.p < sc.end && *sc.p == ',') { ++sc.p; continue; }
+      if (sc.p < sc.end && *sc.p == '}') { ++sc.p; break; }
+      return RS_JSON;
+    }
   }
-  Found fs, fa;
-  fs.s = fa.s = nullptr;
-  if (ty->seq_field[0] || ty->arg_kind != SURGE_EVJ_ARG_NONE)
-    (void)scan_object<true>(v, len, ty->seq_field[0] ? ty->seq_field : nullptr, &fs, ty->arg_kind != SURGE_EVJ_ARG_NONE ? ty->arg_field : nullptr, &fa);
+  sc.ws();
+  if (sc.p != sc.end) return RS_JSON;
+  int ty = -1;
+  if (t->name_len[0] == 0) {
+    ty = 0;
+  } else {
+    if (!disc.present || !disc.is_str) return RS_FIELD;
+    for (uint32_t i = 0; i < t->n_types && ty < 0; ++i)
+      if (!disc.escaped && name_is(t->type_name[i], t->type_name_len[i], disc.s, disc.len)) ty = (int)i;
+    if (ty < 0) return RS_TYPE;
+  }
+  auto pick = [&](int name_idx, P* s, int* l) {  // the tracked field of that name (name_idx >= 1)
+    *l = -1;
+#pragma unroll
+    for (int j = 0; j < kEvjTrack; ++j)
+      if (j + 1 == name_idx) { *s = num_s[j]; *l = num_len[j]; }
+  };
   int32_t seq = 0;
-  if (ty->seq_field[0]) {
-    if (!fs.s || !fs.is_num || parse_i32(fs.s, fs.len, &seq) != 0) return RS_FIELD;
+  if (t->seq_name[ty] != 0xff) {
+    P s = v; int l;
+    pick(t->seq_name[ty], &s, &l);
+    if (l < 0 || parse_i32(s, l, &seq) != 0) return RS_FIELD;
   }
   uint64_t raw = 0;
   uint32_t status = RS_OK;
-  if (ty->arg_kind != SURGE_EVJ_ARG_NONE) {
-    if (!fa.s || !fa.is_num) return RS_FIELD;
-    if (ty->arg_kind == SURGE_EVJ_ARG_I32) {
+  if (t->arg_kind[ty] != SURGE_EVJ_ARG_NONE) {
+    P s = v; int l;
+    pick(t->arg_name[ty], &s, &l);
+    if (l < 0) return RS_FIELD;
+    if (t->arg_kind[ty] == SURGE_EVJ_ARG_I32) {
       int32_t a = 0;
-      if (parse_i32(fa.s, fa.len, &a) != 0) return RS_FIELD;
+      if (parse_i32(s, l, &a) != 0) return RS_FIELD;
       raw = (uint64_t)(uint32_t)a;
     } else {
-      const int rc = surge::f64_parse_json_number(fa.s, fa.len, ptab, &raw);
+      const int rc = surge::f64_parse_json_number((const uint8_t*)s, l, ptab, &raw);  // (a flat pointer: the parser is shared with the host)
       if (rc == surge::F64_PARSE_MALFORMED) return RS_FIELD;
       if (rc == surge::F64_PARSE_AMBIGUOUS) status = RS_F64_HOST;  // type and seq are final; the host fills in the payload
     }
   }
-  *out = make_uint4(ty->event_type, (uint32_t)seq, (uint32_t)raw, (uint32_t)(raw >> 32));
+  *out = make_uint4(t->event_type[ty], (uint32_t)seq, (uint32_t)raw, (uint32_t)(raw >> 32));
   return status;
 }
 
-// One thread per record.  The records of a block lie next to each other in the staged bytes (a section's records are
-// contiguous), so the block first copies the span that holds its keys and values into LDS with 16-byte loads and every
-// thread then walks its JSON text there: the walk is a chain of dependent single-byte reads, and an LDS read answers in
-// a tenth of the time a global one does (1.3 ms -> see DESIGN N1 per 1 M records).  A span that does not fit (records
-// handed over as separate key / value arrays, very long values) is read in place.
-constexpr int kResolveStage = 40960;
-__global__ void __launch_bounds__(256) resolve_kernel(RecMeta* __restrict__ meta, int64_t n_rec, const uint8_t* __restrict__ bytes, Table t,
-                                                      const uint8_t* __restrict__ arena, const int64_t* __restrict__ key_off,
-                                                      const surge_event_json_template* tmpl, const surge::F64ParseTable* ptab,
-                                                      int64_t* __restrict__ agg_tmp, uint4* __restrict__ ev_tmp, uint32_t* __restrict__ keep,
-                                                      uint32_t* __restrict__ f64_host_list, ErrorCell* err) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
-  __shared__ unsigned long long s_lo, s_hi;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// a record value -> event16 + status
+template <typename P>
+__device__ __forceinline__ uint32_t decode_value(const EvjDevice* __restrict__ tmpl, const surge::F64ParseTable* ptab, P vp, int val_len, uint4* e) {
+  if (tmpl) return decode_json_event(tmpl, ptab, vp, val_len, e);
+  if (val_len != 16) return RS_SIZE;
+  uint32_t w[4];
+  for (int q = 0; q < 4; ++q) w[q] = (uint32_t)vp[4 * q] | ((uint32_t)vp[4 * q + 1] << 8) | ((uint32_t)vp[4 * q + 2] << 16) | ((uint32_t)vp[4 * q + 3] << 24);
+  *e = make_uint4(w[0], w[1], w[2], w[3]);
+  return RS_OK;
+}
+
+// one record body [body, end) of a section that starts at `base` (absolute offset sec_off in the staged bytes)
+template <typename P>
+__device__ __forceinline__ void decode_record(P base, int64_t sec_off, int64_t base_offset, int32_t body, int32_t end, int64_t gi, uint64_t seed,
+                                              const EvjDevice* __restrict__ tmpl, const surge::F64ParseTable* ptab, RecMeta* __restrict__ meta,
+                                              uint4* __restrict__ ev_tmp, uint32_t* __restrict__ f64_host_list, ErrorCell* err) {
   RecMeta m;
-  m.status = RS_MALFORMED;
-  if (i < n_rec) m = meta[i];
-  const bool live = i < n_rec && m.status == RS_OK;
-  if (threadIdx.x == 0) { s_lo = ~0ull; s_hi = 0ull; }
-  __syncthreads();
-  if (live) {
-    const int64_t v1 = m.val_off + (m.val_len > 0 ? m.val_len : 0), k1 = m.key_off + (m.key_len > 0 ? m.key_len : 0);
-    atomicMin(&s_lo, (unsigned long long)(m.key_off < m.val_off ? m.key_off : m.val_off));
-    atomicMax(&s_hi, (unsigned long long)(v1 > k1 ? v1 : k1));
+  m.key_off = m.val_off = m.offset = 0; m.hash = 0; m.key_len = m.val_len = 0; m.slot = 0; m.status = RS_MALFORMED;
+  uint4 e = make_uint4(0, 0, 0, 0);
+  if (body >= 0) {
+    ReaderT<P> q{base + body, base + end, true};
+    if (q.p < q.end) ++q.p; else q.ok = false;  // attributes
+    (void)q.varlong();                            // timestampDelta
+    const int64_t offset_delta = q.varlong();
+    const int64_t klen = q.varlong();
+    P key = q.p;
+    if (q.ok && klen > 0) { if (q.end - q.p >= klen) q.p += klen; else q.ok = false; }
+    const int64_t vlen = q.ok ? q.varlong() : 0;
+    P val = q.p;
+    if (q.ok && vlen > 0) { if (q.end - q.p >= vlen) q.p += vlen; else q.ok = false; }
+    // (headers follow; the chain already knows where the record ends)
+    if (q.ok && klen >= -1 && vlen >= -1 && klen < (1ll << 31) && vlen < (1ll << 31)) {
+      m.offset = base_offset + offset_delta;
+      if (klen == 0 && vlen == 0) {
+        m.status = RS_SKIP;  // KafkaProducerActorImpl.scala:322-329
+      } else if (klen < 0 || vlen < 0) {
+        m.status = RS_NULL;
+      } else {
+        int n = 0;
+        while (n < (int)klen && key[n] != (uint8_t)':') ++n;  // PartitionStringUpToColon (KafkaPartitioner.scala:38-42)
+        m.key_off = sec_off + (key - base);
+        m.key_len = n;
+        m.val_off = sec_off + (val - base);
+        m.val_len = (int32_t)vlen;
+        m.hash = hash_key(key, n, seed);
+        uint32_t st = decode_value(tmpl, ptab, val, (int)vlen, &e);
+        if (st == RS_F64_HOST) {
+          f64_host_list[atomicAdd(&err->n_f64_host, 1u)] = (uint32_t)gi;
+          st = RS_OK;
+        }
+        m.status = st;
+      }
+    }
   }
+  if (m.status >= RS_NULL) report(err, gi, m.status);
+  meta[gi] = m;
+  ev_tmp[gi] = e;
+}
+
+constexpr int kSecThreads = 256;
+constexpr int kSecRecs = 512;  // records chained per round (LDS: two int32 per record)
+
+// the length varints of up to kSecRecs records from relative position *pos on; false = unreadable from record `bad` on
+template <typename P>
+__device__ bool chain_records(P base, int32_t len, int32_t* pos, int32_t cnt, int32_t* rec_body, int32_t* rec_end, int32_t* bad) {
+  ReaderT<P> r{base + *pos, base + len, true};
+  for (int32_t i = 0; i < cnt; ++i) {
+    const int64_t l = r.varlong();
+    const int32_t at = (int32_t)(r.p - base);
+    if (!r.ok || l < 0 || r.end - r.p < l) { *bad = i; return false; }
+    rec_body[i] = at;
+    rec_end[i] = at + (int32_t)l;
+    r.p += l;
+  }
+  *pos = (int32_t)(r.p - base);
+  return true;
+}
+
+// A workgroup takes its section when lo_excl < byte_len and (byte_len <= cap or take_rest); byte_len <= cap is staged.
+__global__ void __launch_bounds__(kSecThreads) section_kernel(const uint8_t* __restrict__ bytes, const Section* __restrict__ sections, int64_t n_sections,
+                                                              int64_t lo_excl, int64_t cap, int32_t take_rest, uint64_t seed,
+                                                              const EvjDevice* __restrict__ tmpl, const surge::F64ParseTable* ptab, RecMeta* __restrict__ meta,
+                                                              uint4* __restrict__ ev_tmp, uint32_t* __restrict__ f64_host_list, ErrorCell* err) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t sec_smem[];
+  __shared__ int32_t s_pos, s_bad;
+  const Section sec = sections[blockIdx.x];
+  if (sec.n_records <= 0) return;
+  const int64_t len = sec.byte_len;
+  if (!(len > lo_excl && (len <= cap || take_rest))) return;
+  const bool staged = len <= cap && len < (1ll << 31);
+  int32_t* const rec_body = (int32_t*)(sec_smem + ((cap + 47) & ~15ll));
+  int32_t* const rec_end = rec_body + kSecRecs;
+  const int64_t a0 = sec.byte_off & ~15ll;
+  const int32_t skew = (int32_t)(sec.byte_off - a0);
+  if (staged) {  // (the staged bytes buffer ends 16 bytes after its last byte)
+    const int n16 = (int)((skew + len + 15) >> 4);
+    for (int c = threadIdx.x; c < n16; c += kSecThreads) ((uint4*)sec_smem)[c] = *(const uint4*)(bytes + a0 + 16ll * c);
+  }
+  if (threadIdx.x == 0) { s_pos = 0; s_bad = -1; }
   __syncthreads();
-  const unsigned long long lo = s_lo & ~15ull, hi = s_hi;
-  const bool staged = hi > lo && hi - lo <= (unsigned long long)kResolveStage;  // block-uniform
-  if (staged) {
-    const int n16 = (int)((hi - lo + 15) >> 4);  // the staged bytes buffer ends 16 bytes after its last byte
-    for (int c = threadIdx.x; c < n16; c += blockDim.x) ((uint4*)stage)[c] = *(const uint4*)(bytes + lo + 16ull * (unsigned)c);
+  if (len >= (1ll << 31)) {  // a section of 2 GiB: nothing writes one (a batch's length is an int32)
+    for (int32_t i = threadIdx.x; i < sec.n_records; i += kSecThreads)
+      decode_record(bytes, 0, 0, -1, -1, sec.rec_first + i, seed, tmpl, ptab, meta, ev_tmp, f64_host_list, err);
+    return;
+  }
+  const lds_ptr_t lbase = (lds_ptr_t)sec_smem + skew;
+  const uint8_t* gbase = bytes + sec.byte_off;
+  for (int32_t r0 = 0; r0 < sec.n_records; r0 += kSecRecs) {
+    const int32_t cnt = sec.n_records - r0 < kSecRecs ? sec.n_records - r0 : kSecRecs;
+    if (threadIdx.x == 0) {
+      if (s_bad < 0) {
+        int32_t pos = s_pos, bad = 0;
+        const bool ok = staged ? chain_records(lbase, (int32_t)len, &pos, cnt, rec_body, rec_end, &bad) : chain_records(gbase, (int32_t)len, &pos, cnt, rec_body, rec_end, &bad);
+        s_pos = pos;
+        if (!ok) {
+          // everything from here to the end of the batch is unreadable: the rest is marked, the first is reported
+          s_bad = r0 + bad;
+          for (int32_t k = bad; k < cnt; ++k) rec_body[k] = -1;
+          report(err, sec.rec_first + r0 + bad, RS_MALFORMED);
+        }
+      } else {
+        for (int32_t k = 0; k < cnt; ++k) rec_body[k] = -1;
+      }
+    }
+    __syncthreads();
+    for (int32_t i = threadIdx.x; i < cnt; i += kSecThreads) {
+      const int32_t body = rec_body[i], end = body >= 0 ? rec_end[i] : -1;
+      if (staged)
+        decode_record(lbase, sec.byte_off, sec.base_offset, body, end, sec.rec_first + r0 + i, seed, tmpl, ptab, meta, ev_tmp, f64_host_list, err);
+      else
+        decode_record(gbase, sec.byte_off, sec.base_offset, body, end, sec.rec_first + r0 + i, seed, tmpl, ptab, meta, ev_tmp, f64_host_list, err);
+    }
     __syncthreads();
   }
+}
+
+// records that arrive already framed (a JVM's ConsumerRecords: key bytes, value bytes, offset per record): the bytes buffer
+// holds the keys first, the values from `val_base` on
+__global__ void records_kernel(const uint8_t* __restrict__ bytes, const int64_t* __restrict__ key_off, const int64_t* __restrict__ val_off,
+                               const int64_t* __restrict__ offsets, int64_t val_base, int64_t n_rec, uint64_t seed, const EvjDevice* __restrict__ tmpl,
+                               const surge::F64ParseTable* ptab, RecMeta* __restrict__ meta, uint4* __restrict__ ev_tmp, uint32_t* __restrict__ f64_host_list,
+                               ErrorCell* err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rec) return;
-  uint32_t k = 0;
-  if (live) {
-    const uint8_t* kp = staged ? (const uint8_t*)stage + (m.key_off - (int64_t)lo) : bytes + m.key_off;
-    const uint8_t* vp = staged ? (const uint8_t*)stage + (m.val_off - (int64_t)lo) : bytes + m.val_off;
-    const uint32_t id = t.key_id[m.slot];
-    const int64_t a0 = key_off[id], a1 = key_off[id + 1];
-    bool same = a1 - a0 == m.key_len;
-    for (int b = 0; same && b < m.key_len; ++b) same = arena[a0 + b] == kp[b];
-    uint4 e = make_uint4(0, 0, 0, 0);
-    uint32_t st = RS_OK;
-    if (!same) {
-      st = RS_COLLISION;
-    } else if (tmpl) {
-      st = decode_json_event(tmpl, ptab, vp, m.val_len, &e);
-    } else if (m.val_len == 16) {
-      uint32_t w[4];
-      for (int q = 0; q < 4; ++q) w[q] = (uint32_t)vp[4 * q] | ((uint32_t)vp[4 * q + 1] << 8) | ((uint32_t)vp[4 * q + 2] << 16) | ((uint32_t)vp[4 * q + 3] << 24);
-      e = make_uint4(w[0], w[1], w[2], w[3]);
-    } else {
-      st = RS_SIZE;
-    }
+  RecMeta m;
+  const int64_t k0 = key_off[i], k1 = key_off[i + 1], v0 = val_off[i], v1 = val_off[i + 1];
+  m.key_off = k0; m.val_off = val_base + v0; m.offset = offsets ? offsets[i] : i; m.hash = 0; m.key_len = 0; m.val_len = 0; m.slot = 0;
+  uint4 e = make_uint4(0, 0, 0, 0);
+  if (k1 < k0 || v1 < v0 || k1 - k0 >= (1ll << 31) || v1 - v0 >= (1ll << 31)) {
+    m.status = RS_MALFORMED;
+  } else if (k1 == k0 && v1 == v0) {
+    m.status = RS_SKIP;  // the producer's flush record
+  } else {
+    const uint8_t* key = bytes + k0;
+    int n = 0;
+    while (n < (int)(k1 - k0) && key[n] != (uint8_t)':') ++n;
+    m.key_len = n;
+    m.val_len = (int32_t)(v1 - v0);
+    m.hash = hash_key(key, n, seed);
+    uint32_t st = decode_value(tmpl, ptab, bytes + m.val_off, m.val_len, &e);
     if (st == RS_F64_HOST) {
       f64_host_list[atomicAdd(&err->n_f64_host, 1u)] = (uint32_t)i;
       st = RS_OK;
     }
-    if (st != RS_OK) {
-      report(err, i, st);
-      meta[i].status = st;
-    } else {
-      agg_tmp[i] = (int64_t)id;
-      ev_tmp[i] = e;
-      k = 1;
+    m.status = st;
+  }
+  if (m.status >= RS_NULL) report(err, i, m.status);
+  meta[i] = m;
+  ev_tmp[i] = e;
+}
+
+// ---- interning the aggregate ids -----------------------------------------------------------------------------------------
+struct Table {
+  unsigned long long* hash;  // 0 = empty
+  uint32_t* key_id;          // 0xffffffff = not assigned yet (inserted by the push in flight)
+  uint32_t* first_rec;       // of a slot inserted by the push in flight: its first record (0xffffffff otherwise)
+  uint64_t mask;
+};
+
+// insert-or-find by hash; a slot this push inserts remembers its first record
+__global__ void probe_kernel(RecMeta* __restrict__ meta, int64_t n_rec, Table t) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rec) return;
+  if (meta[i].status != RS_OK) return;
+  const unsigned long long h = meta[i].hash;
+  uint64_t s = h & t.mask;
+  while (true) {
+    const unsigned long long old = atomicCAS(&t.hash[s], 0ull, h);
+    if (old == 0ull || old == h) break;
+    s = (s + 1) & t.mask;
+  }
+  meta[i].slot = (uint32_t)s;
+  if (t.key_id[s] == 0xffffffffu) atomicMin(&t.first_rec[s], (uint32_t)i);
+}
+
+// Per record: is it the first record of a key this push discovers (those get the next ids, in record order: the host
+// decoder's first-delivered numbering — an exclusive scan of the flags, no sort); does its key equal, byte for byte, the
+// key its slot stands for (the key arena for a known key, the slot's first record for a new one): a 64-bit hash
+// collision is detected here, before anything of the push is committed.  first[i] = flag << 40 | key length (scanned:
+// id rank and arena offset in one pass); keep[i] = the record is delivered.
+__global__ void flag_kernel(const RecMeta* __restrict__ meta, int64_t n_rec, const uint8_t* __restrict__ bytes, Table t, const uint8_t* __restrict__ arena,
+                            const int64_t* __restrict__ key_off, unsigned long long* __restrict__ first, uint32_t* __restrict__ keep, ErrorCell* err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n_rec) return;
+  unsigned long long f = 0ull;
+  uint32_t k = 0u;
+  if (i < n_rec) {
+    const RecMeta m = meta[i];
+    if (m.status == RS_OK) {
+      const uint32_t id = t.key_id[m.slot];
+      const uint8_t* kp = bytes + m.key_off;
+      bool same;
+      if (id != 0xffffffffu) {
+        const int64_t a0 = key_off[id], a1 = key_off[id + 1];
+        same = a1 - a0 == m.key_len;
+        for (int b = 0; same && b < m.key_len; ++b) same = arena[a0 + b] == kp[b];
+      } else {
+        const uint32_t fr = t.first_rec[m.slot];
+        if ((int64_t)fr == i) {
+          same = true;
+          f = (1ull << 40) | (unsigned long long)(uint32_t)m.key_len;
+        } else {
+          const RecMeta o = meta[fr];
+          const uint8_t* op = bytes + o.key_off;
+          same = o.key_len == m.key_len;
+          for (int b = 0; same && b < m.key_len; ++b) same = op[b] == kp[b];
+        }
+      }
+      if (same) k = 1u; else report(err, i, RS_COLLISION);
     }
   }
+  first[i] = f;  // (entry n_rec = 0: the scans' totals land there)
   keep[i] = k;
 }
 
-__global__ void scatter_kernel(const uint32_t* __restrict__ keep, const uint32_t* __restrict__ pos, int64_t n_rec, const RecMeta* __restrict__ meta,
-                               const int64_t* __restrict__ agg_tmp, const uint4* __restrict__ ev_tmp, int64_t out_base, int64_t* __restrict__ agg_out,
-                               uint4* __restrict__ ev_out, int64_t* __restrict__ off_out) {
+// the keys this push discovered: id = n_keys + rank, bytes to the arena; their slots stop being "new"
+__global__ void assign_kernel(const RecMeta* __restrict__ meta, int64_t n_rec, const uint8_t* __restrict__ bytes, const unsigned long long* __restrict__ first,
+                              const unsigned long long* __restrict__ first_scan, int64_t n_keys, int64_t arena_base, Table t, uint8_t* __restrict__ arena,
+                              int64_t* __restrict__ key_off, unsigned long long* __restrict__ key_hash) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rec || first[i] == 0ull) return;
+  const RecMeta m = meta[i];
+  const unsigned long long sc = first_scan[i];
+  const int64_t id = n_keys + (int64_t)(sc >> 40);
+  const int64_t dst = arena_base + (int64_t)(sc & ((1ull << 40) - 1));
+  for (int b = 0; b < m.key_len; ++b) arena[dst + b] = bytes[m.key_off + b];
+  key_off[id + 1] = dst + m.key_len;
+  key_hash[id] = m.hash;
+  t.key_id[m.slot] = (uint32_t)id;
+  t.first_rec[m.slot] = 0xffffffffu;
+}
+
+// delivered records -> the result arrays (aggregate index from the record's slot)
+__global__ void finalize_kernel(const RecMeta* __restrict__ meta, int64_t n_rec, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ pos, Table t,
+                                const uint4* __restrict__ ev_tmp, int64_t out_base, int64_t* __restrict__ agg_out, uint4* __restrict__ ev_out,
+                                int64_t* __restrict__ off_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rec || !keep[i]) return;
   const int64_t o = out_base + pos[i];
-  agg_out[o] = agg_tmp[i];
+  agg_out[o] = (int64_t)t.key_id[meta[i].slot];
   ev_out[o] = ev_tmp[i];
   off_out[o] = meta[i].offset;
+}
+
+// a push that fails after its keys were probed takes them out again: slots it inserted go back to empty (they only ever
+// occupied slots that were empty before, so the table is what it was)
+__global__ void rollback_kernel(const RecMeta* __restrict__ meta, int64_t n_rec, Table t) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rec || meta[i].status != RS_OK) return;
+  const uint32_t s = meta[i].slot;
+  if (t.key_id[s] == 0xffffffffu) {
+    t.hash[s] = 0ull;
+    t.first_rec[s] = 0xffffffffu;
+  }
+}
+
+__global__ void rehash_kernel(const unsigned long long* __restrict__ key_hash, int64_t n_keys, Table t) {
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= n_keys) return;
+  const unsigned long long h = key_hash[id];
+  uint64_t s = h & t.mask;
+  // (two known keys that collide under a new seed share a hash and get two slots: lookups of the second then find the
+  // first, flag_kernel reports the mismatch and the table is re-seeded once more)
+  while (atomicCAS(&t.hash[s], 0ull, h) != 0ull) s = (s + 1) & t.mask;
+  t.key_id[s] = (uint32_t)id;
+}
+
+// after a re-seed: every known key's hash from its bytes in the arena, every record's from its key in the staged bytes
+__global__ void rekey_keys_kernel(const uint8_t* __restrict__ arena, const int64_t* __restrict__ key_off, int64_t n_keys, uint64_t seed,
+                                  unsigned long long* __restrict__ key_hash) {
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= n_keys) return;
+  key_hash[id] = hash_key(arena + key_off[id], (int)(key_off[id + 1] - key_off[id]), seed);
+}
+__global__ void rekey_records_kernel(RecMeta* __restrict__ meta, int64_t n_rec, const uint8_t* __restrict__ bytes, uint64_t seed) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rec || meta[i].status != RS_OK) return;
+  meta[i].hash = hash_key(bytes + meta[i].key_off, meta[i].key_len, seed);
 }
 
 struct Buf {
@@ -732,21 +1054,26 @@ struct surge_device_decoder {
   int device = 0;
   hipStream_t stream = nullptr;
   bool json = false;
+  bool poisoned = false;  // a device error left the tables in an unknown state: every later push is refused
   std::string err;
   Buf d_tmpl, d_ptab, d_err;
+  surge_event_json_template h_tmpl;  // (host copy: Doubles the device cannot decide are re-parsed with it)
   // per push
-  Buf lz4_blocks, lz4_sizes;
-  Buf d_bytes, d_sections, rec_pos, rec_end, meta, new_slots, sort_k_a, sort_k_b, sort_v_b, lens, agg_tmp, ev_tmp, keep, keep_pos, f64_list, temp;
+  Buf lz4_blocks, lz4_sizes, lz4_nseq, lz4_seq, lz4_cls;
+  Buf d_bytes, d_sections, rec_pos, rec_end, meta, first, first_scan, ev_tmp, keep, keep_pos, f64_list, temp;
   void* pinned = nullptr;
   size_t pinned_cap = 0;
+  std::vector<Section> h_secs;      // (sources of asynchronous copies: they live until the push's first synchronisation at least)
+  std::vector<Lz4Block> h_blocks;
   // hash table + key table
   Buf t_hash, t_key_id, t_first, arena, key_off, key_hash;
-  uint64_t t_cap = 0;
+  uint64_t t_cap = 0, seed = 0;
   int64_t n_keys = 0, arena_bytes = 0;
   // result
   Buf r_agg, r_ev, r_off;
   int64_t n_records = 0;
   int64_t counters[4] = {0, 0, 0, 0};  // records seen, delivered, flush records skipped, f64 values re-parsed on the host
+  int64_t reseeds = 0, pushes = 0;
 };
 
 namespace {
@@ -826,6 +1153,8 @@ int32_t surge_device_decoder_create(int32_t device_id, void* hip_stream, const s
   d->device = device_id;
   d->stream = (hipStream_t)hip_stream;
   d->json = tmpl != nullptr;
+  if (const char* v = std::getenv("SURGE_INGEST_DEBUG_WEAK_HASH"))
+    if (v[0] == '1') d->seed = 1ull << 63;  // test hook: the table's first hash function keeps 8 bits, so keys collide and the re-seed runs
   int prev = 0;
   (void)hipGetDevice(&prev);
   int32_t rc = OK;
@@ -835,8 +1164,37 @@ int32_t surge_device_decoder_create(int32_t device_id, void* hip_stream, const s
     DCHK(d, d->key_off.reserve(8, false, d->stream));
     DCHK(d, hipMemset(d->key_off.p, 0, 8));
     if (tmpl) {
-      DCHK(d, d->d_tmpl.reserve(sizeof(*tmpl), false, d->stream));
-      DCHK(d, hipMemcpy(d->d_tmpl.p, tmpl, sizeof(*tmpl), hipMemcpyHostToDevice));
+      d->h_tmpl = *tmpl;
+      // the distinct field names, each once, and per type which of them it reads
+      static EvjDevice ev;  // (400-odd bytes of names: off the stack; create is not a hot path, guarded by the copy below)
+      static std::mutex ev_mu;
+      std::lock_guard<std::mutex> lk(ev_mu);
+      std::memset(&ev, 0, sizeof(ev));
+      ev.n_types = tmpl->n_types;
+      auto intern = [&](const char* name) -> uint8_t {
+        if (!name[0]) return 0xff;
+        for (uint32_t j = 1; j < ev.n_names; ++j)
+          if (std::strncmp(ev.names[j], name, SURGE_EVJ_NAME) == 0) return (uint8_t)j;
+        std::memcpy(ev.names[ev.n_names], name, SURGE_EVJ_NAME);
+        ev.name_len[ev.n_names] = (uint8_t)strnlen(name, SURGE_EVJ_NAME);
+        return (uint8_t)ev.n_names++;
+      };
+      std::memcpy(ev.names[0], tmpl->discriminator, SURGE_EVJ_NAME);
+      ev.name_len[0] = (uint8_t)strnlen(tmpl->discriminator, SURGE_EVJ_NAME);
+      ev.n_names = 1;
+      for (uint32_t i = 0; i < tmpl->n_types; ++i) {
+        const surge_event_json_type& ty = tmpl->types[i];
+        std::memcpy(ev.type_name[i], ty.name, SURGE_EVJ_NAME);
+        ev.type_name_len[i] = (uint8_t)strnlen(ty.name, SURGE_EVJ_NAME);
+        ev.seq_name[i] = intern(ty.seq_field);
+        ev.arg_name[i] = intern(ty.arg_field);
+        ev.event_type[i] = ty.event_type;
+        ev.arg_kind[i] = ty.arg_kind;
+      }
+      if (ev.n_names - 1 > (uint32_t)kEvjTrack)
+        return dfail(d, E_UNSUPPORTED, "the event template names more than 8 distinct sequence / argument fields (decode this topic with surge_ingest_drain_json)");
+      DCHK(d, d->d_tmpl.reserve(sizeof(ev), false, d->stream));
+      DCHK(d, hipMemcpy(d->d_tmpl.p, &ev, sizeof(ev), hipMemcpyHostToDevice));
       DCHK(d, d->d_ptab.reserve(sizeof(surge::F64ParseTable), false, d->stream));
       DCHK(d, hipMemcpy(d->d_ptab.p, surge::f64_parse_table_host(), sizeof(surge::F64ParseTable), hipMemcpyHostToDevice));
     }
@@ -858,9 +1216,9 @@ int32_t surge_device_decoder_destroy(surge_device_decoder* d) {
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  Buf* bufs[] = {&d->lz4_blocks, &d->lz4_sizes, &d->d_tmpl, &d->d_ptab, &d->d_err, &d->d_bytes, &d->d_sections, &d->rec_pos, &d->rec_end, &d->meta, &d->new_slots, &d->sort_k_a,
-                 &d->sort_k_b, &d->sort_v_b, &d->lens, &d->agg_tmp, &d->ev_tmp, &d->keep, &d->keep_pos, &d->f64_list, &d->temp, &d->t_hash,
-                 &d->t_key_id, &d->t_first, &d->arena, &d->key_off, &d->key_hash, &d->r_agg, &d->r_ev, &d->r_off};
+  Buf* bufs[] = {&d->lz4_blocks, &d->lz4_sizes, &d->lz4_nseq, &d->lz4_seq, &d->lz4_cls, &d->d_tmpl, &d->d_ptab, &d->d_err, &d->d_bytes, &d->d_sections, &d->rec_pos,
+                 &d->rec_end, &d->meta, &d->first, &d->first_scan, &d->ev_tmp, &d->keep, &d->keep_pos, &d->f64_list, &d->temp, &d->t_hash, &d->t_key_id,
+                 &d->t_first, &d->arena, &d->key_off, &d->key_hash, &d->r_agg, &d->r_ev, &d->r_off};
   for (Buf* b : bufs) b->release();
   if (d->pinned) (void)hipHostFree(d->pinned);
   (void)hipSetDevice(prev);
@@ -874,129 +1232,167 @@ namespace {
 
 // scratch of one push and a fresh error cell; the hash table sized for n_rec more keys
 int32_t begin_push(surge_device_decoder* d, int64_t n_rec) {
+  if (d->poisoned) return dfail(d, SURGE_E_STATE, "an earlier push failed on the device half way: destroy this decoder and create a new one");
   hipStream_t st = d->stream;
   const size_t R = (size_t)n_rec;
   DCHK(d, d->meta.reserve(R * sizeof(RecMeta), false, st));
-  DCHK(d, d->new_slots.reserve(R * 4, false, st));
-  DCHK(d, d->agg_tmp.reserve(R * 8, false, st));
+  DCHK(d, d->first.reserve((R + 1) * 8, false, st));
+  DCHK(d, d->first_scan.reserve((R + 1) * 8, false, st));
   DCHK(d, d->ev_tmp.reserve(R * 16, false, st));
-  DCHK(d, d->keep.reserve(R * 4, false, st));
-  DCHK(d, d->keep_pos.reserve(R * 4, false, st));
+  DCHK(d, d->keep.reserve((R + 1) * 4, false, st));
+  DCHK(d, d->keep_pos.reserve((R + 1) * 4, false, st));
   DCHK(d, d->f64_list.reserve(R * 4, false, st));
+  size_t tb_a = 0, tb_b = 0;
+  DCHK(d, rocprim::exclusive_scan(nullptr, tb_a, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, 0ull, R + 1, rocprim::plus<unsigned long long>(), st));
+  DCHK(d, rocprim::exclusive_scan(nullptr, tb_b, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, R + 1, rocprim::plus<uint32_t>(), st));
+  DCHK(d, d->temp.reserve(tb_a > tb_b ? tb_a : tb_b, false, st));
   ErrorCell zero{~0ull, 0u, 0u, ~0u, 0u};
   DCHK(d, hipMemcpyAsync(d->d_err.p, &zero, sizeof(zero), hipMemcpyHostToDevice, st));
   return ensure_table(d, n_rec);
 }
 
-// everything behind the per-record metadata: interning, value decode, compaction, append
-int32_t finish_push(surge_device_decoder* d, int64_t n_rec) {
+const char* why_bad(uint32_t status) {
+  static const char* why[] = {"", "", "has a null key or value (not an event)", "is malformed (a length runs past its record or batch)",
+                              "is not the JSON object the event template describes", "names an event type the template does not know",
+                              "lacks a field the template names, or the field is not the number it should be", "is not a 16-byte fixed event", "",
+                              "collides with another key on its 64-bit hash"};
+  return status < 10 ? why[status] : "is bad";
+}
+
+// Everything behind the per-record metadata and decoded values: interning, compaction, append.  Two synchronisations:
+// one in the middle (what the push discovered: errors, new keys, their bytes, delivered records — everything the
+// allocations behind it need), one at the end.  Nothing is committed before the first: a push that fails takes the keys
+// it probed out of the table again (rollback_kernel), so a failed push leaves the decoder exactly as it was.
+int32_t finish_push(surge_device_decoder* d, int64_t n_rec, const surge_batch_section* sections) {
   hipStream_t st = d->stream;
   const size_t R = (size_t)n_rec;
   const uint8_t* dby = (const uint8_t*)d->d_bytes.p;
   ErrorCell* derr = (ErrorCell*)d->d_err.p;
   RecMeta* dmeta = (RecMeta*)d->meta.p;
-  const unsigned rb = (unsigned)((n_rec + 255) / 256);
-  hipLaunchKernelGGL(probe_kernel, dim3(rb), dim3(256), 0, st, dmeta, n_rec, table_of(d), (uint32_t*)d->new_slots.p, derr);
+  const unsigned rb = (unsigned)((n_rec + 255) / 256), rb1 = (unsigned)((n_rec + 256) / 256);
+  auto poison = [&](int32_t rc) { d->poisoned = true; return rc; };
+#define PCHK(call)                                                                                                      \
+  do {                                                                                                                  \
+    hipError_t e_ = (call);                                                                                             \
+    if (e_ != hipSuccess) return poison(dfail(d, e_ == hipErrorOutOfMemory ? E_NOMEM : E_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_))); \
+  } while (0)
   ErrorCell ec;
-  DCHK(d, hipMemcpyAsync(&ec, derr, sizeof(ec), hipMemcpyDeviceToHost, st));
-  DCHK(d, hipStreamSynchronize(st));
-  const uint32_t n_new = ec.n_new;
-  if (n_new > 0) {
-    // new keys in first-delivered order
-    DCHK(d, d->sort_k_a.reserve((size_t)n_new * 4, false, st));
-    DCHK(d, d->sort_k_b.reserve((size_t)n_new * 4, false, st));
-    DCHK(d, d->sort_v_b.reserve((size_t)n_new * 4, false, st));
-    DCHK(d, d->lens.reserve(((size_t)n_new + 1) * 8, false, st));
-    DCHK(d, d->key_off.reserve((size_t)(d->n_keys + n_new + 1) * 8, true, st));
-    DCHK(d, d->key_hash.reserve((size_t)(d->n_keys + n_new) * 8, true, st));
-    size_t tb_sort = 0, tb_scan = 0;
-    DCHK(d, rocprim::radix_sort_pairs(nullptr, tb_sort, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                      (size_t)n_new, 0u, 32u, st));
-    DCHK(d, rocprim::exclusive_scan(nullptr, tb_scan, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)n_new + 1,
-                                    rocprim::plus<int64_t>(), st));
-    DCHK(d, d->temp.reserve(tb_sort > tb_scan ? tb_sort : tb_scan, false, st));
-    const unsigned nb = (n_new + 256u) / 256u;
-    hipLaunchKernelGGL(newkey_keys_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t*)d->new_slots.p, n_new, table_of(d), (uint32_t*)d->sort_k_a.p);
+  unsigned long long first_total = 0;
+  uint32_t kept = 0;
+  for (int attempt = 0;; ++attempt) {
+    hipLaunchKernelGGL(probe_kernel, dim3(rb), dim3(256), 0, st, dmeta, n_rec, table_of(d));
+    hipLaunchKernelGGL(flag_kernel, dim3(rb1), dim3(256), 0, st, (const RecMeta*)dmeta, n_rec, dby, table_of(d), (const uint8_t*)d->arena.p, (const int64_t*)d->key_off.p,
+                       (unsigned long long*)d->first.p, (uint32_t*)d->keep.p, derr);
     size_t tb = d->temp.cap;
-    DCHK(d, rocprim::radix_sort_pairs(d->temp.p, tb, (const uint32_t*)d->sort_k_a.p, (uint32_t*)d->sort_k_b.p, (const uint32_t*)d->new_slots.p,
-                                      (uint32_t*)d->sort_v_b.p, (size_t)n_new, 0u, 32u, st));
-    hipLaunchKernelGGL(newkey_len_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t*)d->sort_k_b.p, n_new, dmeta, (int64_t*)d->lens.p);
+    PCHK(rocprim::exclusive_scan(d->temp.p, tb, (const unsigned long long*)d->first.p, (unsigned long long*)d->first_scan.p, 0ull, R + 1,
+                                 rocprim::plus<unsigned long long>(), st));
     tb = d->temp.cap;
-    DCHK(d, rocprim::exclusive_scan(d->temp.p, tb, (const int64_t*)d->lens.p, (int64_t*)d->lens.p, (int64_t)0, (size_t)n_new + 1,
-                                    rocprim::plus<int64_t>(), st));
-    int64_t new_bytes = 0;
-    DCHK(d, hipMemcpyAsync(&new_bytes, (int64_t*)d->lens.p + n_new, 8, hipMemcpyDeviceToHost, st));
-    DCHK(d, hipStreamSynchronize(st));
-    DCHK(d, d->arena.reserve((size_t)(d->arena_bytes + new_bytes) + 16, true, st));
-    hipLaunchKernelGGL(newkey_assign_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t*)d->sort_k_b.p, (const uint32_t*)d->sort_v_b.p, n_new, dmeta, dby,
-                       (const int64_t*)d->lens.p, d->n_keys, d->arena_bytes, table_of(d), (uint8_t*)d->arena.p, (int64_t*)d->key_off.p,
-                       (unsigned long long*)d->key_hash.p);
-    d->n_keys += n_new;
-    d->arena_bytes += new_bytes;
+    PCHK(rocprim::exclusive_scan(d->temp.p, tb, (const uint32_t*)d->keep.p, (uint32_t*)d->keep_pos.p, 0u, R + 1, rocprim::plus<uint32_t>(), st));
+    PCHK(hipMemcpyAsync(&ec, derr, sizeof(ec), hipMemcpyDeviceToHost, st));
+    PCHK(hipMemcpyAsync(&first_total, (unsigned long long*)d->first_scan.p + R, 8, hipMemcpyDeviceToHost, st));
+    PCHK(hipMemcpyAsync(&kept, (uint32_t*)d->keep_pos.p + R, 4, hipMemcpyDeviceToHost, st));
+    PCHK(hipStreamSynchronize(st));
+    if (ec.lz4_bad == ~0u && ec.first_bad != ~0ull && (uint32_t)(ec.first_bad & 0xff) == RS_COLLISION && attempt < 3) {
+      // Two different keys share a 64-bit hash (about 3 in a million pushes at 10^7 keys): the table gets another hash
+      // function — every known key re-hashed from its bytes in the arena, the push's records from theirs — and the push
+      // goes through again.  Nothing of it was committed.
+      hipLaunchKernelGGL(rollback_kernel, dim3(rb), dim3(256), 0, st, (const RecMeta*)dmeta, n_rec, table_of(d));
+      d->seed = (d->seed & ~(1ull << 63)) + 1;
+      ++d->reseeds;
+      PCHK(hipMemsetAsync(d->t_hash.p, 0, d->t_cap * 8, st));
+      PCHK(hipMemsetAsync(d->t_key_id.p, 0xff, d->t_cap * 4, st));
+      PCHK(hipMemsetAsync(d->t_first.p, 0xff, d->t_cap * 4, st));
+      if (d->n_keys > 0) {
+        const unsigned kb = (unsigned)((d->n_keys + 255) / 256);
+        hipLaunchKernelGGL(rekey_keys_kernel, dim3(kb), dim3(256), 0, st, (const uint8_t*)d->arena.p, (const int64_t*)d->key_off.p, d->n_keys, d->seed,
+                           (unsigned long long*)d->key_hash.p);
+        hipLaunchKernelGGL(rehash_kernel, dim3(kb), dim3(256), 0, st, (const unsigned long long*)d->key_hash.p, d->n_keys, table_of(d));
+      }
+      hipLaunchKernelGGL(rekey_records_kernel, dim3(rb), dim3(256), 0, st, dmeta, n_rec, dby, d->seed);
+      ErrorCell zero{~0ull, 0u, ec.n_f64_host, ~0u, 0u};
+      PCHK(hipMemcpyAsync(derr, &zero, sizeof(zero), hipMemcpyHostToDevice, st));
+      continue;
+    }
+    break;
   }
-  hipLaunchKernelGGL(resolve_kernel, dim3(rb), dim3(256), (size_t)kResolveStage, st, dmeta, n_rec, dby, table_of(d), (const uint8_t*)d->arena.p, (const int64_t*)d->key_off.p,
-                     d->json ? (const surge_event_json_template*)d->d_tmpl.p : nullptr, (const surge::F64ParseTable*)d->d_ptab.p,
-                     (int64_t*)d->agg_tmp.p, (uint4*)d->ev_tmp.p, (uint32_t*)d->keep.p, (uint32_t*)d->f64_list.p, derr);
-  // the first-record marks of this push's new slots are spent
-  if (n_new > 0) DCHK(d, hipMemsetAsync(d->t_first.p, 0xff, d->t_cap * 4, st));
-  size_t tb_scan = 0;
-  DCHK(d, rocprim::exclusive_scan(nullptr, tb_scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, R, rocprim::plus<uint32_t>(), st));
-  DCHK(d, d->temp.reserve(tb_scan, false, st));
-  size_t tb = d->temp.cap;
-  DCHK(d, rocprim::exclusive_scan(d->temp.p, tb, (const uint32_t*)d->keep.p, (uint32_t*)d->keep_pos.p, 0u, R, rocprim::plus<uint32_t>(), st));
-  uint32_t last_pos = 0, last_keep = 0;
-  DCHK(d, hipMemcpyAsync(&last_pos, (uint32_t*)d->keep_pos.p + (R - 1), 4, hipMemcpyDeviceToHost, st));
-  DCHK(d, hipMemcpyAsync(&last_keep, (uint32_t*)d->keep.p + (R - 1), 4, hipMemcpyDeviceToHost, st));
-  DCHK(d, hipMemcpyAsync(&ec, derr, sizeof(ec), hipMemcpyDeviceToHost, st));
-  DCHK(d, hipStreamSynchronize(st));
   d->counters[0] += n_rec;
+  auto rollback = [&]() -> int32_t {
+    hipLaunchKernelGGL(rollback_kernel, dim3(rb), dim3(256), 0, st, (const RecMeta*)dmeta, n_rec, table_of(d));
+    PCHK(hipStreamSynchronize(st));
+    return OK;
+  };
+  if (ec.lz4_bad != ~0u) {
+    const int32_t rc = rollback();
+    if (rc != OK) return rc;
+    return dfail(d, SURGE_E_CORRUPT, "bad LZ4 frame in the batch at base offset " + std::to_string(sections ? sections[ec.lz4_bad].base_offset : -1) +
+                                     " (malformed sequence, or a block that is not 64 KiB where it must be)");
+  }
   if (ec.first_bad != ~0ull) {
     const int64_t rec = (int64_t)(ec.first_bad >> 8);
     const uint32_t status = (uint32_t)(ec.first_bad & 0xff);
     RecMeta m;
-    DCHK(d, hipMemcpy(&m, dmeta + rec, sizeof(m), hipMemcpyDeviceToHost));
-    static const char* why[] = {"", "", "has a null key or value (not an event)", "is malformed (a length runs past its record or batch)",
-                                "is not the JSON object the event template describes", "names an event type the template does not know",
-                                "lacks a field the template names, or the field is not the number it should be",
-                                "is not a 16-byte fixed event", "", "collides with another key on its 64-bit hash (decode this topic with the host decoder)"};
-    // nothing of this push is delivered; keys it discovered stay interned (harmless: they are ids without events)
+    PCHK(hipMemcpy(&m, dmeta + rec, sizeof(m), hipMemcpyDeviceToHost));
+    const int32_t rc = rollback();
+    if (rc != OK) return rc;
+    // nothing of this push is delivered and no key it discovered stays interned
     return dfail(d, status == RS_COLLISION ? E_UNSUPPORTED : SURGE_E_CORRUPT,
-                 "record " + std::to_string(rec) + " of the push (offset " + std::to_string(m.offset) + ") " + (status < 10 ? why[status] : "is bad"));
+                 "record " + std::to_string(rec) + " of the push (offset " + std::to_string(m.offset) + ") " + why_bad(status) +
+                     (status == RS_COLLISION ? " under four hash functions in a row" : ""));
   }
-  const int64_t kept = (int64_t)last_pos + last_keep;
-  DCHK(d, d->r_agg.reserve((size_t)(d->n_records + kept) * 8 + 16, true, st));
-  DCHK(d, d->r_ev.reserve((size_t)(d->n_records + kept) * 16 + 16, true, st));
-  DCHK(d, d->r_off.reserve((size_t)(d->n_records + kept) * 8 + 16, true, st));
-  hipLaunchKernelGGL(scatter_kernel, dim3(rb), dim3(256), 0, st, (const uint32_t*)d->keep.p, (const uint32_t*)d->keep_pos.p, n_rec, dmeta,
-                     (const int64_t*)d->agg_tmp.p, (const uint4*)d->ev_tmp.p, d->n_records, (int64_t*)d->r_agg.p, (uint4*)d->r_ev.p, (int64_t*)d->r_off.p);
-  DCHK(d, hipGetLastError());
+  const int64_t n_new = (int64_t)(first_total >> 40), new_bytes = (int64_t)(first_total & ((1ull << 40) - 1));
+  {
+    // everything that can fail for want of memory, before the first commit
+    hipError_t e = hipSuccess;
+    if (n_new > 0) {
+      e = d->key_off.reserve((size_t)(d->n_keys + n_new + 1) * 8, true, st);
+      if (e == hipSuccess) e = d->key_hash.reserve((size_t)(d->n_keys + n_new) * 8, true, st);
+      if (e == hipSuccess) e = d->arena.reserve((size_t)(d->arena_bytes + new_bytes) + 16, true, st);
+    }
+    if (e == hipSuccess) e = d->r_agg.reserve((size_t)(d->n_records + kept) * 8 + 16, true, st);
+    if (e == hipSuccess) e = d->r_ev.reserve((size_t)(d->n_records + kept) * 16 + 16, true, st);
+    if (e == hipSuccess) e = d->r_off.reserve((size_t)(d->n_records + kept) * 8 + 16, true, st);
+    if (e != hipSuccess) {
+      const int32_t rc = rollback();
+      if (rc != OK) return rc;
+      return dfail(d, e == hipErrorOutOfMemory ? E_NOMEM : E_DEVICE, std::string("growing the key table / result arrays: ") + hipGetErrorString(e));
+    }
+  }
+  if (n_new > 0)
+    hipLaunchKernelGGL(assign_kernel, dim3(rb), dim3(256), 0, st, (const RecMeta*)dmeta, n_rec, dby, (const unsigned long long*)d->first.p,
+                       (const unsigned long long*)d->first_scan.p, d->n_keys, d->arena_bytes, table_of(d), (uint8_t*)d->arena.p, (int64_t*)d->key_off.p,
+                       (unsigned long long*)d->key_hash.p);
+  hipLaunchKernelGGL(finalize_kernel, dim3(rb), dim3(256), 0, st, (const RecMeta*)dmeta, n_rec, (const uint32_t*)d->keep.p, (const uint32_t*)d->keep_pos.p, table_of(d),
+                     (const uint4*)d->ev_tmp.p, d->n_records, (int64_t*)d->r_agg.p, (uint4*)d->r_ev.p, (int64_t*)d->r_off.p);
+  PCHK(hipGetLastError());
+  d->n_keys += n_new;
+  d->arena_bytes += new_bytes;
   if (ec.n_f64_host > 0) {
-    DCHK(d, hipStreamSynchronize(st));  // the scatter has to be done before the payloads are patched
+    PCHK(hipStreamSynchronize(st));  // the results have to be in place before the payloads are patched
     // Doubles the fast parser could not decide (more than 19 digits, or one of Eisel-Lemire's rare ambiguous products):
     // the host parses exactly those values with the library's host decoder and patches the payload in place
     std::vector<uint32_t> list(ec.n_f64_host);
-    DCHK(d, hipMemcpy(list.data(), d->f64_list.p, (size_t)ec.n_f64_host * 4, hipMemcpyDeviceToHost));
-    surge_event_json_template tmpl;
-    DCHK(d, hipMemcpy(&tmpl, d->d_tmpl.p, sizeof(tmpl), hipMemcpyDeviceToHost));
+    PCHK(hipMemcpy(list.data(), d->f64_list.p, (size_t)ec.n_f64_host * 4, hipMemcpyDeviceToHost));
     for (uint32_t i : list) {
       RecMeta m;
       uint32_t pos = 0;
-      DCHK(d, hipMemcpy(&m, dmeta + i, sizeof(m), hipMemcpyDeviceToHost));
-      DCHK(d, hipMemcpy(&pos, (uint32_t*)d->keep_pos.p + i, 4, hipMemcpyDeviceToHost));
+      PCHK(hipMemcpy(&m, dmeta + i, sizeof(m), hipMemcpyDeviceToHost));
+      PCHK(hipMemcpy(&pos, (uint32_t*)d->keep_pos.p + i, 4, hipMemcpyDeviceToHost));
       uint8_t ev[16];
       std::vector<uint8_t> value((size_t)m.val_len + 1);
-      DCHK(d, hipMemcpy(value.data(), dby + m.val_off, (size_t)m.val_len, hipMemcpyDeviceToHost));  // (an LZ4 section exists decompressed on the device only)
-      if (surge_event_json_decode(&tmpl, value.data(), m.val_len, ev) != 0)
-        return dfail(d, SURGE_E_CORRUPT, "record at offset " + std::to_string(m.offset) + ": " + surge_event_json_last_error());
-      DCHK(d, hipMemcpy((uint8_t*)d->r_ev.p + (size_t)(d->n_records + pos) * 16, ev, 16, hipMemcpyHostToDevice));
+      PCHK(hipMemcpy(value.data(), dby + m.val_off, (size_t)m.val_len, hipMemcpyDeviceToHost));  // (an LZ4 section exists decompressed on the device only)
+      if (surge_event_json_decode(&d->h_tmpl, value.data(), m.val_len, ev) != 0)  // (the device accepted the number's spelling: cannot happen)
+        return poison(dfail(d, SURGE_E_CORRUPT, "record at offset " + std::to_string(m.offset) + ": " + surge_event_json_last_error()));
+      PCHK(hipMemcpy((uint8_t*)d->r_ev.p + (size_t)(d->n_records + pos) * 16, ev, 16, hipMemcpyHostToDevice));
     }
     d->counters[3] += ec.n_f64_host;
   }
   d->n_records += kept;
   d->counters[1] += kept;
   d->counters[2] += n_rec - kept;
-  DCHK(d, hipStreamSynchronize(st));
+  ++d->pushes;
+  PCHK(hipStreamSynchronize(st));
   return OK;
+#undef PCHK
 }
 
 }  // namespace
@@ -1009,7 +1405,7 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
   if (n_sections == 0) return OK;
   // the span of the arena this push needs, and every batch's first record index
   int64_t lo = INT64_MAX, hi = 0, n_rec = 0;
-  std::vector<Section> secs;
+  std::vector<Section>& secs = d->h_secs;
   try {
     secs.resize((size_t)n_sections);
   } catch (const std::bad_alloc&) {
@@ -1030,9 +1426,13 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
   // LZ4 sections (codec 3: the batch's records section is still one LZ4 frame): the host reads the frame header and the
   // block size words, the device decodes the blocks.  Frames it cannot take block by block (blocks larger than 64 KiB,
   // dependent blocks) are decompressed here, on the host, and travel as plain bytes behind the raw span.
-  std::vector<Lz4Block> blocks;
+  std::vector<Lz4Block>& blocks = d->h_blocks;
+  blocks.clear();
   std::vector<uint8_t> extra;
   int64_t area = 0;  // bytes of the device-side decompressed area handed out so far (multiples of 64 KiB)
+  int64_t n_seq_entries = 0;  // sequence-table entries handed out (two-pass decode)
+  bool any_one_pass = false;
+  static const bool force_one_pass = [] { const char* v = std::getenv("SURGE_INGEST_LZ4_ONEPASS"); return v && v[0] == '1'; }();
   try {
     for (int64_t s = 0; s < n_sections; ++s) {
       if (sections[s].codec != 3 || sections[s].n_records == 0) continue;
@@ -1049,6 +1449,7 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
         ++p;
       }
       const size_t first_block = blocks.size();
+      const int64_t seq_mark = n_seq_entries;
       int32_t k = 0;
       while (device_ok) {
         if (fl - p < 4) { device_ok = false; break; }
@@ -1064,6 +1465,13 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
         b.section = (int32_t)s;
         b.last = 0;
         b.index = k++;
+        // a sequence with a match takes at least 3 bytes of the block, the closing literal run at least 1
+        if (!force_one_pass && size < (uint32_t)kLz4BlockMax) {
+          b.seq_off = n_seq_entries;
+          n_seq_entries += (bs & 0x80000000u) ? 0 : (int64_t)size / 3 + 2;
+        } else {
+          b.seq_off = -1;
+        }
         blocks.push_back(b);
         p += size;
         if (f[4] & 0x10) p += 4;  // block checksum (not verified: the batch CRC already covers these bytes)
@@ -1075,6 +1483,7 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
         area += (int64_t)k * kLz4BlockMax;
       } else {
         blocks.resize(first_block);
+        n_seq_entries = seq_mark;
         int64_t cap = fl * 8 + 1024, got;
         const size_t at = extra.size();
         while (true) {
@@ -1102,11 +1511,8 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
   struct Restore { int dev; ~Restore() { (void)hipSetDevice(dev); } } restore{prev};
   DCHK(d, hipSetDevice(d->device));
   hipStream_t st = d->stream;
-  const size_t R = (size_t)n_rec;
   DCHK(d, d->d_bytes.reserve((size_t)(area_base + area) + 16, false, st));
   DCHK(d, d->d_sections.reserve(sizeof(Section) * (size_t)n_sections, false, st));
-  DCHK(d, d->rec_pos.reserve(R * 8, false, st));
-  DCHK(d, d->rec_end.reserve(R * 8, false, st));
   {
     const int32_t rc = begin_push(d, n_rec);
     if (rc != OK) return rc;
@@ -1145,26 +1551,54 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
     DCHK(d, hipMemcpyAsync(d->lz4_blocks.p, blocks.data(), blocks.size() * sizeof(Lz4Block), hipMemcpyHostToDevice, st));
     DCHK(d, d->lz4_sizes.reserve(blocks.size() * 4, false, st));
     const int64_t nb = (int64_t)blocks.size();
-    const unsigned grid = (unsigned)(nb < 8192 ? nb : 8192);
-    const int32_t caps[3] = {16384, 32768, kLz4BlockMax};  // LDS per wave of the three launches
-    for (int c = 0; c < 3; ++c)
-      hipLaunchKernelGGL(lz4_block_kernel, dim3(grid), dim3(64), (size_t)caps[c], st, dby, (uint8_t*)d->d_bytes.p + area_base,
-                         (const Lz4Block*)d->lz4_blocks.p, nb, (int32_t*)d->lz4_sizes.p, c, caps[c], dsec, derr);
-    // a frame that does not decode fails the push HERE, before any key of the push is interned (`blocks` is host memory:
-    // the copy has to be done before it goes out of scope anyway)
-    ErrorCell lz;
-    DCHK(d, hipMemcpyAsync(&lz, derr, sizeof(lz), hipMemcpyDeviceToHost, st));
-    DCHK(d, hipStreamSynchronize(st));
-    if (lz.lz4_bad != ~0u)
-      return dfail(d, SURGE_E_CORRUPT, "bad LZ4 frame in the batch at base offset " + std::to_string(sections[lz.lz4_bad].base_offset) +
-                                       " (malformed sequence, or a block that is not 64 KiB where it must be)");
+    if (nb >= (1ll << 31)) return dfail(d, E_UNSUPPORTED, "more than 2^31 LZ4 blocks in one push: push fewer sections at a time");
+    for (const Lz4Block& b : blocks) any_one_pass = any_one_pass || b.seq_off < 0;
+    if (!force_one_pass) {
+      // two passes: the sequence headers by one lane per block, then the copies by one wave per block in a launch with
+      // the LDS the block's size needs (the first pass knows it)
+      Lz4Work w;
+      DCHK(d, d->lz4_nseq.reserve((size_t)nb * 4, false, st));
+      DCHK(d, d->lz4_seq.reserve((size_t)(n_seq_entries + 1) * 8, false, st));
+      DCHK(d, d->lz4_cls.reserve((size_t)(kLz4Classes + 1) * ((size_t)nb + 1) * 4, false, st));
+      w.state = (int32_t*)d->lz4_sizes.p;
+      w.n_seq = (int32_t*)d->lz4_nseq.p;
+      w.seq = (uint2*)d->lz4_seq.p;
+      w.cls_count = (int32_t*)d->lz4_cls.p;
+      w.cls_list = w.cls_count + (kLz4Classes + 1);
+      DCHK(d, hipMemsetAsync(w.cls_count, 0, (kLz4Classes + 1) * 4, st));
+      hipLaunchKernelGGL(lz4_parse_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st, dby, (uint8_t*)d->d_bytes.p + area_base, (const Lz4Block*)d->lz4_blocks.p,
+                         (int32_t)nb, w, dsec, derr);
+      for (int c = 0; c <= kLz4Classes; ++c) {
+        const int32_t cap = c < kLz4Classes ? kLz4ClassCapHost[c] : 0;
+        const size_t lds = cap ? (size_t)cap + 64 + (size_t)kLz4Map * 2 : 0;
+        const int64_t resident = 256ll * (lds ? (int64_t)(160 * 1024 / lds) : 16);  // waves the chip holds at this LDS size
+        const unsigned grid = (unsigned)(nb < resident ? nb : resident);
+        hipLaunchKernelGGL(lz4_exec_kernel, dim3(grid), dim3(64), lds, st, dby, (uint8_t*)d->d_bytes.p + area_base, (const Lz4Block*)d->lz4_blocks.p, (int32_t)nb, w, c, cap);
+      }
+    }
+    if (any_one_pass) {
+      const unsigned grid = (unsigned)(nb < 8192 ? nb : 8192);
+      const int32_t caps[3] = {16384, 32768, kLz4BlockMax};  // LDS per wave of the three launches
+      for (int c = 0; c < 3; ++c)
+        hipLaunchKernelGGL(lz4_block_kernel, dim3(grid), dim3(64), (size_t)caps[c], st, dby, (uint8_t*)d->d_bytes.p + area_base,
+                           (const Lz4Block*)d->lz4_blocks.p, nb, (int32_t*)d->lz4_sizes.p, c, caps[c], dsec, derr);
+    }
+    // (a frame that does not decode zeroes its section and raises the error cell: the push fails at its first
+    // synchronisation, before anything is committed)
   }
-  const unsigned rb = (unsigned)((n_rec + 255) / 256);
-  hipLaunchKernelGGL(chain_kernel, dim3((unsigned)((n_sections + 63) / 64)), dim3(64), 0, st, dby, (const Section*)dsec, n_sections, (int64_t*)d->rec_pos.p,
-                     (int64_t*)d->rec_end.p, derr);
-  hipLaunchKernelGGL(parse_kernel, dim3(rb), dim3(256), 0, st, dby, (const Section*)dsec, n_sections, (const int64_t*)d->rec_pos.p, (const int64_t*)d->rec_end.p,
-                     n_rec, dmeta, derr);
-  return finish_push(d, n_rec);
+  // chain + parse + decode, one workgroup per batch: sections up to 20 KiB (the reference producer closes a batch at 16 KiB)
+  // out of 24 KiB of LDS, the rest out of 68 KiB or, beyond 64 KiB, in place
+  {
+    const EvjDevice* dt = d->json ? (const EvjDevice*)d->d_tmpl.p : nullptr;
+    const int64_t caps[2] = {20480, 65536};
+    for (int c = 0; c < 2; ++c) {
+      const size_t lds = (size_t)((caps[c] + 47) & ~15ll) + 2 * (size_t)kSecRecs * 4;
+      hipLaunchKernelGGL(section_kernel, dim3((unsigned)n_sections), dim3(kSecThreads), lds, st, dby, (const Section*)dsec, n_sections, c == 0 ? -1 : caps[0], caps[c],
+                         c == 1 ? 1 : 0, d->seed, dt, (const surge::F64ParseTable*)d->d_ptab.p, dmeta, (uint4*)d->ev_tmp.p, (uint32_t*)d->f64_list.p, derr);
+    }
+    DCHK(d, hipGetLastError());
+  }
+  return finish_push(d, n_rec, sections);
 }
 
 int32_t surge_device_decoder_push_records(surge_device_decoder* d, const uint8_t* keys, const int64_t* key_off, const uint8_t* values,
@@ -1205,14 +1639,18 @@ int32_t surge_device_decoder_push_records(surge_device_decoder* d, const uint8_t
   int64_t* p_vo = p_ko + (n + 1);
   int64_t* p_of = p_vo + (n + 1);
   for (int64_t i = 0; i <= n; ++i) { p_ko[i] = key_off[i] - key_off[0]; p_vo[i] = value_off[i] - value_off[0]; }
+  for (int64_t i = 0; i < n; ++i)  // (the kernels index the staged bytes with these: no launch on offsets that run backwards)
+    if (p_ko[i + 1] < p_ko[i] || p_vo[i + 1] < p_vo[i]) return dfail(d, E_INVALID, "key_off / value_off must not decrease (record " + std::to_string(i) + ")");
   if (offsets) std::memcpy(p_of, offsets, (size_t)n * 8);
   if (n_bytes) DCHK(d, hipMemcpyAsync(d->d_bytes.p, pin, n_bytes, hipMemcpyHostToDevice, st));
   DCHK(d, hipMemcpyAsync(d->rec_pos.p, p_ko, off_bytes, hipMemcpyHostToDevice, st));
   DCHK(d, hipMemcpyAsync(d->rec_end.p, p_vo, off_bytes, hipMemcpyHostToDevice, st));
   if (offsets) DCHK(d, hipMemcpyAsync(d->d_sections.p, p_of, (size_t)n * 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(records_meta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)d->d_bytes.p, (const int64_t*)d->rec_pos.p,
-                     (const int64_t*)d->rec_end.p, offsets ? (const int64_t*)d->d_sections.p : nullptr, kb, n, (RecMeta*)d->meta.p, (ErrorCell*)d->d_err.p);
-  return finish_push(d, n);
+  hipLaunchKernelGGL(records_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)d->d_bytes.p, (const int64_t*)d->rec_pos.p,
+                     (const int64_t*)d->rec_end.p, offsets ? (const int64_t*)d->d_sections.p : nullptr, kb, n, d->seed,
+                     d->json ? (const EvjDevice*)d->d_tmpl.p : nullptr, (const surge::F64ParseTable*)d->d_ptab.p, (RecMeta*)d->meta.p, (uint4*)d->ev_tmp.p,
+                     (uint32_t*)d->f64_list.p, (ErrorCell*)d->d_err.p);
+  return finish_push(d, n, nullptr);
 }
 
 int32_t surge_device_decoder_result(surge_device_decoder* d, int64_t* n_records, const int64_t** d_agg_idx, const void** d_events16,
@@ -1290,6 +1728,16 @@ int32_t surge_device_decoder_key_table(surge_device_decoder* d, const uint8_t** 
 int32_t surge_device_decoder_counters(const surge_device_decoder* d, int64_t out[4]) {
   if (!d || !out) return E_INVALID;
   for (int i = 0; i < 4; ++i) out[i] = d->counters[i];
+  return OK;
+}
+
+int32_t surge_device_decoder_stats(const surge_device_decoder* d, int64_t out[8]) {
+  if (!d || !out) return E_INVALID;
+  for (int i = 0; i < 4; ++i) out[i] = d->counters[i];
+  out[4] = d->reseeds;
+  out[5] = (int64_t)d->t_cap;
+  out[6] = d->pushes;
+  out[7] = (int64_t)(d->seed & ~(1ull << 63));
   return OK;
 }
 

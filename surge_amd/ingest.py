@@ -376,3 +376,10 @@ class DeviceDecoder:
         c = (ctypes.c_int64 * 4)()
         self._lib.surge_device_decoder_counters(self._h, ctypes.byref(c))
         return dict(zip(["records_seen", "records_delivered", "flush_records_skipped", "doubles_parsed_on_host"], [int(x) for x in c]))
+
+    def stats(self) -> dict:
+        """The counters plus the key table's: re-seeds after a detected 64-bit hash collision, slots, pushes, hash function."""
+        c = (ctypes.c_int64 * 8)()
+        self._lib.surge_device_decoder_stats(self._h, ctypes.byref(c))
+        return dict(zip(["records_seen", "records_delivered", "flush_records_skipped", "doubles_parsed_on_host", "hash_reseeds", "table_slots", "pushes",
+                         "hash_function"], [int(x) for x in c]))

@@ -284,6 +284,88 @@ def test_device_decoder_rejects_what_the_host_decoder_rejects_and_names_the_offs
 
 
 @pytest.mark.gpu
+def test_a_failed_push_leaves_the_decoder_exactly_as_it_was():
+    """a push that fails after its keys were probed must not leave them half-inserted (the next push would read
+    an unassigned id) nor interned (ids would drift from the host decoder's first-delivered numbering).  The push is
+    rolled back on the device: the same decoder then numbers a good topic exactly like a fresh one."""
+    good1 = kw.record_batch(0, [(f"k{j}:1".encode(), counter_event(1, j, 1)) for j in range(50)])
+    bad = kw.record_batch(50, [(b"new-a:1", counter_event(1, 1, 1)), (b"new-b:1", b"not sixteen bytes"), (b"k3:2", counter_event(1, 2, 1))])
+    good2 = kw.record_batch(53, [(b"new-b:1", counter_event(2, 5, 7)), (b"k3:2", counter_event(1, 2, 1)), (b"new-a:1", counter_event(1, 1, 1))])
+    with EventsTopicIngest(frames=True) as g, DeviceDecoder() as d:
+        g.feed(good1)
+        d.push_from(g)
+        g.feed(bad)
+        with pytest.raises(IngestError, match="16-byte"):
+            d.push_from(g)
+        assert d.keys() == [f"k{j}" for j in range(50)] and d.result()[0].shape[0] == 50  # nothing interned, nothing appended
+        g.feed(good2)
+        d.push_from(g)
+        assert d.keys() == [f"k{j}" for j in range(50)] + ["new-b", "new-a"]  # first-delivered order of the push that went through
+        agg = d.result()[0].cpu().numpy()
+        assert agg[50:].tolist() == [50, 3, 51]
+        assert d.stats()["pushes"] == 2 and d.stats()["hash_reseeds"] == 0
+
+
+@pytest.mark.gpu
+def test_a_key_hash_collision_is_handled_by_reseeding_the_table(monkeypatch):
+    """two aggregate ids with the same 64-bit hash used to fail the push (detected, not handled).  With
+    SURGE_INGEST_DEBUG_WEAK_HASH=1 the table's first hash function keeps 8 bits, so 2000 ids are certain to collide: the
+    decoder detects it before anything is committed, gives the table another hash function (known keys re-hashed from
+    the key arena, the push's records from their bytes) and runs the push again — same records, ids and key table as the
+    host decoder, over several pushes, with keys from before and after the re-seed."""
+    monkeypatch.setenv("SURGE_INGEST_DEBUG_WEAK_HASH", "1")
+    rng = random.Random(3)
+    ids = [f"agg-{i}" for i in range(2000)]
+    seq = ids * 2
+    rng.shuffle(seq)
+    seq = ids[:3] + seq  # the first push (one batch) holds no collision yet: the re-seed happens with keys already interned
+    wire, off = [kw.record_batch(0, [(f"{a}:{j}".encode(), counter_event(1, j, 1)) for j, a in enumerate(seq[:3])])], 3
+    for s0 in range(3, len(seq), 500):
+        chunk = seq[s0:s0 + 500]
+        wire.append(kw.record_batch(off, [(f"{a}:{j}".encode(), counter_event(1, j, 1)) for j, a in enumerate(chunk)]))
+        off += len(chunk)
+    first = len(wire[0])
+    wire = b"".join(wire)
+    with EventsTopicIngest() as g:
+        g.feed(wire)
+        host = g.drain_fixed16()
+        host_keys = list(g.key_table().keys)
+    with EventsTopicIngest(frames=True) as g, DeviceDecoder() as d:
+        g.feed(wire[:first])
+        d.push_from(g)
+        assert d.stats()["hash_reseeds"] == 0
+        rest = wire[first:]
+        for c0 in range(0, len(rest), len(rest) // 3 + 1):
+            g.feed(rest[c0:c0 + len(rest) // 3 + 1])
+            d.push_from(g)
+        st = d.stats()
+        assert st["hash_reseeds"] == 1 and st["hash_function"] == 1  # one re-seed took the weak function out of use
+        agg, ev, off_d, n_keys = d.result()
+        assert d.keys() == host_keys and n_keys == len(host_keys)
+        assert agg.cpu().numpy().tobytes() == host[0].tobytes() and ev.cpu().numpy().tobytes() == host[1].tobytes()
+        assert off_d.cpu().numpy().tobytes() == host[2].tobytes()
+
+
+@pytest.mark.gpu
+def test_push_records_refuses_offsets_that_run_backwards_before_any_launch():
+    import ctypes
+
+    from surge_amd import _native
+
+    lib = _native.load()
+    with DeviceDecoder() as d:
+        keys = np.frombuffer(b"a:1b:1c:1", dtype=np.uint8)
+        vals = np.frombuffer(counter_event(1, 1, 1) * 3, dtype=np.uint8)
+        ko = np.array([0, 1_000_000, 5, 9], dtype=np.int64)  # ADVICE r3: an intermediate offset far outside the buffer
+        vo = np.array([0, 16, 32, 48], dtype=np.int64)
+        rc = lib.surge_device_decoder_push_records(d._h, keys.ctypes.data_as(ctypes.c_void_p), ko.ctypes.data_as(ctypes.c_void_p),
+                                                   vals.ctypes.data_as(ctypes.c_void_p), vo.ctypes.data_as(ctypes.c_void_p), None, 3)
+        assert rc == -1 and b"must not decrease" in lib.surge_device_decoder_last_error(d._h)
+        d.push_records([b"a:1", b"b:1"], [counter_event(1, 1, 1)] * 2)  # the decoder is still usable
+        assert d.keys() == ["a", "b"]
+
+
+@pytest.mark.gpu
 def test_lz4_frames_decoded_on_the_device_block_by_block():
     """SURGE_INGEST_DEVICE_LZ4: the records section of an lz4 batch stays one LZ4 frame; the host reads the frame header and
     the block size words, one wave per block decodes it.  Frames of every shape the writers here can produce — many
