@@ -178,7 +178,9 @@ def main():
     ap.add_argument("--device-batches", action="store_true", help="c5: batches already in HBM (no staging / H2D)")
     ap.add_argument("--codec", default="lz4", choices=["lz4", "none"], help="e2e: compression of the record batches (the reference's producer: lz4)")
     ap.add_argument("--host-framing", action="store_true", help="c5: frame the state-topic record batches with the host writer instead of the device framer")
-    ap.add_argument("--serial-framing", action="store_true", help="e2e: frame each fetch and then run its device stage, one after the other (default: the host frames one fetch ahead on a second thread)")
+    ap.add_argument("--serial-framing", action="store_true", help="e2e: frame each fetch, then push it, then fold it, one after the other (default: framing one fetch ahead on its own threads, three pushes in flight)")
+    ap.add_argument("--events-cap", type=int, default=8, help="e2e: every aggregate publishes the first min(count, cap) of its events (8: 6.4e7 records over the 10 M aggregates)")
+    ap.add_argument("--framing-threads", type=int, default=8, help="e2e: host threads framing a fetch's partitions side by side")
     ap.add_argument("--aggregates", type=int, default=None, help="global aggregate count (default 10 M for c4, 1 M for c2)")
     ap.add_argument("--events-per-aggregate", type=int, default=C2_EVENTS, help="c2 only")
     ap.add_argument("--algo", default=None,
@@ -200,7 +202,9 @@ def main():
         print(json.dumps(run_v2(args)))
         return
     if args.workload == "e2e":
-        print(json.dumps(run_e2e(args)))
+        line = run_e2e(args)
+        if line is not None:  # rank 0
+            print(json.dumps(line))
         return
 
     import numpy as np
@@ -210,38 +214,7 @@ def main():
     from surge_amd import synth
     from surge_amd.replay import ReplayEngine
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # plain `python bench.py --gpus N`: start one rank per GPU ourselves (what the driver's torchrun line does)
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.stdout.flush()
-        os.execv(sys.executable, cmd)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the replay engine has no CPU fallback")
-    # Rehearsal (SURGE_BENCH_REHEARSAL=1): every rank on cuda:0, gloo control plane on CPU tensors — exercises the whole
-    # N > 1 code path on a one-GPU box (with SURGE_RCCL_LIBRARY = tests/rccl_stub for the data exchange, since RCCL refuses
-    # two ranks on one device).  The line it prints is labelled; its throughput means nothing.
-    rehearsal = world > 1 and os.environ.get("SURGE_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ctl = torch.device("cpu") if rehearsal else dev  # where the control-plane tensors live
-
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)  # control plane: barriers, the timing reductions, the communicator id
+    world, rank, local_rank, dev, ctl, dist, rehearsal = init_ranks(args, torch)
 
     zipf = args.workload in ("c4", "c3")
     weak = args.workload == "c2-weak"
@@ -773,141 +746,335 @@ def run_v2(args):
     }
 
 
-def run_e2e(args):
-    """From the bytes Kafka hands over to recovered states (SURVEY §8f N1 in front of R2): record batches (message format
-    v2, 16 KiB = 140 records each like the reference producer's, the Counter fixture's play-json event text as the reference writes it: TestBoundedContext.scala:
-    122-124; lz4-compressed like the reference's producer, reference.conf:112, frames written by liblz4) -> host framing
-    (headers, CRC-32C, read_committed; ONE host thread, running one fetch ahead of the device stage on its own thread:
-    surge_amd.ingest.FramedFetches; --serial-framing puts the two stages one after the other) -> surge_device_decoder
-    (LZ4 blocks, records, key interning, JSON -> 16-byte events, on the GPU) -> device group-by + fold onto the resident
-    state (K3).  A step = one fetch of --batch-events records (default 1 M); `value` = events/s over K fetches incl.
-    everything between the bytes and the states, timed from the completed fold of the last warm-up fetch to the completed
-    fold of the last timed one.  The same bytes through the library's host decoder beside it; the states after the run are compared
-    with the oracle's fold of the decoded events, aggregate by aggregate."""
-    import struct
+def init_ranks(args, torch):
+    """One process per GPU: starts the ranks when bench.py was called without a launcher, joins the process group.
+    Returns (world, rank, local_rank, dev, ctl, dist, rehearsal)."""
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start one rank per GPU ourselves (what the driver's torchrun line does)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the replay engine has no CPU fallback")
+    # Rehearsal (SURGE_BENCH_REHEARSAL=1): every rank on cuda:0, gloo control plane on CPU tensors — exercises the whole
+    # N > 1 code path on a one-GPU box (with SURGE_RCCL_LIBRARY = tests/rccl_stub for the data exchange, since RCCL refuses
+    # two ranks on one device).  The line it prints is labelled; its throughput means nothing.
+    rehearsal = world > 1 and os.environ.get("SURGE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ctl = torch.device("cpu") if rehearsal else dev  # where the control-plane tensors live
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
 
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # control plane: barriers, the timing reductions, the communicator id
+    return world, rank, local_rank, dev, ctl, dist, rehearsal
+
+
+E2E_SEED = 11
+
+
+def e2e_events(np, synth, agg, j):
+    """The Counter event aggregate ``agg`` publishes as its j-th (1-based): (type 0 increment / 1 decrement / 2 no-op,
+    argument 0..999), a pure function of (agg, j) — the topic generator and the parity check both call it."""
+    idx = agg.astype(np.int64) * 8192 + j
+    return (synth._h(E2E_SEED, idx, 21) % 3).astype(np.int32), (synth._h(E2E_SEED, idx, 22) % 1000).astype(np.int32)
+
+
+def run_e2e(args):
+    """From the bytes Kafka hands over to recovered states, on the population BASELINE.json's target is quoted on
+    (SURVEY §8f N1 in front of R2; the recovery SurgeStateStoreConsumer.scala:57-76 performs record by record).
+
+    Topic: the 10,000,000 aggregates of config C3 / C4 (ids ``acct-%08d``, Zipf(1..4096) event counts, seed 3), every
+    aggregate publishing the first min(count, --events-cap) of its Counter events (play-json text as the reference writes
+    it, TestBoundedContext.scala:42-49,122-124; keys ``<id>:<seq>``), interleaved in rounds — round j holds the j-th event
+    of every aggregate that has one, in a fixed pseudo-random order, so a fetch of a million records touches a million
+    different aggregates: the key table and the resident state see no locality at all — over 64 partitions by the
+    reference's partitioner (KafkaPartitioner.scala:8,38-42), in record batches closed at 16 KiB and lz4-compressed like
+    the reference's producer (reference.conf:112-115), written by the product's own record-batch writer.  With N GPUs rank
+    r consumes the partitions p % N == r (PartitionAssignments.scala:51-63) and the final snapshot is all-gathered through
+    the C ABI.
+
+    Path, per rank: a fetch response = the next ~--batch-events records of the rank's partitions -> host framing (headers,
+    CRC-32C, read_committed) per partition on --framing-threads threads, one fetch ahead -> ONE device push per fetch
+    (surge_device_decoder_push_parts_async: copy, LZ4 blocks, records, JSON -> 16-byte events; up to three in flight) ->
+    key interning -> device group-by + fold onto the resident state (K3).  A step = one fetch; `value` = events/s from the
+    completed fold of the last warm-up fetch to the completed fold of the last fetch, over all ranks, framing included.
+    The states after the run are compared, aggregate by aggregate, with the oracle's fold of the SOURCE events (the
+    (agg, j) -> event function the generator wrote the topic from), not of anything the device decoded."""
     import numpy as np
     import torch
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "examples"))
-    import kafka_wire as kw
-    from fixture_models import CounterBusinessLogic, CountDecremented, CountIncremented, NoOpEvent
+    import topic_gen
+    from fixture_models import CT_DEC, CT_INC, CT_NOOP, CounterBusinessLogic, CountDecremented, CountIncremented, NoOpEvent
     from oracle import oracle
     from surge_amd import schema as S
-    from surge_amd.ingest import DeviceDecoder, EventsTopicIngest, FramedFetches
+    from surge_amd import synth
+    from surge_amd.dist import partitions_of_ids, shard_of_partition
+    from surge_amd.ingest import DeviceDecoder, EventsTopicIngest, PartitionedFramedFetches
     from surge_amd.replay import ReplayEngine
+    from surge_amd.snapshot import RecordBatchWriter
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the replay engine has no CPU fallback")
-    dev = torch.device("cuda:0")
-    PER = 140  # ~16 KiB of play-json Counter events: where the reference's producer closes a batch (kafka.publisher.batch-size = 16384)
-    n_fetch = max(PER, (args.batch_events if args.batch_events != 100_000 else 1_000_000) // PER * PER)
-    K = args.steps if args.steps != 20 else 8
+    world, rank, local_rank, dev, ctl, dist, rehearsal = init_ranks(args, torch)
+    A = args.aggregates or N_AGGREGATES
+    cap = args.events_cap
+    P = N_PARTITIONS
+    n_fetch = args.batch_events if args.batch_events != 100_000 else 1_000_000
     W = min(args.warmup, 2)
-    rng = np.random.default_rng(1)
+    depth = 1 if args.serial_framing else 3
     bl = CounterBusinessLogic()
     model, fmt = bl.command_model(), bl.event_write_formatting()
     tmpl = model.event_json_template()
-    protos = []
-    for b in range(64):  # 32 000 distinct records; a fetch cycles through them with fresh offsets
-        recs = []
-        for i in range(PER):
-            agg = f"acct-{int(rng.integers(0, 1_000_000)):08d}"
-            e = [CountIncremented(agg, int(rng.integers(0, 1000)), i + 1), CountDecremented(agg, int(rng.integers(0, 1000)), i + 1), NoOpEvent(agg, i + 1)][i % 3]
-            m = fmt.write_event(e)
-            recs.append((m.key.encode(), m.value))
-        if args.codec == "lz4":  # frames written by liblz4 itself (as bundled by Apache Arrow), one 64 KiB-block frame per batch
-            import pyarrow as pa
+    t_gen = time.perf_counter()
 
-            protos.append(bytearray(kw.record_batch(0, recs, compression="lz4", compressor=lambda raw: pa.Codec("lz4").compress(raw, asbytes=True))))
-        else:
-            protos.append(bytearray(kw.record_batch(0, recs)))
-    offset = [0]
+    eng = ReplayEngine(model.event_algebra(), device=local_rank)
+    # ---- this rank's aggregates: its partitions' -------------------------------------------------------------------------
+    ids_all = torch.arange(A, dtype=torch.int64, device=dev)
+    part_all = partitions_of_ids(ids_all, P, eng).to(torch.int64)
+    mine = shard_of_partition(part_all, world) == rank
+    my_ids = ids_all[mine].cpu().numpy()
+    my_part = part_all[mine].cpu().numpy().astype(np.int32)
+    del ids_all, part_all, mine
+    counts = np.minimum(synth.zipf_lengths(my_ids, ZIPF_SEED), cap).astype(np.int64)
+    order = np.argsort(synth._h(E2E_SEED, my_ids, 23), kind="stable")  # the order aggregates take turns in, every round
+    my_ids, my_part, counts = my_ids[order], my_part[order], counts[order]
+    n_total = int(counts.sum())
+    if args.steps != 20:  # an explicit --steps: that many timed fetches
+        n_total = min(n_total, (W + args.steps) * n_fetch)
+    # ---- the topic, fetch by fetch: (agg, j) stream -> record text -> record batches per partition ----------------------
+    fetches, n_pub = [], 0
+    wire_bytes = 0
+    incl = np.zeros(my_ids.shape[0], np.int64)  # events of each aggregate that made it into the topic
+    sample_checked = False
+    with RecordBatchWriter(P, 0, 16384, args.codec) as writer:
+        pend_a, pend_j, pend_p, pend_n = [], [], [], 0
 
-    def fetch():
-        parts = []
-        for b in range(n_fetch // PER):
-            p = bytearray(protos[(offset[0] // PER) % len(protos)])
-            struct.pack_into(">q", p, 0, offset[0])  # baseOffset is outside the CRC
-            offset[0] += PER
-            parts.append(bytes(p))
-        return b"".join(parts)
+        def flush(final=False):
+            nonlocal pend_a, pend_j, pend_p, pend_n, wire_bytes, sample_checked
+            while pend_n >= n_fetch or (final and pend_n > 0):
+                a, j, p = np.concatenate(pend_a), np.concatenate(pend_j), np.concatenate(pend_p)
+                take = min(n_fetch, a.shape[0])
+                pend_a, pend_j, pend_p, pend_n = [a[take:]], [j[take:]], [p[take:]], a.shape[0] - take
+                a, j, p = a[:take], j[:take], p[:take]
+                ty, arg = e2e_events(np, synth, a, j)
+                k, ko, v, vo = topic_gen.counter_records(a, ty, arg, j)
+                if not sample_checked:  # the generator's text IS what the fixture's event writer writes
+                    for i in range(0, take, max(1, take // 200)):
+                        agg = f"acct-{a[i]:08d}"
+                        e = [CountIncremented(agg, int(arg[i]), int(j[i])), CountDecremented(agg, int(arg[i]), int(j[i])), NoOpEvent(agg, int(j[i]))][ty[i]]
+                        m = fmt.write_event(e)
+                        assert bytes(k[ko[i]:ko[i + 1]]) == m.key.encode() and bytes(v[vo[i]:vo[i + 1]]) == m.value
+                    sample_checked = True
+                parts = topic_gen.frame_partitions(writer, p, k, ko, v, vo)
+                wire_bytes += sum(len(x) for x in parts if x)
+                fetches.append((parts, take))
 
-    fetches = [fetch() for _ in range(W + K)]
-    wire_bytes = sum(len(f) for f in fetches[W:])
-    lat, host_ms, dev_ms = [], [], []
-    overlap = not args.serial_framing
-    marks = []  # perf_counter when each fetch's fold has completed
+        for j in range(1, cap + 1):
+            if n_pub >= n_total:
+                break
+            sel = np.flatnonzero(counts >= j)
+            if n_pub + sel.shape[0] > n_total:
+                sel = sel[: n_total - n_pub]
+            if not sel.shape[0]:
+                break
+            incl[sel] += 1
+            n_pub += sel.shape[0]
+            pend_a.append(my_ids[sel]); pend_j.append(np.full(sel.shape[0], j, np.int32)); pend_p.append(my_part[sel]); pend_n += sel.shape[0]
+            flush()
+        flush(final=True)
+    gen_s = time.perf_counter() - t_gen
+    K = len(fetches) - W
+    if K < 1:
+        raise SystemExit(f"--workload e2e: the topic holds {len(fetches)} fetch(es): nothing to time behind {W} warm-up fetch(es)")
 
+    # ---- the run --------------------------------------------------------------------------------------------------------
+    marks, dev_ms, keys_at = [], [], []
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
     t_start = time.perf_counter()
-    with FramedFetches(fetches, overlap=overlap) as framed, DeviceDecoder(tmpl) as d, ReplayEngine(model.event_algebra()) as eng:
+    with PartitionedFramedFetches((f for f, _ in fetches), P, threads=args.framing_threads, hold=depth, overlap=not args.serial_framing) as framed, \
+            DeviceDecoder(tmpl, device=local_rank) as d:
         eng.load_csr(np.zeros(1, np.int64), np.zeros(0, dtype=S.EVENT_DTYPE))
         eng.fold()
         n_agg = 0
-        all_agg, all_ev = [], []
-        for i, (sections, arena) in enumerate(framed):
+        pending = []
+
+        def finish_one():
+            nonlocal n_agg
             t1 = time.perf_counter()
-            d.push(sections, arena)
+            d.finish()
             agg, ev, _, n_keys = d.result()
             if n_keys > n_agg:
-                eng.grow(n_keys)
-                n_agg = n_keys
+                eng.grow(max(n_keys, min(2 * n_agg, my_ids.shape[0])))  # (grow in big steps: a grow copies the resident state)
+                n_agg = eng.n_agg
             eng.append_events(agg, ev)
             eng.synchronize()
+            d.clear()
             t2 = time.perf_counter()
             marks.append(t2)
-            if i >= W:
-                dev_ms.append((t2 - t1) * 1e3)
-            all_agg.append(agg.clone())  # kept on the device for the parity check after the timed region
-            all_ev.append(ev.clone())
-            d.clear()
+            dev_ms.append((t2 - t1) * 1e3)
+            keys_at.append(n_keys)
+
+        for parts in framed:
+            if len(pending) == depth:
+                finish_one()
+                pending.pop(0)
+            d.push_async(parts)
+            pending.append(1)
+        while pending:
+            finish_one()
+            pending.pop(0)
         torch.cuda.synchronize(dev)
-        # the timed region: from the completed fold of the last warm-up fetch (its states are on the device, the stream is
-        # idle: eng.synchronize() above) to the completed fold of the last timed fetch.  When the framing runs ahead, the
-        # first timed fetch is being framed on the other thread at that moment — the steady state of a recovery.
         t_begin = marks[W - 1] if W > 0 else t_start
-        elapsed = marks[W + K - 1] - t_begin
-        host_ms = [x * 1e3 for x in framed.framing_seconds[W:]]
-        lat = [(marks[i] - (marks[i - 1] if i > 0 else t_start)) * 1e3 for i in range(W, W + K)]  # completed fold to completed fold
-        states = eng.snapshot()
-        counters = d.counters()
-    n_events = n_fetch * K
-    # parity: the oracle folds the decoded events grouped by aggregate (stable: topic order inside an aggregate)
-    agg_all = np.concatenate([a.cpu().numpy() for a in all_agg])
-    ev_all = np.concatenate([e.cpu().numpy().view(S.EVENT_DTYPE).reshape(-1) for e in all_ev])
-    order = np.argsort(agg_all, kind="stable")
-    off = np.zeros(n_agg + 1, np.int64)
-    np.cumsum(np.bincount(agg_all, minlength=n_agg), out=off[1:])
-    exp = oracle.fold_csr(off, ev_all[order], None, model.event_algebra(), threads=int(effective_cpus()[0]))
-    parity = states.tobytes() == exp.tobytes()
-    # the library's host decoder on the timed fetches (one thread), for scale
+        elapsed_local = marks[-1] - t_begin
+        n_keys = keys_at[-1]
+        states = eng.snapshot()[:n_keys]
+        stats = d.stats()
+        # the key table, as numbers (ids are acct-%08d: 13 bytes each)
+        import ctypes
+
+        lib = d._lib
+        nk, nb = ctypes.c_int64(), ctypes.c_int64()
+        lib.surge_device_decoder_keys(d._h, None, 0, None, ctypes.byref(nk), ctypes.byref(nb))
+        kb = np.zeros(max(nb.value, 1), np.uint8)
+        koff = np.zeros(nk.value + 1, np.int64)
+        lib.surge_device_decoder_keys(d._h, kb.ctypes.data_as(ctypes.c_void_p), kb.shape[0], koff.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nk), ctypes.byref(nb))
+        host_ms = [x * 1e3 for x in framed.framing_seconds]
+        ingest_counters = framed.counters()
+    assert np.all(np.diff(koff) == 13), "every key is an acct-%08d id"
+    digits = kb[: 13 * n_keys].reshape(n_keys, 13)[:, 5:].astype(np.int64) - 48
+    key_ids = (digits * (10 ** np.arange(7, -1, -1, dtype=np.int64))).sum(axis=1)
+    # ---- parity: the oracle folds the SOURCE events of every aggregate, in the device's key order ------------------------
+    t_par = time.perf_counter()
+    sorter = np.argsort(my_ids)
+    at = sorter[np.searchsorted(my_ids, key_ids, sorter=sorter)]
+    assert np.array_equal(my_ids[at], key_ids) and np.unique(key_ids).shape[0] == n_keys == int((incl > 0).sum()), "the key table is not this rank's published aggregates, each once"
+    cnt_k = incl[at]
+    off = np.zeros(n_keys + 1, np.int64)
+    np.cumsum(cnt_k, out=off[1:])
+    ev_agg = np.repeat(key_ids, cnt_k)
+    ev_j = (np.arange(off[-1], dtype=np.int64) - np.repeat(off[:-1], cnt_k) + 1).astype(np.int32)
+    ty, arg = e2e_events(np, synth, ev_agg, ev_j)
+    src = np.zeros(off[-1], dtype=S.EVENT_DTYPE)
+    src["type"] = np.array([CT_INC, CT_DEC, CT_NOOP], np.int32)[ty]
+    src["seq"] = ev_j
+    src["raw"] = arg.astype(np.uint32).astype(np.uint64)
+    t_or = time.perf_counter()
+    exp = oracle.fold_csr(off, src, None, model.event_algebra(), threads=int(effective_cpus()[0]))
+    oracle_s = time.perf_counter() - t_or
+    parity = bool(states.tobytes() == exp.tobytes()) and int(off[-1]) == n_pub
+    del src, ev_agg, ev_j
+    parity_s = time.perf_counter() - t_par
+    # ---- N > 1: the final snapshot to every rank ----------------------------------------------------------------------------
+    exchange = None
+    n_events_timed = sum(n for _, n in fetches[W:])
+    elapsed = torch.tensor([elapsed_local], dtype=torch.float64, device=ctl)
+    totals = torch.tensor([n_events_timed, n_keys, int(parity), wire_bytes, n_pub], dtype=torch.int64, device=ctl)
+    per_rank = [n_events_timed]
+    if dist is not None:
+        from surge_amd.dist import NativeSnapshotGather
+
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        mine_t = totals.clone()
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+        allr = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(allr, mine_t)
+        per_rank = [int(t[0].item()) for t in allr]
+        parity_all = all(int(t[2].item()) == 1 for t in allr)
+        gather = NativeSnapshotGather(n_keys, dev, eng)
+        local = gather.make_local_buffers()[0]
+        local[:n_keys] = torch.from_numpy(states.view(np.uint8).reshape(n_keys, 64)).to(dev)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        ta = time.perf_counter()
+        gather.launch(0, local, None)
+        gather.synchronize(0)
+        torch.cuda.synchronize(dev)
+        exchange = (time.perf_counter() - ta) * 1e3
+        res = gather.result(0)
+        own = torch.stack([local[:n_keys].reshape(-1).view(torch.int64).sum()]).to(ctl)
+        sums = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(sums, own)
+        for r in range(world):
+            got = res[r, : gather.counts[r]].reshape(-1).view(torch.int64).sum()
+            assert int(got.item()) == int(sums[r].item()), f"rank {rank}: gathered block of rank {r} differs from its shard"
+        assert torch.equal(res[rank, :n_keys], local[:n_keys]), "all-gathered snapshot does not contain the local shard"
+        exm = torch.tensor([exchange], dtype=torch.float64, device=ctl)
+        dist.all_reduce(exm, op=dist.ReduceOp.MAX)
+        exchange = float(exm.item())
+        gathered_aggregates = int(sum(gather.counts))
+    else:
+        parity_all = parity
+        gathered_aggregates = None
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return None
+    elapsed_s = float(elapsed.item())
+    total_events, total_keys, total_wire = int(totals[0].item()), int(totals[1].item()), int(totals[3].item())
+    # the library's host decoder on a bounded sample of the same fetches (one thread), for scale
     t0 = time.perf_counter()
+    sample_records = 0
     with EventsTopicIngest() as gh:
-        for wire in fetches[W:]:
-            gh.feed(wire)
-            gh.drain_json(tmpl)
+        for parts, n in fetches[W:W + 2]:
+            for data in parts:
+                if data:
+                    gh.feed(data)
+                    gh.drain_json(tmpl)
+            sample_records += n
     host_decoder_s = time.perf_counter() - t0
-    return {
-        "metric": "events/sec replayed", "value": n_events / elapsed, "unit": "events/s", "n_gpus": 1, "steps": K, "warmup": W,
-        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bytes -> int32 events -> int32/int64 adds", "data": "synthetic (Counter fixture events as play-json text in Kafka record batches v2, built on the host)",
-        "config": {"workload": f"E2E: events-topic bytes -> states; fetches of {n_fetch} records ({PER}-record batches, play-json Counter events, "
-                               f"compression {args.codec}), host framing on ONE thread (headers, CRC-32C, transactions)"
-                               f"{' one fetch ahead of the device stage (FramedFetches: framing of fetch i + 1 overlaps the GPU work of fetch i)' if overlap else ', then the device stage, one after the other'}"
-                               f"; LZ4 / records / key interning / JSON decode / group-by / fold on the GPU",
-                   "framing_overlapped": overlap,
-                   "fetch_records": n_fetch, "wire_bytes_per_record": wire_bytes / n_events, "aggregates_seen": int(n_agg),
-                   "fetch_ms": {"p50": float(np.percentile(lat, 50)), "max": float(np.max(lat))},
-                   "host_framing_ms_per_fetch": float(np.mean(host_ms)), "device_decode_groupby_fold_ms_per_fetch": float(np.mean(dev_ms)),
-                   "wire_GBps": wire_bytes / elapsed / 1e9, "decoder_counters": counters},
-        "roofline": {"bound": "hbm", "achieved": wire_bytes / elapsed / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": wire_bytes / elapsed / 1e9 / HBM_PEAK_GBPS,
-                     "traffic": None, "kernel": "host framing + surge_device_decoder + K3",
-                     "note": "not a bandwidth-bound kernel measurement: the step is bounded by the single host thread's framing and the PCIe copy"},
-        "cpu_baseline": {"value": n_events / host_decoder_s, "unit": "events/s", "cores": 1, "kind": "port",
-                         "sample": "the same fetches through the library's host decoder (surge_ingest_feed + surge_ingest_drain_json), decode only — no fold",
-                         "gpu_states_match_cpu_fold_of_the_decoded_events": bool(parity)},
+    lat = [(marks[i] - marks[i - 1]) * 1e3 for i in range(max(W, 1), len(marks))]
+    disc = [i for i in range(max(W, 1), len(marks)) if keys_at[i] > keys_at[i - 1] + fetches[i][1] // 2]  # fetches that mostly discover keys
+    steady = [i for i in range(max(W, 1), len(marks)) if keys_at[i] == keys_at[i - 1]]
+    rate = lambda idx: (sum(fetches[i][1] for i in idx) / sum(marks[i] - marks[i - 1] for i in idx)) if idx else None  # noqa: E731
+    out = {
+        "metric": "events/sec replayed", "value": total_events / elapsed_s, "unit": "events/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": elapsed_s / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bytes -> int32 events -> int32/int64 adds", "data": "synthetic (Counter fixture events as play-json text in Kafka record batches v2, written by the product's record-batch writer)",
+        "config": {"workload": f"E2E: events-topic bytes -> states on the C3 / C4 population: {A} aggregates (acct-%08d, Zipf(1..4096) counts, seed {ZIPF_SEED}), the first "
+                               f"<= {cap} events of each, published in rounds (a fetch touches as many different aggregates as it has records), {P} partitions by "
+                               f"partitionForKey, {args.codec} batches closed at 16 KiB; fetches of {n_fetch} records per rank; host framing (headers, CRC-32C, "
+                               f"transactions) per partition on {args.framing_threads} threads one fetch ahead; one device push per fetch, {depth} in flight: LZ4 / records / "
+                               f"JSON decode / key interning / group-by / fold on the GPU" + (" [REHEARSAL: every rank on cuda:0, throughput meaningless]" if rehearsal else ""),
+                   "parallelism": f"partitions p % {world} == rank; no data-path collective; final snapshot all-gathered through the C ABI" if world > 1 else "one GPU",
+                   "aggregates": A, "events_cap": cap, "partitions": P, "fetch_records": n_fetch, "fetches": len(fetches), "pushes_in_flight": depth,
+                   "framing_threads": args.framing_threads, "events_timed": total_events, "per_rank_events": per_rank, "keys_interned": total_keys,
+                   "wire_bytes_per_record": total_wire / max(1, int(totals[4].item())),
+                   "fetch_ms": {"p50": float(np.percentile(lat, 50)), "p90": float(np.percentile(lat, 90)), "max": float(np.max(lat))},
+                   "host_framing_ms_per_fetch": float(np.mean(host_ms[W:])), "finish_and_fold_ms_per_fetch": float(np.mean(dev_ms[W:])),
+                   "events_per_s_while_discovering_keys": rate(disc), "events_per_s_all_keys_known": rate(steady),
+                   "decoder": stats, "ingest": ingest_counters, "generate_s": gen_s, "parity_s": parity_s,
+                   "snapshot_exchange_ms": exchange, "gathered_aggregates": gathered_aggregates},
+        "roofline": {"bound": "hbm", "achieved": total_wire / elapsed_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": total_wire / elapsed_s / 1e9 / HBM_PEAK_GBPS,
+                     "traffic": None, "kernel": "surge_device_decoder (lz4_parse + lz4_exec + section_kernel + interning) + K3",
+                     "note": "wire bytes per second against the HBM peak: this path is not bandwidth-bound — its kernels are latency- / instruction-bound (serial LZ4 "
+                             "sequence walks, byte-wise JSON scans; profiles/r04_e2e_*): the kernel-level split is in the committed rocprofv3 summary, the roofline "
+                             "figure of the fold this path feeds is the default workload's"},
+        "cpu_baseline": {"value": sample_records / host_decoder_s, "unit": "events/s", "cores": 1, "kind": "port",
+                         "sample": f"{sample_records} records of the same fetches through the library's host decoder (surge_ingest_feed + surge_ingest_drain_json), decode only — no fold",
+                         "oracle_fold_events_per_s": int(off[-1]) / oracle_s if oracle_s > 0 else None,
+                         "gpu_states_match_cpu_fold_of_the_source_events": bool(parity_all)},
     }
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
 
 
 def effective_cpus():

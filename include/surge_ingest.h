@@ -143,12 +143,24 @@ typedef struct surge_batch_section {
 } surge_batch_section;
 /* Pops up to max deliverable batches (committed / non-transactional, before any open transaction), in offset order.
  * SURGE_E_STATE on a decoder that was not created in FRAMES mode.
- * Lifetime of the spans: a FRAMES decoder alternates between two arenas, one per feed, so the sections handed out here
- * (and the address surge_ingest_arena returned right after this drain) stay valid THROUGH the next feed and until the
- * feed after it — one thread can frame fetch i + 1 (feed, drain_sections, surge_ingest_arena) while another thread's
- * surge_device_decoder_push still reads fetch i.  The handle itself is for one thread at a time; what the second thread
- * touches is only the arena memory.  Batches still queued at a feed (open transactions) move to the new arena with it. */
+ * Lifetime of the spans: a FRAMES decoder rotates through four arenas, one per feed, so the sections handed out here
+ * (and the address surge_ingest_arena returned right after this drain) stay valid THROUGH the next three feeds — host
+ * threads can frame fetches i + 1 .. i + 3 (feed, drain_sections, surge_ingest_arena) while a device decoder's pushes of
+ * fetch i .. i + 2 are still in flight (surge_device_decoder_push_async).  The handle itself is for one thread at a
+ * time; what the other threads touch is only the arena memory.  Batches still queued at a feed (open transactions) move to
+ * the new arena with it. */
 int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge_batch_section* out, int64_t* n_out);
+
+/* A consumer that is assigned several partitions gets, per fetch response, the next bytes of each of them: one FRAMES
+ * handle per partition (transactions, last stable offsets and cut batches are per partition), fed and drained side by
+ * side on up to `threads` host threads (a handle is touched by one thread): for p in [0, n) feed(g[p], data[p], len[p])
+ * — skipped when len[p] is 0 — then drain_sections(g[p], max_sections_each, sections_out[p], &n_sections_out[p]) and
+ * arena_out[p] = surge_ingest_arena(g[p]); consumed_out (nullable) as surge_ingest_feed reports it; status_out[p] =
+ * partition p's status (its message: surge_ingest_last_error(g[p])).  Returns the first non-zero status, or 0.  What
+ * it is for: the n parts of ONE surge_device_decoder_push_parts_async. */
+int32_t surge_ingest_feed_drain_many(surge_ingest* const* g, const uint8_t* const* data, const int64_t* len, int32_t n, int32_t threads,
+                                     int64_t max_sections_each, surge_batch_section* const* sections_out, int64_t* n_sections_out,
+                                     const uint8_t** arena_out, int64_t* consumed_out, int32_t* status_out);
 
 /* Where the arena's memory comes from (before the first feed; NULL / NULL = malloc / free).  surge_ingest_use_pinned_arena
  * makes it page-locked host memory of the HIP runtime: a device decoder then copies the sections to the GPU straight out
@@ -168,6 +180,22 @@ const char* surge_device_decoder_last_error(const surge_device_decoder* d);
  * record that does not decode fails the whole push (SURGE_E_CORRUPT, the message names the record's offset): nothing of
  * the push is appended.  Synchronous. */
 int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes, const surge_batch_section* sections, int64_t n_sections);
+/* The two halves of a push, for a consumer that keeps the GPU busy across fetches.  push_async enqueues everything of a
+ * push that does not touch the key table — the copy to the device, the LZ4 blocks, chaining / parsing the records and
+ * decoding their values — on a stream of its own and returns; push_finish interns the keys of the OLDEST unfinished
+ * push, appends its records to the result and returns what surge_device_decoder_push would have returned.  Up to three
+ * pushes may be unfinished at a time (SURGE_E_STATE beyond that, and from push / push_records while any is), so the
+ * copy engine, the latency-bound LZ4 kernels and the compute-bound decode of consecutive fetches overlap on the chip:
+ *     push_async(fetch 0); push_async(fetch 1);
+ *     loop i: push_async(fetch i + 2); push_finish() -> fold the result of fetch i; clear
+ * `bytes` and `sections` must stay valid until the matching push_finish.  push_parts_async takes the sections of
+ * several arenas — e.g. one per partition of a fetch response, framed on as many host threads — as ONE push: part p's
+ * sections index bytes[p]; records are delivered part after part.  A push_async that fails occupies no slot. */
+int32_t surge_device_decoder_push_async(surge_device_decoder* d, const uint8_t* bytes, const surge_batch_section* sections, int64_t n_sections);
+int32_t surge_device_decoder_push_parts_async(surge_device_decoder* d, int32_t n_parts, const uint8_t* const* bytes,
+                                              const surge_batch_section* const* sections, const int64_t* n_sections);
+int32_t surge_device_decoder_push_finish(surge_device_decoder* d);
+int32_t surge_device_decoder_pending(const surge_device_decoder* d); /* pushes enqueued and not finished */
 /* The same for records that arrive already framed — what a JVM's KafkaConsumer hands over (ConsumerRecord key / value
  * bytes and offset): record i's key is keys[key_off[i] .. key_off[i+1]), its value values[value_off[i] .. value_off[i+1]),
  * offsets nullable (then 0, 1, 2 ..).  A record with an empty key AND an empty value is the producer's flush record and

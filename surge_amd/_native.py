@@ -96,6 +96,7 @@ INGEST_EXPORTS = (
     "surge_ingest_drain_fixed16",
     "surge_ingest_drain_json",
     "surge_ingest_drain_sections",
+    "surge_ingest_feed_drain_many",
     "surge_ingest_set_allocator",
     "surge_ingest_use_pinned_arena",
     "surge_device_decoder_create",
@@ -103,6 +104,10 @@ INGEST_EXPORTS = (
     "surge_device_decoder_last_error",
     "surge_device_decoder_push",
     "surge_device_decoder_push_records",
+    "surge_device_decoder_push_async",
+    "surge_device_decoder_push_parts_async",
+    "surge_device_decoder_push_finish",
+    "surge_device_decoder_pending",
     "surge_device_decoder_result",
     "surge_device_decoder_clear",
     "surge_replay_append_decoded",
@@ -303,6 +308,7 @@ def load() -> ctypes.CDLL:
         "surge_ingest_drain_fixed16": ([vp, i64, vp, vp, vp, ctypes.POINTER(i64)], i32),
         "surge_ingest_drain_json": ([vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)], i32),
         "surge_ingest_drain_sections": ([vp, i64, vp, ctypes.POINTER(i64)], i32),
+        "surge_ingest_feed_drain_many": ([vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp], i32),
         "surge_ingest_set_allocator": ([vp, vp, vp], i32),
         "surge_ingest_use_pinned_arena": ([vp], i32),
         "surge_device_decoder_create": ([i32, vp, vp, ctypes.POINTER(vp)], i32),
@@ -310,6 +316,10 @@ def load() -> ctypes.CDLL:
         "surge_device_decoder_last_error": ([vp], ctypes.c_char_p),
         "surge_device_decoder_push": ([vp, vp, vp, i64], i32),
         "surge_device_decoder_push_records": ([vp, vp, vp, vp, vp, vp, i64], i32),
+        "surge_device_decoder_push_async": ([vp, vp, vp, i64], i32),
+        "surge_device_decoder_push_parts_async": ([vp, i32, vp, vp, vp], i32),
+        "surge_device_decoder_push_finish": ([vp], i32),
+        "surge_device_decoder_pending": ([vp], i32),
         "surge_device_decoder_result": ([vp, ctypes.POINTER(i64), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64)], i32),
         "surge_device_decoder_clear": ([vp], i32),
         "surge_replay_append_decoded": ([vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),

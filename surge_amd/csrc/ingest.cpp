@@ -237,10 +237,12 @@ struct surge_ingest {
   bool frames = false;  // SURGE_INGEST_FRAMES: records are not parsed here, their sections go to a surge_device_decoder
   bool device_lz4 = false;  // SURGE_INGEST_DEVICE_LZ4: ... and LZ4 frames stay compressed (the device decoder undoes them)
   std::string err;
-  // FRAMES mode alternates between two arenas, one per feed: the sections a drain handed out stay where they are while
-  // the NEXT feed fills the other arena, so one thread can frame fetch i + 1 while a device decoder reads fetch i.
-  // The other modes only ever use the first.
-  Arena arenas[2];
+  // FRAMES mode rotates through four arenas, one per feed: the sections a drain handed out stay where they are while
+  // the next THREE feeds fill the others, so host threads can frame fetches i + 1 .. i + 3 while a device decoder still
+  // reads fetch i (surge_device_decoder_push_async keeps up to three pushes in flight).  The other modes only ever use
+  // the first.
+  static constexpr int kArenas = 4;
+  Arena arenas[kArenas];
   int cur = 0;
   bool handed_out = false;  // a drain has handed out spans of arenas[cur] since the last switch
   int crc_threads = 1;      // surge_ingest_set_threads: host threads that verify the batches' CRC-32C of one feed
@@ -526,10 +528,10 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
   if (consumed_out) *consumed_out = 0;
   if (g->frames && g->handed_out) {
     // switch arenas: the sections still queued (open transactions, undrained batches) move along, the ones the last
-    // drain handed out stay untouched in the arena this feed leaves behind (valid until the feed after this one).  A feed
+    // drain handed out stay untouched in the arena this feed leaves behind (valid through the three feeds after it).  A feed
     // that follows no drain keeps appending where the last one stopped: nothing is copied.
     try {
-      Arena& next = g->arenas[g->cur ^ 1];
+      Arena& next = g->arenas[(g->cur + 1) % surge_ingest::kArenas];
       const Arena& prev = g->arenas[g->cur];
       next.clear();
       for (Batch& qb : g->queue) {
@@ -538,7 +540,7 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
         next.append(prev.data() + qb.sect_off, (size_t)qb.sect_len);
         qb.sect_off = at;
       }
-      g->cur ^= 1;
+      g->cur = (g->cur + 1) % surge_ingest::kArenas;
       g->handed_out = false;
     } catch (const std::bad_alloc&) {
       return fail(g, E_NOMEM, "out of host memory while decoding");
@@ -696,7 +698,8 @@ const uint8_t* surge_ingest_arena(const surge_ingest* g) { return g ? g->arena_n
 
 int32_t surge_ingest_set_allocator(surge_ingest* g, void* (*alloc)(size_t), void (*release)(void*)) {
   if (!g || !alloc != !release) return fail(g, E_INVALID, "bad argument");
-  if (g->arenas[0].cap || g->arenas[1].cap) return fail(g, -2, "surge_ingest_set_allocator after the first feed");
+  for (const Arena& a : g->arenas)
+    if (a.cap) return fail(g, -2, "surge_ingest_set_allocator after the first feed");
   for (Arena& a : g->arenas) {
     a.alloc = alloc;
     a.release = release;
@@ -798,6 +801,49 @@ int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge
   g->counters[2] += recs;  // handed to the device decoder (its own counters tell flush records from events)
   if (n > 0) g->handed_out = true;
   *n_out = n;
+  return OK;
+}
+
+// One fetch response of a consumer with several partitions: feed + drain of every partition's framer, side by side.
+int32_t surge_ingest_feed_drain_many(surge_ingest* const* g, const uint8_t* const* data, const int64_t* len, int32_t n, int32_t threads,
+                                     int64_t max_sections_each, surge_batch_section* const* sections_out, int64_t* n_sections_out,
+                                     const uint8_t** arena_out, int64_t* consumed_out, int32_t* status_out) {
+  if (n < 0 || (n > 0 && (!g || !data || !len || !sections_out || !n_sections_out || !arena_out || !status_out)) || max_sections_each < 0)
+    return fail(nullptr, E_INVALID, "bad argument");
+  std::atomic<int32_t> next{0};
+  auto work = [&]() {
+    for (;;) {
+      const int32_t p = next.fetch_add(1);
+      if (p >= n) return;
+      n_sections_out[p] = 0;
+      arena_out[p] = nullptr;
+      if (consumed_out) consumed_out[p] = 0;
+      int32_t rc = OK;
+      try {  // (nothing may leave a thread)
+        if (!g[p]) {
+          rc = E_INVALID;
+        } else {
+          if (len[p] > 0) rc = surge_ingest_feed(g[p], data[p], len[p], consumed_out ? &consumed_out[p] : nullptr);
+          if (rc == OK) rc = surge_ingest_drain_sections(g[p], max_sections_each, sections_out[p], &n_sections_out[p]);
+          if (rc == OK) arena_out[p] = surge_ingest_arena(g[p]);
+        }
+      } catch (...) {
+        rc = E_NOMEM;
+      }
+      status_out[p] = rc;
+    }
+  };
+  int32_t t = threads < 1 ? 1 : threads;
+  if (t > n) t = n;
+  std::vector<std::thread> th;
+  try {
+    for (int32_t i = 1; i < t; ++i) th.emplace_back(work);
+  } catch (...) {  // std::system_error: the threads that did start — and this one — do the work
+  }
+  work();
+  for (std::thread& x : th) x.join();
+  for (int32_t p = 0; p < n; ++p)
+    if (status_out[p] != OK) return status_out[p];
   return OK;
 }
 

@@ -1048,6 +1048,27 @@ struct Buf {
 
 thread_local std::string g_dec_err;
 
+// Everything one push needs until it is finished.  A push has two halves: stage 1 does not touch the key table — copy to
+// the device, LZ4, chain / parse / decode — and runs on the slot's own stream; stage 2 — interning, compaction, append —
+// runs on the decoder's stream, one push after the other.  With several slots the host enqueues stage 1 of the next
+// fetches (surge_device_decoder_push_async) while stage 2 and the fold of the current one run: the copy engine, the
+// latency-bound LZ4 kernels and the compute-bound decode of different fetches overlap on the chip.
+struct PushSlot {
+  Buf lz4_blocks, lz4_sizes, lz4_nseq, lz4_seq, lz4_cls;
+  Buf d_bytes, d_sections, rec_a, rec_b, rec_c, meta, ev_tmp, f64_list, d_err;
+  void* pinned = nullptr;
+  size_t pinned_cap = 0;
+  std::vector<Section> h_secs;      // (sources of asynchronous copies: they live as long as the slot is busy)
+  std::vector<Lz4Block> h_blocks;
+  ErrorCell h_err;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  int64_t n_rec = 0;
+  uint64_t seed = 0;   // the hash function stage 1 hashed the keys with
+  bool busy = false, wire = false;
+};
+constexpr int kSlots = 3;
+
 }  // namespace
 
 struct surge_device_decoder {
@@ -1056,15 +1077,12 @@ struct surge_device_decoder {
   bool json = false;
   bool poisoned = false;  // a device error left the tables in an unknown state: every later push is refused
   std::string err;
-  Buf d_tmpl, d_ptab, d_err;
+  Buf d_tmpl, d_ptab;
   surge_event_json_template h_tmpl;  // (host copy: Doubles the device cannot decide are re-parsed with it)
-  // per push
-  Buf lz4_blocks, lz4_sizes, lz4_nseq, lz4_seq, lz4_cls;
-  Buf d_bytes, d_sections, rec_pos, rec_end, meta, first, first_scan, ev_tmp, keep, keep_pos, f64_list, temp;
-  void* pinned = nullptr;
-  size_t pinned_cap = 0;
-  std::vector<Section> h_secs;      // (sources of asynchronous copies: they live until the push's first synchronisation at least)
-  std::vector<Lz4Block> h_blocks;
+  PushSlot slots[kSlots];
+  int head = 0, n_pending = 0;  // slots [head, head + n_pending) hold pushes whose stage 1 is enqueued
+  // stage 2 scratch
+  Buf first, first_scan, keep, keep_pos, temp;
   // hash table + key table
   Buf t_hash, t_key_id, t_first, arena, key_off, key_hash;
   uint64_t t_cap = 0, seed = 0;
@@ -1160,13 +1178,17 @@ int32_t surge_device_decoder_create(int32_t device_id, void* hip_stream, const s
   int32_t rc = OK;
   auto init = [&]() -> int32_t {
     DCHK(d, hipSetDevice(device_id));
-    DCHK(d, d->d_err.reserve(sizeof(ErrorCell), false, d->stream));
+    for (PushSlot& s : d->slots) {
+      DCHK(d, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+      DCHK(d, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+      DCHK(d, s.d_err.reserve(sizeof(ErrorCell), false, d->stream));
+    }
     DCHK(d, d->key_off.reserve(8, false, d->stream));
     DCHK(d, hipMemset(d->key_off.p, 0, 8));
     if (tmpl) {
       d->h_tmpl = *tmpl;
       // the distinct field names, each once, and per type which of them it reads
-      static EvjDevice ev;  // (400-odd bytes of names: off the stack; create is not a hot path, guarded by the copy below)
+      static EvjDevice ev;  // (a few KB of names: off the stack; create is not a hot path)
       static std::mutex ev_mu;
       std::lock_guard<std::mutex> lk(ev_mu);
       std::memset(&ev, 0, sizeof(ev));
@@ -1216,11 +1238,17 @@ int32_t surge_device_decoder_destroy(surge_device_decoder* d) {
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  Buf* bufs[] = {&d->lz4_blocks, &d->lz4_sizes, &d->lz4_nseq, &d->lz4_seq, &d->lz4_cls, &d->d_tmpl, &d->d_ptab, &d->d_err, &d->d_bytes, &d->d_sections, &d->rec_pos,
-                 &d->rec_end, &d->meta, &d->first, &d->first_scan, &d->ev_tmp, &d->keep, &d->keep_pos, &d->f64_list, &d->temp, &d->t_hash, &d->t_key_id,
+  for (PushSlot& s : d->slots) {
+    if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); }
+    if (s.done) (void)hipEventDestroy(s.done);
+    Buf* sb[] = {&s.lz4_blocks, &s.lz4_sizes, &s.lz4_nseq, &s.lz4_seq, &s.lz4_cls, &s.d_bytes, &s.d_sections, &s.rec_a, &s.rec_b, &s.rec_c, &s.meta, &s.ev_tmp,
+                 &s.f64_list, &s.d_err};
+    for (Buf* b : sb) b->release();
+    if (s.pinned) (void)hipHostFree(s.pinned);
+  }
+  Buf* bufs[] = {&d->d_tmpl, &d->d_ptab, &d->first, &d->first_scan, &d->keep, &d->keep_pos, &d->temp, &d->t_hash, &d->t_key_id,
                  &d->t_first, &d->arena, &d->key_off, &d->key_hash, &d->r_agg, &d->r_ev, &d->r_off};
   for (Buf* b : bufs) b->release();
-  if (d->pinned) (void)hipHostFree(d->pinned);
   (void)hipSetDevice(prev);
   delete d;
   return OK;
@@ -1230,27 +1258,6 @@ int32_t surge_device_decoder_destroy(surge_device_decoder* d) {
 
 namespace {
 
-// scratch of one push and a fresh error cell; the hash table sized for n_rec more keys
-int32_t begin_push(surge_device_decoder* d, int64_t n_rec) {
-  if (d->poisoned) return dfail(d, SURGE_E_STATE, "an earlier push failed on the device half way: destroy this decoder and create a new one");
-  hipStream_t st = d->stream;
-  const size_t R = (size_t)n_rec;
-  DCHK(d, d->meta.reserve(R * sizeof(RecMeta), false, st));
-  DCHK(d, d->first.reserve((R + 1) * 8, false, st));
-  DCHK(d, d->first_scan.reserve((R + 1) * 8, false, st));
-  DCHK(d, d->ev_tmp.reserve(R * 16, false, st));
-  DCHK(d, d->keep.reserve((R + 1) * 4, false, st));
-  DCHK(d, d->keep_pos.reserve((R + 1) * 4, false, st));
-  DCHK(d, d->f64_list.reserve(R * 4, false, st));
-  size_t tb_a = 0, tb_b = 0;
-  DCHK(d, rocprim::exclusive_scan(nullptr, tb_a, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, 0ull, R + 1, rocprim::plus<unsigned long long>(), st));
-  DCHK(d, rocprim::exclusive_scan(nullptr, tb_b, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, R + 1, rocprim::plus<uint32_t>(), st));
-  DCHK(d, d->temp.reserve(tb_a > tb_b ? tb_a : tb_b, false, st));
-  ErrorCell zero{~0ull, 0u, 0u, ~0u, 0u};
-  DCHK(d, hipMemcpyAsync(d->d_err.p, &zero, sizeof(zero), hipMemcpyHostToDevice, st));
-  return ensure_table(d, n_rec);
-}
-
 const char* why_bad(uint32_t status) {
   static const char* why[] = {"", "", "has a null key or value (not an event)", "is malformed (a length runs past its record or batch)",
                               "is not the JSON object the event template describes", "names an event type the template does not know",
@@ -1259,16 +1266,337 @@ const char* why_bad(uint32_t status) {
   return status < 10 ? why[status] : "is bad";
 }
 
-// Everything behind the per-record metadata and decoded values: interning, compaction, append.  Two synchronisations:
-// one in the middle (what the push discovered: errors, new keys, their bytes, delivered records — everything the
-// allocations behind it need), one at the end.  Nothing is committed before the first: a push that fails takes the keys
-// it probed out of the table again (rollback_kernel), so a failed push leaves the decoder exactly as it was.
-int32_t finish_push(surge_device_decoder* d, int64_t n_rec, const surge_batch_section* sections) {
+struct DeviceScope {  // the calling thread's device, restored on the way out
+  int prev = 0;
+  explicit DeviceScope(int dev) { (void)hipGetDevice(&prev); (void)hipSetDevice(dev); }
+  ~DeviceScope() { (void)hipSetDevice(prev); }
+};
+
+// the slot a new push's stage 1 goes into (nullptr with the error set: every slot holds an unfinished push)
+PushSlot* claim_slot(surge_device_decoder* d, int32_t* rc) {
+  if (d->poisoned) {
+    *rc = dfail(d, SURGE_E_STATE, "an earlier push failed on the device half way: destroy this decoder and create a new one");
+    return nullptr;
+  }
+  if (d->n_pending == kSlots) {
+    *rc = dfail(d, SURGE_E_STATE, "every push slot holds an unfinished push: call surge_device_decoder_push_finish first");
+    return nullptr;
+  }
+  return &d->slots[(d->head + d->n_pending) % kSlots];
+}
+
+int32_t slot_scratch(surge_device_decoder* d, PushSlot& s, int64_t n_rec) {
+  const size_t R = (size_t)n_rec;
+  DCHK(d, s.meta.reserve(R * sizeof(RecMeta), false, s.stream));
+  DCHK(d, s.ev_tmp.reserve(R * 16, false, s.stream));
+  DCHK(d, s.f64_list.reserve(R * 4, false, s.stream));
+  static const ErrorCell kZero{~0ull, 0u, 0u, ~0u, 0u};  // (the source of an asynchronous copy: it must outlive the call)
+  DCHK(d, hipMemcpyAsync(s.d_err.p, &kZero, sizeof(kZero), hipMemcpyHostToDevice, s.stream));
+  return OK;
+}
+
+int32_t slot_pinned(surge_device_decoder* d, PushSlot& s, size_t bytes) {
+  if (bytes <= s.pinned_cap) return OK;
+  if (s.pinned) (void)hipHostFree(s.pinned);
+  s.pinned = nullptr;
+  s.pinned_cap = 0;
+  DCHK(d, hipHostMalloc(&s.pinned, bytes, hipHostMallocDefault));
+  s.pinned_cap = bytes;
+  return OK;
+}
+
+// Stage 1 of a wire push: the parts' records sections to the device, LZ4 blocks decoded, every record chained, parsed and
+// its value decoded.  Nothing here reads or writes the key table.
+int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const uint8_t* const* bytes, const surge_batch_section* const* sections,
+                    const int64_t* n_sections) {
+  int64_t total_sections = 0;
+  for (int32_t p = 0; p < n_parts; ++p) {
+    if (n_sections[p] < 0 || (n_sections[p] > 0 && (!bytes[p] || !sections[p]))) return dfail(d, E_INVALID, "bad argument");
+    total_sections += n_sections[p];
+  }
+  s.n_rec = 0;
+  s.wire = true;
+  if (total_sections == 0) return OK;
+  if (total_sections >= (1ll << 31)) return dfail(d, E_UNSUPPORTED, "more than 2^31 batches in one push");
+  std::vector<Section>& secs = s.h_secs;
+  std::vector<Lz4Block>& blocks = s.h_blocks;
+  std::vector<uint8_t> extra;
+  std::vector<int64_t> part_lo((size_t)n_parts, 0), part_dev((size_t)n_parts, 0), part_len((size_t)n_parts, 0);
+  int64_t n_rec = 0, n_raw = 0;
+  try {
+    secs.resize((size_t)total_sections);
+    blocks.clear();
+    // the span of each part's arena this push needs, laid out one after the other (16-byte aligned) on the device
+    int64_t at = 0;
+    for (int32_t p = 0; p < n_parts; ++p) {
+      int64_t lo = INT64_MAX, hi = 0;
+      for (int64_t i = 0; i < n_sections[p]; ++i) {
+        const surge_batch_section& in = sections[p][i];
+        if (in.byte_off < 0 || in.byte_len < 0 || in.n_records < 0) return dfail(d, E_INVALID, "negative section field");
+        lo = in.byte_off < lo ? in.byte_off : lo;
+        hi = in.byte_off + in.byte_len > hi ? in.byte_off + in.byte_len : hi;
+      }
+      if (n_sections[p] == 0) lo = hi = 0;
+      part_lo[(size_t)p] = lo;
+      part_len[(size_t)p] = hi - lo;
+      part_dev[(size_t)p] = n_raw;
+      n_raw = (n_raw + (hi - lo) + 15) & ~15ll;
+      for (int64_t i = 0; i < n_sections[p]; ++i, ++at) {
+        const surge_batch_section& in = sections[p][i];
+        secs[(size_t)at] = Section{part_dev[(size_t)p] + (in.byte_off - lo), in.byte_len, in.base_offset, in.n_records, 0, n_rec};
+        n_rec += in.n_records;
+      }
+    }
+  } catch (const std::bad_alloc&) {
+    return dfail(d, E_NOMEM, "out of host memory");
+  }
+  if (n_rec == 0) return OK;
+  if (n_rec >= (1ll << 32) - 1) return dfail(d, E_UNSUPPORTED, "more than 2^32 - 2 records in one push: push fewer sections at a time");
+  // LZ4 sections (codec 3: the batch's records section is still one LZ4 frame): the host reads the frame header and the
+  // block size words, the device decodes the blocks.  Frames it cannot take block by block (blocks larger than 64 KiB,
+  // dependent blocks) are decompressed here, on the host, and travel as plain bytes behind the raw spans.
+  int64_t area = 0;           // bytes of the device-side decompressed area handed out so far (multiples of 64 KiB)
+  int64_t n_seq_entries = 0;  // sequence-table entries handed out (two-pass decode)
+  bool any_one_pass = false;
+  static const bool force_one_pass = [] { const char* v = std::getenv("SURGE_INGEST_LZ4_ONEPASS"); return v && v[0] == '1'; }();
+  try {
+    int64_t at = 0;
+    for (int32_t p = 0; p < n_parts; ++p) {
+      for (int64_t i = 0; i < n_sections[p]; ++i, ++at) {
+        const surge_batch_section& in = sections[p][i];
+        if (in.codec != 3 || in.n_records == 0) continue;
+        Section& sec = secs[(size_t)at];
+        const uint8_t* f = bytes[p] + in.byte_off;
+        const int64_t fl = in.byte_len;
+        bool device_ok = fl >= 7 && f[0] == 0x04 && f[1] == 0x22 && f[2] == 0x4D && f[3] == 0x18 && (f[4] >> 6) == 1 && (f[4] & 0x20) &&
+                         ((f[5] >> 4) & 7) == 4;
+        int64_t q = 6;
+        if (device_ok) {
+          if (f[4] & 0x08) q += 8;  // content size
+          if (f[4] & 0x01) q += 4;  // dictionary id
+          device_ok = q < fl && f[q] == (uint8_t)(surge_xxh32(f + 4, q - 4, 0) >> 8);
+          ++q;
+        }
+        const size_t first_block = blocks.size();
+        const int64_t seq_mark = n_seq_entries;
+        int32_t k = 0;
+        while (device_ok) {
+          if (fl - q < 4) { device_ok = false; break; }
+          const uint32_t bs = (uint32_t)f[q] | ((uint32_t)f[q + 1] << 8) | ((uint32_t)f[q + 2] << 16) | ((uint32_t)f[q + 3] << 24);
+          q += 4;
+          if (bs == 0) break;  // EndMark
+          const uint32_t size = bs & 0x7fffffffu;
+          if ((int64_t)size > fl - q || size > (1u << 30)) { device_ok = false; break; }
+          Lz4Block b;
+          b.src_off = sec.byte_off + q;
+          b.dst_off = area + (int64_t)k * kLz4BlockMax;
+          b.src_len = (int32_t)size | (int32_t)(bs & 0x80000000u);
+          b.section = (int32_t)at;
+          b.last = 0;
+          b.index = k++;
+          // a sequence with a match takes at least 3 bytes of the block, the closing literal run at least 1
+          if (!force_one_pass && size < (uint32_t)kLz4BlockMax) {
+            b.seq_off = n_seq_entries;
+            n_seq_entries += (bs & 0x80000000u) ? 0 : (int64_t)size / 3 + 2;
+          } else {
+            b.seq_off = -1;
+            any_one_pass = true;
+          }
+          blocks.push_back(b);
+          q += size;
+          if (f[4] & 0x10) q += 4;  // block checksum (not verified: the batch CRC already covers these bytes)
+        }
+        if (device_ok && k > 0) {
+          blocks.back().last = 1;
+          sec.byte_off = -1 - area;  // resolved below, once the raw spans' final size is known
+          sec.byte_len = 0;          // set by the kernel that decodes the frame's last block
+          area += (int64_t)k * kLz4BlockMax;
+        } else {
+          blocks.resize(first_block);
+          n_seq_entries = seq_mark;
+          int64_t cap = fl * 8 + 1024, got;
+          const size_t ex = extra.size();
+          while (true) {
+            extra.resize(ex + (size_t)cap);
+            got = surge_lz4_frame_decompress(f, fl, extra.data() + ex, cap);
+            if (got != -6) break;
+            cap *= 4;
+            if (cap > (1ll << 31)) return dfail(d, SURGE_E_CORRUPT, "LZ4 batch expands beyond 2 GiB");
+          }
+          if (got < 0) return dfail(d, SURGE_E_CORRUPT, "bad LZ4 frame in the section at base offset " + std::to_string(in.base_offset));
+          extra.resize(ex + (size_t)got);
+          sec.byte_off = n_raw + (int64_t)ex;
+          sec.byte_len = got;
+        }
+      }
+    }
+    any_one_pass = false;
+    for (const Lz4Block& b : blocks) any_one_pass = any_one_pass || b.seq_off < 0;
+  } catch (const std::bad_alloc&) {
+    return dfail(d, E_NOMEM, "out of host memory");
+  }
+  const int64_t n_bytes = n_raw + (int64_t)extra.size();              // what is staged and copied
+  const int64_t area_base = (n_bytes + 15) & ~15ll;                    // where the device-decompressed frames start
+  for (Section& sc : secs)
+    if (sc.byte_off < 0) sc.byte_off = area_base + (-1 - sc.byte_off);
+  hipStream_t st = s.stream;
+  DCHK(d, s.d_bytes.reserve((size_t)(area_base + area) + 16, false, st));
+  DCHK(d, s.d_sections.reserve(sizeof(Section) * (size_t)total_sections, false, st));
+  {
+    const int32_t rc = slot_scratch(d, s, n_rec);
+    if (rc != OK) return rc;
+  }
+  // H2D: a part goes straight out of the caller's arena when that is page-locked (surge_ingest_use_pinned_arena), else
+  // through the slot's own pinned staging (one extra host copy)
+  size_t need_stage = extra.size();
+  std::vector<char> in_place((size_t)n_parts, 0);
+  for (int32_t p = 0; p < n_parts; ++p) {
+    if (part_len[(size_t)p] == 0) continue;
+    hipPointerAttribute_t attr;
+    in_place[(size_t)p] = hipPointerGetAttributes(&attr, bytes[p] + part_lo[(size_t)p]) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();  // a pageable pointer makes hipPointerGetAttributes fail: not an error of this call
+    if (!in_place[(size_t)p]) need_stage += (size_t)part_len[(size_t)p];
+  }
+  {
+    const int32_t rc = slot_pinned(d, s, need_stage);
+    if (rc != OK) return rc;
+  }
+  size_t staged = 0;
+  for (int32_t p = 0; p < n_parts; ++p) {
+    const size_t len = (size_t)part_len[(size_t)p];
+    if (len == 0) continue;
+    const uint8_t* src = bytes[p] + part_lo[(size_t)p];
+    if (!in_place[(size_t)p]) {
+      std::memcpy((uint8_t*)s.pinned + staged, src, len);
+      src = (const uint8_t*)s.pinned + staged;
+      staged += len;
+    }
+    DCHK(d, hipMemcpyAsync((uint8_t*)s.d_bytes.p + part_dev[(size_t)p], src, len, hipMemcpyHostToDevice, st));
+  }
+  if (!extra.empty()) {
+    std::memcpy((uint8_t*)s.pinned + staged, extra.data(), extra.size());
+    DCHK(d, hipMemcpyAsync((uint8_t*)s.d_bytes.p + n_raw, (const uint8_t*)s.pinned + staged, extra.size(), hipMemcpyHostToDevice, st));
+  }
+  DCHK(d, hipMemcpyAsync(s.d_sections.p, secs.data(), sizeof(Section) * (size_t)total_sections, hipMemcpyHostToDevice, st));
+  const uint8_t* dby = (const uint8_t*)s.d_bytes.p;
+  Section* dsec = (Section*)s.d_sections.p;
+  ErrorCell* derr = (ErrorCell*)s.d_err.p;
+  RecMeta* dmeta = (RecMeta*)s.meta.p;
+  if (!blocks.empty()) {
+    DCHK(d, s.lz4_blocks.reserve(blocks.size() * sizeof(Lz4Block), false, st));
+    DCHK(d, hipMemcpyAsync(s.lz4_blocks.p, blocks.data(), blocks.size() * sizeof(Lz4Block), hipMemcpyHostToDevice, st));
+    DCHK(d, s.lz4_sizes.reserve(blocks.size() * 4, false, st));
+    const int64_t nb = (int64_t)blocks.size();
+    if (nb >= (1ll << 31)) return dfail(d, E_UNSUPPORTED, "more than 2^31 LZ4 blocks in one push: push fewer sections at a time");
+    if (!force_one_pass) {
+      // two passes: the sequence headers by one lane per block, then the copies by one wave per block in a launch with
+      // the LDS the block's size needs (the first pass knows it)
+      Lz4Work w;
+      DCHK(d, s.lz4_nseq.reserve((size_t)nb * 4, false, st));
+      DCHK(d, s.lz4_seq.reserve((size_t)(n_seq_entries + 1) * 8, false, st));
+      DCHK(d, s.lz4_cls.reserve((size_t)(kLz4Classes + 1) * ((size_t)nb + 1) * 4, false, st));
+      w.state = (int32_t*)s.lz4_sizes.p;
+      w.n_seq = (int32_t*)s.lz4_nseq.p;
+      w.seq = (uint2*)s.lz4_seq.p;
+      w.cls_count = (int32_t*)s.lz4_cls.p;
+      w.cls_list = w.cls_count + (kLz4Classes + 1);
+      DCHK(d, hipMemsetAsync(w.cls_count, 0, (kLz4Classes + 1) * 4, st));
+      hipLaunchKernelGGL(lz4_parse_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st, dby, (uint8_t*)s.d_bytes.p + area_base, (const Lz4Block*)s.lz4_blocks.p,
+                         (int32_t)nb, w, dsec, derr);
+      for (int c = 0; c <= kLz4Classes; ++c) {
+        const int32_t cap = c < kLz4Classes ? kLz4ClassCapHost[c] : 0;
+        const size_t lds = cap ? (size_t)cap + 64 + (size_t)kLz4Map * 2 : 0;
+        const int64_t resident = 256ll * (lds ? (int64_t)(160 * 1024 / lds) : 16);  // waves the chip holds at this LDS size
+        const unsigned grid = (unsigned)(nb < resident ? nb : resident);
+        hipLaunchKernelGGL(lz4_exec_kernel, dim3(grid), dim3(64), lds, st, dby, (uint8_t*)s.d_bytes.p + area_base, (const Lz4Block*)s.lz4_blocks.p, (int32_t)nb, w, c, cap);
+      }
+    }
+    if (any_one_pass) {
+      const unsigned grid = (unsigned)(nb < 8192 ? nb : 8192);
+      const int32_t caps[3] = {16384, 32768, kLz4BlockMax};  // LDS per wave of the three launches
+      for (int c = 0; c < 3; ++c)
+        hipLaunchKernelGGL(lz4_block_kernel, dim3(grid), dim3(64), (size_t)caps[c], st, dby, (uint8_t*)s.d_bytes.p + area_base,
+                           (const Lz4Block*)s.lz4_blocks.p, nb, (int32_t*)s.lz4_sizes.p, c, caps[c], dsec, derr);
+    }
+    // (a frame that does not decode zeroes its section and raises the error cell: the push fails in stage 2's first
+    // synchronisation, before anything is committed)
+  }
+  // chain + parse + decode, one workgroup per batch: sections up to 20 KiB (the reference producer closes a batch at 16 KiB)
+  // out of 24 KiB of LDS, the rest out of 68 KiB or, beyond 64 KiB, in place
+  {
+    const EvjDevice* dt = d->json ? (const EvjDevice*)d->d_tmpl.p : nullptr;
+    const int64_t caps[2] = {20480, 65536};
+    for (int c = 0; c < 2; ++c) {
+      const size_t lds = (size_t)((caps[c] + 47) & ~15ll) + 2 * (size_t)kSecRecs * 4;
+      hipLaunchKernelGGL(section_kernel, dim3((unsigned)total_sections), dim3(kSecThreads), lds, st, dby, (const Section*)dsec, total_sections, c == 0 ? -1 : caps[0],
+                         caps[c], c == 1 ? 1 : 0, d->seed, dt, (const surge::F64ParseTable*)d->d_ptab.p, dmeta, (uint4*)s.ev_tmp.p, (uint32_t*)s.f64_list.p, derr);
+    }
+    DCHK(d, hipGetLastError());
+  }
+  s.n_rec = n_rec;
+  s.seed = d->seed;
+  return OK;
+}
+
+// Stage 1 of a push of records that are already framed
+int32_t stage1_records(surge_device_decoder* d, PushSlot& s, const uint8_t* keys, const int64_t* key_off, const uint8_t* values, const int64_t* value_off,
+                       const int64_t* offsets, int64_t n) {
+  s.n_rec = 0;
+  s.wire = false;
+  if (n == 0) return OK;
+  if (n >= (1ll << 32) - 1) return dfail(d, E_UNSUPPORTED, "more than 2^32 - 2 records in one push");
+  const int64_t kb = key_off[n] - key_off[0], vb = value_off[n] - value_off[0];
+  if (kb < 0 || vb < 0 || (kb > 0 && !keys) || (vb > 0 && !values)) return dfail(d, E_INVALID, "bad key / value spans");
+  for (int64_t i = 0; i < n; ++i)  // (the kernels index the staged bytes with these: no launch on offsets that run backwards)
+    if (key_off[i + 1] < key_off[i] || value_off[i + 1] < value_off[i]) return dfail(d, E_INVALID, "key_off / value_off must not decrease (record " + std::to_string(i) + ")");
+  hipStream_t st = s.stream;
+  const size_t n_bytes = (size_t)(kb + vb), off_bytes = (size_t)(n + 1) * 8;
+  const size_t stage = n_bytes + 2 * off_bytes + (offsets ? (size_t)n * 8 : 0) + 64;
+  DCHK(d, s.d_bytes.reserve(n_bytes + 16, false, st));
+  DCHK(d, s.rec_a.reserve(off_bytes, false, st));  // the device copies of key_off / value_off / offsets
+  DCHK(d, s.rec_b.reserve(off_bytes, false, st));
+  DCHK(d, s.rec_c.reserve((size_t)n * 8 + 8, false, st));
+  {
+    int32_t rc = slot_scratch(d, s, n);
+    if (rc == OK) rc = slot_pinned(d, s, stage);
+    if (rc != OK) return rc;
+  }
+  // pinned staging: [keys][values][key_off (rebased)][value_off (rebased)][offsets]
+  uint8_t* pin = (uint8_t*)s.pinned;
+  if (kb) std::memcpy(pin, keys + key_off[0], (size_t)kb);
+  if (vb) std::memcpy(pin + kb, values + value_off[0], (size_t)vb);
+  int64_t* p_ko = (int64_t*)(pin + ((n_bytes + 7) & ~(size_t)7));
+  int64_t* p_vo = p_ko + (n + 1);
+  int64_t* p_of = p_vo + (n + 1);
+  for (int64_t i = 0; i <= n; ++i) { p_ko[i] = key_off[i] - key_off[0]; p_vo[i] = value_off[i] - value_off[0]; }
+  if (offsets) std::memcpy(p_of, offsets, (size_t)n * 8);
+  if (n_bytes) DCHK(d, hipMemcpyAsync(s.d_bytes.p, pin, n_bytes, hipMemcpyHostToDevice, st));
+  DCHK(d, hipMemcpyAsync(s.rec_a.p, p_ko, off_bytes, hipMemcpyHostToDevice, st));
+  DCHK(d, hipMemcpyAsync(s.rec_b.p, p_vo, off_bytes, hipMemcpyHostToDevice, st));
+  if (offsets) DCHK(d, hipMemcpyAsync(s.rec_c.p, p_of, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(records_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)s.d_bytes.p, (const int64_t*)s.rec_a.p,
+                     (const int64_t*)s.rec_b.p, offsets ? (const int64_t*)s.rec_c.p : nullptr, kb, n, d->seed,
+                     d->json ? (const EvjDevice*)d->d_tmpl.p : nullptr, (const surge::F64ParseTable*)d->d_ptab.p, (RecMeta*)s.meta.p, (uint4*)s.ev_tmp.p,
+                     (uint32_t*)s.f64_list.p, (ErrorCell*)s.d_err.p);
+  DCHK(d, hipGetLastError());
+  s.n_rec = n;
+  s.seed = d->seed;
+  return OK;
+}
+
+// Stage 2: everything behind the per-record metadata and decoded values — interning, compaction, append — on the
+// decoder's stream.  Two synchronisations: one in the middle (what the push discovered: errors, new keys, their bytes,
+// delivered records — everything the allocations behind it need), one at the end.  Nothing is committed before the
+// first: a push that fails takes the keys it probed out of the table again (rollback_kernel), so a failed push leaves
+// the decoder exactly as it was.
+int32_t stage2(surge_device_decoder* d, PushSlot& s) {
+  const int64_t n_rec = s.n_rec;
+  if (n_rec == 0) return OK;
   hipStream_t st = d->stream;
   const size_t R = (size_t)n_rec;
-  const uint8_t* dby = (const uint8_t*)d->d_bytes.p;
-  ErrorCell* derr = (ErrorCell*)d->d_err.p;
-  RecMeta* dmeta = (RecMeta*)d->meta.p;
+  const uint8_t* dby = (const uint8_t*)s.d_bytes.p;
+  ErrorCell* derr = (ErrorCell*)s.d_err.p;
+  RecMeta* dmeta = (RecMeta*)s.meta.p;
   const unsigned rb = (unsigned)((n_rec + 255) / 256), rb1 = (unsigned)((n_rec + 256) / 256);
   auto poison = [&](int32_t rc) { d->poisoned = true; return rc; };
 #define PCHK(call)                                                                                                      \
@@ -1276,6 +1604,22 @@ int32_t finish_push(surge_device_decoder* d, int64_t n_rec, const surge_batch_se
     hipError_t e_ = (call);                                                                                             \
     if (e_ != hipSuccess) return poison(dfail(d, e_ == hipErrorOutOfMemory ? E_NOMEM : E_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_))); \
   } while (0)
+  // scratch (nothing of the push is in the table yet: an allocation failure here needs no rollback)
+  DCHK(d, d->first.reserve((R + 1) * 8, false, st));
+  DCHK(d, d->first_scan.reserve((R + 1) * 8, false, st));
+  DCHK(d, d->keep.reserve((R + 1) * 4, false, st));
+  DCHK(d, d->keep_pos.reserve((R + 1) * 4, false, st));
+  {
+    size_t tb_a = 0, tb_b = 0;
+    DCHK(d, rocprim::exclusive_scan(nullptr, tb_a, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, 0ull, R + 1, rocprim::plus<unsigned long long>(), st));
+    DCHK(d, rocprim::exclusive_scan(nullptr, tb_b, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, R + 1, rocprim::plus<uint32_t>(), st));
+    DCHK(d, d->temp.reserve(tb_a > tb_b ? tb_a : tb_b, false, st));
+    const int32_t rc = ensure_table(d, n_rec);
+    if (rc != OK) return rc;
+  }
+  PCHK(hipStreamWaitEvent(st, s.done, 0));
+  if (s.seed != d->seed)  // the table was re-seeded after this push's stage 1 hashed its keys
+    hipLaunchKernelGGL(rekey_records_kernel, dim3(rb), dim3(256), 0, st, dmeta, n_rec, dby, d->seed);
   ErrorCell ec;
   unsigned long long first_total = 0;
   uint32_t kept = 0;
@@ -1309,8 +1653,8 @@ int32_t finish_push(surge_device_decoder* d, int64_t n_rec, const surge_batch_se
         hipLaunchKernelGGL(rehash_kernel, dim3(kb), dim3(256), 0, st, (const unsigned long long*)d->key_hash.p, d->n_keys, table_of(d));
       }
       hipLaunchKernelGGL(rekey_records_kernel, dim3(rb), dim3(256), 0, st, dmeta, n_rec, dby, d->seed);
-      ErrorCell zero{~0ull, 0u, ec.n_f64_host, ~0u, 0u};
-      PCHK(hipMemcpyAsync(derr, &zero, sizeof(zero), hipMemcpyHostToDevice, st));
+      s.h_err = ErrorCell{~0ull, 0u, ec.n_f64_host, ~0u, 0u};
+      PCHK(hipMemcpyAsync(derr, &s.h_err, sizeof(s.h_err), hipMemcpyHostToDevice, st));
       continue;
     }
     break;
@@ -1324,7 +1668,7 @@ int32_t finish_push(surge_device_decoder* d, int64_t n_rec, const surge_batch_se
   if (ec.lz4_bad != ~0u) {
     const int32_t rc = rollback();
     if (rc != OK) return rc;
-    return dfail(d, SURGE_E_CORRUPT, "bad LZ4 frame in the batch at base offset " + std::to_string(sections ? sections[ec.lz4_bad].base_offset : -1) +
+    return dfail(d, SURGE_E_CORRUPT, "bad LZ4 frame in the batch at base offset " + std::to_string(ec.lz4_bad < s.h_secs.size() ? s.h_secs[ec.lz4_bad].base_offset : -1) +
                                      " (malformed sequence, or a block that is not 64 KiB where it must be)");
   }
   if (ec.first_bad != ~0ull) {
@@ -1362,7 +1706,7 @@ int32_t finish_push(surge_device_decoder* d, int64_t n_rec, const surge_batch_se
                        (const unsigned long long*)d->first_scan.p, d->n_keys, d->arena_bytes, table_of(d), (uint8_t*)d->arena.p, (int64_t*)d->key_off.p,
                        (unsigned long long*)d->key_hash.p);
   hipLaunchKernelGGL(finalize_kernel, dim3(rb), dim3(256), 0, st, (const RecMeta*)dmeta, n_rec, (const uint32_t*)d->keep.p, (const uint32_t*)d->keep_pos.p, table_of(d),
-                     (const uint4*)d->ev_tmp.p, d->n_records, (int64_t*)d->r_agg.p, (uint4*)d->r_ev.p, (int64_t*)d->r_off.p);
+                     (const uint4*)s.ev_tmp.p, d->n_records, (int64_t*)d->r_agg.p, (uint4*)d->r_ev.p, (int64_t*)d->r_off.p);
   PCHK(hipGetLastError());
   d->n_keys += n_new;
   d->arena_bytes += new_bytes;
@@ -1371,7 +1715,7 @@ int32_t finish_push(surge_device_decoder* d, int64_t n_rec, const surge_batch_se
     // Doubles the fast parser could not decide (more than 19 digits, or one of Eisel-Lemire's rare ambiguous products):
     // the host parses exactly those values with the library's host decoder and patches the payload in place
     std::vector<uint32_t> list(ec.n_f64_host);
-    PCHK(hipMemcpy(list.data(), d->f64_list.p, (size_t)ec.n_f64_host * 4, hipMemcpyDeviceToHost));
+    PCHK(hipMemcpy(list.data(), s.f64_list.p, (size_t)ec.n_f64_host * 4, hipMemcpyDeviceToHost));
     for (uint32_t i : list) {
       RecMeta m;
       uint32_t pos = 0;
@@ -1395,262 +1739,86 @@ int32_t finish_push(surge_device_decoder* d, int64_t n_rec, const surge_batch_se
 #undef PCHK
 }
 
+// stage 1 is enqueued: the slot joins the queue
+int32_t commit_slot(surge_device_decoder* d, PushSlot& s) {
+  DCHK(d, hipEventRecord(s.done, s.stream));
+  s.busy = true;
+  ++d->n_pending;
+  return OK;
+}
+
+int32_t finish_oldest(surge_device_decoder* d) {
+  PushSlot& s = d->slots[d->head];
+  const int32_t rc = stage2(d, s);
+  if (rc != OK) {
+    // the slot's buffers are still being written by its own stream if stage 2 never waited for it
+    (void)hipStreamSynchronize(s.stream);
+  }
+  s.busy = false;
+  d->head = (d->head + 1) % kSlots;
+  --d->n_pending;
+  return rc;
+}
+
 }  // namespace
 
 extern "C" {
 
+int32_t surge_device_decoder_push_parts_async(surge_device_decoder* d, int32_t n_parts, const uint8_t* const* bytes, const surge_batch_section* const* sections,
+                                              const int64_t* n_sections) {
+  if (!d) return dfail(nullptr, E_INVALID, "decoder is NULL");
+  if (n_parts < 0 || (n_parts > 0 && (!bytes || !sections || !n_sections))) return dfail(d, E_INVALID, "bad argument");
+  int32_t rc = OK;
+  PushSlot* s = claim_slot(d, &rc);
+  if (!s) return rc;
+  DeviceScope scope(d->device);
+  rc = stage1_wire(d, *s, n_parts, bytes, sections, n_sections);
+  if (rc != OK) {
+    (void)hipStreamSynchronize(s->stream);  // whatever was enqueued before the failure reads host memory of this call
+    return rc;
+  }
+  return commit_slot(d, *s);
+}
+
+int32_t surge_device_decoder_push_async(surge_device_decoder* d, const uint8_t* bytes, const surge_batch_section* sections, int64_t n_sections) {
+  return surge_device_decoder_push_parts_async(d, 1, &bytes, &sections, &n_sections);
+}
+
+int32_t surge_device_decoder_push_finish(surge_device_decoder* d) {
+  if (!d) return dfail(nullptr, E_INVALID, "decoder is NULL");
+  if (d->n_pending == 0) return dfail(d, SURGE_E_STATE, "push_finish without a pending push_async");
+  DeviceScope scope(d->device);
+  return finish_oldest(d);
+}
+
+int32_t surge_device_decoder_pending(const surge_device_decoder* d) { return d ? d->n_pending : 0; }
+
 int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes, const surge_batch_section* sections, int64_t n_sections) {
   if (!d) return dfail(nullptr, E_INVALID, "decoder is NULL");
   if (n_sections < 0 || (n_sections > 0 && (!bytes || !sections))) return dfail(d, E_INVALID, "bad argument");
+  if (d->n_pending != 0) return dfail(d, SURGE_E_STATE, "asynchronous pushes are pending: finish them first (results are appended in push order)");
   if (n_sections == 0) return OK;
-  // the span of the arena this push needs, and every batch's first record index
-  int64_t lo = INT64_MAX, hi = 0, n_rec = 0;
-  std::vector<Section>& secs = d->h_secs;
-  try {
-    secs.resize((size_t)n_sections);
-  } catch (const std::bad_alloc&) {
-    return dfail(d, E_NOMEM, "out of host memory");
-  }
-  for (int64_t s = 0; s < n_sections; ++s) {
-    const surge_batch_section& in = sections[s];
-    if (in.byte_off < 0 || in.byte_len < 0 || in.n_records < 0) return dfail(d, E_INVALID, "negative section field");
-    lo = in.byte_off < lo ? in.byte_off : lo;
-    hi = in.byte_off + in.byte_len > hi ? in.byte_off + in.byte_len : hi;
-    secs[(size_t)s] = Section{in.byte_off, in.byte_len, in.base_offset, in.n_records, 0, n_rec};
-    n_rec += in.n_records;
-  }
-  if (n_rec == 0) return OK;
-  if (n_rec >= (1ll << 32) - 1) return dfail(d, E_UNSUPPORTED, "more than 2^32 - 2 records in one push: push fewer sections at a time");
-  for (Section& s : secs) s.byte_off -= lo;
-  const int64_t n_raw = hi - lo;
-  // LZ4 sections (codec 3: the batch's records section is still one LZ4 frame): the host reads the frame header and the
-  // block size words, the device decodes the blocks.  Frames it cannot take block by block (blocks larger than 64 KiB,
-  // dependent blocks) are decompressed here, on the host, and travel as plain bytes behind the raw span.
-  std::vector<Lz4Block>& blocks = d->h_blocks;
-  blocks.clear();
-  std::vector<uint8_t> extra;
-  int64_t area = 0;  // bytes of the device-side decompressed area handed out so far (multiples of 64 KiB)
-  int64_t n_seq_entries = 0;  // sequence-table entries handed out (two-pass decode)
-  bool any_one_pass = false;
-  static const bool force_one_pass = [] { const char* v = std::getenv("SURGE_INGEST_LZ4_ONEPASS"); return v && v[0] == '1'; }();
-  try {
-    for (int64_t s = 0; s < n_sections; ++s) {
-      if (sections[s].codec != 3 || sections[s].n_records == 0) continue;
-      Section& sec = secs[(size_t)s];
-      const uint8_t* f = bytes + sections[s].byte_off;
-      const int64_t fl = sections[s].byte_len;
-      bool device_ok = fl >= 7 && f[0] == 0x04 && f[1] == 0x22 && f[2] == 0x4D && f[3] == 0x18 && (f[4] >> 6) == 1 && (f[4] & 0x20) &&
-                       ((f[5] >> 4) & 7) == 4;
-      int64_t p = 6;
-      if (device_ok) {
-        if (f[4] & 0x08) p += 8;  // content size
-        if (f[4] & 0x01) p += 4;  // dictionary id
-        device_ok = p < fl && f[p] == (uint8_t)(surge_xxh32(f + 4, p - 4, 0) >> 8);
-        ++p;
-      }
-      const size_t first_block = blocks.size();
-      const int64_t seq_mark = n_seq_entries;
-      int32_t k = 0;
-      while (device_ok) {
-        if (fl - p < 4) { device_ok = false; break; }
-        const uint32_t bs = (uint32_t)f[p] | ((uint32_t)f[p + 1] << 8) | ((uint32_t)f[p + 2] << 16) | ((uint32_t)f[p + 3] << 24);
-        p += 4;
-        if (bs == 0) break;  // EndMark
-        const uint32_t size = bs & 0x7fffffffu;
-        if ((int64_t)size > fl - p || size > (1u << 30)) { device_ok = false; break; }
-        Lz4Block b;
-        b.src_off = sec.byte_off + p;
-        b.dst_off = area + (int64_t)k * kLz4BlockMax;
-        b.src_len = (int32_t)size | (int32_t)(bs & 0x80000000u);
-        b.section = (int32_t)s;
-        b.last = 0;
-        b.index = k++;
-        // a sequence with a match takes at least 3 bytes of the block, the closing literal run at least 1
-        if (!force_one_pass && size < (uint32_t)kLz4BlockMax) {
-          b.seq_off = n_seq_entries;
-          n_seq_entries += (bs & 0x80000000u) ? 0 : (int64_t)size / 3 + 2;
-        } else {
-          b.seq_off = -1;
-        }
-        blocks.push_back(b);
-        p += size;
-        if (f[4] & 0x10) p += 4;  // block checksum (not verified: the batch CRC already covers these bytes)
-      }
-      if (device_ok && k > 0) {
-        blocks.back().last = 1;
-        sec.byte_off = -1 - area;  // resolved below, once the raw span's final size is known
-        sec.byte_len = 0;          // set by the kernel that decodes the frame's last block
-        area += (int64_t)k * kLz4BlockMax;
-      } else {
-        blocks.resize(first_block);
-        n_seq_entries = seq_mark;
-        int64_t cap = fl * 8 + 1024, got;
-        const size_t at = extra.size();
-        while (true) {
-          extra.resize(at + (size_t)cap);
-          got = surge_lz4_frame_decompress(f, fl, extra.data() + at, cap);
-          if (got != -6) break;
-          cap *= 4;
-          if (cap > (1ll << 31)) return dfail(d, SURGE_E_CORRUPT, "LZ4 batch expands beyond 2 GiB");
-        }
-        if (got < 0) return dfail(d, SURGE_E_CORRUPT, "bad LZ4 frame in the section at base offset " + std::to_string(sections[s].base_offset));
-        extra.resize(at + (size_t)got);
-        sec.byte_off = n_raw + (int64_t)at;
-        sec.byte_len = got;
-      }
-    }
-  } catch (const std::bad_alloc&) {
-    return dfail(d, E_NOMEM, "out of host memory");
-  }
-  const int64_t n_bytes = n_raw + (int64_t)extra.size();              // what is staged and copied
-  const int64_t area_base = (n_bytes + 15) & ~15ll;                    // where the device-decompressed frames start
-  for (Section& s : secs)
-    if (s.byte_off < 0) s.byte_off = area_base + (-1 - s.byte_off);
-  int prev = 0;
-  (void)hipGetDevice(&prev);
-  struct Restore { int dev; ~Restore() { (void)hipSetDevice(dev); } } restore{prev};
-  DCHK(d, hipSetDevice(d->device));
-  hipStream_t st = d->stream;
-  DCHK(d, d->d_bytes.reserve((size_t)(area_base + area) + 16, false, st));
-  DCHK(d, d->d_sections.reserve(sizeof(Section) * (size_t)n_sections, false, st));
-  {
-    const int32_t rc = begin_push(d, n_rec);
-    if (rc != OK) return rc;
-  }
-  // H2D: straight out of the caller's arena when that is page-locked (surge_ingest_use_pinned_arena), else through the
-  // decoder's own pinned staging (one extra host copy per push)
-  hipPointerAttribute_t attr;
-  const bool in_place = hipPointerGetAttributes(&attr, bytes + lo) == hipSuccess && attr.type == hipMemoryTypeHost;
-  (void)hipGetLastError();  // a pageable pointer makes hipPointerGetAttributes fail: not an error of this call
-  const size_t staged = in_place ? extra.size() : (size_t)n_bytes;
-  if (staged > d->pinned_cap) {
-    if (d->pinned) (void)hipHostFree(d->pinned);
-    d->pinned = nullptr;
-    d->pinned_cap = 0;
-    DCHK(d, hipHostMalloc(&d->pinned, staged, hipHostMallocDefault));
-    d->pinned_cap = staged;
-  }
-  if (in_place) {
-    DCHK(d, hipMemcpyAsync(d->d_bytes.p, bytes + lo, (size_t)n_raw, hipMemcpyHostToDevice, st));
-    if (!extra.empty()) {
-      std::memcpy(d->pinned, extra.data(), extra.size());
-      DCHK(d, hipMemcpyAsync((uint8_t*)d->d_bytes.p + n_raw, d->pinned, extra.size(), hipMemcpyHostToDevice, st));
-    }
-  } else {
-    std::memcpy(d->pinned, bytes + lo, (size_t)n_raw);
-    if (!extra.empty()) std::memcpy((uint8_t*)d->pinned + n_raw, extra.data(), extra.size());
-    DCHK(d, hipMemcpyAsync(d->d_bytes.p, d->pinned, (size_t)n_bytes, hipMemcpyHostToDevice, st));
-  }
-  DCHK(d, hipMemcpyAsync(d->d_sections.p, secs.data(), sizeof(Section) * (size_t)n_sections, hipMemcpyHostToDevice, st));
-  const uint8_t* dby = (const uint8_t*)d->d_bytes.p;
-  Section* dsec = (Section*)d->d_sections.p;
-  ErrorCell* derr = (ErrorCell*)d->d_err.p;
-  RecMeta* dmeta = (RecMeta*)d->meta.p;
-  if (!blocks.empty()) {
-    DCHK(d, d->lz4_blocks.reserve(blocks.size() * sizeof(Lz4Block), false, st));
-    DCHK(d, hipMemcpyAsync(d->lz4_blocks.p, blocks.data(), blocks.size() * sizeof(Lz4Block), hipMemcpyHostToDevice, st));
-    DCHK(d, d->lz4_sizes.reserve(blocks.size() * 4, false, st));
-    const int64_t nb = (int64_t)blocks.size();
-    if (nb >= (1ll << 31)) return dfail(d, E_UNSUPPORTED, "more than 2^31 LZ4 blocks in one push: push fewer sections at a time");
-    for (const Lz4Block& b : blocks) any_one_pass = any_one_pass || b.seq_off < 0;
-    if (!force_one_pass) {
-      // two passes: the sequence headers by one lane per block, then the copies by one wave per block in a launch with
-      // the LDS the block's size needs (the first pass knows it)
-      Lz4Work w;
-      DCHK(d, d->lz4_nseq.reserve((size_t)nb * 4, false, st));
-      DCHK(d, d->lz4_seq.reserve((size_t)(n_seq_entries + 1) * 8, false, st));
-      DCHK(d, d->lz4_cls.reserve((size_t)(kLz4Classes + 1) * ((size_t)nb + 1) * 4, false, st));
-      w.state = (int32_t*)d->lz4_sizes.p;
-      w.n_seq = (int32_t*)d->lz4_nseq.p;
-      w.seq = (uint2*)d->lz4_seq.p;
-      w.cls_count = (int32_t*)d->lz4_cls.p;
-      w.cls_list = w.cls_count + (kLz4Classes + 1);
-      DCHK(d, hipMemsetAsync(w.cls_count, 0, (kLz4Classes + 1) * 4, st));
-      hipLaunchKernelGGL(lz4_parse_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st, dby, (uint8_t*)d->d_bytes.p + area_base, (const Lz4Block*)d->lz4_blocks.p,
-                         (int32_t)nb, w, dsec, derr);
-      for (int c = 0; c <= kLz4Classes; ++c) {
-        const int32_t cap = c < kLz4Classes ? kLz4ClassCapHost[c] : 0;
-        const size_t lds = cap ? (size_t)cap + 64 + (size_t)kLz4Map * 2 : 0;
-        const int64_t resident = 256ll * (lds ? (int64_t)(160 * 1024 / lds) : 16);  // waves the chip holds at this LDS size
-        const unsigned grid = (unsigned)(nb < resident ? nb : resident);
-        hipLaunchKernelGGL(lz4_exec_kernel, dim3(grid), dim3(64), lds, st, dby, (uint8_t*)d->d_bytes.p + area_base, (const Lz4Block*)d->lz4_blocks.p, (int32_t)nb, w, c, cap);
-      }
-    }
-    if (any_one_pass) {
-      const unsigned grid = (unsigned)(nb < 8192 ? nb : 8192);
-      const int32_t caps[3] = {16384, 32768, kLz4BlockMax};  // LDS per wave of the three launches
-      for (int c = 0; c < 3; ++c)
-        hipLaunchKernelGGL(lz4_block_kernel, dim3(grid), dim3(64), (size_t)caps[c], st, dby, (uint8_t*)d->d_bytes.p + area_base,
-                           (const Lz4Block*)d->lz4_blocks.p, nb, (int32_t*)d->lz4_sizes.p, c, caps[c], dsec, derr);
-    }
-    // (a frame that does not decode zeroes its section and raises the error cell: the push fails at its first
-    // synchronisation, before anything is committed)
-  }
-  // chain + parse + decode, one workgroup per batch: sections up to 20 KiB (the reference producer closes a batch at 16 KiB)
-  // out of 24 KiB of LDS, the rest out of 68 KiB or, beyond 64 KiB, in place
-  {
-    const EvjDevice* dt = d->json ? (const EvjDevice*)d->d_tmpl.p : nullptr;
-    const int64_t caps[2] = {20480, 65536};
-    for (int c = 0; c < 2; ++c) {
-      const size_t lds = (size_t)((caps[c] + 47) & ~15ll) + 2 * (size_t)kSecRecs * 4;
-      hipLaunchKernelGGL(section_kernel, dim3((unsigned)n_sections), dim3(kSecThreads), lds, st, dby, (const Section*)dsec, n_sections, c == 0 ? -1 : caps[0], caps[c],
-                         c == 1 ? 1 : 0, d->seed, dt, (const surge::F64ParseTable*)d->d_ptab.p, dmeta, (uint4*)d->ev_tmp.p, (uint32_t*)d->f64_list.p, derr);
-    }
-    DCHK(d, hipGetLastError());
-  }
-  return finish_push(d, n_rec, sections);
+  const int32_t rc = surge_device_decoder_push_async(d, bytes, sections, n_sections);
+  return rc != OK ? rc : surge_device_decoder_push_finish(d);
 }
 
 int32_t surge_device_decoder_push_records(surge_device_decoder* d, const uint8_t* keys, const int64_t* key_off, const uint8_t* values,
                                           const int64_t* value_off, const int64_t* offsets, int64_t n) {
   if (!d) return dfail(nullptr, E_INVALID, "decoder is NULL");
   if (n < 0 || (n > 0 && (!key_off || !value_off))) return dfail(d, E_INVALID, "bad argument");
+  if (d->n_pending != 0) return dfail(d, SURGE_E_STATE, "asynchronous pushes are pending: finish them first (results are appended in push order)");
   if (n == 0) return OK;
-  if (n >= (1ll << 32) - 1) return dfail(d, E_UNSUPPORTED, "more than 2^32 - 2 records in one push");
-  const int64_t kb = key_off[n] - key_off[0], vb = value_off[n] - value_off[0];
-  if (kb < 0 || vb < 0 || (kb > 0 && !keys) || (vb > 0 && !values)) return dfail(d, E_INVALID, "bad key / value spans");
-  int prev = 0;
-  (void)hipGetDevice(&prev);
-  struct Restore { int dev; ~Restore() { (void)hipSetDevice(dev); } } restore{prev};
-  DCHK(d, hipSetDevice(d->device));
-  hipStream_t st = d->stream;
-  const size_t n_bytes = (size_t)(kb + vb), off_bytes = (size_t)(n + 1) * 8;
-  const size_t stage = n_bytes + 2 * off_bytes + (offsets ? (size_t)n * 8 : 0) + 64;
-  DCHK(d, d->d_bytes.reserve(n_bytes + 16, false, st));
-  DCHK(d, d->rec_pos.reserve(off_bytes, false, st));  // reused as the device copies of key_off / value_off / offsets
-  DCHK(d, d->rec_end.reserve(off_bytes, false, st));
-  DCHK(d, d->d_sections.reserve((size_t)n * 8 + 8, false, st));
-  {
-    const int32_t rc = begin_push(d, n);
-    if (rc != OK) return rc;
+  int32_t rc = OK;
+  PushSlot* s = claim_slot(d, &rc);
+  if (!s) return rc;
+  DeviceScope scope(d->device);
+  rc = stage1_records(d, *s, keys, key_off, values, value_off, offsets, n);
+  if (rc != OK) {
+    (void)hipStreamSynchronize(s->stream);
+    return rc;
   }
-  if (stage > d->pinned_cap) {
-    if (d->pinned) (void)hipHostFree(d->pinned);
-    d->pinned = nullptr;
-    d->pinned_cap = 0;
-    DCHK(d, hipHostMalloc(&d->pinned, stage, hipHostMallocDefault));
-    d->pinned_cap = stage;
-  }
-  // pinned staging: [keys][values][key_off (rebased)][value_off (rebased)][offsets]
-  uint8_t* pin = (uint8_t*)d->pinned;
-  if (kb) std::memcpy(pin, keys + key_off[0], (size_t)kb);
-  if (vb) std::memcpy(pin + kb, values + value_off[0], (size_t)vb);
-  int64_t* p_ko = (int64_t*)(pin + ((n_bytes + 7) & ~(size_t)7));
-  int64_t* p_vo = p_ko + (n + 1);
-  int64_t* p_of = p_vo + (n + 1);
-  for (int64_t i = 0; i <= n; ++i) { p_ko[i] = key_off[i] - key_off[0]; p_vo[i] = value_off[i] - value_off[0]; }
-  for (int64_t i = 0; i < n; ++i)  // (the kernels index the staged bytes with these: no launch on offsets that run backwards)
-    if (p_ko[i + 1] < p_ko[i] || p_vo[i + 1] < p_vo[i]) return dfail(d, E_INVALID, "key_off / value_off must not decrease (record " + std::to_string(i) + ")");
-  if (offsets) std::memcpy(p_of, offsets, (size_t)n * 8);
-  if (n_bytes) DCHK(d, hipMemcpyAsync(d->d_bytes.p, pin, n_bytes, hipMemcpyHostToDevice, st));
-  DCHK(d, hipMemcpyAsync(d->rec_pos.p, p_ko, off_bytes, hipMemcpyHostToDevice, st));
-  DCHK(d, hipMemcpyAsync(d->rec_end.p, p_vo, off_bytes, hipMemcpyHostToDevice, st));
-  if (offsets) DCHK(d, hipMemcpyAsync(d->d_sections.p, p_of, (size_t)n * 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(records_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)d->d_bytes.p, (const int64_t*)d->rec_pos.p,
-                     (const int64_t*)d->rec_end.p, offsets ? (const int64_t*)d->d_sections.p : nullptr, kb, n, d->seed,
-                     d->json ? (const EvjDevice*)d->d_tmpl.p : nullptr, (const surge::F64ParseTable*)d->d_ptab.p, (RecMeta*)d->meta.p, (uint4*)d->ev_tmp.p,
-                     (uint32_t*)d->f64_list.p, (ErrorCell*)d->d_err.p);
-  return finish_push(d, n, nullptr);
+  rc = commit_slot(d, *s);
+  return rc != OK ? rc : finish_oldest(d);
 }
 
 int32_t surge_device_decoder_result(surge_device_decoder* d, int64_t* n_records, const int64_t** d_agg_idx, const void** d_events16,

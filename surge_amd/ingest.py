@@ -200,23 +200,28 @@ class FramedFetches:
     (``feed`` = batch headers, CRC-32C, ``read_committed`` — and the fetch itself, when ``fetches`` is a generator that
     polls) while the caller's thread keeps the device busy with the previous fetch (``DeviceDecoder.push`` + the
     fold).  One ``EventsTopicIngest`` in FRAMES mode does all the framing, so transactions and partial batches carry
-    from fetch to fetch; its two alternating arenas (``surge_ingest_drain_sections`` in ``surge_ingest.h``) are what
-    makes the overlap safe: the sections of fetch i stay where they are while fetch i + 1 is framed, and fetch i + 2 is
-    not started before the consumer has asked for fetch i + 1 (= is done with fetch i).
+    from fetch to fetch; its four rotating arenas (``surge_ingest_drain_sections`` in ``surge_ingest.h``) are what
+    makes the overlap safe: the sections of fetch i stay where they are while fetches i + 1 .. i + ``hold`` are framed,
+    and the next one is not started before the consumer has asked for fetch i + ``hold`` (= is done with fetch i).
+    ``hold`` (1 .. 3) is how many fetches the consumer keeps alive at a time: 1 for push-then-fold, 2 or 3 when it keeps
+    that many ``DeviceDecoder.push_async`` in flight.
 
     Iterating yields ``(sections, arena_address)`` per fetch, in order.  ``overlap=False`` frames inline (same results,
     one thread)."""
 
-    def __init__(self, fetches, isolation_level: int = READ_COMMITTED, device_lz4: bool = True, overlap: bool = True, threads: int = 1):
+    def __init__(self, fetches, isolation_level: int = READ_COMMITTED, device_lz4: bool = True, overlap: bool = True, threads: int = 1, hold: int = 1):
         import queue
         import threading
 
+        if not 1 <= hold <= 3:
+            raise ValueError("hold must be 1, 2 or 3 (the framer has four arenas)")
         self._g = EventsTopicIngest(isolation_level, frames=True, device_lz4=device_lz4, threads=threads)
         self._fetches = iter(fetches)
         self._overlap = overlap
+        self._hold = hold
         self.framing_seconds: List[float] = []
         self._q: "queue.Queue" = queue.Queue()
-        self._slots = threading.Semaphore(2)  # framed fetches alive at once: the one being read + the one being framed
+        self._slots = threading.Semaphore(hold + 1)  # framed fetches alive at once: the ones being read + the one being framed
         self._stop = False
         self._held = 0
         self._thread = threading.Thread(target=self._run, name="surge-framing", daemon=True) if overlap else None
@@ -250,7 +255,7 @@ class FramedFetches:
     def __next__(self):
         if not self._overlap:
             return self._frame(next(self._fetches))
-        if self._held:  # the consumer is done with the fetch it got last time: its arena may be framed into again
+        if self._held == self._hold:  # the consumer is done with the oldest fetch it holds: its arena may be framed into again
             self._held -= 1
             self._slots.release()
         item = self._q.get()
@@ -270,11 +275,102 @@ class FramedFetches:
     def close(self):
         self._stop = True
         if self._thread:
-            self._slots.release()
-            self._slots.release()
+            for _ in range(self._hold + 1):
+                self._slots.release()
             self._thread.join()
             self._thread = None
         self._g.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class PartitionedFramedFetches:
+    """The same one-fetch-ahead framing for a consumer that is assigned several partitions: ``fetches`` yields, per fetch
+    response, the next bytes of every partition (a sequence of ``bytes`` / ``None``, always in the same partition order).
+    One FRAMES ingest per partition — transactions, last stable offsets and cut batches are per partition
+    (``SurgeStateStoreConsumer.scala:33-46``: one restore consumer per task, ``isolation.level`` as configured) — framed side
+    by side on ``threads`` host threads (a partition's framer is touched by one thread at a time; the library calls release
+    the GIL).  Iterating yields, per fetch, the list of ``(sections, arena_address)`` parts of the partitions that had
+    something to deliver: ONE ``DeviceDecoder.push_async``.  ``hold`` as in :class:`FramedFetches`."""
+
+    def __init__(self, fetches, n_partitions: int, threads: int = 8, hold: int = 3, isolation_level: int = READ_COMMITTED, device_lz4: bool = True,
+                 overlap: bool = True):
+        import queue
+        import threading
+
+        if not 1 <= hold <= 3:
+            raise ValueError("hold must be 1, 2 or 3 (a framer has four arenas)")
+        self._g = [EventsTopicIngest(isolation_level, frames=True, device_lz4=device_lz4) for _ in range(n_partitions)]
+        self._lib = _native.load()
+        self._threads = max(1, min(threads, n_partitions))
+        self._n = n_partitions
+        self._handles = (ctypes.c_void_p * n_partitions)(*[g._h for g in self._g])
+        self._fetches = iter(fetches)
+        self._overlap, self._hold = overlap, hold
+        self.framing_seconds: List[float] = []
+        self._q: "queue.Queue" = queue.Queue()
+        self._slots = threading.Semaphore(hold + 1)
+        self._stop = False
+        self._held = 0
+        self._thread = threading.Thread(target=self._run, name="surge-framing-driver", daemon=True) if overlap else None
+        if self._thread:
+            self._thread.start()
+
+    def _frame(self, fetch):
+        """One library call per fetch (``surge_ingest_feed_drain_many``): the partitions' framers run on C++ threads, no
+        per-partition Python."""
+        import time
+
+        t0 = time.perf_counter()
+        n = self._n
+        bufs = []
+        for g, data in zip(self._g, fetch):  # a partition's cut batch from the last fetch goes in front (rare: whole batches are the rule)
+            data = data or b""
+            bufs.append(g._tail + bytes(data) if g._tail else (data if isinstance(data, bytes) else bytes(data)))
+        data_arr = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) if b else None for b in bufs])
+        len_arr = (ctypes.c_int64 * n)(*[len(b) for b in bufs])
+        max_sec = max(16, max((len(b) for b in bufs), default=0) // 61 + 16)  # a batch is at least its 61-byte header
+        secs = np.zeros((n, max_sec), dtype=SECTION_DTYPE)
+        sec_arr = (ctypes.c_void_p * n)(*[secs[p].ctypes.data for p in range(n)])
+        n_sec = (ctypes.c_int64 * n)()
+        arena = (ctypes.c_void_p * n)()
+        consumed = (ctypes.c_int64 * n)()
+        status = (ctypes.c_int32 * n)()
+        rc = self._lib.surge_ingest_feed_drain_many(self._handles, data_arr, len_arr, n, self._threads, max_sec, sec_arr, n_sec, arena, consumed, status)
+        for p, g in enumerate(self._g):  # also on failure: batches decoded before the failing one ARE queued
+            g._tail = bufs[p][consumed[p]:] if len_arr[p] else g._tail
+        if rc != 0:
+            bad = next(p for p in range(n) if status[p] != 0)
+            raise IngestError(status[bad], f"partition {bad}: " + (self._lib.surge_ingest_last_error(self._g[bad]._h) or b"").decode())
+        parts = [(secs[p, : n_sec[p]], int(arena[p] or 0)) for p in range(n) if n_sec[p] > 0]
+        self.framing_seconds.append(time.perf_counter() - t0)
+        return parts
+
+    _run = FramedFetches._run
+    __iter__ = FramedFetches.__iter__
+    __next__ = FramedFetches.__next__
+
+    def counters(self) -> dict:
+        """The partitions' ingest counters, summed; call it when the iteration has ended."""
+        out: dict = {}
+        for g in self._g:
+            for k, v in g.counters().items():
+                out[k] = out.get(k, 0) + v
+        return out
+
+    def close(self):
+        self._stop = True
+        if self._thread:
+            for _ in range(self._hold + 1):
+                self._slots.release()
+            self._thread.join()
+            self._thread = None
+        for g in self._g:
+            g.close()
 
     def __enter__(self):
         return self
@@ -315,6 +411,33 @@ class DeviceDecoder:
         sections = np.ascontiguousarray(sections, dtype=SECTION_DTYPE)
         self._check(self._lib.surge_device_decoder_push(self._h, ctypes.c_void_p(arena_address), sections.ctypes.data_as(ctypes.c_void_p),
                                                         sections.shape[0]))
+
+    def push_async(self, parts) -> None:
+        """Stage 1 of a push — copy, LZ4, record parsing, value decode — enqueued on a stream of its own; ``parts`` is one
+        ``(sections, arena_address)`` pair or a list of them (e.g. one per partition of a fetch response: one push, records
+        delivered part after part).  The arenas must stay as they are until the matching ``finish()``; up to three pushes
+        may be in flight."""
+        if isinstance(parts, tuple):
+            parts = [parts]
+        secs = [np.ascontiguousarray(s, dtype=SECTION_DTYPE) for s, _ in parts]
+        n = len(parts)
+        bytes_arr = (ctypes.c_void_p * n)(*[ctypes.c_void_p(a) for _, a in parts])
+        secs_arr = (ctypes.c_void_p * n)(*[s.ctypes.data_as(ctypes.c_void_p) for s in secs])
+        cnt = (ctypes.c_int64 * n)(*[s.shape[0] for s in secs])
+        self._check(self._lib.surge_device_decoder_push_parts_async(self._h, n, bytes_arr, secs_arr, cnt))
+        self._inflight = getattr(self, "_inflight", [])
+        self._inflight.append((secs, bytes_arr, secs_arr, cnt))  # the section arrays are read until finish()
+
+    def finish(self) -> None:
+        """Stage 2 of the oldest unfinished push: key interning, append to the result (``result()``)."""
+        rc = self._lib.surge_device_decoder_push_finish(self._h)
+        if getattr(self, "_inflight", None):
+            self._inflight.pop(0)
+        self._check(rc)
+
+    @property
+    def pending(self) -> int:
+        return int(self._lib.surge_device_decoder_pending(self._h))
 
     def push_records(self, keys: List[bytes], values: List[bytes], offsets=None) -> None:
         """Records that are already framed (a consumer's key / value byte arrays), in bulk."""

@@ -121,29 +121,53 @@ class GpuReplayStateStore:
         self._restored = True
         return counters
 
-    def restore_from_fetches(self, fetches, capacity: int = 0, overlap: bool = True) -> dict:
+    def restore_from_fetches(self, fetches, capacity: int = 0, overlap: bool = True, n_partitions: int = 0, framing_threads: int = 8) -> dict:
         """Recover from the events topic as a consumer receives it: ``fetches`` yields the record-batch bytes of one
-        partition, fetch by fetch, in offset order (a list, or a generator that polls).  The host frames fetch i + 1
-        (headers, CRC-32C, transactions — ``FramedFetches``) while the GPU decodes, groups and folds fetch i
-        (``surge_device_decoder`` -> the K3 group-by -> the fold onto the resident state), so neither waits for the
-        other; the resident state and the device key table grow as new aggregates appear.  What
+        partition, fetch by fetch, in offset order (a list, or a generator that polls) — or, with ``n_partitions``, per
+        fetch response the next bytes of each of the consumer's partitions (``PartitionedFramedFetches``: one framer per
+        partition on ``framing_threads`` host threads, one device push per fetch).  The host frames the next fetches
+        (headers, CRC-32C, transactions) while the GPU works on up to three earlier ones: their copy, LZ4 blocks, record
+        parsing and value decode (``DeviceDecoder.push_async``) run ahead of the one whose keys are being interned and
+        whose events are grouped and folded onto the resident state (the K3 path), so neither side waits for the other;
+        the resident state and the device key table grow as new aggregates appear.  What
         ``SurgeStateStoreConsumer.scala:33-46,57-76`` does record by record through Kafka Streams' restore.
         Needs values the device decoder reads (16-byte fixed events, or JSON with the model's
         ``event_json_template``); returns the ingest + decoder counters."""
-        from .ingest import DeviceDecoder, FramedFetches
+        from .ingest import DeviceDecoder, FramedFetches, PartitionedFramedFetches
         from .log import KeyTable
         from .schema import EVENT_DTYPE
 
         template = self.model.event_json_template()
         d = None
         n_agg = -1
+        depth = 3 if overlap else 1  # pushes in flight: stage 1 of the next fetches runs while this one is interned and folded
+        pending = 0
+
+        def finish_one():
+            nonlocal n_agg
+            d.finish()
+            agg_idx, events, _, n_keys = d.result()
+            if n_keys > n_agg:
+                self.engine.grow(n_keys)
+                n_agg = n_keys
+            if agg_idx.shape[0]:
+                self.engine.append_events(agg_idx, events)  # device arrays straight into the device group-by
+                self.engine.synchronize()  # the arrays are the decoder's: done with them before the next finish
+            d.clear()
+
         try:
-            with FramedFetches(fetches, overlap=overlap) as framed:
-                for sections, arena in framed:
-                    if not sections.shape[0]:
+            framer = (PartitionedFramedFetches(fetches, n_partitions, threads=framing_threads, hold=depth, overlap=overlap) if n_partitions
+                      else FramedFetches(fetches, overlap=overlap, hold=depth))
+            with framer as framed:
+                for item in framed:
+                    parts = item if isinstance(item, list) else [item]
+                    parts = [(sec, arena) for sec, arena in parts if sec.shape[0]]
+                    if not parts:
                         continue
                     if d is None:
-                        kind = _sniff_value_kind(sections, arena)  # "fixed16", "json" or None (no deliverable record)
+                        kind = None
+                        for sec, arena in parts:
+                            kind = kind or _sniff_value_kind(sec, arena)  # "fixed16", "json" or None (no deliverable record)
                         if kind == "json" and template is None:
                             raise _NotDeviceDecodable("JSON event values need the model's event_json_template")
                         d = DeviceDecoder(template if kind == "json" else None, device=self.engine.device)
@@ -151,15 +175,14 @@ class GpuReplayStateStore:
                         n_agg = capacity
                         self.engine.load_csr(np.zeros(n_agg + 1, dtype=np.int64), np.zeros(0, dtype=EVENT_DTYPE))
                         self.engine.fold()  # every aggregate None
-                    d.push(sections, arena)
-                    agg_idx, events, _, n_keys = d.result()
-                    if n_keys > n_agg:
-                        self.engine.grow(n_keys)
-                        n_agg = n_keys
-                    if agg_idx.shape[0]:
-                        self.engine.append_events(agg_idx, events)  # device arrays straight into the device group-by
-                        self.engine.synchronize()  # the arrays are the decoder's: done with them before the next push
-                    d.clear()
+                    if pending == depth:
+                        finish_one()
+                        pending -= 1
+                    d.push_async(parts)
+                    pending += 1
+                while pending:
+                    finish_one()
+                    pending -= 1
                 counters = framed.counters()
             if n_agg < 0:  # nothing deliverable in the whole topic
                 n_agg = capacity

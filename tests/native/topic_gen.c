@@ -1,0 +1,61 @@
+/* TEST / BENCH INFRASTRUCTURE (not part of the product): the events topic's record keys and values for the Counter
+ * fixture, in bulk — what `CounterEventFormat.write_event` (examples/fixture_models.py, restating
+ * TestBoundedContext.scala:42-49,122-124) writes per event, for arrays of (aggregate number, type, argument, sequence
+ * number).  bench.py --workload e2e and tests/test_bench_rehearsal.py synthesise topics of 10^8 records with it; a
+ * sample of its output is compared with write_event byte for byte wherever it is used.
+ *   key   = "acct-%08d:<seq>"
+ *   value = {"aggregateId":"acct-%08d","incrementBy":<arg>,"sequenceNumber":<seq>,"_type":"countIncremented"}   type 0
+ *           {"aggregateId":"acct-%08d","decrementBy":<arg>,"sequenceNumber":<seq>,"_type":"countDecremented"}   type 1
+ *           {"aggregateId":"acct-%08d","sequenceNumber":<seq>,"_type":"no-op"}                                   type 2
+ * gcc -O2 -shared -fPIC tests/native/topic_gen.c -o tests/native/libtopic_gen.so */
+#include <stdint.h>
+#include <string.h>
+
+static uint8_t* put(uint8_t* p, const char* s) {
+  const size_t n = strlen(s);
+  memcpy(p, s, n);
+  return p + n;
+}
+static uint8_t* put_u(uint8_t* p, uint64_t v) {
+  char tmp[24];
+  int n = 0;
+  do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+  while (n) *p++ = (uint8_t)tmp[--n];
+  return p;
+}
+static uint8_t* put_i(uint8_t* p, int64_t v) {
+  if (v < 0) { *p++ = '-'; return put_u(p, (uint64_t)(-v)); }
+  return put_u(p, (uint64_t)v);
+}
+static uint8_t* put_id(uint8_t* p, int64_t agg) {
+  p = put(p, "acct-");
+  for (int k = 7; k >= 0; --k) { p[k] = (uint8_t)('0' + agg % 10); agg /= 10; }
+  return p + 8;
+}
+
+/* keys / vals need 40 / 128 bytes per record at most; key_off / val_off have n + 1 entries.  Returns n. */
+int64_t surge_test_counter_records(int64_t n, const int64_t* agg, const int32_t* type, const int32_t* arg, const int32_t* seq, uint8_t* keys,
+                                   int64_t* key_off, uint8_t* vals, int64_t* val_off) {
+  uint8_t* k = keys;
+  uint8_t* v = vals;
+  key_off[0] = 0;
+  val_off[0] = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    k = put_id(k, agg[i]);
+    *k++ = ':';
+    k = put_i(k, seq[i]);
+    key_off[i + 1] = k - keys;
+    v = put(v, "{\"aggregateId\":\"");
+    v = put_id(v, agg[i]);
+    v = put(v, "\",");
+    if (type[i] == 0) { v = put(v, "\"incrementBy\":"); v = put_i(v, arg[i]); *v++ = ','; }
+    if (type[i] == 1) { v = put(v, "\"decrementBy\":"); v = put_i(v, arg[i]); *v++ = ','; }
+    v = put(v, "\"sequenceNumber\":");
+    v = put_i(v, seq[i]);
+    v = put(v, ",\"_type\":\"");
+    v = put(v, type[i] == 0 ? "countIncremented" : type[i] == 1 ? "countDecremented" : "no-op");
+    v = put(v, "\"}");
+    val_off[i + 1] = v - vals;
+  }
+  return n;
+}

@@ -91,12 +91,33 @@ def test_bench_workload_v2_reports_four_variants_of_the_same_device_code_and_ful
 
 
 @pytest.mark.gpu
-def test_bench_workload_e2e_goes_from_topic_bytes_to_states_and_checks_them():
-    n = 140 * 143  # whole 16 KiB batches of 140 play-json records (bench.py cuts a fetch to a multiple of the batch)
-    d = run_single(["--workload", "e2e", "--batch-events", str(n), "--steps", "3", "--warmup", "1"])
+@pytest.mark.parametrize("extra", [[], ["--serial-framing"], ["--codec", "none"]])
+def test_bench_workload_e2e_goes_from_topic_bytes_to_states_and_checks_them_against_the_source_events(extra):
+    """The C3-shaped topic at a small size: 30 000 aggregates over 64 partitions, lz4 batches of 16 KiB, fetches of 20 000
+    records framed per partition on host threads, one device push per fetch (three in flight), states compared with the
+    oracle's fold of the events the GENERATOR published — not of what the device decoded."""
+    d = run_single(["--workload", "e2e", "--aggregates", "30000", "--batch-events", "20000", "--warmup", "1", "--framing-threads", "4"] + extra)
     cfg = d["config"]
-    assert cfg["fetch_records"] == n and cfg["decoder_counters"]["records_delivered"] == n * 4 and cfg["aggregates_seen"] > 1000
-    assert d["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_decoded_events"] is True and d["value"] > 0
+    assert cfg["fetch_records"] == 20000 and cfg["partitions"] == 64 and cfg["keys_interned"] == 30000
+    assert cfg["decoder"]["records_delivered"] == cfg["ingest"]["records_delivered"] == cfg["events_timed"] + 20000  # + the warm-up fetch
+    assert cfg["pushes_in_flight"] == (1 if "--serial-framing" in extra else 3) and cfg["decoder"]["hash_reseeds"] == 0
+    assert d["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_source_events"] is True and d["value"] > 0 and d["n_gpus"] == 1
+    assert abs(d["value"] - cfg["events_timed"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_workload_e2e_shards_the_ingest_by_partition_over_the_ranks(tmp_path, world):
+    """`--workload e2e --gpus N` — every rank frames and decodes the partitions p % N == rank, folds its
+    shard, and the final snapshot is all-gathered through the C ABI (here over the stub transport, all ranks on one GPU):
+    one line with n_gpus = N, per-rank records, every rank's shard equal to the oracle's fold of its source events, every
+    block of the gathered snapshot equal to its owner's shard."""
+    d = run_bench(tmp_path, ["--workload", "e2e", "--aggregates", "40000", "--batch-events", "8000", "--framing-threads", "2"], world=world)
+    cfg = d["config"]
+    assert d["n_gpus"] == world and len(cfg["per_rank_events"]) == world and min(cfg["per_rank_events"]) > 0
+    assert sum(cfg["per_rank_events"]) == cfg["events_timed"] and cfg["keys_interned"] == 40000 == cfg["gathered_aggregates"]
+    assert cfg["snapshot_exchange_ms"] > 0 and f"p % {world} == rank" in cfg["parallelism"]
+    assert d["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_source_events"] is True and "REHEARSAL" in cfg["workload"]
 
 
 @pytest.mark.gpu

@@ -573,33 +573,103 @@ def _section_bytes(sections, arena):
     return [ctypes.string_at(arena + int(s["byte_off"]), int(s["byte_len"])) for s in sections]
 
 
-def test_frames_mode_alternates_two_arenas_so_the_next_feed_leaves_the_drained_sections_alone():
-    """What lets one thread frame fetch i + 1 while a device decoder still reads fetch i (surge_ingest.h,
-    surge_ingest_drain_sections): a drained section stays byte-identical, at the same address, through the NEXT feed — and
-    batches that are still queued at a feed (an open transaction) travel to the new arena."""
+def test_frames_mode_rotates_four_arenas_so_the_next_three_feeds_leave_the_drained_sections_alone():
+    """What lets host threads frame fetches i + 1 .. i + 3 while the device decoder's pushes of fetch i .. i + 2 are still in
+    flight (surge_ingest.h, surge_ingest_drain_sections): a drained section stays byte-identical, at the same address,
+    through the next THREE feeds — and batches that are still queued at a feed (an open transaction) travel to the new arena."""
     ev = lambda seq: counter_event(S.EVT_INC, seq, seq)
     batch = lambda off, key, n, **kw_: kw.record_batch(off, [(key, ev(off + i + 1)) for i in range(n)], **kw_)
-    a, b, c = batch(0, b"a:1", 300), batch(300, b"b:1", 200), batch(500, b"c:1", 5000)
+    a, b, c, d4, e5 = batch(0, b"a:1", 300), batch(300, b"b:1", 200), batch(500, b"c:1", 5000), batch(5500, b"d:1", 7), batch(5507, b"e:1", 900)
     with EventsTopicIngest(frames=True) as g:
         g.feed(a)
         sa, arena_a = g.drain_sections()
         assert _section_bytes(sa, arena_a) == [a[61:]]
-        g.feed(b)  # fills the other arena
+        g.feed(b)  # fills the next arena
         sb, arena_b = g.drain_sections()
         assert arena_b != arena_a and _section_bytes(sa, arena_a) == [a[61:]] and _section_bytes(sb, arena_b) == [b[61:]]
-        g.feed(c)  # back in the first arena (grown for the larger fetch): b's spans are the ones that survive now
+        g.feed(c)
         sc, arena_c = g.drain_sections()
-        assert _section_bytes(sb, arena_b) == [b[61:]] and _section_bytes(sc, arena_c) == [c[61:]]
+        g.feed(d4)
+        sd, arena_d = g.drain_sections()
+        assert len({arena_a, arena_b, arena_c, arena_d}) == 4
+        assert [_section_bytes(x, y) for x, y in ((sa, arena_a), (sb, arena_b), (sc, arena_c), (sd, arena_d))] == [[a[61:]], [b[61:]], [c[61:]], [d4[61:]]]
+        g.feed(e5)  # the fifth feed is back in the first arena: a's spans are gone, the other three survive
+        se, arena_e = g.drain_sections()
+        assert [_section_bytes(x, y) for x, y in ((sb, arena_b), (sc, arena_c), (sd, arena_d), (se, arena_e))] == [[b[61:]], [c[61:]], [d4[61:]], [e5[61:]]]
         # an open transaction is carried from arena to arena until its marker arrives
-        t = batch(5500, b"t:1", 40, transactional=True, producer_id=3)
+        t = batch(6500, b"t:1", 40, transactional=True, producer_id=3)
         g.feed(t)
         assert g.drain_sections()[0].shape[0] == 0
-        g.feed(batch(5540, b"d:1", 10))  # behind the open transaction: not deliverable either
+        g.feed(batch(6540, b"d:1", 10))  # behind the open transaction: not deliverable either
         assert g.drain_sections()[0].shape[0] == 0 and g.counters()["open_transactions"] == 1
-        g.feed(kw.control_batch(5550, 3, kw.COMMIT))
+        g.feed(kw.control_batch(6550, 3, kw.COMMIT))
         st, arena_t = g.drain_sections()
-        assert [int(s["base_offset"]) for s in st] == [5500, 5540]
-        assert _section_bytes(st, arena_t) == [t[61:], batch(5540, b"d:1", 10)[61:]]
+        assert [int(s["base_offset"]) for s in st] == [6500, 6540]
+        assert _section_bytes(st, arena_t) == [t[61:], batch(6540, b"d:1", 10)[61:]]
+
+
+def test_partitioned_framed_fetches_frame_every_partition_like_its_own_framer_and_keep_three_fetches_alive():
+    """surge_ingest_feed_drain_many behind PartitionedFramedFetches: a consumer's fetch responses over several partitions,
+    framed on C++ threads (one framer per partition), yield per fetch the same sections each partition's own framer
+    yields — transactions per partition, a cut batch completed by the next fetch, partitions with nothing in a fetch —
+    and with hold = 3 the sections of three consecutive fetches are intact at the same time."""
+    from surge_amd.ingest import PartitionedFramedFetches
+
+    ev = lambda seq: counter_event(S.EVT_INC, seq, seq)
+    rnd = random.Random(9)
+    P, F = 5, 9
+    logs = []
+    for p in range(P):  # a partition's log: batches, some transactional (committed / aborted / committed a fetch later)
+        chunks, off, pid = [], 0, 100 * p
+        for f in range(F):
+            parts = []
+            for b in range(rnd.randrange(0, 4)):
+                n = rnd.randrange(1, 200)
+                txn = rnd.random() < 0.4
+                parts.append(kw.record_batch(off, [(b"k%d:%d" % (rnd.randrange(30), i), ev(off + i + 1)) for i in range(n)], compression=rnd.choice(["none", "lz4"]),
+                                             transactional=txn, producer_id=pid if txn else -1))
+                off += n
+                if txn:
+                    parts.append(kw.control_batch(off, pid, kw.COMMIT if rnd.random() < 0.7 else kw.ABORT))
+                    off += 1
+                    pid += 1
+            chunks.append(b"".join(parts))
+        logs.append(chunks)
+    cut = len(logs[2][3]) // 2  # partition 2's fourth fetch ends in the middle of a batch
+    logs[2][3], logs[2][4] = logs[2][3][:cut], logs[2][3][cut:] + logs[2][4]
+    fetches = [[logs[p][f] or None for p in range(P)] for f in range(F)]
+    want = []  # per fetch, per partition: what that partition's own framer delivers
+    singles = [EventsTopicIngest(frames=True, device_lz4=True) for _ in range(P)]
+    try:
+        for f in range(F):
+            row = []
+            for p in range(P):
+                if fetches[f][p]:
+                    singles[p].feed(fetches[f][p])
+                sec, arena = singles[p].drain_sections()
+                if sec.shape[0]:
+                    row.append([(int(s["base_offset"]), int(s["n_records"]), int(s["codec"]), b) for s, b in zip(sec, _section_bytes(sec, arena))])
+            want.append(row)
+        want_counters = {}
+        for g in singles:
+            for k, v in g.counters().items():
+                want_counters[k] = want_counters.get(k, 0) + v
+    finally:
+        for g in singles:
+            g.close()
+    for overlap in (False, True):
+        alive, got = [], []
+        with PartitionedFramedFetches(iter(fetches), P, threads=3, hold=3, overlap=overlap) as framed:
+            for parts in framed:
+                alive.append(parts)
+                if len(alive) > 3:
+                    alive.pop(0)
+                # everything still alive reads back unchanged while the framer is (up to) a fetch ahead
+                snap = [[[(int(s["base_offset"]), int(s["n_records"]), int(s["codec"]), b) for s, b in zip(sec, _section_bytes(sec, arena))] for sec, arena in pp] for pp in alive]
+                got.append(snap[-1])
+                assert snap == want[len(got) - len(alive): len(got)]
+            assert framed.counters() == want_counters
+        assert got == want
 
 
 def test_framed_fetches_yield_the_same_sections_one_fetch_ahead_as_inline():
