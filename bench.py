@@ -902,7 +902,7 @@ def run_e2e(args):
         raise SystemExit(f"--workload e2e: the topic holds {len(fetches)} fetch(es): nothing to time behind {W} warm-up fetch(es)")
 
     # ---- the run --------------------------------------------------------------------------------------------------------
-    marks, dev_ms, keys_at = [], [], []
+    marks, dev_ms, keys_at, push_ms = [], [], [], []
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -934,7 +934,9 @@ def run_e2e(args):
             if len(pending) == depth:
                 finish_one()
                 pending.pop(0)
+            tp = time.perf_counter()
             d.push_async(parts)
+            push_ms.append((time.perf_counter() - tp) * 1e3)
             pending.append(1)
         while pending:
             finish_one()
@@ -1058,6 +1060,7 @@ def run_e2e(args):
                    "wire_bytes_per_record": total_wire / max(1, int(totals[4].item())),
                    "fetch_ms": {"p50": float(np.percentile(lat, 50)), "p90": float(np.percentile(lat, 90)), "max": float(np.max(lat))},
                    "host_framing_ms_per_fetch": float(np.mean(host_ms[W:])), "finish_and_fold_ms_per_fetch": float(np.mean(dev_ms[W:])),
+                   "push_async_host_ms_per_fetch": float(np.mean(push_ms[W:])),
                    "events_per_s_while_discovering_keys": rate(disc), "events_per_s_all_keys_known": rate(steady),
                    "decoder": stats, "ingest": ingest_counters, "generate_s": gen_s, "parity_s": parity_s,
                    "snapshot_exchange_ms": exchange, "gathered_aggregates": gathered_aggregates},

@@ -151,16 +151,26 @@ typedef struct surge_batch_section {
  * the new arena with it. */
 int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge_batch_section* out, int64_t* n_out);
 
-/* A consumer that is assigned several partitions gets, per fetch response, the next bytes of each of them: one FRAMES
- * handle per partition (transactions, last stable offsets and cut batches are per partition), fed and drained side by
- * side on up to `threads` host threads (a handle is touched by one thread): for p in [0, n) feed(g[p], data[p], len[p])
- * — skipped when len[p] is 0 — then drain_sections(g[p], max_sections_each, sections_out[p], &n_sections_out[p]) and
- * arena_out[p] = surge_ingest_arena(g[p]); consumed_out (nullable) as surge_ingest_feed reports it; status_out[p] =
- * partition p's status (its message: surge_ingest_last_error(g[p])).  Returns the first non-zero status, or 0.  What
- * it is for: the n parts of ONE surge_device_decoder_push_parts_async. */
-int32_t surge_ingest_feed_drain_many(surge_ingest* const* g, const uint8_t* const* data, const int64_t* len, int32_t n, int32_t threads,
-                                     int64_t max_sections_each, surge_batch_section* const* sections_out, int64_t* n_sections_out,
-                                     const uint8_t** arena_out, int64_t* consumed_out, int32_t* status_out);
+/* A consumer that is assigned several partitions gets, per fetch response, the next bytes of each of them; transactions,
+ * last stable offsets and cut batches are per partition, so each partition needs a framer of its own.  A group owns n
+ * FRAMES handles and, instead of an arena per handle, four rotating SLABS; a feed lays partition 0's records sections,
+ * then partition 1's ... out in the next slab (every partition's slice is sized for the feed up front; batches a
+ * partition still holds — open transactions — move along), so what comes back is one array of sections, partition after
+ * partition, whose spans index one buffer: one part of surge_device_decoder_push_parts_async, one host-to-device copy.
+ * A slab stays as it is through the next three feeds.  data[p] / len[p]: partition p's bytes of this fetch response (len
+ * 0: nothing, the partition is only carried along); consumed_out (nullable, n entries); sections_out holds up to
+ * max_sections entries (the total of len[] / 61 + n is always enough).  SURGE_INGEST_DEVICE_LZ4 / isolation level as in
+ * surge_ingest_create (FRAMES is implied).  Returns the first failing partition's status (its message in
+ * surge_ingest_group_last_error); the sections of the partitions that did not fail are delivered all the same. */
+typedef struct surge_ingest_group surge_ingest_group;
+int32_t surge_ingest_group_create(int32_t n_partitions, int32_t isolation_level, surge_ingest_group** out);
+int32_t surge_ingest_group_destroy(surge_ingest_group* g);
+const char* surge_ingest_group_last_error(const surge_ingest_group* g);
+int32_t surge_ingest_group_feed(surge_ingest_group* g, const uint8_t* const* data, const int64_t* len, int32_t threads, int64_t* consumed_out,
+                                int64_t max_sections, surge_batch_section* sections_out, int64_t* n_sections_out, const uint8_t** slab_out);
+int32_t surge_ingest_group_counters(const surge_ingest_group* g, int64_t out[8]); /* surge_ingest_counters, summed */
+int32_t surge_ingest_group_set_allocator(surge_ingest_group* g, void* (*alloc)(size_t), void (*release)(void*));
+int32_t surge_ingest_group_use_pinned_slabs(surge_ingest_group* g); /* page-locked slabs (SURGE_E_DEVICE without a HIP runtime) */
 
 /* Where the arena's memory comes from (before the first feed; NULL / NULL = malloc / free).  surge_ingest_use_pinned_arena
  * makes it page-locked host memory of the HIP runtime: a device decoder then copies the sections to the GPU straight out

@@ -96,7 +96,13 @@ INGEST_EXPORTS = (
     "surge_ingest_drain_fixed16",
     "surge_ingest_drain_json",
     "surge_ingest_drain_sections",
-    "surge_ingest_feed_drain_many",
+    "surge_ingest_group_create",
+    "surge_ingest_group_destroy",
+    "surge_ingest_group_last_error",
+    "surge_ingest_group_feed",
+    "surge_ingest_group_counters",
+    "surge_ingest_group_set_allocator",
+    "surge_ingest_group_use_pinned_slabs",
     "surge_ingest_set_allocator",
     "surge_ingest_use_pinned_arena",
     "surge_device_decoder_create",
@@ -308,7 +314,13 @@ def load() -> ctypes.CDLL:
         "surge_ingest_drain_fixed16": ([vp, i64, vp, vp, vp, ctypes.POINTER(i64)], i32),
         "surge_ingest_drain_json": ([vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)], i32),
         "surge_ingest_drain_sections": ([vp, i64, vp, ctypes.POINTER(i64)], i32),
-        "surge_ingest_feed_drain_many": ([vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp], i32),
+        "surge_ingest_group_create": ([i32, i32, ctypes.POINTER(vp)], i32),
+        "surge_ingest_group_destroy": ([vp], i32),
+        "surge_ingest_group_last_error": ([vp], ctypes.c_char_p),
+        "surge_ingest_group_feed": ([vp, vp, vp, i32, vp, i64, vp, ctypes.POINTER(i64), ctypes.POINTER(vp)], i32),
+        "surge_ingest_group_counters": ([vp, ctypes.POINTER(i64 * 8)], i32),
+        "surge_ingest_group_set_allocator": ([vp, vp, vp], i32),
+        "surge_ingest_group_use_pinned_slabs": ([vp], i32),
         "surge_ingest_set_allocator": ([vp, vp, vp], i32),
         "surge_ingest_use_pinned_arena": ([vp], i32),
         "surge_device_decoder_create": ([i32, vp, vp, ctypes.POINTER(vp)], i32),

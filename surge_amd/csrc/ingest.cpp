@@ -203,14 +203,32 @@ struct Arena {
   size_t n = 0, cap = 0;
   void* (*alloc)(size_t) = nullptr;
   void (*release)(void*) = nullptr;
+  bool external = false;  // a view into memory someone else owns (a slice of a surge_ingest_group's slab): never grown, never freed
   Arena() = default;
   Arena(const Arena&) = delete;
   Arena& operator=(const Arena&) = delete;
   ~Arena() { drop(); }
   void drop() {
-    if (p) (release ? release : std::free)(p);
+    if (p && !external) (release ? release : std::free)(p);
     p = nullptr;
     n = cap = 0;
+  }
+  void view(uint8_t* at, size_t bytes) {
+    external = true;
+    p = at;
+    cap = bytes;
+    n = 0;
+  }
+  void reserve(size_t want) {  // an EMPTY arena gets room for `want` bytes in one allocation
+    if (want <= cap) return;
+    size_t c = cap ? cap : (size_t)1 << 16;
+    while (c < want) c += c / 2 + 4096;
+    uint8_t* fresh = (uint8_t*)(alloc ? alloc(c) : std::malloc(c));
+    if (!fresh) throw std::bad_alloc();
+    if (n) std::memcpy(fresh, p, n);
+    if (p) (release ? release : std::free)(p);
+    p = fresh;
+    cap = c;
   }
   size_t size() const { return n; }
   const uint8_t* data() const { return p; }
@@ -218,6 +236,7 @@ struct Arena {
   void clear() { n = 0; }
   void append(const uint8_t* src, size_t len) {
     if (n + len > cap) {
+      if (external) throw std::bad_alloc();  // (a group sizes its members' slices for the whole feed: cannot happen)
       size_t want = cap ? cap * 2 : (size_t)1 << 16;
       while (want < n + len) want *= 2;
       uint8_t* fresh = (uint8_t*)(alloc ? alloc(want) : std::malloc(want));
@@ -246,8 +265,13 @@ struct surge_ingest {
   int cur = 0;
   bool handed_out = false;  // a drain has handed out spans of arenas[cur] since the last switch
   int crc_threads = 1;      // surge_ingest_set_threads: host threads that verify the batches' CRC-32C of one feed
-  Arena& arena_now() { return arenas[cur]; }
-  const Arena& arena_now() const { return arenas[cur]; }
+  // a member of a surge_ingest_group frames every feed into the slice of the group's slab it is given for that feed
+  bool grouped = false;
+  Arena ext[kArenas];
+  uint8_t* ext_next = nullptr;
+  size_t ext_next_cap = 0;
+  Arena& arena_now() { return grouped ? ext[cur] : arenas[cur]; }
+  const Arena& arena_now() const { return grouped ? ext[cur] : arenas[cur]; }
   std::deque<Batch> queue;
   std::vector<std::string> keys;   // aggregate ids in first-seen order
   std::vector<uint64_t> key_hash;  // their hashes
@@ -526,14 +550,19 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
   if (!g) return fail(nullptr, E_INVALID, "handle is NULL");
   if (len < 0 || (!data && len > 0)) return fail(g, E_INVALID, "bad buffer");
   if (consumed_out) *consumed_out = 0;
-  if (g->frames && g->handed_out) {
+  if (g->frames && (g->handed_out || g->grouped)) {
     // switch arenas: the sections still queued (open transactions, undrained batches) move along, the ones the last
     // drain handed out stay untouched in the arena this feed leaves behind (valid through the three feeds after it).  A feed
     // that follows no drain keeps appending where the last one stopped: nothing is copied.
     try {
-      Arena& next = g->arenas[(g->cur + 1) % surge_ingest::kArenas];
-      const Arena& prev = g->arenas[g->cur];
-      next.clear();
+      Arena& next = g->grouped ? g->ext[(g->cur + 1) % surge_ingest::kArenas] : g->arenas[(g->cur + 1) % surge_ingest::kArenas];
+      const Arena& prev = g->arena_now();
+      if (g->grouped) next.view(g->ext_next, g->ext_next_cap); else next.clear();
+      if (!g->grouped) {  // room for the whole feed at once: a page-locked arena that doubles its way up costs an allocation per step
+        size_t queued = 0;
+        for (const Batch& qb : g->queue) queued += qb.sect_off >= 0 ? (size_t)qb.sect_len : 0;
+        next.reserve(queued + (size_t)len);
+      }
       for (Batch& qb : g->queue) {
         if (qb.sect_off < 0) continue;
         const int64_t at = (int64_t)next.size();
@@ -804,33 +833,121 @@ int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge
   return OK;
 }
 
-// One fetch response of a consumer with several partitions: feed + drain of every partition's framer, side by side.
-int32_t surge_ingest_feed_drain_many(surge_ingest* const* g, const uint8_t* const* data, const int64_t* len, int32_t n, int32_t threads,
-                                     int64_t max_sections_each, surge_batch_section* const* sections_out, int64_t* n_sections_out,
-                                     const uint8_t** arena_out, int64_t* consumed_out, int32_t* status_out) {
-  if (n < 0 || (n > 0 && (!g || !data || !len || !sections_out || !n_sections_out || !arena_out || !status_out)) || max_sections_each < 0)
-    return fail(nullptr, E_INVALID, "bad argument");
+}  // extern "C" (the group's type)
+
+// A consumer's partitions framed as ONE unit: every feed lays the partitions' records sections out in one slab — the
+// group rotates through four, like a single framer's arenas — so a fetch response reaches the device in one copy.
+struct surge_ingest_group {
+  std::vector<surge_ingest*> g;
+  Arena slabs[surge_ingest::kArenas];
+  int cur = 0;
+  std::string err;
+  std::vector<std::vector<surge_batch_section>> drained;
+  std::vector<int64_t> off;
+  ~surge_ingest_group() {
+    for (surge_ingest* x : g) delete x;
+  }
+};
+
+extern "C" {
+
+int32_t surge_ingest_group_create(int32_t n_partitions, int32_t isolation_level, surge_ingest_group** out) {
+  if (!out) return fail(nullptr, E_INVALID, "out is NULL");
+  *out = nullptr;
+  if (n_partitions < 1 || n_partitions > (1 << 20)) return fail(nullptr, E_INVALID, "n_partitions out of range");
+  surge_ingest_group* grp = new (std::nothrow) surge_ingest_group();
+  if (!grp) return fail(nullptr, E_NOMEM, "out of host memory");
+  try {
+    grp->g.reserve((size_t)n_partitions);
+    grp->drained.resize((size_t)n_partitions);
+    grp->off.resize((size_t)n_partitions + 1);
+    for (int32_t p = 0; p < n_partitions; ++p) {
+      surge_ingest* x = nullptr;
+      const int32_t rc = surge_ingest_create(isolation_level | SURGE_INGEST_FRAMES, &x);
+      if (rc != OK) {
+        delete grp;
+        return rc;
+      }
+      x->grouped = true;
+      grp->g.push_back(x);
+    }
+  } catch (const std::bad_alloc&) {
+    delete grp;
+    return fail(nullptr, E_NOMEM, "out of host memory");
+  }
+  *out = grp;
+  return OK;
+}
+
+int32_t surge_ingest_group_destroy(surge_ingest_group* grp) {
+  delete grp;
+  return OK;
+}
+
+const char* surge_ingest_group_last_error(const surge_ingest_group* grp) { return grp ? grp->err.c_str() : g_err.c_str(); }
+
+int32_t surge_ingest_group_set_allocator(surge_ingest_group* grp, void* (*alloc)(size_t), void (*release)(void*)) {
+  if (!grp || !alloc != !release) return fail(nullptr, E_INVALID, "bad argument");
+  for (Arena& a : grp->slabs) {
+    if (a.cap) { grp->err = "surge_ingest_group_set_allocator after the first feed"; return -2; }
+    a.alloc = alloc;
+    a.release = release;
+  }
+  return OK;
+}
+
+int32_t surge_ingest_group_feed(surge_ingest_group* grp, const uint8_t* const* data, const int64_t* len, int32_t threads, int64_t* consumed_out,
+                                int64_t max_sections, surge_batch_section* sections_out, int64_t* n_sections_out, const uint8_t** slab_out) {
+  if (!grp || !data || !len || !n_sections_out || !slab_out || max_sections < 0 || (!sections_out && max_sections > 0)) return fail(nullptr, E_INVALID, "bad argument");
+  const int32_t n = (int32_t)grp->g.size();
+  *n_sections_out = 0;
+  *slab_out = nullptr;
+  // every partition's slice: what it still holds (open transactions, batches not drained yet) + this feed
+  int64_t total = 0;
+  for (int32_t p = 0; p < n; ++p) {
+    if (len[p] < 0 || (!data[p] && len[p] > 0)) { grp->err = "bad buffer for partition " + std::to_string(p); return E_INVALID; }
+    int64_t queued = 0;
+    for (const Batch& qb : grp->g[(size_t)p]->queue) queued += qb.sect_off >= 0 ? qb.sect_len : 0;
+    grp->off[(size_t)p] = total;
+    total = (total + queued + len[p] + 15) & ~15ll;
+  }
+  grp->off[(size_t)n] = total;
+  Arena& slab = grp->slabs[(grp->cur + 1) % surge_ingest::kArenas];
+  try {
+    slab.clear();
+    slab.reserve((size_t)total + 16);
+  } catch (const std::bad_alloc&) {
+    grp->err = "out of host memory for the group's slab";
+    return E_NOMEM;
+  }
+  grp->cur = (grp->cur + 1) % surge_ingest::kArenas;
+  std::vector<int32_t> status((size_t)n, OK);
   std::atomic<int32_t> next{0};
   auto work = [&]() {
     for (;;) {
       const int32_t p = next.fetch_add(1);
       if (p >= n) return;
-      n_sections_out[p] = 0;
-      arena_out[p] = nullptr;
-      if (consumed_out) consumed_out[p] = 0;
+      surge_ingest* x = grp->g[(size_t)p];
       int32_t rc = OK;
       try {  // (nothing may leave a thread)
-        if (!g[p]) {
-          rc = E_INVALID;
-        } else {
-          if (len[p] > 0) rc = surge_ingest_feed(g[p], data[p], len[p], consumed_out ? &consumed_out[p] : nullptr);
-          if (rc == OK) rc = surge_ingest_drain_sections(g[p], max_sections_each, sections_out[p], &n_sections_out[p]);
-          if (rc == OK) arena_out[p] = surge_ingest_arena(g[p]);
+        x->ext_next = slab.data() + grp->off[(size_t)p];
+        x->ext_next_cap = (size_t)(grp->off[(size_t)p + 1] - grp->off[(size_t)p]);
+        int64_t consumed = 0;
+        rc = surge_ingest_feed(x, data[p], len[p], &consumed);
+        if (consumed_out) consumed_out[p] = consumed;
+        std::vector<surge_batch_section>& out = grp->drained[(size_t)p];
+        out.clear();
+        if (rc == OK && !x->queue.empty()) {
+          out.resize(x->queue.size());
+          int64_t got = 0;
+          rc = surge_ingest_drain_sections(x, (int64_t)out.size(), out.data(), &got);
+          out.resize(rc == OK ? (size_t)got : 0);
+          for (surge_batch_section& sct : out) sct.byte_off += grp->off[(size_t)p];
         }
       } catch (...) {
         rc = E_NOMEM;
       }
-      status_out[p] = rc;
+      status[(size_t)p] = rc;
     }
   };
   int32_t t = threads < 1 ? 1 : threads;
@@ -842,8 +959,28 @@ int32_t surge_ingest_feed_drain_many(surge_ingest* const* g, const uint8_t* cons
   }
   work();
   for (std::thread& x : th) x.join();
-  for (int32_t p = 0; p < n; ++p)
-    if (status_out[p] != OK) return status_out[p];
+  int64_t at = 0;
+  int32_t first_bad = OK;
+  for (int32_t p = 0; p < n; ++p) {
+    if (status[(size_t)p] != OK && first_bad == OK) {
+      first_bad = status[(size_t)p];
+      grp->err = "partition " + std::to_string(p) + ": " + grp->g[(size_t)p]->err;
+    }
+    for (const surge_batch_section& sct : grp->drained[(size_t)p]) {
+      if (at == max_sections) { grp->err = "sections_out is too small (a batch is at least 61 bytes of a feed)"; return E_INVALID; }
+      sections_out[at++] = sct;
+    }
+  }
+  *n_sections_out = at;
+  *slab_out = slab.data();
+  return first_bad;
+}
+
+int32_t surge_ingest_group_counters(const surge_ingest_group* grp, int64_t out[8]) {
+  if (!grp || !out) return E_INVALID;
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  for (const surge_ingest* x : grp->g)
+    for (int i = 0; i < 8; ++i) out[i] += x->counters[i];
   return OK;
 }
 

@@ -1157,6 +1157,12 @@ int32_t surge_ingest_use_pinned_arena(surge_ingest* g) {
   return surge_ingest_set_allocator(g, pinned_alloc, pinned_release);
 }
 
+int32_t surge_ingest_group_use_pinned_slabs(surge_ingest_group* g) {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return dfail(nullptr, E_DEVICE, "no usable HIP device: the slabs stay in pageable memory");
+  return surge_ingest_group_set_allocator(g, pinned_alloc, pinned_release);
+}
+
 const char* surge_device_decoder_last_error(const surge_device_decoder* d) { return d ? d->err.c_str() : g_dec_err.c_str(); }
 
 int32_t surge_device_decoder_create(int32_t device_id, void* hip_stream, const surge_event_json_template* tmpl, surge_device_decoder** out) {

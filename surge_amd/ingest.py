@@ -9,6 +9,7 @@ uncompressed, ``read_committed`` by default like ``SurgeStateStoreConsumer.scala
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -90,7 +91,7 @@ class EventsTopicIngest:
         rc = self._lib.surge_ingest_create(isolation_level | (FRAMES if frames else 0) | (DEVICE_LZ4 if device_lz4 else 0), ctypes.byref(self._h))
         if rc != 0:
             raise IngestError(rc, (self._lib.surge_ingest_last_error(None) or b"").decode())
-        if frames or device_lz4:
+        if (frames or device_lz4) and os.environ.get("SURGE_INGEST_PAGEABLE_ARENA") != "1":
             # page-locked arena when a GPU is there: the device decoder copies out of it in place (a pageable arena works too)
             self._lib.surge_ingest_use_pinned_arena(self._h)
         if threads != 1:  # host threads verifying the batches' CRC-32C of one feed (surge_ingest_set_threads)
@@ -291,11 +292,12 @@ class FramedFetches:
 class PartitionedFramedFetches:
     """The same one-fetch-ahead framing for a consumer that is assigned several partitions: ``fetches`` yields, per fetch
     response, the next bytes of every partition (a sequence of ``bytes`` / ``None``, always in the same partition order).
-    One FRAMES ingest per partition — transactions, last stable offsets and cut batches are per partition
-    (``SurgeStateStoreConsumer.scala:33-46``: one restore consumer per task, ``isolation.level`` as configured) — framed side
-    by side on ``threads`` host threads (a partition's framer is touched by one thread at a time; the library calls release
-    the GIL).  Iterating yields, per fetch, the list of ``(sections, arena_address)`` parts of the partitions that had
-    something to deliver: ONE ``DeviceDecoder.push_async``.  ``hold`` as in :class:`FramedFetches`."""
+    A ``surge_ingest_group`` frames them: one framer per partition — transactions, last stable offsets and cut batches are
+    per partition (``SurgeStateStoreConsumer.scala:33-46``: ``isolation.level`` as configured) — side by side on
+    ``threads`` host threads (C++ threads inside the library call), all of a fetch's records sections laid out in ONE
+    page-locked slab.  Iterating yields ``(sections, slab_address)`` per fetch — partition after partition, offset order
+    inside a partition: one ``DeviceDecoder.push_async``, one host-to-device copy.  ``hold`` as in :class:`FramedFetches`
+    (the group rotates through four slabs)."""
 
     def __init__(self, fetches, n_partitions: int, threads: int = 8, hold: int = 3, isolation_level: int = READ_COMMITTED, device_lz4: bool = True,
                  overlap: bool = True):
@@ -303,15 +305,21 @@ class PartitionedFramedFetches:
         import threading
 
         if not 1 <= hold <= 3:
-            raise ValueError("hold must be 1, 2 or 3 (a framer has four arenas)")
-        self._g = [EventsTopicIngest(isolation_level, frames=True, device_lz4=device_lz4) for _ in range(n_partitions)]
+            raise ValueError("hold must be 1, 2 or 3 (the group has four slabs)")
         self._lib = _native.load()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.surge_ingest_group_create(n_partitions, isolation_level | (DEVICE_LZ4 if device_lz4 else 0), ctypes.byref(self._h))
+        if rc != 0:
+            raise IngestError(rc, (self._lib.surge_ingest_group_last_error(None) or b"").decode())
+        if os.environ.get("SURGE_INGEST_PAGEABLE_ARENA") != "1":
+            self._lib.surge_ingest_group_use_pinned_slabs(self._h)  # (fails without a GPU: the slabs stay pageable, which works too)
         self._threads = max(1, min(threads, n_partitions))
         self._n = n_partitions
-        self._handles = (ctypes.c_void_p * n_partitions)(*[g._h for g in self._g])
+        self._tails = [b""] * n_partitions
         self._fetches = iter(fetches)
         self._overlap, self._hold = overlap, hold
         self.framing_seconds: List[float] = []
+        self._ring = [None] * (hold + 2)  # section tables, reused (the consumer keeps `hold` fetches alive while the next is framed)
         self._q: "queue.Queue" = queue.Queue()
         self._slots = threading.Semaphore(hold + 1)
         self._stop = False
@@ -321,34 +329,32 @@ class PartitionedFramedFetches:
             self._thread.start()
 
     def _frame(self, fetch):
-        """One library call per fetch (``surge_ingest_feed_drain_many``): the partitions' framers run on C++ threads, no
-        per-partition Python."""
+        """One library call per fetch (``surge_ingest_group_feed``): no per-partition Python."""
         import time
 
         t0 = time.perf_counter()
         n = self._n
         bufs = []
-        for g, data in zip(self._g, fetch):  # a partition's cut batch from the last fetch goes in front (rare: whole batches are the rule)
+        for tail, data in zip(self._tails, fetch):  # a partition's cut batch from the last fetch goes in front (rare: whole batches are the rule)
             data = data or b""
-            bufs.append(g._tail + bytes(data) if g._tail else (data if isinstance(data, bytes) else bytes(data)))
+            bufs.append(tail + bytes(data) if tail else (data if isinstance(data, bytes) else bytes(data)))
         data_arr = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) if b else None for b in bufs])
         len_arr = (ctypes.c_int64 * n)(*[len(b) for b in bufs])
-        max_sec = max(16, max((len(b) for b in bufs), default=0) // 61 + 16)  # a batch is at least its 61-byte header
-        secs = np.zeros((n, max_sec), dtype=SECTION_DTYPE)
-        sec_arr = (ctypes.c_void_p * n)(*[secs[p].ctypes.data for p in range(n)])
-        n_sec = (ctypes.c_int64 * n)()
-        arena = (ctypes.c_void_p * n)()
+        max_sec = sum(len(b) for b in bufs) // 61 + 4 * n + 16  # a batch is at least its 61-byte header (+ what the partitions still hold)
+        slot = len(self.framing_seconds) % len(self._ring)
+        if self._ring[slot] is None or self._ring[slot].shape[0] < max_sec:
+            self._ring[slot] = np.empty(max_sec + max_sec // 4, dtype=SECTION_DTYPE)
+        secs = self._ring[slot]
+        n_sec = ctypes.c_int64()
+        slab = ctypes.c_void_p()
         consumed = (ctypes.c_int64 * n)()
-        status = (ctypes.c_int32 * n)()
-        rc = self._lib.surge_ingest_feed_drain_many(self._handles, data_arr, len_arr, n, self._threads, max_sec, sec_arr, n_sec, arena, consumed, status)
-        for p, g in enumerate(self._g):  # also on failure: batches decoded before the failing one ARE queued
-            g._tail = bufs[p][consumed[p]:] if len_arr[p] else g._tail
+        rc = self._lib.surge_ingest_group_feed(self._h, data_arr, len_arr, self._threads, consumed, secs.shape[0], secs.ctypes.data_as(ctypes.c_void_p),
+                                               ctypes.byref(n_sec), ctypes.byref(slab))
+        self._tails = [bufs[p][consumed[p]:] for p in range(n)]  # also on failure: batches decoded before the failing one ARE queued
         if rc != 0:
-            bad = next(p for p in range(n) if status[p] != 0)
-            raise IngestError(status[bad], f"partition {bad}: " + (self._lib.surge_ingest_last_error(self._g[bad]._h) or b"").decode())
-        parts = [(secs[p, : n_sec[p]], int(arena[p] or 0)) for p in range(n) if n_sec[p] > 0]
+            raise IngestError(rc, (self._lib.surge_ingest_group_last_error(self._h) or b"").decode())
         self.framing_seconds.append(time.perf_counter() - t0)
-        return parts
+        return secs[: n_sec.value], int(slab.value or 0)
 
     _run = FramedFetches._run
     __iter__ = FramedFetches.__iter__
@@ -356,11 +362,11 @@ class PartitionedFramedFetches:
 
     def counters(self) -> dict:
         """The partitions' ingest counters, summed; call it when the iteration has ended."""
-        out: dict = {}
-        for g in self._g:
-            for k, v in g.counters().items():
-                out[k] = out.get(k, 0) + v
-        return out
+        c = (ctypes.c_int64 * 8)()
+        self._lib.surge_ingest_group_counters(self._h, ctypes.byref(c))
+        names = ["batches", "records_decoded", "records_delivered", "records_aborted", "control_batches",
+                 "flush_records_skipped", "bytes_decompressed", "open_transactions"]
+        return dict(zip(names, [int(x) for x in c]))
 
     def close(self):
         self._stop = True
@@ -369,8 +375,9 @@ class PartitionedFramedFetches:
                 self._slots.release()
             self._thread.join()
             self._thread = None
-        for g in self._g:
-            g.close()
+        if self._h:
+            self._lib.surge_ingest_group_destroy(self._h)
+            self._h = ctypes.c_void_p()
 
     def __enter__(self):
         return self

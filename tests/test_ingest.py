@@ -609,10 +609,11 @@ def test_frames_mode_rotates_four_arenas_so_the_next_three_feeds_leave_the_drain
 
 
 def test_partitioned_framed_fetches_frame_every_partition_like_its_own_framer_and_keep_three_fetches_alive():
-    """surge_ingest_feed_drain_many behind PartitionedFramedFetches: a consumer's fetch responses over several partitions,
-    framed on C++ threads (one framer per partition), yield per fetch the same sections each partition's own framer
-    yields — transactions per partition, a cut batch completed by the next fetch, partitions with nothing in a fetch —
-    and with hold = 3 the sections of three consecutive fetches are intact at the same time."""
+    """surge_ingest_group behind PartitionedFramedFetches: a consumer's fetch responses over several partitions, framed on
+    C++ threads (one framer per partition) into one slab per fetch, yield per fetch the sections each partition's own
+    framer yields, partition after partition — transactions per partition, a cut batch completed by the next fetch,
+    partitions with nothing in a fetch — and with hold = 3 the sections of three consecutive fetches are intact at the
+    same time."""
     from surge_amd.ingest import PartitionedFramedFetches
 
     ev = lambda seq: counter_event(S.EVT_INC, seq, seq)
@@ -657,136 +658,17 @@ def test_partitioned_framed_fetches_frame_every_partition_like_its_own_framer_an
     finally:
         for g in singles:
             g.close()
+    flat_want = [[x for row in rows for x in row] for rows in want]  # partition after partition
     for overlap in (False, True):
         alive, got = [], []
         with PartitionedFramedFetches(iter(fetches), P, threads=3, hold=3, overlap=overlap) as framed:
-            for parts in framed:
-                alive.append(parts)
+            for sec, slab in framed:
+                alive.append((sec, slab))
                 if len(alive) > 3:
                     alive.pop(0)
                 # everything still alive reads back unchanged while the framer is (up to) a fetch ahead
-                snap = [[[(int(s["base_offset"]), int(s["n_records"]), int(s["codec"]), b) for s, b in zip(sec, _section_bytes(sec, arena))] for sec, arena in pp] for pp in alive]
+                snap = [[(int(s["base_offset"]), int(s["n_records"]), int(s["codec"]), b) for s, b in zip(sc, _section_bytes(sc, sl))] for sc, sl in alive]
                 got.append(snap[-1])
-                assert snap == want[len(got) - len(alive): len(got)]
+                assert snap == flat_want[len(got) - len(alive): len(got)]
             assert framed.counters() == want_counters
-        assert got == want
-
-
-def test_framed_fetches_yield_the_same_sections_one_fetch_ahead_as_inline():
-    from surge_amd.ingest import FramedFetches
-
-    ev = lambda seq: counter_event(S.EVT_INC, seq, seq)
-    rnd = random.Random(5)
-    fetches, off = [], 0
-    for f in range(12):
-        parts = []
-        for b in range(rnd.randrange(1, 6)):
-            n = rnd.randrange(1, 400)
-            parts.append(kw.record_batch(off, [(b"k%d:%d" % (rnd.randrange(50), i), ev(off + i + 1)) for i in range(n)],
-                                         compression=rnd.choice(["none", "lz4"])))
-            off += n
-        fetches.append(b"".join(parts))
-    # a fetch that cuts a batch in two: the tail is completed by the next fetch
-    cut = len(fetches[3]) - 37
-    fetches[3], fetches[4] = fetches[3][:cut], fetches[3][cut:] + fetches[4]
-
-    def collect(overlap, slow_consumer):
-        import time
-
-        got = []
-        with FramedFetches(iter(fetches), device_lz4=True, overlap=overlap) as framed:
-            for sections, arena in framed:
-                if slow_consumer:
-                    time.sleep(0.01)  # the framing thread runs ahead; the spans must still be intact afterwards
-                got.append([(int(s["base_offset"]), int(s["n_records"]), int(s["codec"]), b) for s, b in zip(sections, _section_bytes(sections, arena))])
-            c = framed.counters()
-        return got, c
-
-    inline, c0 = collect(False, False)
-    ahead, c1 = collect(True, True)
-    assert inline == ahead and c0 == c1 and sum(len(x) for x in inline) == c0["batches"] and len(inline) == len(fetches)
-
-    def failing():
-        yield fetches[0]
-        yield b"\x00" * 80  # not a record batch
-    with FramedFetches(failing(), overlap=True) as framed:
-        it = iter(framed)
-        next(it)
-        with pytest.raises(IngestError):
-            next(it)
-
-
-def test_framed_fetches_can_be_abandoned_midway_without_hanging():
-    import threading
-    import time
-
-    from surge_amd.ingest import FramedFetches
-
-    ev = lambda seq: counter_event(S.EVT_INC, seq, seq)
-    fetches = [kw.record_batch(10 * i, [(b"k:%d" % j, ev(10 * i + j + 1)) for j in range(10)]) for i in range(50)]
-    done = []
-
-    def consume():
-        with FramedFetches(iter(fetches)) as framed:
-            for n, (sections, arena) in enumerate(framed):
-                assert _section_bytes(sections, arena) == [fetches[n][61:]]
-                if n == 2:
-                    break  # the framing thread is waiting for a free arena: close() has to release it
-        done.append(True)
-
-    t = threading.Thread(target=consume, daemon=True)
-    t0 = time.time()
-    t.start()
-    t.join(timeout=20)
-    assert done == [True] and time.time() - t0 < 20
-
-
-@pytest.mark.parametrize("frames", [False, True])
-def test_crc_threads_give_the_same_records_counters_and_errors_as_one_thread(frames):
-    """surge_ingest_set_threads: the batches' CRCs of a feed are verified up front on several threads; everything the feed
-    reports — records, counters, WHICH batch fails and how many bytes count as consumed — is what one thread reports."""
-    rnd = random.Random(21)
-    ev = lambda seq: counter_event(S.EVT_INC, seq, seq)
-    batches, off = [], 0
-    for b in range(1500):
-        n = rnd.randrange(1, 60)
-        tx = b % 7 == 0
-        batches.append(kw.record_batch(off, [(b"k%d:%d" % (rnd.randrange(500), i), ev(off + i + 1)) for i in range(n)],
-                                       compression=rnd.choice(["none", "lz4"]), transactional=tx, producer_id=4))
-        off += n
-        if tx:
-            batches.append(kw.control_batch(off, 4, kw.ABORT if b % 21 == 0 else kw.COMMIT))
-            off += 1
-    good = b"".join(batches)
-    assert len(good) > (1 << 20)  # below 1 MiB a feed does not bother with threads
-    cut = good[: len(good) - 13]  # a fetch that ends inside a batch
-    k = 700
-    at = sum(len(x) for x in batches[:k])
-    bad_crc = bytearray(good); bad_crc[at + 70] ^= 0x10             # a payload byte of batch k: its CRC no longer holds
-    bad_magic = bytearray(good); bad_magic[at + 16] = 1             # batch k claims message format v1
-    bad_len = bytearray(good); bad_len[at + 8:at + 12] = b"\x00\x00\x00\x05"  # batchLength below the header size
-
-    def run(wire, threads):
-        with EventsTopicIngest(frames=frames, threads=threads) as g:
-            err = None
-            consumed = 0
-            try:
-                consumed = g.feed(bytes(wire))
-            except IngestError as e:
-                err = (e.status, str(e))
-                consumed = len(wire) - len(g._tail)
-            if frames:
-                sections, arena = g.drain_sections()
-                got = [(int(x["base_offset"]), int(x["n_records"]), int(x["codec"]), b) for x, b in zip(sections, _section_bytes(sections, arena))]
-            else:
-                got = g.drain_records()
-            return err, consumed, got, g.counters()
-
-    for wire in (good, cut, bad_crc, bad_magic, bad_len):
-        one = run(wire, 1)
-        for threads in (2, 5):
-            assert run(wire, threads) == one
-    assert run(bad_crc, 4)[0][0] == -7 and run(bad_crc, 4)[1] == at  # the bytes of the good batches before it count as consumed
-    with EventsTopicIngest() as g:
-        with pytest.raises(IngestError):
-            g._check(g._lib.surge_ingest_set_threads(g._h, 0))
+        assert got == flat_want
