@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--host-framing", action="store_true", help="c5: frame the state-topic record batches with the host writer instead of the device framer")
     ap.add_argument("--serial-framing", action="store_true", help="e2e: frame each fetch, then push it, then fold it, one after the other (default: framing one fetch ahead on its own threads, three pushes in flight)")
     ap.add_argument("--events-cap", type=int, default=8, help="e2e: every aggregate publishes the first min(count, cap) of its events (8: 6.4e7 records over the 10 M aggregates)")
+    ap.add_argument("--no-capacity-hint", action="store_true", help="e2e: let the resident state and the key table grow as aggregates appear instead of sizing them up front")
     ap.add_argument("--framing-threads", type=int, default=8, help="e2e: host threads framing a fetch's partitions side by side")
     ap.add_argument("--aggregates", type=int, default=None, help="global aggregate count (default 10 M for c4, 1 M for c2)")
     ap.add_argument("--events-per-aggregate", type=int, default=C2_EVENTS, help="c2 only")
@@ -909,23 +910,33 @@ def run_e2e(args):
     t_start = time.perf_counter()
     with PartitionedFramedFetches((f for f, _ in fetches), P, threads=args.framing_threads, hold=depth, overlap=not args.serial_framing) as framed, \
             DeviceDecoder(tmpl, device=local_rank) as d:
-        eng.load_csr(np.zeros(1, np.int64), np.zeros(0, dtype=S.EVENT_DTYPE))
+        # capacity hints (a recovery knows roughly how many aggregates the store held: its last snapshot): the resident state
+        # and the decoder's key table are sized for this rank's aggregates up front instead of growing step by step
+        # (--no-capacity-hint: every growth step allocates, copies and frees device memory — tens of ms each at this size)
+        hint = 0 if args.no_capacity_hint else int(my_ids.shape[0])
+        eng.load_csr(np.zeros(hint + 1, np.int64), np.zeros(0, dtype=S.EVENT_DTYPE))
         eng.fold()
-        n_agg = 0
+        if hint:
+            d.reserve(hint, 13 * hint)
+        n_agg = hint
         pending = []
 
         def finish_one():
             nonlocal n_agg
             t1 = time.perf_counter()
             d.finish()
+            ta = time.perf_counter()
             agg, ev, _, n_keys = d.result()
             if n_keys > n_agg:
                 eng.grow(max(n_keys, min(2 * n_agg, my_ids.shape[0])))  # (grow in big steps: a grow copies the resident state)
                 n_agg = eng.n_agg
+            tb = time.perf_counter()
             eng.append_events(agg, ev)
             eng.synchronize()
             d.clear()
             t2 = time.perf_counter()
+            if os.environ.get("SURGE_BENCH_TRACE"):
+                print(f"[bench] fetch {len(marks)}: finish {(ta - t1) * 1e3:.2f} grow {(tb - ta) * 1e3:.2f} fold {(t2 - tb) * 1e3:.2f} ms, keys {n_keys}", file=sys.stderr)
             marks.append(t2)
             dev_ms.append((t2 - t1) * 1e3)
             keys_at.append(n_keys)
@@ -1056,7 +1067,7 @@ def run_e2e(args):
                                f"JSON decode / key interning / group-by / fold on the GPU" + (" [REHEARSAL: every rank on cuda:0, throughput meaningless]" if rehearsal else ""),
                    "parallelism": f"partitions p % {world} == rank; no data-path collective; final snapshot all-gathered through the C ABI" if world > 1 else "one GPU",
                    "aggregates": A, "events_cap": cap, "partitions": P, "fetch_records": n_fetch, "fetches": len(fetches), "pushes_in_flight": depth,
-                   "framing_threads": args.framing_threads, "events_timed": total_events, "per_rank_events": per_rank, "keys_interned": total_keys,
+                   "framing_threads": args.framing_threads, "capacity_hint": not args.no_capacity_hint, "events_timed": total_events, "per_rank_events": per_rank, "keys_interned": total_keys,
                    "wire_bytes_per_record": total_wire / max(1, int(totals[4].item())),
                    "fetch_ms": {"p50": float(np.percentile(lat, 50)), "p90": float(np.percentile(lat, 90)), "max": float(np.max(lat))},
                    "host_framing_ms_per_fetch": float(np.mean(host_ms[W:])), "finish_and_fold_ms_per_fetch": float(np.mean(dev_ms[W:])),

@@ -206,6 +206,10 @@ int32_t surge_device_decoder_push_parts_async(surge_device_decoder* d, int32_t n
                                               const surge_batch_section* const* sections, const int64_t* n_sections);
 int32_t surge_device_decoder_push_finish(surge_device_decoder* d);
 int32_t surge_device_decoder_pending(const surge_device_decoder* d); /* pushes enqueued and not finished */
+/* Optional capacity hint — e.g. the aggregate count of the store's last snapshot: room for n_keys aggregate ids of
+ * key_bytes bytes in all (hash table, key arena, offsets), so a recovery does not grow them step by step (every step
+ * allocates, copies and frees device memory: tens of milliseconds at 10^7 keys).  Growing beyond it still works. */
+int32_t surge_device_decoder_reserve(surge_device_decoder* d, int64_t n_keys, int64_t key_bytes);
 /* The same for records that arrive already framed — what a JVM's KafkaConsumer hands over (ConsumerRecord key / value
  * bytes and offset): record i's key is keys[key_off[i] .. key_off[i+1]), its value values[value_off[i] .. value_off[i+1]),
  * offsets nullable (then 0, 1, 2 ..).  A record with an empty key AND an empty value is the producer's flush record and

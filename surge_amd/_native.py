@@ -114,6 +114,7 @@ INGEST_EXPORTS = (
     "surge_device_decoder_push_parts_async",
     "surge_device_decoder_push_finish",
     "surge_device_decoder_pending",
+    "surge_device_decoder_reserve",
     "surge_device_decoder_result",
     "surge_device_decoder_clear",
     "surge_replay_append_decoded",
@@ -332,6 +333,7 @@ def load() -> ctypes.CDLL:
         "surge_device_decoder_push_parts_async": ([vp, i32, vp, vp, vp], i32),
         "surge_device_decoder_push_finish": ([vp], i32),
         "surge_device_decoder_pending": ([vp], i32),
+        "surge_device_decoder_reserve": ([vp, i64, i64], i32),
         "surge_device_decoder_result": ([vp, ctypes.POINTER(i64), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64)], i32),
         "surge_device_decoder_clear": ([vp], i32),
         "surge_replay_append_decoded": ([vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),

@@ -22,6 +22,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -352,22 +353,27 @@ __global__ void __launch_bounds__(64) lz4_parse_kernel(const uint8_t* __restrict
     uint2* __restrict__ out = w.seq + blk.seq_off;
     int32_t ip = 0;
     while (ip < n_in) {
-      // (the staged bytes end 16 bytes after their last byte: the load may run past the block, never past the buffer)
+      // (the staged bytes end 64 bytes after their last byte: the load may run past the block, never past the buffer.  Cutting
+      // several sequences out of one wider register window — 32 bytes unaligned, 48 bytes aligned — was tried: 0.95 and
+      // 1.19 ms against 0.85: with one wave per SIMD the walk is bound by its instruction count, not by the load)
       Unaligned16 win;
       __builtin_memcpy(&win, in + ip, 16);
       const uint32_t token = (uint32_t)win.lo & 0xffu;
       const int32_t lit = (int32_t)(token >> 4), mlc = (int32_t)(token & 15u);
       const int32_t need = 3 + lit + (mlc == 15 ? 1 : 0);
       const uint32_t tail = (uint32_t)window_bits(win.lo, win.hi, 8 * (1 + lit));  // offset (16 bits), then the length byte
-      bool fast = lit <= 12 && need <= n_in - ip && op + 16 <= kLz4BlockMax && !(mlc == 15 && ((tail >> 16) & 0xffu) == 255u);
-      // (need < n_in - ip would also do: a sequence that ends the block exactly still carries its match; the last,
-      // literal-only sequence has no room for an offset and takes the slow path)
+      bool fast = lit <= 12 && need <= n_in - ip && lit <= kLz4BlockMax - op && !(mlc == 15 && ((tail >> 16) & 0xffu) == 255u);
+      // (the block's last, literal-only sequence has no room for an offset and takes the slow path)
       if (fast) {
-        if (lit > 0) {  // 16 bytes where the literals go: what follows them is overwritten by the match / the next literals
-          Unaligned16 lits;
-          lits.lo = (win.lo >> 8) | (win.hi << 56);
-          lits.hi = win.hi >> 8;
-          __builtin_memcpy(dst + op, &lits, 16);
+        if (lit > 0) {
+          if (op + 16 <= kLz4BlockMax) {  // 16 bytes where the literals go: what follows them is overwritten by the match / the next literals
+            Unaligned16 lits;
+            lits.lo = (win.lo >> 8) | (win.hi << 56);
+            lits.hi = win.hi >> 8;
+            __builtin_memcpy(dst + op, &lits, 16);
+          } else {
+            for (int j = 0; j < lit; ++j) dst[op + j] = (uint8_t)window_bits(win.lo, win.hi, 8 * (1 + j));
+          }
         }
         const int32_t offset = (int32_t)(tail & 0xffffu);
         const int32_t ml = mlc + 4 + (mlc == 15 ? (int32_t)((tail >> 16) & 0xffu) : 0);
@@ -1315,6 +1321,15 @@ int32_t slot_pinned(surge_device_decoder* d, PushSlot& s, size_t bytes) {
 // its value decoded.  Nothing here reads or writes the key table.
 int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const uint8_t* const* bytes, const surge_batch_section* const* sections,
                     const int64_t* n_sections) {
+  static const bool dbg_t = std::getenv("SURGE_DBG_TIMING") != nullptr;
+  auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = dbg_t ? now_us() : 0.0;
+  auto lap = [&](const char* what) {
+    if (!dbg_t) return;
+    const double t = now_us();
+    std::fprintf(stderr, "[surge dbg] stage1 %-14s %8.1f us\n", what, t - t_mark);
+    t_mark = t;
+  };
   int64_t total_sections = 0;
   for (int32_t p = 0; p < n_parts; ++p) {
     if (n_sections[p] < 0 || (n_sections[p] > 0 && (!bytes[p] || !sections[p]))) return dfail(d, E_INVALID, "bad argument");
@@ -1370,6 +1385,9 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
     for (int32_t p = 0; p < n_parts; ++p) {
       for (int64_t i = 0; i < n_sections[p]; ++i, ++at) {
         const surge_batch_section& in = sections[p][i];
+        // (the frame headers were written by the framing threads, on other cores: one cache miss per batch — 1.2 ms per
+        // 7000-batch push — unless they are asked for ahead of time)
+        if (i + 12 < n_sections[p]) __builtin_prefetch(bytes[p] + sections[p][i + 12].byte_off);
         if (in.codec != 3 || in.n_records == 0) continue;
         Section& sec = secs[(size_t)at];
         const uint8_t* f = bytes[p] + in.byte_off;
@@ -1441,12 +1459,13 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
   } catch (const std::bad_alloc&) {
     return dfail(d, E_NOMEM, "out of host memory");
   }
+  lap("walk sections");
   const int64_t n_bytes = n_raw + (int64_t)extra.size();              // what is staged and copied
   const int64_t area_base = (n_bytes + 15) & ~15ll;                    // where the device-decompressed frames start
   for (Section& sc : secs)
     if (sc.byte_off < 0) sc.byte_off = area_base + (-1 - sc.byte_off);
   hipStream_t st = s.stream;
-  DCHK(d, s.d_bytes.reserve((size_t)(area_base + area) + 16, false, st));
+  DCHK(d, s.d_bytes.reserve((size_t)(area_base + area) + 64, false, st));
   DCHK(d, s.d_sections.reserve(sizeof(Section) * (size_t)total_sections, false, st));
   {
     const int32_t rc = slot_scratch(d, s, n_rec);
@@ -1454,43 +1473,47 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
   }
   // H2D: a part goes straight out of the caller's arena when that is page-locked (surge_ingest_use_pinned_arena), else
   // through the slot's own pinned staging (one extra host copy)
-  size_t need_stage = extra.size();
+  lap("reserve");
+  // the section and block tables travel through page-locked staging too: a copy from pageable memory waits for the stream
+  // (1.4 ms of host time per push went there)
+  const size_t sec_bytes = sizeof(Section) * (size_t)total_sections, blk_bytes = sizeof(Lz4Block) * blocks.size();
+  size_t need_stage = ((extra.size() + 15) & ~(size_t)15) + sec_bytes + blk_bytes + 64;
   std::vector<char> in_place((size_t)n_parts, 0);
   for (int32_t p = 0; p < n_parts; ++p) {
     if (part_len[(size_t)p] == 0) continue;
     hipPointerAttribute_t attr;
     in_place[(size_t)p] = hipPointerGetAttributes(&attr, bytes[p] + part_lo[(size_t)p]) == hipSuccess && attr.type == hipMemoryTypeHost;
     (void)hipGetLastError();  // a pageable pointer makes hipPointerGetAttributes fail: not an error of this call
-    if (!in_place[(size_t)p]) need_stage += (size_t)part_len[(size_t)p];
+    if (!in_place[(size_t)p]) need_stage += ((size_t)part_len[(size_t)p] + 15) & ~(size_t)15;
   }
   {
     const int32_t rc = slot_pinned(d, s, need_stage);
     if (rc != OK) return rc;
   }
   size_t staged = 0;
+  auto stage = [&](const void* src, size_t len) -> const uint8_t* {
+    uint8_t* at = (uint8_t*)s.pinned + staged;
+    std::memcpy(at, src, len);
+    staged += (len + 15) & ~(size_t)15;
+    return at;
+  };
   for (int32_t p = 0; p < n_parts; ++p) {
     const size_t len = (size_t)part_len[(size_t)p];
     if (len == 0) continue;
     const uint8_t* src = bytes[p] + part_lo[(size_t)p];
-    if (!in_place[(size_t)p]) {
-      std::memcpy((uint8_t*)s.pinned + staged, src, len);
-      src = (const uint8_t*)s.pinned + staged;
-      staged += len;
-    }
+    if (!in_place[(size_t)p]) src = stage(src, len);
     DCHK(d, hipMemcpyAsync((uint8_t*)s.d_bytes.p + part_dev[(size_t)p], src, len, hipMemcpyHostToDevice, st));
   }
-  if (!extra.empty()) {
-    std::memcpy((uint8_t*)s.pinned + staged, extra.data(), extra.size());
-    DCHK(d, hipMemcpyAsync((uint8_t*)s.d_bytes.p + n_raw, (const uint8_t*)s.pinned + staged, extra.size(), hipMemcpyHostToDevice, st));
-  }
-  DCHK(d, hipMemcpyAsync(s.d_sections.p, secs.data(), sizeof(Section) * (size_t)total_sections, hipMemcpyHostToDevice, st));
+  if (!extra.empty()) DCHK(d, hipMemcpyAsync((uint8_t*)s.d_bytes.p + n_raw, stage(extra.data(), extra.size()), extra.size(), hipMemcpyHostToDevice, st));
+  DCHK(d, hipMemcpyAsync(s.d_sections.p, stage(secs.data(), sec_bytes), sec_bytes, hipMemcpyHostToDevice, st));
+  lap("copies");
   const uint8_t* dby = (const uint8_t*)s.d_bytes.p;
   Section* dsec = (Section*)s.d_sections.p;
   ErrorCell* derr = (ErrorCell*)s.d_err.p;
   RecMeta* dmeta = (RecMeta*)s.meta.p;
   if (!blocks.empty()) {
-    DCHK(d, s.lz4_blocks.reserve(blocks.size() * sizeof(Lz4Block), false, st));
-    DCHK(d, hipMemcpyAsync(s.lz4_blocks.p, blocks.data(), blocks.size() * sizeof(Lz4Block), hipMemcpyHostToDevice, st));
+    DCHK(d, s.lz4_blocks.reserve(blk_bytes, false, st));
+    DCHK(d, hipMemcpyAsync(s.lz4_blocks.p, stage(blocks.data(), blk_bytes), blk_bytes, hipMemcpyHostToDevice, st));
     DCHK(d, s.lz4_sizes.reserve(blocks.size() * 4, false, st));
     const int64_t nb = (int64_t)blocks.size();
     if (nb >= (1ll << 31)) return dfail(d, E_UNSUPPORTED, "more than 2^31 LZ4 blocks in one push: push fewer sections at a time");
@@ -1527,6 +1550,7 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
     // (a frame that does not decode zeroes its section and raises the error cell: the push fails in stage 2's first
     // synchronisation, before anything is committed)
   }
+  lap("lz4 launches");
   // chain + parse + decode, one workgroup per batch: sections up to 20 KiB (the reference producer closes a batch at 16 KiB)
   // out of 24 KiB of LDS, the rest out of 68 KiB or, beyond 64 KiB, in place
   {
@@ -1539,6 +1563,7 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
     }
     DCHK(d, hipGetLastError());
   }
+  lap("section launches");
   s.n_rec = n_rec;
   s.seed = d->seed;
   return OK;
@@ -1798,6 +1823,24 @@ int32_t surge_device_decoder_push_finish(surge_device_decoder* d) {
 }
 
 int32_t surge_device_decoder_pending(const surge_device_decoder* d) { return d ? d->n_pending : 0; }
+
+int32_t surge_device_decoder_reserve(surge_device_decoder* d, int64_t n_keys, int64_t key_bytes) {
+  if (!d) return dfail(nullptr, E_INVALID, "decoder is NULL");
+  if (n_keys < 0 || key_bytes < 0) return dfail(d, E_INVALID, "negative capacity");
+  if (d->n_pending != 0) return dfail(d, SURGE_E_STATE, "asynchronous pushes are pending");
+  DeviceScope scope(d->device);
+  hipStream_t st = d->stream;
+  const int64_t extra = n_keys > d->n_keys ? n_keys - d->n_keys : 0;
+  {
+    const int32_t rc = ensure_table(d, extra);
+    if (rc != OK) return rc;
+  }
+  DCHK(d, d->key_off.reserve((size_t)(n_keys + 1) * 8, true, st));
+  DCHK(d, d->key_hash.reserve((size_t)n_keys * 8, true, st));
+  DCHK(d, d->arena.reserve((size_t)key_bytes + 16, true, st));
+  DCHK(d, hipStreamSynchronize(st));
+  return OK;
+}
 
 int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes, const surge_batch_section* sections, int64_t n_sections) {
   if (!d) return dfail(nullptr, E_INVALID, "decoder is NULL");

@@ -442,6 +442,10 @@ class DeviceDecoder:
             self._inflight.pop(0)
         self._check(rc)
 
+    def reserve(self, n_keys: int, key_bytes: int) -> None:
+        """Capacity hint (``surge_device_decoder_reserve``): room for ``n_keys`` aggregate ids of ``key_bytes`` bytes in all."""
+        self._check(self._lib.surge_device_decoder_reserve(self._h, int(n_keys), int(key_bytes)))
+
     @property
     def pending(self) -> int:
         return int(self._lib.surge_device_decoder_pending(self._h))

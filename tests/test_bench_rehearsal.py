@@ -91,7 +91,7 @@ def test_bench_workload_v2_reports_four_variants_of_the_same_device_code_and_ful
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--serial-framing"], ["--codec", "none"]])
+@pytest.mark.parametrize("extra", [[], ["--serial-framing"], ["--codec", "none"], ["--no-capacity-hint"]])
 def test_bench_workload_e2e_goes_from_topic_bytes_to_states_and_checks_them_against_the_source_events(extra):
     """The C3-shaped topic at a small size: 30 000 aggregates over 64 partitions, lz4 batches of 16 KiB, fetches of 20 000
     records framed per partition on host threads, one device push per fetch (three in flight), states compared with the
