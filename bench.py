@@ -185,8 +185,8 @@ def main():
     ap.add_argument("--aggregates", type=int, default=None, help="global aggregate count (default 10 M for c4, 1 M for c2)")
     ap.add_argument("--events-per-aggregate", type=int, default=C2_EVENTS, help="c2 only")
     ap.add_argument("--algo", default=None,
-                    help="auto | fixed | flat | rows | sorted | chunked | tiled (or the SURGE_ALGO_* number); default: tiled for the "
-                         "Zipf log (c3 / c4), auto for c2")
+                    help="auto | fixed | flat | rows | sorted | chunked | tiled (or the SURGE_ALGO_* number); default: auto — the "
+                         "kernel the engine picks for a log it folds straight from CSR (the tile-major fold is reported beside it at N = 1)")
     ap.add_argument("--parity", default="full", choices=["full", "sample", "none"],
                     help="N = 1: check the GPU states against the CPU restatement on the whole log (default), on the cpu_baseline "
                          "sample only, or not at all")
@@ -221,7 +221,7 @@ def main():
     weak = args.workload == "c2-weak"
     algo = parse_algo(args.algo)
     if algo is None:
-        algo = S.ALGO_TILED if zipf else S.ALGO_AUTO
+        algo = S.ALGO_AUTO  # what a recovery runs: the fold straight from the CSR log, no copy of it (round 3's default was TILED)
     L = args.events_per_aggregate
     n_global = args.aggregates or (N_AGGREGATES if zipf else C2_AGGREGATES)
     if weak:
@@ -365,8 +365,8 @@ def main():
     if rank == 0:
         probe_gbps = None
         try:
-            ms = min(eng.stream_probe_ms(events[: min(events.shape[0], 1 << 28)]) for _ in range(5))
-            probe_gbps = min(events.shape[0], 1 << 28) * 16 / (ms * 1e-3) / 1e9
+            ms = min(eng.stream_probe_ms(events[: min(events.shape[0], 1 << 29)]) for _ in range(5))  # an 8 GB window, best of five
+            probe_gbps = min(events.shape[0], 1 << 29) * 16 / (ms * 1e-3) / 1e9
         except Exception as e:  # pragma: no cover
             print(f"stream probe failed: {e}", file=sys.stderr)
         ms_per_step = elapsed_s / args.steps * 1e3
@@ -388,9 +388,10 @@ def main():
             "chunk_events": layout.chunk_events,
             "note": "device time between HIP events (wall for *_wall_ms), rank 0; paid once per bound log, outside the timed region",
         }
-        csr_direct = None
+        # the other transport, measured in the same run on the same log (N = 1): the tile-major fold when the primary folds
+        # straight from the CSR log (the default), the CSR fold when --algo tiled was asked for
+        csr_direct, tile_major = None, None
         if world == 1 and st.last_algo == S.ALGO_TILED:
-            # the same log folded straight from CSR (no copy): what a one-shot recovery would run
             eng.set_state_out(bufs[1 - last])
             t_p = time.perf_counter()
             eng.fold(S.ALGO_AUTO)
@@ -405,6 +406,30 @@ def main():
                           "events_per_sec": total_events / (float(np.mean(tm2)) * 1e-3),
                           "states_equal_primary": bool(torch.equal(bufs[0], bufs[1]))}
             eng.set_state_out(bufs[last])
+        elif world == 1 and zipf and not args.no_secondary:
+            try:
+                eng.set_state_out(bufs[1 - last])
+                torch.cuda.synchronize(dev)
+                t_p = time.perf_counter()
+                eng.prepare(S.ALGO_TILED)  # a second copy of the log in HBM + one re-layout pass: paid once per bound log
+                eng.synchronize()
+                tm_prepare_wall = (time.perf_counter() - t_p) * 1e3
+                tl = eng.layout_info()
+                dt2, st2, tm2 = time_folds(eng, torch, dev, S.ALGO_TILED, max(5, args.steps // 2), 2)
+                tile_major = {"algo": algo_name(S, st2.last_algo), "kernel": kernel_name(S, st2.last_algo),
+                              "kernel_ms_min_median_max": [float(np.min(tm2)), float(np.median(tm2)), float(np.max(tm2))],
+                              "frac": st2.algorithmic_bytes / (float(np.mean(tm2)) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                              "events_per_sec": total_events / (float(np.mean(tm2)) * 1e-3),
+                              "traffic": pmc_traffic(kernel_name(S, st2.last_algo), st2.algorithmic_bytes),
+                              "one_shot": {"index_build_ms": tl.index_build_ms, "relayout_ms": tl.relayout_ms, "prepare_wall_ms": tm_prepare_wall,
+                                           "tile_major_copy_bytes": tl.tiled_bytes, "padding_events": tl.padding_events,
+                                           "note": "prepare_wall_ms includes a device allocation of the log's size: on a box whose free VRAM was handed back moments "
+                                                   "ago that allocation alone can take seconds (the driver scrubs freed VRAM before it hands it out again: "
+                                                   "profiles/r04_vram_alloc_probe.txt) — which is why the headline no longer depends on this copy"},
+                              "states_equal_primary": bool(torch.equal(bufs[0], bufs[1]))}
+                eng.set_state_out(bufs[last])
+            except Exception as exc:  # pragma: no cover - e.g. not enough HBM for the copy
+                tile_major = {"skipped": str(exc)}
         if zipf:
             wl = (f"C{'3' if world == 1 else '4'}: {n_global} aggregates, Zipf(1..4096) events each, CSR, 16 B events, 64 B state, "
                   f"ids acct-%08d sharded over {world} GPU(s) by partitionForKey(id, {N_PARTITIONS}) % {world}; log resident in HBM")
@@ -446,11 +471,28 @@ def main():
             "roofline": roof,
             "one_shot": one_shot,
             "csr_direct": csr_direct,
+            "tile_major": tile_major,
             "cpu_baseline": cpu_baseline,
         }
-        if world == 1 and zipf and not args.no_secondary:
-            result["secondary"] = run_secondary_c2(args, S, synth, ReplayEngine, torch, dev, local_rank)
     eng.close()
+    del events, seg_off
+    if rank == 0 and world == 1 and zipf and not args.no_secondary:
+        torch.cuda.empty_cache()
+        result["secondary"] = run_secondary_c2(args, S, synth, ReplayEngine, torch, dev, local_rank)
+        # BASELINE config 5 and the ABI v2 path, bounded to a few seconds each, so that the driver's run times them too
+        import argparse as _ap
+
+        try:
+            c5 = run_c5(_ap.Namespace(**{**vars(args), "workload": "c5", "steps": 150, "warmup": 3, "batch_events": 100_000, "snapshot_every": 30,
+                                         "device_batches": False, "host_framing": False, "aggregates": None, "parity": "full"}))
+            result["c5"] = {k: c5[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "cpu_baseline")}
+        except Exception as exc:  # pragma: no cover
+            result["c5"] = {"skipped": repr(exc)}
+        try:
+            v2 = run_v2(_ap.Namespace(**{**vars(args), "workload": "v2", "steps": 10, "warmup": 2, "aggregates": None}))
+            result["v2"] = {k: v2[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "roofline", "one_shot", "cpu_baseline")}
+        except Exception as exc:  # pragma: no cover
+            result["v2"] = {"skipped": repr(exc)}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -459,8 +501,9 @@ def main():
 
 
 def run_secondary_c2(args, S, synth, ReplayEngine, torch, dev, local_rank):
-    """BASELINE config C2 (1 M aggregates x 256 events, uniform fan-in) on the same GPU, with its own roofline: the
-    tile-major fold (with its one-off layout cost) and, beside it, the fold straight from the CSR log (ROWS)."""
+    """BASELINE config C2 (1 M aggregates x 256 events, uniform fan-in) on the same GPU, with its own roofline: the fold AUTO
+    picks straight from the CSR log (ROWS) and, beside it, the tile-major fold with its one-off layout cost — each with the
+    counter traffic of the committed PMC profile of exactly that kernel and shape."""
     import numpy as np
 
     so, ev = synth.fixed_log_device(C2_AGGREGATES, C2_EVENTS, C2_SEED, dev)
@@ -468,12 +511,12 @@ def run_secondary_c2(args, S, synth, ReplayEngine, torch, dev, local_rank):
     with ReplayEngine(device=local_rank) as e2:
         e2.load_csr(so, ev, None, out)
         steps = 150  # ~0.7 ms each: a > 100 ms timed region
+        dt, st, times_ms = time_folds(e2, torch, dev, S.ALGO_AUTO, steps, 5)
+        auto_states = out.clone()
         e2.prepare(S.ALGO_TILED)
         e2.synchronize()
         layout = e2.layout_info()
-        dt, st, times_ms = time_folds(e2, torch, dev, S.ALGO_TILED, steps, 5)
-        tiled_states = out.clone()
-        dt_csr, st_csr, times_csr = time_folds(e2, torch, dev, S.ALGO_AUTO, steps, 5)
+        dt_t, st_t, times_t = time_folds(e2, torch, dev, S.ALGO_TILED, steps, 5)
         return {
             "config": {"workload": f"C2: {C2_AGGREGATES} aggregates x {C2_EVENTS} events, 16 B events, 64 B state, single GPU, log resident in HBM",
                        "algo": algo_name(S, st.last_algo), "wave_tasks": st.n_tasks},
@@ -483,11 +526,12 @@ def run_secondary_c2(args, S, synth, ReplayEngine, torch, dev, local_rank):
             "steps": steps,
             "ms_per_step": dt / steps * 1e3,
             "roofline": roofline_of(S, st, times_ms),
-            "one_shot": {"index_build_ms": layout.index_build_ms, "relayout_ms": layout.relayout_ms, "tile_major_copy_bytes": layout.tiled_bytes},
-            "csr_direct": {"algo": algo_name(S, st_csr.last_algo), "kernel": kernel_name(S, st_csr.last_algo), "ms_per_step": dt_csr / steps * 1e3,
-                           "kernel_ms_min_median_max": [float(np.min(times_csr)), float(np.median(times_csr)), float(np.max(times_csr))],
-                           "frac": st_csr.algorithmic_bytes / (float(np.mean(times_csr)) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                           "states_equal_primary": bool(torch.equal(tiled_states, out))},
+            "tile_major": {"algo": algo_name(S, st_t.last_algo), "kernel": kernel_name(S, st_t.last_algo), "ms_per_step": dt_t / steps * 1e3,
+                           "kernel_ms_min_median_max": [float(np.min(times_t)), float(np.median(times_t)), float(np.max(times_t))],
+                           "frac": st_t.algorithmic_bytes / (float(np.mean(times_t)) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                           "traffic": pmc_traffic(kernel_name(S, st_t.last_algo), st_t.algorithmic_bytes),
+                           "one_shot": {"index_build_ms": layout.index_build_ms, "relayout_ms": layout.relayout_ms, "tile_major_copy_bytes": layout.tiled_bytes},
+                           "states_equal_primary": bool(torch.equal(auto_states, out))},
         }
 
 

@@ -1938,7 +1938,7 @@ int32_t surge_replay_stream_probe(surge_replay_handle* h, const void* d_src, int
     n_bytes = h->t_n_sub * (int64_t)kTileSubBytes;
   }
   float best = 0.f;
-  for (int variant = 0; variant < 3; ++variant) {  // plain / non-temporal register loads, LDS-DMA tile stream: report the fastest
+  for (int variant = 0; variant < 6; ++variant) {  // plain / non-temporal loads, the LDS-DMA tile stream at 9 / 6 / 4 waves per CU, register tiles: report the fastest
     HIPCHK(h, hipEventRecord(h->ev_h0, h->stream));
     HIPCHK(h, launch_stream_probe((const uint4*)d_src, n_bytes / 16, (uint32_t*)h->poison_count.ptr, variant, h->stream));
     HIPCHK(h, hipEventRecord(h->ev_h1, h->stream));

@@ -94,6 +94,31 @@ __global__ void __launch_bounds__(kWave) stream_probe_lds_kernel(const uint4* __
   if (acc == 0x9e3779b9u) sink[0] = acc;
 }
 
+// one wave streams a contiguous range in steps of 16 KiB held in registers (16 non-temporal dwordx4 loads per lane in flight)
+__global__ void __launch_bounds__(kWave) stream_probe_regs_kernel(const uint4* __restrict__ src, int64_t n_vec, int64_t vec_per_wave,
+                                                                  uint32_t* __restrict__ sink) {
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x;
+  const int64_t v0 = (int64_t)blockIdx.x * vec_per_wave;
+  int64_t v1 = v0 + vec_per_wave;
+  v1 = v1 < n_vec ? v1 : n_vec;
+  uint32_t acc = 0;
+  v4u r[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) r[q] = v4u{0u, 0u, 0u, 0u};
+  for (int64_t v = v0; v + 1024 <= v1; v += 1024) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc ^= r[q].x ^ r[q].w;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r[q] = __builtin_nontemporal_load((const v4u*)&src[v + q * 64 + lane]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc ^= r[q].y;
+  if (acc == 0x9e3779b9u) sink[0] = acc;
+}
+
 // ---- N3: fixed 64-byte state -> serialized text (two passes around an exclusive scan) -----------------
 struct JsonTemplateDev {
   uint32_t n_parts;
@@ -439,14 +464,22 @@ hipError_t launch_partition_hash(const uint16_t* utf16, const int64_t* str_off, 
   return hipGetLastError();
 }
 
+// variants: 0 plain / 1 non-temporal register loads, grid-stride; 2 / 3 / 4: the LDS-DMA tile stream (the folds' transport)
+// with 9 / 6 / 4 resident waves per CU; 5: 16 KiB of non-temporal register loads per wave step, 4 waves per CU (the two
+// best configurations of scripts/experiments/probe2.hip — round 3's probe only ran 0..2 and read 6.3 TB/s where these
+// read 6.8 - 7.0 on the same boxes)
 hipError_t launch_stream_probe(const uint4* src, int64_t n_vec, uint32_t* sink, int variant, hipStream_t stream) {
-  if (variant == 2) {  // LDS-DMA tile stream, one resident generation of waves
-    const int64_t waves = 256 * 9;
+  if (variant >= 2) {
+    const int64_t per_cu = variant == 2 ? 9 : variant == 3 ? 6 : 4;
+    const int64_t waves = 256 * per_cu;
     int64_t per = (n_vec / waves) / 1024 * 1024;
     if (per < 1024) per = 1024;
     const int64_t n_waves = n_vec / per;
     if (n_waves <= 0) return hipSuccess;
-    hipLaunchKernelGGL(stream_probe_lds_kernel, dim3((unsigned)n_waves), dim3(kWave), 16384, stream, src, n_vec, per, sink);
+    if (variant == 5)
+      hipLaunchKernelGGL(stream_probe_regs_kernel, dim3((unsigned)n_waves), dim3(kWave), 0, stream, src, n_vec, per, sink);
+    else
+      hipLaunchKernelGGL(stream_probe_lds_kernel, dim3((unsigned)n_waves), dim3(kWave), 16384, stream, src, n_vec, per, sink);
     return hipGetLastError();
   }
   if (variant == 1)

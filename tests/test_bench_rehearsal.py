@@ -41,8 +41,8 @@ def run_bench(tmp_path, extra, world=2, launcher="self"):
 def test_two_rank_bench_rehearsal_on_one_gpu(tmp_path, extra, algo):
     d = run_bench(tmp_path, extra)
     cfg = d["config"]
-    if algo is None:  # the Zipf log defaults to the tile-major fold and says what its one-off layout cost
-        assert cfg["algo"] == "tiled" and d["one_shot"]["relayout_ms"] > 0 and d["one_shot"]["tile_major_copy_bytes"] > 0
+    if algo is None:  # the Zipf log defaults to the fold AUTO picks straight from the CSR log: no copy of the log, only its index
+        assert cfg["algo"] in ("chunked", "sorted", "flat") and d["one_shot"]["tile_major_copy_bytes"] == 0 and d["one_shot"]["relayout_ms"] == 0
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "strong" and "rehearsal" in d
     assert d["metric"] == "events/sec replayed" and d["unit"] == "events/s" and d["higher_is_better"] is True
     assert len(cfg["per_rank_events"]) == 2 and sum(cfg["per_rank_events"]) == cfg["events"] and min(cfg["per_rank_events"]) > 0
@@ -79,6 +79,22 @@ def run_single(args):
     lines = [l for l in res.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
     assert len(lines) == 1, res.stdout[-2000:]
     return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_default_bench_line_carries_the_tile_major_fold_c2_c5_and_v2_beside_the_headline():
+    """The default invocation at a small size: the headline is the fold AUTO picks from the CSR log, `tile_major` the fold over
+    the re-laid copy with its one-off cost, `secondary` config C2 (AUTO + tile-major), `c5` / `v2` the streaming config and
+    the ABI v2 path — all timed by whoever runs bench.py, not only by a builder's own invocations."""
+    d = run_single(["--aggregates", "200000", "--steps", "5", "--warmup", "2", "--cpu-seconds", "2"])
+    assert d["config"]["algo"] in ("chunked", "sorted", "flat") and d["csr_direct"] is None
+    tm = d["tile_major"]
+    assert tm["algo"] == "tiled" and tm["states_equal_primary"] is True and tm["one_shot"]["relayout_ms"] > 0 and tm["frac"] > 0
+    sec = d["secondary"]
+    assert sec["config"]["algo"] == "rows" and sec["tile_major"]["algo"] == "tiled" and sec["tile_major"]["states_equal_primary"] is True
+    assert d["c5"]["cpu_baseline"]["gpu_matches_cpu_full_run"] is True and d["c5"]["value"] > 0
+    assert d["v2"]["cpu_baseline"]["gpu_matches_cpu_full_log"] is True and d["v2"]["roofline"]["kernel"] == "surge_slots_tiled2"
+    assert d["roofline"]["stream_read_probe_GBps"] > 1000 and d["cpu_baseline"]["gpu_matches_cpu_full_log"] is True
 
 
 @pytest.mark.gpu
