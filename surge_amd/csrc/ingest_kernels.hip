@@ -279,9 +279,11 @@ struct Lz4Work {
   int32_t* cls_list;   // [kLz4Classes + 1][n_blocks]
 };
 constexpr int kLz4Classes = 6;
-constexpr int kLz4Map = 4096;  // bytes of output one group's map may span (a power of two)
+constexpr int kLz4Map = 2048;  // bytes of output one group's map may span (a power of two; 64 sequences of play-json text span ~1 KB)
 __device__ __constant__ int32_t kLz4ClassCap[kLz4Classes] = {8192, 16384, 24576, 32768, 49152, 65536};
 static const int32_t kLz4ClassCapHost[kLz4Classes] = {8192, 16384, 24576, 32768, 49152, 65536};
+
+typedef const __attribute__((address_space(3))) uint8_t* lds_ptr_t;
 
 struct __attribute__((packed)) Unaligned16 { uint64_t lo, hi; };
 
@@ -291,10 +293,20 @@ __device__ __forceinline__ uint64_t window_bits(uint64_t lo, uint64_t hi, int b)
   return b < 64 ? low : hi >> (b & 63);
 }
 
-// one sequence of the block, byte by byte (the block's last sequence, literal runs above 12 bytes, lengths continued over
-// several bytes, the block's edge): false = malformed
-__device__ bool lz4_slow_sequence(const uint8_t* __restrict__ in, int32_t n_in, uint8_t* __restrict__ dst, int32_t& ip, int32_t& op, uint2* __restrict__ out,
-                                  int32_t& ns) {
+__device__ __forceinline__ int32_t wave_inclusive_sum(int32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int32_t u = __shfl_up(v, d, 64);
+    if (lane >= d) v += u;
+  }
+  return v;
+}
+
+// One sequence whose header does not fit the 16-byte window (literal runs above 12 bytes, lengths continued over several
+// bytes) or that ends the block: its header byte by byte out of LDS — every lane reads the same bytes, the values are
+// wave-uniform — and its literal run copied by the whole wave.  false = malformed.
+__device__ bool lz4_slow_sequence(lds_ptr_t in, int32_t n_in, uint8_t* __restrict__ dst, int32_t& ip, int32_t& op, uint2* __restrict__ out, int32_t& ns,
+                                  int lane) {
   const uint32_t token = in[ip++];
   int32_t lit = (int32_t)(token >> 4);
   if (lit == 15) {
@@ -306,10 +318,11 @@ __device__ bool lz4_slow_sequence(const uint8_t* __restrict__ in, int32_t n_in, 
     } while (x == 255u && lit < (1 << 24));
   }
   if (lit > n_in - ip || lit > kLz4BlockMax - op) return false;  // (n_in < 64 KiB: a length always fits 16 bits)
-  for (int32_t j = 0; j < lit; ++j) dst[op + j] = in[ip + j];
+  for (int32_t j = lane; j < lit; j += 64) dst[op + j] = in[ip + j];
   ip += lit;
   if (ip >= n_in) {  // the last sequence carries literals only
-    out[ns++] = make_uint2((uint32_t)op | ((uint32_t)lit << 16), 0u);
+    if (lane == 0) out[ns] = make_uint2((uint32_t)op | ((uint32_t)lit << 16), 0u);
+    ++ns;
     op += lit;
     return true;
   }
@@ -329,68 +342,115 @@ __device__ bool lz4_slow_sequence(const uint8_t* __restrict__ in, int32_t n_in, 
   const int32_t D = op + lit;
   // offset <= D and offset >= 1 make D >= 1, so a match that fits the block is at most 65535 long
   if (offset == 0 || offset > D || ml > kLz4BlockMax - D) return false;
-  out[ns++] = make_uint2((uint32_t)op | ((uint32_t)lit << 16), (uint32_t)ml | ((uint32_t)offset << 16));
+  if (lane == 0) out[ns] = make_uint2((uint32_t)op | ((uint32_t)lit << 16), (uint32_t)ml | ((uint32_t)offset << 16));
+  ++ns;
   op = D + ml;
   return true;
 }
 
+// Pass 1, one WAVE per block.  Where a sequence starts is only known once the one before it is decoded — but decoding a
+// header is cheap, so every lane decodes the header that WOULD start at its byte of the current 64-byte window of the
+// compressed block (staged in LDS), and the wave then follows the chain of real starts through those 64 candidates with
+// v_readlane (a play-json block has a sequence every ~5 bytes: a dozen real ones per window).  The real lanes get their
+// output positions from a wave prefix sum, write their table entries side by side and store their literal bytes.  (The
+// first version gave every block ONE LANE that walked its headers alone: ~150 dependent instructions per sequence on a
+// wave that has the SIMD to itself — 0.9 ms per 1 M records however the loads were arranged.)  A wave takes its block
+// when lo_excl < staged bytes <= cap (two launches: 8 KiB of LDS, 20 waves per CU, for the batches a 16 KiB producer
+// writes; 64 KiB for the rest).
 __global__ void __launch_bounds__(64) lz4_parse_kernel(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ out_base, const Lz4Block* __restrict__ blocks,
-                                                       int32_t n_blocks, Lz4Work w, Section* __restrict__ sections, ErrorCell* err) {
-  const int32_t b = (int32_t)(blockIdx.x * 64u + threadIdx.x);
-  if (b >= n_blocks) return;
+                                                       int32_t n_blocks, Lz4Work w, Section* __restrict__ sections, ErrorCell* err, int32_t lo_excl, int32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lz4_in[];
+  const int lane = threadIdx.x;
+  const int32_t b = (int32_t)blockIdx.x;
   const Lz4Block blk = blocks[b];
   if (blk.seq_off < 0) return;  // the one-pass kernel's
-  const uint8_t* __restrict__ in = bytes + blk.src_off;
-  uint8_t* __restrict__ dst = out_base + blk.dst_off;
   const int32_t n_in = blk.src_len & 0x7fffffff;
+  const bool stored = blk.src_len < 0;
+  const int32_t skew = (int32_t)(blk.src_off & 15);
+  const int32_t need_lds = stored ? 0 : skew + n_in + 48;
+  if (!(need_lds > lo_excl && need_lds <= cap)) return;
+  uint8_t* __restrict__ dst = out_base + blk.dst_off;
   int32_t op = 0, ns = 0;
   bool ok = true;
   int32_t cls = kLz4Classes;  // stored
-  if (blk.src_len < 0) {
+  if (stored) {
     op = n_in;
     ok = n_in <= kLz4BlockMax;
   } else {
+    {  // the block's bytes, from the 16-byte line its first byte lies in (the staged bytes end 64 bytes after their last byte)
+      const uint4* src = (const uint4*)(bytes + blk.src_off - skew);
+      const int n16 = (skew + n_in + 47) >> 4;
+      for (int i = lane; i < n16; i += 64) ((uint4*)lz4_in)[i] = src[i];
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const lds_ptr_t in = (lds_ptr_t)lz4_in + skew;
+    const uint32_t* in32 = (const uint32_t*)lz4_in;
     uint2* __restrict__ out = w.seq + blk.seq_off;
-    int32_t ip = 0;
-    while (ip < n_in) {
-      // (the staged bytes end 64 bytes after their last byte: the load may run past the block, never past the buffer.  Cutting
-      // several sequences out of one wider register window — 32 bytes unaligned, 48 bytes aligned — was tried: 0.95 and
-      // 1.19 ms against 0.85: with one wave per SIMD the walk is bound by its instruction count, not by the load)
-      Unaligned16 win;
-      __builtin_memcpy(&win, in + ip, 16);
-      const uint32_t token = (uint32_t)win.lo & 0xffu;
+    int32_t base = 0, t0 = 0;
+    while (ok && base + t0 < n_in) {
+      const int32_t q = base + lane;
+      // the 16 bytes from this lane's position on: five aligned dwords, shifted into place
+      const uint32_t A = (uint32_t)(skew + q);
+      const uint32_t* d = in32 + (A >> 2);
+      const uint32_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
+      const uint32_t shb = A & 3u;
+      const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, shb), w1 = __builtin_amdgcn_alignbyte(d2, d1, shb);
+      const uint32_t w2 = __builtin_amdgcn_alignbyte(d3, d2, shb), w3 = __builtin_amdgcn_alignbyte(d4, d3, shb);
+      const uint64_t lo = (uint64_t)w0 | ((uint64_t)w1 << 32), hi = (uint64_t)w2 | ((uint64_t)w3 << 32);
+      const uint32_t token = w0 & 0xffu;
       const int32_t lit = (int32_t)(token >> 4), mlc = (int32_t)(token & 15u);
       const int32_t need = 3 + lit + (mlc == 15 ? 1 : 0);
-      const uint32_t tail = (uint32_t)window_bits(win.lo, win.hi, 8 * (1 + lit));  // offset (16 bits), then the length byte
-      bool fast = lit <= 12 && need <= n_in - ip && lit <= kLz4BlockMax - op && !(mlc == 15 && ((tail >> 16) & 0xffu) == 255u);
-      // (the block's last, literal-only sequence has no room for an offset and takes the slow path)
-      if (fast) {
-        if (lit > 0) {
-          if (op + 16 <= kLz4BlockMax) {  // 16 bytes where the literals go: what follows them is overwritten by the match / the next literals
-            Unaligned16 lits;
-            lits.lo = (win.lo >> 8) | (win.hi << 56);
-            lits.hi = win.hi >> 8;
-            __builtin_memcpy(dst + op, &lits, 16);
-          } else {
-            for (int j = 0; j < lit; ++j) dst[op + j] = (uint8_t)window_bits(win.lo, win.hi, 8 * (1 + j));
-          }
-        }
-        const int32_t offset = (int32_t)(tail & 0xffffu);
-        const int32_t ml = mlc + 4 + (mlc == 15 ? (int32_t)((tail >> 16) & 0xffu) : 0);
-        const int32_t D = op + lit;
-        if (offset == 0 || offset > D || ml > kLz4BlockMax - D) { ok = false; break; }
-        out[ns++] = make_uint2((uint32_t)op | ((uint32_t)lit << 16), (uint32_t)ml | ((uint32_t)offset << 16));
-        ip += need;
-        op = D + ml;
-      } else if (!lz4_slow_sequence(in, n_in, dst, ip, op, out, ns)) {
-        ok = false;
-        break;
+      const uint32_t tail = (uint32_t)window_bits(lo, hi, 8 * (1 + (lit & 15)));  // offset (16 bits), then the length byte
+      // (the block's last, literal-only sequence has no room for an offset: not simple)
+      const bool simple = q < n_in && lit <= 12 && need <= n_in - q && !(mlc == 15 && ((tail >> 16) & 0xffu) == 255u);
+      const int32_t offset = (int32_t)(tail & 0xffffu);
+      const int32_t ml = mlc + 4 + (mlc == 15 ? (int32_t)((tail >> 16) & 0xffu) : 0);
+      const int32_t nxt = lane + need;
+      // the chain of real sequence starts through this window
+      const unsigned long long smask = __ballot(simple);
+      unsigned long long real = 0ull;
+      int32_t t = t0;
+      while (t < 64 && ((smask >> t) & 1ull)) {
+        real |= 1ull << t;
+        t = __builtin_amdgcn_readlane(nxt, t);
+      }
+      const bool is_real = (real >> lane) & 1ull;
+      const int32_t v = is_real ? lit + ml : 0;
+      const int32_t incl = wave_inclusive_sum(v, lane);
+      const int32_t my_op = op + incl - v, D = my_op + lit;
+      const bool bad = is_real && (lit > kLz4BlockMax - my_op || offset == 0 || offset > D || ml > kLz4BlockMax - D);
+      if (__any(bad)) { ok = false; break; }
+      if (is_real) {
+        const int32_t rank = __builtin_popcountll(real & ((1ull << lane) - 1ull));
+        out[ns + rank] = make_uint2((uint32_t)my_op | ((uint32_t)lit << 16), (uint32_t)ml | ((uint32_t)offset << 16));
+      }
+      // the literal bytes, exactly (two sequences of one window may lie closer together than a wide store is long)
+      {
+        const int32_t my_lit = is_real ? lit : 0;
+        const uint64_t lits_lo = (lo >> 8) | (hi << 56), lits_hi = hi >> 8;
+        for (int32_t j = 0; __any(j < my_lit); ++j)
+          if (j < my_lit) dst[my_op + j] = (uint8_t)((j < 8 ? lits_lo : lits_hi) >> (8 * (j & 7)));
+      }
+      ns += __builtin_popcountll(real);
+      op += __builtin_amdgcn_readlane(incl, 63);
+      if (t >= 64) {
+        base += 64;
+        t0 = t - 64;
+      } else {
+        int32_t ip = base + t;
+        if (ip >= n_in) break;
+        // (stores of this wave to one address keep their order: the literal bytes written above are not overtaken)
+        if (!lz4_slow_sequence(in, n_in, dst, ip, op, out, ns, lane)) { ok = false; break; }
+        base = ip & ~63;
+        t0 = ip & 63;
       }
     }
     cls = 0;
     while (cls < kLz4Classes - 1 && op > kLz4ClassCap[cls]) ++cls;
   }
   if (ok && !blk.last && op != kLz4BlockMax) ok = false;  // every block of a frame but its last is exactly full
+  if (lane != 0) return;
   w.n_seq[b] = ns;
   if (!ok) {
     w.state[b] = -1;
@@ -445,12 +505,22 @@ __global__ void __launch_bounds__(64) lz4_exec_kernel(const uint8_t* __restrict_
           const int32_t pos = p + lane;
           const bool act = pos < g1;
           const int32_t src = act ? (int32_t)map[pos & (kLz4Map - 1)] : pos;
-          // bytes of this window that copy from this window: a chain of them is at most that many long
-          const unsigned long long dep = __ballot(act && src >= p && src != pos);
-          const int n_it = dep ? __builtin_popcountll(dep) + 1 : 1;
-          for (int it = 0; it < n_it; ++it) {
+          // Bytes that copy from THIS window wait for their source: first everything whose source lies below the window (or is
+          // the byte itself: a literal), then, round by round, the bytes whose source was written in the round before — as
+          // many rounds as the longest chain inside the window is deep (one or two; the first version ran one round per
+          // dependent BYTE: a 13-byte match at offset 20 cost 14 rounds).
+          const bool dep = act && src >= p && src != pos;
+          bool done = !dep;
+          {
             const uint8_t v = lz4_out[src];
-            if (act) lz4_out[pos] = v;
+            if (act && !dep) lz4_out[pos] = v;
+          }
+          while (__any(!done)) {
+            const bool src_done = __shfl((int)done, (src - p) & 63, 64) != 0;
+            const bool can = !done && src_done;
+            const uint8_t v = lz4_out[src];
+            if (can) lz4_out[pos] = v;
+            done = done || can;
           }
         }
       } else {
@@ -485,7 +555,6 @@ __global__ void __launch_bounds__(64) lz4_exec_kernel(const uint8_t* __restrict_
 // section into LDS with 16-byte loads, one thread walks the length varints there (the only sequential step, now at LDS
 // latency), then every thread parses its record and decodes its value from LDS.  A section that does not fit the LDS of
 // its launch is read in place (same code, global pointers).
-typedef const __attribute__((address_space(3))) uint8_t* lds_ptr_t;
 
 template <typename P>
 struct ReaderT {
@@ -493,6 +562,17 @@ struct ReaderT {
   P end;
   bool ok;
   __device__ int64_t varlong() {
+    // one and two bytes without the loop: a record's length, its key / value lengths and its offset delta almost always
+    // (the counters put most of section_kernel's scalar instructions into the exec-mask bookkeeping of these loops)
+    if (end - p >= 2) {
+      const uint32_t b0 = p[0], b1 = p[1];
+      if (!(b0 & 0x80u)) { ++p; return (int64_t)(b0 >> 1) ^ -(int64_t)(b0 & 1u); }
+      if (!(b1 & 0x80u)) {
+        p += 2;
+        const uint32_t w = (b0 & 0x7fu) | (b1 << 7);
+        return (int64_t)(w >> 1) ^ -(int64_t)(w & 1u);
+      }
+    }
     uint64_t v = 0;
     int shift = 0;
     while (true) {
@@ -506,16 +586,22 @@ struct ReaderT {
   }
 };
 
-// 64-bit hash of an aggregate id under the table's seed (a re-seed follows a detected collision); 0 marks an empty slot
-template <typename P>
-__device__ __forceinline__ uint64_t hash_key(P p, int n, uint64_t seed) {
-  uint64_t h = (0x9E3779B97F4A7C15ull ^ (uint64_t)n) + seed * 0xC2B2AE3D27D4EB4Full;
-  for (int i = 0; i < n; ++i) h = (h ^ p[i]) * 0x100000001B3ull;
+// 64-bit hash of an aggregate id under the table's seed (a re-seed follows a detected collision); 0 marks an empty slot.
+// (begin / end: the record parser hashes the id while it looks for its ':')
+__device__ __forceinline__ uint64_t hash_key_begin(uint64_t seed) { return 0x9E3779B97F4A7C15ull + seed * 0xC2B2AE3D27D4EB4Full; }
+__device__ __forceinline__ uint64_t hash_key_end(uint64_t h, int n, uint64_t seed) {
+  h ^= (uint64_t)n * 0xFF51AFD7ED558CCDull;
   h ^= h >> 29;
   h *= 0xD6E8FEB86659FD93ull;
   h ^= h >> 32;
   if (seed >> 63) h &= 0xffull;  // test hook (SURGE_INGEST_DEBUG_WEAK_HASH): collisions guaranteed until the first re-seed
   return h == 0ull ? 1ull : h;
+}
+template <typename P>
+__device__ __forceinline__ uint64_t hash_key(P p, int n, uint64_t seed) {
+  uint64_t h = hash_key_begin(seed);
+  for (int i = 0; i < n; ++i) h = (h ^ p[i]) * 0x100000001B3ull;
+  return hash_key_end(h, n, seed);
 }
 
 // ---- event values ------------------------------------------------------------------------------------------------------
@@ -730,10 +816,20 @@ __device__ uint32_t decode_json_event(const EvjDevice* __restrict__ t, const sur
   return status;
 }
 
+// (Tried in round 4 and dropped: the same grammar as a table-driven automaton — one loop over the bytes in lockstep, next
+// state looked up by (state, byte) in LDS, field names recognised by length + hash and verified afterwards, this walk as
+// the fallback.  It traded the walk's scalar exec-mask bookkeeping for twice the vector instructions: section_kernel
+// alone 0.70 -> 0.77 ms per 1 M records.  The counters say where this kernel's scalar work really is: chaining and
+// parsing the varint-framed records, not the JSON.)
+struct JsonCtx {  // what the value decoder needs besides the value
+  const EvjDevice* tmpl;  // nullptr: 16-byte fixed events
+  const surge::F64ParseTable* ptab;
+};
+
 // a record value -> event16 + status
 template <typename P>
-__device__ __forceinline__ uint32_t decode_value(const EvjDevice* __restrict__ tmpl, const surge::F64ParseTable* ptab, P vp, int val_len, uint4* e) {
-  if (tmpl) return decode_json_event(tmpl, ptab, vp, val_len, e);
+__device__ __forceinline__ uint32_t decode_value(const JsonCtx& jc, P vp, int val_len, uint4* e) {
+  if (jc.tmpl) return decode_json_event(jc.tmpl, jc.ptab, vp, val_len, e);
   if (val_len != 16) return RS_SIZE;
   uint32_t w[4];
   for (int q = 0; q < 4; ++q) w[q] = (uint32_t)vp[4 * q] | ((uint32_t)vp[4 * q + 1] << 8) | ((uint32_t)vp[4 * q + 2] << 16) | ((uint32_t)vp[4 * q + 3] << 24);
@@ -741,15 +837,19 @@ __device__ __forceinline__ uint32_t decode_value(const EvjDevice* __restrict__ t
   return RS_OK;
 }
 
-// one record body [body, end) of a section that starts at `base` (absolute offset sec_off in the staged bytes)
+// One record body [body, end) of a section that starts at `base` (absolute offset sec_off in the staged bytes); `valid` =
+// this lane has a record.
 template <typename P>
-__device__ __forceinline__ void decode_record(P base, int64_t sec_off, int64_t base_offset, int32_t body, int32_t end, int64_t gi, uint64_t seed,
-                                              const EvjDevice* __restrict__ tmpl, const surge::F64ParseTable* ptab, RecMeta* __restrict__ meta,
-                                              uint4* __restrict__ ev_tmp, uint32_t* __restrict__ f64_host_list, ErrorCell* err) {
+__device__ __forceinline__ void decode_record(P base, int64_t sec_off, int64_t base_offset, bool valid, int32_t body, int32_t end, int64_t gi, uint64_t seed,
+                                              const JsonCtx& jc, RecMeta* __restrict__ meta, uint4* __restrict__ ev_tmp,
+                                              uint32_t* __restrict__ f64_host_list, ErrorCell* err) {
   RecMeta m;
   m.key_off = m.val_off = m.offset = 0; m.hash = 0; m.key_len = m.val_len = 0; m.slot = 0; m.status = RS_MALFORMED;
   uint4 e = make_uint4(0, 0, 0, 0);
-  if (body >= 0) {
+  bool has_value = false;
+  P val = base;
+  int vlen32 = 0;
+  if (valid && body >= 0) {
     ReaderT<P> q{base + body, base + end, true};
     if (q.p < q.end) ++q.p; else q.ok = false;  // attributes
     (void)q.varlong();                            // timestampDelta
@@ -758,7 +858,7 @@ __device__ __forceinline__ void decode_record(P base, int64_t sec_off, int64_t b
     P key = q.p;
     if (q.ok && klen > 0) { if (q.end - q.p >= klen) q.p += klen; else q.ok = false; }
     const int64_t vlen = q.ok ? q.varlong() : 0;
-    P val = q.p;
+    val = q.p;
     if (q.ok && vlen > 0) { if (q.end - q.p >= vlen) q.p += vlen; else q.ok = false; }
     // (headers follow; the chain already knows where the record ends)
     if (q.ok && klen >= -1 && vlen >= -1 && klen < (1ll << 31) && vlen < (1ll << 31)) {
@@ -769,28 +869,38 @@ __device__ __forceinline__ void decode_record(P base, int64_t sec_off, int64_t b
         m.status = RS_NULL;
       } else {
         int n = 0;
-        while (n < (int)klen && key[n] != (uint8_t)':') ++n;  // PartitionStringUpToColon (KafkaPartitioner.scala:38-42)
+        uint64_t hk = hash_key_begin(seed);
+        for (; n < (int)klen; ++n) {  // PartitionStringUpToColon (KafkaPartitioner.scala:38-42), hashed on the way
+          const uint8_t c = key[n];
+          if (c == (uint8_t)':') break;
+          hk = (hk ^ c) * 0x100000001B3ull;
+        }
         m.key_off = sec_off + (key - base);
         m.key_len = n;
         m.val_off = sec_off + (val - base);
         m.val_len = (int32_t)vlen;
-        m.hash = hash_key(key, n, seed);
-        uint32_t st = decode_value(tmpl, ptab, val, (int)vlen, &e);
-        if (st == RS_F64_HOST) {
-          f64_host_list[atomicAdd(&err->n_f64_host, 1u)] = (uint32_t)gi;
-          st = RS_OK;
-        }
-        m.status = st;
+        m.hash = hash_key_end(hk, n, seed);
+        has_value = true;
+        vlen32 = (int32_t)vlen;
       }
     }
   }
+  if (has_value) {
+    uint32_t st = decode_value(jc, val, vlen32, &e);
+    if (st == RS_F64_HOST) {
+      f64_host_list[atomicAdd(&err->n_f64_host, 1u)] = (uint32_t)gi;
+      st = RS_OK;
+    }
+    m.status = st;
+  }
+  if (!valid) return;
   if (m.status >= RS_NULL) report(err, gi, m.status);
   meta[gi] = m;
   ev_tmp[gi] = e;
 }
 
 constexpr int kSecThreads = 256;
-constexpr int kSecRecs = 512;  // records chained per round (LDS: two int32 per record)
+constexpr int kSecRecs = 256;  // records chained per round (LDS: two int32 per record; a 16 KiB batch holds ~140 events)
 
 // the length varints of up to kSecRecs records from relative position *pos on; false = unreadable from record `bad` on
 template <typename P>
@@ -810,9 +920,9 @@ __device__ bool chain_records(P base, int32_t len, int32_t* pos, int32_t cnt, in
 
 // A workgroup takes its section when lo_excl < byte_len and (byte_len <= cap or take_rest); byte_len <= cap is staged.
 __global__ void __launch_bounds__(kSecThreads) section_kernel(const uint8_t* __restrict__ bytes, const Section* __restrict__ sections, int64_t n_sections,
-                                                              int64_t lo_excl, int64_t cap, int32_t take_rest, uint64_t seed,
-                                                              const EvjDevice* __restrict__ tmpl, const surge::F64ParseTable* ptab, RecMeta* __restrict__ meta,
-                                                              uint4* __restrict__ ev_tmp, uint32_t* __restrict__ f64_host_list, ErrorCell* err) {
+                                                              int64_t lo_excl, int64_t cap, int32_t take_rest, uint64_t seed, JsonCtx jc,
+                                                              RecMeta* __restrict__ meta, uint4* __restrict__ ev_tmp, uint32_t* __restrict__ f64_host_list,
+                                                              ErrorCell* err) {
   extern __shared__ __attribute__((aligned(16))) uint8_t sec_smem[];
   __shared__ int32_t s_pos, s_bad;
   const Section sec = sections[blockIdx.x];
@@ -831,8 +941,8 @@ __global__ void __launch_bounds__(kSecThreads) section_kernel(const uint8_t* __r
   if (threadIdx.x == 0) { s_pos = 0; s_bad = -1; }
   __syncthreads();
   if (len >= (1ll << 31)) {  // a section of 2 GiB: nothing writes one (a batch's length is an int32)
-    for (int32_t i = threadIdx.x; i < sec.n_records; i += kSecThreads)
-      decode_record(bytes, 0, 0, -1, -1, sec.rec_first + i, seed, tmpl, ptab, meta, ev_tmp, f64_host_list, err);
+    for (int32_t i0 = 0; i0 < sec.n_records; i0 += kSecThreads)
+      decode_record(bytes, 0, 0, i0 + (int32_t)threadIdx.x < sec.n_records, -1, -1, sec.rec_first + i0 + threadIdx.x, seed, jc, meta, ev_tmp, f64_host_list, err);
     return;
   }
   const lds_ptr_t lbase = (lds_ptr_t)sec_smem + skew;
@@ -855,12 +965,14 @@ __global__ void __launch_bounds__(kSecThreads) section_kernel(const uint8_t* __r
       }
     }
     __syncthreads();
-    for (int32_t i = threadIdx.x; i < cnt; i += kSecThreads) {
-      const int32_t body = rec_body[i], end = body >= 0 ? rec_end[i] : -1;
+    for (int32_t i0 = 0; i0 < cnt; i0 += kSecThreads) {
+      const int32_t i = i0 + (int32_t)threadIdx.x;
+      const bool valid = i < cnt;
+      const int32_t body = valid ? rec_body[i] : -1, end = body >= 0 ? rec_end[i] : -1;
       if (staged)
-        decode_record(lbase, sec.byte_off, sec.base_offset, body, end, sec.rec_first + r0 + i, seed, tmpl, ptab, meta, ev_tmp, f64_host_list, err);
+        decode_record(lbase, sec.byte_off, sec.base_offset, valid, body, end, sec.rec_first + r0 + i, seed, jc, meta, ev_tmp, f64_host_list, err);
       else
-        decode_record(gbase, sec.byte_off, sec.base_offset, body, end, sec.rec_first + r0 + i, seed, tmpl, ptab, meta, ev_tmp, f64_host_list, err);
+        decode_record(gbase, sec.byte_off, sec.base_offset, valid, body, end, sec.rec_first + r0 + i, seed, jc, meta, ev_tmp, f64_host_list, err);
     }
     __syncthreads();
   }
@@ -868,28 +980,35 @@ __global__ void __launch_bounds__(kSecThreads) section_kernel(const uint8_t* __r
 
 // records that arrive already framed (a JVM's ConsumerRecords: key bytes, value bytes, offset per record): the bytes buffer
 // holds the keys first, the values from `val_base` on
-__global__ void records_kernel(const uint8_t* __restrict__ bytes, const int64_t* __restrict__ key_off, const int64_t* __restrict__ val_off,
-                               const int64_t* __restrict__ offsets, int64_t val_base, int64_t n_rec, uint64_t seed, const EvjDevice* __restrict__ tmpl,
-                               const surge::F64ParseTable* ptab, RecMeta* __restrict__ meta, uint4* __restrict__ ev_tmp, uint32_t* __restrict__ f64_host_list,
-                               ErrorCell* err) {
+__global__ void __launch_bounds__(256) records_kernel(const uint8_t* __restrict__ bytes, const int64_t* __restrict__ key_off, const int64_t* __restrict__ val_off,
+                                                      const int64_t* __restrict__ offsets, int64_t val_base, int64_t n_rec, uint64_t seed, JsonCtx jc,
+                                                      RecMeta* __restrict__ meta, uint4* __restrict__ ev_tmp, uint32_t* __restrict__ f64_host_list, ErrorCell* err) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_rec) return;
+  const bool valid = i < n_rec;
   RecMeta m;
-  const int64_t k0 = key_off[i], k1 = key_off[i + 1], v0 = val_off[i], v1 = val_off[i + 1];
-  m.key_off = k0; m.val_off = val_base + v0; m.offset = offsets ? offsets[i] : i; m.hash = 0; m.key_len = 0; m.val_len = 0; m.slot = 0;
+  m.key_off = m.val_off = m.offset = 0; m.hash = 0; m.key_len = m.val_len = 0; m.slot = 0; m.status = RS_MALFORMED;
   uint4 e = make_uint4(0, 0, 0, 0);
-  if (k1 < k0 || v1 < v0 || k1 - k0 >= (1ll << 31) || v1 - v0 >= (1ll << 31)) {
-    m.status = RS_MALFORMED;
-  } else if (k1 == k0 && v1 == v0) {
-    m.status = RS_SKIP;  // the producer's flush record
-  } else {
-    const uint8_t* key = bytes + k0;
-    int n = 0;
-    while (n < (int)(k1 - k0) && key[n] != (uint8_t)':') ++n;
-    m.key_len = n;
-    m.val_len = (int32_t)(v1 - v0);
-    m.hash = hash_key(key, n, seed);
-    uint32_t st = decode_value(tmpl, ptab, bytes + m.val_off, m.val_len, &e);
+  bool has_value = false;
+  if (valid) {
+    const int64_t k0 = key_off[i], k1 = key_off[i + 1], v0 = val_off[i], v1 = val_off[i + 1];
+    m.key_off = k0; m.val_off = val_base + v0; m.offset = offsets ? offsets[i] : i;
+    if (k1 < k0 || v1 < v0 || k1 - k0 >= (1ll << 31) || v1 - v0 >= (1ll << 31)) {
+      m.status = RS_MALFORMED;
+    } else if (k1 == k0 && v1 == v0) {
+      m.status = RS_SKIP;  // the producer's flush record
+    } else {
+      const uint8_t* key = bytes + k0;
+      int n = 0;
+      while (n < (int)(k1 - k0) && key[n] != (uint8_t)':') ++n;
+      m.key_len = n;
+      m.val_len = (int32_t)(v1 - v0);
+      m.hash = hash_key(key, n, seed);
+      has_value = true;
+    }
+  }
+  if (!valid) return;
+  if (has_value) {
+    uint32_t st = decode_value(jc, bytes + m.val_off, m.val_len, &e);
     if (st == RS_F64_HOST) {
       f64_host_list[atomicAdd(&err->n_f64_host, 1u)] = (uint32_t)i;
       st = RS_OK;
@@ -1530,8 +1649,12 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
       w.cls_count = (int32_t*)s.lz4_cls.p;
       w.cls_list = w.cls_count + (kLz4Classes + 1);
       DCHK(d, hipMemsetAsync(w.cls_count, 0, (kLz4Classes + 1) * 4, st));
-      hipLaunchKernelGGL(lz4_parse_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st, dby, (uint8_t*)s.d_bytes.p + area_base, (const Lz4Block*)s.lz4_blocks.p,
-                         (int32_t)nb, w, dsec, derr);
+      {
+        const int32_t caps[2] = {8192, kLz4BlockMax + 64};  // LDS of the two launches of the first pass (a block of the 16 KiB producer compresses to ~5 KiB)
+        for (int c = 0; c < 2; ++c)
+          hipLaunchKernelGGL(lz4_parse_kernel, dim3((unsigned)nb), dim3(64), (size_t)caps[c], st, dby, (uint8_t*)s.d_bytes.p + area_base, (const Lz4Block*)s.lz4_blocks.p,
+                             (int32_t)nb, w, dsec, derr, c == 0 ? -1 : caps[0], caps[c]);
+      }
       for (int c = 0; c <= kLz4Classes; ++c) {
         const int32_t cap = c < kLz4Classes ? kLz4ClassCapHost[c] : 0;
         const size_t lds = cap ? (size_t)cap + 64 + (size_t)kLz4Map * 2 : 0;
@@ -1551,15 +1674,15 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
     // synchronisation, before anything is committed)
   }
   lap("lz4 launches");
-  // chain + parse + decode, one workgroup per batch: sections up to 20 KiB (the reference producer closes a batch at 16 KiB)
-  // out of 24 KiB of LDS, the rest out of 68 KiB or, beyond 64 KiB, in place
+  // chain + parse + decode, one workgroup per batch: sections up to 16.25 KiB (the reference producer closes a batch at 16 KiB)
+  // out of 18.3 KiB of LDS (8 workgroups per CU), the rest out of 66 KiB or, beyond 64 KiB, in place
   {
-    const EvjDevice* dt = d->json ? (const EvjDevice*)d->d_tmpl.p : nullptr;
-    const int64_t caps[2] = {20480, 65536};
+    JsonCtx jc{d->json ? (const EvjDevice*)d->d_tmpl.p : nullptr, (const surge::F64ParseTable*)d->d_ptab.p};
+    const int64_t caps[2] = {16640, 65536};
     for (int c = 0; c < 2; ++c) {
       const size_t lds = (size_t)((caps[c] + 47) & ~15ll) + 2 * (size_t)kSecRecs * 4;
       hipLaunchKernelGGL(section_kernel, dim3((unsigned)total_sections), dim3(kSecThreads), lds, st, dby, (const Section*)dsec, total_sections, c == 0 ? -1 : caps[0],
-                         caps[c], c == 1 ? 1 : 0, d->seed, dt, (const surge::F64ParseTable*)d->d_ptab.p, dmeta, (uint4*)s.ev_tmp.p, (uint32_t*)s.f64_list.p, derr);
+                         caps[c], c == 1 ? 1 : 0, d->seed, jc, dmeta, (uint4*)s.ev_tmp.p, (uint32_t*)s.f64_list.p, derr);
     }
     DCHK(d, hipGetLastError());
   }
@@ -1607,8 +1730,8 @@ int32_t stage1_records(surge_device_decoder* d, PushSlot& s, const uint8_t* keys
   if (offsets) DCHK(d, hipMemcpyAsync(s.rec_c.p, p_of, (size_t)n * 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(records_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)s.d_bytes.p, (const int64_t*)s.rec_a.p,
                      (const int64_t*)s.rec_b.p, offsets ? (const int64_t*)s.rec_c.p : nullptr, kb, n, d->seed,
-                     d->json ? (const EvjDevice*)d->d_tmpl.p : nullptr, (const surge::F64ParseTable*)d->d_ptab.p, (RecMeta*)s.meta.p, (uint4*)s.ev_tmp.p,
-                     (uint32_t*)s.f64_list.p, (ErrorCell*)s.d_err.p);
+                     JsonCtx{d->json ? (const EvjDevice*)d->d_tmpl.p : nullptr, (const surge::F64ParseTable*)d->d_ptab.p},
+                     (RecMeta*)s.meta.p, (uint4*)s.ev_tmp.p, (uint32_t*)s.f64_list.p, (ErrorCell*)s.d_err.p);
   DCHK(d, hipGetLastError());
   s.n_rec = n;
   s.seed = d->seed;

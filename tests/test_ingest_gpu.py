@@ -247,6 +247,82 @@ def test_device_decoder_decodes_play_json_counter_and_bank_account_events_like_t
 
 
 @pytest.mark.gpu
+def test_the_fast_json_walk_accepts_and_decodes_exactly_what_the_host_decoder_does_on_mutated_values():
+    """The device decodes event values with a table-driven automaton (one loop over the bytes, in lockstep) that only ever
+    accepts, and falls back to the exact walk otherwise.  Held to the host decoder on values mutated every which way:
+    whitespace, reordered / duplicated / escaped field names, nested values, odd number spellings, truncations, stray
+    bytes — every value the host accepts decodes to the same event, every value it rejects fails the push."""
+    rng = random.Random(13)
+    tmpl = CounterBusinessLogic().command_model().event_json_template()
+    from surge_amd.ingest import IngestError as IE
+
+    def base():
+        agg, seq, arg = f"a{rng.randrange(50)}", rng.randrange(-5, 2 ** 31 + 3), rng.randrange(-2 ** 31 - 3, 2 ** 31 + 3)  # (a few beyond Int)
+        kind = rng.randrange(3)
+        fields = [("aggregateId", json.dumps(agg))]
+        if kind == 0:
+            fields.append(("incrementBy", str(arg)))
+        if kind == 1:
+            fields.append(("decrementBy", str(arg)))
+        fields += [("sequenceNumber", str(seq)), ("_type", json.dumps(["countIncremented", "countDecremented", "no-op"][kind]))]
+        return fields
+
+    def render(fields):
+        ws = lambda: rng.choice(["", "", "", " ", "\n", "\t "])  # noqa: E731
+        body = ",".join(f'{ws()}"{k}"{ws()}:{ws()}{v}{ws()}' for k, v in fields)
+        return (ws() + "{" + body + "}" + ws()).encode()
+
+    values = []
+    for _ in range(6000):
+        f = base()
+        r = rng.random()
+        if r < 0.15:
+            rng.shuffle(f)
+        elif r < 0.25:
+            f.insert(rng.randrange(len(f) + 1), rng.choice([("extra", '{"a":[1,"}",{"b":null}],"c":"\\\""}'), ("sequenceNumber", '"7"'), ("sequenceNumber", "9"),
+                                                             ("_type", '"no-op"'), ("_type", "5"), ("incrementBy", "1e3"), ("incrementBy", "+5"), ("x", "true"),
+                                                             ("se\\u0071uenceNumber", "4"), ("y", "[]"), ("z", ".5"), ("w", "-"), ("v", "tru"), ("u", "nul1")]))
+        elif r < 0.30:
+            f = f * 7  # more than 24 fields
+        v = render(f)
+        r = rng.random()
+        if r < 0.12:  # a byte-level mutation
+            b = bytearray(v)
+            k = rng.randrange(len(b))
+            op = rng.randrange(3)
+            if op == 0:
+                del b[k]
+            elif op == 1:
+                b.insert(k, rng.choice(b' {}[]",:\\\\0-e.tx'))
+            else:
+                b[k] = rng.choice(b' {}[]",:\\\\0-e.tx')
+            v = bytes(b)
+        elif r < 0.15:
+            v = v[: rng.randrange(len(v))]
+        values.append(v)
+    good, bad, want = [], [], []
+    for v in values:
+        try:
+            want.append(tmpl.decode(v))
+            good.append(v)
+        except IE:
+            bad.append(v)
+    assert len(good) > 4000 and len(bad) > 300
+    with DeviceDecoder(tmpl) as d:
+        d.push_records([b"k%d:1" % (i % 97) for i in range(len(good))], good)
+        ev = d.result()[1].cpu().numpy().view(S.EVENT_DTYPE).reshape(-1)
+        assert ev.tobytes() == np.array(want, dtype=S.EVENT_DTYPE).tobytes()
+        for v in bad[:120]:
+            with pytest.raises(IE):
+                d.push_records([b"k:1", b"j:1"], [good[0], v])
+        assert d.result()[0].shape[0] == len(good)  # the failed pushes appended nothing
+    # the same through the wire path (values staged in LDS)
+    wire = b"".join(kw.record_batch(s0, [(b"k%d:1" % (i % 97), v) for i, v in enumerate(good[s0:s0 + 150], s0)]) for s0 in range(0, len(good), 150))
+    host, host_keys, dev, dev_keys, _ = both_decoders(wire, tmpl)
+    assert dev_keys == host_keys and all(h.tobytes() == g.tobytes() for h, g in zip(host, dev)) and dev[1].tobytes() == np.array(want, dtype=S.EVENT_DTYPE).tobytes()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("bad,why", [
     (b'{"_type":"docs.command.Nope","newBalance":1}', "event type"),
     (b'{"_type":"docs.command.BankAccountUpdated"}', "field"),
