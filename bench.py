@@ -985,10 +985,16 @@ def run_e2e(args):
             dev_ms.append((t2 - t1) * 1e3)
             keys_at.append(n_keys)
 
-        for parts in framed:
+        fetch_iter = iter(framed)
+        while True:
+            # the oldest push is finished BEFORE the next fetch is asked for: asking tells the framer that the oldest fetch's
+            # slab may be framed into again, and a push reads its bytes until it is finished
             if len(pending) == depth:
                 finish_one()
                 pending.pop(0)
+            parts = next(fetch_iter, None)
+            if parts is None:
+                break
             tp = time.perf_counter()
             d.push_async(parts)
             push_ms.append((time.perf_counter() - tp) * 1e3)

@@ -205,7 +205,8 @@ class FramedFetches:
     makes the overlap safe: the sections of fetch i stay where they are while fetches i + 1 .. i + ``hold`` are framed,
     and the next one is not started before the consumer has asked for fetch i + ``hold`` (= is done with fetch i).
     ``hold`` (1 .. 3) is how many fetches the consumer keeps alive at a time: 1 for push-then-fold, 2 or 3 when it keeps
-    that many ``DeviceDecoder.push_async`` in flight.
+    that many ``DeviceDecoder.push_async`` in flight.  ASKING for the next fetch while ``hold`` are held releases the
+    oldest one: a consumer with pushes in flight finishes the oldest push first, then asks (``store.restore_from_fetches``).
 
     Iterating yields ``(sections, arena_address)`` per fetch, in order.  ``overlap=False`` frames inline (same results,
     one thread)."""

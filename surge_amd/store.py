@@ -159,11 +159,20 @@ class GpuReplayStateStore:
             framer = (PartitionedFramedFetches(fetches, n_partitions, threads=framing_threads, hold=depth, overlap=overlap) if n_partitions
                       else FramedFetches(fetches, overlap=overlap, hold=depth))
             with framer as framed:
-                for item in framed:
+                fetch_iter = iter(framed)
+                while True:
+                    # the oldest push is finished BEFORE the next fetch is asked for: asking tells the framer that the oldest
+                    # fetch's arena / slab may be framed into again, and a push reads its bytes until it is finished
+                    if pending == depth:
+                        finish_one()
+                        pending -= 1
+                    item = next(fetch_iter, None)
+                    if item is None:
+                        break
                     parts = item if isinstance(item, list) else [item]
                     parts = [(sec, arena) for sec, arena in parts if sec.shape[0]]
-                    if not parts:
-                        continue
+                    if not parts and d is None:
+                        continue  # (nothing pushed yet: nothing in flight that the framer could overtake)
                     if d is None:
                         kind = None
                         for sec, arena in parts:
@@ -175,9 +184,6 @@ class GpuReplayStateStore:
                         n_agg = capacity
                         self.engine.load_csr(np.zeros(n_agg + 1, dtype=np.int64), np.zeros(0, dtype=EVENT_DTYPE))
                         self.engine.fold()  # every aggregate None
-                    if pending == depth:
-                        finish_one()
-                        pending -= 1
                     d.push_async(parts)
                     pending += 1
                 while pending:
