@@ -13,11 +13,13 @@ send/recv of the 40-byte wire form on the library's side stream), overlapped wit
 resident in HBM before the timed region.  ``--workload c2`` runs BASELINE config C2 (1 M aggregates x 256 events) instead;
 ``--workload c2-weak`` is round 1's weak-scaled C2-per-GPU run.
 
-The default algorithm for the Zipf log is the TILE-MAJOR fold (SURGE_ALGO_TILED: the handle copies the bound log once into
-group-major 8 KiB subtiles and every fold streams that copy linearly).  A recovery folds a log once, so what "once" costs
-is part of the line: ``one_shot`` carries the index build, the re-layout copy and the first (cold) fold, ``csr_direct`` the
-fold straight from the CSR log (no copy: SORTED / CHUNKED) measured in the same run.  ``python bench.py --gpus N`` with
-N > 1 and no torchrun environment starts its own ranks (torch.distributed.run on 127.0.0.1).
+The default algorithm is what a one-shot recovery runs: AUTO — the fold straight from the CSR log, no copy of it (the
+10 M-aggregate Zipf log: SORTED; C2: ROWS); ``one_shot`` carries its index build and first (cold) fold.  At N = 1 the line
+also carries ``tile_major`` — the same log through the tile-major copy (SURGE_ALGO_TILED: group-major 8 KiB subtiles
+streamed linearly), with what that copy costs once — ``secondary`` (config C2, both transports), ``c5`` (config 5, bounded)
+and ``v2`` (the ABI v2 slot path).  ``python bench.py --gpus N`` with N > 1 and no torchrun environment starts its own
+ranks (torch.distributed.run on 127.0.0.1).  ``--workload e2e [--gpus N]``: events-topic BYTES -> states on the same
+10 M-aggregate population (run_e2e's docstring).
 
 Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant fold kernel against the 8 TB/s HBM peak using the
 algorithmic bytes 16*E + 8*(A+1) + 64*A and the kernel's HIP-event times measured inside the timed region on

@@ -1060,7 +1060,9 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       p.n_seg = n_seg;
       const int64_t groups = (n_seg + kWave - 1) / kWave;
       // resident waves per CU = min(LDS, registers): 8 KiB tiles 12 (136 VGPRs), 16 KiB tiles 8 (18.6 KB LDS), 32 KiB tiles 4
-      const int64_t slots = (int64_t)h->n_cus * (le == 8 ? 12 : (le == 16 ? 8 : 4));
+      int64_t per_cu = le == 8 ? 12 : (le == 16 ? 8 : 4);
+      if (const char* v = std::getenv("SURGE_REPLAY_SORTED_WAVES")) per_cu = std::atoi(v) > 0 && std::atoi(v) < per_cu ? std::atoi(v) : per_cu;  // (experiments: fewer)
+      const int64_t slots = (int64_t)h->n_cus * per_cu;
       const int64_t n_waves = groups < slots ? groups : slots;
       hipEvent_t e0, e1;
       const int32_t rc = next_fold_events(h, &e0, &e1);

@@ -288,6 +288,73 @@ def test_recovery_fetch_by_fetch_equals_recovery_from_the_whole_partition(overla
 
 
 # ---- round-2 regressions (aggregates that first appear after recovery) ------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [False, True])
+def test_recovery_of_a_consumer_with_several_partitions_equals_the_literal_fold(overlap):
+    """restore_from_fetches(n_partitions=P): what a restore consumer with several assigned partitions receives — per fetch
+    response the next bytes of every partition, framed per partition (transactions, an aborted flush, a flush that commits a
+    fetch later, a batch cut by the end of a fetch) into one slab, ONE device push per fetch with three in flight, the
+    resident state growing as aggregates appear — gives every aggregate the state the literal handle_event fold gives it."""
+    import random
+
+    import kafka_wire as kw
+    from surge_amd.kafka import partition_for_keys
+    from surge_amd.store import GpuReplayStateStore
+
+    bl = CounterBusinessLogic()
+    model, fmt = bl.command_model(), bl.event_write_formatting()
+    rng = random.Random(21)
+    P, F = 6, 7
+    ids = [f"agg-{i}" for i in range(400)]
+    part_of = dict(zip(ids, partition_for_keys(ids, P, up_to_colon=True)))
+    seq = {k: 0 for k in ids}
+    expect = {}
+    logs = [[] for _ in range(P)]   # per partition: the byte chunks of its log, fetch by fetch
+    offs = [0] * P
+    pid = 50
+    for f in range(F):
+        for p in range(P):
+            chunk = []
+            for _ in range(rng.randrange(0, 4)):
+                mine = [k for k in ids if part_of[k] == p]
+                events = []
+                for _ in range(rng.randrange(1, 60)):
+                    k = rng.choice(mine)
+                    seq[k] += 1
+                    events.append(rng.choice([CountIncremented(k, rng.randrange(50), seq[k]), CountDecremented(k, rng.randrange(50), seq[k]), NoOpEvent(k, seq[k])]))
+                outcome = kw.COMMIT if rng.random() < 0.8 else kw.ABORT
+                msgs = [fmt.write_event(e) for e in events]
+                chunk.append(kw.record_batch(offs[p], [(m.key.encode(), m.value) for m in msgs], compression=rng.choice(["lz4", "none"]), transactional=True,
+                                             producer_id=pid))
+                offs[p] += len(msgs)
+                chunk.append(kw.control_batch(offs[p], pid, outcome))
+                offs[p] += 1
+                pid += 1
+                if outcome == kw.COMMIT:
+                    for e in events:
+                        expect[e.aggregateId] = model.handle_event(expect.get(e.aggregateId), e)
+                else:
+                    for e in events:  # an aborted flush never happened: its sequence numbers are used again
+                        seq[e.aggregateId] -= 1
+            logs[p].append(b"".join(chunk))
+    # partition 2's third fetch ends in the middle of a batch; partition 4's commit marker of its last flush of fetch 1 arrives a fetch later
+    if len(logs[2][2]) > 40:
+        cut = len(logs[2][2]) - 33
+        logs[2][2], logs[2][3] = logs[2][2][:cut], logs[2][2][cut:] + logs[2][3]
+    if len(logs[4][1]) > 78:
+        logs[4][1], logs[4][2] = logs[4][1][:-78], logs[4][1][-78:] + logs[4][2]   # (a control batch is 78 bytes on this wire)
+    fetches = [[logs[p][f] or None for p in range(P)] for f in range(F)]
+    store = GpuReplayStateStore(bl)
+    try:
+        counters = store.restore_from_fetches(fetches, n_partitions=P, framing_threads=3, overlap=overlap)
+        assert counters["open_transactions"] == 0
+        assert set(store.keys.keys) == set(expect) and counters["records_aborted"] > 0
+        for k, st in expect.items():
+            assert store.get_aggregate_bytes(k) == bl.aggregate_write_formatting().write_state(st).value, k
+    finally:
+        store.close()
+
+
 def test_pack_batch_rejects_an_over_capacity_batch_without_interning_anything():
     from surge_amd.log import KeyTable, pack_batch
 
