@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--device-batches", action="store_true", help="c5: batches already in HBM (no staging / H2D)")
     ap.add_argument("--codec", default="lz4", choices=["lz4", "none"], help="e2e: compression of the record batches (the reference's producer: lz4)")
     ap.add_argument("--host-framing", action="store_true", help="c5: frame the state-topic record batches with the host writer instead of the device framer")
-    ap.add_argument("--serial-framing", action="store_true", help="e2e: frame each fetch, then push it, then fold it, one after the other (default: framing one fetch ahead on its own threads, three pushes in flight)")
+    ap.add_argument("--serial-framing", action="store_true", help="e2e: frame each fetch, then push it, then fold it, one after the other (default: framing one fetch ahead on its own threads, four pushes in flight)")
     ap.add_argument("--events-cap", type=int, default=8, help="e2e: every aggregate publishes the first min(count, cap) of its events (8: 6.4e7 records over the 10 M aggregates)")
     ap.add_argument("--no-capacity-hint", action="store_true", help="e2e: let the resident state and the key table grow as aggregates appear instead of sizing them up front")
     ap.add_argument("--framing-threads", type=int, default=8, help="e2e: host threads framing a fetch's partitions side by side")
@@ -856,7 +856,7 @@ def run_e2e(args):
 
     Path, per rank: a fetch response = the next ~--batch-events records of the rank's partitions -> host framing (headers,
     CRC-32C, read_committed) per partition on --framing-threads threads, one fetch ahead -> ONE device push per fetch
-    (surge_device_decoder_push_parts_async: copy, LZ4 blocks, records, JSON -> 16-byte events; up to three in flight) ->
+    (surge_device_decoder_push_parts_async: copy, LZ4 blocks, records, JSON -> 16-byte events; four in flight) ->
     key interning -> device group-by + fold onto the resident state (K3).  A step = one fetch; `value` = events/s from the
     completed fold of the last warm-up fetch to the completed fold of the last fetch, over all ranks, framing included.
     The states after the run are compared, aggregate by aggregate, with the oracle's fold of the SOURCE events (the
@@ -882,7 +882,7 @@ def run_e2e(args):
     P = N_PARTITIONS
     n_fetch = args.batch_events if args.batch_events != 100_000 else 1_000_000
     W = min(args.warmup, 2)
-    depth = 1 if args.serial_framing else 3
+    depth = 1 if args.serial_framing else int(os.environ.get("SURGE_BENCH_DEPTH", "4"))
     bl = CounterBusinessLogic()
     model, fmt = bl.command_model(), bl.event_write_formatting()
     tmpl = model.event_json_template()

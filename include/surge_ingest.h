@@ -143,21 +143,21 @@ typedef struct surge_batch_section {
 } surge_batch_section;
 /* Pops up to max deliverable batches (committed / non-transactional, before any open transaction), in offset order.
  * SURGE_E_STATE on a decoder that was not created in FRAMES mode.
- * Lifetime of the spans: a FRAMES decoder rotates through four arenas, one per feed, so the sections handed out here
- * (and the address surge_ingest_arena returned right after this drain) stay valid THROUGH the next three feeds — host
- * threads can frame fetches i + 1 .. i + 3 (feed, drain_sections, surge_ingest_arena) while a device decoder's pushes of
- * fetch i .. i + 2 are still in flight (surge_device_decoder_push_async).  The handle itself is for one thread at a
+ * Lifetime of the spans: a FRAMES decoder rotates through six arenas, one per feed, so the sections handed out here
+ * (and the address surge_ingest_arena returned right after this drain) stay valid THROUGH the next five feeds — host
+ * threads can frame fetches i + 1 .. i + 5 (feed, drain_sections, surge_ingest_arena) while a device decoder's pushes of
+ * fetch i .. i + 4 are still in flight (surge_device_decoder_push_async).  The handle itself is for one thread at a
  * time; what the other threads touch is only the arena memory.  Batches still queued at a feed (open transactions) move to
  * the new arena with it. */
 int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge_batch_section* out, int64_t* n_out);
 
 /* A consumer that is assigned several partitions gets, per fetch response, the next bytes of each of them; transactions,
  * last stable offsets and cut batches are per partition, so each partition needs a framer of its own.  A group owns n
- * FRAMES handles and, instead of an arena per handle, four rotating SLABS; a feed lays partition 0's records sections,
+ * FRAMES handles and, instead of an arena per handle, six rotating SLABS; a feed lays partition 0's records sections,
  * then partition 1's ... out in the next slab (every partition's slice is sized for the feed up front; batches a
  * partition still holds — open transactions — move along), so what comes back is one array of sections, partition after
  * partition, whose spans index one buffer: one part of surge_device_decoder_push_parts_async, one host-to-device copy.
- * A slab stays as it is through the next three feeds.  data[p] / len[p]: partition p's bytes of this fetch response (len
+ * A slab stays as it is through the next five feeds.  data[p] / len[p]: partition p's bytes of this fetch response (len
  * 0: nothing, the partition is only carried along); consumed_out (nullable, n entries); sections_out holds up to
  * max_sections entries (the total of len[] / 61 + n is always enough).  SURGE_INGEST_DEVICE_LZ4 / isolation level as in
  * surge_ingest_create (FRAMES is implied).  Returns the first failing partition's status (its message in
@@ -193,7 +193,7 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
 /* The two halves of a push, for a consumer that keeps the GPU busy across fetches.  push_async enqueues everything of a
  * push that does not touch the key table — the copy to the device, the LZ4 blocks, chaining / parsing the records and
  * decoding their values — on a stream of its own and returns; push_finish interns the keys of the OLDEST unfinished
- * push, appends its records to the result and returns what surge_device_decoder_push would have returned.  Up to three
+ * push, appends its records to the result and returns what surge_device_decoder_push would have returned.  Up to five
  * pushes may be unfinished at a time (SURGE_E_STATE beyond that, and from push / push_records while any is), so the
  * copy engine, the latency-bound LZ4 kernels and the compute-bound decode of consecutive fetches overlap on the chip:
  *     push_async(fetch 0); push_async(fetch 1);

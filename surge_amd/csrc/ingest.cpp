@@ -256,11 +256,11 @@ struct surge_ingest {
   bool frames = false;  // SURGE_INGEST_FRAMES: records are not parsed here, their sections go to a surge_device_decoder
   bool device_lz4 = false;  // SURGE_INGEST_DEVICE_LZ4: ... and LZ4 frames stay compressed (the device decoder undoes them)
   std::string err;
-  // FRAMES mode rotates through four arenas, one per feed: the sections a drain handed out stay where they are while
-  // the next THREE feeds fill the others, so host threads can frame fetches i + 1 .. i + 3 while a device decoder still
-  // reads fetch i (surge_device_decoder_push_async keeps up to three pushes in flight).  The other modes only ever use
+  // FRAMES mode rotates through six arenas, one per feed: the sections a drain handed out stay where they are while
+  // the next FIVE feeds fill the others, so host threads can frame fetches i + 1 .. i + 5 while a device decoder still
+  // reads fetch i (surge_device_decoder_push_async keeps up to five pushes in flight).  The other modes only ever use
   // the first.
-  static constexpr int kArenas = 4;
+  static constexpr int kArenas = 6;
   Arena arenas[kArenas];
   int cur = 0;
   bool handed_out = false;  // a drain has handed out spans of arenas[cur] since the last switch
@@ -552,7 +552,7 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
   if (consumed_out) *consumed_out = 0;
   if (g->frames && (g->handed_out || g->grouped)) {
     // switch arenas: the sections still queued (open transactions, undrained batches) move along, the ones the last
-    // drain handed out stay untouched in the arena this feed leaves behind (valid through the three feeds after it).  A feed
+    // drain handed out stay untouched in the arena this feed leaves behind (valid through the five feeds after it).  A feed
     // that follows no drain keeps appending where the last one stopped: nothing is copied.
     try {
       Arena& next = g->grouped ? g->ext[(g->cur + 1) % surge_ingest::kArenas] : g->arenas[(g->cur + 1) % surge_ingest::kArenas];
@@ -836,7 +836,7 @@ int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge
 }  // extern "C" (the group's type)
 
 // A consumer's partitions framed as ONE unit: every feed lays the partitions' records sections out in one slab — the
-// group rotates through four, like a single framer's arenas — so a fetch response reaches the device in one copy.
+// group rotates through six, like a single framer's arenas — so a fetch response reaches the device in one copy.
 struct surge_ingest_group {
   std::vector<surge_ingest*> g;
   Arena slabs[surge_ingest::kArenas];

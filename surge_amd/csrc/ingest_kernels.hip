@@ -1192,7 +1192,7 @@ struct PushSlot {
   uint64_t seed = 0;   // the hash function stage 1 hashed the keys with
   bool busy = false, wire = false;
 };
-constexpr int kSlots = 3;
+constexpr int kSlots = 5;
 
 }  // namespace
 

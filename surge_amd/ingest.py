@@ -201,10 +201,10 @@ class FramedFetches:
     (``feed`` = batch headers, CRC-32C, ``read_committed`` — and the fetch itself, when ``fetches`` is a generator that
     polls) while the caller's thread keeps the device busy with the previous fetch (``DeviceDecoder.push`` + the
     fold).  One ``EventsTopicIngest`` in FRAMES mode does all the framing, so transactions and partial batches carry
-    from fetch to fetch; its four rotating arenas (``surge_ingest_drain_sections`` in ``surge_ingest.h``) are what
+    from fetch to fetch; its six rotating arenas (``surge_ingest_drain_sections`` in ``surge_ingest.h``) are what
     makes the overlap safe: the sections of fetch i stay where they are while fetches i + 1 .. i + ``hold`` are framed,
     and the next one is not started before the consumer has asked for fetch i + ``hold`` (= is done with fetch i).
-    ``hold`` (1 .. 3) is how many fetches the consumer keeps alive at a time: 1 for push-then-fold, 2 or 3 when it keeps
+    ``hold`` (1 .. 5) is how many fetches the consumer keeps alive at a time: 1 for push-then-fold, 2 .. 5 when it keeps
     that many ``DeviceDecoder.push_async`` in flight.  ASKING for the next fetch while ``hold`` are held releases the
     oldest one: a consumer with pushes in flight finishes the oldest push first, then asks (``store.restore_from_fetches``).
 
@@ -215,8 +215,8 @@ class FramedFetches:
         import queue
         import threading
 
-        if not 1 <= hold <= 3:
-            raise ValueError("hold must be 1, 2 or 3 (the framer has four arenas)")
+        if not 1 <= hold <= 5:
+            raise ValueError("hold must be 1 .. 5 (the framer has six arenas)")
         self._g = EventsTopicIngest(isolation_level, frames=True, device_lz4=device_lz4, threads=threads)
         self._fetches = iter(fetches)
         self._overlap = overlap
@@ -298,15 +298,15 @@ class PartitionedFramedFetches:
     ``threads`` host threads (C++ threads inside the library call), all of a fetch's records sections laid out in ONE
     page-locked slab.  Iterating yields ``(sections, slab_address)`` per fetch — partition after partition, offset order
     inside a partition: one ``DeviceDecoder.push_async``, one host-to-device copy.  ``hold`` as in :class:`FramedFetches`
-    (the group rotates through four slabs)."""
+    (the group rotates through six slabs)."""
 
     def __init__(self, fetches, n_partitions: int, threads: int = 8, hold: int = 3, isolation_level: int = READ_COMMITTED, device_lz4: bool = True,
                  overlap: bool = True):
         import queue
         import threading
 
-        if not 1 <= hold <= 3:
-            raise ValueError("hold must be 1, 2 or 3 (the group has four slabs)")
+        if not 1 <= hold <= 5:
+            raise ValueError("hold must be 1 .. 5 (the group has six slabs)")
         self._lib = _native.load()
         self._h = ctypes.c_void_p()
         rc = self._lib.surge_ingest_group_create(n_partitions, isolation_level | (DEVICE_LZ4 if device_lz4 else 0), ctypes.byref(self._h))
@@ -423,7 +423,7 @@ class DeviceDecoder:
     def push_async(self, parts) -> None:
         """Stage 1 of a push — copy, LZ4, record parsing, value decode — enqueued on a stream of its own; ``parts`` is one
         ``(sections, arena_address)`` pair or a list of them (e.g. one per partition of a fetch response: one push, records
-        delivered part after part).  The arenas must stay as they are until the matching ``finish()``; up to three pushes
+        delivered part after part).  The arenas must stay as they are until the matching ``finish()``; up to five pushes
         may be in flight."""
         if isinstance(parts, tuple):
             parts = [parts]

@@ -573,46 +573,46 @@ def _section_bytes(sections, arena):
     return [ctypes.string_at(arena + int(s["byte_off"]), int(s["byte_len"])) for s in sections]
 
 
-def test_frames_mode_rotates_four_arenas_so_the_next_three_feeds_leave_the_drained_sections_alone():
-    """What lets host threads frame fetches i + 1 .. i + 3 while the device decoder's pushes of fetch i .. i + 2 are still in
+def test_frames_mode_rotates_six_arenas_so_the_next_five_feeds_leave_the_drained_sections_alone():
+    """What lets host threads frame the next fetches while the device decoder's pushes of the earlier ones are still in
     flight (surge_ingest.h, surge_ingest_drain_sections): a drained section stays byte-identical, at the same address,
-    through the next THREE feeds — and batches that are still queued at a feed (an open transaction) travel to the new arena."""
+    through the next FIVE feeds — and batches that are still queued at a feed (an open transaction) travel to the new arena."""
     ev = lambda seq: counter_event(S.EVT_INC, seq, seq)
     batch = lambda off, key, n, **kw_: kw.record_batch(off, [(key, ev(off + i + 1)) for i in range(n)], **kw_)
-    a, b, c, d4, e5 = batch(0, b"a:1", 300), batch(300, b"b:1", 200), batch(500, b"c:1", 5000), batch(5500, b"d:1", 7), batch(5507, b"e:1", 900)
+    sizes = [300, 200, 5000, 7, 900, 40, 1200]
+    batches, off = [], 0
+    for i, n in enumerate(sizes):
+        batches.append(batch(off, b"k%d:1" % i, n))
+        off += n
     with EventsTopicIngest(frames=True) as g:
-        g.feed(a)
-        sa, arena_a = g.drain_sections()
-        assert _section_bytes(sa, arena_a) == [a[61:]]
-        g.feed(b)  # fills the next arena
-        sb, arena_b = g.drain_sections()
-        assert arena_b != arena_a and _section_bytes(sa, arena_a) == [a[61:]] and _section_bytes(sb, arena_b) == [b[61:]]
-        g.feed(c)
-        sc, arena_c = g.drain_sections()
-        g.feed(d4)
-        sd, arena_d = g.drain_sections()
-        assert len({arena_a, arena_b, arena_c, arena_d}) == 4
-        assert [_section_bytes(x, y) for x, y in ((sa, arena_a), (sb, arena_b), (sc, arena_c), (sd, arena_d))] == [[a[61:]], [b[61:]], [c[61:]], [d4[61:]]]
-        g.feed(e5)  # the fifth feed is back in the first arena: a's spans are gone, the other three survive
-        se, arena_e = g.drain_sections()
-        assert [_section_bytes(x, y) for x, y in ((sb, arena_b), (sc, arena_c), (sd, arena_d), (se, arena_e))] == [[b[61:]], [c[61:]], [d4[61:]], [e5[61:]]]
+        drained = []
+        for i, b in enumerate(batches[:6]):
+            g.feed(b)
+            drained.append(g.drain_sections())
+            # everything drained so far is where it was, byte for byte
+            assert [_section_bytes(sc, ar) for sc, ar in drained] == [[x[61:]] for x in batches[: i + 1]]
+        assert len({ar for _, ar in drained}) == 6
+        g.feed(batches[6])  # the seventh feed is back in the first arena: the first fetch's spans are gone, the other five survive
+        drained.append(g.drain_sections())
+        assert [_section_bytes(sc, ar) for sc, ar in drained[1:]] == [[x[61:]] for x in batches[1:]]
+        off0 = off
         # an open transaction is carried from arena to arena until its marker arrives
-        t = batch(6500, b"t:1", 40, transactional=True, producer_id=3)
+        t = batch(off0, b"t:1", 40, transactional=True, producer_id=3)
         g.feed(t)
         assert g.drain_sections()[0].shape[0] == 0
-        g.feed(batch(6540, b"d:1", 10))  # behind the open transaction: not deliverable either
+        g.feed(batch(off0 + 40, b"d:1", 10))  # behind the open transaction: not deliverable either
         assert g.drain_sections()[0].shape[0] == 0 and g.counters()["open_transactions"] == 1
-        g.feed(kw.control_batch(6550, 3, kw.COMMIT))
+        g.feed(kw.control_batch(off0 + 50, 3, kw.COMMIT))
         st, arena_t = g.drain_sections()
-        assert [int(s["base_offset"]) for s in st] == [6500, 6540]
-        assert _section_bytes(st, arena_t) == [t[61:], batch(6540, b"d:1", 10)[61:]]
+        assert [int(s["base_offset"]) for s in st] == [off0, off0 + 40]
+        assert _section_bytes(st, arena_t) == [t[61:], batch(off0 + 40, b"d:1", 10)[61:]]
 
 
 def test_partitioned_framed_fetches_frame_every_partition_like_its_own_framer_and_keep_three_fetches_alive():
     """surge_ingest_group behind PartitionedFramedFetches: a consumer's fetch responses over several partitions, framed on
     C++ threads (one framer per partition) into one slab per fetch, yield per fetch the sections each partition's own
     framer yields, partition after partition — transactions per partition, a cut batch completed by the next fetch,
-    partitions with nothing in a fetch — and with hold = 3 the sections of three consecutive fetches are intact at the
+    partitions with nothing in a fetch — and with hold = 5 the sections of five consecutive fetches are intact at the
     same time."""
     from surge_amd.ingest import PartitionedFramedFetches
 
@@ -661,10 +661,10 @@ def test_partitioned_framed_fetches_frame_every_partition_like_its_own_framer_an
     flat_want = [[x for row in rows for x in row] for rows in want]  # partition after partition
     for overlap in (False, True):
         alive, got = [], []
-        with PartitionedFramedFetches(iter(fetches), P, threads=3, hold=3, overlap=overlap) as framed:
+        with PartitionedFramedFetches(iter(fetches), P, threads=3, hold=5, overlap=overlap) as framed:
             for sec, slab in framed:
                 alive.append((sec, slab))
-                if len(alive) > 3:
+                if len(alive) > 5:
                     alive.pop(0)
                 # everything still alive reads back unchanged while the framer is (up to) a fetch ahead
                 snap = [[(int(s["base_offset"]), int(s["n_records"]), int(s["codec"]), b) for s, b in zip(sc, _section_bytes(sc, sl))] for sc, sl in alive]

@@ -293,7 +293,7 @@ def test_recovery_fetch_by_fetch_equals_recovery_from_the_whole_partition(overla
 def test_recovery_of_a_consumer_with_several_partitions_equals_the_literal_fold(overlap):
     """restore_from_fetches(n_partitions=P): what a restore consumer with several assigned partitions receives — per fetch
     response the next bytes of every partition, framed per partition (transactions, an aborted flush, a flush that commits a
-    fetch later, a batch cut by the end of a fetch) into one slab, ONE device push per fetch with three in flight, the
+    fetch later, a batch cut by the end of a fetch) into one slab, ONE device push per fetch with four in flight, the
     resident state growing as aggregates appear — gives every aggregate the state the literal handle_event fold gives it."""
     import random
 
