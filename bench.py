@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--device-batches", action="store_true", help="c5: batches already in HBM (no staging / H2D)")
     ap.add_argument("--codec", default="lz4", choices=["lz4", "none"], help="e2e: compression of the record batches (the reference's producer: lz4)")
     ap.add_argument("--host-framing", action="store_true", help="c5: frame the state-topic record batches with the host writer instead of the device framer")
+    ap.add_argument("--two-thread-consumer", action="store_true", help="e2e: a worker thread enqueues the pushes, this one finishes them with an event-ordered hand-over to the fold and no host wait (default: one thread does both and waits for the device after each half — the device is the bound, the extra thread measured 7 %% slower)")
     ap.add_argument("--serial-framing", action="store_true", help="e2e: frame each fetch, then push it, then fold it, one after the other (default: framing one fetch ahead on its own threads, four pushes in flight)")
     ap.add_argument("--events-cap", type=int, default=8, help="e2e: every aggregate publishes the first min(count, cap) of its events (8: 6.4e7 records over the 10 M aggregates)")
     ap.add_argument("--no-capacity-hint", action="store_true", help="e2e: let the resident state and the key table grow as aggregates appear instead of sizing them up front")
@@ -872,7 +873,7 @@ def run_e2e(args):
     from surge_amd import schema as S
     from surge_amd import synth
     from surge_amd.dist import partitions_of_ids, shard_of_partition
-    from surge_amd.ingest import DeviceDecoder, EventsTopicIngest, PartitionedFramedFetches
+    from surge_amd.ingest import DeviceDecoder, EventsTopicIngest, PartitionedFramedFetches, PushPipeline
     from surge_amd.replay import ReplayEngine
     from surge_amd.snapshot import RecordBatchWriter
 
@@ -883,6 +884,7 @@ def run_e2e(args):
     n_fetch = args.batch_events if args.batch_events != 100_000 else 1_000_000
     W = min(args.warmup, 2)
     depth = 1 if args.serial_framing else int(os.environ.get("SURGE_BENCH_DEPTH", "4"))
+    one_thread = args.serial_framing or not args.two_thread_consumer
     bl = CounterBusinessLogic()
     model, fmt = bl.command_model(), bl.event_write_formatting()
     tmpl = model.event_json_template()
@@ -965,21 +967,18 @@ def run_e2e(args):
         if hint:
             d.reserve(hint, 13 * hint)
         n_agg = hint
-        pending = []
 
-        def finish_one():
+        def finish_one(wait):
             nonlocal n_agg
             t1 = time.perf_counter()
-            d.finish()
+            d.finish(wait=wait)
             ta = time.perf_counter()
-            agg, ev, _, n_keys = d.result()
+            n_keys = d.n_keys
             if n_keys > n_agg:
                 eng.grow(max(n_keys, min(2 * n_agg, my_ids.shape[0])))  # (grow in big steps: a grow copies the resident state)
                 n_agg = eng.n_agg
             tb = time.perf_counter()
-            eng.append_events(agg, ev)
-            eng.synchronize()
-            d.clear()
+            d.fold_into(eng, wait=wait)
             t2 = time.perf_counter()
             if os.environ.get("SURGE_BENCH_TRACE"):
                 print(f"[bench] fetch {len(marks)}: finish {(ta - t1) * 1e3:.2f} grow {(tb - ta) * 1e3:.2f} fold {(t2 - tb) * 1e3:.2f} ms, keys {n_keys}", file=sys.stderr)
@@ -987,23 +986,43 @@ def run_e2e(args):
             dev_ms.append((t2 - t1) * 1e3)
             keys_at.append(n_keys)
 
-        fetch_iter = iter(framed)
-        while True:
-            # the oldest push is finished BEFORE the next fetch is asked for: asking tells the framer that the oldest fetch's
-            # slab may be framed into again, and a push reads its bytes until it is finished
-            if len(pending) == depth:
-                finish_one()
-                pending.pop(0)
-            parts = next(fetch_iter, None)
-            if parts is None:
-                break
-            tp = time.perf_counter()
-            d.push_async(parts)
-            push_ms.append((time.perf_counter() - tp) * 1e3)
-            pending.append(1)
-        while pending:
-            finish_one()
-            pending.pop(0)
+        if one_thread:
+            # one host thread enqueues stage 1 of fetch i + depth, then finishes fetch i and folds it, waiting for the device
+            # after each half (the device is the bound: profiles/r04_e2e_consumer_threads.txt)
+            pending = 0
+            fetch_iter = iter(framed)
+            while True:
+                # the oldest push is finished BEFORE the next fetch is asked for: asking tells the framer that the oldest fetch's
+                # slab may be framed into again, and a push reads its bytes until it is finished
+                if pending == depth:
+                    finish_one(True)
+                    pending -= 1
+                parts = next(fetch_iter, None)
+                if parts is None:
+                    break
+                tp = time.perf_counter()
+                d.push_async(parts)
+                push_ms.append((time.perf_counter() - tp) * 1e3)
+                pending += 1
+            while pending:
+                finish_one(True)
+                pending -= 1
+        else:
+            # three host threads: the framer's driver, the pipeline's worker (stage 1 of up to `depth` fetches ahead: section
+            # tables, staging, launches) and this one (stage 2 + fold of the oldest push, no host wait behind either: the
+            # decoder's stream and the engine's — a stream of its own here — are ordered by events)
+            def push(parts):
+                d.push_async(parts)
+                return True
+
+            with eng.on_own_stream(), PushPipeline(framed, push, depth) as pipe:
+                for _ in pipe:
+                    finish_one(False)
+                    pipe.done()
+                eng.synchronize()
+            push_ms = [x * 1e3 for x in pipe.push_seconds]
+        torch.cuda.synchronize(dev)
+        marks[-1] = time.perf_counter()  # (the last fetch counts as done when the device is)
         torch.cuda.synchronize(dev)
         t_begin = marks[W - 1] if W > 0 else t_start
         elapsed_local = marks[-1] - t_begin
@@ -1119,6 +1138,7 @@ def run_e2e(args):
                                f"JSON decode / key interning / group-by / fold on the GPU" + (" [REHEARSAL: every rank on cuda:0, throughput meaningless]" if rehearsal else ""),
                    "parallelism": f"partitions p % {world} == rank; no data-path collective; final snapshot all-gathered through the C ABI" if world > 1 else "one GPU",
                    "aggregates": A, "events_cap": cap, "partitions": P, "fetch_records": n_fetch, "fetches": len(fetches), "pushes_in_flight": depth,
+                   "consumer": "one thread, a host wait behind interning and behind the fold" if one_thread else "push worker thread + finisher, event-ordered hand-over to the fold (no host wait behind either)",
                    "framing_threads": args.framing_threads, "capacity_hint": not args.no_capacity_hint, "events_timed": total_events, "per_rank_events": per_rank, "keys_interned": total_keys,
                    "wire_bytes_per_record": total_wire / max(1, int(totals[4].item())),
                    "fetch_ms": {"p50": float(np.percentile(lat, 50)), "p90": float(np.percentile(lat, 90)), "max": float(np.max(lat))},

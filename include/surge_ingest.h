@@ -179,7 +179,10 @@ int32_t surge_ingest_set_allocator(surge_ingest* g, void* (*alloc)(size_t), void
 int32_t surge_ingest_use_pinned_arena(surge_ingest* g);
 
 typedef struct surge_device_decoder surge_device_decoder;
-/* (One decoder serves one consumer thread at a time: calls on the same decoder must not overlap.) */
+/* (Calls on the same decoder must not overlap, with one exception made for throughput: ONE thread may enqueue pushes
+ * (push_async / push_parts_async) while ONE other thread finishes them and consumes the results (push_finish*, result,
+ * clear, surge_replay_append_decoded*): the host work of framing tables and launches of fetch i + depth then runs beside
+ * the interning and the fold of fetch i.) */
 /* tmpl == NULL: record values are 16-byte surge_event16; otherwise the reference's JSON event text, decoded by the
  * template with surge_event_json_decode's rules (Doubles correctly rounded on the device — f64_parse.h — the rare value
  * its fast path cannot decide is re-parsed on the host).  hip_stream: the stream the decoder works on (NULL = default). */
@@ -205,6 +208,10 @@ int32_t surge_device_decoder_push_async(surge_device_decoder* d, const uint8_t* 
 int32_t surge_device_decoder_push_parts_async(surge_device_decoder* d, int32_t n_parts, const uint8_t* const* bytes,
                                               const surge_batch_section* const* sections, const int64_t* n_sections);
 int32_t surge_device_decoder_push_finish(surge_device_decoder* d);
+/* push_finish without its closing wait for the device: the results are complete in the order of the decoder's stream
+ * (hand them over with surge_replay_append_decoded_async, or synchronise that stream before reading them).  The one
+ * wait that remains is the one in the middle of the call — errors, new keys, the record count: what the host decides on. */
+int32_t surge_device_decoder_push_finish_async(surge_device_decoder* d);
 int32_t surge_device_decoder_pending(const surge_device_decoder* d); /* pushes enqueued and not finished */
 /* Optional capacity hint — e.g. the aggregate count of the store's last snapshot: room for n_keys aggregate ids of
  * key_bytes bytes in all (hash table, key arena, offsets), so a recovery does not grow them step by step (every step
@@ -226,6 +233,12 @@ int32_t surge_device_decoder_clear(surge_device_decoder* d); /* drops the record
  * do: load a CSR of zero aggregates and fold).  *n_events_out / *n_keys_out (nullable): what was folded / the key count. */
 struct surge_replay_handle;
 int32_t surge_replay_append_decoded(struct surge_replay_handle* h, surge_device_decoder* d, int64_t* n_events_out, int64_t* n_keys_out);
+/* The same without a host wait: the handle's stream waits (event) for the decoder's, group-by + fold are enqueued, the
+ * decoder is cleared; the next push_finish* waits (event, on the device) for the group-by's last read of the result
+ * arrays before it writes them again.  With the handle on a stream of its own (surge_replay_set_stream, non-blocking),
+ * interning of fetch i + 1 overlaps the fold of fetch i.  Errors of the fold surface at the next
+ * surge_replay_synchronize. */
+int32_t surge_replay_append_decoded_async(struct surge_replay_handle* h, surge_device_decoder* d, int64_t* n_events_out, int64_t* n_keys_out);
 /* The key table (aggregate ids in first-delivered order): to the host (NULL / NULL = size query), or where it lives on
  * the device (n_keys + 1 offsets; what the GPU state encoders and K4 take). */
 int32_t surge_device_decoder_keys(surge_device_decoder* d, uint8_t* utf8_out, int64_t utf8_capacity, int64_t* key_off_out, int64_t* n_keys_out,

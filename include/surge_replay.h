@@ -302,6 +302,9 @@ const char* surge_replay_last_error(const surge_replay_handle* h);
 
 /* Launch all work of this handle on the given hipStream_t (NULL = default stream). */
 int32_t surge_replay_set_stream(surge_replay_handle* h, void* hip_stream);
+/* The hipStream_t the handle's work is enqueued on (what set_stream was given; NULL = default stream): for a host that
+ * orders its own device work against the handle's with events instead of surge_replay_synchronize. */
+int32_t surge_replay_get_stream(surge_replay_handle* h, void** hip_stream_out);
 /* Waits for the handle's stream; also where a skipped device micro-batch (see surge_replay_append_events_device) is
  * reported. */
 int32_t surge_replay_synchronize(surge_replay_handle* h);

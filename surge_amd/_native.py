@@ -36,6 +36,7 @@ EXPORTS = (
     "surge_replay_destroy",
     "surge_replay_last_error",
     "surge_replay_set_stream",
+    "surge_replay_get_stream",
     "surge_replay_synchronize",
     "surge_replay_load_csr",
     "surge_replay_bind_device_csr",
@@ -113,11 +114,13 @@ INGEST_EXPORTS = (
     "surge_device_decoder_push_async",
     "surge_device_decoder_push_parts_async",
     "surge_device_decoder_push_finish",
+    "surge_device_decoder_push_finish_async",
     "surge_device_decoder_pending",
     "surge_device_decoder_reserve",
     "surge_device_decoder_result",
     "surge_device_decoder_clear",
     "surge_replay_append_decoded",
+    "surge_replay_append_decoded_async",
     "surge_device_decoder_keys",
     "surge_device_decoder_key_table",
     "surge_device_decoder_counters",
@@ -256,6 +259,7 @@ def load() -> ctypes.CDLL:
         "surge_replay_destroy": ([vp], i32),
         "surge_replay_last_error": ([vp], ctypes.c_char_p),
         "surge_replay_set_stream": ([vp, vp], i32),
+        "surge_replay_get_stream": ([vp, ctypes.POINTER(vp)], i32),
         "surge_replay_synchronize": ([vp], i32),
         "surge_replay_load_csr": ([vp, vp, i64, vp, i64, vp], i32),
         "surge_replay_bind_device_csr": ([vp, vp, i64, vp, i64, vp, vp], i32),
@@ -332,11 +336,13 @@ def load() -> ctypes.CDLL:
         "surge_device_decoder_push_async": ([vp, vp, vp, i64], i32),
         "surge_device_decoder_push_parts_async": ([vp, i32, vp, vp, vp], i32),
         "surge_device_decoder_push_finish": ([vp], i32),
+        "surge_device_decoder_push_finish_async": ([vp], i32),
         "surge_device_decoder_pending": ([vp], i32),
         "surge_device_decoder_reserve": ([vp, i64, i64], i32),
         "surge_device_decoder_result": ([vp, ctypes.POINTER(i64), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64)], i32),
         "surge_device_decoder_clear": ([vp], i32),
         "surge_replay_append_decoded": ([vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
+        "surge_replay_append_decoded_async": ([vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
         "surge_device_decoder_keys": ([vp, vp, i64, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
         "surge_device_decoder_key_table": ([vp, ctypes.POINTER(vp), ctypes.POINTER(vp)], i32),
         "surge_device_decoder_counters": ([vp, ctypes.POINTER(i64 * 4)], i32),

@@ -595,6 +595,12 @@ int32_t surge_replay_set_stream(surge_replay_handle* h, void* hip_stream) {
   return SURGE_OK;
 }
 
+int32_t surge_replay_get_stream(surge_replay_handle* h, void** hip_stream_out) {
+  if (!h || !hip_stream_out) return fail(h, SURGE_E_INVALID, "NULL argument");
+  *hip_stream_out = (void*)h->stream;
+  return SURGE_OK;
+}
+
 // A micro-batch whose aggregate indices were out of range is skipped on the device (stream_kernels.hip) and reported
 // here, at the host's next synchronisation point, once.
 static int32_t report_skipped_batches(surge_replay_handle* h) {

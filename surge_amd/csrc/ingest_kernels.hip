@@ -22,6 +22,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -1187,7 +1188,9 @@ struct PushSlot {
   std::vector<Lz4Block> h_blocks;
   ErrorCell h_err;
   hipStream_t stream = nullptr;
-  hipEvent_t done = nullptr;
+  hipEvent_t done = nullptr;      // recorded on `stream` behind stage 1
+  hipEvent_t released = nullptr;  // recorded on the decoder's stream behind stage 2: the slot's buffers may be written again
+  bool released_valid = false;
   int64_t n_rec = 0;
   uint64_t seed = 0;   // the hash function stage 1 hashed the keys with
   bool busy = false, wire = false;
@@ -1200,21 +1203,30 @@ struct surge_device_decoder {
   int device = 0;
   hipStream_t stream = nullptr;
   bool json = false;
-  bool poisoned = false;  // a device error left the tables in an unknown state: every later push is refused
+  // Two host threads may drive one decoder: one enqueues stage 1 (push_async / push_parts_async), the other finishes pushes
+  // (push_finish*, result, clear, append_decoded*).  `mu` covers what both touch: the slot queue and the error text.
+  std::mutex mu;
+  std::atomic<bool> poisoned{false};  // a device error left the tables in an unknown state: every later push is refused
   std::string err;
   Buf d_tmpl, d_ptab;
   surge_event_json_template h_tmpl;  // (host copy: Doubles the device cannot decide are re-parsed with it)
   PushSlot slots[kSlots];
-  int head = 0, n_pending = 0;  // slots [head, head + n_pending) hold pushes whose stage 1 is enqueued
+  int head = 0;
+  std::atomic<int> n_pending{0};  // slots [head, head + n_pending) hold pushes whose stage 1 is enqueued (changes under `mu`)
   // stage 2 scratch
   Buf first, first_scan, keep, keep_pos, temp;
   // hash table + key table
   Buf t_hash, t_key_id, t_first, arena, key_off, key_hash;
-  uint64_t t_cap = 0, seed = 0;
+  uint64_t t_cap = 0;
+  std::atomic<uint64_t> seed{0};  // (stage 1 reads it once per push; stage 2 of an earlier push may move it on: PushSlot::seed)
   int64_t n_keys = 0, arena_bytes = 0;
   // result
   Buf r_agg, r_ev, r_off;
   int64_t n_records = 0;
+  // hand-over of the result arrays to a consumer on another stream (surge_replay_append_decoded_async): `consumed` is
+  // recorded on the consumer's stream behind its last read, the next stage 2 waits for it before it writes the arrays
+  hipEvent_t ready = nullptr, consumed = nullptr;
+  bool consumed_valid = false;
   int64_t counters[4] = {0, 0, 0, 0};  // records seen, delivered, flush records skipped, f64 values re-parsed on the host
   int64_t reseeds = 0, pushes = 0;
 };
@@ -1222,7 +1234,10 @@ struct surge_device_decoder {
 namespace {
 
 int32_t dfail(surge_device_decoder* d, int32_t code, const std::string& m) {
-  if (d) d->err = m;
+  if (d) {
+    std::lock_guard<std::mutex> lk(d->mu);
+    d->err = m;
+  }
   g_dec_err = m;
   return code;
 }
@@ -1288,7 +1303,13 @@ int32_t surge_ingest_group_use_pinned_slabs(surge_ingest_group* g) {
   return surge_ingest_group_set_allocator(g, pinned_alloc, pinned_release);
 }
 
-const char* surge_device_decoder_last_error(const surge_device_decoder* d) { return d ? d->err.c_str() : g_dec_err.c_str(); }
+const char* surge_device_decoder_last_error(const surge_device_decoder* d) {
+  if (d) {  // (a copy: the other thread of a two-thread host may be setting its own error text)
+    std::lock_guard<std::mutex> lk(const_cast<surge_device_decoder*>(d)->mu);
+    g_dec_err = d->err;
+  }
+  return g_dec_err.c_str();
+}
 
 int32_t surge_device_decoder_create(int32_t device_id, void* hip_stream, const surge_event_json_template* tmpl, surge_device_decoder** out) {
   if (!out) return dfail(nullptr, E_INVALID, "out is NULL");
@@ -1312,8 +1333,11 @@ int32_t surge_device_decoder_create(int32_t device_id, void* hip_stream, const s
     for (PushSlot& s : d->slots) {
       DCHK(d, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
       DCHK(d, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+      DCHK(d, hipEventCreateWithFlags(&s.released, hipEventDisableTiming));
       DCHK(d, s.d_err.reserve(sizeof(ErrorCell), false, d->stream));
     }
+    DCHK(d, hipEventCreateWithFlags(&d->ready, hipEventDisableTiming));
+    DCHK(d, hipEventCreateWithFlags(&d->consumed, hipEventDisableTiming));
     DCHK(d, d->key_off.reserve(8, false, d->stream));
     DCHK(d, hipMemset(d->key_off.p, 0, 8));
     if (tmpl) {
@@ -1372,6 +1396,7 @@ int32_t surge_device_decoder_destroy(surge_device_decoder* d) {
   for (PushSlot& s : d->slots) {
     if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); }
     if (s.done) (void)hipEventDestroy(s.done);
+    if (s.released) (void)hipEventDestroy(s.released);
     Buf* sb[] = {&s.lz4_blocks, &s.lz4_sizes, &s.lz4_nseq, &s.lz4_seq, &s.lz4_cls, &s.d_bytes, &s.d_sections, &s.rec_a, &s.rec_b, &s.rec_c, &s.meta, &s.ev_tmp,
                  &s.f64_list, &s.d_err};
     for (Buf* b : sb) b->release();
@@ -1380,6 +1405,8 @@ int32_t surge_device_decoder_destroy(surge_device_decoder* d) {
   Buf* bufs[] = {&d->d_tmpl, &d->d_ptab, &d->first, &d->first_scan, &d->keep, &d->keep_pos, &d->temp, &d->t_hash, &d->t_key_id,
                  &d->t_first, &d->arena, &d->key_off, &d->key_hash, &d->r_agg, &d->r_ev, &d->r_off};
   for (Buf* b : bufs) b->release();
+  if (d->ready) (void)hipEventDestroy(d->ready);
+  if (d->consumed) (void)hipEventDestroy(d->consumed);
   (void)hipSetDevice(prev);
   delete d;
   return OK;
@@ -1409,11 +1436,22 @@ PushSlot* claim_slot(surge_device_decoder* d, int32_t* rc) {
     *rc = dfail(d, SURGE_E_STATE, "an earlier push failed on the device half way: destroy this decoder and create a new one");
     return nullptr;
   }
-  if (d->n_pending == kSlots) {
-    *rc = dfail(d, SURGE_E_STATE, "every push slot holds an unfinished push: call surge_device_decoder_push_finish first");
-    return nullptr;
+  PushSlot* s = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(d->mu);
+    if (d->n_pending < kSlots) s = &d->slots[(d->head + d->n_pending) % kSlots];  // (a finish on the other thread moves head and n_pending together: the same slot)
   }
-  return &d->slots[(d->head + d->n_pending) % kSlots];
+  if (!s) *rc = dfail(d, SURGE_E_STATE, "every push slot holds an unfinished push: call surge_device_decoder_push_finish first");
+  return s;
+}
+
+// the slot's last push was finished without waiting for the device (push_finish_async): its buffers are free once the
+// decoder's stream has passed the end of that stage 2
+int32_t await_release(surge_device_decoder* d, PushSlot& s) {
+  if (!s.released_valid) return OK;
+  DCHK(d, hipStreamWaitEvent(s.stream, s.released, 0));
+  s.released_valid = false;
+  return OK;
 }
 
 int32_t slot_scratch(surge_device_decoder* d, PushSlot& s, int64_t n_rec) {
@@ -1449,6 +1487,7 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
     std::fprintf(stderr, "[surge dbg] stage1 %-14s %8.1f us\n", what, t - t_mark);
     t_mark = t;
   };
+  const uint64_t seed = d->seed.load();
   int64_t total_sections = 0;
   for (int32_t p = 0; p < n_parts; ++p) {
     if (n_sections[p] < 0 || (n_sections[p] > 0 && (!bytes[p] || !sections[p]))) return dfail(d, E_INVALID, "bad argument");
@@ -1682,13 +1721,13 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
     for (int c = 0; c < 2; ++c) {
       const size_t lds = (size_t)((caps[c] + 47) & ~15ll) + 2 * (size_t)kSecRecs * 4;
       hipLaunchKernelGGL(section_kernel, dim3((unsigned)total_sections), dim3(kSecThreads), lds, st, dby, (const Section*)dsec, total_sections, c == 0 ? -1 : caps[0],
-                         caps[c], c == 1 ? 1 : 0, d->seed, jc, dmeta, (uint4*)s.ev_tmp.p, (uint32_t*)s.f64_list.p, derr);
+                         caps[c], c == 1 ? 1 : 0, seed, jc, dmeta, (uint4*)s.ev_tmp.p, (uint32_t*)s.f64_list.p, derr);
     }
     DCHK(d, hipGetLastError());
   }
   lap("section launches");
   s.n_rec = n_rec;
-  s.seed = d->seed;
+  s.seed = seed;
   return OK;
 }
 
@@ -1697,6 +1736,7 @@ int32_t stage1_records(surge_device_decoder* d, PushSlot& s, const uint8_t* keys
                        const int64_t* offsets, int64_t n) {
   s.n_rec = 0;
   s.wire = false;
+  const uint64_t seed = d->seed.load();
   if (n == 0) return OK;
   if (n >= (1ll << 32) - 1) return dfail(d, E_UNSUPPORTED, "more than 2^32 - 2 records in one push");
   const int64_t kb = key_off[n] - key_off[0], vb = value_off[n] - value_off[0];
@@ -1729,12 +1769,12 @@ int32_t stage1_records(surge_device_decoder* d, PushSlot& s, const uint8_t* keys
   DCHK(d, hipMemcpyAsync(s.rec_b.p, p_vo, off_bytes, hipMemcpyHostToDevice, st));
   if (offsets) DCHK(d, hipMemcpyAsync(s.rec_c.p, p_of, (size_t)n * 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(records_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)s.d_bytes.p, (const int64_t*)s.rec_a.p,
-                     (const int64_t*)s.rec_b.p, offsets ? (const int64_t*)s.rec_c.p : nullptr, kb, n, d->seed,
+                     (const int64_t*)s.rec_b.p, offsets ? (const int64_t*)s.rec_c.p : nullptr, kb, n, seed,
                      JsonCtx{d->json ? (const EvjDevice*)d->d_tmpl.p : nullptr, (const surge::F64ParseTable*)d->d_ptab.p},
                      (RecMeta*)s.meta.p, (uint4*)s.ev_tmp.p, (uint32_t*)s.f64_list.p, (ErrorCell*)s.d_err.p);
   DCHK(d, hipGetLastError());
   s.n_rec = n;
-  s.seed = d->seed;
+  s.seed = seed;
   return OK;
 }
 
@@ -1742,8 +1782,9 @@ int32_t stage1_records(surge_device_decoder* d, PushSlot& s, const uint8_t* keys
 // decoder's stream.  Two synchronisations: one in the middle (what the push discovered: errors, new keys, their bytes,
 // delivered records — everything the allocations behind it need), one at the end.  Nothing is committed before the
 // first: a push that fails takes the keys it probed out of the table again (rollback_kernel), so a failed push leaves
-// the decoder exactly as it was.
-int32_t stage2(surge_device_decoder* d, PushSlot& s) {
+// the decoder exactly as it was.  wait = false leaves the second synchronisation out: the results are complete in the
+// order of the decoder's stream (surge_device_decoder_push_finish_async).
+int32_t stage2(surge_device_decoder* d, PushSlot& s, bool wait) {
   const int64_t n_rec = s.n_rec;
   if (n_rec == 0) return OK;
   hipStream_t st = d->stream;
@@ -1855,6 +1896,10 @@ int32_t stage2(surge_device_decoder* d, PushSlot& s) {
       return dfail(d, e == hipErrorOutOfMemory ? E_NOMEM : E_DEVICE, std::string("growing the key table / result arrays: ") + hipGetErrorString(e));
     }
   }
+  if (d->consumed_valid) {  // an asynchronous consumer of the last results (surge_replay_append_decoded_async) reads the arrays finalize_kernel writes
+    PCHK(hipStreamWaitEvent(st, d->consumed, 0));
+    d->consumed_valid = false;
+  }
   if (n_new > 0)
     hipLaunchKernelGGL(assign_kernel, dim3(rb), dim3(256), 0, st, (const RecMeta*)dmeta, n_rec, dby, (const unsigned long long*)d->first.p,
                        (const unsigned long long*)d->first_scan.p, d->n_keys, d->arena_bytes, table_of(d), (uint8_t*)d->arena.p, (int64_t*)d->key_off.p,
@@ -1888,7 +1933,12 @@ int32_t stage2(surge_device_decoder* d, PushSlot& s) {
   d->counters[1] += kept;
   d->counters[2] += n_rec - kept;
   ++d->pushes;
-  PCHK(hipStreamSynchronize(st));
+  if (wait) {
+    PCHK(hipStreamSynchronize(st));
+  } else {  // the slot's buffers are read until here: its next stage 1 waits for this point of the stream
+    PCHK(hipEventRecord(s.released, st));
+    s.released_valid = true;
+  }
   return OK;
 #undef PCHK
 }
@@ -1897,18 +1947,30 @@ int32_t stage2(surge_device_decoder* d, PushSlot& s) {
 int32_t commit_slot(surge_device_decoder* d, PushSlot& s) {
   DCHK(d, hipEventRecord(s.done, s.stream));
   s.busy = true;
+  std::lock_guard<std::mutex> lk(d->mu);
   ++d->n_pending;
   return OK;
 }
 
-int32_t finish_oldest(surge_device_decoder* d) {
-  PushSlot& s = d->slots[d->head];
-  const int32_t rc = stage2(d, s);
+int32_t finish_oldest(surge_device_decoder* d, bool wait) {
+  PushSlot* sp;
+  {
+    std::lock_guard<std::mutex> lk(d->mu);
+    if (d->n_pending == 0) sp = nullptr;
+    else sp = &d->slots[d->head];
+  }
+  if (!sp) return dfail(d, SURGE_E_STATE, "push_finish without a pending push_async");
+  PushSlot& s = *sp;
+  const int32_t rc = stage2(d, s, wait);
   if (rc != OK) {
-    // the slot's buffers are still being written by its own stream if stage 2 never waited for it
+    // the slot's buffers are still being written by its own stream if stage 2 never waited for it, and read by
+    // whatever stage 2 launched before it gave up
     (void)hipStreamSynchronize(s.stream);
+    (void)hipStreamSynchronize(d->stream);
+    s.released_valid = false;
   }
   s.busy = false;
+  std::lock_guard<std::mutex> lk(d->mu);
   d->head = (d->head + 1) % kSlots;
   --d->n_pending;
   return rc;
@@ -1926,6 +1988,8 @@ int32_t surge_device_decoder_push_parts_async(surge_device_decoder* d, int32_t n
   PushSlot* s = claim_slot(d, &rc);
   if (!s) return rc;
   DeviceScope scope(d->device);
+  rc = await_release(d, *s);
+  if (rc != OK) return rc;
   rc = stage1_wire(d, *s, n_parts, bytes, sections, n_sections);
   if (rc != OK) {
     (void)hipStreamSynchronize(s->stream);  // whatever was enqueued before the failure reads host memory of this call
@@ -1940,12 +2004,21 @@ int32_t surge_device_decoder_push_async(surge_device_decoder* d, const uint8_t* 
 
 int32_t surge_device_decoder_push_finish(surge_device_decoder* d) {
   if (!d) return dfail(nullptr, E_INVALID, "decoder is NULL");
-  if (d->n_pending == 0) return dfail(d, SURGE_E_STATE, "push_finish without a pending push_async");
   DeviceScope scope(d->device);
-  return finish_oldest(d);
+  return finish_oldest(d, true);
 }
 
-int32_t surge_device_decoder_pending(const surge_device_decoder* d) { return d ? d->n_pending : 0; }
+int32_t surge_device_decoder_push_finish_async(surge_device_decoder* d) {
+  if (!d) return dfail(nullptr, E_INVALID, "decoder is NULL");
+  DeviceScope scope(d->device);
+  return finish_oldest(d, false);
+}
+
+int32_t surge_device_decoder_pending(const surge_device_decoder* d) {
+  if (!d) return 0;
+  std::lock_guard<std::mutex> lk(const_cast<surge_device_decoder*>(d)->mu);
+  return d->n_pending;
+}
 
 int32_t surge_device_decoder_reserve(surge_device_decoder* d, int64_t n_keys, int64_t key_bytes) {
   if (!d) return dfail(nullptr, E_INVALID, "decoder is NULL");
@@ -1984,13 +2057,15 @@ int32_t surge_device_decoder_push_records(surge_device_decoder* d, const uint8_t
   PushSlot* s = claim_slot(d, &rc);
   if (!s) return rc;
   DeviceScope scope(d->device);
+  rc = await_release(d, *s);
+  if (rc != OK) return rc;
   rc = stage1_records(d, *s, keys, key_off, values, value_off, offsets, n);
   if (rc != OK) {
     (void)hipStreamSynchronize(s->stream);
     return rc;
   }
   rc = commit_slot(d, *s);
-  return rc != OK ? rc : finish_oldest(d);
+  return rc != OK ? rc : finish_oldest(d, true);
 }
 
 int32_t surge_device_decoder_result(surge_device_decoder* d, int64_t* n_records, const int64_t** d_agg_idx, const void** d_events16,
@@ -2030,6 +2105,43 @@ int32_t surge_replay_append_decoded(surge_replay_handle* h, surge_device_decoder
     if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
     rc = surge_replay_synchronize(h);  // the arrays are reused by the next push
     if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
+  }
+  d->n_records = 0;
+  return OK;
+}
+
+// The same hand-over without a host wait on either side: the handle's stream waits (event) for the decoder's stream to
+// have written the arrays, the group-by and the fold are enqueued behind that, and the next push_finish's stage 2 waits
+// (event) for the group-by's last read before it writes the arrays again.  The host thread only ever waits in the middle
+// of stage 2 (what the push discovered), so interning of fetch i + 1 overlaps the fold of fetch i on the device.
+int32_t surge_replay_append_decoded_async(surge_replay_handle* h, surge_device_decoder* d, int64_t* n_events_out, int64_t* n_keys_out) {
+  if (!h || !d) return dfail(d, E_INVALID, "NULL argument");
+  if (n_events_out) *n_events_out = d->n_records;
+  if (n_keys_out) *n_keys_out = d->n_keys;
+  void* d_states = nullptr;
+  int64_t n_agg = 0;
+  int32_t rc = surge_replay_device_state(h, &d_states, &n_agg);
+  if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
+  if (d->n_keys > n_agg) {
+    rc = surge_replay_grow(h, d->n_keys);
+    if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
+  }
+  if (d->n_records > 0) {
+    void* hs = nullptr;
+    rc = surge_replay_get_stream(h, &hs);
+    if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
+    DeviceScope scope(d->device);
+    DCHK(d, hipEventRecord(d->ready, d->stream));
+    DCHK(d, hipStreamWaitEvent((hipStream_t)hs, d->ready, 0));
+    rc = surge_replay_append_events_device(h, (const int64_t*)d->r_agg.p, d->r_ev.p, d->n_records);
+    // (recorded also when the append failed half way: whatever it enqueued reads the arrays)
+    const hipError_t e = hipEventRecord(d->consumed, (hipStream_t)hs);
+    d->consumed_valid = e == hipSuccess;
+    if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
+    if (e != hipSuccess) {
+      (void)surge_replay_synchronize(h);
+      return dfail(d, E_DEVICE, std::string("hipEventRecord: ") + hipGetErrorString(e));
+    }
   }
   d->n_records = 0;
   return OK;

@@ -387,6 +387,99 @@ class PartitionedFramedFetches:
         self.close()
 
 
+class PushPipeline:
+    """Keeps ``depth`` pushes in flight with the host work of ENQUEUEING them off the consumer's thread: a worker takes the
+    framed fetches from ``source`` (a ``FramedFetches`` / ``PartitionedFramedFetches`` made with ``hold=depth``) and calls
+    ``push(item)`` — section tables, staging, a dozen launches: about a millisecond of host time per 10^6-record fetch —
+    while the caller's thread finishes the oldest push and folds it.  Iterating yields once per enqueued push (whatever
+    ``push`` returned; a falsy return = nothing was pushed for that fetch, nothing is yielded); the caller finishes that
+    push and calls ``done()``.  The worker asks ``source`` for fetch i + depth only after ``done()`` for fetch i — asking is
+    what lets the framer reuse fetch i's slab.  ``threaded=False``: the same protocol inline, one push at a time."""
+
+    def __init__(self, source, push, depth: int, threaded: bool = True):
+        import queue
+        import threading
+
+        self._source, self._push, self._depth = iter(source), push, depth
+        self._free = threading.Semaphore(depth)
+        self._q: "queue.Queue" = queue.Queue()
+        self._stop = False
+        self.push_seconds: List[float] = []
+        self._thread = threading.Thread(target=self._run, name="surge-push", daemon=True) if threaded else None
+        if self._thread:
+            self._thread.start()
+
+    def _one(self):
+        """-> a token to yield, None to skip this fetch, or StopIteration"""
+        import time
+
+        item = next(self._source)
+        t0 = time.perf_counter()
+        token = self._push(item)
+        if token:
+            self.push_seconds.append(time.perf_counter() - t0)
+        return token
+
+    def _run(self):
+        try:
+            while True:
+                self._free.acquire()
+                if self._stop:
+                    break
+                try:
+                    token = self._one()
+                except StopIteration:
+                    break
+                if token:
+                    self._q.put(token)
+                else:
+                    self._free.release()
+        except BaseException as e:  # handed to the consumer
+            self._q.put(e)
+        finally:
+            self._q.put(None)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._thread is None:
+            while True:
+                if not self._free.acquire(blocking=False):
+                    raise RuntimeError("PushPipeline(threaded=False): call done() for the previous push before asking for the next")
+                token = self._one()  # (StopIteration ends the iteration)
+                if token:
+                    return token
+                self._free.release()
+        item = self._q.get()
+        if item is None:
+            self._q.put(None)
+            raise StopIteration
+        if isinstance(item, BaseException):
+            self._q.put(None)
+            raise item
+        return item
+
+    def done(self) -> None:
+        self._free.release()
+
+    def close(self) -> None:
+        """Stops the worker (it finishes the push it is in).  ``source`` must still be open: the worker may be waiting for
+        its next fetch."""
+        self._stop = True
+        if self._thread:
+            for _ in range(self._depth):
+                self._free.release()
+            self._thread.join()
+            self._thread = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 class DeviceDecoder:
     """``surge_device_decoder``: records sections (host bytes) -> device-resident ``(agg_idx, events, offsets)`` and a
     device key table.  ``template=None``: record values are 16-byte events; otherwise the model's ``EventJsonTemplate``."""
@@ -395,6 +488,7 @@ class DeviceDecoder:
         self._lib = _native.load()
         self._h = ctypes.c_void_p()
         self.device = device
+        self._inflight = []
         c = template.to_c() if template is not None else None
         rc = self._lib.surge_device_decoder_create(device, stream, ctypes.byref(c) if c is not None else None, ctypes.byref(self._h))
         if rc != 0:
@@ -433,15 +527,33 @@ class DeviceDecoder:
         secs_arr = (ctypes.c_void_p * n)(*[s.ctypes.data_as(ctypes.c_void_p) for s in secs])
         cnt = (ctypes.c_int64 * n)(*[s.shape[0] for s in secs])
         self._check(self._lib.surge_device_decoder_push_parts_async(self._h, n, bytes_arr, secs_arr, cnt))
-        self._inflight = getattr(self, "_inflight", [])
-        self._inflight.append((secs, bytes_arr, secs_arr, cnt))  # the section arrays are read until finish()
+        self._inflight.append((secs, bytes_arr, secs_arr, cnt))  # (kept until finish(); list.append / pop are atomic: a pushing and a finishing thread share it)
 
-    def finish(self) -> None:
-        """Stage 2 of the oldest unfinished push: key interning, append to the result (``result()``)."""
-        rc = self._lib.surge_device_decoder_push_finish(self._h)
-        if getattr(self, "_inflight", None):
+    def finish(self, wait: bool = True) -> None:
+        """Stage 2 of the oldest unfinished push: key interning, append to the result (``result()``).  ``wait=False``
+        (``surge_device_decoder_push_finish_async``) returns without the closing wait for the device: the results are
+        complete in the order of the decoder's stream — hand them over with ``fold_into(engine, wait=False)``.  One thread
+        may call ``push_async`` while another calls ``finish`` / ``fold_into`` (``PushPipeline``)."""
+        rc = (self._lib.surge_device_decoder_push_finish if wait else self._lib.surge_device_decoder_push_finish_async)(self._h)
+        if self._inflight:
             self._inflight.pop(0)
         self._check(rc)
+
+    def fold_into(self, engine, wait: bool = True):
+        """Everything decoded since the last clear, folded onto ``engine``'s resident state (grown first for ids seen for the
+        first time), and cleared: ``surge_replay_append_decoded``; with ``wait=False`` its ``_async`` form — no host wait,
+        the two streams are ordered by events, so with the engine on a stream of its own the interning of the next fetch
+        overlaps this fold.  Returns ``(n_events, n_keys)``."""
+        n_ev, n_keys = ctypes.c_int64(), ctypes.c_int64()
+        fn = self._lib.surge_replay_append_decoded if wait else self._lib.surge_replay_append_decoded_async
+        self._check(fn(engine._h, self._h, ctypes.byref(n_ev), ctypes.byref(n_keys)))
+        return int(n_ev.value), int(n_keys.value)
+
+    @property
+    def n_keys(self) -> int:
+        n = ctypes.c_int64()
+        self._check(self._lib.surge_device_decoder_result(self._h, None, None, None, None, ctypes.byref(n)))
+        return int(n.value)
 
     def reserve(self, n_keys: int, key_bytes: int) -> None:
         """Capacity hint (``surge_device_decoder_reserve``): room for ``n_keys`` aggregate ids of ``key_bytes`` bytes in all."""

@@ -11,6 +11,7 @@ Host (numpy) buffers go through ``surge_replay_load_csr``; device buffers (torch
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 from typing import Optional
 
@@ -114,6 +115,34 @@ class ReplayEngine:
         """Launch on a ``torch.cuda.Stream`` (or ``None`` for the default stream)."""
         ptr = None if stream is None else ctypes.c_void_p(stream.cuda_stream)
         self._check(self._lib.surge_replay_set_stream(self._h, ptr))
+
+    @property
+    def stream_ptr(self) -> int:
+        """The ``hipStream_t`` the engine's work goes to, as an integer (0 = the default stream)."""
+        p = ctypes.c_void_p()
+        self._check(self._lib.surge_replay_get_stream(self._h, ctypes.byref(p)))
+        return int(p.value or 0)
+
+    @contextlib.contextmanager
+    def on_own_stream(self):
+        """For the duration of the block the engine works on a non-blocking stream of its own (unless it was given one
+        already): work that other streams enqueue — a device decoder's interning on the default stream — then overlaps the
+        engine's group-by and fold instead of queueing behind them.  Synchronised on the way in and on the way out."""
+        if self.stream_ptr:
+            yield
+            return
+        import torch
+
+        self.synchronize()
+        st = torch.cuda.Stream(device=self.device)  # (PyTorch's pool streams are created non-blocking)
+        self.use_stream(st)
+        try:
+            yield
+        finally:
+            try:
+                self.synchronize()
+            finally:
+                self.use_stream(None)
 
     def synchronize(self) -> None:
         self._check(self._lib.surge_replay_synchronize(self._h))

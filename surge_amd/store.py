@@ -17,6 +17,7 @@ format stays the plugin's: the engine hands a fixed-width state to ``writeState`
 from __future__ import annotations
 
 import bisect
+import contextlib
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -121,7 +122,8 @@ class GpuReplayStateStore:
         self._restored = True
         return counters
 
-    def restore_from_fetches(self, fetches, capacity: int = 0, overlap: bool = True, n_partitions: int = 0, framing_threads: int = 8) -> dict:
+    def restore_from_fetches(self, fetches, capacity: int = 0, overlap: bool = True, n_partitions: int = 0, framing_threads: int = 8,
+                             consumer_threads: int = 1) -> dict:
         """Recover from the events topic as a consumer receives it: ``fetches`` yields the record-batch bytes of one
         partition, fetch by fetch, in offset order (a list, or a generator that polls) — or, with ``n_partitions``, per
         fetch response the next bytes of each of the consumer's partitions (``PartitionedFramedFetches``: one framer per
@@ -131,64 +133,94 @@ class GpuReplayStateStore:
         whose events are grouped and folded onto the resident state (the K3 path), so neither side waits for the other;
         the resident state and the device key table grow as new aggregates appear.  What
         ``SurgeStateStoreConsumer.scala:33-46,57-76`` does record by record through Kafka Streams' restore.
+        ``consumer_threads=2`` moves the host work of enqueueing a push (section tables, staging, launches: about a
+        millisecond per 10^6-record fetch) to a worker thread and hands the results to the fold without a host wait
+        (``PushPipeline``, ``surge_replay_append_decoded_async``); measured on the 10^7-aggregate topic it is not faster —
+        the device is the bound there, not this thread — so one thread is the default.
         Needs values the device decoder reads (16-byte fixed events, or JSON with the model's
         ``event_json_template``); returns the ingest + decoder counters."""
-        from .ingest import DeviceDecoder, FramedFetches, PartitionedFramedFetches
+        from .ingest import DeviceDecoder, FramedFetches, PartitionedFramedFetches, PushPipeline
         from .log import KeyTable
         from .schema import EVENT_DTYPE
 
         template = self.model.event_json_template()
         d = None
         n_agg = -1
-        depth = 4 if overlap else 1  # pushes in flight (measured on the 10 M-aggregate topic: 2 / 3 / 4 / 5 in flight = 4.1 / 4.3 / 4.65 / 4.7e8 events/s on one box): stage 1 of the next fetches runs while this one is interned and folded
-        pending = 0
+        # pushes in flight (measured on the 10 M-aggregate topic: 2 / 3 / 4 / 5 in flight = 4.1 / 4.3 / 4.65 / 4.7e8 events/s on
+        # one box): stage 1 of the next fetches runs while this one is interned and folded
+        depth = 4 if overlap else 1
+
+        def push(item):
+            """(the pipeline's worker thread) stage 1 of one fetch; the decoder is made for the first fetch with a record in it"""
+            nonlocal d
+            parts = item if isinstance(item, list) else [item]
+            parts = [(sec, arena) for sec, arena in parts if sec.shape[0]]
+            if not parts and d is None:
+                return False  # (nothing pushed yet: nothing in flight that the framer could overtake)
+            if d is None:
+                kind = None
+                for sec, arena in parts:
+                    kind = kind or _sniff_value_kind(sec, arena)  # "fixed16", "json" or None (no deliverable record)
+                if kind == "json" and template is None:
+                    raise _NotDeviceDecodable("JSON event values need the model's event_json_template")
+                d = DeviceDecoder(template if kind == "json" else None, device=self.engine.device)
+            d.push_async(parts)
+            return True
+
+        two_threads = overlap and consumer_threads >= 2
 
         def finish_one():
             nonlocal n_agg
-            d.finish()
-            agg_idx, events, _, n_keys = d.result()
+            if n_agg < 0:
+                n_agg = capacity
+                self.engine.load_csr(np.zeros(n_agg + 1, dtype=np.int64), np.zeros(0, dtype=EVENT_DTYPE))
+                self.engine.fold()  # every aggregate None
+            # two threads: no host wait behind the interning or the fold — the decoder's stream and the engine's are ordered by
+            # events, so the next fetch's interning runs beside this one's group-by and fold
+            d.finish(wait=not two_threads)
+            _, n_keys = d.fold_into(self.engine, wait=not two_threads)  # grows the resident state for new ids, group-by + fold (K3), clears
             if n_keys > n_agg:
-                self.engine.grow(n_keys)
-                n_agg = n_keys
-            if agg_idx.shape[0]:
-                self.engine.append_events(agg_idx, events)  # device arrays straight into the device group-by
-                self.engine.synchronize()  # the arrays are the decoder's: done with them before the next finish
-            d.clear()
+                self.engine.n_agg = n_agg = n_keys  # (grown inside the call)
 
         try:
             framer = (PartitionedFramedFetches(fetches, n_partitions, threads=framing_threads, hold=depth, overlap=overlap) if n_partitions
                       else FramedFetches(fetches, overlap=overlap, hold=depth))
-            with framer as framed:
-                fetch_iter = iter(framed)
-                while True:
-                    # the oldest push is finished BEFORE the next fetch is asked for: asking tells the framer that the oldest
-                    # fetch's arena / slab may be framed into again, and a push reads its bytes until it is finished
-                    if pending == depth:
-                        finish_one()
-                        pending -= 1
-                    item = next(fetch_iter, None)
-                    if item is None:
-                        break
-                    parts = item if isinstance(item, list) else [item]
-                    parts = [(sec, arena) for sec, arena in parts if sec.shape[0]]
-                    if not parts and d is None:
-                        continue  # (nothing pushed yet: nothing in flight that the framer could overtake)
-                    if d is None:
-                        kind = None
-                        for sec, arena in parts:
-                            kind = kind or _sniff_value_kind(sec, arena)  # "fixed16", "json" or None (no deliverable record)
-                        if kind == "json" and template is None:
-                            raise _NotDeviceDecodable("JSON event values need the model's event_json_template")
-                        d = DeviceDecoder(template if kind == "json" else None, device=self.engine.device)
-                    if n_agg < 0:
-                        n_agg = capacity
-                        self.engine.load_csr(np.zeros(n_agg + 1, dtype=np.int64), np.zeros(0, dtype=EVENT_DTYPE))
-                        self.engine.fold()  # every aggregate None
-                    d.push_async(parts)
-                    pending += 1
-                while pending:
-                    finish_one()
-                    pending -= 1
+            with framer as framed, (self.engine.on_own_stream() if two_threads else contextlib.nullcontext()):
+                try:
+                    if two_threads:
+                        # the framer's thread (headers, CRC-32C, transactions of the next fetch), the pipeline's worker (stage 1 of
+                        # up to `depth` fetches ahead) and this one (interning + fold of the oldest push).  The worker asks for
+                        # fetch i + depth only after push i is finished: asking tells the framer that fetch i's arena / slab may
+                        # be framed into again, and a push reads its bytes until then.
+                        with PushPipeline(framed, push, depth) as pipe:
+                            for _ in pipe:
+                                finish_one()
+                                pipe.done()
+                    else:
+                        pending = 0
+                        fetch_iter = iter(framed)
+                        while True:
+                            # the oldest push is finished BEFORE the next fetch is asked for (see above)
+                            if pending == depth:
+                                finish_one()
+                                pending -= 1
+                            item = next(fetch_iter, None)
+                            if item is None:
+                                break
+                            if push(item):
+                                pending += 1
+                        while pending:
+                            finish_one()
+                            pending -= 1
+                finally:
+                    if d is not None:  # (an error path: pushes that are enqueued read the framer's slabs until they are finished)
+                        while d.pending:
+                            try:
+                                d.finish()
+                            except Exception:
+                                pass
+                if d is not None:
+                    self.engine.synchronize()
                 counters = framed.counters()
             if n_agg < 0:  # nothing deliverable in the whole topic
                 n_agg = capacity

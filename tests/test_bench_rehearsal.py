@@ -107,16 +107,18 @@ def test_bench_workload_v2_reports_four_variants_of_the_same_device_code_and_ful
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--serial-framing"], ["--codec", "none"], ["--no-capacity-hint"]])
+@pytest.mark.parametrize("extra", [[], ["--serial-framing"], ["--codec", "none"], ["--no-capacity-hint"], ["--two-thread-consumer"]])
 def test_bench_workload_e2e_goes_from_topic_bytes_to_states_and_checks_them_against_the_source_events(extra):
     """The C3-shaped topic at a small size: 30 000 aggregates over 64 partitions, lz4 batches of 16 KiB, fetches of 20 000
-    records framed per partition on host threads, one device push per fetch (four in flight), states compared with the
-    oracle's fold of the events the GENERATOR published — not of what the device decoded."""
+    records framed per partition on host threads, one device push per fetch (four in flight; ``--two-thread-consumer``:
+    enqueued by a worker thread while this thread interns and folds the oldest without a host wait),
+    states compared with the oracle's fold of the events the GENERATOR published — not of what the device decoded."""
     d = run_single(["--workload", "e2e", "--aggregates", "30000", "--batch-events", "20000", "--warmup", "1", "--framing-threads", "4"] + extra)
     cfg = d["config"]
     assert cfg["fetch_records"] == 20000 and cfg["partitions"] == 64 and cfg["keys_interned"] == 30000
     assert cfg["decoder"]["records_delivered"] == cfg["ingest"]["records_delivered"] == cfg["events_timed"] + 20000  # + the warm-up fetch
     assert cfg["pushes_in_flight"] == (1 if "--serial-framing" in extra else 4) and cfg["decoder"]["hash_reseeds"] == 0
+    assert cfg["consumer"].startswith("push worker thread" if "--two-thread-consumer" in extra else "one thread")
     assert d["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_source_events"] is True and d["value"] > 0 and d["n_gpus"] == 1
     assert abs(d["value"] - cfg["events_timed"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
 

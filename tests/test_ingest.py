@@ -672,3 +672,65 @@ def test_partitioned_framed_fetches_frame_every_partition_like_its_own_framer_an
                 assert snap == flat_want[len(got) - len(alive): len(got)]
             assert framed.counters() == want_counters
         assert got == flat_want
+
+
+def test_push_pipeline_runs_pushes_on_its_worker_at_most_depth_ahead_and_in_order():
+    """The protocol ``store.restore_from_fetches`` and ``bench.py --workload e2e`` consume fetches with: the worker asks the
+    source for item i + depth only after ``done()`` for item i, tokens come out in source order, items whose push returns a
+    falsy value are skipped without taking a slot, and the worker's exception is raised in the consumer."""
+    import threading
+    import time
+
+    from surge_amd.ingest import PushPipeline
+
+    asked, pushed, finished = [], [], []
+    main = threading.get_ident()
+
+    def source():
+        for i in range(20):
+            asked.append((i, len(finished)))
+            yield i
+
+    def push(i):
+        assert threading.get_ident() != main
+        if i % 5 == 4:
+            return False  # (an empty fetch)
+        pushed.append(i)
+        return ("token", i)
+
+    with PushPipeline(source(), push, 3) as pipe:
+        for tok in pipe:
+            time.sleep(0.002)  # (the worker runs ahead while the consumer is busy)
+            finished.append(tok[1])
+            pipe.done()
+    assert finished == pushed == [i for i in range(20) if i % 5 != 4]
+    for i, n_done in asked:  # when item i was asked for, all but at most depth - 1 of the pushes before it were finished
+        before = sum(1 for j in range(i) if j % 5 != 4)
+        assert before - n_done <= 2, (i, n_done)
+    assert max(before - n for i, n in asked for before in [sum(1 for j in range(i) if j % 5 != 4)]) == 2  # it does run ahead
+
+    # inline: same tokens, one at a time, on the caller's thread
+    seen = []
+    pipe = PushPipeline(iter(range(6)), lambda i: (seen.append(threading.get_ident()), i + 1)[1], 1, threaded=False)
+    out = []
+    for tok in pipe:
+        out.append(tok)
+        pipe.done()
+    assert out == [1, 2, 3, 4, 5, 6] and set(seen) == {main}
+    pipe = PushPipeline(iter(range(3)), lambda i: i + 1, 1, threaded=False)
+    assert next(pipe) == 1
+    with pytest.raises(RuntimeError, match="done"):
+        next(pipe)
+
+    def bad_push(i):
+        if i == 2:
+            raise ValueError("push 2 failed")
+        return True
+
+    got = 0
+    with pytest.raises(ValueError, match="push 2 failed"):
+        with PushPipeline(iter(range(10)), bad_push, 2) as pipe:
+            for _ in pipe:
+                got += 1
+                pipe.done()
+    assert got == 2

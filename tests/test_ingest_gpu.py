@@ -610,3 +610,72 @@ def test_events_topic_bytes_to_states_without_the_host_touching_a_record():
         for a in (0, len(keys) // 2, len(keys) - 1):
             o = json.loads(out[offs[a]:offs[a + 1]])
             assert o["aggregateId"] == keys[a] and o["count"] == int(states[a]["count"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weak_hash", [False, True])
+def test_two_host_threads_drive_one_decoder_and_the_fold_takes_the_results_without_a_host_wait(monkeypatch, weak_hash):
+    """The recovery pipeline's threading contract (include/surge_ingest.h): ONE thread enqueues stage 1 of up to four fetches
+    ahead (``PushPipeline``'s worker: ``push_async``), ONE other finishes the oldest push without the closing wait
+    (``finish(wait=False)``) and hands the results to the engine — on a stream of its own — with
+    ``surge_replay_append_decoded_async`` (events order the two streams; slots and result arrays are reused behind events,
+    not behind host waits).  40 fetches through 5 slots: same key table and same states as the same bytes pushed one at a
+    time with a host wait after every step — also when the table is re-seeded (weak first hash function) while later
+    fetches, hashed with the old function, are already in flight."""
+    from surge_amd.ingest import FramedFetches, PushPipeline
+    from surge_amd.replay import ReplayEngine
+
+    if weak_hash:
+        monkeypatch.setenv("SURGE_INGEST_DEBUG_WEAK_HASH", "1")
+    rng = random.Random(77)
+    bl = CounterBusinessLogic()
+    model, fmt = bl.command_model(), bl.event_write_formatting()
+    seqs, recs, published = {}, [], {}
+    for i in range(60000):
+        agg = f"agg-{min(i // 12, int(rng.paretovariate(1.1)) % 6000)}"  # new ids keep appearing through the whole topic
+        seqs[agg] = seqs.get(agg, 0) + 1
+        e = rng.choice([CountIncremented(agg, rng.randrange(1, 9), seqs[agg]), CountDecremented(agg, rng.randrange(1, 9), seqs[agg]), NoOpEvent(agg, seqs[agg])])
+        m = fmt.write_event(e)
+        recs.append((m.key.encode(), m.value))
+        published.setdefault(agg, []).append(e)
+    batches = [kw.record_batch(s, recs[s:s + 300], compression="lz4" if (s // 300) % 3 else "none") for s in range(0, len(recs), 300)]
+    fetches = [b"".join(batches[i:i + 5]) for i in range(0, len(batches), 5)]
+    assert len(fetches) == 40
+
+    def run(pipelined):
+        with DeviceDecoder(model.event_json_template()) as d, ReplayEngine(model.event_algebra()) as eng:
+            eng.load_csr(np.zeros(1, np.int64), np.zeros(0, dtype=S.EVENT_DTYPE))
+            eng.fold()
+            if pipelined:
+                def push(item):
+                    d.push_async(item)
+                    return True
+
+                with FramedFetches(fetches, hold=4) as framed, eng.on_own_stream(), PushPipeline(framed, push, 4) as pipe:
+                    assert eng.stream_ptr != 0
+                    for _ in pipe:
+                        d.finish(wait=False)
+                        d.fold_into(eng, wait=False)
+                        pipe.done()
+                    eng.synchronize()
+                assert eng.stream_ptr == 0
+            else:
+                with EventsTopicIngest(frames=True) as g:
+                    for f in fetches:
+                        g.feed(f)
+                        d.push_from(g)
+                        d.fold_into(eng)
+            n_keys = d.n_keys
+            eng.n_agg = n_keys  # (grown inside fold_into)
+            return d.keys(), eng.snapshot(), d.stats()
+
+    keys_a, states_a, st_a = run(False)
+    keys_b, states_b, st_b = run(True)
+    assert keys_a == keys_b and len(keys_a) == len(seqs) and states_a.tobytes() == states_b.tobytes()
+    assert st_b["records_delivered"] == 60000 == st_a["records_delivered"] and st_b["pushes"] == 40
+    assert (st_b["hash_reseeds"] >= 1) == weak_hash
+    by_key = {k: i for i, k in enumerate(keys_b)}
+    for agg in list(published)[:: max(1, len(published) // 60)]:  # and against the oracle's fold of the published events, per aggregate
+        evs = model.encode_events(published[agg])
+        off = np.array([0, evs.shape[0]], np.int64)
+        assert states_b[by_key[agg]].tobytes() == oracle.fold_csr(off, evs, None, model.event_algebra())[0].tobytes(), agg

@@ -289,12 +289,13 @@ def test_recovery_fetch_by_fetch_equals_recovery_from_the_whole_partition(overla
 
 # ---- round-2 regressions (aggregates that first appear after recovery) ------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("overlap", [False, True])
-def test_recovery_of_a_consumer_with_several_partitions_equals_the_literal_fold(overlap):
+@pytest.mark.parametrize("overlap,consumer_threads", [(False, 1), (True, 1), (True, 2)])
+def test_recovery_of_a_consumer_with_several_partitions_equals_the_literal_fold(overlap, consumer_threads):
     """restore_from_fetches(n_partitions=P): what a restore consumer with several assigned partitions receives — per fetch
     response the next bytes of every partition, framed per partition (transactions, an aborted flush, a flush that commits a
     fetch later, a batch cut by the end of a fetch) into one slab, ONE device push per fetch with four in flight, the
-    resident state growing as aggregates appear — gives every aggregate the state the literal handle_event fold gives it."""
+    resident state growing as aggregates appear — gives every aggregate the state the literal handle_event fold gives it;
+    also with the pushes enqueued by a worker thread and handed to the fold without a host wait (consumer_threads=2)."""
     import random
 
     import kafka_wire as kw
@@ -346,7 +347,7 @@ def test_recovery_of_a_consumer_with_several_partitions_equals_the_literal_fold(
     fetches = [[logs[p][f] or None for p in range(P)] for f in range(F)]
     store = GpuReplayStateStore(bl)
     try:
-        counters = store.restore_from_fetches(fetches, n_partitions=P, framing_threads=3, overlap=overlap)
+        counters = store.restore_from_fetches(fetches, n_partitions=P, framing_threads=3, overlap=overlap, consumer_threads=consumer_threads)
         assert counters["open_transactions"] == 0
         assert set(store.keys.keys) == set(expect) and counters["records_aborted"] > 0
         for k, st in expect.items():
