@@ -297,6 +297,10 @@ int32_t surge_replay_kernel_info(surge_replay_handle* h, surge_replay_kernel_inf
  * GPU.  code_out nullable (size query); *code_bytes is set either way.  For build-time checks of a model's schema. */
 int32_t surge_replay_compile_schema_v2(const surge_replay_schema_v2* schema, const char* arch, void* code_out, int64_t capacity,
                                        int64_t* code_bytes);
+/* The same for a v1 schema: the code object of the flat fold kernel (K3 appends; AUTO on logs of few long rows) compiled
+ * for the schema's op table — the one v1 kernel that is bound by its instruction stream, and the one a v1 handle compiles
+ * at its first flat fold (surge_replay_kernel_info says which build runs; SURGE_REPLAY_RTC=0 keeps the ahead-of-time one). */
+int32_t surge_replay_compile_schema(const surge_replay_schema* schema, const char* arch, void* code_out, int64_t capacity, int64_t* code_bytes);
 int32_t surge_replay_destroy(surge_replay_handle* h);
 const char* surge_replay_last_error(const surge_replay_handle* h);
 

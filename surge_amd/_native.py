@@ -24,7 +24,7 @@ def _read_sources() -> tuple:
 
 
 SOURCES = _read_sources()
-HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "fold_chunk_device.h"), os.path.join(CSRC, "fold_slots_device.h"), os.path.join(CSRC, "f64_text.h"), os.path.join(CSRC, "f64_parse.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
+HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "fold_chunk_device.h"), os.path.join(CSRC, "fold_flat_device.h"), os.path.join(CSRC, "fold_slots_device.h"), os.path.join(CSRC, "f64_text.h"), os.path.join(CSRC, "f64_parse.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
 EXPORTS = (
@@ -33,6 +33,7 @@ EXPORTS = (
     "surge_replay_create_v2",
     "surge_replay_kernel_info",
     "surge_replay_compile_schema_v2",
+    "surge_replay_compile_schema",
     "surge_replay_destroy",
     "surge_replay_last_error",
     "surge_replay_set_stream",
@@ -256,6 +257,7 @@ def load() -> ctypes.CDLL:
         "surge_replay_create_v2": ([vp, i32, ctypes.POINTER(vp)], i32),
         "surge_replay_kernel_info": ([vp, ctypes.POINTER(CKernelInfo)], i32),
         "surge_replay_compile_schema_v2": ([vp, ctypes.c_char_p, vp, i64, ctypes.POINTER(i64)], i32),
+        "surge_replay_compile_schema": ([vp, ctypes.c_char_p, vp, i64, ctypes.POINTER(i64)], i32),
         "surge_replay_destroy": ([vp], i32),
         "surge_replay_last_error": ([vp], ctypes.c_char_p),
         "surge_replay_set_stream": ([vp, vp], i32),

@@ -63,6 +63,10 @@ struct surge_replay_handle {
   surge_replay_schema_v2 schema2{};
   alignas(16) unsigned char slot_params[kSlotParamsBytes] = {};
   SlotKernels* spec = nullptr;         // v2: the kernels hiprtc compiled for this schema (process-wide cache); nullptr = interpreter
+  V1Kernels* spec1 = nullptr;          // v1: the flat kernel compiled for this handle's op table (acquired at the first flat fold)
+  bool spec1_tried = false;
+  double spec1_compile_ms = 0.0;
+  std::string spec1_why;
   double spec_compile_ms = 0.0;
   std::string spec_why;                // why the interpreter runs instead / which libhiprtc compiled the kernels
   std::string err;
@@ -174,10 +178,21 @@ int32_t fail_hip(surge_replay_handle* h, hipError_t e, const char* what) {
     if (e_ != hipSuccess) return fail_hip(h, e_, #call); \
   } while (0)
 
-void fill_params(const surge_replay_handle* h, FoldParams& p) {
+// the flat kernel for this handle's op table: compiled (hiprtc, ~1 s) the first time a process folds with the table, shared
+// by every handle with the same table; nullptr = the ahead-of-time kernel (why: surge_replay_kernel_info)
+const V1Kernels* flat_spec(surge_replay_handle* h, const FoldParams& p) {
+  if (!h->spec1_tried) {
+    h->spec1_tried = true;
+    v1_kernels_acquire(p.table, h->device, &h->spec1, &h->spec1_compile_ms, &h->spec1_why);
+    if (h->spec1) h->spec1_why = std::string("flat kernel compiled for the op table by ") + rtc_library_path();
+  }
+  return h->spec1;
+}
+
+void fill_params(const surge_replay_schema& schema, FoldParams& p) {
   std::memset(&p, 0, sizeof(p));
   for (int i = 0; i < kTableEntries; ++i) {
-    const uint32_t d = ((uint32_t)i < h->schema.n_types && i < SURGE_MAX_EVENT_TYPES) ? h->schema.desc[i] : SURGE_D_POISON;
+    const uint32_t d = ((uint32_t)i < schema.n_types && i < SURGE_MAX_EVENT_TYPES) ? schema.desc[i] : SURGE_D_POISON;
     uint32_t* w = p.table[i];
     const uint32_t cop = d & SURGE_D_COUNT_MASK, sop = d & SURGE_D_SUM_MASK, cls = d & SURGE_CLS_MASK;
     if (d & SURGE_D_POISON) {
@@ -210,7 +225,7 @@ void fill_params(const surge_replay_handle* h, FoldParams& p) {
     w[TW_MAX] = (d & SURGE_D_MAX_ARG) ? ~0u : 0u;
     w[TW_FLAGS] = 0u;  // bit0 poison, bit16 delete; materializes goes in its own accumulator (TW_MATERIALIZES & 1)
   }
-  const surge_state64& d = h->schema.default_state;
+  const surge_state64& d = schema.default_state;
   p.d_count = d.count;
   p.d_version = d.version;
   p.d_sum = d.sum64;
@@ -219,6 +234,8 @@ void fill_params(const surge_replay_handle* h, FoldParams& p) {
   p.d_max = d.max_arg;
   p.d_evcount = d.event_count;
 }
+
+void fill_params(const surge_replay_handle* h, FoldParams& p) { fill_params(h->schema, p); }
 
 // Wave-task size in events: a multiple of one tile (64 * lane_events events), about kTaskBytes of
 // events at most, small enough that short logs still spread over the chip.
@@ -330,7 +347,7 @@ int32_t run_flat(surge_replay_handle* h, FoldParams& p, const int64_t* off, int6
   const int32_t rc = next_fold_events(h, &e0, &e1);
   if (rc != SURGE_OK) return rc;
   HIPCHK(h, hipEventRecord(e0, h->stream));
-  HIPCHK(h, launch_fold_flat(p, n_tasks, le, h->stream));
+  HIPCHK(h, launch_fold_flat(p, flat_spec(h, p), n_tasks, le, h->stream));
   HIPCHK(h, hipEventRecord(e1, h->stream));
   h->st.n_tasks = (int32_t)n_tasks;
   return SURGE_OK;
@@ -906,10 +923,40 @@ extern "C" {
 int32_t surge_replay_kernel_info(surge_replay_handle* h, surge_replay_kernel_info_t* out) {
   if (!h || !out) return fail(h, SURGE_E_INVALID, "NULL argument");
   std::memset(out, 0, sizeof(*out));
-  out->specialised = h->spec ? 1 : 0;
-  out->compile_ms = h->spec_compile_ms;
-  const std::string d = h->v2 ? h->spec_why : std::string("v1 schema: the ahead-of-time kernels interpret the op table");
+  if (!h->v2) {  // v1: the flat kernel (K3 appends, AUTO on logs of few long rows) is the one compiled per op table
+    DeviceGuard g(h->device);
+    FoldParams p;
+    fill_params(h, p);
+    (void)flat_spec(h, p);
+  }
+  out->specialised = h->v2 ? (h->spec ? 1 : 0) : (h->spec1 ? 1 : 0);
+  out->compile_ms = h->v2 ? h->spec_compile_ms : h->spec1_compile_ms;
+  const std::string d = h->v2 ? h->spec_why
+                              : (h->spec1 ? h->spec1_why : "v1 schema, ahead-of-time kernels interpret the op table: " + h->spec1_why);
   std::snprintf(out->detail, sizeof(out->detail), "%s", d.c_str());
+  return SURGE_OK;
+}
+
+int32_t surge_replay_compile_schema(const surge_replay_schema* schema, const char* arch, void* code_out, int64_t capacity, int64_t* code_bytes) {
+  if (!schema || !arch || !code_bytes) return fail(nullptr, SURGE_E_INVALID, "NULL argument");
+  *code_bytes = 0;
+  {
+    const int32_t rc = validate_schema(schema);
+    if (rc != SURGE_OK) return rc;
+  }
+  FoldParams p;
+  fill_params(*schema, p);
+  const std::string src = v1_spec_source(p.table);
+  if (src.empty()) return fail(nullptr, SURGE_E_UNSUPPORTED, "the op table holds words the specialised build cannot express");
+  std::vector<char> code;
+  std::string log;
+  double ms = 0.0;
+  if (!rtc_compile(src, arch, &code, &log, &ms)) return fail(nullptr, SURGE_E_UNSUPPORTED, log);
+  *code_bytes = (int64_t)code.size();
+  if (code_out) {
+    if (capacity < (int64_t)code.size()) return fail(nullptr, SURGE_E_INVALID, "code_out is too small (see *code_bytes)");
+    std::memcpy(code_out, code.data(), code.size());
+  }
   return SURGE_OK;
 }
 
@@ -1281,7 +1328,7 @@ int32_t surge_replay_append_events_device(surge_replay_handle* h, const int64_t*
     const int32_t rc = next_fold_events(h, &e0, &e1);
     if (rc != SURGE_OK) return rc;
     HIPCHK(h, hipEventRecord(e0, h->stream));
-    HIPCHK(h, launch_fold_flat(p, n_tasks, le, h->stream));
+    HIPCHK(h, launch_fold_flat(p, flat_spec(h, p), n_tasks, le, h->stream));
     HIPCHK(h, hipEventRecord(e1, h->stream));
     h->st.n_tasks = (int32_t)n_tasks;
   }

@@ -284,21 +284,51 @@ struct Geo {
   }
 };
 
+// A build specialised for one v1 schema (hiprtc; fold_kernels.hip writes the program): the op table is not data but 16
+// compile-time bit masks over the 18 table entries — SURGE_V1_MASK(k) has bit e set when word k of entry e is non-zero
+// (every walk word is all-ones or zero, TW_EVC 0 or 1; TW_FLAGS is split into SURGE_V1_THROWS / SURGE_V1_DELETES) — so an
+// event's reference is its entry INDEX, a table word is one v_bfe_i32 of a constant, and a word that is zero for every
+// entry is the constant 0: the arithmetic of a field no event type touches folds away.  No LDS copy of the table.
+#ifdef SURGE_V1_SPEC
+constexpr bool kSpecV1 = true;
+#else
+constexpr bool kSpecV1 = false;
+#define SURGE_V1_MASK(k) 0u
+#define SURGE_V1_THROWS 0u
+#define SURGE_V1_DELETES 0u
+#endif
 // Op-table entries are addressed by BYTE offset into the LDS copy of the table (tyc[] below): an event's entry is
 // min(type, 16) * 80 bytes in — one v_min + one v_mul per event, no shift in front of the ds_read; the tile-major re-layout
 // stores that offset in place of the type word, so its fold spends nothing on it.
 constexpr uint32_t kTableStrideBytes = kTableStride * 4u;
-constexpr uint32_t kNullEntryOffBytes = kNullEntryOff * 4u;
-__device__ __forceinline__ uint32_t type_off(uint32_t ty) { return (ty < 16u ? ty : 16u) * kTableStrideBytes; }
+constexpr uint32_t kNullEntryOffBytes = kSpecV1 ? 17u : kNullEntryOff * 4u;  // the null event's reference: its entry index in a specialised build
+template <int K>
+__device__ __forceinline__ uint32_t spec_word(uint32_t entry) {
+  constexpr uint32_t m = SURGE_V1_MASK(K);
+  if (m == 0u) return 0u;
+  if (K == TW_EVC) return (m >> entry) & 1u;
+  return (uint32_t)__builtin_amdgcn_sbfe((int32_t)m, entry, 1u);
+}
+__device__ __forceinline__ uint32_t type_off(uint32_t ty) { return (ty < 16u ? ty : 16u) * (kSpecV1 ? 1u : kTableStrideBytes); }
 __device__ __forceinline__ const uint4* table_entry(const uint32_t* lds_tab, uint32_t off) {
   return (const uint4*)((const char*)lds_tab + off);
 }
 __device__ __forceinline__ uint32_t table_word(const uint32_t* lds_tab, uint32_t off, int word) {
   return *(const uint32_t*)((const char*)lds_tab + off + word * 4);
 }
+// the two words of the flat kernel's presence pre-pass
+__device__ __forceinline__ uint32_t flags_word(const uint32_t* lds_tab, uint32_t ref) {
+  if (kSpecV1) return ((SURGE_V1_THROWS >> ref) & 1u) | (((SURGE_V1_DELETES >> ref) & 1u) << 16);
+  return table_word(lds_tab, ref, TW_FLAGS);
+}
+__device__ __forceinline__ uint32_t materializes_word(const uint32_t* lds_tab, uint32_t ref) {
+  if (kSpecV1) return spec_word<TW_MATERIALIZES>(ref);
+  return table_word(lds_tab, ref, TW_MATERIALIZES);
+}
 
 template <int LE>
 __device__ __forceinline__ void load_table(const FoldParams& p, uint32_t* lds_tab, int lane) {
+  if (kSpecV1) return;
   const uint32_t* src = &p.table[0][0];
   for (int i = lane; i < kTableEntries * kTableWords; i += kWave)
     lds_tab[(i / kTableWords == kTableEntries - 1 ? kNullEntryOff : (i / kTableWords) * kTableStride) + (i % kTableWords)] = src[i];
@@ -344,6 +374,19 @@ __device__ __forceinline__ void issue_tile_loads(const FoldParams& p, int64_t te
 template <int LE, bool HEADS, typename OnHead>
 __device__ __forceinline__ void walk_events(Acc& a, uint32_t& frozenM, uint32_t& corr, const uint4* ev, const uint32_t* tyc,
                                             uint32_t hb, const uint32_t* lds_tab, const FoldParams& p, OnHead on_head) {
+  if (kSpecV1) {
+#pragma unroll
+    for (int j = 0; j < LE; ++j) {
+      const uint32_t e = tyc[j];
+      const uint4 q0 = {spec_word<0>(e), spec_word<1>(e), spec_word<2>(e), spec_word<3>(e)};
+      const uint4 q1 = {spec_word<4>(e), spec_word<5>(e), spec_word<6>(e), spec_word<7>(e)};
+      const uint4 q2 = {spec_word<8>(e), spec_word<9>(e), spec_word<10>(e), spec_word<11>(e)};
+      const uint2 q3 = {spec_word<12>(e), spec_word<13>(e)};
+      if (HEADS && ((hb >> j) & 1u)) on_head(j);
+      apply_event(a, frozenM, corr, q0, q1, q2, q3, ev[j].y, ev[j].z, ev[j].w, p);
+    }
+    return;
+  }
   uint4 tq0, tq1, tq2;
   uint2 tq3;
   {

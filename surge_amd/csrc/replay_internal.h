@@ -24,7 +24,12 @@ struct CsrAnalysis {
 
 // Launch wrappers (fold_kernels.hip).  All asynchronous on `stream`.
 hipError_t launch_fold_fixed(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream);
-hipError_t launch_fold_flat(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream);
+// The flat kernel compiled for one v1 op table (hiprtc; fold_kernels.hip).  A V1Kernels object is shared by every handle
+// of the process with the same table on the same device; nullptr = the ahead-of-time kernel that reads the table from LDS.
+struct V1Kernels;
+std::string v1_spec_source(const uint32_t (*table)[kTableWords]);  // the program handed to hiprtc ("" = not expressible)
+void v1_kernels_acquire(const uint32_t (*table)[kTableWords], int device, V1Kernels** out, double* compile_ms, std::string* why);
+hipError_t launch_fold_flat(const FoldParams& p, const V1Kernels* spec, int64_t n_tasks, int lane_events, hipStream_t stream);
 hipError_t launch_fold_rows(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream);
 hipError_t launch_fold_sorted(const FoldParams& p, int64_t n_waves, int lane_events, hipStream_t stream);
 // ---- index_kernels.hip: the per-log indexes (length order, chunk table), built with rocPRIM sorts / scans -----------

@@ -28,6 +28,7 @@
 SURGE_EMBED(surge_src_fold_layout_h, "fold_layout.h")
 SURGE_EMBED(surge_src_fold_device_h, "fold_device.h")
 SURGE_EMBED(surge_src_fold_slots_device_h, "fold_slots_device.h")
+SURGE_EMBED(surge_src_fold_flat_device_h, "fold_flat_device.h")
 
 namespace surge {
 namespace {
@@ -120,10 +121,10 @@ bool rtc_compile(const std::string& source, const char* arch, std::vector<char>*
     return false;
   }
   const auto t0 = std::chrono::steady_clock::now();
-  const char* headers[] = {surge_src_fold_layout_h, surge_src_fold_device_h, surge_src_fold_slots_device_h};
-  const char* names[] = {"fold_layout.h", "fold_device.h", "fold_slots_device.h"};
+  const char* headers[] = {surge_src_fold_layout_h, surge_src_fold_device_h, surge_src_fold_slots_device_h, surge_src_fold_flat_device_h};
+  const char* names[] = {"fold_layout.h", "fold_device.h", "fold_slots_device.h", "fold_flat_device.h"};
   hiprtcProgram prog = nullptr;
-  int rc = g_rtc.CreateProgram(&prog, source.c_str(), "surge_slots_spec.hip", 3, headers, names);
+  int rc = g_rtc.CreateProgram(&prog, source.c_str(), "surge_schema_spec.hip", 4, headers, names);
   if (rc != 0) {
     *log = std::string("hiprtcCreateProgram: ") + g_rtc.GetErrorString(rc);
     return false;

@@ -254,3 +254,38 @@ def test_device_framer_fails_loudly_without_a_gpu():
 
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         DeviceFramer(4)
+
+
+def test_a_v1_schema_compiles_its_flat_kernel_for_gfx950_without_a_gpu_and_a_narrow_schema_to_fewer_vector_instructions(tmp_path):
+    """surge_replay_compile_schema: the flat fold kernel's own device source (csrc/fold_flat_device.h) compiled by hiprtc with
+    the schema's op table as compile-time masks — what a v1 handle runs from its first flat fold on.  Checkable on a build
+    machine; and the point of it is visible in the code objects: the Counter fixture's schema (count and version only)
+    compiles to a fifth fewer vector instructions than the built-in schema that uses every field, and neither build reads
+    an op table from LDS."""
+    import shutil
+    import subprocess
+
+    from fixture_models import COUNTER_ALGEBRA
+
+    lib = _native.load()
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    valu = {}
+    for name, algebra in (("default", DEFAULT_ALGEBRA), ("counter", COUNTER_ALGEBRA)):
+        sc = algebra.to_c()
+        n = ctypes.c_int64()
+        assert lib.surge_replay_compile_schema(ctypes.byref(sc), b"gfx950", None, 0, ctypes.byref(n)) == 0, lib.surge_replay_last_error(None).decode()
+        buf = ctypes.create_string_buffer(n.value)
+        assert lib.surge_replay_compile_schema(ctypes.byref(sc), b"gfx950", buf, n.value, ctypes.byref(n)) == 0
+        assert buf.raw[:4] == b"\x7fELF" and b"surge_v1_flat8" in buf.raw and b"surge_v1_flat16" in buf.raw
+        assert lib.surge_replay_compile_schema(ctypes.byref(sc), b"gfx950", buf, 16, ctypes.byref(n)) == -1  # too small
+        if os.path.exists(objdump):
+            co = tmp_path / f"{name}.co"
+            co.write_bytes(buf.raw[: n.value])
+            asm = subprocess.run([objdump, "-d", str(co)], capture_output=True, text=True, check=True).stdout
+            body = asm[asm.index("<surge_v1_flat16>:"):]
+            valu[name] = sum(1 for l in body.splitlines() if l.split()[:1] and l.split()[0].startswith("v_"))
+    if valu:
+        assert valu["counter"] < 0.85 * valu["default"], valu
+    bad = DEFAULT_ALGEBRA.to_c()
+    bad.state_size = 48
+    assert lib.surge_replay_compile_schema(ctypes.byref(bad), b"gfx950", None, 0, ctypes.byref(n)) != 0

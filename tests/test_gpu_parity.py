@@ -934,3 +934,70 @@ def test_snapshot_gather_on_the_rccl_backend_single_rank():
             assert bufs[0][:2000].cpu().numpy().tobytes() == exp.tobytes()
     finally:
         dist.destroy_process_group()
+
+
+def _random_algebra(rng):
+    """1 .. 16 event types with random classes and field ops, a few of them throwing, random defaults"""
+    n_types = int(rng.integers(1, S.MAX_EVENT_TYPES + 1))
+    desc = []
+    for _ in range(n_types):
+        d = int(rng.choice([S.CLS_MATERIALIZE, S.CLS_REQUIRE, S.CLS_CREATE, S.CLS_DELETE], p=[0.45, 0.35, 0.12, 0.08]))
+        d |= int(rng.choice([0, S.D_COUNT_ADD, S.D_COUNT_SUB, S.D_COUNT_SET])) | int(rng.choice([0, S.D_SUM_ADD, S.D_SUM_SUB]))
+        for bit in (S.D_VERSION_SET, S.D_BALANCE_SET, S.D_MIN_ARG, S.D_MAX_ARG, S.D_EVCOUNT_INC):
+            d |= bit if rng.random() < 0.4 else 0
+        if rng.random() < 0.06:
+            d |= S.D_POISON
+        desc.append(d)
+    if rng.random() < 0.4:  # a narrow schema: one or two fields in use, so whole parts of the walk fold away in the compiled build
+        keep = S.CLS_MASK | S.D_POISON | int(rng.choice([S.D_COUNT_MASK | S.D_VERSION_SET, S.D_SUM_MASK, S.D_BALANCE_SET | S.D_EVCOUNT_INC, S.D_MIN_ARG | S.D_MAX_ARG]))
+        desc = [d & keep for d in desc]
+    return S.EventAlgebra(desc=tuple(desc), default_count=int(rng.integers(-5, 5)), default_version=int(rng.integers(0, 3)),
+                          default_sum64=int(rng.integers(-1 << 40, 1 << 40)), default_balance=float(rng.standard_normal()),
+                          default_event_count=int(rng.integers(0, 3)))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SURGE_TEST_FUZZ_SEEDS", "6"))))
+def test_the_flat_kernel_compiled_for_a_v1_schema_equals_the_interpreter_and_the_oracle(seed, monkeypatch):
+    """a v1 handle compiles the flat kernel for its op table at its first flat fold (hiprtc: the table's
+    words become compile-time masks over the event type, no LDS copy of the table; SURGE_REPLAY_RTC=0 keeps the
+    ahead-of-time build that reads the table from LDS).  Random schemas — 1 .. 16 types, every class and field op, throwing
+    types, narrow ones whose unused fields fold away — on random log shapes with event types beyond the schema (poison),
+    with and without a prior snapshot: whole logs (ALGO_FLAT) and micro-batches onto the resident state (K3), both builds,
+    bit for bit the oracle's states."""
+    rng = np.random.default_rng(4000 + seed)
+    for _ in range(3):
+        alg = _random_algebra(rng)
+        n = int(rng.integers(1, 2500))
+        lens = [rng.integers(0, 6, size=n), rng.integers(0, 60, size=n), np.where(rng.random(n) < 0.98, rng.integers(0, 9, size=n), rng.integers(500, 9000, size=n))][int(rng.integers(0, 3))]
+        so = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=so[1:])
+        m = int(so[-1])
+        ty = rng.integers(0, len(alg.desc) + (2 if rng.random() < 0.3 else 0), m)  # now and then a type the schema does not know
+        ev = S.make_events(ty, rng.integers(0, 1 << 30, m), rng.integers(-(1 << 31), 1 << 31, m))
+        prior = None
+        if rng.random() < 0.5:
+            pl = rng.integers(0, 4, size=n)
+            po = np.zeros(n + 1, np.int64)
+            np.cumsum(pl, out=po[1:])
+            pe = S.make_events(rng.integers(0, len(alg.desc), int(po[-1])), rng.integers(0, 1 << 30, int(po[-1])), rng.integers(-1000, 1000, int(po[-1])))
+            prior = oracle.fold_csr(po, pe, None, alg)
+        exp = oracle.fold_csr(so, ev, prior, alg)
+        # micro-batches: the same events in a random interleaving of the aggregates (each aggregate's own events in order)
+        topic_agg = rng.permutation(np.repeat(np.arange(n, dtype=np.int64), lens))
+        src = np.zeros(m, np.int64)
+        src[np.argsort(topic_agg, kind="stable")] = np.arange(m)  # the k-th record of aggregate a is its k-th event
+        for build in ("1", "0"):
+            monkeypatch.setenv("SURGE_REPLAY_RTC", build)
+            with ReplayEngine(alg) as eng:
+                info = eng.kernel_info()
+                assert info["specialised"] == (build == "1"), info
+                eng.load_csr(so, ev, prior)
+                eng.fold(S.ALGO_FLAT)
+                assert eng.snapshot().tobytes() == exp.tobytes(), (seed, build, alg.desc)
+                if m:
+                    eng.load_csr(np.zeros(n + 1, np.int64), np.zeros(0, dtype=S.EVENT_DTYPE), prior)
+                    eng.fold()
+                    for c0 in range(0, m, m // 3 + 1):
+                        eng.append_events(topic_agg[c0:c0 + m // 3 + 1], ev[src[c0:c0 + m // 3 + 1]])
+                    eng.synchronize()
+                    assert eng.snapshot().tobytes() == exp.tobytes(), (seed, build, "K3", alg.desc)
