@@ -22,8 +22,34 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #endif
 constexpr int kLoadAux = SURGE_LOAD_AUX;
 
+// A build specialised for one v1 schema (hiprtc; fold_kernels.hip writes the program): the op table is not data but 16
+// compile-time bit masks over the 18 table entries — SURGE_V1_MASK(k) has bit e set when word k of entry e is non-zero
+// (every walk word is all-ones or zero, TW_EVC 0 or 1; TW_FLAGS is split into SURGE_V1_THROWS / SURGE_V1_DELETES) — so an
+// event's reference is its entry INDEX, a table word is one v_bfe_i32 of a constant, and a word that is zero for every
+// entry is the constant 0: the arithmetic of a field no event type touches folds away.  No LDS copy of the table.
+#ifdef SURGE_V1_SPEC
+constexpr bool kSpecV1 = true;
+#else
+constexpr bool kSpecV1 = false;
+#define SURGE_V1_MASK(k) 0u
+#define SURGE_V1_THROWS 0u
+#define SURGE_V1_DELETES 0u
+#endif
+// Fields no event type of the schema touches (Counter: everything but count and version).  Such a field of a present
+// aggregate is either its default — a reset (CREATE, or materialising from None) happened since the state the fold started
+// from — or still the prior state's value; one flag bit (FL_DFLT) says which, so the field itself is not carried through
+// the walk, the scan and the carries at all: store_state_flat writes the default or copies the prior's bytes.
+constexpr bool kLiveCount = !kSpecV1 || (SURGE_V1_MASK(TW_CNT_NZ) | SURGE_V1_MASK(TW_CNT_SET)) != 0u;
+constexpr bool kLiveVersion = !kSpecV1 || SURGE_V1_MASK(TW_VER_SET) != 0u;
+constexpr bool kLiveSum = !kSpecV1 || SURGE_V1_MASK(TW_SUM_NZ) != 0u;
+constexpr bool kLiveBal = !kSpecV1 || SURGE_V1_MASK(TW_BAL_SET) != 0u;
+constexpr bool kLiveMin = !kSpecV1 || SURGE_V1_MASK(TW_MIN) != 0u;
+constexpr bool kLiveMax = !kSpecV1 || SURGE_V1_MASK(TW_MAX) != 0u;
+constexpr bool kLiveN = !kSpecV1 || SURGE_V1_MASK(TW_EVC) != 0u;
+constexpr bool kAnyDead = !(kLiveCount && kLiveVersion && kLiveSum && kLiveBal && kLiveMin && kLiveMax && kLiveN);
 constexpr uint32_t FL_PRESENT = 1u;
 constexpr uint32_t FL_POISONED = 2u;
+constexpr uint32_t FL_DFLT = 4u;  // (specialised builds with untouched fields only) the untouched fields hold their defaults
 constexpr uint32_t FL_HEAD = 16u;
 constexpr uint32_t SM_COUNT = 1u << 8;
 constexpr uint32_t SM_VERSION = 1u << 9;
@@ -44,7 +70,7 @@ struct Acc {
 __device__ __forceinline__ Acc acc_none() {  // the aggregate is None (absolute)
   Acc a;
   a.count = 0; a.version = 0; a.sum = 0; a.bal = 0; a.mn = 0x7fffffff; a.mx = (int32_t)0x80000000; a.n = 0;
-  a.fl = SM_ALL;
+  a.fl = SM_ALL | (kAnyDead ? FL_DFLT : 0u);
   return a;
 }
 
@@ -75,7 +101,7 @@ __device__ __forceinline__ void apply_event(Acc& a, uint32_t& frozenM, uint32_t&
 
   uint32_t fl = a.fl | (ispM & FL_POISONED);
   fl = andn(fl, delM & FL_PRESENT) | (delM & SM_ALL);
-  fl |= rstM & (FL_PRESENT | SM_ALL);
+  fl |= rstM & (FL_PRESENT | SM_ALL | (kAnyDead ? FL_DFLT : 0u));
 
   uint32_t count = bfi(rstM, (uint32_t)p.d_count, (uint32_t)a.count);
   uint32_t version = bfi(rstM, (uint32_t)p.d_version, (uint32_t)a.version);
@@ -186,6 +212,7 @@ __device__ __forceinline__ Acc seq_acc(const Acc& f, const Acc& g) {
   r.n = all ? g.n : f.n + g.n;
   const uint32_t present = (f.fl & FL_POISONED) ? (f.fl & FL_PRESENT) : (g.fl & FL_PRESENT);
   r.fl = present | ((f.fl | g.fl) & (FL_POISONED | SM_ALL)) | (f.fl & FL_HEAD);
+  if (kAnyDead) r.fl |= (all ? g.fl : f.fl) & FL_DFLT;  // untouched fields become absolute only through a reset / delete / head
   return r;
 }
 
@@ -237,6 +264,39 @@ __device__ __forceinline__ void store_state(uint4* out, int64_t idx, const Acc& 
   o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3;
 }
 
+// store_state for a build with untouched fields: those are not in `a` (whatever it holds for them is dead code) — the
+// default when a reset happened since the prior state (FL_DFLT), else the prior state's own bytes.  Without a prior
+// snapshot every segment starts from None, whose only way to Some is a reset: FL_DFLT is always set on a present state.
+__device__ __forceinline__ void store_state_flat(const FoldParams& p, int64_t idx, const Acc& a) {
+  if (!kAnyDead) {
+    store_state(p.out, idx, a);
+    return;
+  }
+  const bool pr = (a.fl & FL_PRESENT) != 0;
+  const bool dflt = (a.fl & FL_DFLT) != 0 || p.init == nullptr;
+  uint4 q0 = {0u, 0u, 0u, 0u}, q1 = {0u, 0u, 0u, 0u}, q2 = {0u, 0u, 0u, 0u};
+  if (pr && !dflt) {
+    const uint4* s = p.init + idx * 4;
+    q0 = s[0]; q1 = s[1]; q2 = s[2];
+  }
+  const uint32_t count = kLiveCount ? (uint32_t)a.count : (dflt ? (uint32_t)p.d_count : q0.x);
+  const uint32_t version = kLiveVersion ? (uint32_t)a.version : (dflt ? (uint32_t)p.d_version : q0.y);
+  const uint32_t sum_lo = kLiveSum ? (uint32_t)a.sum : (dflt ? (uint32_t)p.d_sum : q0.z);
+  const uint32_t sum_hi = kLiveSum ? (uint32_t)((uint64_t)a.sum >> 32) : (dflt ? (uint32_t)((uint64_t)p.d_sum >> 32) : q0.w);
+  const uint32_t bal_lo = kLiveBal ? (uint32_t)a.bal : (dflt ? (uint32_t)p.d_balance : q1.x);
+  const uint32_t bal_hi = kLiveBal ? (uint32_t)(a.bal >> 32) : (dflt ? (uint32_t)(p.d_balance >> 32) : q1.y);
+  const uint32_t mn = kLiveMin ? (uint32_t)a.mn : (dflt ? (uint32_t)p.d_min : q1.z);
+  const uint32_t mx = kLiveMax ? (uint32_t)a.mx : (dflt ? (uint32_t)p.d_max : q1.w);
+  const uint32_t n = kLiveN ? a.n : (dflt ? p.d_evcount : q2.x);
+  uint4 v0, v1, v2, v3;
+  v0.x = pr ? count : 0u; v0.y = pr ? version : 0u; v0.z = pr ? sum_lo : 0u; v0.w = pr ? sum_hi : 0u;
+  v1.x = pr ? bal_lo : 0u; v1.y = pr ? bal_hi : 0u; v1.z = pr ? mn : 0u; v1.w = pr ? mx : 0u;
+  v2.x = pr ? n : 0u; v2.y = a.fl & (FL_PRESENT | FL_POISONED); v2.z = 0u; v2.w = 0u;
+  v3.x = v3.y = v3.z = v3.w = 0u;
+  uint4* o = p.out + idx * 4;
+  o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3;
+}
+
 __device__ __forceinline__ Acc load_state(const uint4* in, int64_t idx) {
   const uint4* s = in + idx * 4;
   const uint4 v0 = s[0], v1 = s[1], v2 = s[2];
@@ -284,19 +344,6 @@ struct Geo {
   }
 };
 
-// A build specialised for one v1 schema (hiprtc; fold_kernels.hip writes the program): the op table is not data but 16
-// compile-time bit masks over the 18 table entries — SURGE_V1_MASK(k) has bit e set when word k of entry e is non-zero
-// (every walk word is all-ones or zero, TW_EVC 0 or 1; TW_FLAGS is split into SURGE_V1_THROWS / SURGE_V1_DELETES) — so an
-// event's reference is its entry INDEX, a table word is one v_bfe_i32 of a constant, and a word that is zero for every
-// entry is the constant 0: the arithmetic of a field no event type touches folds away.  No LDS copy of the table.
-#ifdef SURGE_V1_SPEC
-constexpr bool kSpecV1 = true;
-#else
-constexpr bool kSpecV1 = false;
-#define SURGE_V1_MASK(k) 0u
-#define SURGE_V1_THROWS 0u
-#define SURGE_V1_DELETES 0u
-#endif
 // Op-table entries are addressed by BYTE offset into the LDS copy of the table (tyc[] below): an event's entry is
 // min(type, 16) * 80 bytes in — one v_min + one v_mul per event, no shift in front of the ds_read; the tile-major re-layout
 // stores that offset in place of the type word, so its fold spends nothing on it.

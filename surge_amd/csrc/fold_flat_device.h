@@ -196,7 +196,7 @@ __device__ __forceinline__ void fold_flat_body(const FoldParams& p, char* smem) 
         seen = true;
       } else {
         const int64_t oi = p.out_map ? p.out_map[seg_open] : seg_open;
-        store_state(p.out, oi, a);
+        store_state_flat(p, oi, a);
       }
       seg_open += 1;
       if (p.init) {
@@ -235,7 +235,7 @@ __device__ __forceinline__ void fold_flat_body(const FoldParams& p, char* smem) 
     if (seen && lead_seg >= S0) {
       const Acc fin = seq_acc(prefix, lead);
       const int64_t oi = p.out_map ? p.out_map[lead_seg] : lead_seg;
-      store_state(p.out, oi, fin);
+      store_state_flat(p, oi, fin);
     }
     carry = readlane_acc(el, 63);
 
@@ -247,7 +247,7 @@ __device__ __forceinline__ void fold_flat_body(const FoldParams& p, char* smem) 
 
   if (lane == 0) {
     const int64_t oi = p.out_map ? p.out_map[S1 - 1] : (S1 - 1);
-    store_state(p.out, oi, carry);
+    store_state_flat(p, oi, carry);
   }
 }
 

@@ -260,8 +260,9 @@ def test_a_v1_schema_compiles_its_flat_kernel_for_gfx950_without_a_gpu_and_a_nar
     """surge_replay_compile_schema: the flat fold kernel's own device source (csrc/fold_flat_device.h) compiled by hiprtc with
     the schema's op table as compile-time masks — what a v1 handle runs from its first flat fold on.  Checkable on a build
     machine; and the point of it is visible in the code objects: the Counter fixture's schema (count and version only)
-    compiles to a fifth fewer vector instructions than the built-in schema that uses every field, and neither build reads
-    an op table from LDS."""
+    compiles to fewer vector instructions than the built-in schema that uses every field — although every segment end
+    carries a longer store (the untouched fields come from the defaults or the prior state) — and to half the cross-lane
+    shuffles (the untouched fields are not in the scan)."""
     import shutil
     import subprocess
 
@@ -283,9 +284,10 @@ def test_a_v1_schema_compiles_its_flat_kernel_for_gfx950_without_a_gpu_and_a_nar
             co.write_bytes(buf.raw[: n.value])
             asm = subprocess.run([objdump, "-d", str(co)], capture_output=True, text=True, check=True).stdout
             body = asm[asm.index("<surge_v1_flat16>:"):]
-            valu[name] = sum(1 for l in body.splitlines() if l.split()[:1] and l.split()[0].startswith("v_"))
+            ops = [l.split()[0] for l in body.splitlines() if l.split()[:1]]
+            valu[name] = (sum(1 for o in ops if o.startswith("v_")), sum(1 for o in ops if o.startswith("ds_bpermute")))
     if valu:
-        assert valu["counter"] < 0.85 * valu["default"], valu
+        assert valu["counter"][0] < 0.9 * valu["default"][0] and valu["counter"][1] < 0.6 * valu["default"][1], valu
     bad = DEFAULT_ALGEBRA.to_c()
     bad.state_size = 48
     assert lib.surge_replay_compile_schema(ctypes.byref(bad), b"gfx950", None, 0, ctypes.byref(n)) != 0
