@@ -82,8 +82,8 @@ def csrc_sha16():
     """Identity of the kernel sources a profile was taken with (profiles/traffic_manifest.json records it)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "surge_amd", "csrc")
-    for name in ("fold_layout.h", "fold_device.h", "fold_chunk_device.h", "fold_slots_device.h", "fold_kernels.hip", "fold_chunked.hip",
-                 "fold_tiled.hip"):  # what the fold kernels are built from
+    for name in ("fold_layout.h", "fold_device.h", "fold_chunk_device.h", "fold_slots_device.h", "fold_flat_device.h", "fold_kernels.hip",
+                 "fold_chunked.hip", "fold_tiled.hip"):  # what the fold kernels are built from
         h.update(name.encode())
         h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]

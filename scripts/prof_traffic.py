@@ -30,6 +30,8 @@ def short_name(k):
               "chunk_stitch_kernel", "stream_probe", "plan_kernel"):
         if n in k:
             return n
+    if "surge_v1_flat" in k:  # the flat kernel compiled for the handle's op table (hiprtc)
+        return "fold_kernel<FLAT>"
     if "fold_kernel" in k:
         return "fold_kernel<FIXED>" if re.search(r"fold_kernel<0|fold_kernelILi0", k) else "fold_kernel<FLAT>"
     return None
