@@ -466,6 +466,10 @@ __global__ void __launch_bounds__(64) lz4_parse_kernel(const uint8_t* __restrict
 
 // cls == kLz4Classes: stored blocks (launched without LDS).  LDS: the block's image (the class's capacity + 64 bytes
 // that a masked-off lane may address), then the byte map (kLz4Map 16-bit positions).
+// BATCHED = false: the map read per window and the dependency rounds through a cross-lane read, as first written — kept
+// selectable (SURGE_INGEST_LZ4_WINDOWS=1) for a same-box comparison (profiles/r04_e2e_lz4_windows.txt: the batched loop
+// is 1.8 % faster end to end — the kernels' LDS footprint x time bounds the path, not this loop's latency alone).
+template <bool BATCHED>
 __global__ void __launch_bounds__(64) lz4_exec_kernel(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ out_base, const Lz4Block* __restrict__ blocks,
                                                       int32_t n_blocks, Lz4Work w, int32_t cls, int32_t cap) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lz4_out[];
@@ -502,26 +506,62 @@ __global__ void __launch_bounds__(64) lz4_exec_kernel(const uint8_t* __restrict_
         const int32_t m_lane = lane < cnt ? M : 0;
         for (int32_t i = 0; __any(i < m_lane); ++i)
           if (i < m_lane) map[(D + i) & (kLz4Map - 1)] = (uint16_t)(D - O + i);
-        for (int32_t p = g0; p < g1; p += 64) {
-          const int32_t pos = p + lane;
-          const bool act = pos < g1;
-          const int32_t src = act ? (int32_t)map[pos & (kLz4Map - 1)] : pos;
-          // Bytes that copy from THIS window wait for their source: first everything whose source lies below the window (or is
-          // the byte itself: a literal), then, round by round, the bytes whose source was written in the round before — as
-          // many rounds as the longest chain inside the window is deep (one or two; the first version ran one round per
-          // dependent BYTE: a 13-byte match at offset 20 cost 14 rounds).
-          const bool dep = act && src >= p && src != pos;
-          bool done = !dep;
-          {
-            const uint8_t v = lz4_out[src];
-            if (act && !dep) lz4_out[pos] = v;
+        // Eight windows' map entries are read together (the map does not change while it is applied): one LDS round trip
+        // for eight windows instead of one each.  A window is then: gather, write, and per dependency round a ballot, a
+        // gather and a write — whether a byte's source is written yet is a bit of the ballot, not a cross-lane read.
+        constexpr int kWin = 8;
+        if (!BATCHED) {
+          for (int32_t p = g0; p < g1; p += 64) {
+            const int32_t pos = p + lane;
+            const bool act = pos < g1;
+            const int32_t src = act ? (int32_t)map[pos & (kLz4Map - 1)] : pos;
+            const bool dep = act && src >= p && src != pos;
+            bool done = !dep;
+            {
+              const uint8_t v = lz4_out[src];
+              if (act && !dep) lz4_out[pos] = v;
+            }
+            while (__any(!done)) {
+              const bool src_done = __shfl((int)done, (src - p) & 63, 64) != 0;
+              const bool can = !done && src_done;
+              const uint8_t v = lz4_out[src];
+              if (can) lz4_out[pos] = v;
+              done = done || can;
+            }
           }
-          while (__any(!done)) {
-            const bool src_done = __shfl((int)done, (src - p) & 63, 64) != 0;
-            const bool can = !done && src_done;
-            const uint8_t v = lz4_out[src];
-            if (can) lz4_out[pos] = v;
-            done = done || can;
+        }
+        for (int32_t p0 = g0; BATCHED && p0 < g1; p0 += 64 * kWin) {
+          int32_t srcs[kWin];
+#pragma unroll
+          for (int k = 0; k < kWin; ++k) {
+            const int32_t pos = p0 + 64 * k + lane;
+            srcs[k] = pos < g1 ? (int32_t)map[pos & (kLz4Map - 1)] : pos;
+          }
+#pragma unroll
+          for (int k = 0; k < kWin; ++k) {
+            const int32_t p = p0 + 64 * k;
+            if (p >= g1) break;  // (wave-uniform)
+            const int32_t pos = p + lane;
+            const bool act = pos < g1;
+            const int32_t src = srcs[k];
+            // Bytes that copy from THIS window wait for their source: first everything whose source lies below the window (or
+            // is the byte itself: a literal), then, round by round, the bytes whose source was written in the round before —
+            // as many rounds as the longest chain inside the window is deep (one or two; the first version ran one round per
+            // dependent BYTE: a 13-byte match at offset 20 cost 14 rounds).
+            const bool dep = act && src >= p && src != pos;
+            bool done = !dep;
+            {
+              const uint8_t v = lz4_out[src];
+              if (act && !dep) lz4_out[pos] = v;
+            }
+            unsigned long long dm = __ballot(done);
+            while (dm != ~0ull) {
+              const bool can = !done && ((dm >> ((src - p) & 63)) & 1ull) != 0ull;
+              const uint8_t v = lz4_out[src];
+              if (can) lz4_out[pos] = v;
+              done = done || can;
+              dm = __ballot(done);
+            }
           }
         }
       } else {
@@ -1699,7 +1739,11 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
         const size_t lds = cap ? (size_t)cap + 64 + (size_t)kLz4Map * 2 : 0;
         const int64_t resident = 256ll * (lds ? (int64_t)(160 * 1024 / lds) : 16);  // waves the chip holds at this LDS size
         const unsigned grid = (unsigned)(nb < resident ? nb : resident);
-        hipLaunchKernelGGL(lz4_exec_kernel, dim3(grid), dim3(64), lds, st, dby, (uint8_t*)s.d_bytes.p + area_base, (const Lz4Block*)s.lz4_blocks.p, (int32_t)nb, w, c, cap);
+        static const bool one_window = [] { const char* v = std::getenv("SURGE_INGEST_LZ4_WINDOWS"); return v && v[0] == '1'; }();
+        if (one_window)
+          hipLaunchKernelGGL(lz4_exec_kernel<false>, dim3(grid), dim3(64), lds, st, dby, (uint8_t*)s.d_bytes.p + area_base, (const Lz4Block*)s.lz4_blocks.p, (int32_t)nb, w, c, cap);
+        else
+          hipLaunchKernelGGL(lz4_exec_kernel<true>, dim3(grid), dim3(64), lds, st, dby, (uint8_t*)s.d_bytes.p + area_base, (const Lz4Block*)s.lz4_blocks.p, (int32_t)nb, w, c, cap);
       }
     }
     if (any_one_pass) {
