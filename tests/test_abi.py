@@ -291,3 +291,38 @@ def test_a_v1_schema_compiles_its_flat_kernel_for_gfx950_without_a_gpu_and_a_nar
     bad = DEFAULT_ALGEBRA.to_c()
     bad.state_size = 48
     assert lib.surge_replay_compile_schema(ctypes.byref(bad), b"gfx950", None, 0, ctypes.byref(n)) != 0
+
+
+def test_no_kernel_of_the_library_spills_to_scratch_except_the_one_that_is_known_to(tmp_path):
+    """The code objects inside libsurge_replay.so (llvm-objdump --offloading), kernel by kernel from their metadata notes: a
+    kernel of this library that starts to spill registers to scratch memory loses its place on the roofline silently — this
+    fails loudly instead.  Known and tolerated: fold_chunked_kernel<16> (256 VGPRs, 10 of them spilled, 44 bytes per lane —
+    DESIGN.md section 6d).  rocPRIM's kernels are the library's own business."""
+    import shutil
+    import subprocess
+
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(f"{tools}/llvm-objdump") and os.path.exists(f"{tools}/llvm-readelf")):
+        pytest.skip("no llvm-objdump / llvm-readelf")
+    shutil.copy(_native.build(), tmp_path / "lib.so")
+    subprocess.run([f"{tools}/llvm-objdump", "--offloading", "lib.so"], cwd=tmp_path, capture_output=True, check=True)
+    objects = sorted(p for p in os.listdir(tmp_path) if p.endswith("gfx950"))
+    assert len(objects) >= 8, objects  # one per translation unit with device code
+    kernels = {}
+    for name in objects:
+        notes = subprocess.run([f"{tools}/llvm-readelf", "--notes", name], cwd=tmp_path, capture_output=True, text=True, check=True).stdout
+        cur = None
+        for line in notes.splitlines():
+            m = re.match(r"\s+\.(name|private_segment_fixed_size|vgpr_spill_count|vgpr_count):\s+(\S+)", line)
+            if not m:
+                continue
+            if m.group(1) == "name":
+                cur = kernels.setdefault(m.group(2), {})
+            elif cur is not None:
+                cur[m.group(1)] = int(m.group(2))
+    ours = {k: v for k, v in kernels.items() if "rocprim" not in k and "private_segment_fixed_size" in v}
+    assert len(ours) >= 70, len(ours)
+    for hot in ("fold_sorted_kernelILi16", "fold_rows_kernelILi8", "fold_tiled_kernelILi2", "fold_kernelILi1ELi16", "section_kernel", "lz4_exec_kernelILb1"):
+        assert any(hot in k for k in ours), hot
+    spilling = {k: v for k, v in ours.items() if v["private_segment_fixed_size"] or v.get("vgpr_spill_count", 0)}
+    assert all("fold_chunked_kernelILi16" in k and v["private_segment_fixed_size"] <= 64 for k, v in spilling.items()), spilling
