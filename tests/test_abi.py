@@ -284,6 +284,8 @@ def test_a_v1_schema_compiles_its_flat_kernel_for_gfx950_without_a_gpu_and_a_nar
             co.write_bytes(buf.raw[: n.value])
             asm = subprocess.run([objdump, "-d", str(co)], capture_output=True, text=True, check=True).stdout
             body = asm[asm.index("<surge_v1_flat16>:"):]
+            notes = subprocess.run([os.path.join(os.path.dirname(objdump), "llvm-readelf"), "--notes", str(co)], capture_output=True, text=True).stdout
+            assert "surge_v1_flat16" in notes and not re.search(r"\.(private_segment_fixed_size|vgpr_spill_count):\s+[1-9]", notes), "the compiled flat kernel spills"
             ops = [l.split()[0] for l in body.splitlines() if l.split()[:1]]
             valu[name] = (sum(1 for o in ops if o.startswith("v_")), sum(1 for o in ops if o.startswith("ds_bpermute")))
     if valu:
