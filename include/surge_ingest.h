@@ -159,15 +159,22 @@ int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge
  * partition, whose spans index one buffer: one part of surge_device_decoder_push_parts_async, one host-to-device copy.
  * A slab stays as it is through the next five feeds.  data[p] / len[p]: partition p's bytes of this fetch response (len
  * 0: nothing, the partition is only carried along); consumed_out (nullable, n entries); sections_out holds up to
- * max_sections entries (the total of len[] / 61 + n is always enough).  SURGE_INGEST_DEVICE_LZ4 / isolation level as in
- * surge_ingest_create (FRAMES is implied).  Returns the first failing partition's status (its message in
- * surge_ingest_group_last_error); the sections of the partitions that did not fail are delivered all the same. */
+ * max_sections entries: the total of len[] / 61 + surge_ingest_group_queued_sections() is always enough (a feed also
+ * delivers what earlier feeds left queued — a transaction whose COMMIT marker arrives in this one).  `threads` host
+ * threads frame the partitions side by side: the calling thread + a pool the group keeps for its lifetime.
+ * SURGE_INGEST_DEVICE_LZ4 / isolation level as in surge_ingest_create (FRAMES is implied; without DEVICE_LZ4 the host
+ * decompresses lz4 batches into the slab, sized by trial).
+ * A feed is ALL OR NOTHING: when a partition fails (its status is returned, its message in
+ * surge_ingest_group_last_error) or sections_out is too small (SURGE_E_INVALID with the count the feed delivers in
+ * *n_sections_out), every partition's framer is put back exactly as it was before the call — nothing consumed, nothing
+ * drained, consumed_out all 0 — so the caller can feed again (a larger table; without the failing partition's bytes). */
 typedef struct surge_ingest_group surge_ingest_group;
 int32_t surge_ingest_group_create(int32_t n_partitions, int32_t isolation_level, surge_ingest_group** out);
 int32_t surge_ingest_group_destroy(surge_ingest_group* g);
 const char* surge_ingest_group_last_error(const surge_ingest_group* g);
 int32_t surge_ingest_group_feed(surge_ingest_group* g, const uint8_t* const* data, const int64_t* len, int32_t threads, int64_t* consumed_out,
                                 int64_t max_sections, surge_batch_section* sections_out, int64_t* n_sections_out, const uint8_t** slab_out);
+int64_t surge_ingest_group_queued_sections(const surge_ingest_group* g); /* batches the partitions hold from earlier feeds (upper bound of what the next feed delivers beyond its own) */
 int32_t surge_ingest_group_counters(const surge_ingest_group* g, int64_t out[8]); /* surge_ingest_counters, summed */
 int32_t surge_ingest_group_set_allocator(surge_ingest_group* g, void* (*alloc)(size_t), void (*release)(void*));
 int32_t surge_ingest_group_use_pinned_slabs(surge_ingest_group* g); /* page-locked slabs (SURGE_E_DEVICE without a HIP runtime) */

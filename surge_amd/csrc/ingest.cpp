@@ -8,6 +8,9 @@
 #include <new>
 #include <string>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -198,6 +201,8 @@ int lz4_block(const uint8_t* ip, const uint8_t* iend, uint8_t* dst, int64_t* op_
 // The byte arena records / sections are copied into: a growable buffer whose memory comes from a pluggable allocator, so
 // that a device decoder can have it PAGE-LOCKED (surge_ingest_set_allocator: its H2D copy then reads the arena in place
 // instead of staging it through a pinned buffer of its own).
+struct SliceOverflow : std::bad_alloc {};  // an external arena (a slice of a group's slab) is full
+
 struct Arena {
   uint8_t* p = nullptr;
   size_t n = 0, cap = 0;
@@ -236,7 +241,9 @@ struct Arena {
   void clear() { n = 0; }
   void append(const uint8_t* src, size_t len) {
     if (n + len > cap) {
-      if (external) throw std::bad_alloc();  // (a group sizes its members' slices for the whole feed: cannot happen)
+      // a group sizes its members' slices for the whole feed; only host-side LZ4 (a group without SURGE_INGEST_DEVICE_LZ4)
+      // can outgrow one: surge_ingest_group_feed undoes the feed and runs it again with more room
+      if (external) throw SliceOverflow();
       size_t want = cap ? cap * 2 : (size_t)1 << 16;
       while (want < n + len) want *= 2;
       uint8_t* fresh = (uint8_t*)(alloc ? alloc(want) : std::malloc(want));
@@ -270,6 +277,7 @@ struct surge_ingest {
   Arena ext[kArenas];
   uint8_t* ext_next = nullptr;
   size_t ext_next_cap = 0;
+  bool slice_overflow = false;  // the last feed ran out of its slice (host-side LZ4 in a group: the group retries with more room)
   Arena& arena_now() { return grouped ? ext[cur] : arenas[cur]; }
   const Arena& arena_now() const { return grouped ? ext[cur] : arenas[cur]; }
   std::deque<Batch> queue;
@@ -571,6 +579,9 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
       }
       g->cur = (g->cur + 1) % surge_ingest::kArenas;
       g->handed_out = false;
+    } catch (const SliceOverflow&) {
+      g->slice_overflow = true;
+      return fail(g, E_NOMEM, "the group's slice for this partition is full");
     } catch (const std::bad_alloc&) {
       return fail(g, E_NOMEM, "out of host memory while decoding");
     }
@@ -689,6 +700,10 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
       }
       pos += 12 + batch_len;
     }
+  } catch (const SliceOverflow&) {
+    if (consumed_out) *consumed_out = pos;
+    g->slice_overflow = true;
+    return fail(g, E_NOMEM, "the group's slice for this partition is full");
   } catch (const std::bad_alloc&) {
     if (consumed_out) *consumed_out = pos;
     return fail(g, E_NOMEM, "out of host memory while decoding");
@@ -837,6 +852,84 @@ int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge
 
 // A consumer's partitions framed as ONE unit: every feed lays the partitions' records sections out in one slab — the
 // group rotates through six, like a single framer's arenas — so a fetch response reaches the device in one copy.
+//
+// Threads: the group keeps a POOL of framing threads for its lifetime (started at the first feed that asks for them;
+// a feed hands them one job and takes part in it itself) — a consumer feeds every couple of milliseconds, and creating
+// and joining seven threads per feed cost more than some feeds' framing.
+//
+// Failure: a feed either frames every partition or leaves the group exactly as it was.  What a member's feed changes —
+// its queue (open transactions move to the new slice), its counters, which arena is current — is saved before the feed
+// (a FRAMES queue holds only the few batches of open transactions: cheap) and put back when any partition fails or the
+// caller's section table is too small; the slab the failed feed wrote into is the one the next feed writes into again.
+namespace {
+
+struct FramingPool {
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  std::vector<std::thread> th;
+  const std::function<void()>* job = nullptr;
+  uint64_t gen = 0;
+  int want = 0;     // workers 0 .. want-1 take part in the current job
+  int pending = 0;  // ... and have not finished it yet
+  bool stop = false;
+
+  void worker(int idx) {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv_job.wait(lk, [&] { return stop || gen != seen; });
+      if (stop) return;
+      seen = gen;
+      if (idx >= want) continue;
+      const std::function<void()>* j = job;
+      lk.unlock();
+      (*j)();  // (catches everything itself)
+      lk.lock();
+      if (--pending == 0) cv_done.notify_one();
+    }
+  }
+  // Runs `work` on this thread and on up to `helpers` pool threads; returns when all of them have left it.
+  void run(const std::function<void()>& work, int helpers) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      while ((int)th.size() < helpers) {
+        try {
+          const int idx = (int)th.size();
+          th.emplace_back([this, idx] { worker(idx); });
+        } catch (...) {  // std::system_error: the threads that did start — and the caller — do the work
+          break;
+        }
+      }
+      if (helpers > (int)th.size()) helpers = (int)th.size();
+      job = &work;
+      want = pending = helpers;
+      ++gen;
+    }
+    if (helpers > 0) cv_job.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return pending == 0; });
+    job = nullptr;
+  }
+  ~FramingPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_job.notify_all();
+    for (std::thread& t : th) t.join();
+  }
+};
+
+struct MemberSave {
+  std::deque<Batch> queue;
+  int64_t counters[8];
+  int cur;
+  bool handed_out;
+};
+
+}  // namespace
+
 struct surge_ingest_group {
   std::vector<surge_ingest*> g;
   Arena slabs[surge_ingest::kArenas];
@@ -844,6 +937,10 @@ struct surge_ingest_group {
   std::string err;
   std::vector<std::vector<surge_batch_section>> drained;
   std::vector<int64_t> off;
+  std::vector<MemberSave> saved;
+  std::vector<int32_t> status;
+  std::vector<int64_t> consumed;
+  FramingPool pool;
   ~surge_ingest_group() {
     for (surge_ingest* x : g) delete x;
   }
@@ -855,12 +952,15 @@ int32_t surge_ingest_group_create(int32_t n_partitions, int32_t isolation_level,
   if (!out) return fail(nullptr, E_INVALID, "out is NULL");
   *out = nullptr;
   if (n_partitions < 1 || n_partitions > (1 << 20)) return fail(nullptr, E_INVALID, "n_partitions out of range");
-  surge_ingest_group* grp = new (std::nothrow) surge_ingest_group();
-  if (!grp) return fail(nullptr, E_NOMEM, "out of host memory");
+  surge_ingest_group* grp = nullptr;
   try {
+    grp = new surge_ingest_group();
     grp->g.reserve((size_t)n_partitions);
     grp->drained.resize((size_t)n_partitions);
     grp->off.resize((size_t)n_partitions + 1);
+    grp->saved.resize((size_t)n_partitions);
+    grp->status.resize((size_t)n_partitions);
+    grp->consumed.resize((size_t)n_partitions);
     for (int32_t p = 0; p < n_partitions; ++p) {
       surge_ingest* x = nullptr;
       const int32_t rc = surge_ingest_create(isolation_level | SURGE_INGEST_FRAMES, &x);
@@ -896,84 +996,139 @@ int32_t surge_ingest_group_set_allocator(surge_ingest_group* grp, void* (*alloc)
   return OK;
 }
 
+int64_t surge_ingest_group_queued_sections(const surge_ingest_group* grp) {
+  if (!grp) return 0;
+  int64_t n = 0;
+  for (const surge_ingest* x : grp->g) n += (int64_t)x->queue.size();
+  return n;
+}
+
 int32_t surge_ingest_group_feed(surge_ingest_group* grp, const uint8_t* const* data, const int64_t* len, int32_t threads, int64_t* consumed_out,
                                 int64_t max_sections, surge_batch_section* sections_out, int64_t* n_sections_out, const uint8_t** slab_out) {
   if (!grp || !data || !len || !n_sections_out || !slab_out || max_sections < 0 || (!sections_out && max_sections > 0)) return fail(nullptr, E_INVALID, "bad argument");
   const int32_t n = (int32_t)grp->g.size();
   *n_sections_out = 0;
   *slab_out = nullptr;
-  // every partition's slice: what it still holds (open transactions, batches not drained yet) + this feed
-  int64_t total = 0;
-  for (int32_t p = 0; p < n; ++p) {
+  if (consumed_out)
+    for (int32_t p = 0; p < n; ++p) consumed_out[p] = 0;
+  for (int32_t p = 0; p < n; ++p)
     if (len[p] < 0 || (!data[p] && len[p] > 0)) { grp->err = "bad buffer for partition " + std::to_string(p); return E_INVALID; }
-    int64_t queued = 0;
-    for (const Batch& qb : grp->g[(size_t)p]->queue) queued += qb.sect_off >= 0 ? qb.sect_len : 0;
-    grp->off[(size_t)p] = total;
-    total = (total + queued + len[p] + 15) & ~15ll;
-  }
-  grp->off[(size_t)n] = total;
-  Arena& slab = grp->slabs[(grp->cur + 1) % surge_ingest::kArenas];
-  try {
-    slab.clear();
-    slab.reserve((size_t)total + 16);
-  } catch (const std::bad_alloc&) {
-    grp->err = "out of host memory for the group's slab";
-    return E_NOMEM;
-  }
-  grp->cur = (grp->cur + 1) % surge_ingest::kArenas;
-  std::vector<int32_t> status((size_t)n, OK);
-  std::atomic<int32_t> next{0};
-  auto work = [&]() {
-    for (;;) {
-      const int32_t p = next.fetch_add(1);
-      if (p >= n) return;
+  const int group_cur = grp->cur;
+  auto undo = [&]() {
+    for (int32_t p = 0; p < n; ++p) {
       surge_ingest* x = grp->g[(size_t)p];
-      int32_t rc = OK;
-      try {  // (nothing may leave a thread)
-        x->ext_next = slab.data() + grp->off[(size_t)p];
-        x->ext_next_cap = (size_t)(grp->off[(size_t)p + 1] - grp->off[(size_t)p]);
-        int64_t consumed = 0;
-        rc = surge_ingest_feed(x, data[p], len[p], &consumed);
-        if (consumed_out) consumed_out[p] = consumed;
-        std::vector<surge_batch_section>& out = grp->drained[(size_t)p];
-        out.clear();
-        if (rc == OK && !x->queue.empty()) {
-          out.resize(x->queue.size());
-          int64_t got = 0;
-          rc = surge_ingest_drain_sections(x, (int64_t)out.size(), out.data(), &got);
-          out.resize(rc == OK ? (size_t)got : 0);
-          for (surge_batch_section& sct : out) sct.byte_off += grp->off[(size_t)p];
-        }
-      } catch (...) {
-        rc = E_NOMEM;
-      }
-      status[(size_t)p] = rc;
+      MemberSave& sv = grp->saved[(size_t)p];
+      x->queue.swap(sv.queue);
+      std::memcpy(x->counters, sv.counters, sizeof sv.counters);
+      x->cur = sv.cur;
+      x->handed_out = sv.handed_out;
+      grp->drained[(size_t)p].clear();
     }
+    grp->cur = group_cur;
+    if (consumed_out)
+      for (int32_t p = 0; p < n; ++p) consumed_out[p] = 0;
   };
-  int32_t t = threads < 1 ? 1 : threads;
-  if (t > n) t = n;
-  std::vector<std::thread> th;
-  try {
-    for (int32_t i = 1; i < t; ++i) th.emplace_back(work);
-  } catch (...) {  // std::system_error: the threads that did start — and this one — do the work
-  }
-  work();
-  for (std::thread& x : th) x.join();
-  int64_t at = 0;
-  int32_t first_bad = OK;
-  for (int32_t p = 0; p < n; ++p) {
-    if (status[(size_t)p] != OK && first_bad == OK) {
-      first_bad = status[(size_t)p];
-      grp->err = "partition " + std::to_string(p) + ": " + grp->g[(size_t)p]->err;
+  // Every partition's slice: what it still holds (open transactions, batches not drained yet) + this feed.  With
+  // SURGE_INGEST_DEVICE_LZ4 a section is never longer than its batch; without it the host decompresses lz4 batches INTO the
+  // slice, whose size is then only known afterwards: the feed is undone and run again with `expand` times the room.
+  for (int64_t expand = 1;; expand *= 4) {
+    // what a failed feed is undone from
+    try {
+      for (int32_t p = 0; p < n; ++p) {
+        const surge_ingest* x = grp->g[(size_t)p];
+        MemberSave& sv = grp->saved[(size_t)p];
+        sv.queue = x->queue;
+        std::memcpy(sv.counters, x->counters, sizeof sv.counters);
+        sv.cur = x->cur;
+        sv.handed_out = x->handed_out;
+      }
+    } catch (const std::bad_alloc&) {
+      grp->err = "out of host memory";
+      return E_NOMEM;
     }
-    for (const surge_batch_section& sct : grp->drained[(size_t)p]) {
-      if (at == max_sections) { grp->err = "sections_out is too small (a batch is at least 61 bytes of a feed)"; return E_INVALID; }
-      sections_out[at++] = sct;
+    int64_t total = 0;
+    for (int32_t p = 0; p < n; ++p) {
+      int64_t queued = 0;
+      for (const Batch& qb : grp->g[(size_t)p]->queue) queued += qb.sect_off >= 0 ? qb.sect_len : 0;
+      grp->off[(size_t)p] = total;
+      total = (total + queued + len[p] * expand + 15) & ~15ll;
     }
+    grp->off[(size_t)n] = total;
+    Arena& slab = grp->slabs[(group_cur + 1) % surge_ingest::kArenas];
+    try {
+      slab.clear();
+      slab.reserve((size_t)total + 16);
+    } catch (const std::bad_alloc&) {
+      grp->err = "out of host memory for the group's slab";
+      return E_NOMEM;
+    }
+    grp->cur = (group_cur + 1) % surge_ingest::kArenas;
+    std::atomic<int32_t> next{0};
+    const std::function<void()> work = [&]() {
+      for (;;) {
+        const int32_t p = next.fetch_add(1);
+        if (p >= n) return;
+        surge_ingest* x = grp->g[(size_t)p];
+        int32_t rc = OK;
+        int64_t consumed = 0;
+        try {  // (nothing may leave a thread)
+          x->ext_next = slab.data() + grp->off[(size_t)p];
+          x->ext_next_cap = (size_t)(grp->off[(size_t)p + 1] - grp->off[(size_t)p]);
+          x->slice_overflow = false;
+          rc = surge_ingest_feed(x, data[p], len[p], &consumed);
+          std::vector<surge_batch_section>& out = grp->drained[(size_t)p];
+          out.clear();
+          if (rc == OK && !x->queue.empty()) {
+            out.resize(x->queue.size());
+            int64_t got = 0;
+            rc = surge_ingest_drain_sections(x, (int64_t)out.size(), out.data(), &got);
+            out.resize(rc == OK ? (size_t)got : 0);
+            for (surge_batch_section& sct : out) sct.byte_off += grp->off[(size_t)p];
+          }
+        } catch (...) {
+          rc = E_NOMEM;
+        }
+        grp->status[(size_t)p] = rc;
+        grp->consumed[(size_t)p] = consumed;
+      }
+    };
+    int32_t t = threads < 1 ? 1 : threads;
+    if (t > n) t = n;
+    grp->pool.run(work, t - 1);
+    int32_t first_bad = OK;
+    bool overflow = false;
+    for (int32_t p = 0; p < n; ++p) {
+      overflow |= grp->g[(size_t)p]->slice_overflow;
+      if (grp->status[(size_t)p] != OK && first_bad == OK) {
+        first_bad = grp->status[(size_t)p];
+        grp->err = "partition " + std::to_string(p) + ": " + grp->g[(size_t)p]->err;
+      }
+    }
+    if (overflow && expand < 4096) {  // (an LZ4 block expands at most 255 x)
+      undo();
+      continue;
+    }
+    if (first_bad != OK) {
+      undo();
+      return first_bad;
+    }
+    int64_t need = 0;
+    for (int32_t p = 0; p < n; ++p) need += (int64_t)grp->drained[(size_t)p].size();
+    if (need > max_sections) {
+      undo();
+      *n_sections_out = need;
+      grp->err = "sections_out is too small: this feed delivers " + std::to_string(need) + " sections (n_sections_out; the feed was undone — call again with room for them)";
+      return E_INVALID;
+    }
+    int64_t at = 0;
+    for (int32_t p = 0; p < n; ++p) {
+      for (const surge_batch_section& sct : grp->drained[(size_t)p]) sections_out[at++] = sct;
+      if (consumed_out) consumed_out[p] = grp->consumed[(size_t)p];
+    }
+    *n_sections_out = at;
+    *slab_out = slab.data();
+    return OK;
   }
-  *n_sections_out = at;
-  *slab_out = slab.data();
-  return first_bad;
 }
 
 int32_t surge_ingest_group_counters(const surge_ingest_group* grp, int64_t out[8]) {

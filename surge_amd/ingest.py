@@ -335,25 +335,35 @@ class PartitionedFramedFetches:
 
         t0 = time.perf_counter()
         n = self._n
+        fetch = list(fetch)
+        if len(fetch) != n:  # (before anything is fed: a short response must not leave some partitions fed and others not)
+            raise ValueError(f"a fetch response holds {len(fetch)} entries for {n} partitions (pass None for a partition without bytes)")
         bufs = []
         for tail, data in zip(self._tails, fetch):  # a partition's cut batch from the last fetch goes in front (rare: whole batches are the rule)
             data = data or b""
             bufs.append(tail + bytes(data) if tail else (data if isinstance(data, bytes) else bytes(data)))
         data_arr = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) if b else None for b in bufs])
         len_arr = (ctypes.c_int64 * n)(*[len(b) for b in bufs])
-        max_sec = sum(len(b) for b in bufs) // 61 + 4 * n + 16  # a batch is at least its 61-byte header (+ what the partitions still hold)
+        # a batch is at least its 61-byte header; a feed also delivers what the partitions still hold from earlier feeds (a
+        # transaction whose COMMIT marker only arrives now)
+        max_sec = sum(len(b) for b in bufs) // 61 + int(self._lib.surge_ingest_group_queued_sections(self._h)) + 16
         slot = len(self.framing_seconds) % len(self._ring)
-        if self._ring[slot] is None or self._ring[slot].shape[0] < max_sec:
-            self._ring[slot] = np.empty(max_sec + max_sec // 4, dtype=SECTION_DTYPE)
-        secs = self._ring[slot]
         n_sec = ctypes.c_int64()
         slab = ctypes.c_void_p()
         consumed = (ctypes.c_int64 * n)()
-        rc = self._lib.surge_ingest_group_feed(self._h, data_arr, len_arr, self._threads, consumed, secs.shape[0], secs.ctypes.data_as(ctypes.c_void_p),
-                                               ctypes.byref(n_sec), ctypes.byref(slab))
-        self._tails = [bufs[p][consumed[p]:] for p in range(n)]  # also on failure: batches decoded before the failing one ARE queued
-        if rc != 0:
+        while True:
+            if self._ring[slot] is None or self._ring[slot].shape[0] < max_sec:
+                self._ring[slot] = np.empty(max_sec + max_sec // 4, dtype=SECTION_DTYPE)
+            secs = self._ring[slot]
+            rc = self._lib.surge_ingest_group_feed(self._h, data_arr, len_arr, self._threads, consumed, secs.shape[0], secs.ctypes.data_as(ctypes.c_void_p),
+                                                   ctypes.byref(n_sec), ctypes.byref(slab))
+            if rc != 0 and n_sec.value > secs.shape[0]:  # table too small: the feed was undone and says what it needs
+                max_sec = int(n_sec.value)
+                continue
+            break
+        if rc != 0:  # all or nothing: the group is what it was before the call (the tails too)
             raise IngestError(rc, (self._lib.surge_ingest_group_last_error(self._h) or b"").decode())
+        self._tails = [bufs[p][consumed[p]:] for p in range(n)]
         self.framing_seconds.append(time.perf_counter() - t0)
         return secs[: n_sec.value], int(slab.value or 0)
 

@@ -139,22 +139,24 @@ COMMIT, ABORT = 1, 0
 
 def record_batch(base_offset: int, records, *, compression: str = "none", transactional: bool = False, control: bool = False,
                  producer_id: int = -1, producer_epoch: int = 0, base_sequence: int = -1, base_timestamp: int = 0,
-                 magic: int = 2, codec_override=None, compressor=None) -> bytes:
+                 magic: int = 2, codec_override=None, compressor=None, timestamp_deltas=None) -> bytes:
     """``records``: list of (key, value) or (key, value, headers); offsets are base_offset + index.  ``compressor``
-    replaces this module's own LZ4 frame writer (e.g. with the reference lz4 library as bundled by Apache Arrow)."""
-    recs = b"".join(record(i, *(r if len(r) == 3 else (r[0], r[1], ()))) for i, r in enumerate(records))
+    replaces this module's own LZ4 frame writer (e.g. with the reference lz4 library as bundled by Apache Arrow).
+    ``timestamp_deltas``: per record, ms after ``base_timestamp`` (maxTimestamp follows)."""
+    td = list(timestamp_deltas) if timestamp_deltas is not None else [0] * len(records)
+    recs = b"".join(record(i, *(r if len(r) == 3 else (r[0], r[1], ())), timestamp_delta=td[i]) for i, r in enumerate(records))
     codec = {"none": 0, "gzip": 1, "snappy": 2, "lz4": 3, "zstd": 4}[compression] if codec_override is None else codec_override
     payload = (compressor(recs) if compressor else lz4_frame(recs)) if compression == "lz4" else recs
     attrs = codec | (0x10 if transactional else 0) | (0x20 if control else 0)
     n = len(records)
-    after_crc = struct.pack(">hiqqqhii", attrs, max(n - 1, 0), base_timestamp, base_timestamp, producer_id, producer_epoch,
+    after_crc = struct.pack(">hiqqqhii", attrs, max(n - 1, 0), base_timestamp, base_timestamp + max(td, default=0), producer_id, producer_epoch,
                             base_sequence, n) + payload
     body = struct.pack(">ib", 0, magic) + struct.pack(">I", crc32c(after_crc)) + after_crc
     return struct.pack(">qi", base_offset, len(body)) + body
 
 
-def control_batch(offset: int, producer_id: int, kind: int, producer_epoch: int = 0) -> bytes:
+def control_batch(offset: int, producer_id: int, kind: int, producer_epoch: int = 0, timestamp: int = 0) -> bytes:
     key = struct.pack(">hh", 0, kind)         # version, type (0 ABORT, 1 COMMIT)
     value = struct.pack(">hi", 0, 0)          # version, coordinatorEpoch
     return record_batch(offset, [(key, value)], transactional=True, control=True, producer_id=producer_id,
-                        producer_epoch=producer_epoch)
+                        producer_epoch=producer_epoch, base_timestamp=timestamp)
