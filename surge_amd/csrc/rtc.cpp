@@ -6,8 +6,11 @@
 // hiprtc -> a gfx950 code object -> hipModuleLoadData (fold_slots.hip).  libhiprtc is dlopen'ed on first use — hosts
 // without it keep the interpreter (surge_replay_kernel_info says which one a handle runs).
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -49,6 +52,7 @@ struct RtcApi {
 
 std::mutex g_rtc_mu;
 RtcApi g_rtc;
+long g_rtc_cache_hits = 0;  // code objects served from the disk cache by this process
 bool g_rtc_tried = false;
 
 // libhiprtc: SURGE_HIPRTC_LIBRARY, then the copy that sits beside the HIP runtime this process already uses (PyTorch
@@ -110,28 +114,113 @@ bool load_rtc_locked() {
   return false;
 }
 
+// ---- the code-object cache on disk ---------------------------------------------------------------------------------------
+// A compile costs 0.6 - 1 s per schema and process; the result depends on nothing but the text compiled, the target and
+// the compiler, so it is kept: <dir>/<128-bit key>.co, dir = $SURGE_REPLAY_CACHE_DIR, else $XDG_CACHE_HOME/surge_amd, else
+// $HOME/.cache/surge_amd, else /tmp/surge_amd-<uid> (SURGE_REPLAY_CACHE=0: no cache).  A file is "SRGCO1\0\0" + length +
+// FNV-1a of the code + the code; anything that does not check out is compiled again and overwritten (rename: atomic).
+uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
+  const unsigned char* p = (const unsigned char*)data;
+  for (size_t i = 0; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+  return h;
+}
+
+std::string cache_dir() {
+  if (const char* v = std::getenv("SURGE_REPLAY_CACHE"))
+    if (std::atoi(v) == 0) return "";
+  std::string d;
+  if (const char* v = std::getenv("SURGE_REPLAY_CACHE_DIR")) d = v;
+  else if (const char* x = std::getenv("XDG_CACHE_HOME")) d = std::string(x) + "/surge_amd";
+  else if (const char* hme = std::getenv("HOME")) {
+    const std::string c = std::string(hme) + "/.cache";
+    (void)mkdir(c.c_str(), 0700);
+    d = c + "/surge_amd";
+  } else d = "/tmp/surge_amd-" + std::to_string((long)getuid());
+  if (mkdir(d.c_str(), 0700) != 0) {
+    struct stat st;
+    if (stat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return "";
+  }
+  return d;
+}
+
+std::string cache_key(const std::string& source, const char* const* headers, int n_headers, const char* const* opts, int n_opts) {
+  uint64_t a = 1469598103934665603ull, b = 0x9E3779B97F4A7C15ull;
+  auto mix = [&](const void* p, size_t n) {
+    a = fnv1a(p, n, a);
+    a = fnv1a("\x1f", 1, a);
+    b = fnv1a(p, n, b ^ (uint64_t)n);
+  };
+  mix(source.data(), source.size());
+  for (int i = 0; i < n_headers; ++i) mix(headers[i], std::strlen(headers[i]));
+  for (int i = 0; i < n_opts; ++i) mix(opts[i], std::strlen(opts[i]));
+  // the compiler: the HIP runtime's version (hiprtc ships with it) — a ROCm upgrade compiles afresh
+  int ver = 0;
+  if (void* f = dlsym(RTLD_DEFAULT, "hipRuntimeGetVersion")) (void)((int (*)(int*))f)(&ver);
+  mix(&ver, sizeof ver);
+  char hex[40];
+  std::snprintf(hex, sizeof hex, "%016llx%016llx", (unsigned long long)a, (unsigned long long)b);
+  return hex;
+}
+
+bool cache_load(const std::string& path, std::vector<char>* code) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  char head[24];
+  bool ok = std::fread(head, 1, 24, f) == 24 && std::memcmp(head, "SRGCO1\0\0", 8) == 0;
+  uint64_t len = 0, sum = 0;
+  if (ok) {
+    std::memcpy(&len, head + 8, 8);
+    std::memcpy(&sum, head + 16, 8);
+    ok = len > 0 && len < (1ull << 30);
+  }
+  if (ok) {
+    code->resize((size_t)len);
+    ok = std::fread(code->data(), 1, (size_t)len, f) == (size_t)len && std::fgetc(f) == EOF && fnv1a(code->data(), (size_t)len, 1469598103934665603ull) == sum;
+  }
+  std::fclose(f);
+  if (!ok) code->clear();
+  return ok;
+}
+
+void cache_store(const std::string& path, const std::vector<char>& code) {
+  const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  FILE* f = std::fopen(tmp.c_str(), "wb");
+  if (!f) return;
+  const uint64_t len = code.size(), sum = fnv1a(code.data(), code.size(), 1469598103934665603ull);
+  bool ok = std::fwrite("SRGCO1\0\0", 1, 8, f) == 8 && std::fwrite(&len, 8, 1, f) == 1 && std::fwrite(&sum, 8, 1, f) == 1 && std::fwrite(code.data(), 1, code.size(), f) == code.size();
+  ok = std::fclose(f) == 0 && ok;
+  if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
+}
+
 }  // namespace
 
 // Compile `source` (which #includes the embedded headers by their file names) for `arch`.  Returns false with *log set
 // on any failure.  ms: wall time of the compilation.
 bool rtc_compile(const std::string& source, const char* arch, std::vector<char>* code, std::string* log, double* ms) {
   std::lock_guard<std::mutex> lk(g_rtc_mu);
+  const auto t0 = std::chrono::steady_clock::now();
+  const char* headers[] = {surge_src_fold_layout_h, surge_src_fold_device_h, surge_src_fold_slots_device_h, surge_src_fold_flat_device_h};
+  const char* names[] = {"fold_layout.h", "fold_device.h", "fold_slots_device.h", "fold_flat_device.h"};
+  const std::string arch_opt = std::string("--offload-arch=") + arch;
+  // -ffp-contract=off: an f64 ADD must round exactly like the JVM's (no fused multiply-add anywhere near it)
+  const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
+  const std::string dir = cache_dir();
+  const std::string cached = dir.empty() ? "" : dir + "/" + cache_key(source, headers, 4, opts, 4) + ".co";
+  if (!cached.empty() && cache_load(cached, code)) {  // (needs no libhiprtc at all)
+    g_rtc_cache_hits += 1;
+    *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return true;
+  }
   if (!load_rtc_locked()) {
     *log = "libhiprtc not available: " + g_rtc.why;
     return false;
   }
-  const auto t0 = std::chrono::steady_clock::now();
-  const char* headers[] = {surge_src_fold_layout_h, surge_src_fold_device_h, surge_src_fold_slots_device_h, surge_src_fold_flat_device_h};
-  const char* names[] = {"fold_layout.h", "fold_device.h", "fold_slots_device.h", "fold_flat_device.h"};
   hiprtcProgram prog = nullptr;
   int rc = g_rtc.CreateProgram(&prog, source.c_str(), "surge_schema_spec.hip", 4, headers, names);
   if (rc != 0) {
     *log = std::string("hiprtcCreateProgram: ") + g_rtc.GetErrorString(rc);
     return false;
   }
-  const std::string arch_opt = std::string("--offload-arch=") + arch;
-  // -ffp-contract=off: an f64 ADD must round exactly like the JVM's (no fused multiply-add anywhere near it)
-  const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
   rc = g_rtc.CompileProgram(prog, 4, opts);
   size_t ls = 0;
   if (g_rtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
@@ -151,13 +240,14 @@ bool rtc_compile(const std::string& source, const char* arch, std::vector<char>*
     if (!ok) *log = "hiprtcGetCode failed";
   }
   g_rtc.DestroyProgram(&prog);
+  if (ok && !cached.empty()) cache_store(cached, *code);
   *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return ok;
 }
 
 const char* rtc_library_path() {
   std::lock_guard<std::mutex> lk(g_rtc_mu);
-  return g_rtc.lib ? g_rtc.path.c_str() : "";
+  return g_rtc.lib ? g_rtc.path.c_str() : (g_rtc_cache_hits ? "the code-object cache on disk (no compile)" : "");
 }
 
 }  // namespace surge

@@ -85,10 +85,49 @@ def test_a_libhiprtc_candidate_that_fails_to_load_does_not_take_the_process_down
         "rc = lib.surge_replay_compile_schema_v2(ctypes.byref(sc), b'gfx950', None, 0, ctypes.byref(n))\n"
         "print('RC', rc, n.value)\n"
     )
-    env = dict(os.environ, SURGE_HIPRTC_LIBRARY="/nonexistent/libhiprtc.so")
+    env = dict(os.environ, SURGE_HIPRTC_LIBRARY="/nonexistent/libhiprtc.so", SURGE_REPLAY_CACHE="0")  # (a cache hit would not load libhiprtc at all)
     res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr  # 139 = the segfault
     assert "RC 0 " in res.stdout or "RC -" in res.stdout, res.stdout + res.stderr
+
+
+def test_compiled_code_objects_are_kept_on_disk_and_a_damaged_file_is_compiled_again(tmp_path, monkeypatch):
+    """the 0.6 - 1 s hiprtc compile of a schema's kernels is paid once per machine — the code object is
+    stored under SURGE_REPLAY_CACHE_DIR keyed by the text compiled, the target and the runtime's version; a file that does not
+    check out (truncated, flipped byte) is ignored and rewritten; SURGE_REPLAY_CACHE=0 turns the cache off."""
+    import time
+
+    from tests.test_slots import LEDGER
+
+    lib = _native.load()
+    sc = LEDGER.to_c()
+    monkeypatch.setenv("SURGE_REPLAY_CACHE_DIR", str(tmp_path))
+    monkeypatch.delenv("SURGE_REPLAY_CACHE", raising=False)
+
+    def compile_once():
+        n = ctypes.c_int64(0)
+        t0 = time.perf_counter()
+        rc = lib.surge_replay_compile_schema_v2(ctypes.byref(sc), b"gfx950", None, 0, ctypes.byref(n))
+        if rc != 0:
+            pytest.skip("no libhiprtc here")
+        buf = ctypes.create_string_buffer(n.value)
+        assert lib.surge_replay_compile_schema_v2(ctypes.byref(sc), b"gfx950", buf, n.value, ctypes.byref(n)) == 0
+        return buf.raw[: n.value], time.perf_counter() - t0
+
+    first, t_first = compile_once()
+    files = sorted(tmp_path.glob("*.co"))
+    assert len(files) == 1 and files[0].read_bytes()[24:] == first and files[0].read_bytes()[:8] == b"SRGCO1\0\0"
+    again, t_again = compile_once()
+    assert again == first and t_again < t_first / 3  # served from the file
+    blob = bytearray(files[0].read_bytes())
+    blob[len(blob) // 2] ^= 1
+    files[0].write_bytes(bytes(blob))
+    assert compile_once()[0] == first and files[0].read_bytes()[24:] == first  # compiled again, stored again
+    files[0].write_bytes(bytes(blob[:100]))
+    assert compile_once()[0] == first and files[0].read_bytes()[24:] == first
+    monkeypatch.setenv("SURGE_REPLAY_CACHE", "0")
+    files[0].unlink()
+    assert compile_once()[0] == first and not list(tmp_path.glob("*.co"))
 
 
 def test_default_schema_matches_python_mirror():

@@ -45,3 +45,19 @@ def test_multithreaded_snapshot_writer_is_race_free_under_thread_sanitizer(tmp_p
     assert build.returncode == 0, build.stderr[-3000:]
     res = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
     assert res.returncode == 0 and res.stdout.count("PASS") == 2 and "ThreadSanitizer" not in res.stderr, res.stdout + res.stderr[-4000:]
+
+
+def test_ingest_group_pool_slabs_and_undo_are_race_free_under_thread_sanitizer(tmp_path):
+    """surge_ingest_group_feed on 8 pool threads through more than two turns of the six slabs while a consumer thread reads
+    the slabs of up to five earlier fetches (what device pushes in flight do), with failing feeds undone in between
+    (tests/cpp/tsan_ingest_group.cpp): no report from -fsanitize=thread, and every fetch's sections equal what each
+    partition's own framer delivers."""
+    exe = str(tmp_path / "tsan_ingest_group")
+    srcs = [os.path.join(HERE, "cpp", "tsan_ingest_group.cpp")] + [os.path.join(ROOT, "surge_amd", "csrc", f) for f in ("ingest.cpp", "event_decode.cpp", "f64_text.cpp", "lz4_frame.cpp")]
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I" + os.path.join(ROOT, "include")] + srcs + ["-lpthread", "-o", exe],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "tsan" in (build.stderr or "").lower():
+        pytest.skip("no ThreadSanitizer runtime next to g++")
+    assert build.returncode == 0, build.stderr[-3000:]
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    assert res.returncode == 0 and "PASS group" in res.stdout and "ThreadSanitizer" not in res.stderr, res.stdout + res.stderr[-4000:]

@@ -550,6 +550,47 @@ def test_lz4_frames_decoded_on_the_device_block_by_block():
 
 
 @pytest.mark.gpu
+def test_a_full_lz4_block_that_ends_in_an_empty_last_sequence_decodes_like_on_the_host():
+    """a 64 KiB block whose last match runs to the block's end, followed by a token with no literals (encoders
+    other than liblz4 write that): the empty sequence's position, 65536, does not fit a table entry's 16 bits — it gets no
+    entry.  The device result equals the host decoder's."""
+    import struct as st
+
+    def section(hv_len):
+        hv = (b"0123456789abcdefghijklmnopqrstuvwxyz" * 2000)[: hv_len - 30000] + b"ab" * 15000
+        return kw.record_batch(0, [(b"acct-0001:1", counter_event(1, 1, 5), [(b"h", hv)])])[61:]
+
+    hv_len = 65536 - 60
+    while len(section(hv_len)) != 65536:
+        hv_len += 65536 - len(section(hv_len))
+    raw_expected = section(hv_len)
+    assert raw_expected.endswith(b"ab" * 15000)
+
+    def odd_encoder(raw):
+        assert raw == raw_expected
+        lit, ml = 65536 - 29000, 29000  # the last 29000 bytes repeat with period 2
+
+        def ext(v):
+            out = bytearray()
+            while v >= 255:
+                out.append(255)
+                v -= 255
+            out.append(v)
+            return bytes(out)
+
+        block = bytes([0xFF]) + ext(lit - 15) + raw[:lit] + st.pack("<H", 2) + ext(ml - 4 - 15) + b"\x00"
+        flg, bd = 0x60, 0x40
+        return st.pack("<I", 0x184D2204) + bytes([flg, bd, kw.header_checksum(bytes([flg, bd]))]) + st.pack("<I", len(block)) + block + st.pack("<I", 0)
+
+    wire = kw.record_batch(0, [(b"acct-0001:1", counter_event(1, 1, 5), [(b"h", raw_expected[-hv_len:])])], compression="lz4", compressor=odd_encoder)
+    wire += kw.record_batch(1, [(b"acct-0002:1", counter_event(1, 1, 7))], compression="lz4")
+    host, host_keys, dev, dev_keys, _ = both_decoders(wire, device_lz4=True)
+    assert dev_keys == host_keys == ["acct-0001", "acct-0002"]
+    for h, g2 in zip(host, dev):
+        assert h.tobytes() == g2.tobytes()
+
+
+@pytest.mark.gpu
 def test_events_topic_bytes_to_states_without_the_host_touching_a_record():
     """Kafka bytes -> host framing -> device decode -> device group-by + fold (K3) -> states, against the oracle's fold of
     the published events; the GPU state encoder takes the decoder's DEVICE key table as it is."""
