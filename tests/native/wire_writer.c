@@ -236,51 +236,126 @@ int64_t surge_test_wire_control(uint8_t* out, int64_t offset, int64_t producer_i
 
 /* ---- a whole topic, fetch response by fetch response ------------------------------------------------------------------------ */
 typedef struct {
-  int32_t P;
-  int64_t* next_offset;  /* per partition: the log end offset */
-  int64_t* flush_no;     /* per partition: flushes (transactions) written so far */
-  int32_t* base_seq;     /* per partition: the idempotent producer's next sequence number */
-  int8_t* marker_due;    /* per partition: -1 none, else the kind of the marker held back at the end of the last fetch */
-  uint8_t* buf;
-  int64_t cap;
-  int64_t* part_off; /* P + 1: partition p's bytes of the last fetch = buf[part_off[p] .. part_off[p + 1]) */
-  uint8_t *recs, *scratch;
+  uint8_t* buf;  /* the partition's bytes of the last fetch */
+  int64_t cap, len;
+  uint8_t *recs, *scratch; /* one batch's records section / its LZ4 frame */
   int64_t recs_cap;
+  int64_t next_offset; /* the log end offset */
+  int64_t flush_no;    /* flushes (transactions) written so far */
+  int32_t base_seq;    /* the idempotent producer's next sequence number */
+  int8_t marker_due;   /* -1 none, else the kind of the marker held back at the end of the last fetch */
+  int64_t counts[8];
+} wire_partition;
+
+typedef struct {
+  int32_t P;
+  wire_partition* part;
   int64_t* order;
   int64_t order_cap;
+  int64_t* start; /* P + 1 */
 } wire_topic;
 
 wire_topic* surge_test_wire_topic_create(int32_t P) {
   wire_topic* t = (wire_topic*)calloc(1, sizeof(wire_topic));
   if (!t) return NULL;
   t->P = P;
-  t->next_offset = (int64_t*)calloc((size_t)P, 8);
-  t->flush_no = (int64_t*)calloc((size_t)P, 8);
-  t->base_seq = (int32_t*)calloc((size_t)P, 4);
-  t->marker_due = (int8_t*)malloc((size_t)P);
-  t->part_off = (int64_t*)calloc((size_t)P + 1, 8);
-  memset(t->marker_due, -1, (size_t)P);
+  t->part = (wire_partition*)calloc((size_t)P, sizeof(wire_partition));
+  t->start = (int64_t*)calloc((size_t)P + 1, 8);
+  for (int32_t p = 0; p < P; ++p) t->part[p].marker_due = -1;
   return t;
 }
 void surge_test_wire_topic_destroy(wire_topic* t) {
   if (!t) return;
-  free(t->next_offset); free(t->flush_no); free(t->base_seq); free(t->marker_due); free(t->buf); free(t->part_off); free(t->recs); free(t->scratch); free(t->order);
+  for (int32_t p = 0; p < t->P; ++p) { free(t->part[p].buf); free(t->part[p].recs); free(t->part[p].scratch); }
+  free(t->part); free(t->order); free(t->start);
   free(t);
 }
 const uint8_t* surge_test_wire_topic_partition(const wire_topic* t, int32_t p, int64_t* len_out) {
-  *len_out = t->part_off[p + 1] - t->part_off[p];
-  return t->buf + t->part_off[p];
+  *len_out = t->part[p].len;
+  return t->part[p].buf;
 }
-int64_t surge_test_wire_topic_end_offset(const wire_topic* t, int32_t p) { return t->next_offset[p]; }
+int64_t surge_test_wire_topic_end_offset(const wire_topic* t, int32_t p) { return t->part[p].next_offset; }
 
-static int grow(wire_topic* t, int64_t at, int64_t more) {
-  if (at + more <= t->cap) return 0;
-  int64_t c = t->cap ? t->cap : (1 << 20);
-  while (c < at + more) c += c / 2;
-  uint8_t* nb = (uint8_t*)realloc(t->buf, (size_t)c);
+static int grow(wire_partition* w, int64_t more) {
+  if (w->len + more <= w->cap) return 0;
+  int64_t c = w->cap ? w->cap : (1 << 16);
+  while (c < w->len + more) c += c / 2;
+  uint8_t* nb = (uint8_t*)realloc(w->buf, (size_t)c);
   if (!nb) return -1;
-  t->buf = nb;
-  t->cap = c;
+  w->buf = nb;
+  w->cap = c;
+  return 0;
+}
+
+/* partition p's share of a fetch: records idx[0 .. np) */
+static int32_t partition_fetch(wire_partition* w, int32_t p, const int64_t* idx, int64_t np, int64_t max_rec, const uint8_t* keys, const int64_t* key_off,
+                               const uint8_t* vals, const int64_t* val_off, int64_t flush_events, int64_t max_batch_bytes, int32_t lz4, int64_t abort_every,
+                               int32_t hold_markers) {
+  const int64_t pid = 1000 + p;
+  w->len = 0;
+  const int64_t recs_cap = (max_batch_bytes > 0 ? max_batch_bytes : (1 << 20)) + max_rec + 64;
+  if (w->recs_cap < recs_cap) {
+    free(w->recs); free(w->scratch);
+    w->recs = (uint8_t*)malloc((size_t)recs_cap);
+    w->scratch = (uint8_t*)malloc((size_t)(recs_cap + recs_cap / 255 + 64 + 8 * (recs_cap / 65536 + 1)));
+    w->recs_cap = (w->recs && w->scratch) ? recs_cap : 0;
+    if (!w->recs_cap) return -1;
+  }
+  const int64_t batch_room = 61 + recs_cap + recs_cap / 255 + 64 + 8 * (recs_cap / 65536 + 1);
+  if (w->marker_due >= 0) { /* the marker the last fetch held back */
+    if (grow(w, 128)) return -1;
+    w->len += surge_test_wire_control(w->buf + w->len, w->next_offset++, pid, 0, w->marker_due, 1700000000000ll + 50 * w->flush_no);
+    w->marker_due = -1;
+    w->counts[1] += 1;
+  }
+  const int64_t K = flush_events > 0 ? flush_events : (np > 0 ? np : 1);
+  for (int64_t f0 = 0; f0 < np; f0 += K) {
+    const int64_t fn = np - f0 < K ? np - f0 : K;
+    const int txn = flush_events > 0;
+    const int fails_first = txn && abort_every > 0 && (w->flush_no % abort_every) == abort_every - 1;
+    for (int attempt = fails_first ? 0 : 1; attempt < 2; ++attempt) {
+      const int64_t ts = 1700000000000ll + 50 * (w->flush_no + 1) + attempt;
+      int64_t done = 0;
+      while (done < fn) { /* one data batch */
+        uint8_t* rp = w->recs;
+        int64_t cnt = 0, first_delta = -1, max_delta = 0;
+        while (done + cnt < fn) {
+          const int64_t r = idx[f0 + done + cnt];
+          const int64_t kl = key_off[r + 1] - key_off[r], vl = val_off[r + 1] - val_off[r];
+          if (cnt > 0 && max_batch_bytes > 0 && (rp - w->recs) + kl + vl + 12 > max_batch_bytes) break;
+          const int64_t when = txn ? ((done + cnt) * 50) / fn : 0; /* ms into the flush interval */
+          if (first_delta < 0) first_delta = when;
+          if (when - first_delta > max_delta) max_delta = when - first_delta;
+          rp = put_record(rp, when - first_delta, (int32_t)cnt, keys + key_off[r], kl, vals + val_off[r], vl);
+          ++cnt;
+        }
+        if (grow(w, batch_room)) return -1;
+        const int64_t first_ts = ts - 50 + first_delta;
+        w->len += put_batch(w->buf + w->len, w->next_offset, (int32_t)cnt, w->recs, rp - w->recs, (lz4 ? WIRE_LZ4 : 0) | (txn ? WIRE_TRANSACTIONAL : 0), txn ? pid : -1, 0,
+                            txn ? w->base_seq : -1, first_ts, first_ts + max_delta, w->scratch);
+        w->next_offset += cnt;
+        if (txn) w->base_seq += (int32_t)cnt;
+        done += cnt;
+        w->counts[0] += 1;
+        w->counts[2] += cnt;
+        if (attempt == 0) w->counts[3] += cnt;
+      }
+      if (txn) {
+        const int kind = attempt == 0 ? 0 : 1; /* ABORT, then the retry's COMMIT */
+        const int last = f0 + fn >= np && attempt == 1;
+        if (last && hold_markers > 0 && p % hold_markers == 1) {
+          w->marker_due = (int8_t)kind;
+        } else {
+          if (grow(w, 128)) return -1;
+          w->len += surge_test_wire_control(w->buf + w->len, w->next_offset++, pid, 0, kind, ts);
+          w->counts[1] += 1;
+        }
+        w->counts[4] += 1;
+      }
+    }
+    if (txn) ++w->flush_no;
+  }
+  w->counts[5] += w->len;
   return 0;
 }
 
@@ -294,20 +369,22 @@ static int grow(wire_topic* t, int64_t at, int64_t more) {
  *     fetch (a fetch response ends where the broker's byte budget ends — between a transaction's data and its marker as
  *     likely as anywhere); surge_test_wire_topic_fetch with n = 0 flushes what is held back.
  * Timestamps: flush f of a partition happens at 1.7e12 + 50 f ms, its records spread over the 50 ms before it.
- * counts[8] (added to): data batches, control batches, records written (aborted copies included), aborted records,
- * transactions, bytes, -, -.  Returns 0, or -1 (out of memory). */
+ * counts[8] (SET to the totals so far): data batches, control batches, records written (aborted copies included), aborted
+ * records, transactions, bytes, -, -.  Partitions are written side by side (OpenMP, when compiled with it).
+ * Returns 0, or -1 (out of memory). */
 int32_t surge_test_wire_topic_fetch(wire_topic* t, int64_t n, const int32_t* partition, const uint8_t* keys, const int64_t* key_off, const uint8_t* vals,
                                     const int64_t* val_off, int64_t flush_events, int64_t max_batch_bytes, int32_t lz4, int64_t abort_every, int32_t hold_markers,
                                     int64_t* counts) {
   const int32_t P = t->P;
+  if (!crc_ready) crc_init(); /* (before the threads start) */
   /* stable counting sort of the record numbers by partition */
-  int64_t* start = (int64_t*)calloc((size_t)P + 1, 8);
-  if (!start) return -1;
+  int64_t* start = t->start;
+  memset(start, 0, ((size_t)P + 1) * 8);
   if (t->order_cap < n) {
     free(t->order);
     t->order = (int64_t*)malloc((size_t)(n + 1) * 8);
     t->order_cap = t->order ? n : 0;
-    if (!t->order) { free(start); return -1; }
+    if (!t->order) return -1;
   }
   int64_t max_rec = 64;
   for (int64_t i = 0; i < n; ++i) {
@@ -318,82 +395,22 @@ int32_t surge_test_wire_topic_fetch(wire_topic* t, int64_t n, const int32_t* par
   for (int32_t p = 0; p < P; ++p) start[p + 1] += start[p];
   {
     int64_t* fill = (int64_t*)malloc((size_t)P * 8);
-    if (!fill) { free(start); return -1; }
+    if (!fill) return -1;
     memcpy(fill, start, (size_t)P * 8);
     for (int64_t i = 0; i < n; ++i) t->order[fill[partition[i]]++] = i;
     free(fill);
   }
-  const int64_t recs_cap = (max_batch_bytes > 0 ? max_batch_bytes : (1 << 20)) + max_rec + 64;
-  if (t->recs_cap < recs_cap) {
-    free(t->recs); free(t->scratch);
-    t->recs = (uint8_t*)malloc((size_t)recs_cap);
-    t->scratch = (uint8_t*)malloc((size_t)(recs_cap + recs_cap / 255 + 64 + 8 * (recs_cap / 65536 + 1)));
-    t->recs_cap = (t->recs && t->scratch) ? recs_cap : 0;
-    if (!t->recs_cap) { free(start); return -1; }
-  }
-  const int64_t batch_room = 61 + recs_cap + recs_cap / 255 + 64 + 8 * (recs_cap / 65536 + 1);
-  int64_t at = 0;
+  int32_t bad = 0;
+#pragma omp parallel for schedule(dynamic, 1)
   for (int32_t p = 0; p < P; ++p) {
-    t->part_off[p] = at;
-    const int64_t pid = 1000 + p;
-    if (t->marker_due[p] >= 0) { /* the marker the last fetch held back */
-      if (grow(t, at, 128)) { free(start); return -1; }
-      at += surge_test_wire_control(t->buf + at, t->next_offset[p]++, pid, 0, t->marker_due[p], 1700000000000ll + 50 * t->flush_no[p]);
-      t->marker_due[p] = -1;
-      counts[1] += 1;
-    }
-    const int64_t* idx = t->order + start[p];
-    const int64_t np = start[p + 1] - start[p];
-    const int64_t K = flush_events > 0 ? flush_events : (np > 0 ? np : 1);
-    for (int64_t f0 = 0; f0 < np; f0 += K) {
-      const int64_t fn = np - f0 < K ? np - f0 : K;
-      const int txn = flush_events > 0;
-      const int fails_first = txn && abort_every > 0 && (t->flush_no[p] % abort_every) == abort_every - 1;
-      for (int attempt = fails_first ? 0 : 1; attempt < 2; ++attempt) {
-        const int64_t ts = 1700000000000ll + 50 * (t->flush_no[p] + 1) + attempt;
-        int64_t done = 0;
-        while (done < fn) { /* one data batch */
-          uint8_t* rp = t->recs;
-          int64_t cnt = 0, first_delta = -1, max_delta = 0;
-          while (done + cnt < fn) {
-            const int64_t r = idx[f0 + done + cnt];
-            const int64_t kl = key_off[r + 1] - key_off[r], vl = val_off[r + 1] - val_off[r];
-            if (cnt > 0 && max_batch_bytes > 0 && (rp - t->recs) + kl + vl + 12 > max_batch_bytes) break;
-            const int64_t when = txn ? ((done + cnt) * 50) / fn : 0; /* ms into the flush interval */
-            if (first_delta < 0) first_delta = when;
-            if (when - first_delta > max_delta) max_delta = when - first_delta;
-            rp = put_record(rp, when - first_delta, (int32_t)cnt, keys + key_off[r], kl, vals + val_off[r], vl);
-            ++cnt;
-          }
-          if (grow(t, at, batch_room)) { free(start); return -1; }
-          const int64_t first_ts = ts - 50 + first_delta;
-          at += put_batch(t->buf + at, t->next_offset[p], (int32_t)cnt, t->recs, rp - t->recs, (lz4 ? WIRE_LZ4 : 0) | (txn ? WIRE_TRANSACTIONAL : 0), txn ? pid : -1, 0,
-                          txn ? t->base_seq[p] : -1, first_ts, first_ts + max_delta, t->scratch);
-          t->next_offset[p] += cnt;
-          if (txn) t->base_seq[p] += (int32_t)cnt;
-          done += cnt;
-          counts[0] += 1;
-          counts[2] += cnt;
-          if (attempt == 0) counts[3] += cnt;
-        }
-        if (txn) {
-          const int kind = attempt == 0 ? 0 : 1; /* ABORT, then the retry's COMMIT */
-          const int last = f0 + fn >= np && attempt == 1;
-          if (last && hold_markers > 0 && p % hold_markers == 1) {
-            t->marker_due[p] = (int8_t)kind;
-          } else {
-            if (grow(t, at, 128)) { free(start); return -1; }
-            at += surge_test_wire_control(t->buf + at, t->next_offset[p]++, pid, 0, kind, ts);
-            counts[1] += 1;
-          }
-          counts[4] += 1;
-        }
-      }
-      if (txn) ++t->flush_no[p];
+    if (partition_fetch(&t->part[p], p, t->order + start[p], start[p + 1] - start[p], max_rec, keys, key_off, vals, val_off, flush_events, max_batch_bytes, lz4,
+                        abort_every, hold_markers) != 0) {
+#pragma omp atomic write
+      bad = 1;
     }
   }
-  t->part_off[P] = at;
-  counts[5] += at;
-  free(start);
-  return 0;
+  for (int k = 0; k < 8; ++k) counts[k] = 0;
+  for (int32_t p = 0; p < P; ++p)
+    for (int k = 0; k < 8; ++k) counts[k] += t->part[p].counts[k];
+  return bad ? -1 : 0;
 }
