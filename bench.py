@@ -183,6 +183,15 @@ def main():
     ap.add_argument("--two-thread-consumer", action="store_true", help="e2e: a worker thread enqueues the pushes, this one finishes them with an event-ordered hand-over to the fold and no host wait (default: one thread does both and waits for the device after each half — the device is the bound, the extra thread measured 7 %% slower)")
     ap.add_argument("--serial-framing", action="store_true", help="e2e: frame each fetch, then push it, then fold it, one after the other (default: framing one fetch ahead on its own threads, four pushes in flight)")
     ap.add_argument("--events-cap", type=int, default=8, help="e2e: every aggregate publishes the first min(count, cap) of its events (8: 6.4e7 records over the 10 M aggregates)")
+    ap.add_argument("--writer", default="independent", choices=["independent", "product"],
+                    help="e2e: who writes the topic — the independent test-side producer (tests/native/wire_writer.c: shares no code with the library that "
+                         "reads it; default) or the product's own RecordBatchWriter (plain 16 KiB batches only)")
+    ap.add_argument("--txn-flush-events", type=int, default=512,
+                    help="e2e, independent writer: records per partition per publisher flush — every flush ONE transaction closed by a COMMIT control batch, "
+                         "its data batches closed by the flush or at 16 KiB (KafkaProducerActorImpl.scala:397-453, flush-interval 50 ms: reference.conf:20); "
+                         "0 = no transactions, every batch filled to 16 KiB (rounds 3 / 4's layout)")
+    ap.add_argument("--abort-every", type=int, default=50, help="e2e, transactional topic: every N-th flush of a partition first fails (its records + an ABORT marker) and is retried; 0 = none")
+    ap.add_argument("--hold-markers", type=int, default=4, help="e2e, transactional topic: on partitions p %% N == 1 the last marker of a fetch response arrives with the next one; 0 = never")
     ap.add_argument("--no-capacity-hint", action="store_true", help="e2e: let the resident state and the key table grow as aggregates appear instead of sizing them up front")
     ap.add_argument("--framing-threads", type=int, default=8, help="e2e: host threads framing a fetch's partitions side by side")
     ap.add_argument("--aggregates", type=int, default=None, help="global aggregate count (default 10 M for c4, 1 M for c2)")
@@ -496,11 +505,81 @@ def main():
             result["v2"] = {k: v2[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "roofline", "one_shot", "cpu_baseline")}
         except Exception as exc:  # pragma: no cover
             result["v2"] = {"skipped": repr(exc)}
+        # the kernel BASELINE config C4 runs on every GPU: rank 0's shard of the 8-GPU split (its partitions' aggregates), AUTO, 100 folds
+        try:
+            torch.cuda.empty_cache()
+            result["c4_shard"] = run_c4_shard(args, S, synth, ReplayEngine, torch, dev, local_rank)
+        except Exception as exc:  # pragma: no cover
+            result["c4_shard"] = {"skipped": repr(exc)}
+        # topic BYTES -> states (what a recovery really runs: SurgeStateStoreConsumer.scala:57-76), bounded to 3e7 records of the C3 population, on a
+        # topic shaped like the reference's publisher writes it (one transaction + COMMIT marker per flush per partition) by the independent writer;
+        # beside it the same path on the two neighbouring layouts (small flushes / no transactions and full 16 KiB batches), 1.2e7 records each
+        try:
+            torch.cuda.empty_cache()
+            keep = ("value", "unit", "steps", "warmup", "ms_per_step", "data", "config", "roofline", "cpu_baseline")
+            base = {**vars(args), "workload": "e2e", "warmup": 2, "batch_events": 1_000_000, "aggregates": None, "events_cap": 8, "writer": "independent",
+                    "codec": "lz4", "serial_framing": False, "two_thread_consumer": False, "no_capacity_hint": False, "framing_threads": 8,
+                    "abort_every": 50, "hold_markers": 4}
+            e2e = run_e2e(_ap.Namespace(**{**base, "steps": 28, "txn_flush_events": 512}))
+            result["e2e"] = {k: e2e[k] for k in keep}
+            layouts = {"flush_512": {"value": e2e["value"], "control_batches": e2e["config"]["control_batches"], "parity": e2e["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_source_events"]}}
+            for name, kf in (("flush_64", 64), ("full_16KiB_no_transactions", 0)):
+                torch.cuda.empty_cache()
+                o = run_e2e(_ap.Namespace(**{**base, "steps": 10, "txn_flush_events": kf}))
+                layouts[name] = {"value": o["value"], "control_batches": o["config"]["control_batches"], "data_batches": o["config"]["topic"]["data_batches"],
+                                 "events_timed": o["config"]["events_timed"], "parity": o["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_source_events"]}
+            result["e2e"]["layouts_events_per_s"] = layouts
+        except Exception as exc:  # pragma: no cover
+            result["e2e"] = {"skipped": repr(exc)}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def run_c4_shard(args, S, synth, ReplayEngine, torch, dev, local_rank, world=8, rank=0, steps=100):
+    """What ONE GPU of BASELINE config C4 folds — rank ``rank``'s shard of the 10 M-aggregate Zipf log split over ``world``
+    GPUs by partitionForKey(id, 64) % world (KafkaPartitioner.scala:8, PartitionAssignments.scala:51-63): ~1.25 M aggregates,
+    ~5.8e8 events — on this GPU, through AUTO, exactly as ``--gpus 8`` generates and folds it (no exchange: the driver has no
+    8-GPU node; this times the kernel that configuration runs).  Every aggregate is checked against the CPU restatement."""
+    import numpy as np
+
+    from oracle import oracle
+    from surge_amd.dist import local_aggregate_ids
+
+    with ReplayEngine(device=local_rank) as e2:
+        agg_ids = local_aggregate_ids(N_AGGREGATES, N_PARTITIONS, rank, world, dev, e2)
+        lens = synth.zipf_lengths(agg_ids, ZIPF_SEED)
+        so, ev = synth.csr_log_device(lens, ZIPF_SEED, agg_ids=agg_ids, global_seg_off=_LazyGlobalOffsets())
+        n_local, n_ev = int(agg_ids.numel()), int(so[-1].item())
+        out = torch.zeros((n_local, 64), dtype=torch.uint8, device=dev)
+        e2.load_csr(so, ev, None, out)
+        torch.cuda.synchronize(dev)
+        t_p = time.perf_counter()
+        e2.fold(S.ALGO_AUTO)
+        e2.synchronize()
+        first_wall = (time.perf_counter() - t_p) * 1e3
+        layout = e2.layout_info()
+        dt, st, times_ms = time_folds(e2, torch, dev, S.ALGO_AUTO, steps, 5)
+        t_or = time.perf_counter()
+        exp = oracle.fold_csr(so.cpu().numpy(), synth.to_event_records(ev), threads=int(effective_cpus()[0]))
+        got = out.cpu().numpy().view(S.STATE_DTYPE).reshape(-1)
+        parity = bool(got.tobytes() == exp.tobytes())
+        oracle_s = time.perf_counter() - t_or
+        roof = roofline_of(S, st, times_ms)
+        return {
+            "config": {"workload": f"C4, one GPU's share: rank {rank} of {world} — {n_local} aggregates ({n_ev} events) of the 10 M-aggregate Zipf(1..4096) log, "
+                                   f"partitions p % {world} == {rank}; log resident in HBM; no exchange",
+                       "algo": algo_name(S, st.last_algo), "wave_tasks": st.n_tasks, "aggregates": n_local, "events": n_ev},
+            "metric": "events/sec replayed", "value": n_ev * steps / dt, "unit": "events/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "eight_gpu_projection_events_per_s": 8 * n_ev * steps / dt,
+            "projection_note": "8 x this rate = what eight such GPUs fold per second when the snapshot exchange hides behind the next fold (bench.py --gpus 8 "
+                               "measures that; no 8-GPU node was available to the builder) — a projection, not a measurement",
+            "roofline": roof,
+            "one_shot": {"index_build_ms": layout.index_build_ms, "first_fold_wall_ms_incl_index": first_wall},
+            "cpu_baseline": {"gpu_matches_cpu_full_shard": parity, "aggregates_checked": n_local, "events_checked": n_ev, "seconds": oracle_s, "kind": "port"},
+        }
 
 
 def run_secondary_c2(args, S, synth, ReplayEngine, torch, dev, local_rank):
@@ -909,7 +988,10 @@ def run_e2e(args):
     wire_bytes = 0
     incl = np.zeros(my_ids.shape[0], np.int64)  # events of each aggregate that made it into the topic
     sample_checked = False
-    with RecordBatchWriter(P, 0, 16384, args.codec) as writer:
+    independent = args.writer == "independent"
+    K_flush = args.txn_flush_events if independent else 0
+    with (topic_gen.WireTopic(P, K_flush, 16384, args.codec, args.abort_every if K_flush else 0, args.hold_markers if K_flush else 0) if independent
+          else RecordBatchWriter(P, 0, 16384, args.codec)) as writer:
         pend_a, pend_j, pend_p, pend_n = [], [], [], 0
 
         def flush(final=False):
@@ -928,7 +1010,7 @@ def run_e2e(args):
                         m = fmt.write_event(e)
                         assert bytes(k[ko[i]:ko[i + 1]]) == m.key.encode() and bytes(v[vo[i]:vo[i + 1]]) == m.value
                     sample_checked = True
-                parts = topic_gen.frame_partitions(writer, p, k, ko, v, vo)
+                parts = writer.fetch(p, k, ko, v, vo) if independent else topic_gen.frame_partitions(writer, p, k, ko, v, vo)
                 wire_bytes += sum(len(x) for x in parts if x)
                 fetches.append((parts, take))
 
@@ -945,6 +1027,13 @@ def run_e2e(args):
             pend_a.append(my_ids[sel]); pend_j.append(np.full(sel.shape[0], j, np.int32)); pend_p.append(my_part[sel]); pend_n += sel.shape[0]
             flush()
         flush(final=True)
+        if independent and K_flush and args.hold_markers:
+            # the markers the last fetch response held back: a response of control batches only (the transactions they close become visible with it)
+            parts = writer.fetch(np.zeros(0, np.int32), None, None, None, None)
+            if any(parts):
+                wire_bytes += sum(len(x) for x in parts if x)
+                fetches.append((parts, 0))
+        topic_counts = writer.counts if independent else None
     gen_s = time.perf_counter() - t_gen
     K = len(fetches) - W
     if K < 1:
@@ -1115,13 +1204,16 @@ def run_e2e(args):
     # the library's host decoder on a bounded sample of the same fetches (one thread), for scale
     t0 = time.perf_counter()
     sample_records = 0
-    with EventsTopicIngest() as gh:
-        for parts, n in fetches[W:W + 2]:
-            for data in parts:
+    handles = [EventsTopicIngest() for _ in range(P)]  # (one handle per partition: read_committed state is a partition's)
+    try:
+        for parts, _ in fetches[W:W + 2]:
+            for q, data in enumerate(parts):
                 if data:
-                    gh.feed(data)
-                    gh.drain_json(tmpl)
-            sample_records += n
+                    handles[q].feed(data)
+                    sample_records += int(handles[q].drain_json(tmpl)[0].shape[0])
+    finally:
+        for gh in handles:
+            gh.close()
     host_decoder_s = time.perf_counter() - t0
     lat = [(marks[i] - marks[i - 1]) * 1e3 for i in range(max(W, 1), len(marks))]
     disc = [i for i in range(max(W, 1), len(marks)) if keys_at[i] > keys_at[i - 1] + fetches[i][1] // 2]  # fetches that mostly discover keys
@@ -1130,13 +1222,19 @@ def run_e2e(args):
     out = {
         "metric": "events/sec replayed", "value": total_events / elapsed_s, "unit": "events/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed_s / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bytes -> int32 events -> int32/int64 adds", "data": "synthetic (Counter fixture events as play-json text in Kafka record batches v2, written by the product's record-batch writer)",
+        "dtype": "bytes -> int32 events -> int32/int64 adds", "data": "synthetic (Counter fixture events as play-json text in Kafka record batches v2, written by "
+                                                                   + ("the independent test-side producer tests/native/wire_writer.c — no code shared with the library that reads them)" if independent
+                                                                      else "the product's record-batch writer)"),
         "config": {"workload": f"E2E: events-topic bytes -> states on the C3 / C4 population: {A} aggregates (acct-%08d, Zipf(1..4096) counts, seed {ZIPF_SEED}), the first "
                                f"<= {cap} events of each, published in rounds (a fetch touches as many different aggregates as it has records), {P} partitions by "
-                               f"partitionForKey, {args.codec} batches closed at 16 KiB; fetches of {n_fetch} records per rank; host framing (headers, CRC-32C, "
+                               f"partitionForKey, {args.codec} batches, " + (f"one transaction per publisher flush of {K_flush} records per partition (data batches closed by the flush or at 16 KiB, "
+                               f"then a COMMIT control batch; every {args.abort_every}th flush aborted and retried; on partitions p % {args.hold_markers} == 1 a response's last marker "
+                               f"arrives a fetch late)" if K_flush else "not transactional, every batch filled to 16 KiB") + f"; fetches of {n_fetch} records per rank; host framing (headers, CRC-32C, "
                                f"transactions) per partition on {args.framing_threads} threads one fetch ahead; one device push per fetch, {depth} in flight: LZ4 / records / "
                                f"JSON decode / key interning / group-by / fold on the GPU" + (" [REHEARSAL: every rank on cuda:0, throughput meaningless]" if rehearsal else ""),
                    "parallelism": f"partitions p % {world} == rank; no data-path collective; final snapshot all-gathered through the C ABI" if world > 1 else "one GPU",
+                   "writer": args.writer, "txn_flush_events": K_flush, "topic": topic_counts,
+                   "control_batches": None if topic_counts is None else topic_counts["control_batches"],
                    "aggregates": A, "events_cap": cap, "partitions": P, "fetch_records": n_fetch, "fetches": len(fetches), "pushes_in_flight": depth,
                    "consumer": "one thread, a host wait behind interning and behind the fold" if one_thread else "push worker thread + finisher, event-ordered hand-over to the fold (no host wait behind either)",
                    "framing_threads": args.framing_threads, "capacity_hint": not args.no_capacity_hint, "events_timed": total_events, "per_rank_events": per_rank, "keys_interned": total_keys,

@@ -734,3 +734,24 @@ def test_push_pipeline_runs_pushes_on_its_worker_at_most_depth_ahead_and_in_orde
                 got += 1
                 pipe.done()
     assert got == 2
+
+
+def test_kafka_clients_pin_of_the_wire_format():
+    """Record batches written by kafka-clients itself (tools/WirePin.java) read by the product's host decoder: the same
+    records, in order, committed transactions only, the flush record skipped.  Skipped — and the record-batch reader
+    stays "parity unpinned" against kafka-clients — until a JDK has produced tests/golden/wire_pin.tsv (none in the image)."""
+    import os
+
+    pin = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wire_pin.tsv")
+    if not os.path.exists(pin):
+        pytest.skip("no tests/golden/wire_pin.tsv yet (javac + kafka-clients needed: tools/WirePin.java): kafka-clients' own bytes have never met this reader")
+    for line in open(pin).read().splitlines():
+        name, wire_hex, recs = line.split("\t")
+        want = []
+        for r in recs.split(",") if recs else []:
+            k, v = r.split(":")
+            want.append((None if k == "-" else bytes.fromhex(k), None if v == "-" else bytes.fromhex(v)))
+        with EventsTopicIngest() as g:
+            g.feed(bytes.fromhex(wire_hex))
+            got = [(k, v) for _, _, k, v in g.drain_records() if not (k == b"" and v == b"")]
+        assert got == want, name
