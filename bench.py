@@ -167,7 +167,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c4", choices=["c4", "c3", "c2", "c2-weak", "c5", "v2", "e2e"],
+    ap.add_argument("--workload", default="c4", choices=["c4", "c3", "c2", "c2-weak", "c5", "v2", "e2e", "c4-shard"],
                     help="c4 / c3 (default): the 10 M-aggregate Zipf log, strong-scaled over the GPUs; c2: 1 M x 256 fixed fan-in "
                          "(strong-scaled); c2-weak: 1 M x 256 PER GPU (round 1's run); c5: streaming micro-batches onto a resident "
                          "state store with periodic state-topic snapshots (one GPU; a step = one micro-batch, default 600 steps); "
@@ -213,6 +213,17 @@ def main():
         return
     if args.workload == "v2":
         print(json.dumps(run_v2(args)))
+        return
+    if args.workload == "c4-shard":  # one GPU's share of config C4 (rank 0 of 8) on this GPU: the default line's c4_shard leg alone
+        import torch
+
+        from surge_amd import schema as S
+        from surge_amd import synth
+        from surge_amd.replay import ReplayEngine
+
+        world, rank, local_rank, dev, ctl, dist, rehearsal = init_ranks(args, torch)
+        print(json.dumps(run_c4_shard(args, S, synth, ReplayEngine, torch, dev, local_rank, steps=args.steps if args.steps != 20 else 100,
+                                      algo=parse_algo(args.algo), check=not args.no_cpu_baseline)))
         return
     if args.workload == "e2e":
         line = run_e2e(args)
@@ -538,7 +549,7 @@ def main():
         print(json.dumps(result))
 
 
-def run_c4_shard(args, S, synth, ReplayEngine, torch, dev, local_rank, world=8, rank=0, steps=100):
+def run_c4_shard(args, S, synth, ReplayEngine, torch, dev, local_rank, world=8, rank=0, steps=100, algo=None, check=True):
     """What ONE GPU of BASELINE config C4 folds — rank ``rank``'s shard of the 10 M-aggregate Zipf log split over ``world``
     GPUs by partitionForKey(id, 64) % world (KafkaPartitioner.scala:8, PartitionAssignments.scala:51-63): ~1.25 M aggregates,
     ~5.8e8 events — on this GPU, through AUTO, exactly as ``--gpus 8`` generates and folds it (no exchange: the driver has no
@@ -557,15 +568,18 @@ def run_c4_shard(args, S, synth, ReplayEngine, torch, dev, local_rank, world=8, 
         e2.load_csr(so, ev, None, out)
         torch.cuda.synchronize(dev)
         t_p = time.perf_counter()
-        e2.fold(S.ALGO_AUTO)
+        algo = S.ALGO_AUTO if algo is None else algo
+        e2.fold(algo)
         e2.synchronize()
         first_wall = (time.perf_counter() - t_p) * 1e3
         layout = e2.layout_info()
-        dt, st, times_ms = time_folds(e2, torch, dev, S.ALGO_AUTO, steps, 5)
+        dt, st, times_ms = time_folds(e2, torch, dev, algo, steps, 5)
         t_or = time.perf_counter()
-        exp = oracle.fold_csr(so.cpu().numpy(), synth.to_event_records(ev), threads=int(effective_cpus()[0]))
-        got = out.cpu().numpy().view(S.STATE_DTYPE).reshape(-1)
-        parity = bool(got.tobytes() == exp.tobytes())
+        parity = None
+        if check:
+            exp = oracle.fold_csr(so.cpu().numpy(), synth.to_event_records(ev), threads=int(effective_cpus()[0]))
+            got = out.cpu().numpy().view(S.STATE_DTYPE).reshape(-1)
+            parity = bool(got.tobytes() == exp.tobytes())
         oracle_s = time.perf_counter() - t_or
         roof = roofline_of(S, st, times_ms)
         return {

@@ -33,6 +33,9 @@ struct DevBuf {
     if (e == hipSuccess) cap = bytes ? bytes : 16;
     return e;
   }
+  // for the buffers of a stream of micro-batches: the next batch is a few per cent larger or smaller than this one, and a
+  // buffer that grows is freed — hipFree waits for the whole device (3 - 6 ms spikes per fetch on the bytes -> states path)
+  hipError_t reserve_roomy(size_t bytes) { return bytes <= cap ? hipSuccess : reserve(bytes + bytes / 4 + 4096); }
   void release() {
     if (ptr) (void)hipFree(ptr);
     ptr = nullptr;
@@ -1252,9 +1255,9 @@ int32_t surge_replay_append_fold(surge_replay_handle* h, const int64_t* group_ag
     return fail(h, SURGE_E_NOMEM, "out of host memory while validating the micro-batch");
   }
   DeviceGuard g(h->device);
-  HIPCHK(h, h->batch_group_agg.reserve((size_t)n_groups * 8));
-  HIPCHK(h, h->batch_group_off.reserve((size_t)(n_groups + 1) * 8));
-  HIPCHK(h, h->batch_events.reserve((size_t)n_events * 16));
+  HIPCHK(h, h->batch_group_agg.reserve_roomy((size_t)n_groups * 8));
+  HIPCHK(h, h->batch_group_off.reserve_roomy((size_t)(n_groups + 1) * 8));
+  HIPCHK(h, h->batch_events.reserve_roomy((size_t)n_events * 16));
   HIPCHK(h, hipEventRecord(h->ev_h0, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->batch_group_agg.ptr, group_agg, (size_t)n_groups * 8, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->batch_group_off.ptr, group_off, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, h->stream));
@@ -1280,12 +1283,12 @@ int32_t surge_replay_append_events_device(surge_replay_handle* h, const int64_t*
   while (bits < 32 && (h->n_agg >> bits) != 0) ++bits;
   size_t temp = 0;
   HIPCHK(h, groupby_temp_bytes(n, bits, &temp));
-  HIPCHK(h, h->gb_temp.reserve(temp));
-  HIPCHK(h, h->gb_u32.reserve((size_t)n * 4 * 6));
+  HIPCHK(h, h->gb_temp.reserve_roomy(temp));
+  HIPCHK(h, h->gb_u32.reserve_roomy((size_t)n * 4 * 6));
   HIPCHK(h, h->gb_flags.reserve(16));
-  HIPCHK(h, h->batch_group_agg.reserve((size_t)n * 8));
-  HIPCHK(h, h->batch_group_off.reserve((size_t)(n + 1) * 8));
-  HIPCHK(h, h->batch_events.reserve((size_t)n * 16));
+  HIPCHK(h, h->batch_group_agg.reserve_roomy((size_t)n * 8));
+  HIPCHK(h, h->batch_group_off.reserve_roomy((size_t)(n + 1) * 8));
+  HIPCHK(h, h->batch_events.reserve_roomy((size_t)n * 16));
   uint32_t* u = (uint32_t*)h->gb_u32.ptr;
   if (!h->host_flags) {
     HIPCHK(h, hipHostMalloc((void**)&h->host_flags, 16, hipHostMallocDefault));
@@ -1319,7 +1322,7 @@ int32_t surge_replay_append_events_device(surge_replay_handle* h, const int64_t*
     const int le = env_lane_events("SURGE_REPLAY_LE_FLAT", 16);
     const int64_t task_events = choose_task_events(n_events, le);
     const int64_t n_tasks = (n_events + task_events - 1) / task_events;
-    HIPCHK(h, h->plan.reserve((size_t)(n_tasks + 1) * 8));
+    HIPCHK(h, h->plan.reserve_roomy((size_t)(n_tasks + 1) * 8));
     HIPCHK(h, launch_plan_dev((const int64_t*)h->batch_group_off.ptr, (const uint32_t*)h->gb_flags.ptr, task_events, n_tasks,
                               (int64_t*)h->plan.ptr, h->stream));
     p.seg_off = (const int64_t*)h->batch_group_off.ptr;
@@ -1376,8 +1379,8 @@ int32_t surge_replay_append_events(surge_replay_handle* h, const int64_t* agg_id
   // the device-side landing buffers are reused by every batch: stream order keeps a batch's copies behind the previous
   // batch's kernels; growing them must wait for those kernels
   if ((size_t)n_events * 8 > h->gb_agg_idx.cap || (size_t)n_events * 16 > h->gb_events.cap) HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, h->gb_agg_idx.reserve((size_t)n_events * 8));
-  HIPCHK(h, h->gb_events.reserve((size_t)n_events * 16));
+  HIPCHK(h, h->gb_agg_idx.reserve_roomy((size_t)n_events * 8));
+  HIPCHK(h, h->gb_events.reserve_roomy((size_t)n_events * 16));
   std::memcpy(h->pinned[k], agg_idx, (size_t)n_events * 8);
   std::memcpy((char*)h->pinned[k] + (size_t)n_events * 8, events, (size_t)n_events * 16);
   HIPCHK(h, hipEventRecord(h->ev_h0, h->stream));

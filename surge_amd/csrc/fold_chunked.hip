@@ -115,19 +115,31 @@ fold_chunked_kernel(const FoldParams p, const ChunkTable t) {
     lds_rs[lane] = m.start;
     lds_len[lane] = m.len;
   };
+  // The address of a load is events + 16 * (chunk start + tile offset + the lane's event of the instruction's class): the
+  // per-lane part is kept as kClasses 64-bit bases the compiler cannot take apart (three inlined copies of this lambda each
+  // hoisted their own variants of it out of the loops — 42 VGPRs of loop invariants, ten of them spilled to scratch).
+  uint64_t ebase[G::kClasses];
+#pragma unroll
+  for (int k = 0; k < G::kClasses; ++k) {
+    ebase[k] = (uint64_t)p.events + 16ull * G::load_j(lane, k);
+    asm volatile("" : "+v"(ebase[k]));
+  }
   auto issue = [&](int c, uint32_t minlen) {
     if ((uint32_t)(c + 1) * LE <= minlen) {
+      const uint64_t coff = (uint64_t)(uint32_t)c * (uint32_t)(LE * 16);
 #pragma unroll
       for (int q = 0; q < G::kLoads; ++q) {
-        const int64_t e = lds_rs[G::kRowsPerLoad * q + lane / LE] + (int64_t)c * LE + G::load_j(lane, q % G::kClasses);
-        __builtin_amdgcn_global_load_lds((gptr_t)(p.events + e), (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
+        const uint64_t a = ebase[q % G::kClasses] + coff + ((uint64_t)lds_rs[G::kRowsPerLoad * q + lane / LE] << 4);
+        __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
       }
     } else {  // some chunk ends inside this tile: never read past a chunk's own events
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));  // (this path is rare: its per-lane constants are computed here, not kept in registers)
 #pragma unroll
       for (int q = 0; q < G::kLoads; ++q) {
-        const int r = G::kRowsPerLoad * q + lane / LE;
+        const int r = G::kRowsPerLoad * q + lane_o / LE;
         const uint32_t rlen = lds_len[r];
-        uint32_t j = (uint32_t)c * LE + G::load_j(lane, q % G::kClasses);
+        uint32_t j = (uint32_t)c * LE + G::load_j(lane_o, q % G::kClasses);
         const uint32_t lastj = rlen ? rlen - 1u : 0u;
         j = j < lastj ? j : lastj;
         __builtin_amdgcn_global_load_lds((gptr_t)(p.events + (lds_rs[r] + j)), (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);

@@ -1200,7 +1200,10 @@ struct Buf {
   size_t cap = 0;
   hipError_t reserve(size_t bytes, bool keep, hipStream_t stream) {
     if (bytes <= cap) return hipSuccess;
-    size_t want = cap * 2 > bytes ? cap * 2 : bytes;
+    // room to spare: a fetch is a few per cent larger or smaller than the one before it, and a buffer that grows is freed —
+    // hipFree waits for the whole device (1 - 3 ms with four pushes in flight: the spikes of round 4's per-fetch times)
+    const size_t roomy = bytes + bytes / 4 + 4096;
+    size_t want = cap * 2 > roomy ? cap * 2 : roomy;
     void* fresh = nullptr;
     hipError_t e = hipMalloc(&fresh, want);
     if (e != hipSuccess) return e;
@@ -1274,6 +1277,7 @@ struct surge_device_decoder {
   bool consumed_valid = false;
   int64_t counters[4] = {0, 0, 0, 0};  // records seen, delivered, flush records skipped, f64 values re-parsed on the host
   int64_t reseeds = 0, pushes = 0;
+  bool slots_sized = false;  // the first wire push has sized every slot's buffers like its own
 };
 
 namespace {
@@ -1514,6 +1518,7 @@ int32_t slot_pinned(surge_device_decoder* d, PushSlot& s, size_t bytes) {
   if (s.pinned) (void)hipHostFree(s.pinned);
   s.pinned = nullptr;
   s.pinned_cap = 0;
+  bytes += bytes / 4 + 65536;  // (room to spare: the next fetch's tables are a few per cent larger or smaller)
   DCHK(d, hipHostMalloc(&s.pinned, bytes, hipHostMallocDefault));
   s.pinned_cap = bytes;
   return OK;
@@ -1668,10 +1673,37 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
   for (Section& sc : secs)
     if (sc.byte_off < 0) sc.byte_off = area_base + (-1 - sc.byte_off);
   hipStream_t st = s.stream;
-  DCHK(d, s.d_bytes.reserve((size_t)(area_base + area) + 64, false, st));
-  DCHK(d, s.d_sections.reserve(sizeof(Section) * (size_t)total_sections, false, st));
+  const size_t sec_bytes = sizeof(Section) * (size_t)total_sections, blk_bytes = sizeof(Lz4Block) * blocks.size();
+  // The device buffers of this push.  The FIRST wire push of a decoder sizes every slot like its own: the fetches of a
+  // recovery are alike, and a slot that sizes its buffers when its turn comes does so in the middle of the pipeline (an
+  // allocation per buffer, and a hipFree — a device-wide wait — for every one that grows).
+  auto size_slot = [&](PushSlot& t) -> int32_t {
+    DCHK(d, t.d_bytes.reserve((size_t)(area_base + area) + 64, false, t.stream));
+    DCHK(d, t.d_sections.reserve(sec_bytes, false, t.stream));
+    DCHK(d, t.meta.reserve((size_t)n_rec * sizeof(RecMeta), false, t.stream));
+    DCHK(d, t.ev_tmp.reserve((size_t)n_rec * 16, false, t.stream));
+    DCHK(d, t.f64_list.reserve((size_t)n_rec * 4, false, t.stream));
+    if (!blocks.empty()) {
+      const size_t nb = blocks.size();
+      DCHK(d, t.lz4_blocks.reserve(blk_bytes, false, t.stream));
+      DCHK(d, t.lz4_sizes.reserve(nb * 4, false, t.stream));
+      if (!force_one_pass) {
+        DCHK(d, t.lz4_nseq.reserve(nb * 4, false, t.stream));
+        DCHK(d, t.lz4_seq.reserve((size_t)(n_seq_entries + 1) * 8, false, t.stream));
+        DCHK(d, t.lz4_cls.reserve((size_t)(kLz4Classes + 1) * (nb + 1) * 4, false, t.stream));
+      }
+    }
+    return OK;
+  };
+  if (!d->slots_sized) {
+    d->slots_sized = true;
+    for (PushSlot& t : d->slots)
+      if (&t != &s && !t.busy) (void)size_slot(t);  // (best effort: a slot that could not be sized now reports it when its turn comes)
+    (void)hipGetLastError();
+  }
   {
-    const int32_t rc = slot_scratch(d, s, n_rec);
+    int32_t rc = size_slot(s);
+    if (rc == OK) rc = slot_scratch(d, s, n_rec);
     if (rc != OK) return rc;
   }
   // H2D: a part goes straight out of the caller's arena when that is page-locked (surge_ingest_use_pinned_arena), else
@@ -1679,7 +1711,6 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
   lap("reserve");
   // the section and block tables travel through page-locked staging too: a copy from pageable memory waits for the stream
   // (1.4 ms of host time per push went there)
-  const size_t sec_bytes = sizeof(Section) * (size_t)total_sections, blk_bytes = sizeof(Lz4Block) * blocks.size();
   size_t need_stage = ((extra.size() + 15) & ~(size_t)15) + sec_bytes + blk_bytes + 64;
   std::vector<char> in_place((size_t)n_parts, 0);
   for (int32_t p = 0; p < n_parts; ++p) {
@@ -1690,8 +1721,12 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
     if (!in_place[(size_t)p]) need_stage += ((size_t)part_len[(size_t)p] + 15) & ~(size_t)15;
   }
   {
+    const bool first_staging = s.pinned_cap == 0;
     const int32_t rc = slot_pinned(d, s, need_stage);
     if (rc != OK) return rc;
+    if (first_staging)  // (page-locking memory takes milliseconds: every slot's staging while the pipeline is still empty)
+      for (PushSlot& t : d->slots)
+        if (&t != &s && !t.busy && t.pinned_cap == 0) (void)slot_pinned(d, t, need_stage);
   }
   size_t staged = 0;
   auto stage = [&](const void* src, size_t len) -> const uint8_t* {

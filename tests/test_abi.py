@@ -334,11 +334,12 @@ def test_a_v1_schema_compiles_its_flat_kernel_for_gfx950_without_a_gpu_and_a_nar
     assert lib.surge_replay_compile_schema(ctypes.byref(bad), b"gfx950", None, 0, ctypes.byref(n)) != 0
 
 
-def test_no_kernel_of_the_library_spills_to_scratch_except_the_one_that_is_known_to(tmp_path):
+def test_no_kernel_of_the_library_spills_to_scratch(tmp_path):
     """The code objects inside libsurge_replay.so (llvm-objdump --offloading), kernel by kernel from their metadata notes: a
     kernel of this library that starts to spill registers to scratch memory loses its place on the roofline silently — this
-    fails loudly instead.  Known and tolerated: fold_chunked_kernel<16> (256 VGPRs, 10 of them spilled, 44 bytes per lane —
-    DESIGN.md section 6d).  rocPRIM's kernels are the library's own business."""
+    fails loudly instead.  (Until round 5 fold_chunked_kernel<16> was the tolerated exception: 256 VGPRs, 10 of them spilled —
+    loop-invariant load addresses the compiler hoisted three times over; kept as kClasses opaque bases it needs 204 and no
+    scratch.)  rocPRIM's kernels are the library's own business."""
     import shutil
     import subprocess
 
@@ -366,4 +367,6 @@ def test_no_kernel_of_the_library_spills_to_scratch_except_the_one_that_is_known
     for hot in ("fold_sorted_kernelILi16", "fold_rows_kernelILi8", "fold_tiled_kernelILi2", "fold_kernelILi1ELi16", "section_kernel", "lz4_exec_kernelILb1"):
         assert any(hot in k for k in ours), hot
     spilling = {k: v for k, v in ours.items() if v["private_segment_fixed_size"] or v.get("vgpr_spill_count", 0)}
-    assert all("fold_chunked_kernelILi16" in k and v["private_segment_fixed_size"] <= 64 for k, v in spilling.items()), spilling
+    assert not spilling, spilling
+    chunked = [v for k, v in ours.items() if "fold_chunked_kernelILi16" in k]
+    assert chunked and chunked[0]["vgpr_count"] <= 256, chunked
