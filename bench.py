@@ -53,7 +53,7 @@ ALGO_NAMES = {"auto": 0, "fixed": 1, "flat": 2, "rows": 3, "sorted": 4, "chunked
 
 def kernel_name(S, algo):
     return {S.ALGO_FIXED: "fold_kernel<FIXED,16>", S.ALGO_FLAT: "fold_kernel<FLAT,16>", S.ALGO_ROWS: "fold_rows_kernel<8>",
-            S.ALGO_SORTED: "fold_sorted_kernel<16>", S.ALGO_CHUNKED: "fold_chunked_kernel<16> + chunk_stitch_kernel",
+            S.ALGO_SORTED: "fold_sorted_kernel<16>" if os.environ.get("SURGE_REPLAY_SORTED_KERNEL") == "plain" else "fold_sorted_pf_kernel<16>", S.ALGO_CHUNKED: "fold_chunked_kernel<16> + chunk_stitch_kernel",
             S.ALGO_TILED: "fold_tiled_kernel<2> + chunk_stitch_kernel"}.get(algo, str(algo))
 
 

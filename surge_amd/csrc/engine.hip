@@ -1125,7 +1125,11 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       const int32_t rc = next_fold_events(h, &e0, &e1);
       if (rc != SURGE_OK) return rc;
       HIPCHK(h, hipEventRecord(e0, h->stream));
-      HIPCHK(h, launch_fold_sorted(p, n_waves, le, h->stream));
+      // round 5: the walk that fetches the next group's first tile during this group's last one (fold_sorted_pf_kernel);
+      // SURGE_REPLAY_SORTED_KERNEL=plain keeps fold_sorted_kernel for a same-box comparison, and 32-event lanes are its only
+      static const bool plain = [] { const char* v = std::getenv("SURGE_REPLAY_SORTED_KERNEL"); return v && std::strcmp(v, "plain") == 0; }();
+      if (plain || le == 32) HIPCHK(h, launch_fold_sorted(p, n_waves, le, h->stream));
+      else HIPCHK(h, launch_fold_sorted_pf(p, n_waves, le, h->stream));
       HIPCHK(h, hipEventRecord(e1, h->stream));
       h->st.n_tasks = (int32_t)n_waves;
     } else if (use == SURGE_ALGO_CHUNKED) {

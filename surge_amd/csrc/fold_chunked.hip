@@ -67,10 +67,13 @@ __global__ void chunk_stitch_kernel(const FoldParams p, const uint32_t* __restri
   store_state(p.out, oi, x);
 }
 
-// Register budget = resident waves: 2 per SIMD (<= 256 VGPRs) with 16 KiB tiles, 3 per SIMD (<= 168) with 8 KiB tiles.
-template <int LE>
-__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(LE == 8 ? 3 : 2)))
-fold_chunked_kernel(const FoldParams p, const ChunkTable t) {
+// The walk of both kernels of this file.  PERM = false: the virtual rows of the chunk table (fold_chunked_kernel).
+// PERM = true: whole aggregates in length order straight from the CSR arrays — row i is aggregate perm[i] (p.plan), its
+// start and length come from seg_off like in fold_sorted_kernel (fold_kernels.hip); nothing is relative, nothing goes to the
+// side buffer, and the deciding-event loop compiles away.  What it has over fold_sorted_kernel is this file's pipeline: the
+// next group's first tile is fetched during the current group's last tile (no wait for a cold tile at every group switch).
+template <int LE, bool PERM>
+__device__ __forceinline__ void chunk_walk(const FoldParams& p, const ChunkTable& t) {
   using G = Geo<LE>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_ev = smem;
@@ -80,7 +83,8 @@ fold_chunked_kernel(const FoldParams p, const ChunkTable t) {
   const int lane = threadIdx.x;
   load_table<LE>(p, lds_tab, lane);
   const uint32_t ev_row = G::ev_row(lane);
-  const int64_t n_groups = (t.n_vrows + kWave - 1) / kWave;
+  const int64_t n_rows = PERM ? p.n_seg : t.n_vrows;
+  const int64_t n_groups = (n_rows + kWave - 1) / kWave;
 
   auto grab = [&]() -> int64_t {
     unsigned long long g = 0;
@@ -91,8 +95,20 @@ fold_chunked_kernel(const FoldParams p, const ChunkTable t) {
   auto load_meta = [&](int64_t g) -> Meta {
     Meta m; m.dest = -1; m.start = 0; m.len = 0u; m.info = 0u;
     const int64_t idx = g * kWave + lane;
-    if (g < n_groups && idx < t.n_vrows) {
-      m.dest = t.v_dest[idx]; m.start = t.v_start[idx]; m.len = t.v_len[idx]; m.info = t.v_info[idx];
+    if (g < n_groups && idx < n_rows) {
+      if constexpr (PERM) {
+        // a row is tiled from the 128-byte line that holds its first event: the events in front of it (its predecessor's) are
+        // walked as null events (fold_sorted_kernel's rule)
+        const int64_t sg = p.plan[idx];
+        const int64_t st = p.seg_off[sg];
+        const uint32_t pad = (uint32_t)(st & 7);
+        m.dest = p.out_map ? p.out_map[sg] : sg;
+        m.start = st - pad;
+        m.len = (uint32_t)(p.seg_off[sg + 1] - st) + pad;
+        m.info = pad << VI_PAD_SHIFT;
+      } else {
+        m.dest = t.v_dest[idx]; m.start = t.v_start[idx]; m.len = t.v_len[idx]; m.info = t.v_info[idx];
+      }
     }
     return m;
   };
@@ -160,7 +176,7 @@ fold_chunked_kernel(const FoldParams p, const ChunkTable t) {
     const int n_tiles = sh.n_tiles;
 
     const uint32_t pad = (cur.info >> VI_PAD_SHIFT) & 7u;
-    const bool whole = (cur.info & VI_RELATIVE) == 0u;
+    const bool whole = PERM || (cur.info & VI_RELATIVE) == 0u;
     // an aggregate in one piece starts from its known state, a chunk from "whatever comes in" (relative)
     Acc a = whole ? ((p.init && cur.dest >= 0) ? load_state(p.init, cur.dest) : acc_none()) : acc_identity();
     Acc P = acc_identity();
@@ -168,7 +184,7 @@ fold_chunked_kernel(const FoldParams p, const ChunkTable t) {
     uint32_t frozenM = whole ? (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 1, 1) : 0u;
     uint32_t corr = 0u;
     // wave-uniform: is any chunk here still waiting for its deciding event?  (usually settled within the first tile)
-    bool watching = __builtin_amdgcn_ballot_w64(!whole) != 0ull;
+    bool watching = !PERM && __builtin_amdgcn_ballot_w64(!whole) != 0ull;
     // one tile: wait for it, pull my LE events out of LDS, start the next tile's fetch, walk
     auto tile_step = [&](int c, auto tracking) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -208,12 +224,13 @@ fold_chunked_kernel(const FoldParams p, const ChunkTable t) {
     // chunks of cut aggregates) carries P and the deciding-event test; the plain loop is the sorted-rows kernel's walk
     // and gets scheduled like it (one loop with both walks cost +13 % VALU instructions in the plain path).
     int c = 0;
-    for (; c < n_tiles && watching; ++c) tile_step(c, std::true_type{});
+    if constexpr (!PERM)
+      for (; c < n_tiles && watching; ++c) tile_step(c, std::true_type{});
     for (; c < n_tiles; ++c) tile_step(c, std::false_type{});
     a.sum = (int64_t)((uint64_t)a.sum + corr);
 
     if (cur.dest >= 0) {
-      if (cur.info & VI_SIDE) {
+      if (!PERM && (cur.info & VI_SIDE)) {
         // a chunk without a deciding event (or an empty one, which walked clamped garbage) is all prefix
         const bool empty = cur.len == 0u;
         const bool undecided = undecM != 0u || empty;
@@ -233,7 +250,32 @@ fold_chunked_kernel(const FoldParams p, const ChunkTable t) {
   dispenser_leave(p.counter, lane);
 }
 
+// Register budget = resident waves: 2 per SIMD (<= 256 VGPRs) with 16 KiB tiles, 3 per SIMD (<= 168) with 8 KiB tiles.
+template <int LE>
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(LE == 8 ? 3 : 2)))
+fold_chunked_kernel(const FoldParams p, const ChunkTable t) {
+  chunk_walk<LE, false>(p, t);
+}
+
+// K2 "sorted rows", pipelined across groups (round 5; SURGE_ALGO_SORTED's kernel — fold_sorted_kernel stays selectable)
+template <int LE>
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(LE == 8 ? 3 : 2)))
+fold_sorted_pf_kernel(const FoldParams p) {
+  ChunkTable t;
+  t.v_start = nullptr; t.v_len = nullptr; t.v_info = nullptr; t.v_dest = nullptr; t.n_vrows = 0; t.side = nullptr;
+  chunk_walk<LE, true>(p, t);
+}
+
 }  // namespace
+
+hipError_t launch_fold_sorted_pf(const FoldParams& p, int64_t n_waves, int lane_events, hipStream_t stream) {
+  if (n_waves <= 0) return hipSuccess;
+  if (lane_events == 8)
+    hipLaunchKernelGGL((fold_sorted_pf_kernel<8>), dim3((unsigned)n_waves), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxSorted), stream, p);
+  else
+    hipLaunchKernelGGL((fold_sorted_pf_kernel<16>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxSorted), stream, p);
+  return hipGetLastError();
+}
 
 // the fold over the chunk table + the stitch of the cut aggregates
 hipError_t launch_fold_chunked(const FoldParams& p, const int64_t* v_start, const uint32_t* v_len, const uint32_t* v_info,

@@ -273,6 +273,7 @@ __global__ void __launch_bounds__(64) lz4_block_kernel(const uint8_t* __restrict
 //           the sequence-by-sequence loop.
 // Blocks whose compressed size is 64 KiB or more (a compressor that expands instead of storing) keep the one-pass kernel.
 struct Lz4Work {
+  int32_t dbg = 0;     // SURGE_DBG_DECODE (timing experiments only): 1 = image in, image out; 2 = the byte maps are built, never applied
   int32_t* state;      // per block: >= 0 decoded (its size), -1 malformed
   int32_t* n_seq;      // per block: entries written
   uint2* seq;          // the sequence table
@@ -497,7 +498,7 @@ __global__ void __launch_bounds__(64) lz4_exec_kernel(const uint8_t* __restrict_
     const int32_t n = w.n_seq[b];
     const uint2* __restrict__ sq = w.seq + blk.seq_off;
     uint2 e_next = lane < n ? sq[lane] : make_uint2(0u, 0u);
-    for (int32_t g = 0; g < n; g += 64) {
+    for (int32_t g = 0; g < (w.dbg == 1 ? 0 : n); g += 64) {
       const uint2 e = e_next;
       if (g + 64 < n) e_next = g + 64 + lane < n ? sq[g + 64 + lane] : make_uint2(0u, 0u);  // in flight during this group
       const int32_t cnt = n - g < 64 ? n - g : 64;
@@ -515,6 +516,7 @@ __global__ void __launch_bounds__(64) lz4_exec_kernel(const uint8_t* __restrict_
         // for eight windows instead of one each.  A window is then: gather, write, and per dependency round a ballot, a
         // gather and a write — whether a byte's source is written yet is a bit of the ballot, not a cross-lane read.
         constexpr int kWin = 8;
+        if (w.dbg == 2) continue;
         if (!BATCHED) {
           for (int32_t p = g0; p < g1; p += 64) {
             const int32_t pos = p + lane;
@@ -870,6 +872,7 @@ __device__ uint32_t decode_json_event(const EvjDevice* __restrict__ t, const sur
 struct JsonCtx {  // what the value decoder needs besides the value
   const EvjDevice* tmpl;  // nullptr: 16-byte fixed events
   const surge::F64ParseTable* ptab;
+  int32_t dbg = 0;  // SURGE_DBG_DECODE (timing experiments only, results are NOT the topic's): 1 = sections are staged, nothing else; 2 = staged and chained, no record decoded
 };
 
 // a record value -> event16 + status
@@ -986,6 +989,12 @@ __global__ void __launch_bounds__(kSecThreads) section_kernel(const uint8_t* __r
   }
   if (threadIdx.x == 0) { s_pos = 0; s_bad = -1; }
   __syncthreads();
+  if (jc.dbg) {  // timing experiments: every record of the batch is "skipped"
+    RecMeta m;
+    m.key_off = m.val_off = m.offset = 0; m.hash = 0; m.key_len = m.val_len = 0; m.slot = 0; m.status = RS_SKIP;
+    for (int32_t i = threadIdx.x; i < sec.n_records; i += kSecThreads) { meta[sec.rec_first + i] = m; ev_tmp[sec.rec_first + i] = make_uint4(0, 0, 0, 0); }
+    if (jc.dbg == 1) return;
+  }
   if (len >= (1ll << 31)) {  // a section of 2 GiB: nothing writes one (a batch's length is an int32)
     for (int32_t i0 = 0; i0 < sec.n_records; i0 += kSecThreads)
       decode_record(bytes, 0, 0, i0 + (int32_t)threadIdx.x < sec.n_records, -1, -1, sec.rec_first + i0 + threadIdx.x, seed, jc, meta, ev_tmp, f64_host_list, err);
@@ -1011,7 +1020,7 @@ __global__ void __launch_bounds__(kSecThreads) section_kernel(const uint8_t* __r
       }
     }
     __syncthreads();
-    for (int32_t i0 = 0; i0 < cnt; i0 += kSecThreads) {
+    for (int32_t i0 = 0; i0 < (jc.dbg ? 0 : cnt); i0 += kSecThreads) {
       const int32_t i = i0 + (int32_t)threadIdx.x;
       const bool valid = i < cnt;
       const int32_t body = valid ? rec_body[i] : -1, end = body >= 0 ? rec_end[i] : -1;
@@ -1524,6 +1533,17 @@ int32_t slot_pinned(surge_device_decoder* d, PushSlot& s, size_t bytes) {
   return OK;
 }
 
+// SURGE_DBG_DECODE=<lz4 mode><section mode> (two digits; timing experiments only — see Lz4Work::dbg / JsonCtx::dbg; a
+// lz4 mode needs a section mode, since the sections' bytes are then not the topic's)
+int32_t dbg_decode() {
+  static const int32_t v = [] {
+    const char* e = std::getenv("SURGE_DBG_DECODE");
+    const int32_t x = e ? std::atoi(e) : 0;
+    return (x >= 10 && x % 10 == 0) ? x + 1 : x;
+  }();
+  return v;
+}
+
 // Stage 1 of a wire push: the parts' records sections to the device, LZ4 blocks decoded, every record chained, parsed and
 // its value decoded.  Nothing here reads or writes the key table.
 int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const uint8_t* const* bytes, const surge_batch_section* const* sections,
@@ -1759,6 +1779,7 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
       // two passes: the sequence headers by one lane per block, then the copies by one wave per block in a launch with
       // the LDS the block's size needs (the first pass knows it)
       Lz4Work w;
+      w.dbg = dbg_decode() / 10;
       DCHK(d, s.lz4_nseq.reserve((size_t)nb * 4, false, st));
       DCHK(d, s.lz4_seq.reserve((size_t)(n_seq_entries + 1) * 8, false, st));
       DCHK(d, s.lz4_cls.reserve((size_t)(kLz4Classes + 1) * ((size_t)nb + 1) * 4, false, st));
@@ -1801,6 +1822,7 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
   // out of 18.3 KiB of LDS (8 workgroups per CU), the rest out of 66 KiB or, beyond 64 KiB, in place
   {
     JsonCtx jc{d->json ? (const EvjDevice*)d->d_tmpl.p : nullptr, (const surge::F64ParseTable*)d->d_ptab.p};
+    jc.dbg = dbg_decode() % 10;
     const int64_t caps[2] = {16640, 65536};
     for (int c = 0; c < 2; ++c) {
       const size_t lds = (size_t)((caps[c] + 47) & ~15ll) + 2 * (size_t)kSecRecs * 4;

@@ -32,6 +32,8 @@ void v1_kernels_acquire(const uint32_t (*table)[kTableWords], int device, V1Kern
 hipError_t launch_fold_flat(const FoldParams& p, const V1Kernels* spec, int64_t n_tasks, int lane_events, hipStream_t stream);
 hipError_t launch_fold_rows(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream);
 hipError_t launch_fold_sorted(const FoldParams& p, int64_t n_waves, int lane_events, hipStream_t stream);
+// the same fold, pipelined across groups (fold_chunked.hip: the chunked kernel's walk over whole aggregates); 8 or 16 events per lane
+hipError_t launch_fold_sorted_pf(const FoldParams& p, int64_t n_waves, int lane_events, hipStream_t stream);
 // ---- index_kernels.hip: the per-log indexes (length order, chunk table), built with rocPRIM sorts / scans -----------
 struct IndexScratch {  // engine-owned device scratch, sized for the rows being ordered
   void* temp;          // rocPRIM temporary storage

@@ -247,7 +247,7 @@ bool rtc_compile(const std::string& source, const char* arch, std::vector<char>*
 
 const char* rtc_library_path() {
   std::lock_guard<std::mutex> lk(g_rtc_mu);
-  return g_rtc.lib ? g_rtc.path.c_str() : (g_rtc_cache_hits ? "the code-object cache on disk (no compile)" : "");
+  return g_rtc.lib ? g_rtc.path.c_str() : (g_rtc_cache_hits ? "hiprtc, earlier: the code-object cache on disk (no compile in this process)" : "");
 }
 
 }  // namespace surge

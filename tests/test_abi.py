@@ -364,7 +364,7 @@ def test_no_kernel_of_the_library_spills_to_scratch(tmp_path):
                 cur[m.group(1)] = int(m.group(2))
     ours = {k: v for k, v in kernels.items() if "rocprim" not in k and "private_segment_fixed_size" in v}
     assert len(ours) >= 70, len(ours)
-    for hot in ("fold_sorted_kernelILi16", "fold_rows_kernelILi8", "fold_tiled_kernelILi2", "fold_kernelILi1ELi16", "section_kernel", "lz4_exec_kernelILb1"):
+    for hot in ("fold_sorted_pf_kernelILi16", "fold_sorted_kernelILi16", "fold_rows_kernelILi8", "fold_tiled_kernelILi2", "fold_kernelILi1ELi16", "section_kernel", "lz4_exec_kernelILb1"):
         assert any(hot in k for k in ours), hot
     spilling = {k: v for k, v in ours.items() if v["private_segment_fixed_size"] or v.get("vgpr_spill_count", 0)}
     assert not spilling, spilling
