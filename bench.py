@@ -78,12 +78,24 @@ def free_port():
         return sk.getsockname()[1]
 
 
-def csrc_sha16():
-    """Identity of the kernel sources a profile was taken with (profiles/traffic_manifest.json records it)."""
+def csrc_sha16(kernel=""):
+    """Identity of the sources ``kernel`` is built from (profiles/traffic_manifest.json records it per entry): the two
+    headers every fold shares plus the translation unit(s) of that kernel — a change to the chunked kernel does not make
+    the rows kernel's counter profile stale."""
+    files = ["fold_layout.h", "fold_device.h"]
+    if "sorted_pf" in kernel or "chunked" in kernel:
+        files += ["fold_chunk_device.h", "fold_chunked.hip"]
+    elif "tiled" in kernel and "slots" not in kernel:
+        files += ["fold_chunk_device.h", "fold_tiled.hip"]
+    elif "slots" in kernel:
+        files += ["fold_slots_device.h", "fold_slots.hip"]
+    elif "FLAT" in kernel:
+        files += ["fold_flat_device.h", "fold_kernels.hip"]
+    else:  # rows, sorted (plain), fixed
+        files += ["fold_kernels.hip"]
     h = hashlib.sha256()
     d = os.path.join(ROOT, "surge_amd", "csrc")
-    for name in ("fold_layout.h", "fold_device.h", "fold_chunk_device.h", "fold_slots_device.h", "fold_flat_device.h", "fold_kernels.hip",
-                 "fold_chunked.hip", "fold_tiled.hip"):  # what the fold kernels are built from
+    for name in files:
         h.update(name.encode())
         h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
@@ -101,7 +113,7 @@ def pmc_traffic(kernel, algorithmic_bytes):
         entries = json.load(open(path))
     except Exception:  # pragma: no cover
         return None, None
-    sha = csrc_sha16()
+    sha = csrc_sha16(kernel)
     stale = None
     for e in entries:
         if e.get("kernel") == kernel and int(e.get("algorithmic_bytes", -1)) == int(algorithmic_bytes):
@@ -1024,7 +1036,9 @@ def run_e2e(args):
                         m = fmt.write_event(e)
                         assert bytes(k[ko[i]:ko[i + 1]]) == m.key.encode() and bytes(v[vo[i]:vo[i + 1]]) == m.value
                     sample_checked = True
-                parts = writer.fetch(p, k, ko, v, vo) if independent else topic_gen.frame_partitions(writer, p, k, ko, v, vo)
+                # (the topic's last response holds no marker back: what an earlier response held back arrives with it)
+                last = final and pend_n == 0 or n_pub >= n_total and pend_n == 0
+                parts = writer.fetch(p, k, ko, v, vo, last=last) if independent else topic_gen.frame_partitions(writer, p, k, ko, v, vo)
                 wire_bytes += sum(len(x) for x in parts if x)
                 fetches.append((parts, take))
 

@@ -48,8 +48,7 @@ def test_traffic_manifest_is_keyed_by_kernel_bytes_and_source_hash(tmp_path, mon
     for e in entries:  # what the counters saw is never less than ~the algorithmic bytes and never wildly more
         assert 0.95 < e["traffic_bytes"] / e["algorithmic_bytes"] < 1.25, e["kernel"]
         assert os.path.exists(os.path.join(ROOT, e["source"].split(" ")[0])), e["source"]
-    sha = bench.csrc_sha16()
-    current = [e for e in entries if e["csrc_sha16"] == sha]
+    current = [e for e in entries if e["csrc_sha16"] == bench.csrc_sha16(e["kernel"])]  # (per kernel: the sources THAT kernel is built from)
     e = (current or entries)[0]
     got, src = bench.pmc_traffic(e["kernel"], e["algorithmic_bytes"])
     if current:
@@ -59,7 +58,8 @@ def test_traffic_manifest_is_keyed_by_kernel_bytes_and_source_hash(tmp_path, mon
     # another shape of the same kernel has no committed measurement: null, not a guess
     assert bench.pmc_traffic(e["kernel"], e["algorithmic_bytes"] + 16) == (None, None)
     # a kernel source edit invalidates every entry (the bench line then says "stale" instead of quoting old counters)
-    monkeypatch.setattr(bench, "csrc_sha16", lambda: "0" * 16)
+    assert bench.csrc_sha16("fold_rows_kernel<8>") != bench.csrc_sha16("fold_chunked_kernel<16> + chunk_stitch_kernel") != bench.csrc_sha16("surge_slots_tiled2")
+    monkeypatch.setattr(bench, "csrc_sha16", lambda kernel="": "0" * 16)
     got, src = bench.pmc_traffic(e["kernel"], e["algorithmic_bytes"])
     assert got is None and src.startswith("stale")
 
@@ -67,8 +67,7 @@ def test_traffic_manifest_is_keyed_by_kernel_bytes_and_source_hash(tmp_path, mon
 def test_committed_profiles_describe_the_current_kernel_sources():
     """A reminder rather than a gate: when a fold kernel changes, scripts/prof_traffic.py has to run again on a GPU."""
     entries = json.load(open(os.path.join(ROOT, "profiles", "traffic_manifest.json")))
-    sha = bench.csrc_sha16()
-    stale = sorted({e["source"].split(" ")[0] for e in entries if e["csrc_sha16"] != sha})
+    stale = sorted({e["source"].split(" ")[0] for e in entries if e["csrc_sha16"] != bench.csrc_sha16(e["kernel"])})
     if stale:
         pytest.skip("kernel sources changed since these PMC passes were taken (bench.py reports traffic: null for them): " + ", ".join(stale))
 

@@ -136,9 +136,10 @@ class WireTopic:
     def end_offsets(self):
         return [int(self._lib.surge_test_wire_topic_end_offset(self._h, p)) for p in range(self.n_partitions)]
 
-    def fetch(self, partition, keys, key_off, values, val_off):
+    def fetch(self, partition, keys, key_off, values, val_off, last: bool = False):
         """The next fetch response: one ``bytes`` per partition (``None`` where a partition got nothing).  No records
-        (``partition`` empty) = only the markers held back so far."""
+        (``partition`` empty) = only the markers held back so far.  ``last``: nothing is held back at the end of this
+        response (the topic ends here; the markers the response before held back still arrive with it)."""
         partition = np.ascontiguousarray(partition, dtype=np.int32)
         n = partition.shape[0]
         if n == 0:
@@ -146,7 +147,8 @@ class WireTopic:
             key_off, val_off = np.zeros(1, np.int64), np.zeros(1, np.int64)
         key_off, val_off = np.ascontiguousarray(key_off, dtype=np.int64), np.ascontiguousarray(val_off, dtype=np.int64)
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
-        rc = self._lib.surge_test_wire_topic_fetch(self._h, n, p(partition), p(keys), p(key_off), p(values), p(val_off), *self._args, p(self._counts))
+        args = self._args[:4] + (0,) if last else self._args
+        rc = self._lib.surge_test_wire_topic_fetch(self._h, n, p(partition), p(keys), p(key_off), p(values), p(val_off), *args, p(self._counts))
         if rc != 0:
             raise MemoryError("wire_writer")
         out = []
