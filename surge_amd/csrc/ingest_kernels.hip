@@ -274,6 +274,7 @@ __global__ void __launch_bounds__(64) lz4_block_kernel(const uint8_t* __restrict
 // Blocks whose compressed size is 64 KiB or more (a compressor that expands instead of storing) keep the one-pass kernel.
 struct Lz4Work {
   int32_t dbg = 0;     // SURGE_DBG_DECODE (timing experiments only): 1 = image in, image out; 2 = the byte maps are built, never applied
+  int32_t pad = 0;     // bytes between image and map (SURGE_INGEST_LZ4_PAD=64: round 4's layout, for same-box comparisons)
   int32_t* state;      // per block: >= 0 decoded (its size), -1 malformed
   int32_t* n_seq;      // per block: entries written
   uint2* seq;          // the sequence table
@@ -470,8 +471,11 @@ __global__ void __launch_bounds__(64) lz4_parse_kernel(const uint8_t* __restrict
   if (op > 0) w.cls_list[(int64_t)cls * n_blocks + atomicAdd(&w.cls_count[cls], 1)] = b;
 }
 
-// cls == kLz4Classes: stored blocks (launched without LDS).  LDS: the block's image (the class's capacity + 64 bytes
-// that a masked-off lane may address), then the byte map (kLz4Map 16-bit positions).
+// cls == kLz4Classes: stored blocks (launched without LDS).  LDS: the block's image (the class's capacity), then the byte
+// map (kLz4Map 16-bit positions).  A masked-off lane may READ up to 63 bytes past the image — the start of the map, harmless;
+// nothing is written past the class's capacity — so the image needs no pad of its own: 16 KiB + 4 KiB = 20 480 bytes is
+// exactly an eighth of a CU's 160 KiB (the 64-byte pad of round 4 made it seven waves per CU for the batches the reference's
+// 16 KiB producer writes).
 // BATCHED = false: the map read per window and the dependency rounds through a cross-lane read, as first written — kept
 // selectable (SURGE_INGEST_LZ4_WINDOWS=1) for a same-box comparison (profiles/r04_e2e_lz4_windows.txt: the batched loop
 // is 1.8 % faster end to end — the kernels' LDS footprint x time bounds the path, not this loop's latency alone).
@@ -479,7 +483,7 @@ template <bool BATCHED>
 __global__ void __launch_bounds__(64) lz4_exec_kernel(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ out_base, const Lz4Block* __restrict__ blocks,
                                                       int32_t n_blocks, Lz4Work w, int32_t cls, int32_t cap) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lz4_out[];
-  uint16_t* const map = (uint16_t*)(lz4_out + cap + 64);
+  uint16_t* const map = (uint16_t*)(lz4_out + cap + w.pad);
   const int lane = threadIdx.x;
   const int32_t count = w.cls_count[cls];
   for (int32_t k = (int32_t)blockIdx.x; k < count; k += (int32_t)gridDim.x) {
@@ -990,8 +994,12 @@ __device__ __forceinline__ void decode_record(P base, int64_t sec_off, int64_t b
   ev_tmp[gi] = e;
 }
 
-constexpr int kSecThreads = 256;
-constexpr int kSecRecs = 256;  // records chained per round (LDS: two int32 per record; a 16 KiB batch holds ~140 events)
+// Workgroup sizes of section_kernel.  The decode walks are latency-bound: what counts is how many batches a CU has in
+// flight, and a workgroup's lanes beyond its batch's records only take registers away from other batches.  A 16 KiB batch of
+// the reference's publisher holds ~140 play-json events: 192 lanes decode it in one round where 256 idled 45 % of theirs — and
+// at 90 VGPRs a CU held 5 workgroups of four waves; three-wave workgroups at <= 80 VGPRs make it the 8 the LDS allows.  A
+// push picks the smallest size that takes its largest batch's records in one round (64 for small publisher flushes).
+constexpr int kSecRecs = 256;  // records chained per round (LDS: two int32 per record)
 
 // the length varints of up to kSecRecs records from relative position *pos on; false = unreadable from record `bad` on
 // (This walk is the one sequential step of a batch — one lane works, 255 wait: per record ONE load (the four bytes at the
@@ -1031,10 +1039,10 @@ __device__ bool chain_records(P base, int32_t len, int32_t* pos, int32_t cnt, in
 }
 
 // A workgroup takes its section when lo_excl < byte_len and (byte_len <= cap or take_rest); byte_len <= cap is staged.
-__global__ void __launch_bounds__(kSecThreads) section_kernel(const uint8_t* __restrict__ bytes, const Section* __restrict__ sections, int64_t n_sections,
-                                                              int64_t lo_excl, int64_t cap, int32_t take_rest, uint64_t seed, JsonCtx jc,
-                                                              RecMeta* __restrict__ meta, uint4* __restrict__ ev_tmp, uint32_t* __restrict__ f64_host_list,
-                                                              ErrorCell* err) {
+template <int kSecThreads>
+__global__ void __launch_bounds__(kSecThreads) __attribute__((amdgpu_waves_per_eu(kSecThreads == 256 ? 5 : 6)))  // (four waves at 80 VGPRs spill)
+section_kernel(const uint8_t* __restrict__ bytes, const Section* __restrict__ sections, int64_t n_sections, int64_t lo_excl, int64_t cap, int32_t take_rest,
+               uint64_t seed, JsonCtx jc, RecMeta* __restrict__ meta, uint4* __restrict__ ev_tmp, uint32_t* __restrict__ f64_host_list, ErrorCell* err) {
   extern __shared__ __attribute__((aligned(16))) uint8_t sec_smem[];
   __shared__ int32_t s_pos, s_bad;
   const Section sec = sections[blockIdx.x];
@@ -1635,6 +1643,7 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
   std::vector<uint8_t> extra;
   std::vector<int64_t> part_lo((size_t)n_parts, 0), part_dev((size_t)n_parts, 0), part_len((size_t)n_parts, 0);
   int64_t n_rec = 0, n_raw = 0;
+  int32_t max_recs = 0;  // of one batch of this push (section_kernel's workgroup size)
   try {
     secs.resize((size_t)total_sections);
     blocks.clear();
@@ -1657,6 +1666,7 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
         const surge_batch_section& in = sections[p][i];
         secs[(size_t)at] = Section{part_dev[(size_t)p] + (in.byte_off - lo), in.byte_len, in.base_offset, in.n_records, 0, n_rec};
         n_rec += in.n_records;
+        max_recs = in.n_records > max_recs ? in.n_records : max_recs;
       }
     }
   } catch (const std::bad_alloc&) {
@@ -1843,6 +1853,8 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
       // the LDS the block's size needs (the first pass knows it)
       Lz4Work w;
       w.dbg = dbg_decode() / 10;
+      static const int32_t lz4_pad = [] { const char* v = std::getenv("SURGE_INGEST_LZ4_PAD"); return v ? (std::atoi(v) & ~15) : 0; }();
+      w.pad = lz4_pad < 0 ? 0 : (lz4_pad > 4096 ? 4096 : lz4_pad);
       DCHK(d, s.lz4_nseq.reserve((size_t)nb * 4, false, st));
       DCHK(d, s.lz4_seq.reserve((size_t)(n_seq_entries + 1) * 8, false, st));
       DCHK(d, s.lz4_cls.reserve((size_t)(kLz4Classes + 1) * ((size_t)nb + 1) * 4, false, st));
@@ -1853,14 +1865,20 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
       w.cls_list = w.cls_count + (kLz4Classes + 1);
       DCHK(d, hipMemsetAsync(w.cls_count, 0, (kLz4Classes + 1) * 4, st));
       {
-        const int32_t caps[2] = {8192, kLz4BlockMax + 64};  // LDS of the two launches of the first pass (a block of the 16 KiB producer compresses to ~5 KiB)
-        for (int c = 0; c < 2; ++c)
+        // LDS of the launches of the first pass.  A block of the 16 KiB producer compresses to 3 - 5.5 KiB: 6.5 KiB of LDS is what
+        // 24 waves per CU — all the kernel's 78 VGPRs allow — leave each other (8 KiB: 20 waves); a batch that compresses badly
+        // takes the 16 KiB class (9 waves per CU) instead of sharing a CU with one other wave in the 64 KiB one.
+        static const bool two_launches = [] { const char* v = std::getenv("SURGE_INGEST_LZ4_PARSE_CLASSES"); return v && v[0] == '2'; }();  // experiments: round 4's {8 KiB, 64 KiB}
+        const int32_t caps3[3] = {6656, 16384 + 64, kLz4BlockMax + 64}, caps2[2] = {8192, kLz4BlockMax + 64};
+        const int32_t* caps = two_launches ? caps2 : caps3;
+        const int n_caps = two_launches ? 2 : 3;
+        for (int c = 0; c < n_caps; ++c)
           hipLaunchKernelGGL(lz4_parse_kernel, dim3((unsigned)nb), dim3(64), (size_t)caps[c], st, dby, (uint8_t*)s.d_bytes.p + area_base, (const Lz4Block*)s.lz4_blocks.p,
-                             (int32_t)nb, w, dsec, derr, c == 0 ? -1 : caps[0], caps[c]);
+                             (int32_t)nb, w, dsec, derr, c == 0 ? -1 : caps[c - 1], caps[c]);
       }
       for (int c = 0; c <= kLz4Classes; ++c) {
         const int32_t cap = c < kLz4Classes ? kLz4ClassCapHost[c] : 0;
-        const size_t lds = cap ? (size_t)cap + 64 + (size_t)kLz4Map * 2 : 0;
+        const size_t lds = cap ? (size_t)cap + (size_t)w.pad + (size_t)kLz4Map * 2 : 0;
         const int64_t resident = 256ll * (lds ? (int64_t)(160 * 1024 / lds) : 16);  // waves the chip holds at this LDS size
         const unsigned grid = (unsigned)(nb < resident ? nb : resident);
         static const bool one_window = [] { const char* v = std::getenv("SURGE_INGEST_LZ4_WINDOWS"); return v && v[0] == '1'; }();
@@ -1883,14 +1901,29 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
   lap("lz4 launches");
   // chain + parse + decode, one workgroup per batch: sections up to 16.25 KiB (the reference producer closes a batch at 16 KiB)
   // out of 18.3 KiB of LDS (8 workgroups per CU), the rest out of 66 KiB or, beyond 64 KiB, in place
+  // (round 5: a third, 8 KiB class in front — a publisher that flushes every 64 events writes 7 KiB batches, and 10.4 KiB of LDS
+  // instead of 18.3 lets a CU hold 15 of them; the workgroup is as wide as the push's largest batch needs)
   {
     JsonCtx jc{d->json ? (const EvjDevice*)d->d_tmpl.p : nullptr, (const surge::F64ParseTable*)d->d_ptab.p};
     jc.dbg = dbg_decode() % 10;
-    const int64_t caps[2] = {16640, 65536};
-    for (int c = 0; c < 2; ++c) {
+    static const int force_threads = [] { const char* v = std::getenv("SURGE_INGEST_SEC_THREADS"); return v ? std::atoi(v) : 0; }();  // experiments: 64 / 128 / 192 / 256
+    static const bool two_classes = [] { const char* v = std::getenv("SURGE_INGEST_SEC_CLASSES"); return v && v[0] == '2'; }();      // experiments: round 4's two launches
+    const int threads = force_threads ? force_threads : (max_recs <= 64 ? 64 : max_recs <= 128 ? 128 : max_recs <= 192 ? 192 : 256);
+    const int64_t caps3[3] = {8320, 16640, 65536};
+    const int64_t* caps = two_classes ? caps3 + 1 : caps3;
+    const int n_caps = two_classes ? 2 : 3;
+    for (int c = 0; c < n_caps; ++c) {
       const size_t lds = (size_t)((caps[c] + 47) & ~15ll) + 2 * (size_t)kSecRecs * 4;
-      hipLaunchKernelGGL(section_kernel, dim3((unsigned)total_sections), dim3(kSecThreads), lds, st, dby, (const Section*)dsec, total_sections, c == 0 ? -1 : caps[0],
-                         caps[c], c == 1 ? 1 : 0, seed, jc, dmeta, (uint4*)s.ev_tmp.p, (uint32_t*)s.f64_list.p, derr);
+      const int64_t lo_excl = c == 0 ? -1 : caps[c - 1];
+      const int32_t rest = c == n_caps - 1 ? 1 : 0;
+#define SURGE_SECTION_LAUNCH(T)                                                                                                                       \
+  hipLaunchKernelGGL(section_kernel<T>, dim3((unsigned)total_sections), dim3(T), lds, st, dby, (const Section*)dsec, total_sections, lo_excl, caps[c], rest, seed, \
+                     jc, dmeta, (uint4*)s.ev_tmp.p, (uint32_t*)s.f64_list.p, derr)
+      if (threads <= 64) SURGE_SECTION_LAUNCH(64);
+      else if (threads <= 128) SURGE_SECTION_LAUNCH(128);
+      else if (threads <= 192) SURGE_SECTION_LAUNCH(192);
+      else SURGE_SECTION_LAUNCH(256);
+#undef SURGE_SECTION_LAUNCH
     }
     DCHK(d, hipGetLastError());
   }
