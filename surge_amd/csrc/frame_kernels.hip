@@ -387,8 +387,10 @@ int32_t surge_device_framer_frame(surge_device_framer* f, int64_t n_aggregates, 
   // 2. partition + base size per record, stable sort by partition
   unsigned bits = 1;
   while ((1ll << bits) < P) ++bits;
-  FCHK(f, rocprim::radix_sort_pairs(nullptr, tb_sort, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                    (size_t)n_sel, 0u, bits, st));
+  // (a partition number has 6 bits: one onesweep pass — rocPRIM's default would merge-sort up to 2^20 records in 21 launches; stream_kernels.hip)
+  using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 32768>;
+  FCHK(f, rocprim::radix_sort_pairs<SortConfig>(nullptr, tb_sort, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                                (size_t)n_sel, 0u, bits, st));
   FCHK(f, rocprim::exclusive_scan(nullptr, tb_scan, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)n_sel + 1, rocprim::plus<int64_t>(), st));
   FCHK(f, f->temp.reserve(tb_sort > tb_scan ? tb_sort : tb_scan));
   for (Buf* b : {&f->keys_a, &f->keys_b, &f->vals_a, &f->vals_b, &f->base}) FCHK(f, b->reserve((size_t)n_sel * 4));
@@ -399,8 +401,8 @@ int32_t surge_device_framer_frame(surge_device_framer* f, int64_t n_aggregates, 
   FCHK(f, f->d_next.reserve((size_t)P * 8));
   hipLaunchKernelGGL(frame_size_kernel, dim3(grid(n_sel)), dim3(256), 0, st, (const int64_t*)f->sel.p, n_sel, d_kind, d_partition, P, d_key_off, d_val_off,
                      d_keys_utf8 != nullptr, d_values != nullptr, (uint32_t*)f->keys_a.p, (uint32_t*)f->vals_a.p, (uint32_t*)f->base.p, (uint32_t*)f->bad.p);
-  FCHK(f, rocprim::radix_sort_pairs(f->temp.p, tb_sort, (const uint32_t*)f->keys_a.p, (uint32_t*)f->keys_b.p, (const uint32_t*)f->vals_a.p,
-                                    (uint32_t*)f->vals_b.p, (size_t)n_sel, 0u, bits, st));
+  FCHK(f, rocprim::radix_sort_pairs<SortConfig>(f->temp.p, tb_sort, (const uint32_t*)f->keys_a.p, (uint32_t*)f->keys_b.p, (const uint32_t*)f->vals_a.p,
+                                                (uint32_t*)f->vals_b.p, (size_t)n_sel, 0u, bits, st));
   const uint32_t* order = (const uint32_t*)f->vals_b.p;
   int64_t* c1 = (int64_t*)f->c.p;
   int64_t* c2 = c1 + (n_sel + 1);

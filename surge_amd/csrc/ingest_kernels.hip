@@ -1147,12 +1147,23 @@ __global__ void __launch_bounds__(256) records_kernel(const uint8_t* __restrict_
 }
 
 // ---- interning the aggregate ids -----------------------------------------------------------------------------------------
+// One 16-byte slot per entry (round 5; three parallel arrays before): a probe, the flag pass and the final gather each touch
+// ONE random line of the 2^25-slot table per record instead of two or three.
+struct TableSlot {
+  unsigned long long hash;  // 0 = empty
+  uint32_t key_id;          // 0xffffffff = not assigned yet (inserted by the push in flight)
+  uint32_t first_rec;       // of a slot inserted by the push in flight: its first record (0xffffffff otherwise)
+};
+static_assert(sizeof(TableSlot) == 16, "one slot = one 16-byte store");
 struct Table {
-  unsigned long long* hash;  // 0 = empty
-  uint32_t* key_id;          // 0xffffffff = not assigned yet (inserted by the push in flight)
-  uint32_t* first_rec;       // of a slot inserted by the push in flight: its first record (0xffffffff otherwise)
+  TableSlot* s;
   uint64_t mask;
 };
+
+__global__ void table_clear_kernel(TableSlot* __restrict__ s, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ((uint4*)s)[i] = make_uint4(0u, 0u, 0xffffffffu, 0xffffffffu);
+}
 
 // insert-or-find by hash; a slot this push inserts remembers its first record
 __global__ void probe_kernel(RecMeta* __restrict__ meta, int64_t n_rec, Table t) {
@@ -1162,12 +1173,12 @@ __global__ void probe_kernel(RecMeta* __restrict__ meta, int64_t n_rec, Table t)
   const unsigned long long h = meta[i].hash;
   uint64_t s = h & t.mask;
   while (true) {
-    const unsigned long long old = atomicCAS(&t.hash[s], 0ull, h);
+    const unsigned long long old = atomicCAS(&t.s[s].hash, 0ull, h);
     if (old == 0ull || old == h) break;
     s = (s + 1) & t.mask;
   }
   meta[i].slot = (uint32_t)s;
-  if (t.key_id[s] == 0xffffffffu) atomicMin(&t.first_rec[s], (uint32_t)i);
+  if (t.s[s].key_id == 0xffffffffu) atomicMin(&t.s[s].first_rec, (uint32_t)i);
 }
 
 // Per record: is it the first record of a key this push discovers (those get the next ids, in record order: the host
@@ -1184,7 +1195,7 @@ __global__ void flag_kernel(const RecMeta* __restrict__ meta, int64_t n_rec, con
   if (i < n_rec) {
     const RecMeta m = meta[i];
     if (m.status == RS_OK) {
-      const uint32_t id = t.key_id[m.slot];
+      const uint32_t id = t.s[m.slot].key_id;
       const uint8_t* kp = bytes + m.key_off;
       bool same;
       if (id != 0xffffffffu) {
@@ -1192,7 +1203,7 @@ __global__ void flag_kernel(const RecMeta* __restrict__ meta, int64_t n_rec, con
         same = a1 - a0 == m.key_len;
         for (int b = 0; same && b < m.key_len; ++b) same = arena[a0 + b] == kp[b];
       } else {
-        const uint32_t fr = t.first_rec[m.slot];
+        const uint32_t fr = t.s[m.slot].first_rec;
         if ((int64_t)fr == i) {
           same = true;
           f = (1ull << 40) | (unsigned long long)(uint32_t)m.key_len;
@@ -1223,8 +1234,8 @@ __global__ void assign_kernel(const RecMeta* __restrict__ meta, int64_t n_rec, c
   for (int b = 0; b < m.key_len; ++b) arena[dst + b] = bytes[m.key_off + b];
   key_off[id + 1] = dst + m.key_len;
   key_hash[id] = m.hash;
-  t.key_id[m.slot] = (uint32_t)id;
-  t.first_rec[m.slot] = 0xffffffffu;
+  t.s[m.slot].key_id = (uint32_t)id;
+  t.s[m.slot].first_rec = 0xffffffffu;
 }
 
 // delivered records -> the result arrays (aggregate index from the record's slot)
@@ -1234,7 +1245,7 @@ __global__ void finalize_kernel(const RecMeta* __restrict__ meta, int64_t n_rec,
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rec || !keep[i]) return;
   const int64_t o = out_base + pos[i];
-  agg_out[o] = (int64_t)t.key_id[meta[i].slot];
+  agg_out[o] = (int64_t)t.s[meta[i].slot].key_id;
   ev_out[o] = ev_tmp[i];
   off_out[o] = meta[i].offset;
 }
@@ -1245,9 +1256,9 @@ __global__ void rollback_kernel(const RecMeta* __restrict__ meta, int64_t n_rec,
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rec || meta[i].status != RS_OK) return;
   const uint32_t s = meta[i].slot;
-  if (t.key_id[s] == 0xffffffffu) {
-    t.hash[s] = 0ull;
-    t.first_rec[s] = 0xffffffffu;
+  if (t.s[s].key_id == 0xffffffffu) {
+    t.s[s].hash = 0ull;
+    t.s[s].first_rec = 0xffffffffu;
   }
 }
 
@@ -1258,8 +1269,8 @@ __global__ void rehash_kernel(const unsigned long long* __restrict__ key_hash, i
   uint64_t s = h & t.mask;
   // (two known keys that collide under a new seed share a hash and get two slots: lookups of the second then find the
   // first, flag_kernel reports the mismatch and the table is re-seeded once more)
-  while (atomicCAS(&t.hash[s], 0ull, h) != 0ull) s = (s + 1) & t.mask;
-  t.key_id[s] = (uint32_t)id;
+  while (atomicCAS(&t.s[s].hash, 0ull, h) != 0ull) s = (s + 1) & t.mask;
+  t.s[s].key_id = (uint32_t)id;
 }
 
 // after a re-seed: every known key's hash from its bytes in the arena, every record's from its key in the staged bytes
@@ -1339,12 +1350,21 @@ struct surge_device_decoder {
   Buf d_tmpl, d_ptab;
   surge_event_json_template h_tmpl;  // (host copy: Doubles the device cannot decide are re-parsed with it)
   PushSlot slots[kSlots];
+  // Stage 1 streams.  Consecutive pushes take consecutive streams (PushSlot::stream is set when a push claims its slot): with four
+  // pushes in flight three are in stage 1 at any time, so THREE streams are all the concurrency there is — and with the
+  // stream stage 2 and the fold run on that makes four, the number of hardware queues the HIP runtime creates by default
+  // (GPU_MAX_HW_QUEUES).  Round 4 gave each of the five slots a stream of its own: the fifth and sixth stream of the process
+  // shared a hardware queue with another one, and every fifth fetch waited for a neighbour's stage 1 in front of its stage 2
+  // (profiles/r05_e2e_k512_per_fetch_trace.txt: finish 1.1 - 1.5 ms instead of 0.4 on fetches 8, 13, 18, 23, 28).
+  hipStream_t push_streams[kSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int n_push_streams = 0;
+  uint64_t push_seq = 0;
   int head = 0;
   std::atomic<int> n_pending{0};  // slots [head, head + n_pending) hold pushes whose stage 1 is enqueued (changes under `mu`)
   // stage 2 scratch
   Buf first, first_scan, keep, keep_pos, temp;
   // hash table + key table
-  Buf t_hash, t_key_id, t_first, arena, key_off, key_hash;
+  Buf t_slots, arena, key_off, key_hash;
   uint64_t t_cap = 0;
   std::atomic<uint64_t> seed{0};  // (stage 1 reads it once per push; stage 2 of an earlier push may move it on: PushSlot::seed)
   int64_t n_keys = 0, arena_bytes = 0;
@@ -1380,9 +1400,7 @@ int32_t dfail(surge_device_decoder* d, int32_t code, const std::string& m) {
 
 Table table_of(surge_device_decoder* d) {
   Table t;
-  t.hash = (unsigned long long*)d->t_hash.p;
-  t.key_id = (uint32_t*)d->t_key_id.p;
-  t.first_rec = (uint32_t*)d->t_first.p;
+  t.s = (TableSlot*)d->t_slots.p;
   t.mask = d->t_cap - 1;
   return t;
 }
@@ -1393,15 +1411,11 @@ int32_t ensure_table(surge_device_decoder* d, int64_t extra) {
   while (need < (uint64_t)(d->n_keys + extra) * 2) need *= 2;
   if (need <= d->t_cap) return OK;
   if (need > (1ull << 32)) return dfail(d, E_UNSUPPORTED, "more than 2^31 aggregate ids");
-  Buf h, k, f;
-  DCHK(d, h.reserve(need * 8, false, d->stream));
-  DCHK(d, k.reserve(need * 4, false, d->stream));
-  DCHK(d, f.reserve(need * 4, false, d->stream));
-  DCHK(d, hipMemsetAsync(h.p, 0, need * 8, d->stream));
-  DCHK(d, hipMemsetAsync(k.p, 0xff, need * 4, d->stream));
-  DCHK(d, hipMemsetAsync(f.p, 0xff, need * 4, d->stream));
-  d->t_hash.release(); d->t_key_id.release(); d->t_first.release();
-  d->t_hash = h; d->t_key_id = k; d->t_first = f;
+  Buf fresh;
+  DCHK(d, fresh.reserve(need * sizeof(TableSlot), false, d->stream));
+  hipLaunchKernelGGL(table_clear_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, d->stream, (TableSlot*)fresh.p, need);
+  d->t_slots.release();
+  d->t_slots = fresh;
   d->t_cap = need;
   if (d->n_keys > 0)
     hipLaunchKernelGGL(rehash_kernel, dim3((unsigned)((d->n_keys + 255) / 256)), dim3(256), 0, d->stream, (const unsigned long long*)d->key_hash.p,
@@ -1459,8 +1473,16 @@ int32_t surge_device_decoder_create(int32_t device_id, void* hip_stream, const s
   int32_t rc = OK;
   auto init = [&]() -> int32_t {
     DCHK(d, hipSetDevice(device_id));
+    {
+      int n = 3;
+      if (const char* v = std::getenv("SURGE_INGEST_PUSH_STREAMS")) n = std::atoi(v);  // experiments: 5 = a stream per slot (round 4)
+      n = n < 1 ? 1 : (n > kSlots ? kSlots : n);
+      for (int i = 0; i < n; ++i) {
+        DCHK(d, hipStreamCreateWithFlags(&d->push_streams[i], hipStreamNonBlocking));
+        d->n_push_streams = i + 1;
+      }
+    }
     for (PushSlot& s : d->slots) {
-      DCHK(d, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
       DCHK(d, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
       DCHK(d, hipEventCreateWithFlags(&s.released, hipEventDisableTiming));
       DCHK(d, s.d_err.reserve(sizeof(ErrorCell), false, d->stream));
@@ -1522,8 +1544,11 @@ int32_t surge_device_decoder_destroy(surge_device_decoder* d) {
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
+  for (int i = 0; i < d->n_push_streams; ++i) {
+    (void)hipStreamSynchronize(d->push_streams[i]);
+    (void)hipStreamDestroy(d->push_streams[i]);
+  }
   for (PushSlot& s : d->slots) {
-    if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); }
     if (s.done) (void)hipEventDestroy(s.done);
     if (s.released) (void)hipEventDestroy(s.released);
     Buf* sb[] = {&s.lz4_blocks, &s.lz4_sizes, &s.lz4_nseq, &s.lz4_seq, &s.lz4_cls, &s.d_bytes, &s.d_sections, &s.rec_a, &s.rec_b, &s.rec_c, &s.meta, &s.ev_tmp,
@@ -1531,8 +1556,8 @@ int32_t surge_device_decoder_destroy(surge_device_decoder* d) {
     for (Buf* b : sb) b->release();
     if (s.pinned) (void)hipHostFree(s.pinned);
   }
-  Buf* bufs[] = {&d->d_tmpl, &d->d_ptab, &d->first, &d->first_scan, &d->keep, &d->keep_pos, &d->temp, &d->t_hash, &d->t_key_id,
-                 &d->t_first, &d->arena, &d->key_off, &d->key_hash, &d->r_agg, &d->r_ev, &d->r_off};
+  Buf* bufs[] = {&d->d_tmpl, &d->d_ptab, &d->first, &d->first_scan, &d->keep, &d->keep_pos, &d->temp, &d->t_slots,
+                 &d->arena, &d->key_off, &d->key_hash, &d->r_agg, &d->r_ev, &d->r_off};
   for (Buf* b : bufs) b->release();
   if (d->ready) (void)hipEventDestroy(d->ready);
   if (d->consumed) (void)hipEventDestroy(d->consumed);
@@ -1569,6 +1594,7 @@ PushSlot* claim_slot(surge_device_decoder* d, int32_t* rc) {
   {
     std::lock_guard<std::mutex> lk(d->mu);
     if (d->n_pending < kSlots) s = &d->slots[(d->head + d->n_pending) % kSlots];  // (a finish on the other thread moves head and n_pending together: the same slot)
+    if (s) s->stream = d->push_streams[d->push_seq++ % (uint64_t)d->n_push_streams];
   }
   if (!s) *rc = dfail(d, SURGE_E_STATE, "every push slot holds an unfinished push: call surge_device_decoder_push_finish first");
   return s;
@@ -2040,9 +2066,7 @@ int32_t stage2(surge_device_decoder* d, PushSlot& s, bool wait) {
       hipLaunchKernelGGL(rollback_kernel, dim3(rb), dim3(256), 0, st, (const RecMeta*)dmeta, n_rec, table_of(d));
       d->seed = (d->seed & ~(1ull << 63)) + 1;
       ++d->reseeds;
-      PCHK(hipMemsetAsync(d->t_hash.p, 0, d->t_cap * 8, st));
-      PCHK(hipMemsetAsync(d->t_key_id.p, 0xff, d->t_cap * 4, st));
-      PCHK(hipMemsetAsync(d->t_first.p, 0xff, d->t_cap * 4, st));
+      hipLaunchKernelGGL(table_clear_kernel, dim3((unsigned)((d->t_cap + 255) / 256)), dim3(256), 0, st, (TableSlot*)d->t_slots.p, d->t_cap);
       if (d->n_keys > 0) {
         const unsigned kb = (unsigned)((d->n_keys + 255) / 256);
         hipLaunchKernelGGL(rekey_keys_kernel, dim3(kb), dim3(256), 0, st, (const uint8_t*)d->arena.p, (const int64_t*)d->key_off.p, d->n_keys, d->seed,

@@ -9,10 +9,31 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "replay_internal.h"
 
 namespace surge {
 namespace {
+
+// rocPRIM sorts up to 2^20 items with a block sort + merge passes — for a 10^6-event fetch that is 21 launches (one block sort,
+// ten rounds of two kernels: 0.16 ms on the chip, a third of everything K3 costs per fetch; profiles/r05_e2e_k512_depth1_*) where
+// the LSD "onesweep" radix sort needs a histogram, a scan and one pass per 8 key bits: five launches for the 24 bits a
+// 10 M-aggregate store's indexes need.  The keys here never have more bits than the store has aggregates, so the limit
+// below which merge sort runs is lowered to 2^15 items (SURGE_REPLAY_GROUPBY_SORT=merge: rocPRIM's own choice, for comparisons).
+using GroupbyOnesweep = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 32768>;
+
+bool groupby_onesweep() {
+  static const bool v = [] { const char* e = std::getenv("SURGE_REPLAY_GROUPBY_SORT"); return !(e && std::strcmp(e, "merge") == 0); }();
+  return v;
+}
+
+template <class Config>
+hipError_t sort_pairs(void* temp, size_t& temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
+                      unsigned key_bits, hipStream_t stream) {
+  return rocprim::radix_sort_pairs<Config>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, key_bits, stream);
+}
 
 // keys[i] = low 32 bits of agg_idx[i] (n_agg < 2^32 is checked by the caller), vals[i] = i; bad[0] |= out-of-range index
 __global__ void groupby_keys_kernel(const int64_t* __restrict__ agg_idx, uint32_t n, int64_t n_agg, uint32_t* __restrict__ keys,
@@ -60,9 +81,14 @@ __global__ void groupby_scatter_kernel(const uint32_t* __restrict__ keys, const 
 // scratch bytes the two rocPRIM primitives need for n events (the larger of the two)
 hipError_t groupby_temp_bytes(uint32_t n, unsigned key_bits, size_t* bytes) {
   size_t a = 0, b = 0;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                           (uint32_t*)nullptr, (size_t)n, 0u, key_bits, (hipStream_t) nullptr);
+  hipError_t e = sort_pairs<rocprim::default_config>(nullptr, a, nullptr, nullptr, nullptr, nullptr, (size_t)n, key_bits, (hipStream_t) nullptr);
   if (e != hipSuccess) return e;
+  {  // (the larger of the two sorts' needs: which one runs is a run-time choice)
+    size_t a2 = 0;
+    e = sort_pairs<GroupbyOnesweep>(nullptr, a2, nullptr, nullptr, nullptr, nullptr, (size_t)n, key_bits, (hipStream_t) nullptr);
+    if (e != hipSuccess) return e;
+    a = a2 > a ? a2 : a;
+  }
   e = rocprim::exclusive_scan(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n, rocprim::plus<uint32_t>(),
                               (hipStream_t) nullptr);
   if (e != hipSuccess) return e;
@@ -81,8 +107,12 @@ hipError_t launch_groupby(const int64_t* d_agg_idx, const uint4* d_events, uint3
   hipError_t e = hipMemsetAsync(d_flags, 0, 8, stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(groupby_keys_kernel, dim3(blocks), dim3(256), 0, stream, d_agg_idx, n, n_agg, keys_a, vals_a, d_flags + 1);
-  e = rocprim::radix_sort_pairs(d_temp, temp_bytes, (const uint32_t*)keys_a, keys_b, (const uint32_t*)vals_a, vals_b, (size_t)n, 0u, key_bits, stream);
-  if (e != hipSuccess) return e;
+  {
+    size_t tb = temp_bytes;
+    e = groupby_onesweep() ? sort_pairs<GroupbyOnesweep>(d_temp, tb, keys_a, keys_b, vals_a, vals_b, (size_t)n, key_bits, stream)
+                           : sort_pairs<rocprim::default_config>(d_temp, tb, keys_a, keys_b, vals_a, vals_b, (size_t)n, key_bits, stream);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(groupby_heads_kernel, dim3(blocks), dim3(256), 0, stream, keys_b, n, head);
   e = rocprim::exclusive_scan(d_temp, temp_bytes, (const uint32_t*)head, gid, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream);
   if (e != hipSuccess) return e;
