@@ -205,7 +205,9 @@ def main():
     ap.add_argument("--abort-every", type=int, default=50, help="e2e, transactional topic: every N-th flush of a partition first fails (its records + an ABORT marker) and is retried; 0 = none")
     ap.add_argument("--hold-markers", type=int, default=4, help="e2e, transactional topic: on partitions p %% N == 1 the last marker of a fetch response arrives with the next one; 0 = never")
     ap.add_argument("--no-capacity-hint", action="store_true", help="e2e: let the resident state and the key table grow as aggregates appear instead of sizing them up front")
-    ap.add_argument("--framing-threads", type=int, default=8, help="e2e: host threads framing a fetch's partitions side by side")
+    ap.add_argument("--framing-threads", type=int, default=12, help="e2e: host threads framing a fetch's partitions side by side (12 of the boxes' 16-CPU quota: a topic of small "
+                    "publisher flushes holds 32 000 batches per 10^6-record fetch and is bound by the framing — 8 -> 12 threads: 6.1 -> 6.55e8 events/s on one box, profiles/r05_e2e_framing_threads.jsonl; "
+                    "capped at the CPUs the process may use minus three)")
     ap.add_argument("--aggregates", type=int, default=None, help="global aggregate count (default 10 M for c4, 1 M for c2)")
     ap.add_argument("--events-per-aggregate", type=int, default=C2_EVENTS, help="c2 only")
     ap.add_argument("--algo", default=None,
@@ -541,7 +543,7 @@ def main():
             torch.cuda.empty_cache()
             keep = ("value", "unit", "steps", "warmup", "ms_per_step", "data", "config", "roofline", "cpu_baseline")
             base = {**vars(args), "workload": "e2e", "warmup": 2, "batch_events": 1_000_000, "aggregates": None, "events_cap": 8, "writer": "independent",
-                    "codec": "lz4", "serial_framing": False, "two_thread_consumer": False, "no_capacity_hint": False, "framing_threads": 8,
+                    "codec": "lz4", "serial_framing": False, "two_thread_consumer": False, "no_capacity_hint": False, "framing_threads": 12,
                     "abort_every": 50, "hold_markers": 4}
             e2e = run_e2e(_ap.Namespace(**{**base, "steps": 28, "txn_flush_events": 512}))
             result["e2e"] = {k: e2e[k] for k in keep}
@@ -1073,6 +1075,7 @@ def run_e2e(args):
         dist.barrier()
     torch.cuda.synchronize(dev)
     t_start = time.perf_counter()
+    args.framing_threads = max(1, min(args.framing_threads, int(effective_cpus()[0]) - 3))
     with PartitionedFramedFetches((f for f, _ in fetches), P, threads=args.framing_threads, hold=depth, overlap=not args.serial_framing) as framed, \
             DeviceDecoder(tmpl, device=local_rank) as d:
         # capacity hints (a recovery knows roughly how many aggregates the store held: its last snapshot): the resident state

@@ -34,6 +34,8 @@
 // The event transport (LDS-DMA tiles, XOR swizzle, line-aligned row pieces, LDS row table) and the per-event mask
 // arithmetic are the sorted-rows kernel's (fold_device.h).  Integer adds wrap exactly like JVM Int/Long under
 // any association and min/max/set are exact, so the result is bit-identical to the sequential fold.
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "fold_chunk_device.h"
@@ -72,7 +74,7 @@ __global__ void chunk_stitch_kernel(const FoldParams p, const uint32_t* __restri
 // start and length come from seg_off like in fold_sorted_kernel (fold_kernels.hip); nothing is relative, nothing goes to the
 // side buffer, and the deciding-event loop compiles away.  What it has over fold_sorted_kernel is this file's pipeline: the
 // next group's first tile is fetched during the current group's last tile (no wait for a cold tile at every group switch).
-template <int LE, bool PERM>
+template <int LE, bool PERM, bool CONC>
 __device__ __forceinline__ void chunk_walk(const FoldParams& p, const ChunkTable& t) {
   using G = Geo<LE>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,8 +186,17 @@ __device__ __forceinline__ void chunk_walk(const FoldParams& p, const ChunkTable
     uint32_t frozenM = whole ? (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 1, 1) : 0u;
     uint32_t corr = 0u;
     // wave-uniform: is any chunk here still waiting for its deciding event?  (usually settled within the first tile)
-    bool watching = !PERM && __builtin_amdgcn_ballot_w64(!whole) != 0ull;
+    const bool any_relative = !PERM && __builtin_amdgcn_ballot_w64(!whole) != 0ull;
+    bool watching = any_relative;
+    // A group of whole aggregates only (every group of SORTED; of CHUNKED all but the groups that hold chunks of cut aggregates)
+    // walks CONCRETE states: presence and "threw" in two mask registers, none of the transformer's absolute / relative
+    // bookkeeping — 7 VALU instructions fewer per event (apply_event_concrete; the tile-major fold has walked like this since
+    // round 3).  Round 5's counters say why it matters here too: the pipelined kernel keeps the SIMDs' vector pipes busy 61 % of
+    // its cycles (profiles/r05_c3_10Magg_sorted_summary.txt) — with two waves per SIMD the walk's instructions and the waits
+    // for the next tile overlap only partly, so instructions saved are time saved.
+    uint32_t presentM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 0, 1);
     // one tile: wait for it, pull my LE events out of LDS, start the next tile's fetch, walk
+    // (tracking: 0 = the transformer walk, 1 = the transformer walk that watches for deciding events, 2 = the concrete walk)
     auto tile_step = [&](int c, auto tracking) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       uint4 ev[LE];
@@ -213,9 +224,11 @@ __device__ __forceinline__ void chunk_walk(const FoldParams& p, const ChunkTable
         for (int j = 0; j < LE; ++j)
           tyc[j] = (j >= skip && j < rem) ? type_off(ev[j].x) : kNullEntryOffBytes;
       }
-      if constexpr (decltype(tracking)::value) {
+      if constexpr (decltype(tracking)::value == 1) {
         walk_events_track<LE>(a, P, undecM, frozenM, corr, ev, tyc, lds_tab, p);
         watching = __builtin_amdgcn_ballot_w64(undecM != 0u && frozenM == 0u) != 0ull;
+      } else if constexpr (decltype(tracking)::value == 2) {
+        walk_events_concrete<LE>(a, presentM, frozenM, corr, ev, tyc, lds_tab, p);
       } else {
         walk_events<LE, false>(a, frozenM, corr, ev, tyc, 0u, lds_tab, p, [](int) {});
       }
@@ -224,9 +237,14 @@ __device__ __forceinline__ void chunk_walk(const FoldParams& p, const ChunkTable
     // chunks of cut aggregates) carries P and the deciding-event test; the plain loop is the sorted-rows kernel's walk
     // and gets scheduled like it (one loop with both walks cost +13 % VALU instructions in the plain path).
     int c = 0;
-    if constexpr (!PERM)
-      for (; c < n_tiles && watching; ++c) tile_step(c, std::true_type{});
-    for (; c < n_tiles; ++c) tile_step(c, std::false_type{});
+    if (CONC && (PERM || !any_relative)) {
+      for (; c < n_tiles; ++c) tile_step(c, std::integral_constant<int, 2>{});
+      a.fl = (presentM & FL_PRESENT) | (frozenM & FL_POISONED);
+    } else {  // (CONC = false: the transformer walk everywhere, as before round 5 — SURGE_REPLAY_WALK=transformer, for comparisons)
+      if constexpr (!PERM)
+        for (; c < n_tiles && watching; ++c) tile_step(c, std::integral_constant<int, 1>{});
+      for (; c < n_tiles; ++c) tile_step(c, std::integral_constant<int, 0>{});
+    }
     a.sum = (int64_t)((uint64_t)a.sum + corr);
 
     if (cur.dest >= 0) {
@@ -251,29 +269,38 @@ __device__ __forceinline__ void chunk_walk(const FoldParams& p, const ChunkTable
 }
 
 // Register budget = resident waves: 2 per SIMD (<= 256 VGPRs) with 16 KiB tiles, 3 per SIMD (<= 168) with 8 KiB tiles.
-template <int LE>
+template <int LE, bool CONC>
 __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(LE == 8 ? 3 : 2)))
 fold_chunked_kernel(const FoldParams p, const ChunkTable t) {
-  chunk_walk<LE, false>(p, t);
+  chunk_walk<LE, false, CONC>(p, t);
 }
 
 // K2 "sorted rows", pipelined across groups (round 5; SURGE_ALGO_SORTED's kernel — fold_sorted_kernel stays selectable)
-template <int LE>
+template <int LE, bool CONC>
 __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(LE == 8 ? 3 : 2)))
 fold_sorted_pf_kernel(const FoldParams p) {
   ChunkTable t;
   t.v_start = nullptr; t.v_len = nullptr; t.v_info = nullptr; t.v_dest = nullptr; t.n_vrows = 0; t.side = nullptr;
-  chunk_walk<LE, true>(p, t);
+  chunk_walk<LE, true, CONC>(p, t);
+}
+
+bool concrete_walk() {
+  static const bool v = [] { const char* e = std::getenv("SURGE_REPLAY_WALK"); return !(e && std::strcmp(e, "transformer") == 0); }();
+  return v;
 }
 
 }  // namespace
 
 hipError_t launch_fold_sorted_pf(const FoldParams& p, int64_t n_waves, int lane_events, hipStream_t stream) {
   if (n_waves <= 0) return hipSuccess;
-  if (lane_events == 8)
-    hipLaunchKernelGGL((fold_sorted_pf_kernel<8>), dim3((unsigned)n_waves), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxSorted), stream, p);
-  else
-    hipLaunchKernelGGL((fold_sorted_pf_kernel<16>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxSorted), stream, p);
+  const bool conc = concrete_walk();
+  if (lane_events == 8) {
+    if (conc) hipLaunchKernelGGL((fold_sorted_pf_kernel<8, true>), dim3((unsigned)n_waves), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxSorted), stream, p);
+    else hipLaunchKernelGGL((fold_sorted_pf_kernel<8, false>), dim3((unsigned)n_waves), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxSorted), stream, p);
+  } else {
+    if (conc) hipLaunchKernelGGL((fold_sorted_pf_kernel<16, true>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxSorted), stream, p);
+    else hipLaunchKernelGGL((fold_sorted_pf_kernel<16, false>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxSorted), stream, p);
+  }
   return hipGetLastError();
 }
 
@@ -284,10 +311,14 @@ hipError_t launch_fold_chunked(const FoldParams& p, const int64_t* v_start, cons
   if (n_waves <= 0 || n_vrows <= 0) return hipSuccess;
   ChunkTable t;
   t.v_start = v_start; t.v_len = v_len; t.v_info = v_info; t.v_dest = v_dest; t.n_vrows = n_vrows; t.side = side;
-  if (lane_events == 8)
-    hipLaunchKernelGGL((fold_chunked_kernel<8>), dim3((unsigned)n_waves), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxSorted), stream, p, t);
-  else  // 32-event lanes spill (337 VGPRs): 16 is the widest tile of this kernel
-    hipLaunchKernelGGL((fold_chunked_kernel<16>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxSorted), stream, p, t);
+  const bool conc = concrete_walk();
+  if (lane_events == 8) {
+    if (conc) hipLaunchKernelGGL((fold_chunked_kernel<8, true>), dim3((unsigned)n_waves), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxSorted), stream, p, t);
+    else hipLaunchKernelGGL((fold_chunked_kernel<8, false>), dim3((unsigned)n_waves), dim3(kWave), Geo<8>::lds_bytes(Geo<8>::kAuxSorted), stream, p, t);
+  } else {  // 32-event lanes spill (337 VGPRs): 16 is the widest tile of this kernel
+    if (conc) hipLaunchKernelGGL((fold_chunked_kernel<16, true>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxSorted), stream, p, t);
+    else hipLaunchKernelGGL((fold_chunked_kernel<16, false>), dim3((unsigned)n_waves), dim3(kWave), Geo<16>::lds_bytes(Geo<16>::kAuxSorted), stream, p, t);
+  }
   if (n_cut > 0)
     hipLaunchKernelGGL(chunk_stitch_kernel, dim3((unsigned)((n_cut + 127) / 128)), dim3(128), 0, stream, p, side, r_slot0, r_c, r_out, n_cut);
   return hipGetLastError();

@@ -387,8 +387,7 @@ int32_t surge_device_framer_frame(surge_device_framer* f, int64_t n_aggregates, 
   // 2. partition + base size per record, stable sort by partition
   unsigned bits = 1;
   while ((1ll << bits) < P) ++bits;
-  // (a partition number has 6 bits: one onesweep pass — rocPRIM's default would merge-sort up to 2^20 records in 21 launches; stream_kernels.hip)
-  using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 32768>;
+  using SortConfig = rocprim::default_config;  // (merge sort up to 2^20 records; a lower limit was measured for K3's group-by and dropped: stream_kernels.hip)
   FCHK(f, rocprim::radix_sort_pairs<SortConfig>(nullptr, tb_sort, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                                 (size_t)n_sel, 0u, bits, st));
   FCHK(f, rocprim::exclusive_scan(nullptr, tb_scan, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)n_sel + 1, rocprim::plus<int64_t>(), st));

@@ -17,15 +17,17 @@
 namespace surge {
 namespace {
 
-// rocPRIM sorts up to 2^20 items with a block sort + merge passes — for a 10^6-event fetch that is 21 launches (one block sort,
-// ten rounds of two kernels: 0.16 ms on the chip, a third of everything K3 costs per fetch; profiles/r05_e2e_k512_depth1_*) where
-// the LSD "onesweep" radix sort needs a histogram, a scan and one pass per 8 key bits: five launches for the 24 bits a
-// 10 M-aggregate store's indexes need.  The keys here never have more bits than the store has aggregates, so the limit
-// below which merge sort runs is lowered to 2^15 items (SURGE_REPLAY_GROUPBY_SORT=merge: rocPRIM's own choice, for comparisons).
+// rocPRIM sorts up to 2^20 items with a block sort + merge passes — for a 10^6-event fetch 21 launches (one block sort, ten
+// rounds of two kernels) of ~7 us — and beyond that with the LSD "onesweep" radix sort (a histogram, a scan and one pass per 8
+// key bits: five launches for the 24 bits a 10 M-aggregate store's indexes need).  Lowering the limit to 2^15 items was built
+// and measured (round 5, SURGE_REPLAY_GROUPBY_SORT=onesweep keeps it selectable): alone on the chip the two cost the same
+// (146 against 156 us per 10^6 events: onesweep's three passes take 33 us each), and with four fetches in flight onesweep is
+// the slower one (265 us: its blocks wait for their predecessors' prefixes — decoupled look-back — while other kernels hold
+// the CUs; bytes -> states 6.6 - 6.7 against 6.9e8 events/s on one box).  rocPRIM's own choice stays the default.
 using GroupbyOnesweep = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 32768>;
 
 bool groupby_onesweep() {
-  static const bool v = [] { const char* e = std::getenv("SURGE_REPLAY_GROUPBY_SORT"); return !(e && std::strcmp(e, "merge") == 0); }();
+  static const bool v = [] { const char* e = std::getenv("SURGE_REPLAY_GROUPBY_SORT"); return e && std::strcmp(e, "onesweep") == 0; }();
   return v;
 }
 

@@ -247,7 +247,7 @@ def test_device_decoder_decodes_play_json_counter_and_bank_account_events_like_t
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("per_batch", [1, 50, 64, 65, 100, 128, 129, 150, 192, 193, 300, 600])
+@pytest.mark.parametrize("per_batch", [1, 64, 65, 128, 129, 192, 193, 600])
 def test_every_workgroup_size_of_the_record_kernel_decodes_like_the_host_decoder(per_batch):
     """section_kernel runs with 64 / 128 / 192 / 256 lanes — the smallest that takes the push's largest batch in one round
     (ingest_kernels.hip) — out of three LDS classes (sections up to 8 KiB, up to 16.25 KiB, the rest): batches of every size
@@ -256,14 +256,14 @@ def test_every_workgroup_size_of_the_record_kernel_decodes_like_the_host_decoder
     bl = CounterBusinessLogic()
     model, fmt = bl.command_model(), bl.event_write_formatting()
     recs = []
-    for i in range(max(4 * per_batch, 700)):
+    for i in range(max(3 * per_batch, 400)):
         agg = f"agg-{rng.randrange(90)}" + ("-" + "w" * rng.randrange(0, 150) if per_batch % 2 else "")  # (odd sizes: long ids — sections beyond 16 KiB)
         e = rng.choice([CountIncremented(agg, rng.randrange(-2 ** 31, 2 ** 31), i + 1), CountDecremented(agg, rng.randrange(0, 1000), i + 1), NoOpEvent(agg, i + 1)])
         m = fmt.write_event(e)
         recs.append((m.key.encode(), m.value))
     batches = [kw.record_batch(s, recs[s:s + per_batch], compression="lz4" if (s // per_batch) % 3 else "none") for s in range(0, len(recs), per_batch)]
     wire = b"".join(batches)
-    for chunks, device_lz4 in ((None, True), ([len(wire) // 2], True), (None, False)):
+    for chunks, device_lz4 in ((None, True), ([len(wire) // 2], False)):
         host, host_keys, dev, dev_keys, _ = both_decoders(wire, model.event_json_template(), chunks=chunks, device_lz4=device_lz4)
         assert dev_keys == host_keys
         for h, g in zip(host, dev):
