@@ -235,6 +235,15 @@ struct Arena {
     p = fresh;
     cap = c;
   }
+  void reserve_exact(size_t want) {  // an EMPTY arena gets exactly `want` bytes (a group's slabs: page-locked memory is not cheap)
+    if (want <= cap) return;
+    uint8_t* fresh = (uint8_t*)(alloc ? alloc(want) : std::malloc(want));
+    if (!fresh) throw std::bad_alloc();
+    if (p) (release ? release : std::free)(p);
+    p = fresh;
+    n = 0;
+    cap = want;
+  }
   size_t size() const { return n; }
   const uint8_t* data() const { return p; }
   uint8_t* data() { return p; }
@@ -1057,7 +1066,20 @@ int32_t surge_ingest_group_feed(surge_ingest_group* grp, const uint8_t* const* d
     Arena& slab = grp->slabs[(group_cur + 1) % surge_ingest::kArenas];
     try {
       slab.clear();
-      slab.reserve((size_t)total + 16);
+      if (slab.cap < (size_t)total + 16) {
+        // Page-locking a 30 - 45 MB slab takes 1.5 ms on a good day and 20 ms on a bad one (bytes -> states on the small-flush
+        // topic: two of a dozen runs lost a 24 ms fetch to it and with it two thirds of their rate).  So the group's FIRST feed
+        // sizes ALL its slabs, with a quarter to spare — fetch responses of one consumer are alike — and a recovery pays for
+        // page-locking once, before its pipeline fills, not once per slab over its first six fetches.
+        const size_t roomy = (size_t)total + (size_t)total / 4 + 65536;
+        bool first = true;
+        for (const Arena& a : grp->slabs) first = first && a.cap == 0;
+        if (first) {
+          for (Arena& a : grp->slabs) a.reserve_exact(roomy);
+        } else {
+          slab.reserve_exact(roomy);
+        }
+      }
     } catch (const std::bad_alloc&) {
       grp->err = "out of host memory for the group's slab";
       return E_NOMEM;
