@@ -209,6 +209,65 @@ def test_group_feed_is_all_or_nothing():
     assert clean == disturbed and clean[1][2] == 1600 and clean[1][3] > 0
 
 
+def test_group_sizes_all_its_slabs_at_the_first_feed():
+    """Round 5: page-locking a slab costs milliseconds (sometimes tens), so the group's FIRST feed allocates all six slabs, with a
+    quarter to spare — later fetch responses of the same size, and somewhat larger ones, allocate nothing; a response that
+    outgrows the spare re-sizes only the slab it is framed into.  Counted through the pluggable allocator the pinned slabs use."""
+    L = _native.load()
+    from surge_amd.ingest import SECTION_DTYPE
+
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes = ctypes.c_void_p, [ctypes.c_size_t]
+    libc.free.argtypes = [ctypes.c_void_p]
+    sizes, freed = [], []
+    ALLOC, FREE = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t), ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+
+    @ALLOC
+    def alloc(n):
+        sizes.append(n)
+        return libc.malloc(n)
+
+    @FREE
+    def release(ptr):
+        freed.append(ptr)
+        libc.free(ptr)
+
+    P = 3
+    rnd = random.Random(17)
+    h = ctypes.c_void_p()
+    assert L.surge_ingest_group_create(P, READ_COMMITTED | 0x200, ctypes.byref(h)) == 0
+    try:
+        L.surge_ingest_group_set_allocator.argtypes = [ctypes.c_void_p, ALLOC, FREE]
+        assert L.surge_ingest_group_set_allocator(h, alloc, release) == 0
+        off = [0] * P
+
+        def feed(n_rec, val_len):
+            bufs = []
+            for p in range(P):
+                recs = [(b"k%d:%d" % (p, i), rnd.randbytes(val_len)) for i in range(n_rec)]  # (incompressible: the frames are as large as the records)
+                bufs.append(kw.record_batch(off[p], recs, compression="lz4"))
+                off[p] += n_rec
+            arr = (ctypes.c_void_p * P)(*[ctypes.cast(ctypes.c_char_p(x), ctypes.c_void_p) for x in bufs])
+            ln = (ctypes.c_int64 * P)(*[len(x) for x in bufs])
+            secs = np.zeros(64, SECTION_DTYPE)
+            n_sec, slab = ctypes.c_int64(), ctypes.c_void_p()
+            consumed = (ctypes.c_int64 * P)()
+            assert L.surge_ingest_group_feed(h, arr, ln, 2, consumed, 64, secs.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n_sec), ctypes.byref(slab)) == 0
+            assert n_sec.value == P and [ctypes.string_at(slab.value + int(s["byte_off"]), 4) for s in secs[:P]] == [b"\x04\x22\x4d\x18"] * P  # the LZ4 frames, in the slab
+            return sum(len(x) for x in bufs)
+
+        first = feed(400, 500)
+        assert len(sizes) == 6 and len(set(sizes)) == 1 and sizes[0] >= first + first // 4 and not freed  # six slabs, alike, with room to spare
+        for _ in range(8):  # (more feeds than slabs: every slab is written again)
+            feed(400, 500 + rnd.randrange(50))
+        assert len(sizes) == 6 and not freed
+        feed(400, 4 * 500)  # a response several times the first: only the slab it goes into is re-sized
+        assert len(sizes) == 7 and sizes[6] > sizes[0] and len(freed) == 1
+    finally:
+        L.surge_ingest_group_destroy(h)
+    assert len(freed) == 7  # everything the group allocated went back through the allocator
+
+
 def test_group_without_device_lz4_decompresses_into_slices_it_sizes_by_trial():
     """host-side LZ4 in a group — a batch that expands 20 x does not fit a slice sized for its compressed
     bytes; the group undoes the feed and runs it again with more room instead of failing with 'out of host memory'."""
