@@ -16,10 +16,14 @@ resident in HBM before the timed region.  ``--workload c2`` runs BASELINE config
 The default algorithm is what a one-shot recovery runs: AUTO — the fold straight from the CSR log, no copy of it (the
 10 M-aggregate Zipf log: SORTED; C2: ROWS); ``one_shot`` carries its index build and first (cold) fold.  At N = 1 the line
 also carries ``tile_major`` — the same log through the tile-major copy (SURGE_ALGO_TILED: group-major 8 KiB subtiles
-streamed linearly), with what that copy costs once — ``secondary`` (config C2, both transports), ``c5`` (config 5, bounded)
-and ``v2`` (the ABI v2 slot path).  ``python bench.py --gpus N`` with N > 1 and no torchrun environment starts its own
-ranks (torch.distributed.run on 127.0.0.1).  ``--workload e2e [--gpus N]``: events-topic BYTES -> states on the same
-10 M-aggregate population (run_e2e's docstring).
+streamed linearly), with what that copy costs once — ``secondary`` (config C2, both transports), ``c5`` (config 5, bounded),
+``v2`` (the ABI v2 slot path), ``c4_shard`` (what ONE GPU of config C4 folds: rank 0's 1.25 M aggregates of the 8-GPU split,
+AUTO, 100 folds, every aggregate checked) and ``e2e`` (events-topic BYTES -> states over 3e7 records of the same population on
+a topic shaped like the reference's publisher writes it — one lz4 transaction + COMMIT marker per flush per partition, written
+by the independent test-side producer — with the two neighbouring topic layouts beside it; states checked against the oracle's
+fold of the source events).  ``python bench.py --gpus N`` with N > 1 and no torchrun environment starts its own
+ranks (torch.distributed.run on 127.0.0.1).  ``--workload e2e [--gpus N] [--txn-flush-events K]``: that path alone
+(run_e2e's docstring); ``--workload c4-shard``: the shard alone.
 
 Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant fold kernel against the 8 TB/s HBM peak using the
 algorithmic bytes 16*E + 8*(A+1) + 64*A and the kernel's HIP-event times measured inside the timed region on
@@ -957,8 +961,13 @@ def run_e2e(args):
     it, TestBoundedContext.scala:42-49,122-124; keys ``<id>:<seq>``), interleaved in rounds — round j holds the j-th event
     of every aggregate that has one, in a fixed pseudo-random order, so a fetch of a million records touches a million
     different aggregates: the key table and the resident state see no locality at all — over 64 partitions by the
-    reference's partitioner (KafkaPartitioner.scala:8,38-42), in record batches closed at 16 KiB and lz4-compressed like
-    the reference's producer (reference.conf:112-115), written by the product's own record-batch writer.  With N GPUs rank
+    reference's partitioner (KafkaPartitioner.scala:8,38-42), lz4-compressed like the reference's producer
+    (reference.conf:112-115) and, by default, SHAPED like its publisher's output: per partition one transaction per flush of
+    --txn-flush-events records (KafkaProducerActorImpl.scala:421-453) — data batches closed by the flush or at 16 KiB, then a
+    COMMIT control batch; every --abort-every-th flush first fails (records + ABORT marker) and is retried; on a quarter of
+    the partitions a response's last marker arrives a fetch late — written by the independent test-side producer
+    tests/native/wire_writer.c (--writer product: the product's own record-batch writer, non-transactional, every batch
+    filled to 16 KiB: round 4's topic; --txn-flush-events 0: that layout from the independent writer).  With N GPUs rank
     r consumes the partitions p % N == r (PartitionAssignments.scala:51-63) and the final snapshot is all-gathered through
     the C ABI.
 
