@@ -7,7 +7,7 @@ LIB     ?= surge_amd/libsurge_replay.so
 OBJ     ?= build/make
 FLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall
 SRC     := $(addprefix surge_amd/csrc/,$(shell grep -v "^\#" surge_amd/csrc/SOURCES))
-HDR     := include/surge_replay.h include/surge_ingest.h include/surge_snapshot.h surge_amd/csrc/replay_internal.h surge_amd/csrc/fold_layout.h surge_amd/csrc/fold_device.h surge_amd/csrc/fold_chunk_device.h surge_amd/csrc/fold_flat_device.h surge_amd/csrc/fold_slots_device.h surge_amd/csrc/f64_text.h surge_amd/csrc/f64_parse.h
+HDR     := include/surge_replay.h include/surge_ingest.h include/surge_snapshot.h surge_amd/csrc/replay_internal.h surge_amd/csrc/fold_layout.h surge_amd/csrc/fold_device.h surge_amd/csrc/fold_chunk_device.h surge_amd/csrc/fold_lane_device.h surge_amd/csrc/fold_flat_device.h surge_amd/csrc/fold_slots_device.h surge_amd/csrc/f64_text.h surge_amd/csrc/f64_parse.h
 LDDEMO  := -Lsurge_amd -lsurge_replay -Wl,-rpath,$(CURDIR)/surge_amd -L/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib
 
 .PHONY: all lib oracle demos clean

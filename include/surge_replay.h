@@ -342,6 +342,12 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo);
  * algo reuses it.  Asynchronous except for two small device->host size reads. */
 int32_t surge_replay_prepare(surge_replay_handle* h, int32_t algo);
 int32_t surge_replay_layout_info(surge_replay_handle* h, surge_replay_layout_info_t* out);
+/* The row order of the bound log's index, copied to the host (diagnostics and tests: the order is part of no result):
+ * SURGE_ALGO_SORTED — the kernel-facing aggregates (the non-empty ones, in aggregate order) by descending event count,
+ * equal counts in aggregate order; SURGE_ALGO_CHUNKED — per virtual row of the chunk table, in the order the lanes take
+ * them, its first event slot (rows by descending length, equal lengths in emission order).  order_out holds up to `capacity`
+ * entries; *n_out = the number of rows.  SURGE_E_STATE when the bound log has no such index yet (surge_replay_prepare). */
+int32_t surge_replay_index_order(surge_replay_handle* h, int32_t algo, int64_t* order_out, int64_t capacity, int64_t* n_out);
 
 /* Streaming micro-batch (K3): for every group g,
  *   state[group_agg[g]] = events[group_off[g]..group_off[g+1]).foldLeft(state[group_agg[g]])(handleEvent)

@@ -44,6 +44,7 @@ EXPORTS = (
     "surge_replay_fold",
     "surge_replay_prepare",
     "surge_replay_layout_info",
+    "surge_replay_index_order",
     "surge_replay_append_fold",
     "surge_replay_append_events",
     "surge_replay_append_events_device",
@@ -269,6 +270,7 @@ def load() -> ctypes.CDLL:
         "surge_replay_fold": ([vp, i32], i32),
         "surge_replay_prepare": ([vp, i32], i32),
         "surge_replay_layout_info": ([vp, ctypes.POINTER(CLayoutInfo)], i32),
+        "surge_replay_index_order": ([vp, i32, vp, i64, ctypes.POINTER(i64)], i32),
         "surge_replay_append_fold": ([vp, vp, vp, i64, vp, i64], i32),
         "surge_replay_append_fold_device": ([vp, vp, vp, i64, vp, i64], i32),
         "surge_replay_append_events": ([vp, vp, vp, i64], i32),

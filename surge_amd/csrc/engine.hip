@@ -70,6 +70,10 @@ struct surge_replay_handle {
   bool spec1_tried = false;
   double spec1_compile_ms = 0.0;
   std::string spec1_why;
+  V1Kernels* lanes1 = nullptr;         // v1: the lane-per-row kernels (SORTED / CHUNKED / ROWS) compiled for the op table (first lane fold / prepare)
+  bool lanes1_tried = false;
+  double lanes1_compile_ms = 0.0;
+  std::string lanes1_why;
   double spec_compile_ms = 0.0;
   std::string spec_why;                // why the interpreter runs instead / which libhiprtc compiled the kernels
   std::string err;
@@ -92,16 +96,19 @@ struct surge_replay_handle {
   DevBuf perm, counter;  // SORTED: segments by descending length (built lazily, per bound log)
   // scratch of the index builds (index_kernels.hip): rocPRIM temp, sort keys / values, the chunk table's counts and its
   // rows in aggregate order; released once the bound log's index stands
-  DevBuf ix_temp, ix_keys_a, ix_keys_b, ix_vals_a, ix_vals_b, ix_cnt, ix_u_start, ix_u_len, ix_u_info, ix_u_dest;
+  // (two allocations, carved: a hipMalloc costs 50 - 300 us and a hipFree waits for the device — ten of each were most of
+  // the chunk table's 3 - 7 ms in round 5)
+  DevBuf ix_arena, ix_cnt;
   bool perm_valid = false;
   // CHUNKED / TILED: the chunk table (built lazily, per bound log), the chunk summaries and the list of cut aggregates
   struct ChunkIndex {
-    DevBuf v_start, v_len, v_info, v_seg, v_side, r_slot0, r_c, r_out;
+    DevBuf arena;  // one allocation; the pointers below are views into it
+    void *v_start = nullptr, *v_len = nullptr, *v_info = nullptr, *v_seg = nullptr, *v_side = nullptr, *r_slot0 = nullptr, *r_c = nullptr, *r_out = nullptr;
     int64_t n_vrows = 0, n_cut_rows = 0;
     uint32_t T = 0;  // the chunk target the table was built for (0 = none built)
     void release() {
-      DevBuf* b[] = {&v_start, &v_len, &v_info, &v_seg, &v_side, &r_slot0, &r_c, &r_out};
-      for (DevBuf* x : b) x->release();
+      arena.release();
+      v_start = v_len = v_info = v_seg = v_side = r_slot0 = r_c = r_out = nullptr;
       n_vrows = n_cut_rows = 0;
       T = 0;
     }
@@ -186,10 +193,21 @@ int32_t fail_hip(surge_replay_handle* h, hipError_t e, const char* what) {
 const V1Kernels* flat_spec(surge_replay_handle* h, const FoldParams& p) {
   if (!h->spec1_tried) {
     h->spec1_tried = true;
-    v1_kernels_acquire(p.table, h->device, &h->spec1, &h->spec1_compile_ms, &h->spec1_why);
+    v1_kernels_acquire(p.table, h->device, V1_FLAT, &h->spec1, &h->spec1_compile_ms, &h->spec1_why);
     if (h->spec1) h->spec1_why = std::string("flat kernel compiled for the op table by ") + rtc_library_path();
   }
   return h->spec1;
+}
+
+// ... and the lane-per-row kernels (SORTED / CHUNKED / ROWS): compiled at surge_replay_prepare or the first such fold — like
+// the per-log index, before the fold's timing events, never between them
+const V1Kernels* lane_spec(surge_replay_handle* h, const FoldParams& p) {
+  if (!h->lanes1_tried) {
+    h->lanes1_tried = true;
+    v1_kernels_acquire(p.table, h->device, V1_LANES, &h->lanes1, &h->lanes1_compile_ms, &h->lanes1_why);
+    if (h->lanes1) h->lanes1_why = "compiled for the op table";
+  }
+  return h->lanes1;
 }
 
 void fill_params(const surge_replay_schema& schema, FoldParams& p) {
@@ -368,29 +386,40 @@ int32_t dispenser_begin(surge_replay_handle* h, FoldParams& p) {
   return SURGE_OK;
 }
 
-// scratch for ordering n rows by length (vals_b only when the caller does not supply its own output)
-int32_t index_scratch(surge_replay_handle* h, int64_t n, bool need_vals_b, IndexScratch* sc) {
-  size_t tb = 0;
-  HIPCHK(h, index_temp_bytes(n, &tb));
+// scratch for ordering n rows by length (vals_b only when the caller does not supply its own output).  max_key: the largest
+// key among them — below kCountSortMaxBins the hand-written counting sort orders them (its histograms are the only scratch),
+// else rocPRIM's radix sort (temp + key / value double buffers).  min_temp: bytes the caller wants of `temp` besides.
+int32_t index_scratch(surge_replay_handle* h, int64_t n, bool need_vals_b, int64_t max_key, size_t min_temp, IndexScratch* sc, size_t extra_bytes = 0,
+                      void** extra = nullptr) {
   const size_t rows = (size_t)(n > 0 ? n : 1);
-  HIPCHK(h, h->ix_temp.reserve(tb));
-  HIPCHK(h, h->ix_keys_a.reserve(rows * 4));
-  HIPCHK(h, h->ix_keys_b.reserve(rows * 4));
-  HIPCHK(h, h->ix_vals_a.reserve(rows * 8));
-  if (need_vals_b) HIPCHK(h, h->ix_vals_b.reserve(rows * 8));
-  sc->temp = h->ix_temp.ptr;
+  const char* sort_env = std::getenv("SURGE_REPLAY_INDEX_SORT");  // "radix": rocPRIM's radix sort whatever the keys (the test that compares the two orders)
+  const bool force_radix = sort_env && std::strcmp(sort_env, "radix") == 0;
+  sc->counting = !force_radix && max_key >= 0 && max_key < kCountSortMaxBins;
+  sc->max_key = (uint32_t)(max_key > 0 ? max_key : 0);
+  sc->n_cus = h->n_cus;
+  size_t tb = 0;
+  if (sc->counting) tb = count_sort_scratch_bytes(n, sc->max_key, h->n_cus);
+  else HIPCHK(h, index_temp_bytes(n, &tb));
+  tb = tb > min_temp ? tb : min_temp;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t o_keys_a = up(tb), o_keys_b = o_keys_a + up(rows * 4), o_vals_a = o_keys_b + (sc->counting ? 0 : up(rows * 4)),
+               o_vals_b = o_vals_a + (sc->counting ? 0 : up(rows * 8)), o_extra = o_vals_b + (need_vals_b ? up(rows * 8) : 0);
+  HIPCHK(h, h->ix_arena.reserve(o_extra + extra_bytes));
+  char* base = (char*)h->ix_arena.ptr;
+  sc->temp = base;
   sc->temp_bytes = tb;
-  sc->keys_a = (uint32_t*)h->ix_keys_a.ptr;
-  sc->keys_b = (uint32_t*)h->ix_keys_b.ptr;
-  sc->vals_a = (int64_t*)h->ix_vals_a.ptr;
-  sc->vals_b = (int64_t*)h->ix_vals_b.ptr;
+  sc->keys_a = (uint32_t*)(base + o_keys_a);
+  sc->keys_b = sc->counting ? nullptr : (uint32_t*)(base + o_keys_b);
+  sc->vals_a = sc->counting ? nullptr : (int64_t*)(base + o_vals_a);
+  sc->vals_b = need_vals_b ? (int64_t*)(base + o_vals_b) : nullptr;
+  if (extra) *extra = base + o_extra;
   return SURGE_OK;
 }
 
 // a bound log's index stands: give the build scratch back (a 10 M-aggregate log's is ~0.6 GB); micro-batch sorts keep theirs
 void index_scratch_release(surge_replay_handle* h) {
-  DevBuf* b[] = {&h->ix_temp, &h->ix_keys_a, &h->ix_keys_b, &h->ix_vals_a, &h->ix_vals_b, &h->ix_cnt, &h->ix_u_start, &h->ix_u_len, &h->ix_u_info, &h->ix_u_dest};
-  for (DevBuf* x : b) x->release();
+  h->ix_arena.release();
+  h->ix_cnt.release();
 }
 
 // v2: length-sort the kernel-facing segments (once per bound log / per micro-batch), then one lane per segment
@@ -398,7 +427,8 @@ int32_t run_slots(surge_replay_handle* h, FoldParams& p, const int64_t* off, int
   if (!cache_perm || !h->perm_valid) {
     HIPCHK(h, h->perm.reserve((size_t)(n_seg > 0 ? n_seg : 1) * 8));
     IndexScratch sc;
-    const int32_t rcs = index_scratch(h, n_seg, false, &sc);
+    // (a micro-batch's longest group is not known on the host: the radix sort; a bound log's longest aggregate is)
+    const int32_t rcs = index_scratch(h, n_seg, false, cache_perm ? h->an.max_len : -1, 0, &sc);
     if (rcs != SURGE_OK) return rcs;
     HIPCHK(h, launch_sort_by_length(off, n_seg, sc, (int64_t*)h->perm.ptr, h->stream));
     h->perm_valid = cache_perm;
@@ -591,7 +621,7 @@ int32_t surge_replay_destroy(surge_replay_handle* h) {
   h->host_flags = nullptr;
   h->cidx.release();
   h->tidx.release();
-  DevBuf* bufs[] = {&h->gb_temp, &h->gb_u32, &h->gb_flags, &h->gb_agg_idx, &h->gb_events, &h->published, &h->gathered[0], &h->gathered[1], &h->f64_tables, &h->nan_count, &h->ix_temp, &h->ix_keys_a, &h->ix_keys_b, &h->ix_vals_a, &h->ix_vals_b, &h->ix_cnt, &h->ix_u_start, &h->ix_u_len, &h->ix_u_info, &h->ix_u_dest, &h->t_tiles, &h->t_gsub, &h->perm, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
+  DevBuf* bufs[] = {&h->gb_temp, &h->gb_u32, &h->gb_flags, &h->gb_agg_idx, &h->gb_events, &h->published, &h->gathered[0], &h->gathered[1], &h->f64_tables, &h->nan_count, &h->ix_arena, &h->ix_cnt, &h->t_tiles, &h->t_gsub, &h->perm, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
                     &h->nz_map, &h->block_counts, &h->plan, &h->batch_group_agg, &h->batch_group_off,
                     &h->batch_events, &h->poison_count, &h->gather_idx, &h->gather_out, &h->scan_totals};
   for (DevBuf* b : bufs) b->release();
@@ -795,40 +825,43 @@ int32_t plan_fold(surge_replay_handle* h, int32_t algo, FoldPlan& pl) {
 // chunk table of the kernel-facing CSR for chunk target T (align: rows tiled from their 128-byte lines — CHUNKED)
 int32_t build_chunk_index(surge_replay_handle* h, surge_replay_handle::ChunkIndex& ci, const int64_t* off, int64_t n_seg, uint32_t T,
                           bool align) {
-  IndexScratch sc;
-  {
-    const int32_t rcs = index_scratch(h, n_seg + 1, true, &sc);
-    if (rcs != SURGE_OK) return rcs;
-  }
-  HIPCHK(h, h->ix_cnt.reserve((size_t)(n_seg + 1) * 3 * 8));
+  // a virtual row is at most T + 7 slots long (an aggregate in one piece: at most T; a chunk: span / c rounded to lines)
+  const int64_t max_row = (int64_t)T + 7 < h->an.max_len + 7 ? (int64_t)T + 7 : h->an.max_len + 7;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  // phase 1: the three counts per aggregate and their scans (one allocation: counts, then the scans' block sums)
+  const size_t cnt_bytes = up((size_t)(n_seg + 1) * 3 * 8);
+  HIPCHK(h, h->ix_cnt.reserve(cnt_bytes + scan_i64_scratch_bytes(n_seg + 1, 3)));
   int64_t* cnt = (int64_t*)h->ix_cnt.ptr;
-  HIPCHK(h, launch_chunk_count(off, n_seg, T, align, cnt, sc, h->stream));
+  HIPCHK(h, launch_chunk_count(off, n_seg, T, align, cnt, (char*)h->ix_cnt.ptr + cnt_bytes, h->stream));
   int64_t totals[3] = {0, 0, 0};  // virtual rows, cut aggregates, side slots
   for (int k = 0; k < 3; ++k)
     HIPCHK(h, hipMemcpyAsync(&totals[k], cnt + (int64_t)k * (n_seg + 1) + n_seg, 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   ci.n_vrows = totals[0];
   ci.n_cut_rows = totals[1];
-  HIPCHK(h, ci.v_start.reserve((size_t)ci.n_vrows * 8));
-  HIPCHK(h, ci.v_seg.reserve((size_t)ci.n_vrows * 8));
-  HIPCHK(h, ci.v_len.reserve((size_t)ci.n_vrows * 4));
-  HIPCHK(h, ci.v_info.reserve((size_t)ci.n_vrows * 4));
-  HIPCHK(h, ci.v_side.reserve((size_t)totals[2] * 80));
-  HIPCHK(h, ci.r_slot0.reserve((size_t)totals[1] * 8));
-  HIPCHK(h, ci.r_out.reserve((size_t)totals[1] * 8));
-  HIPCHK(h, ci.r_c.reserve((size_t)totals[1] * 4));
+  // phase 2: the table itself (one allocation) ...
+  const size_t rows = (size_t)(ci.n_vrows > 0 ? ci.n_vrows : 1), cut = (size_t)(totals[1] > 0 ? totals[1] : 1), slots = (size_t)(totals[2] > 0 ? totals[2] : 1);
   {
-    const int32_t rcs = index_scratch(h, ci.n_vrows, true, &sc);  // the rows (>= aggregates) are what gets sorted
+    const size_t o_start = 0, o_seg = o_start + up(rows * 8), o_len = o_seg + up(rows * 8), o_info = o_len + up(rows * 4), o_side = o_info + up(rows * 4),
+                 o_slot0 = o_side + up(slots * 80), o_out = o_slot0 + up(cut * 8), o_c = o_out + up(cut * 8), total = o_c + up(cut * 4);
+    HIPCHK(h, ci.arena.reserve(total));
+    char* b = (char*)ci.arena.ptr;
+    ci.v_start = b + o_start; ci.v_seg = b + o_seg; ci.v_len = b + o_len; ci.v_info = b + o_info; ci.v_side = b + o_side;
+    ci.r_slot0 = b + o_slot0; ci.r_out = b + o_out; ci.r_c = b + o_c;
+  }
+  // ... and the scratch of its build (one allocation): the sort's, then the rows in aggregate order
+  IndexScratch sc;
+  void* extra = nullptr;
+  const size_t o_ustart = 0, o_udest = o_ustart + up(rows * 8), o_ulen = o_udest + up(rows * 8), o_uinfo = o_ulen + up(rows * 4), u_total = o_uinfo + up(rows * 4);
+  {
+    const int32_t rcs = index_scratch(h, ci.n_vrows, true, max_row, 0, &sc, u_total, &extra);  // the rows (>= aggregates) are what gets sorted
     if (rcs != SURGE_OK) return rcs;
   }
-  HIPCHK(h, h->ix_u_start.reserve((size_t)ci.n_vrows * 8));
-  HIPCHK(h, h->ix_u_dest.reserve((size_t)ci.n_vrows * 8));
-  HIPCHK(h, h->ix_u_len.reserve((size_t)ci.n_vrows * 4));
-  HIPCHK(h, h->ix_u_info.reserve((size_t)ci.n_vrows * 4));
+  char* u = (char*)extra;
   HIPCHK(h, launch_chunk_table(off, n_seg, h->an.n_empty > 0 ? (const int64_t*)h->nz_map.ptr : nullptr, T, align, cnt, ci.n_vrows, sc,
-                               (int64_t*)h->ix_u_start.ptr, (uint32_t*)h->ix_u_len.ptr, (uint32_t*)h->ix_u_info.ptr, (int64_t*)h->ix_u_dest.ptr,
-                               (int64_t*)ci.v_start.ptr, (uint32_t*)ci.v_len.ptr, (uint32_t*)ci.v_info.ptr, (int64_t*)ci.v_seg.ptr,
-                               (int64_t*)ci.r_slot0.ptr, (uint32_t*)ci.r_c.ptr, (int64_t*)ci.r_out.ptr, h->stream));
+                               (int64_t*)(u + o_ustart), (uint32_t*)(u + o_ulen), (uint32_t*)(u + o_uinfo), (int64_t*)(u + o_udest),
+                               (int64_t*)ci.v_start, (uint32_t*)ci.v_len, (uint32_t*)ci.v_info, (int64_t*)ci.v_seg,
+                               (int64_t*)ci.r_slot0, (uint32_t*)ci.r_c, (int64_t*)ci.r_out, h->stream));
   ci.T = T;
   return SURGE_OK;
 }
@@ -843,7 +876,7 @@ int32_t ensure_index(surge_replay_handle* h, const FoldPlan& pl) {
   if (pl.use == SURGE_ALGO_SORTED && !h->perm_valid) {
     HIPCHK(h, h->perm.reserve((size_t)n_seg * 8));
     IndexScratch sc;
-    const int32_t rcs = index_scratch(h, n_seg, false, &sc);
+    const int32_t rcs = index_scratch(h, n_seg, false, h->an.max_len, 0, &sc);
     if (rcs != SURGE_OK) return rcs;
     HIPCHK(h, hipEventRecord(h->ev_i0, h->stream));
     HIPCHK(h, launch_sort_by_length(off, n_seg, sc, (int64_t*)h->perm.ptr, h->stream));
@@ -867,7 +900,7 @@ int32_t ensure_index(surge_replay_handle* h, const FoldPlan& pl) {
     if (rc != SURGE_OK) return rc;
     const int64_t n_groups = (h->tidx.n_vrows + kWave - 1) / kWave;
     HIPCHK(h, h->t_gsub.reserve((size_t)(n_groups + 1) * 8));
-    HIPCHK(h, launch_tile_index((const uint32_t*)h->tidx.v_len.ptr, h->tidx.n_vrows, (int64_t*)h->t_gsub.ptr, h->stream));
+    HIPCHK(h, launch_tile_index((const uint32_t*)h->tidx.v_len, h->tidx.n_vrows, (int64_t*)h->t_gsub.ptr, h->stream));
     HIPCHK(h, launch_exclusive_scan_i64((int64_t*)h->t_gsub.ptr, n_groups, h->stream));
     int64_t n_sub = 0;
     HIPCHK(h, hipMemcpyAsync(&n_sub, (int64_t*)h->t_gsub.ptr + n_groups, 8, hipMemcpyDeviceToHost, h->stream));
@@ -876,12 +909,12 @@ int32_t ensure_index(surge_replay_handle* h, const FoldPlan& pl) {
     h->t_n_sub = n_sub;
     HIPCHK(h, h->t_tiles.reserve((size_t)n_sub * kTileSubBytes));
     HIPCHK(h, hipEventRecord(h->ev_r0, h->stream));
-    HIPCHK(h, launch_relayout(h->d_events, (const int64_t*)h->tidx.v_start.ptr, (const uint32_t*)h->tidx.v_len.ptr, h->tidx.n_vrows,
+    HIPCHK(h, launch_relayout(h->d_events, (const int64_t*)h->tidx.v_start, (const uint32_t*)h->tidx.v_len, h->tidx.n_vrows,
                               (const int64_t*)h->t_gsub.ptr, n_sub, (uint4*)h->t_tiles.ptr, h->stream));
     HIPCHK(h, hipEventRecord(h->ev_r1, h->stream));
     if (std::getenv("SURGE_DBG_PRINT"))
       std::fprintf(stderr, "[surge dbg] tiles %p (%lld subtiles) v_len %p v_info %p v_dest %p g_sub %p state %p events %p\n", h->t_tiles.ptr,
-                   (long long)n_sub, h->tidx.v_len.ptr, h->tidx.v_info.ptr, h->tidx.v_seg.ptr, h->t_gsub.ptr, (void*)h->d_state, (const void*)h->d_events);
+                   (long long)n_sub, h->tidx.v_len, h->tidx.v_info, h->tidx.v_seg, h->t_gsub.ptr, (void*)h->d_state, (const void*)h->d_events);
     h->tiled_valid = true;
     h->index_timed = h->relayout_timed = true;
     h->index_algo = SURGE_ALGO_TILED;
@@ -908,8 +941,8 @@ int32_t run_slots_tiled(surge_replay_handle* h, FoldParams& p) {
   const int64_t slots = (int64_t)h->n_cus * per_cu;
   const int64_t n_waves = groups < slots ? groups : slots;
   TileTable t;
-  t.tiles = (const uint4*)h->t_tiles.ptr; t.g_sub0 = (const int64_t*)h->t_gsub.ptr; t.v_len = (const uint32_t*)ci.v_len.ptr;
-  t.v_info = (const uint32_t*)ci.v_info.ptr; t.v_dest = (const int64_t*)ci.v_seg.ptr; t.n_vrows = ci.n_vrows; t.side = nullptr;
+  t.tiles = (const uint4*)h->t_tiles.ptr; t.g_sub0 = (const int64_t*)h->t_gsub.ptr; t.v_len = (const uint32_t*)ci.v_len;
+  t.v_info = (const uint32_t*)ci.v_info; t.v_dest = (const int64_t*)ci.v_seg; t.n_vrows = ci.n_vrows; t.side = nullptr;
   hipEvent_t e0, e1;
   const int32_t rc = next_fold_events(h, &e0, &e1);
   if (rc != SURGE_OK) return rc;
@@ -935,8 +968,9 @@ int32_t surge_replay_kernel_info(surge_replay_handle* h, surge_replay_kernel_inf
   }
   out->specialised = h->v2 ? (h->spec ? 1 : 0) : (h->spec1 ? 1 : 0);
   out->compile_ms = h->v2 ? h->spec_compile_ms : h->spec1_compile_ms;
-  const std::string d = h->v2 ? h->spec_why
-                              : (h->spec1 ? h->spec1_why : "v1 schema, ahead-of-time kernels interpret the op table: " + h->spec1_why);
+  std::string d = h->v2 ? h->spec_why
+                        : (h->spec1 ? h->spec1_why : "v1 schema, ahead-of-time kernels interpret the op table: " + h->spec1_why);
+  if (!h->v2 && h->lanes1_tried) d = "lane kernels " + (h->lanes1 ? h->lanes1_why : "ahead of time (" + h->lanes1_why.substr(0, 60) + ")") + "; " + d;
   std::snprintf(out->detail, sizeof(out->detail), "%s", d.c_str());
   return SURGE_OK;
 }
@@ -950,11 +984,17 @@ int32_t surge_replay_compile_schema(const surge_replay_schema* schema, const cha
   }
   FoldParams p;
   fill_params(*schema, p);
-  const std::string src = v1_spec_source(p.table);
+  const std::string src = v1_spec_source(p.table, V1_FLAT);
   if (src.empty()) return fail(nullptr, SURGE_E_UNSUPPORTED, "the op table holds words the specialised build cannot express");
   std::vector<char> code;
   std::string log;
   double ms = 0.0;
+  if (const char* v = std::getenv("SURGE_REPLAY_RTC_LANES")) {
+    if (std::atoi(v) != 0) {  // the lane kernels' program too (its code object goes to the disk cache, not to the caller)
+      std::vector<char> lanes;
+      if (!rtc_compile(v1_spec_source(p.table, V1_LANES), arch, &lanes, &log, &ms)) return fail(nullptr, SURGE_E_UNSUPPORTED, log);
+    }
+  }
   if (!rtc_compile(src, arch, &code, &log, &ms)) return fail(nullptr, SURGE_E_UNSUPPORTED, log);
   *code_bytes = (int64_t)code.size();
   if (code_out) {
@@ -993,6 +1033,11 @@ int32_t surge_replay_prepare(surge_replay_handle* h, int32_t algo) {
   const int32_t rc = plan_fold(h, algo, pl);
   if (rc != SURGE_OK) return rc;
   if (h->v2 && pl.use != SURGE_ALGO_TILED) return SURGE_OK;  // the slot kernel's length order is built by its first fold
+  if (!h->v2 && (pl.use == SURGE_ALGO_SORTED || pl.use == SURGE_ALGO_CHUNKED || pl.use == SURGE_ALGO_ROWS)) {
+    FoldParams p;
+    fill_params(h, p);
+    (void)lane_spec(h, p);  // the kernels for this op table (hiprtc, or the code-object cache on disk)
+  }
   return ensure_index(h, pl);
 }
 
@@ -1026,6 +1071,32 @@ int32_t surge_replay_layout_info(surge_replay_handle* h, surge_replay_layout_inf
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev_r0, h->ev_r1));
     out->relayout_ms = ms;
+  }
+  return SURGE_OK;
+}
+
+int32_t surge_replay_index_order(surge_replay_handle* h, int32_t algo, int64_t* order_out, int64_t capacity, int64_t* n_out) {
+  if (!h || !n_out) return fail(h, SURGE_E_INVALID, "NULL argument");
+  *n_out = 0;
+  if (!h->bound) return fail(h, SURGE_E_STATE, "index_order before load_csr/bind_device_csr");
+  if (capacity < 0 || (capacity > 0 && !order_out)) return fail(h, SURGE_E_INVALID, "bad capacity / buffer");
+  DeviceGuard g(h->device);
+  const void* src = nullptr;
+  int64_t n = 0;
+  if (algo == SURGE_ALGO_SORTED && h->perm_valid && !h->v2) {
+    src = h->perm.ptr;
+    n = h->an.n_empty > 0 ? h->n_nz : h->n_agg;
+  } else if (algo == SURGE_ALGO_CHUNKED && h->cidx.T != 0) {
+    src = h->cidx.v_start;
+    n = h->cidx.n_vrows;
+  } else {
+    return fail(h, SURGE_E_STATE, "the bound log has no index of that kind (surge_replay_prepare / fold with SURGE_ALGO_SORTED or _CHUNKED first)");
+  }
+  *n_out = n;
+  const int64_t take = n < capacity ? n : capacity;
+  if (take > 0) {
+    HIPCHK(h, hipMemcpyAsync(order_out, src, (size_t)take * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
   }
   return SURGE_OK;
 }
@@ -1082,8 +1153,9 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       hipEvent_t e0, e1;
       const int32_t rc = next_fold_events(h, &e0, &e1);
       if (rc != SURGE_OK) return rc;
+      const V1Kernels* lanes = lane_spec(h, p);
       HIPCHK(h, hipEventRecord(e0, h->stream));
-      HIPCHK(h, launch_fold_rows(p, n_tasks, le, h->stream));
+      HIPCHK(h, launch_fold_rows(p, lanes, n_tasks, le, h->stream));
       HIPCHK(h, hipEventRecord(e1, h->stream));
       h->st.n_tasks = (int32_t)n_tasks;
     } else if (use == SURGE_ALGO_FIXED) {
@@ -1118,18 +1190,19 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       const int64_t groups = (n_seg + kWave - 1) / kWave;
       // resident waves per CU = min(LDS, registers): 8 KiB tiles 12 (136 VGPRs), 16 KiB tiles 8 (18.6 KB LDS), 32 KiB tiles 4
       int64_t per_cu = le == 8 ? 12 : (le == 16 ? 8 : 4);
-      if (const char* v = std::getenv("SURGE_REPLAY_SORTED_WAVES")) per_cu = std::atoi(v) > 0 && std::atoi(v) < per_cu ? std::atoi(v) : per_cu;  // (experiments: fewer)
+      if (const char* v = std::getenv("SURGE_REPLAY_SORTED_WAVES")) per_cu = std::atoi(v) > 0 ? std::atoi(v) : per_cu;  // (experiments)
       const int64_t slots = (int64_t)h->n_cus * per_cu;
       const int64_t n_waves = groups < slots ? groups : slots;
       hipEvent_t e0, e1;
       const int32_t rc = next_fold_events(h, &e0, &e1);
       if (rc != SURGE_OK) return rc;
+      const V1Kernels* lanes = lane_spec(h, p);
       HIPCHK(h, hipEventRecord(e0, h->stream));
       // round 5: the walk that fetches the next group's first tile during this group's last one (fold_sorted_pf_kernel);
       // SURGE_REPLAY_SORTED_KERNEL=plain keeps fold_sorted_kernel for a same-box comparison, and 32-event lanes are its only
       static const bool plain = [] { const char* v = std::getenv("SURGE_REPLAY_SORTED_KERNEL"); return v && std::strcmp(v, "plain") == 0; }();
-      if (plain || le == 32) HIPCHK(h, launch_fold_sorted(p, n_waves, le, h->stream));
-      else HIPCHK(h, launch_fold_sorted_pf(p, n_waves, le, h->stream));
+      if (plain || (le == 32 && !lanes)) HIPCHK(h, launch_fold_sorted(p, n_waves, le, h->stream));
+      else HIPCHK(h, launch_fold_sorted_pf(p, lanes, n_waves, le, h->stream));
       HIPCHK(h, hipEventRecord(e1, h->stream));
       h->st.n_tasks = (int32_t)n_waves;
     } else if (use == SURGE_ALGO_CHUNKED) {
@@ -1147,10 +1220,11 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       hipEvent_t e0, e1;
       const int32_t rc = next_fold_events(h, &e0, &e1);
       if (rc != SURGE_OK) return rc;
+      const V1Kernels* lanes = lane_spec(h, p);
       HIPCHK(h, hipEventRecord(e0, h->stream));  // the stitch kernel is timed with the fold: it is part of it
-      HIPCHK(h, launch_fold_chunked(p, (const int64_t*)ci.v_start.ptr, (const uint32_t*)ci.v_len.ptr, (const uint32_t*)ci.v_info.ptr,
-                                    (const int64_t*)ci.v_seg.ptr, ci.n_vrows, (uint32_t*)ci.v_side.ptr, (const int64_t*)ci.r_slot0.ptr,
-                                    (const uint32_t*)ci.r_c.ptr, (const int64_t*)ci.r_out.ptr, ci.n_cut_rows, n_waves, le, h->stream));
+      HIPCHK(h, launch_fold_chunked(p, (const int64_t*)ci.v_start, (const uint32_t*)ci.v_len, (const uint32_t*)ci.v_info,
+                                    (const int64_t*)ci.v_seg, ci.n_vrows, (uint32_t*)ci.v_side, (const int64_t*)ci.r_slot0,
+                                    (const uint32_t*)ci.r_c, (const int64_t*)ci.r_out, ci.n_cut_rows, lanes, n_waves, le, h->stream));
       HIPCHK(h, hipEventRecord(e1, h->stream));
       h->st.n_tasks = (int32_t)n_waves;
     } else if (use == SURGE_ALGO_TILED) {
@@ -1174,10 +1248,10 @@ int32_t surge_replay_fold(surge_replay_handle* h, int32_t algo) {
       if (rc != SURGE_OK) return rc;
       HIPCHK(h, hipEventRecord(e0, h->stream));  // the stitch kernel is timed with the fold: it is part of it
       HIPCHK(h, launch_fold_tiled(p, (const uint4*)h->t_tiles.ptr, (const int64_t*)h->t_gsub.ptr,
-                                  (const uint32_t*)ci.v_len.ptr, (const uint32_t*)ci.v_info.ptr, (const int64_t*)ci.v_seg.ptr, ci.n_vrows,
-                                  (uint32_t*)ci.v_side.ptr, n_waves, subs, h->stream));
-      HIPCHK(h, launch_chunk_stitch(p, (const uint32_t*)ci.v_side.ptr, (const int64_t*)ci.r_slot0.ptr, (const uint32_t*)ci.r_c.ptr,
-                                    (const int64_t*)ci.r_out.ptr, ci.n_cut_rows, h->stream));
+                                  (const uint32_t*)ci.v_len, (const uint32_t*)ci.v_info, (const int64_t*)ci.v_seg, ci.n_vrows,
+                                  (uint32_t*)ci.v_side, n_waves, subs, h->stream));
+      HIPCHK(h, launch_chunk_stitch(p, (const uint32_t*)ci.v_side, (const int64_t*)ci.r_slot0, (const uint32_t*)ci.r_c,
+                                    (const int64_t*)ci.r_out, ci.n_cut_rows, h->stream));
       HIPCHK(h, hipEventRecord(e1, h->stream));
       h->st.n_tasks = (int32_t)n_waves;
     } else if (h->an.n_empty > 0) {

@@ -20,6 +20,28 @@ template <int LE>
 __device__ __forceinline__ void walk_events_track(Acc& a, Acc& P, uint32_t& undecM, uint32_t& frozenM, uint32_t& corr,
                                                   const uint4* ev, const uint32_t* tyc, const uint32_t* lds_tab,
                                                   const FoldParams& p) {
+  auto decide = [&](uint32_t firstM) {  // wave-uniform branch around it; taken once or twice per chunk
+    a.sum = (int64_t)((uint64_t)a.sum + corr);
+    corr = 0u;
+    const bool f = firstM != 0u;
+    P = select_acc(f, a, P);
+    a = select_acc(f, acc_identity(), a);
+    undecM = andn(undecM, firstM);
+  };
+  if (kSpecV1) {
+#pragma unroll
+    for (int j = 0; j < LE; ++j) {
+      const uint32_t e = tyc[j];
+      const uint4 q0 = {spec_word<0>(e), spec_word<1>(e), spec_word<2>(e), spec_word<3>(e)};
+      const uint4 q1 = {spec_word<4>(e), spec_word<5>(e), spec_word<6>(e), spec_word<7>(e)};
+      const uint4 q2 = {spec_word<8>(e), spec_word<9>(e), spec_word<10>(e), spec_word<11>(e)};
+      const uint2 q3 = {spec_word<12>(e), spec_word<13>(e)};
+      const uint32_t firstM = undecM & q2.z & ~(frozenM | q2.x);
+      if (__builtin_amdgcn_ballot_w64(firstM != 0u) != 0ull) decide(firstM);
+      apply_event(a, frozenM, corr, q0, q1, q2, q3, ev[j].y, ev[j].z, ev[j].w, p);
+    }
+    return;
+  }
   uint4 tq0, tq1, tq2;
   uint2 tq3;
   {
@@ -36,14 +58,7 @@ __device__ __forceinline__ void walk_events_track(Acc& a, Acc& P, uint32_t& unde
     }
     // live (not ignored, not throwing) and not of class REQUIRE: from here on the state is Some or an absolute None
     const uint32_t firstM = undecM & tq2.z & ~(frozenM | tq2.x);
-    if (__builtin_amdgcn_ballot_w64(firstM != 0u) != 0ull) {  // wave-uniform; taken once or twice per chunk
-      a.sum = (int64_t)((uint64_t)a.sum + corr);
-      corr = 0u;
-      const bool f = firstM != 0u;
-      P = select_acc(f, a, P);
-      a = select_acc(f, acc_identity(), a);
-      undecM = andn(undecM, firstM);
-    }
+    if (__builtin_amdgcn_ballot_w64(firstM != 0u) != 0ull) decide(firstM);
     apply_event(a, frozenM, corr, tq0, tq1, tq2, tq3, ev[j].y, ev[j].z, ev[j].w, p);
     tq0 = nq0; tq1 = nq1; tq2 = nq2; tq3 = nq3;
     __builtin_amdgcn_sched_barrier(0);
@@ -95,6 +110,10 @@ struct ChunkTable {
   const int64_t* v_dest;   // aggregate index (state array) or side-buffer slot
   int64_t n_vrows;
   uint32_t* side;
+};
+struct ChunkArgs {  // the argument block of a run-time compiled chunked kernel (one by-value struct: hipModuleLaunchKernel's buffer form)
+  FoldParams p;
+  ChunkTable t;
 };
 
 }  // namespace

@@ -160,41 +160,74 @@ __device__ __forceinline__ void apply_event_concrete(Acc& a, uint32_t& presentM,
   const uint32_t appM = andn(goM, q2.y) & (presentM | q2.z);            // REQUIRE-class events skip None
   const uint32_t rstM = appM & (q2.w | ~presentM);                      // CREATE, or materialising from None
   presentM = andn(presentM, delM) | rstM;
-
-  uint32_t count = bfi(rstM, (uint32_t)p.d_count, (uint32_t)a.count);
-  uint32_t version = bfi(rstM, (uint32_t)p.d_version, (uint32_t)a.version);
-  uint32_t sum_lo = bfi(rstM, (uint32_t)p.d_sum, (uint32_t)a.sum);
-  uint32_t sum_hi = bfi(rstM, (uint32_t)((uint64_t)p.d_sum >> 32), (uint32_t)((uint64_t)a.sum >> 32));
-  uint32_t bal_lo = bfi(rstM, (uint32_t)p.d_balance, (uint32_t)a.bal);
-  uint32_t bal_hi = bfi(rstM, (uint32_t)(p.d_balance >> 32), (uint32_t)(a.bal >> 32));
-  uint32_t mn = bfi(rstM, (uint32_t)p.d_min, (uint32_t)a.mn);
-  uint32_t mx = bfi(rstM, (uint32_t)p.d_max, (uint32_t)a.mx);
-  uint32_t n = bfi(rstM, p.d_evcount, a.n);
-  corr = andn(corr, rstM);
+  // A build for one schema (kSpecV1) does not walk the fields no event type touches: such a field of a present aggregate is
+  // its default when a reset happened since the state the walk started from, else still that state's value — one sticky
+  // mask (kept in a.fl's place: the concrete walk does not use a.fl) says which, finish_concrete() applies it.
+  if (kAnyDead) a.fl |= rstM;
 
   const uint32_t arg = raw_lo;
-  count += ((arg ^ q0.y) - q0.y) & (q0.x & appM);
-  count = bfi(q0.z & appM, arg, count);
-  version = bfi(q0.w & appM, seq, version);
-  {
+  if (kLiveCount) {
+    uint32_t count = bfi(rstM, (uint32_t)p.d_count, (uint32_t)a.count);
+    count += ((arg ^ q0.y) - q0.y) & (q0.x & appM);
+    count = bfi(q0.z & appM, arg, count);
+    a.count = (int32_t)count;
+  }
+  if (kLiveVersion) {
+    uint32_t version = bfi(rstM, (uint32_t)p.d_version, (uint32_t)a.version);
+    version = bfi(q0.w & appM, seq, version);
+    a.version = (int32_t)version;
+  }
+  if (kLiveSum) {
+    uint32_t sum_lo = bfi(rstM, (uint32_t)p.d_sum, (uint32_t)a.sum);
+    uint32_t sum_hi = bfi(rstM, (uint32_t)((uint64_t)p.d_sum >> 32), (uint32_t)((uint64_t)a.sum >> 32));
+    corr = andn(corr, rstM);
     const uint32_t m = q1.x & appM;
     const uint32_t x = (arg ^ q1.y) & m;
     const uint64_t sum = (((uint64_t)sum_hi << 32) | sum_lo) + (uint64_t)(int64_t)(int32_t)x;
-    sum_lo = (uint32_t)sum;
-    sum_hi = (uint32_t)(sum >> 32);
     corr -= q1.y & m;
+    a.sum = (int64_t)sum;
   }
-  const uint32_t mbalM = q1.z & appM;
-  bal_lo = bfi(mbalM, raw_lo, bal_lo);
-  bal_hi = bfi(mbalM, raw_hi, bal_hi);
-  mn = (uint32_t)min((int32_t)mn, (int32_t)bfi(q3.x & appM, arg, 0x7fffffffu));
-  mx = (uint32_t)max((int32_t)mx, (int32_t)bfi(q3.y & appM, arg, 0x80000000u));
-  n += q1.w & appM;
+  if (kLiveBal) {
+    uint32_t bal_lo = bfi(rstM, (uint32_t)p.d_balance, (uint32_t)a.bal);
+    uint32_t bal_hi = bfi(rstM, (uint32_t)(p.d_balance >> 32), (uint32_t)(a.bal >> 32));
+    const uint32_t mbalM = q1.z & appM;
+    bal_lo = bfi(mbalM, raw_lo, bal_lo);
+    bal_hi = bfi(mbalM, raw_hi, bal_hi);
+    a.bal = ((uint64_t)bal_hi << 32) | bal_lo;
+  }
+  if (kLiveMin) {
+    const uint32_t mn = bfi(rstM, (uint32_t)p.d_min, (uint32_t)a.mn);
+    a.mn = min((int32_t)mn, (int32_t)bfi(q3.x & appM, arg, 0x7fffffffu));
+  }
+  if (kLiveMax) {
+    const uint32_t mx = bfi(rstM, (uint32_t)p.d_max, (uint32_t)a.mx);
+    a.mx = max((int32_t)mx, (int32_t)bfi(q3.y & appM, arg, 0x80000000u));
+  }
+  if (kLiveN) {
+    const uint32_t n = bfi(rstM, p.d_evcount, a.n);
+    a.n = n + (q1.w & appM);
+  }
+}
 
-  a.count = (int32_t)count; a.version = (int32_t)version;
-  a.sum = (int64_t)(((uint64_t)sum_hi << 32) | sum_lo);
-  a.bal = ((uint64_t)bal_hi << 32) | bal_lo;
-  a.mn = (int32_t)mn; a.mx = (int32_t)mx; a.n = n;
+// Before a concrete walk: a.fl becomes the "a reset happened" mask of the untouched fields (builds with such fields only).
+__device__ __forceinline__ void begin_concrete(Acc& a) {
+  if (kAnyDead) a.fl = 0u;
+}
+// After it: the untouched fields take their defaults where a reset happened (elsewhere they still hold the value the walk
+// started from), a.fl is rebuilt from the two masks, the "+1"s of the subtractions go into the sum.
+__device__ __forceinline__ void finish_concrete(Acc& a, uint32_t presentM, uint32_t frozenM, uint32_t corr, const FoldParams& p) {
+  if (kAnyDead) {
+    const uint32_t r = a.fl;
+    if (!kLiveCount) a.count = (int32_t)bfi(r, (uint32_t)p.d_count, (uint32_t)a.count);
+    if (!kLiveVersion) a.version = (int32_t)bfi(r, (uint32_t)p.d_version, (uint32_t)a.version);
+    if (!kLiveSum) a.sum = (int64_t)(((uint64_t)bfi(r, (uint32_t)((uint64_t)p.d_sum >> 32), (uint32_t)((uint64_t)a.sum >> 32)) << 32) | bfi(r, (uint32_t)p.d_sum, (uint32_t)a.sum));
+    if (!kLiveBal) a.bal = ((uint64_t)bfi(r, (uint32_t)(p.d_balance >> 32), (uint32_t)(a.bal >> 32)) << 32) | bfi(r, (uint32_t)p.d_balance, (uint32_t)a.bal);
+    if (!kLiveMin) a.mn = (int32_t)bfi(r, (uint32_t)p.d_min, (uint32_t)a.mn);
+    if (!kLiveMax) a.mx = (int32_t)bfi(r, (uint32_t)p.d_max, (uint32_t)a.mx);
+    if (!kLiveN) a.n = bfi(r, p.d_evcount, a.n);
+  }
+  a.fl = (presentM & FL_PRESENT) | (frozenM & FL_POISONED);
+  if (kLiveSum) a.sum = (int64_t)((uint64_t)a.sum + corr);
 }
 
 // g after f.  Absolute fields of g win, relative ones combine with f's.  A poisoned f is only ever
@@ -462,10 +495,26 @@ __device__ __forceinline__ void walk_events(Acc& a, uint32_t& frozenM, uint32_t&
 }
 
 
-// The concrete-state walk (apply_event_concrete); a.fl is rebuilt from the two masks when the walk ends.
+// The concrete-state walk (apply_event_concrete) between begin_concrete() and finish_concrete().
 template <int LE>
 __device__ __forceinline__ void walk_events_concrete(Acc& a, uint32_t& presentM, uint32_t& frozenM, uint32_t& corr, const uint4* ev,
                                                      const uint32_t* tyc, const uint32_t* lds_tab, const FoldParams& p) {
+  if (kSpecV1) {  // table words are bit tests of compile-time masks at the event's entry index: nothing is read from LDS
+#pragma unroll
+    for (int j = 0; j < LE; ++j) {
+      const uint32_t e = tyc[j];
+      const uint4 q0 = {spec_word<0>(e), spec_word<1>(e), spec_word<2>(e), spec_word<3>(e)};
+      const uint4 q1 = {spec_word<4>(e), spec_word<5>(e), spec_word<6>(e), spec_word<7>(e)};
+      const uint4 q2 = {spec_word<8>(e), spec_word<9>(e), spec_word<10>(e), spec_word<11>(e)};
+      const uint2 q3 = {spec_word<12>(e), spec_word<13>(e)};
+#ifdef SURGE_EXP_SKIP_APPLY  // (experiment builds: the transport without the arithmetic)
+      a.count ^= (int32_t)(e ^ ev[j].y ^ ev[j].z ^ ev[j].w);
+#else
+      apply_event_concrete(a, presentM, frozenM, corr, q0, q1, q2, q3, ev[j].y, ev[j].z, ev[j].w, p);
+#endif
+    }
+    return;
+  }
   uint4 tq0, tq1, tq2;
   uint2 tq3;
   {

@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "fold_flat_device.h"
+#include "fold_lane_device.h"
 
 namespace surge {
 namespace {
@@ -56,86 +57,11 @@ __global__ void __launch_bounds__(kWave) fold_kernel(const FoldParams p) {
 // the linear stream).  Lane l then owns row l outright, so its running state is CONCRETE from the first
 // event on: no presence pre-pass, no transformer scan, no cross-lane traffic at all — the walk is the
 // same mask arithmetic as the flat kernel and the 64 B results leave as one contiguous 4 KiB store.
-template <int LE>
+template <int LE, bool CONC>
 __global__ void __launch_bounds__(kWave) fold_rows_kernel(const FoldParams p) {
-  using G = Geo<LE>;
-  // Two separate LDS objects, not one carved-up buffer: the compiler orders every LDS read after all outstanding
-  // global->LDS loads that MAY alias it.  With a single dynamic buffer the op-table reads of the walk "may alias"
-  // the tile being fetched, and hipcc put an s_waitcnt vmcnt(0) in front of the first table read — i.e. each wave
-  // waited for its NEXT tile before walking the current one.  Distinct objects let alias analysis drop that wait.
-  __shared__ __attribute__((aligned(16))) char lds_ev[G::kTileBytes];
+  __shared__ __attribute__((aligned(16))) char lds_ev[Geo<LE>::kTileBytes];
   __shared__ __attribute__((aligned(16))) uint32_t lds_tab[kTableLdsDwords];
-
-  const int lane = threadIdx.x;
-  const int64_t S0 = (int64_t)blockIdx.x * p.segs_per_task;
-  int64_t S1 = S0 + p.segs_per_task;
-  S1 = S1 < p.n_seg ? S1 : p.n_seg;
-  if (S0 >= S1) return;
-  const uint32_t L = (uint32_t)p.fixed_len;
-  const int chunks = (int)(L / LE);
-  const int n_groups = (int)((S1 - S0 + kWave - 1) / kWave);
-  const int n_tiles = n_groups * chunks;
-
-  load_table<LE>(p, lds_tab, lane);
-
-  // lane offsets of the load-instruction classes: row (m / LE) of the instruction's rows, swizzled slot
-  uint32_t voff[G::kClasses];
-#pragma unroll
-  for (int k = 0; k < G::kClasses; ++k) voff[k] = ((uint32_t)(lane / LE) * L + G::load_j(lane, k)) * 16u;
-  const uint32_t ev_row = G::ev_row(lane);
-
-  // buffer_load ... lds (see issue_tile_loads for why not global_load_lds): descriptor base = the group's first row at
-  // this tile's column, lane offset = its row (m / LE) and swizzled slot, instruction q at scalar offset RPL q rows
-  auto issue = [&](int t) {
-    const int g = t / chunks, c = t - g * chunks;
-    const int64_t row0 = S0 + (int64_t)g * kWave;
-    const char* base = (const char*)(p.events + (row0 * L + (int64_t)c * LE));  // wave-uniform
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
-    if (row0 + kWave <= p.n_seg) {
-#pragma unroll
-      for (int q = 0; q < G::kLoads; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds_ev + q * 1024), 16, (int)voff[q % G::kClasses],
-                                                 (int)((uint32_t)(G::kRowsPerLoad * q) * L * 16u), 0, kLoadAux);
-    } else {  // last group of the log: rows past the end re-read the last row (their lanes are idle)
-#pragma unroll
-      for (int q = 0; q < G::kLoads; ++q) {
-        int64_t row = row0 + G::kRowsPerLoad * q + lane / LE;
-        row = row < p.n_seg ? row : p.n_seg - 1;
-        const int off = (int)(((row - row0) * L + G::load_j(lane, q % G::kClasses)) * 16);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds_ev + q * 1024), 16, off, 0, 0, kLoadAux);
-      }
-    }
-  };
-
-  issue(0);
-  Acc a = acc_none();
-  uint32_t frozenM = 0u, corr = 0u;
-  int c = 0;
-  int64_t row = S0 + lane;
-  for (int t = 0; t < n_tiles; ++t) {
-    if (c == 0) {
-      a = (p.init && row < S1) ? load_state(p.init, row) : acc_none();
-      frozenM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 1, 1);
-      corr = 0u;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint4 ev[LE];
-#pragma unroll
-    for (int j = 0; j < LE; ++j) ev[j] = *(const uint4*)(lds_ev + (ev_row ^ (uint32_t)(j * 16)));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (t + 1 < n_tiles) issue(t + 1);
-
-    uint32_t tyc[LE];
-#pragma unroll
-    for (int j = 0; j < LE; ++j) tyc[j] = type_off(ev[j].x);
-    walk_events<LE, false>(a, frozenM, corr, ev, tyc, 0u, lds_tab, p, [](int) {});
-    if (++c == chunks) {
-      c = 0;
-      a.sum = (int64_t)((uint64_t)a.sum + corr);
-      if (row < S1) store_state(p.out, row, a);
-      row += kWave;
-    }
-  }
+  fold_rows_body<LE, CONC>(p, lds_ev, lds_tab);
 }
 
 // ---- K2 "sorted rows": arbitrary CSR, one lane per aggregate ----------------------------------------
@@ -404,14 +330,20 @@ hipError_t launch_fold_fixed(const FoldParams& p, int64_t n_tasks, int lane_even
   return hipGetLastError();
 }
 
-hipError_t launch_fold_rows(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream) {
+hipError_t launch_fold_rows(const FoldParams& p, const V1Kernels* spec, int64_t n_tasks, int lane_events, hipStream_t stream) {
   if (n_tasks <= 0) return hipSuccess;
-  if (lane_events == 8)
-    hipLaunchKernelGGL((fold_rows_kernel<8>), dim3((unsigned)n_tasks), dim3(kWave), 0, stream, p);  // LDS is static in the kernel
-  else if (lane_events == 32)
-    hipLaunchKernelGGL((fold_rows_kernel<32>), dim3((unsigned)n_tasks), dim3(kWave), 0, stream, p);  // LDS is static in the kernel
-  else
-    hipLaunchKernelGGL((fold_rows_kernel<16>), dim3((unsigned)n_tasks), dim3(kWave), 0, stream, p);  // LDS is static in the kernel
+  if (spec && lane_events != 32) return launch_v1_lane(lane_events == 8 ? spec->rows8 : spec->rows16, &p, sizeof(p), n_tasks, 0, stream);
+  static const bool conc = [] { const char* e = std::getenv("SURGE_REPLAY_WALK"); return !(e && std::strcmp(e, "transformer") == 0); }();
+  // LDS is static in the kernel
+  if (lane_events == 8) {
+    if (conc) hipLaunchKernelGGL((fold_rows_kernel<8, true>), dim3((unsigned)n_tasks), dim3(kWave), 0, stream, p);
+    else hipLaunchKernelGGL((fold_rows_kernel<8, false>), dim3((unsigned)n_tasks), dim3(kWave), 0, stream, p);
+  } else if (lane_events == 32) {
+    hipLaunchKernelGGL((fold_rows_kernel<32, false>), dim3((unsigned)n_tasks), dim3(kWave), 0, stream, p);
+  } else {
+    if (conc) hipLaunchKernelGGL((fold_rows_kernel<16, true>), dim3((unsigned)n_tasks), dim3(kWave), 0, stream, p);
+    else hipLaunchKernelGGL((fold_rows_kernel<16, false>), dim3((unsigned)n_tasks), dim3(kWave), 0, stream, p);
+  }
   return hipGetLastError();
 }
 
@@ -431,13 +363,6 @@ hipError_t launch_fold_sorted(const FoldParams& p, int64_t n_waves, int lane_eve
 // compiled once per distinct op table and process with the table's words as compile-time masks (fold_device.h,
 // SURGE_V1_SPEC).  The flat kernel is the one of the v1 folds that is bound by its instruction stream (lane transformers:
 // ~97 VALU instructions per event against 55 in the lane-per-aggregate kernels); the others run at the transport's pace.
-struct V1Kernels {
-  hipModule_t module = nullptr;
-  hipFunction_t flat8 = nullptr, flat16 = nullptr;
-  int device = 0;
-  double compile_ms = 0.0;
-};
-
 namespace {
 
 struct V1Masks {
@@ -463,12 +388,16 @@ bool v1_masks(const uint32_t (*table)[kTableWords], V1Masks* m) {
 }
 
 std::mutex g_v1_mu;
-std::map<std::string, std::unique_ptr<V1Kernels>> g_v1_cache;  // key: device + masks; entries live as long as the process
+std::map<std::string, std::unique_ptr<V1Kernels>> g_v1_cache;  // key: kind + device + masks; entries live as long as the process
 std::map<std::string, std::string> g_v1_failed;
 
 }  // namespace
 
-std::string v1_spec_source(const uint32_t (*table)[kTableWords]) {
+// The program handed to hiprtc for one op table: the masks, then either the flat kernel (V1_FLAT: fold_flat_device.h — K3
+// appends, AUTO on logs of few long rows) or the lane-per-row kernels (V1_LANES: fold_lane_device.h — SORTED, CHUNKED, ROWS).
+// Two programs, not one: a handle that only ever appends micro-batches never pays for the lane kernels' compile and the
+// other way round; each is cached on disk by its text (rtc.cpp).
+std::string v1_spec_source(const uint32_t (*table)[kTableWords], int kind) {
   V1Masks m;
   if (!v1_masks(table, &m)) return std::string();
   std::string s = "#define SURGE_V1_SPEC 1\n#define SURGE_V1_MASK(k) (";
@@ -482,7 +411,22 @@ std::string v1_spec_source(const uint32_t (*table)[kTableWords]) {
   s += b;
   std::snprintf(b, sizeof b, "#define SURGE_V1_DELETES 0x%xu\n", m.deletes);
   s += b;
-  s += R"SRC(
+#ifdef SURGE_EXPERIMENTS  // experiment builds of the library only (scripts/build_experiments_lib.py): extra #defines for the program, "A=1;B=2"
+  if (const char* extra = std::getenv("SURGE_REPLAY_RTC_EXTRA")) {
+    std::string e = extra;
+    size_t pos = 0;
+    while (pos < e.size()) {
+      size_t semi = e.find(';', pos);
+      if (semi == std::string::npos) semi = e.size();
+      std::string d = e.substr(pos, semi - pos);
+      const size_t eq = d.find('=');
+      if (!d.empty()) s += "#define " + (eq == std::string::npos ? d : d.substr(0, eq) + " " + d.substr(eq + 1)) + "\n";
+      pos = semi + 1;
+    }
+  }
+#endif
+  if (kind == V1_FLAT) {
+    s += R"SRC(
 #include "fold_flat_device.h"
 using namespace surge;
 extern "C" __global__ void __launch_bounds__(64) surge_v1_flat8(const FoldParams p) {
@@ -494,15 +438,64 @@ extern "C" __global__ void __launch_bounds__(64) surge_v1_flat16(const FoldParam
   fold_flat_body<MODE_FLAT, 16>(p, smem);
 }
 )SRC";
+  } else {
+    // (register budgets as in fold_chunked.hip: two waves per SIMD with 16 KiB tiles, three with 8 KiB tiles)
+    s += R"SRC(
+#include "fold_lane_device.h"
+using namespace surge;
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) surge_v1_sorted8(const FoldParams p) {
+  ChunkTable t;
+  t.v_start = nullptr; t.v_len = nullptr; t.v_info = nullptr; t.v_dest = nullptr; t.n_vrows = 0; t.side = nullptr;
+  chunk_walk<8, true, true>(p, t);
+}
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) surge_v1_sorted16(const FoldParams p) {
+  ChunkTable t;
+  t.v_start = nullptr; t.v_len = nullptr; t.v_info = nullptr; t.v_dest = nullptr; t.n_vrows = 0; t.side = nullptr;
+  chunk_walk<16, true, true>(p, t);
+}
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) surge_v1_sorted32(const FoldParams p) {
+  ChunkTable t;
+  t.v_start = nullptr; t.v_len = nullptr; t.v_info = nullptr; t.v_dest = nullptr; t.n_vrows = 0; t.side = nullptr;
+  chunk_walk<32, true, true>(p, t);
+}
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) surge_v1_chunked8(const ChunkArgs a) {
+  chunk_walk<8, false, true>(a.p, a.t);
+}
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) surge_v1_chunked16(const ChunkArgs a) {
+  chunk_walk<16, false, true>(a.p, a.t);
+}
+extern "C" __global__ void __launch_bounds__(64) surge_v1_rows8(const FoldParams p) {
+  __shared__ __attribute__((aligned(16))) char lds_ev[Geo<8>::kTileBytes];
+  fold_rows_body<8, true>(p, lds_ev, nullptr);
+}
+extern "C" __global__ void __launch_bounds__(64) surge_v1_rows16(const FoldParams p) {
+  __shared__ __attribute__((aligned(16))) char lds_ev[Geo<16>::kTileBytes];
+  fold_rows_body<16, true>(p, lds_ev, nullptr);
+}
+)SRC";
+  }
   return s;
 }
 
-void v1_kernels_acquire(const uint32_t (*table)[kTableWords], int device, V1Kernels** out, double* compile_ms, std::string* why) {
+void v1_kernels_acquire(const uint32_t (*table)[kTableWords], int device, int kind, V1Kernels** out, double* compile_ms, std::string* why) {
   *out = nullptr;
   *compile_ms = 0.0;
   if (const char* v = std::getenv("SURGE_REPLAY_RTC")) {
     if (std::atoi(v) == 0) {
       *why = "disabled by SURGE_REPLAY_RTC=0";
+      return;
+    }
+  }
+  if (kind == V1_LANES) {
+    // Opt-in (SURGE_REPLAY_RTC_LANES=1).  Measured in round 6 on the 10 M-aggregate log, one box, A/B/A
+    // (profiles/r06_lane_spec_ab_*.jsonl): with 8-event lanes the compiled kernels tie the ahead-of-time ones to 0.1 % —
+    // for the built-in schema (54 -> 53 VALU per event) AND for the Counter fixture's own schema (20 VALU per event): the
+    // walk's instruction count is not what bounds SORTED / CHUNKED; with 16-event lanes they are 13 - 29 % slower at equal
+    // HBM traffic (the waves wait 2.7 x longer for their tiles; not understood).  ROWS gains 0.6 - 2 %.  So the default stays
+    // the ahead-of-time kernels; the compiled ones are kept, fuzzed against the oracle, for schemas and shapes where they pay.
+    const char* v = std::getenv("SURGE_REPLAY_RTC_LANES");
+    if (!v || std::atoi(v) == 0) {
+      *why = "off (SURGE_REPLAY_RTC_LANES=1 compiles them)";
       return;
     }
   }
@@ -512,7 +505,10 @@ void v1_kernels_acquire(const uint32_t (*table)[kTableWords], int device, V1Kern
     return;
   }
   std::string key((const char*)&m, sizeof(m));
-  key += "@" + std::to_string(device);
+  key += "@" + std::to_string(device) + "/" + std::to_string(kind);
+#ifdef SURGE_EXPERIMENTS
+  if (const char* extra = std::getenv("SURGE_REPLAY_RTC_EXTRA")) key += std::string("+") + extra;
+#endif
   std::lock_guard<std::mutex> lk(g_v1_mu);
   auto hit = g_v1_cache.find(key);
   if (hit != g_v1_cache.end()) {
@@ -537,13 +533,17 @@ void v1_kernels_acquire(const uint32_t (*table)[kTableWords], int device, V1Kern
   std::vector<char> code;
   std::string log;
   double ms = 0.0;
-  if (!rtc_compile(v1_spec_source(table), arch.c_str(), &code, &log, &ms)) return give_up(log);
+  if (!rtc_compile(v1_spec_source(table, kind), arch.c_str(), &code, &log, &ms)) return give_up(log);
   auto k = std::make_unique<V1Kernels>();
   k->device = device;
   k->compile_ms = ms;
   hipError_t e = hipModuleLoadData(&k->module, code.data());
   if (e != hipSuccess) return give_up(std::string("hipModuleLoadData: ") + hipGetErrorString(e));
-  struct { hipFunction_t* f; const char* name; } fns[] = {{&k->flat8, "surge_v1_flat8"}, {&k->flat16, "surge_v1_flat16"}};
+  struct Fn { hipFunction_t* f; const char* name; };
+  std::vector<Fn> fns;
+  if (kind == V1_FLAT) fns = {{&k->flat8, "surge_v1_flat8"}, {&k->flat16, "surge_v1_flat16"}};
+  else fns = {{&k->sorted8, "surge_v1_sorted8"}, {&k->sorted16, "surge_v1_sorted16"}, {&k->sorted32, "surge_v1_sorted32"}, {&k->chunked8, "surge_v1_chunked8"},
+              {&k->chunked16, "surge_v1_chunked16"}, {&k->rows8, "surge_v1_rows8"}, {&k->rows16, "surge_v1_rows16"}};
   for (auto& f : fns) {
     e = hipModuleGetFunction(f.f, k->module, f.name);
     if (e != hipSuccess) {
@@ -554,6 +554,19 @@ void v1_kernels_acquire(const uint32_t (*table)[kTableWords], int device, V1Kern
   *compile_ms = ms;
   *out = k.get();
   g_v1_cache[key] = std::move(k);
+}
+
+// one launch of a kernel of a V1_LANES / V1_FLAT module: the argument block by value
+hipError_t launch_v1_lane(hipFunction_t fn, const void* args, size_t args_bytes, int64_t grid, unsigned lds, hipStream_t stream) {
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(args), HIP_LAUNCH_PARAM_BUFFER_SIZE, &args_bytes, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, kWave, 1, 1, lds, stream, nullptr, config);
+}
+
+hipFunction_t v1_lane_fn(const V1Kernels* k, int which, int lane_events) {
+  if (!k) return nullptr;
+  if (which == 0) return lane_events == 8 ? k->sorted8 : k->sorted16;
+  if (which == 1) return lane_events == 8 ? k->chunked8 : k->chunked16;
+  return lane_events == 8 ? k->rows8 : k->rows16;
 }
 
 hipError_t launch_fold_flat(const FoldParams& p, const V1Kernels* spec, int64_t n_tasks, int lane_events, hipStream_t stream) {

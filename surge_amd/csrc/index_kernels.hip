@@ -10,16 +10,16 @@
 //                  virtual row, its entry in the cut list and its first side slot -> rows are emitted in aggregate order ->
 //                  the same radix sort orders them by length -> one gather writes the table the fold kernels read.
 // Both orders are now deterministic (stable sort: equal lengths keep aggregate order), which the atomic cursors were not.
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-
+// Round 6: rows shorter than 8192 events (every log of the BASELINE configs) are ordered by the hand-written counting sort of
+// length_sort.hip and the chunk counts are scanned by its multi-block scan; rocPRIM's radix sort stays for longer rows, in a
+// translation unit of its own (index_radix.hip) — its code objects cost 7 ms to load at the first launch of ANY kernel that
+// shares a translation unit with them, which a recovery that never needs them should not pay.
 #include "fold_chunk_device.h"
 
 namespace surge {
 namespace {
 
 constexpr uint32_t kLenKeyMax = 65535u;  // rows longer than this share the first bucket (they are few: each is long)
-constexpr unsigned kLenKeyBits = 16;
 
 __global__ void length_keys_kernel(const int64_t* __restrict__ off, int64_t n_seg, uint32_t* __restrict__ keys, int64_t* __restrict__ vals) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,7 +84,7 @@ __global__ void chunk_emit_kernel(const int64_t* __restrict__ off, int64_t n_seg
     u_info[pos] = (c > 1 ? (VI_RELATIVE | VI_SIDE) : 0u) | ((k == 0 ? pad : 0u) << VI_PAD_SHIFT);
     u_dest[pos] = c > 1 ? slot0 + k : oi;
     keys[pos] = vl < kLenKeyMax ? vl : kLenKeyMax;
-    vals[pos] = pos;
+    if (vals) vals[pos] = pos;  // (the counting sort numbers the rows itself)
   }
 }
 
@@ -100,45 +100,26 @@ __global__ void chunk_gather_kernel(const int64_t* __restrict__ order, int64_t n
 
 }  // namespace
 
-// scratch bytes rocPRIM needs to sort n (length, id) pairs or scan n int64 (the larger)
-hipError_t index_temp_bytes(int64_t n, size_t* bytes) {
-  size_t a = 0, b = 0;
-  hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int64_t*)nullptr,
-                                                (int64_t*)nullptr, (size_t)(n > 0 ? n : 1), 0u, kLenKeyBits, (hipStream_t) nullptr);
-  if (e != hipSuccess) return e;
-  e = rocprim::exclusive_scan(nullptr, b, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(n > 0 ? n : 1),
-                              rocprim::plus<int64_t>(), (hipStream_t) nullptr);
-  if (e != hipSuccess) return e;
-  *bytes = a > b ? a : b;
-  return hipSuccess;
-}
-
 // perm (n_seg int64) := kernel-facing segment ids sorted by length, longest first (stable)
 hipError_t launch_sort_by_length(const int64_t* off, int64_t n_seg, const IndexScratch& sc, int64_t* perm, hipStream_t stream) {
   if (n_seg <= 0) return hipSuccess;
+  if (sc.counting) return launch_count_sort_desc(nullptr, off, n_seg, sc.max_key, sc.n_cus, sc.temp, perm, stream);
   hipLaunchKernelGGL(length_keys_kernel, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, stream, off, n_seg, sc.keys_a, sc.vals_a);
-  size_t tb = sc.temp_bytes;
-  return rocprim::radix_sort_pairs_desc(sc.temp, tb, (const uint32_t*)sc.keys_a, sc.keys_b, (const int64_t*)sc.vals_a, perm, (size_t)n_seg, 0u,
-                                        kLenKeyBits, stream);
+  return launch_radix_sort_pairs_desc(sc.temp, sc.temp_bytes, sc.keys_a, sc.keys_b, sc.vals_a, perm, n_seg, stream);
 }
 
 // Phase 1 of the chunk table: cnt = three arrays of n_seg + 1 int64 (stride n_seg + 1), left as exclusive scans with their
 // totals in the last element: {virtual rows, cut aggregates, side slots}.  The host reads the three totals, sizes the
 // table and runs phase 2.
-hipError_t launch_chunk_count(const int64_t* off, int64_t n_seg, uint32_t T, bool align, int64_t* cnt, const IndexScratch& sc,
-                              hipStream_t stream) {
+hipError_t launch_chunk_count(const int64_t* off, int64_t n_seg, uint32_t T, bool align, int64_t* cnt, void* scan_scratch, hipStream_t stream) {
   if (n_seg <= 0) return hipSuccess;
   const int64_t stride = n_seg + 1;
   hipLaunchKernelGGL(chunk_count_kernel, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, stream, off, n_seg, T, align, cnt, stride);
   for (int k = 0; k < 3; ++k) {
     hipError_t e = hipMemsetAsync(cnt + k * stride + n_seg, 0, 8, stream);  // the extra element: its scan value is the total
     if (e != hipSuccess) return e;
-    size_t tb = sc.temp_bytes;
-    e = rocprim::exclusive_scan(sc.temp, tb, (const int64_t*)(cnt + k * stride), cnt + k * stride, (int64_t)0, (size_t)stride,
-                                rocprim::plus<int64_t>(), stream);
-    if (e != hipSuccess) return e;
   }
-  return hipGetLastError();
+  return launch_exclusive_scans_i64(cnt, stride, stride, 3, scan_scratch, stream);  // (scan_i64_scratch_bytes(stride, 3) bytes)
 }
 
 // Phase 2: rows in aggregate order (u_*), sorted by length (longest first, stable), gathered into v_*
@@ -149,9 +130,12 @@ hipError_t launch_chunk_table(const int64_t* off, int64_t n_seg, const int64_t* 
   if (n_seg <= 0 || n_vrows <= 0) return hipSuccess;
   hipLaunchKernelGGL(chunk_emit_kernel, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, stream, off, n_seg, out_map, T, align, cnt,
                      n_seg + 1, u_start, u_len, u_info, u_dest, sc.keys_a, sc.vals_a, r_slot0, r_c, r_out);
-  size_t tb = sc.temp_bytes;
-  hipError_t e = rocprim::radix_sort_pairs_desc(sc.temp, tb, (const uint32_t*)sc.keys_a, sc.keys_b, (const int64_t*)sc.vals_a, sc.vals_b,
-                                                (size_t)n_vrows, 0u, kLenKeyBits, stream);
+  hipError_t e;
+  if (sc.counting) {
+    e = launch_count_sort_desc(sc.keys_a, nullptr, n_vrows, sc.max_key, sc.n_cus, sc.temp, sc.vals_b, stream);
+  } else {
+    e = launch_radix_sort_pairs_desc(sc.temp, sc.temp_bytes, sc.keys_a, sc.keys_b, sc.vals_a, sc.vals_b, n_vrows, stream);
+  }
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(chunk_gather_kernel, dim3((unsigned)((n_vrows + 255) / 256)), dim3(256), 0, stream, sc.vals_b, n_vrows, u_start, u_len,
                      u_info, u_dest, v_start, v_len, v_info, v_dest);

@@ -26,33 +26,53 @@ struct CsrAnalysis {
 hipError_t launch_fold_fixed(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream);
 // The flat kernel compiled for one v1 op table (hiprtc; fold_kernels.hip).  A V1Kernels object is shared by every handle
 // of the process with the same table on the same device; nullptr = the ahead-of-time kernel that reads the table from LDS.
-struct V1Kernels;
-std::string v1_spec_source(const uint32_t (*table)[kTableWords]);  // the program handed to hiprtc ("" = not expressible)
-void v1_kernels_acquire(const uint32_t (*table)[kTableWords], int device, V1Kernels** out, double* compile_ms, std::string* why);
+enum { V1_FLAT = 0, V1_LANES = 1 };  // the two run-time compiled programs of a v1 op table (fold_kernels.hip)
+struct V1Kernels {
+  hipModule_t module = nullptr;
+  hipFunction_t flat8 = nullptr, flat16 = nullptr;                                  // V1_FLAT
+  hipFunction_t sorted8 = nullptr, sorted16 = nullptr, sorted32 = nullptr, chunked8 = nullptr, chunked16 = nullptr, rows8 = nullptr, rows16 = nullptr;  // V1_LANES
+  int device = 0;
+  double compile_ms = 0.0;
+};
+std::string v1_spec_source(const uint32_t (*table)[kTableWords], int kind);  // the program handed to hiprtc ("" = not expressible)
+void v1_kernels_acquire(const uint32_t (*table)[kTableWords], int device, int kind, V1Kernels** out, double* compile_ms, std::string* why);
+hipError_t launch_v1_lane(hipFunction_t fn, const void* args, size_t args_bytes, int64_t grid, unsigned lds, hipStream_t stream);
 hipError_t launch_fold_flat(const FoldParams& p, const V1Kernels* spec, int64_t n_tasks, int lane_events, hipStream_t stream);
-hipError_t launch_fold_rows(const FoldParams& p, int64_t n_tasks, int lane_events, hipStream_t stream);
+// lanes: the V1_LANES kernels compiled for the handle's op table, or nullptr = the ahead-of-time kernels (op table in LDS)
+hipError_t launch_fold_rows(const FoldParams& p, const V1Kernels* lanes, int64_t n_tasks, int lane_events, hipStream_t stream);
 hipError_t launch_fold_sorted(const FoldParams& p, int64_t n_waves, int lane_events, hipStream_t stream);
 // the same fold, pipelined across groups (fold_chunked.hip: the chunked kernel's walk over whole aggregates); 8 or 16 events per lane
-hipError_t launch_fold_sorted_pf(const FoldParams& p, int64_t n_waves, int lane_events, hipStream_t stream);
+hipError_t launch_fold_sorted_pf(const FoldParams& p, const V1Kernels* lanes, int64_t n_waves, int lane_events, hipStream_t stream);
 // ---- index_kernels.hip: the per-log indexes (length order, chunk table), built with rocPRIM sorts / scans -----------
 struct IndexScratch {  // engine-owned device scratch, sized for the rows being ordered
-  void* temp;          // rocPRIM temporary storage
+  void* temp;          // the counting sort's histograms (counting) or rocPRIM temporary storage
   size_t temp_bytes;
-  uint32_t *keys_a, *keys_b;  // n x u32 each
-  int64_t *vals_a, *vals_b;   // n x i64 each (launch_sort_by_length writes its result to `perm` instead of vals_b)
+  uint32_t *keys_a, *keys_b;  // n x u32 each (keys_b: rocPRIM path only)
+  int64_t *vals_a, *vals_b;   // n x i64 each (vals_a: rocPRIM path only; launch_sort_by_length writes its result to `perm` instead of vals_b)
+  bool counting;       // keys <= max_key < kCountSortMaxBins: the hand-written counting sort (length_sort.hip), else rocPRIM's radix sort
+  uint32_t max_key;
+  int n_cus;
 };
-hipError_t index_temp_bytes(int64_t n, size_t* bytes);
+hipError_t index_temp_bytes(int64_t n, size_t* bytes);  // index_radix.hip: rocPRIM's radix sort (rows of 8192 events and more)
+hipError_t launch_radix_sort_pairs_desc(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const int64_t* vals_in,
+                                        int64_t* vals_out, int64_t n, hipStream_t stream);
+// ---- length_sort.hip: the stable descending counting sort of the indexes, and the exclusive scans of the chunk counts ----------
+constexpr int kCountSortMaxBins = 8192;
+size_t count_sort_scratch_bytes(int64_t n, uint32_t max_key, int n_cus);
+hipError_t launch_count_sort_desc(const uint32_t* keys, const int64_t* off, int64_t n, uint32_t max_key, int n_cus, void* scratch, int64_t* perm,
+                                  hipStream_t stream);
+size_t scan_i64_scratch_bytes(int64_t n, int k_arrays);
+hipError_t launch_exclusive_scans_i64(int64_t* v, int64_t n, int64_t stride, int k_arrays, void* scratch, hipStream_t stream);
 hipError_t launch_sort_by_length(const int64_t* off, int64_t n_seg, const IndexScratch& sc, int64_t* perm, hipStream_t stream);
 // CHUNKED / TILED: the chunk table of the kernel-facing CSR.  cnt: 3 x (n_seg + 1) int64.
-hipError_t launch_chunk_count(const int64_t* off, int64_t n_seg, uint32_t T, bool align, int64_t* cnt, const IndexScratch& sc,
-                              hipStream_t stream);
+hipError_t launch_chunk_count(const int64_t* off, int64_t n_seg, uint32_t T, bool align, int64_t* cnt, void* scan_scratch, hipStream_t stream);
 hipError_t launch_chunk_table(const int64_t* off, int64_t n_seg, const int64_t* out_map, uint32_t T, bool align, const int64_t* cnt,
                               int64_t n_vrows, const IndexScratch& sc, int64_t* u_start, uint32_t* u_len, uint32_t* u_info, int64_t* u_dest,
                               int64_t* v_start, uint32_t* v_len, uint32_t* v_info, int64_t* v_dest, int64_t* r_slot0, uint32_t* r_c,
                               int64_t* r_out, hipStream_t stream);
 hipError_t launch_fold_chunked(const FoldParams& p, const int64_t* v_start, const uint32_t* v_len, const uint32_t* v_info,
                                const int64_t* v_dest, int64_t n_vrows, uint32_t* side, const int64_t* r_slot0, const uint32_t* r_c,
-                               const int64_t* r_out, int64_t n_cut, int64_t n_waves, int lane_events, hipStream_t stream);
+                               const int64_t* r_out, int64_t n_cut, const V1Kernels* lanes, int64_t n_waves, int lane_events, hipStream_t stream);
 hipError_t launch_chunk_stitch(const FoldParams& p, const uint32_t* side, const int64_t* r_slot0, const uint32_t* r_c, const int64_t* r_out,
                                int64_t n_cut, hipStream_t stream);
 // TILED (fold_tiled.hip): the chunk table's virtual rows copied once into group-major / tile-major order, then the fold

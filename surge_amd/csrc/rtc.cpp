@@ -32,6 +32,8 @@ SURGE_EMBED(surge_src_fold_layout_h, "fold_layout.h")
 SURGE_EMBED(surge_src_fold_device_h, "fold_device.h")
 SURGE_EMBED(surge_src_fold_slots_device_h, "fold_slots_device.h")
 SURGE_EMBED(surge_src_fold_flat_device_h, "fold_flat_device.h")
+SURGE_EMBED(surge_src_fold_chunk_device_h, "fold_chunk_device.h")
+SURGE_EMBED(surge_src_fold_lane_device_h, "fold_lane_device.h")
 
 namespace surge {
 namespace {
@@ -199,13 +201,22 @@ void cache_store(const std::string& path, const std::vector<char>& code) {
 bool rtc_compile(const std::string& source, const char* arch, std::vector<char>* code, std::string* log, double* ms) {
   std::lock_guard<std::mutex> lk(g_rtc_mu);
   const auto t0 = std::chrono::steady_clock::now();
-  const char* headers[] = {surge_src_fold_layout_h, surge_src_fold_device_h, surge_src_fold_slots_device_h, surge_src_fold_flat_device_h};
-  const char* names[] = {"fold_layout.h", "fold_device.h", "fold_slots_device.h", "fold_flat_device.h"};
+  const char* headers[] = {surge_src_fold_layout_h, surge_src_fold_device_h, surge_src_fold_slots_device_h, surge_src_fold_flat_device_h,
+                           surge_src_fold_chunk_device_h, surge_src_fold_lane_device_h};
+  const char* names[] = {"fold_layout.h", "fold_device.h", "fold_slots_device.h", "fold_flat_device.h", "fold_chunk_device.h", "fold_lane_device.h"};
+  constexpr int n_headers = 6;
   const std::string arch_opt = std::string("--offload-arch=") + arch;
   // -ffp-contract=off: an f64 ADD must round exactly like the JVM's (no fused multiply-add anywhere near it)
   const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
   const std::string dir = cache_dir();
-  const std::string cached = dir.empty() ? "" : dir + "/" + cache_key(source, headers, 4, opts, 4) + ".co";
+  const std::string key = cache_key(source, headers, n_headers, opts, 4);
+  const std::string cached = dir.empty() ? "" : dir + "/" + key + ".co";
+  if (const char* dump = std::getenv("SURGE_REPLAY_RTC_DUMP")) {  // the program text, for reading its ISA offline (hipcc -S -I surge_amd/csrc)
+    if (FILE* f = std::fopen((std::string(dump) + "/" + key + ".hip").c_str(), "w")) {
+      std::fwrite(source.data(), 1, source.size(), f);
+      std::fclose(f);
+    }
+  }
   if (!cached.empty() && cache_load(cached, code)) {  // (needs no libhiprtc at all)
     g_rtc_cache_hits += 1;
     *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -216,7 +227,7 @@ bool rtc_compile(const std::string& source, const char* arch, std::vector<char>*
     return false;
   }
   hiprtcProgram prog = nullptr;
-  int rc = g_rtc.CreateProgram(&prog, source.c_str(), "surge_schema_spec.hip", 4, headers, names);
+  int rc = g_rtc.CreateProgram(&prog, source.c_str(), "surge_schema_spec.hip", n_headers, headers, names);
   if (rc != 0) {
     *log = std::string("hiprtcCreateProgram: ") + g_rtc.GetErrorString(rc);
     return false;

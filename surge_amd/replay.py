@@ -201,6 +201,14 @@ class ReplayEngine:
         self._check(self._lib.surge_replay_layout_info(self._h, ctypes.byref(info)))
         return info
 
+    def index_order(self, algo: int) -> np.ndarray:
+        """The row order of the bound log's index (``surge_replay_index_order``; diagnostics / tests)."""
+        n = ctypes.c_int64()
+        self._check(self._lib.surge_replay_index_order(self._h, algo, None, 0, ctypes.byref(n)))
+        out = np.zeros(max(int(n.value), 1), dtype=np.int64)
+        self._check(self._lib.surge_replay_index_order(self._h, algo, out.ctypes.data_as(ctypes.c_void_p), out.shape[0], ctypes.byref(n)))
+        return out[: int(n.value)]
+
     def kernel_info(self) -> dict:
         """Which build of the fold kernels this handle runs (``surge_replay_kernel_info``): v2 handles run kernels
         compiled for their schema at create time when libhiprtc is present."""

@@ -379,3 +379,44 @@ def test_no_kernel_of_the_library_spills_to_scratch(tmp_path):
     for name, limit in budgets:
         hit = [v["vgpr_count"] for k, v in ours.items() if name in k]
         assert hit and max(hit) <= limit, (name, hit, limit)
+
+
+def test_the_lane_kernels_compile_for_a_v1_schema_without_a_gpu_and_without_scratch(tmp_path, monkeypatch):
+    """The V1_LANES program (SORTED / CHUNKED / ROWS compiled for one op table; opt-in, SURGE_REPLAY_RTC_LANES=1) builds for
+    gfx950 on a machine without a GPU; its code object lands in the disk cache.  None of its kernels touches scratch, the
+    8-event sorted walk fits four waves per SIMD (<= 128 VGPRs) and the Counter fixture's schema compiles to well under half
+    the vector instructions of the built-in one (count and version are all its walk carries)."""
+    import subprocess
+
+    from fixture_models import COUNTER_ALGEBRA
+
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(f"{tools}/llvm-objdump") and os.path.exists(f"{tools}/llvm-readelf")):
+        pytest.skip("no llvm-objdump / llvm-readelf")
+    lib = _native.load()
+    monkeypatch.setenv("SURGE_REPLAY_RTC_LANES", "1")
+    valu = {}
+    for name, algebra in (("default", DEFAULT_ALGEBRA), ("counter", COUNTER_ALGEBRA)):
+        cache = tmp_path / name
+        cache.mkdir()
+        monkeypatch.setenv("SURGE_REPLAY_CACHE_DIR", str(cache))
+        sc, n = algebra.to_c(), ctypes.c_int64()
+        assert lib.surge_replay_compile_schema(ctypes.byref(sc), b"gfx950", None, 0, ctypes.byref(n)) == 0, lib.surge_replay_last_error(None).decode()
+        found = False
+        for co in sorted(cache.glob("*.co")):
+            elf = tmp_path / (co.name + ".elf")
+            elf.write_bytes(co.read_bytes()[24:])
+            notes = subprocess.run([f"{tools}/llvm-readelf", "--notes", str(elf)], capture_output=True, text=True, check=True).stdout
+            if "surge_v1_sorted16" not in notes:
+                continue
+            found = True
+            for k in ("surge_v1_sorted8", "surge_v1_sorted16", "surge_v1_chunked8", "surge_v1_chunked16", "surge_v1_rows8", "surge_v1_rows16"):
+                assert k in notes, k
+            assert not re.search(r"\.(private_segment_fixed_size|vgpr_spill_count):\s+[1-9]", notes), "a compiled lane kernel spills"
+            regs = dict(re.findall(r"\.name:\s+(surge_v1_\w+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", notes))
+            assert int(regs["surge_v1_sorted8"]) <= 128 and int(regs["surge_v1_sorted16"]) <= 256 and int(regs["surge_v1_chunked16"]) <= 256, regs
+            asm = subprocess.run([f"{tools}/llvm-objdump", "-d", str(elf)], capture_output=True, text=True, check=True).stdout
+            body = asm[asm.index("<surge_v1_sorted16>:"):asm.index("<surge_v1_sorted32>:")]
+            valu[name] = sum(1 for l in body.splitlines() if l.split()[:1] and l.split()[0].startswith("v_"))
+        assert found, list(cache.iterdir())
+    assert valu["counter"] < 0.75 * valu["default"], valu

@@ -1010,3 +1010,97 @@ def test_the_flat_kernel_compiled_for_a_v1_schema_equals_the_interpreter_and_the
                         eng.append_events(topic_agg[c0:c0 + m // 3 + 1], ev[src[c0:c0 + m // 3 + 1]])
                     eng.synchronize()
                     assert eng.snapshot().tobytes() == exp.tobytes(), (seed, build, "K3", alg.desc)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SURGE_TEST_FUZZ_SEEDS", "6"))))
+def test_the_lane_kernels_compiled_for_a_v1_schema_equal_the_interpreter_and_the_oracle(seed, monkeypatch):
+    """SORTED / CHUNKED / ROWS run kernels compiled for the handle's op table (hiprtc, the V1_LANES program:
+    table words are comparisons of the event type with compile-time constants, fields no event type touches leave the walk;
+    SURGE_REPLAY_RTC_LANES=0 keeps the ahead-of-time kernels that read the table from LDS).  Random schemas — every class
+    and field op, throwing types, narrow ones — on ragged logs (whole aggregates and, with a small chunk target, chunks of cut
+    aggregates whose presence is resolved by the stitch kernel) and uniform logs, 8- and 16-event lanes, event types beyond
+    the schema, priors written under other schemas: both builds, bit for bit the oracle's states."""
+    rng = np.random.default_rng(6000 + seed)
+    for it in range(3):
+        alg = _random_algebra(rng)
+        n = int(rng.integers(1, 2500))
+        uniform = it == 2
+        if uniform:
+            lens = np.full(n, int(rng.choice([16, 32, 48, 256])))
+        else:
+            lens = [rng.integers(0, 60, size=n), np.where(rng.random(n) < 0.97, rng.integers(0, 90, size=n), rng.integers(500, 9000, size=n)),
+                    rng.choice([0, 7, 8, 9, 15, 16, 17, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025], size=n)][int(rng.integers(0, 3))]
+        so = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=so[1:])
+        m = int(so[-1])
+        ty = rng.integers(0, len(alg.desc) + (2 if rng.random() < 0.3 else 0), m)
+        ev = S.make_events(ty, rng.integers(0, 1 << 30, m), rng.integers(-(1 << 31), 1 << 31, m))
+        prior = None
+        if rng.random() < 0.6:
+            pl = rng.integers(0, 4, size=n)
+            po = np.zeros(n + 1, np.int64)
+            np.cumsum(pl, out=po[1:])
+            pe = S.make_events(rng.integers(0, len(alg.desc), int(po[-1])), rng.integers(0, 1 << 30, int(po[-1])), rng.integers(-1000, 1000, int(po[-1])))
+            prior = oracle.fold_csr(po, pe, None, alg)
+            if rng.random() < 0.6:
+                live = (prior["flags"] & S.STATE_PRESENT) != 0
+                for f in ("count", "version", "min_arg", "max_arg"):
+                    prior[f][live] = rng.integers(-1 << 31, 1 << 31, int(live.sum()))
+                prior["sum64"][live] = rng.integers(-1 << 62, 1 << 62, int(live.sum()))
+                prior["event_count"][live] = rng.integers(0, 1 << 32, int(live.sum()))
+                prior["balance"][live] = rng.standard_normal(int(live.sum()))
+        exp = oracle.fold_csr(so, ev, prior, alg)
+        monkeypatch.setenv("SURGE_REPLAY_CHUNK_T", str(int(rng.choice([16, 64, 256, 4096]))))
+        for build in ("1", "0"):
+            monkeypatch.setenv("SURGE_REPLAY_RTC_LANES", build)
+            for le in ("8", "16"):
+                for name in ("SURGE_REPLAY_LE_SORTED", "SURGE_REPLAY_LE_CHUNKED", "SURGE_REPLAY_LE_ROWS"):
+                    monkeypatch.setenv(name, le)
+                with ReplayEngine(alg) as eng:
+                    eng.load_csr(so, ev, prior)
+                    for algo in [S.ALGO_SORTED, S.ALGO_CHUNKED] + ([S.ALGO_ROWS] if uniform and m else []):
+                        eng.fold(algo)
+                        assert eng.snapshot().tobytes() == exp.tobytes(), (seed, it, build, le, algo, alg.desc)
+                    detail = eng.kernel_info()["detail"]
+                    assert detail.startswith("lane kernels compiled for the op table") == (build == "1"), detail
+
+
+@pytest.mark.parametrize("shape", ["zipf", "short", "long_tail", "uniform"])
+def test_the_counting_sort_of_the_index_orders_rows_exactly_like_the_radix_sort(shape, monkeypatch):
+    """the per-log index (length order of SORTED, row order of the chunk table) is built by a hand-written
+    stable counting sort (length_sort.hip: per-wave LDS histograms, ballot ranking, no atomics) whenever the longest row is
+    below 8192 events; rocPRIM's radix sort stays for longer rows.  Both are stable and descending: the two orders must be
+    IDENTICAL element by element (SURGE_REPLAY_INDEX_SORT=radix forces the library sort), and so must the folds."""
+    rng = np.random.default_rng(77)
+    n = 40_000
+    if shape == "zipf":
+        lens = synth.zipf_lengths(np.arange(n, dtype=np.int64), 3)
+    elif shape == "short":
+        lens = rng.integers(0, 5, size=n)
+    elif shape == "long_tail":
+        lens = np.where(rng.random(n) < 0.999, rng.integers(1, 200, size=n), rng.integers(5000, 8100, size=n))
+    else:
+        lens = np.full(n, 48)
+    so, ev = synth.csr_log(lens.astype(np.int64), 11, synth.STRESS_MIX)
+    exp = oracle.fold_csr(so, ev)
+    orders = {}
+    for sort in ("counting", "radix"):
+        if sort == "radix":
+            monkeypatch.setenv("SURGE_REPLAY_INDEX_SORT", "radix")
+        for chunk_t in ("4096", "256"):
+            monkeypatch.setenv("SURGE_REPLAY_CHUNK_T", chunk_t)
+            with ReplayEngine() as eng:
+                eng.load_csr(so, ev)
+                for algo in (S.ALGO_SORTED, S.ALGO_CHUNKED, S.ALGO_TILED):
+                    eng.fold(algo)
+                    assert eng.snapshot().tobytes() == exp.tobytes(), (shape, sort, chunk_t, algo)
+                orders[(sort, chunk_t)] = (eng.index_order(S.ALGO_SORTED), eng.index_order(S.ALGO_CHUNKED))
+    for chunk_t in ("4096", "256"):
+        a, b = orders[("counting", chunk_t)], orders[("radix", chunk_t)]
+        assert np.array_equal(a[0], b[0]), (shape, chunk_t, "length order")
+        assert np.array_equal(a[1], b[1]), (shape, chunk_t, "chunk rows")
+    # the length order itself: descending counts, equal counts in aggregate order (over the non-empty aggregates)
+    nz = np.flatnonzero(lens > 0)
+    ref = nz[np.argsort(-lens[nz], kind="stable")]
+    got = orders[("counting", "4096")][0]
+    assert np.array_equal(nz[got] if lens.min() == 0 else got, ref), shape
