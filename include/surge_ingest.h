@@ -246,6 +246,11 @@ int32_t surge_replay_append_decoded(struct surge_replay_handle* h, surge_device_
  * interning of fetch i + 1 overlaps the fold of fetch i.  Errors of the fold surface at the next
  * surge_replay_synchronize. */
 int32_t surge_replay_append_decoded_async(struct surge_replay_handle* h, surge_device_decoder* d, int64_t* n_events_out, int64_t* n_keys_out);
+/* For a recovery that ends with ONE fold of the whole topic (surge_replay_pack_staged in surge_replay.h): instead of
+ * folding, everything decoded since the last clear is appended to the handle's staging log (surge_replay_stage_events_device)
+ * and the decoder is cleared.  No host wait: the hand-over is ordered by events exactly like append_decoded_async's.
+ * When the topic ends: surge_replay_pack_staged(h, <the decoder's key count>) and one surge_replay_fold. */
+int32_t surge_replay_stage_decoded(struct surge_replay_handle* h, surge_device_decoder* d, int64_t* n_events_out, int64_t* n_keys_out);
 /* The key table (aggregate ids in first-delivered order): to the host (NULL / NULL = size query), or where it lives on
  * the device (n_keys + 1 offsets; what the GPU state encoders and K4 take). */
 int32_t surge_device_decoder_keys(surge_device_decoder* d, uint8_t* utf8_out, int64_t utf8_capacity, int64_t* key_off_out, int64_t* n_keys_out,

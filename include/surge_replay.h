@@ -375,6 +375,28 @@ int32_t surge_replay_append_fold_device(surge_replay_handle* h, const int64_t* d
                                         const int64_t* d_group_off, int64_t n_groups,
                                         const void* d_events, int64_t n_events);
 
+/* ---- the device packer: decoded fetches -> a bound CSR log (SURVEY §8f N1 "ingest -> CSR pack") ---------------------------
+ * A recovery that folds the events topic ONCE wants the whole topic as one log the lane-per-row kernels fold (SORTED /
+ * CHUNKED / TILED: the kernels of the headline numbers), not a flat append per fetch.  surge_replay_stage_events_device
+ * appends n decoded events — topic (offset) order, event i of aggregate d_agg_idx[i], as surge_device_decoder delivers them
+ * fetch by fetch — to a staging log in device memory (20 bytes per event; it grows).  surge_replay_pack_staged turns
+ * everything staged into a CSR log over n_agg aggregates — a stable radix sort of (aggregate, position) pairs, seg_off by a
+ * search of the sorted aggregates, one gather of the 16-byte events: inside an aggregate the topic's order is kept, which is
+ * all foldLeft needs (CommandModels.scala:26); aggregates without events get empty segments — releases the staging log and
+ * binds the result like surge_replay_bind_device_csr does (handle-owned buffers, no prior state, a state buffer of the
+ * handle's own): surge_replay_fold / _prepare with any algorithm follow, and the log stays bound for re-folds.
+ * What it replaces: the per-key grouping Kafka Streams' restore gets for free from RocksDB's key order
+ * (SurgeStateStoreConsumer.scala:57-76) and the host-side pack of event objects (surge_amd/log.py::pack_events).
+ * Limits: fewer than 2^32 staged events and fewer than 2^32 aggregates per pack; an index >= n_agg fails the pack with
+ * SURGE_E_RANGE (nothing bound, the staging log kept).  Both enqueue on the handle's stream; the pack waits for it
+ * twice (sizes).  surge_replay_stage_reserve: capacity for n_events staged events up front (no growth copies). */
+int32_t surge_replay_stage_reserve(surge_replay_handle* h, int64_t n_events);
+int32_t surge_replay_stage_events_device(surge_replay_handle* h, const int64_t* d_agg_idx, const void* d_events, int64_t n_events);
+int32_t surge_replay_staged(surge_replay_handle* h, int64_t* n_events_out);
+int32_t surge_replay_pack_staged(surge_replay_handle* h, int64_t n_agg);
+/* The bound log's device arrays (valid until the next load / bind / pack): seg_off[n_agg + 1], events[n_events] x 16 B. */
+int32_t surge_replay_bound_log(surge_replay_handle* h, const int64_t** d_seg_off, const void** d_events, int64_t* n_agg, int64_t* n_events);
+
 /* New aggregates after recovery (the normal Surge case: ids that first appear in a later micro-batch): extends the
  * RESIDENT state to new_n_agg aggregates, the new ones None.  Indices below the old n_agg keep their states.  Only
  * for a state buffer the handle owns (SURGE_E_UNSUPPORTED otherwise).  The bound CSR no longer covers the state

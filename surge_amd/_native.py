@@ -45,6 +45,11 @@ EXPORTS = (
     "surge_replay_prepare",
     "surge_replay_layout_info",
     "surge_replay_index_order",
+    "surge_replay_stage_reserve",
+    "surge_replay_stage_events_device",
+    "surge_replay_staged",
+    "surge_replay_pack_staged",
+    "surge_replay_bound_log",
     "surge_replay_append_fold",
     "surge_replay_append_events",
     "surge_replay_append_events_device",
@@ -124,6 +129,7 @@ INGEST_EXPORTS = (
     "surge_device_decoder_clear",
     "surge_replay_append_decoded",
     "surge_replay_append_decoded_async",
+    "surge_replay_stage_decoded",
     "surge_device_decoder_keys",
     "surge_device_decoder_key_table",
     "surge_device_decoder_counters",
@@ -271,6 +277,11 @@ def load() -> ctypes.CDLL:
         "surge_replay_prepare": ([vp, i32], i32),
         "surge_replay_layout_info": ([vp, ctypes.POINTER(CLayoutInfo)], i32),
         "surge_replay_index_order": ([vp, i32, vp, i64, ctypes.POINTER(i64)], i32),
+        "surge_replay_stage_reserve": ([vp, i64], i32),
+        "surge_replay_stage_events_device": ([vp, vp, vp, i64], i32),
+        "surge_replay_staged": ([vp, ctypes.POINTER(i64)], i32),
+        "surge_replay_pack_staged": ([vp, i64], i32),
+        "surge_replay_bound_log": ([vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
         "surge_replay_append_fold": ([vp, vp, vp, i64, vp, i64], i32),
         "surge_replay_append_fold_device": ([vp, vp, vp, i64, vp, i64], i32),
         "surge_replay_append_events": ([vp, vp, vp, i64], i32),
@@ -349,6 +360,7 @@ def load() -> ctypes.CDLL:
         "surge_device_decoder_clear": ([vp], i32),
         "surge_replay_append_decoded": ([vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
         "surge_replay_append_decoded_async": ([vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
+        "surge_replay_stage_decoded": ([vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
         "surge_device_decoder_keys": ([vp, vp, i64, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)], i32),
         "surge_device_decoder_key_table": ([vp, ctypes.POINTER(vp), ctypes.POINTER(vp)], i32),
         "surge_device_decoder_counters": ([vp, ctypes.POINTER(i64 * 4)], i32),

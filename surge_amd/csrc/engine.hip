@@ -146,6 +146,10 @@ struct surge_replay_handle {
   uint32_t* host_flags = nullptr;  // pinned: {groups, bad, skipped batches} of the last device group-by, copied back async
   uint32_t skipped_seen = 0;       // skipped batches already reported to the host
 
+  // the packer's staging log (surge_replay_stage_events_device): aggregate indices (u32) and events (16 B) in topic order
+  DevBuf stage_keys, stage_events;
+  int64_t staged_n = 0, stage_cap = 0;
+
   DevBuf published;                      // the last committed snapshot (surge_replay_snapshot_delta), n_agg x 64 B
   int64_t published_n = 0;
   const uint8_t* encode_filter = nullptr;  // surge_replay_set_encode_filter
@@ -621,7 +625,7 @@ int32_t surge_replay_destroy(surge_replay_handle* h) {
   h->host_flags = nullptr;
   h->cidx.release();
   h->tidx.release();
-  DevBuf* bufs[] = {&h->gb_temp, &h->gb_u32, &h->gb_flags, &h->gb_agg_idx, &h->gb_events, &h->published, &h->gathered[0], &h->gathered[1], &h->f64_tables, &h->nan_count, &h->ix_arena, &h->ix_cnt, &h->t_tiles, &h->t_gsub, &h->perm, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
+  DevBuf* bufs[] = {&h->gb_temp, &h->gb_u32, &h->gb_flags, &h->gb_agg_idx, &h->gb_events, &h->published, &h->gathered[0], &h->gathered[1], &h->f64_tables, &h->nan_count, &h->ix_arena, &h->ix_cnt, &h->stage_keys, &h->stage_events, &h->t_tiles, &h->t_gsub, &h->perm, &h->counter, &h->own_seg_off, &h->own_events, &h->own_init, &h->own_state, &h->d_analysis, &h->nz_off,
                     &h->nz_map, &h->block_counts, &h->plan, &h->batch_group_agg, &h->batch_group_off,
                     &h->batch_events, &h->poison_count, &h->gather_idx, &h->gather_out, &h->scan_totals};
   for (DevBuf* b : bufs) b->release();
@@ -1469,6 +1473,121 @@ int32_t surge_replay_append_events(surge_replay_handle* h, const int64_t* agg_id
   h->staged_busy[k] = true;
   h->h2d_valid = true;
   return surge_replay_append_events_device(h, (const int64_t*)h->gb_agg_idx.ptr, h->gb_events.ptr, n_events);
+}
+
+static int32_t stage_grow(surge_replay_handle* h, int64_t want) {
+  if (want <= h->stage_cap) return SURGE_OK;
+  if (want > 0xffffffffll) return fail(h, SURGE_E_UNSUPPORTED, "the staging log holds fewer than 2^32 events per pack");
+  int64_t cap = h->stage_cap * 2 > want ? h->stage_cap * 2 : want;
+  cap = cap < (1 << 16) ? (1 << 16) : (cap > 0xffffffffll ? 0xffffffffll : cap);
+  void *nk = nullptr, *ne = nullptr;
+  HIPCHK(h, hipMalloc(&nk, (size_t)cap * 4));
+  hipError_t e = hipMalloc(&ne, (size_t)cap * 16);
+  if (e == hipSuccess && h->staged_n > 0) {
+    e = hipMemcpyAsync(nk, h->stage_keys.ptr, (size_t)h->staged_n * 4, hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ne, h->stage_events.ptr, (size_t)h->staged_n * 16, hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  }
+  if (e != hipSuccess) {
+    (void)hipFree(nk);
+    if (ne) (void)hipFree(ne);
+    return fail_hip(h, e, "growing the staging log");
+  }
+  h->stage_keys.release();
+  h->stage_events.release();
+  h->stage_keys.ptr = nk; h->stage_keys.cap = (size_t)cap * 4;
+  h->stage_events.ptr = ne; h->stage_events.cap = (size_t)cap * 16;
+  h->stage_cap = cap;
+  return SURGE_OK;
+}
+
+int32_t surge_replay_stage_reserve(surge_replay_handle* h, int64_t n_events) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (n_events < 0) return fail(h, SURGE_E_INVALID, "negative size");
+  DeviceGuard g(h->device);
+  return stage_grow(h, n_events);
+}
+
+int32_t surge_replay_stage_events_device(surge_replay_handle* h, const int64_t* d_agg_idx, const void* d_events, int64_t n_events) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (h->v2) return fail(h, SURGE_E_UNSUPPORTED, "the packer serves v1 handles");
+  if (n_events < 0) return fail(h, SURGE_E_INVALID, "negative size");
+  if (n_events == 0) return SURGE_OK;
+  if (!d_agg_idx || !d_events) return fail(h, SURGE_E_INVALID, "NULL batch buffer");
+  DeviceGuard g(h->device);
+  {
+    const int32_t rc = stage_grow(h, h->staged_n + n_events);
+    if (rc != SURGE_OK) return rc;
+  }
+  HIPCHK(h, launch_pack_stage(d_agg_idx, (uint32_t)n_events, (uint32_t*)h->stage_keys.ptr + h->staged_n, h->stream));
+  HIPCHK(h, hipMemcpyAsync((char*)h->stage_events.ptr + (size_t)h->staged_n * 16, d_events, (size_t)n_events * 16, hipMemcpyDeviceToDevice, h->stream));
+  h->staged_n += n_events;
+  return SURGE_OK;
+}
+
+int32_t surge_replay_staged(surge_replay_handle* h, int64_t* n_events_out) {
+  if (!h || !n_events_out) return fail(h, SURGE_E_INVALID, "NULL argument");
+  *n_events_out = h->staged_n;
+  return SURGE_OK;
+}
+
+int32_t surge_replay_pack_staged(surge_replay_handle* h, int64_t n_agg) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (h->v2) return fail(h, SURGE_E_UNSUPPORTED, "the packer serves v1 handles");
+  if (n_agg < 0 || n_agg > 0xfffffffell) return fail(h, SURGE_E_INVALID, "n_agg out of range");
+  DeviceGuard g(h->device);
+  const uint32_t n = (uint32_t)h->staged_n;
+  unsigned bits = 1;
+  while (bits < 32 && ((uint64_t)(n_agg > 0 ? n_agg : 1) >> bits) != 0) ++bits;  // the key bits an index below n_agg needs
+  size_t temp = 0;
+  HIPCHK(h, pack_temp_bytes(n > 0 ? n : 1, bits, &temp));
+  DevBuf scratch, seg, evs;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t rows = n > 0 ? n : 1;
+  const size_t o_kb = up(temp), o_va = o_kb + up(rows * 4), o_vb = o_va + up(rows * 4), o_bad = o_vb + up(rows * 4), total = o_bad + 256;
+  hipError_t e = scratch.reserve(total);
+  if (e == hipSuccess) e = seg.reserve((size_t)(n_agg + 1) * 8);
+  if (e == hipSuccess) e = evs.reserve(rows * 16);
+  char* sb = (char*)scratch.ptr;
+  if (e == hipSuccess)
+    e = launch_pack((const uint32_t*)h->stage_keys.ptr, (const uint4*)h->stage_events.ptr, n, n_agg, bits, sb, temp, (uint32_t*)(sb + o_kb), (uint32_t*)(sb + o_va),
+                    (uint32_t*)(sb + o_vb), (int64_t*)seg.ptr, (uint4*)evs.ptr, (uint32_t*)(sb + o_bad), h->stream);
+  uint32_t bad = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&bad, sb + o_bad, 4, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  scratch.release();
+  if (e != hipSuccess) {
+    seg.release();
+    evs.release();
+    return fail_hip(h, e, "packing the staged events");
+  }
+  if (bad) {
+    seg.release();
+    evs.release();
+    return fail(h, SURGE_E_RANGE, "a staged event names an aggregate index >= n_agg (nothing bound, the staging log kept)");
+  }
+  // the packed log becomes the handle's own bound log
+  h->bound = false;
+  h->own_seg_off.release();
+  h->own_events.release();
+  h->own_init.release();
+  h->own_seg_off = seg;
+  h->own_events = evs;
+  seg.ptr = nullptr; seg.cap = 0; evs.ptr = nullptr; evs.cap = 0;
+  h->stage_keys.release();
+  h->stage_events.release();
+  h->staged_n = h->stage_cap = 0;
+  return surge_replay_bind_device_csr(h, (const int64_t*)h->own_seg_off.ptr, n_agg, h->own_events.ptr, (int64_t)n, nullptr, nullptr);
+}
+
+int32_t surge_replay_bound_log(surge_replay_handle* h, const int64_t** d_seg_off, const void** d_events, int64_t* n_agg, int64_t* n_events) {
+  if (!h) return fail(nullptr, SURGE_E_INVALID, "handle is NULL");
+  if (!h->bound) return fail(h, SURGE_E_STATE, "bound_log before load_csr/bind_device_csr/pack_staged");
+  if (d_seg_off) *d_seg_off = h->d_seg_off;
+  if (d_events) *d_events = h->d_events;
+  if (n_agg) *n_agg = h->n_agg;
+  if (n_events) *n_events = h->n_events;
+  return SURGE_OK;
 }
 
 int32_t surge_replay_snapshot(surge_replay_handle* h, void* states_out, uint8_t* present_out) {

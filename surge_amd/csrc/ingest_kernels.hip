@@ -2373,6 +2373,30 @@ int32_t surge_replay_append_decoded_async(surge_replay_handle* h, surge_device_d
   return OK;
 }
 
+int32_t surge_replay_stage_decoded(surge_replay_handle* h, surge_device_decoder* d, int64_t* n_events_out, int64_t* n_keys_out) {
+  if (!h || !d) return dfail(d, E_INVALID, "NULL argument");
+  if (n_events_out) *n_events_out = d->n_records;
+  if (n_keys_out) *n_keys_out = d->n_keys;
+  if (d->n_records > 0) {
+    void* hs = nullptr;
+    int32_t rc = surge_replay_get_stream(h, &hs);
+    if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
+    DeviceScope scope(d->device);
+    DCHK(d, hipEventRecord(d->ready, d->stream));
+    DCHK(d, hipStreamWaitEvent((hipStream_t)hs, d->ready, 0));
+    rc = surge_replay_stage_events_device(h, (const int64_t*)d->r_agg.p, d->r_ev.p, d->n_records);
+    const hipError_t e = hipEventRecord(d->consumed, (hipStream_t)hs);  // the next push_finish* waits for the copies out of the result arrays
+    d->consumed_valid = e == hipSuccess;
+    if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
+    if (e != hipSuccess) {
+      (void)surge_replay_synchronize(h);
+      return dfail(d, E_DEVICE, std::string("hipEventRecord: ") + hipGetErrorString(e));
+    }
+  }
+  d->n_records = 0;
+  return OK;
+}
+
 int32_t surge_device_decoder_clear(surge_device_decoder* d) {
   if (!d) return dfail(nullptr, E_INVALID, "decoder is NULL");
   d->n_records = 0;

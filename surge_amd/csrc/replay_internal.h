@@ -146,6 +146,12 @@ hipError_t launch_groupby(const int64_t* d_agg_idx, const uint4* d_events, uint3
                           uint32_t* gid, uint4* d_sorted_events, int64_t* d_group_agg, int64_t* d_group_off, uint32_t* d_flags,
                           hipStream_t stream);
 
+// the packer (surge_replay_pack_staged): staged (aggregate, event) pairs in topic order -> CSR
+hipError_t launch_pack_stage(const int64_t* d_agg_idx, uint32_t n, uint32_t* keys, hipStream_t stream);
+hipError_t pack_temp_bytes(uint32_t n, unsigned key_bits, size_t* bytes);
+hipError_t launch_pack(const uint32_t* keys_a, const uint4* staged_events, uint32_t n, int64_t n_agg, unsigned key_bits, void* d_temp, size_t temp_bytes,
+                       uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t* seg_off, uint4* out, uint32_t* d_bad, hipStream_t stream);
+
 // ---- comm.hip: the snapshot exchange over RCCL (dlopen'ed) ----------------------------------------------------
 struct CommState;
 int32_t comm_unique_id(uint8_t* id_out, std::string* err);

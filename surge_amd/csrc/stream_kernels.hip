@@ -78,7 +78,71 @@ __global__ void groupby_scatter_kernel(const uint32_t* __restrict__ keys, const 
   }
 }
 
+// ---- the packer (surge_replay_pack_staged) ---------------------------------------------------------------------------------
+__global__ void pack_stage_kernel(const int64_t* __restrict__ agg_idx, uint32_t n, uint32_t* __restrict__ keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t a = agg_idx[i];
+  keys[i] = (a < 0 || a > 0xfffffffell) ? 0xffffffffu : (uint32_t)a;  // (out of range: caught by the pack's check of the largest key)
+}
+
+// vals[i] = i; bad[0] |= a staged index that is not an aggregate of the log being packed
+__global__ void pack_iota_kernel(const uint32_t* __restrict__ keys, uint32_t n, int64_t n_agg, uint32_t* __restrict__ vals, uint32_t* __restrict__ bad) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  vals[i] = i;
+  if ((int64_t)keys[i] >= n_agg) atomicOr(bad, 1u);
+}
+
+// seg_off[a] = first position of an aggregate index >= a in the sorted keys (a = n_agg: the end)
+__global__ void pack_seg_off_kernel(const uint32_t* __restrict__ keys, uint32_t n, int64_t n_agg, int64_t* __restrict__ seg_off) {
+  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a > n_agg) return;
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if ((int64_t)keys[mid] < a) lo = mid + 1; else hi = mid;
+  }
+  seg_off[a] = (int64_t)lo;
+}
+
+__global__ void pack_gather_kernel(const uint32_t* __restrict__ pos, uint32_t n, const uint4* __restrict__ staged, uint4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = staged[pos[i]];
+}
+
 }  // namespace
+
+hipError_t launch_pack_stage(const int64_t* d_agg_idx, uint32_t n, uint32_t* keys, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_stage_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, d_agg_idx, n, keys);
+  return hipGetLastError();
+}
+
+hipError_t pack_temp_bytes(uint32_t n, unsigned key_bits, size_t* bytes) {
+  size_t a = 0;
+  const hipError_t e = sort_pairs<rocprim::default_config>(nullptr, a, nullptr, nullptr, nullptr, nullptr, (size_t)n, key_bits, (hipStream_t) nullptr);
+  *bytes = a;
+  return e;
+}
+
+// keys_a: the staged aggregate indices (n x u32); keys_b / vals_a / vals_b: n x u32 scratch; seg_off: n_agg + 1; out: n x 16 B;
+// d_bad: one u32, != 0 afterwards when an index was >= n_agg (the arrays then hold garbage: the caller drops them)
+hipError_t launch_pack(const uint32_t* keys_a, const uint4* staged_events, uint32_t n, int64_t n_agg, unsigned key_bits, void* d_temp, size_t temp_bytes,
+                       uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t* seg_off, uint4* out, uint32_t* d_bad, hipStream_t stream) {
+  const unsigned blocks = (n + 255u) / 256u;
+  hipError_t e0 = hipMemsetAsync(d_bad, 0, 4, stream);
+  if (e0 != hipSuccess) return e0;
+  if (n > 0) {
+    hipLaunchKernelGGL(pack_iota_kernel, dim3(blocks), dim3(256), 0, stream, keys_a, n, n_agg, vals_a, d_bad);
+    size_t tb = temp_bytes;
+    const hipError_t e = sort_pairs<rocprim::default_config>(d_temp, tb, keys_a, keys_b, vals_a, vals_b, (size_t)n, key_bits, stream);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(pack_seg_off_kernel, dim3((unsigned)((n_agg + 1 + 255) / 256)), dim3(256), 0, stream, (const uint32_t*)keys_b, n, n_agg, seg_off);
+  if (n > 0) hipLaunchKernelGGL(pack_gather_kernel, dim3(blocks), dim3(256), 0, stream, (const uint32_t*)vals_b, n, staged_events, out);
+  return hipGetLastError();
+}
 
 // scratch bytes the two rocPRIM primitives need for n events (the larger of the two)
 hipError_t groupby_temp_bytes(uint32_t n, unsigned key_bits, size_t* bytes) {

@@ -559,6 +559,14 @@ class DeviceDecoder:
         self._check(fn(engine._h, self._h, ctypes.byref(n_ev), ctypes.byref(n_keys)))
         return int(n_ev.value), int(n_keys.value)
 
+    def stage_into(self, engine):
+        """Everything decoded since the last clear, appended to ``engine``'s staging log instead of folded, and cleared
+        (``surge_replay_stage_decoded``; no host wait).  A recovery that folds the topic once ends with
+        ``engine.pack_staged(n_keys)`` + one ``engine.fold()``.  Returns ``(n_events, n_keys)``."""
+        n_ev, n_keys = ctypes.c_int64(), ctypes.c_int64()
+        self._check(self._lib.surge_replay_stage_decoded(engine._h, self._h, ctypes.byref(n_ev), ctypes.byref(n_keys)))
+        return int(n_ev.value), int(n_keys.value)
+
     @property
     def n_keys(self) -> int:
         n = ctypes.c_int64()

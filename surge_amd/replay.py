@@ -255,6 +255,49 @@ class ReplayEngine:
             raise ValueError("one aggregate index per event")
         self._check(self._lib.surge_replay_append_events(self._h, _np_ptr(agg_idx), _np_ptr(events), events.shape[0]))
 
+    # -- the device packer: decoded events in topic order -> a bound CSR log ---------------------
+    def stage_reserve(self, n_events: int) -> None:
+        self._check(self._lib.surge_replay_stage_reserve(self._h, int(n_events)))
+
+    def stage_events(self, agg_idx, events) -> None:
+        """Append CUDA tensors ``agg_idx`` (int64) / ``events`` (16 B each), topic order, to the staging log
+        (``surge_replay_stage_events_device``); ``pack_staged`` turns everything staged into the bound log."""
+        n_events = (events.numel() * events.element_size()) // 16
+        if agg_idx.numel() != n_events:
+            raise ValueError("one aggregate index per event")
+        self._check(self._lib.surge_replay_stage_events_device(self._h, _dev_ptr(agg_idx), _dev_ptr(events), n_events))
+        self._keep_batch = [agg_idx, events]
+
+    @property
+    def staged(self) -> int:
+        n = ctypes.c_int64()
+        self._check(self._lib.surge_replay_staged(self._h, ctypes.byref(n)))
+        return int(n.value)
+
+    def pack_staged(self, n_agg: int) -> None:
+        """Everything staged -> a CSR log over ``n_agg`` aggregates, bound to the handle (``surge_replay_pack_staged``)."""
+        self._check(self._lib.surge_replay_pack_staged(self._h, int(n_agg)))
+        self.n_agg = int(n_agg)
+        self._keep = []
+        self._keep_batch = None
+
+    def bound_log(self):
+        """``(seg_off, events[n, 2] int64)`` CUDA tensor views of the bound log (valid until the next load / bind / pack)."""
+        import torch
+
+        po, pe = ctypes.c_void_p(), ctypes.c_void_p()
+        na, ne = ctypes.c_int64(), ctypes.c_int64()
+        self._check(self._lib.surge_replay_bound_log(self._h, ctypes.byref(po), ctypes.byref(pe), ctypes.byref(na), ctypes.byref(ne)))
+        dev = torch.device("cuda", self.device)
+
+        def view(ptr, shape):
+            iface = {"shape": shape, "typestr": "<i8", "data": (ptr.value or 0, False), "version": 2}
+            return torch.as_tensor(type("_Span", (), {"__cuda_array_interface__": iface})(), device=dev)
+
+        so = view(po, (na.value + 1,))
+        ev = view(pe, (ne.value, 2)) if ne.value else torch.zeros((0, 2), dtype=torch.int64, device=dev)
+        return so, ev
+
     def grow(self, new_n_agg: int) -> None:
         """Extend the resident state to ``new_n_agg`` aggregates (the new ones ``None``); see ``surge_replay_grow``."""
         self._check(self._lib.surge_replay_grow(self._h, int(new_n_agg)))

@@ -123,7 +123,7 @@ class GpuReplayStateStore:
         return counters
 
     def restore_from_fetches(self, fetches, capacity: int = 0, overlap: bool = True, n_partitions: int = 0, framing_threads: int = 8,
-                             consumer_threads: int = 1) -> dict:
+                             consumer_threads: int = 1, bound_log: bool = False, algo: int = ALGO_AUTO) -> dict:
         """Recover from the events topic as a consumer receives it: ``fetches`` yields the record-batch bytes of one
         partition, fetch by fetch, in offset order (a list, or a generator that polls) — or, with ``n_partitions``, per
         fetch response the next bytes of each of the consumer's partitions (``PartitionedFramedFetches``: one framer per
@@ -137,6 +137,12 @@ class GpuReplayStateStore:
         millisecond per 10^6-record fetch) to a worker thread and hands the results to the fold without a host wait
         (``PushPipeline``, ``surge_replay_append_decoded_async``); measured on the 10^7-aggregate topic it is not faster —
         the device is the bound there, not this thread — so one thread is the default.
+        ``bound_log=True``: a recovery that folds ONCE — every fetch's decoded events are staged on the device instead of
+        folded (``surge_replay_stage_decoded``), the topic's end packs them into one CSR log (``surge_replay_pack_staged``:
+        stable device sort by aggregate, topic order kept inside an aggregate) and ONE fold with ``algo`` (AUTO: the
+        lane-per-row kernels for a log large enough) produces the states; the packed log stays bound, so ``engine.fold`` /
+        ``engine.prepare`` can replay it.  What the reference's restore gets from RocksDB's key order
+        (``SurgeStateStoreConsumer.scala:57-76``).
         Needs values the device decoder reads (16-byte fixed events, or JSON with the model's
         ``event_json_template``); returns the ingest + decoder counters."""
         from .ingest import DeviceDecoder, FramedFetches, PartitionedFramedFetches, PushPipeline
@@ -171,6 +177,11 @@ class GpuReplayStateStore:
 
         def finish_one():
             nonlocal n_agg
+            if bound_log:
+                d.finish(wait=not two_threads)
+                _, n_keys = d.stage_into(self.engine)  # no fold: the topic's end packs what was staged
+                n_agg = max(n_agg, n_keys)
+                return
             if n_agg < 0:
                 n_agg = capacity
                 self.engine.load_csr(np.zeros(n_agg + 1, dtype=np.int64), np.zeros(0, dtype=EVENT_DTYPE))
@@ -222,7 +233,12 @@ class GpuReplayStateStore:
                 if d is not None:
                     self.engine.synchronize()
                 counters = framed.counters()
-            if n_agg < 0:  # nothing deliverable in the whole topic
+            if bound_log and d is not None:
+                n_agg = max(n_agg, capacity, d.n_keys)
+                self.engine.pack_staged(n_agg)  # decoded fetches -> ONE bound CSR log
+                self.engine.fold(algo)
+                self.engine.synchronize()
+            elif n_agg < 0:  # nothing deliverable in the whole topic
                 n_agg = capacity
                 self.engine.load_csr(np.zeros(n_agg + 1, dtype=np.int64), np.zeros(0, dtype=EVENT_DTYPE))
                 self.engine.fold()
