@@ -212,6 +212,9 @@ def main():
     ap.add_argument("--framing-threads", type=int, default=12, help="e2e: host threads framing a fetch's partitions side by side (12 of the boxes' 16-CPU quota: a topic of small "
                     "publisher flushes holds 32 000 batches per 10^6-record fetch and is bound by the framing — 8 -> 12 threads: 6.1 -> 6.55e8 events/s on one box, profiles/r05_e2e_framing_threads.jsonl; "
                     "capped at the CPUs the process may use minus three)")
+    ap.add_argument("--bound-log", action="store_true", help="e2e: a recovery that folds ONCE — every fetch's decoded events are staged on the device (surge_replay_stage_decoded), the topic's "
+                    "end packs them into one CSR log (surge_replay_pack_staged) and ONE fold of what AUTO picks for that log produces the states; the packed log is then re-folded a few times "
+                    "(refold_events_per_s).  Default: every fetch is folded onto the resident state as it arrives (K3)")
     ap.add_argument("--aggregates", type=int, default=None, help="global aggregate count (default 10 M for c4, 1 M for c2)")
     ap.add_argument("--events-per-aggregate", type=int, default=C2_EVENTS, help="c2 only")
     ap.add_argument("--algo", default=None,
@@ -555,7 +558,7 @@ def main():
             keep = ("value", "unit", "steps", "warmup", "ms_per_step", "data", "config", "roofline", "cpu_baseline")
             base = {**vars(args), "workload": "e2e", "warmup": 2, "batch_events": 1_000_000, "aggregates": None, "events_cap": 8, "writer": "independent",
                     "codec": "lz4", "serial_framing": False, "two_thread_consumer": False, "no_capacity_hint": False, "framing_threads": 12,
-                    "abort_every": 50, "hold_markers": 4}
+                    "abort_every": 50, "hold_markers": 4, "bound_log": False}
             e2e = run_e2e(_ap.Namespace(**{**base, "steps": 28, "txn_flush_events": 512}))
             result["e2e"] = {k: e2e[k] for k in keep}
             layouts = {"flush_512": {"value": e2e["value"], "control_batches": e2e["config"]["control_batches"], "parity": e2e["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_source_events"]}}
@@ -565,6 +568,12 @@ def main():
                 layouts[name] = {"value": o["value"], "control_batches": o["config"]["control_batches"], "data_batches": o["config"]["topic"]["data_batches"],
                                  "events_timed": o["config"]["events_timed"], "parity": o["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_source_events"]}
             result["e2e"]["layouts_events_per_s"] = layouts
+            # ... and the same topic the way a recovery that folds ONCE runs it: fetches staged on the device, one pack, one fold of the kernel AUTO picks
+            # for the packed log (1.2e7 records: the lane-per-row kernels need a log of that size), re-folds of the packed log beside it
+            torch.cuda.empty_cache()
+            o = run_e2e(_ap.Namespace(**{**base, "steps": 10, "txn_flush_events": 512, "bound_log": True}))
+            result["e2e"]["bound_log"] = {"value_bytes_to_staged_events_per_s": o["value"], **(o["config"]["bound_log"] or {}),
+                                          "parity": o["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_source_events"]}
         except Exception as exc:  # pragma: no cover
             result["e2e"] = {"skipped": repr(exc)}
     if dist is not None:
@@ -1093,7 +1102,11 @@ def run_e2e(args):
         dist.barrier()
     torch.cuda.synchronize(dev)
     t_start = time.perf_counter()
-    args.framing_threads = max(1, min(args.framing_threads, int(effective_cpus()[0]) - 3))
+    # host threads: the CPUs this process may use are shared by the node's ranks — each rank frames on its share minus the
+    # consumer thread (one rank: minus the consumer, the framing driver and the Python main thread's neighbours)
+    args.framing_threads = max(1, min(args.framing_threads, int(effective_cpus()[0]) // world - (3 if world == 1 else 1)))
+    bound_log = bool(getattr(args, "bound_log", False))
+    cpu_t0 = [None]
     with PartitionedFramedFetches((f for f, _ in fetches), P, threads=args.framing_threads, hold=depth, overlap=not args.serial_framing) as framed, \
             DeviceDecoder(tmpl, device=local_rank) as d:
         # capacity hints (a recovery knows roughly how many aggregates the store held: its last snapshot): the resident state
@@ -1116,8 +1129,15 @@ def run_e2e(args):
                 eng.grow(max(n_keys, min(2 * n_agg, my_ids.shape[0])))  # (grow in big steps: a grow copies the resident state)
                 n_agg = eng.n_agg
             tb = time.perf_counter()
-            d.fold_into(eng, wait=wait)
+            if bound_log:
+                d.stage_into(eng)  # no fold: the topic's end packs what was staged (below)
+                if wait:
+                    eng.synchronize()
+            else:
+                d.fold_into(eng, wait=wait)
             t2 = time.perf_counter()
+            if len(marks) == W - 1:
+                cpu_t0[0] = time.process_time()  # host CPU seconds (every thread of this process) from the end of the warm-up on
             if os.environ.get("SURGE_BENCH_TRACE"):
                 print(f"[bench] fetch {len(marks)}: finish {(ta - t1) * 1e3:.2f} grow {(tb - ta) * 1e3:.2f} fold {(t2 - tb) * 1e3:.2f} ms, keys {n_keys}", file=sys.stderr)
             marks.append(t2)
@@ -1161,10 +1181,29 @@ def run_e2e(args):
             push_ms = [x * 1e3 for x in pipe.push_seconds]
         torch.cuda.synchronize(dev)
         marks[-1] = time.perf_counter()  # (the last fetch counts as done when the device is)
+        cpu_s = time.process_time() - (cpu_t0[0] if cpu_t0[0] is not None else 0.0)
         torch.cuda.synchronize(dev)
         t_begin = marks[W - 1] if W > 0 else t_start
         elapsed_local = marks[-1] - t_begin
         n_keys = keys_at[-1]
+        packed = None
+        if bound_log:
+            # the topic's end: everything staged -> ONE bound CSR log -> ONE fold (what AUTO picks for it); then the re-fold rate
+            n_staged = eng.staged
+            tp0 = time.perf_counter()
+            eng.pack_staged(max(n_keys, hint))
+            eng.synchronize()
+            tp1 = time.perf_counter()
+            eng.fold()
+            eng.synchronize()
+            tp2 = time.perf_counter()
+            lay = eng.layout_info()
+            dt_r, st_r, tm_r = time_folds(eng, torch, dev, S.ALGO_AUTO, 10, 1)
+            packed = {"staged_events": n_staged, "pack_ms": (tp1 - tp0) * 1e3, "first_fold_ms_incl_index": (tp2 - tp1) * 1e3, "index_build_ms": lay.index_build_ms,
+                      "algo": algo_name(S, st_r.last_algo), "kernel": kernel_name(S, st_r.last_algo), "refold_kernel_ms": float(np.mean(tm_r)),
+                      "refold_events_per_s": n_staged / (float(np.mean(tm_r)) * 1e-3), "refold_frac_of_8TBps": st_r.algorithmic_bytes / (float(np.mean(tm_r)) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                      "bytes_to_states_events_per_s_incl_pack_and_fold": sum(n for _, n in fetches[W:]) / (elapsed_local + (tp2 - tp0)),
+                      "log_bytes": st_r.algorithmic_bytes}
         states = eng.snapshot()[:n_keys]
         stats = d.stats()
         # the key table, as numbers (ids are acct-%08d: 13 bytes each)
@@ -1295,6 +1334,9 @@ def run_e2e(args):
                    "control_batches": None if topic_counts is None else topic_counts["control_batches"],
                    "aggregates": A, "events_cap": cap, "partitions": P, "fetch_records": n_fetch, "fetches": len(fetches), "pushes_in_flight": depth,
                    "consumer": "one thread, a host wait behind interning and behind the fold" if one_thread else "push worker thread + finisher, event-ordered hand-over to the fold (no host wait behind either)",
+                   "bound_log": packed,
+                   "host_cpu_ms_per_1e6_records": cpu_s * 1e3 / max(1, n_events_timed) * 1e6,
+                   "host_cpu_note": "process CPU time (every thread: framing pool, framing driver, consumer) over the timed fetches of rank 0",
                    "framing_threads": args.framing_threads, "capacity_hint": not args.no_capacity_hint, "events_timed": total_events, "per_rank_events": per_rank, "keys_interned": total_keys,
                    "wire_bytes_per_record": total_wire / max(1, int(totals[4].item())),
                    "fetch_ms": {"p50": float(np.percentile(lat, 50)), "p90": float(np.percentile(lat, 90)), "max": float(np.max(lat))},

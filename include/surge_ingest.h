@@ -134,12 +134,27 @@ int32_t surge_ingest_drain_json(surge_ingest* g, int64_t max, const surge_event_
 #define SURGE_INGEST_DEVICE_LZ4 0x200 /* FRAMES, and lz4 batches keep their LZ4 frame: the device decoder decodes the blocks on the
                                          GPU (one wave per 64 KiB block, assembled in LDS); frames kafka-clients would not write —
                                          blocks above 64 KiB, dependent blocks — it decompresses on the host                       */
+#define SURGE_INGEST_DEVICE_CRC 0x400 /* FRAMES, and a data batch's CRC-32C is verified ON THE DEVICE: the host checksums only the 40
+                                         header bytes the CRC covers in front of the records section (the state of the CRC register
+                                         after them travels with the section), the device decoder continues over the section's bytes
+                                         where they already are and fails the push (SURGE_E_CORRUPT, nothing delivered, no key kept)
+                                         when the result is not the batch's CRC.  The per-byte host work of framing is then gone:
+                                         what remains per batch is the header walk and the transaction bookkeeping.  Control batches
+                                         (78 bytes) are still verified on the host.  Sections of such a framer carry
+                                         SURGE_SECTION_CRC_PENDING in `codec` and are only good for a surge_device_decoder.
+                                         The price of verifying late: the framer has already acted on the batch's header (its
+                                         transaction bookkeeping) when the device finds the mismatch — like kafka-clients'
+                                         CorruptRecordException the failure ends this consumer's pass over the partition: discard
+                                         framer and decoder, start again from the last good offsets.                               */
+#define SURGE_SECTION_CRC_PENDING 0x100 /* in surge_batch_section.codec: the 8 bytes in front of byte_off hold {the batch's CRC-32C,
+                                           the CRC register after the covered header bytes}, little-endian u32 each                  */
 typedef struct surge_batch_section {
   int64_t byte_off;    /* the batch's records section inside the arena (surge_ingest_arena)            */
   int64_t byte_len;
   int64_t base_offset; /* Kafka offset of the batch's first record                                     */
   int32_t n_records;
-  int32_t codec;       /* 0: the records themselves; 3: one LZ4 frame that holds them (SURGE_INGEST_DEVICE_LZ4)  */
+  int32_t codec;       /* low byte 0: the records themselves; 3: one LZ4 frame that holds them (SURGE_INGEST_DEVICE_LZ4);
+                          | SURGE_SECTION_CRC_PENDING                                                             */
 } surge_batch_section;
 /* Pops up to max deliverable batches (committed / non-transactional, before any open transaction), in offset order.
  * SURGE_E_STATE on a decoder that was not created in FRAMES mode.

@@ -36,6 +36,7 @@ struct Batch {
   // FRAMES mode (device decode): the batch's records section, verbatim, inside the arena
   int64_t sect_off = -1, sect_len = 0, base_offset = 0;
   int32_t count = 0, sect_codec = 0;
+  bool crc_pending = false;  // SURGE_INGEST_DEVICE_CRC: the section is preceded by 8 bytes {crc, register after the header bytes} (sect_off points at them)
 };
 
 struct CrcTables {
@@ -271,6 +272,7 @@ struct surge_ingest {
   int isolation = SURGE_INGEST_READ_COMMITTED;
   bool frames = false;  // SURGE_INGEST_FRAMES: records are not parsed here, their sections go to a surge_device_decoder
   bool device_lz4 = false;  // SURGE_INGEST_DEVICE_LZ4: ... and LZ4 frames stay compressed (the device decoder undoes them)
+  bool device_crc = false;  // SURGE_INGEST_DEVICE_CRC: ... and a data batch's CRC-32C is finished and compared on the device
   std::string err;
   // FRAMES mode rotates through six arenas, one per feed: the sections a drain handed out stay where they are while
   // the next FIVE feeds fill the others, so host threads can frame fetches i + 1 .. i + 5 while a device decoder still
@@ -499,9 +501,10 @@ int64_t surge_lz4_frame_decompress(const uint8_t* src, int64_t n, uint8_t* dst, 
 int32_t surge_ingest_create(int32_t isolation_level, surge_ingest** out) {
   if (!out) return fail(nullptr, E_INVALID, "out is NULL");
   *out = nullptr;
-  const bool frames = (isolation_level & (SURGE_INGEST_FRAMES | SURGE_INGEST_DEVICE_LZ4)) != 0;
+  const bool frames = (isolation_level & (SURGE_INGEST_FRAMES | SURGE_INGEST_DEVICE_LZ4 | SURGE_INGEST_DEVICE_CRC)) != 0;
   const bool device_lz4 = (isolation_level & SURGE_INGEST_DEVICE_LZ4) != 0;
-  isolation_level &= ~(SURGE_INGEST_FRAMES | SURGE_INGEST_DEVICE_LZ4);
+  const bool device_crc = (isolation_level & SURGE_INGEST_DEVICE_CRC) != 0;
+  isolation_level &= ~(SURGE_INGEST_FRAMES | SURGE_INGEST_DEVICE_LZ4 | SURGE_INGEST_DEVICE_CRC);
   if (isolation_level != SURGE_INGEST_READ_UNCOMMITTED && isolation_level != SURGE_INGEST_READ_COMMITTED)
     return fail(nullptr, E_INVALID, "unknown isolation level");
   surge_ingest* g = new (std::nothrow) surge_ingest();
@@ -509,6 +512,7 @@ int32_t surge_ingest_create(int32_t isolation_level, surge_ingest** out) {
   g->isolation = isolation_level;
   g->frames = frames;
   g->device_lz4 = device_lz4;
+  g->device_crc = device_crc;
   *out = g;
   return OK;
 }
@@ -603,7 +607,7 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
   // nothing but its own bytes; the walk below then looks the verdicts up in order, so what is reported, and when, is
   // exactly what the one-thread walk reports).
   std::vector<uint8_t> crc_ok;
-  if (g->crc_threads > 1 && len >= (1 << 20)) {
+  if (g->crc_threads > 1 && len >= (1 << 20) && !g->device_crc) {
     try {
       verify_crcs_in_parallel(data, len, g->crc_threads, &crc_ok);
     } catch (...) {  // no memory / no thread: the walk computes the CRCs itself
@@ -630,9 +634,18 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
       const uint8_t magic = r.u8();
       if (magic != 2) return bail(E_UNSUPPORTED, "only message format v2 (magic 2) is supported");
       const uint32_t crc = (uint32_t)r.i32();
-      const bool crc_good = batch_no < crc_ok.size() ? crc_ok[batch_no] != 0 : surge_crc32c(r.p, r.end - r.p) == crc;
+      // SURGE_INGEST_DEVICE_CRC: the CRC of a data batch (the control bit is the 0x20 of the attributes, the two bytes behind
+      // the CRC) is only STARTED here — over the 40 header bytes it covers in front of the records section — and finished
+      // where the section's bytes go anyway: on the device.  What this thread still touches of a batch is its header.
+      const bool defer_crc = g->device_crc && batch_len >= 49 && !(r.p[1] & 0x20);
+      uint32_t crc_state = 0;
+      if (defer_crc) {
+        crc_state = ~surge_crc32c(r.p, 40);  // the register (not finalised) after attributes .. recordCount
+      } else {
+        const bool crc_good = batch_no < crc_ok.size() ? crc_ok[batch_no] != 0 : surge_crc32c(r.p, r.end - r.p) == crc;
+        if (!crc_good) return bail(SURGE_E_CORRUPT, "record batch CRC-32C mismatch");
+      }
       ++batch_no;
-      if (!crc_good) return bail(SURGE_E_CORRUPT, "record batch CRC-32C mismatch");
       const int16_t attrs = r.i16();
       (void)r.i32();  // lastOffsetDelta
       (void)r.i64();  // baseTimestamp
@@ -644,6 +657,10 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
       if (!r.ok || count < 0) return bail(SURGE_E_CORRUPT, "truncated batch header");
       const int codec = attrs & 7;
       const bool transactional = attrs & 0x10, control = attrs & 0x20;
+      // (a header that is only verified later, on the device, must not drive anything out of bounds before that: a record takes
+      // at least 7 bytes, and LZ4 expands at most 255 x)
+      if (defer_crc && (int64_t)count > ((r.end - r.p) / 7 + 1) * (codec ? 255 : 1))
+        return bail(SURGE_E_CORRUPT, "recordCount impossible for the batch's size (damaged header)");
       const uint8_t* recs = r.p;
       int64_t recs_len = r.end - r.p;
       int sect_codec = 0;
@@ -684,6 +701,13 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
         b.base_offset = base_offset;
         b.count = count;
         b.sect_codec = sect_codec;
+        if (defer_crc) {
+          if (recs != r.p) return bail(E_UNSUPPORTED, "SURGE_INGEST_DEVICE_CRC needs the sections to travel as they are on the wire (SURGE_INGEST_DEVICE_LZ4 for lz4 topics)");
+          const uint32_t pre[2] = {crc, crc_state};
+          g->arena_now().append((const uint8_t*)pre, 8);
+          b.sect_len += 8;
+          b.crc_pending = true;
+        }
         g->arena_now().append(recs, (size_t)recs_len);
         g->counters[1] += count;
       } else {
@@ -841,11 +865,11 @@ int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge
     Batch& b = g->queue.front();
     if (b.decided == 0) break;  // an open transaction: nothing behind it is stable yet
     if (b.decided == 1) {
-      out[n].byte_off = b.sect_off;
-      out[n].byte_len = b.sect_len;
+      out[n].byte_off = b.sect_off + (b.crc_pending ? 8 : 0);
+      out[n].byte_len = b.sect_len - (b.crc_pending ? 8 : 0);
       out[n].base_offset = b.base_offset;
       out[n].n_records = b.count;
-      out[n].codec = b.sect_codec;
+      out[n].codec = b.sect_codec | (b.crc_pending ? SURGE_SECTION_CRC_PENDING : 0);
       recs += b.count;
       ++n;
     }
@@ -949,6 +973,7 @@ struct surge_ingest_group {
   std::vector<MemberSave> saved;
   std::vector<int32_t> status;
   std::vector<int64_t> consumed;
+  int64_t expand_hint = 1;  // the slice factor the last feed needed (host-side lz4: the topic's compression ratio does not change from feed to feed)
   FramingPool pool;
   ~surge_ingest_group() {
     for (surge_ingest* x : g) delete x;
@@ -1040,7 +1065,10 @@ int32_t surge_ingest_group_feed(surge_ingest_group* grp, const uint8_t* const* d
   // Every partition's slice: what it still holds (open transactions, batches not drained yet) + this feed.  With
   // SURGE_INGEST_DEVICE_LZ4 a section is never longer than its batch; without it the host decompresses lz4 batches INTO the
   // slice, whose size is then only known afterwards: the feed is undone and run again with `expand` times the room.
-  for (int64_t expand = 1;; expand *= 4) {
+  // (the trial starts from the factor the last feed needed, not from 1: a group without SURGE_INGEST_DEVICE_LZ4 on a compressed
+  // topic otherwise framed — CRC, decompression and all — every fetch two or three times over, for ever; the factor is capped
+  // at 256: an LZ4 block expands at most 255 x)
+  for (int64_t expand = grp->expand_hint;; expand *= 4) {
     // what a failed feed is undone from
     try {
       for (int32_t p = 0; p < n; ++p) {
@@ -1126,10 +1154,11 @@ int32_t surge_ingest_group_feed(surge_ingest_group* grp, const uint8_t* const* d
         grp->err = "partition " + std::to_string(p) + ": " + grp->g[(size_t)p]->err;
       }
     }
-    if (overflow && expand < 4096) {  // (an LZ4 block expands at most 255 x)
+    if (overflow && expand < 256) {
       undo();
       continue;
     }
+    if (first_bad == OK) grp->expand_hint = expand;
     if (first_bad != OK) {
       undo();
       return first_bad;

@@ -72,11 +72,136 @@ struct ErrorCell {
   unsigned long long first_bad;  // min over (record index << 8 | status)
   unsigned int reserved, n_f64_host;
   unsigned int lz4_bad;          // the first section whose LZ4 frame did not decode (~0 = none)
-  unsigned int pad;
+  unsigned int crc_bad;          // the first section whose bytes do not give the batch's CRC-32C (~0 = none; SURGE_INGEST_DEVICE_CRC)
 };
 
 __device__ __forceinline__ void report(ErrorCell* err, int64_t rec, uint32_t status) {
   atomicMin(&err->first_bad, ((unsigned long long)rec << 8) | status);
+}
+
+// ---- CRC-32C of a batch, finished on the device (SURGE_INGEST_DEVICE_CRC) ----------------------------------------------------
+// A record batch's CRC-32C (Castagnoli, reflected; kafka-clients: Crc32C over attributes .. end of the batch) covers 40 header
+// bytes and then the records section — the bytes this decoder is handed anyway.  The host framer runs the CRC over the 40
+// header bytes only and passes on the register; one WAVE per section takes it from there, 16 KiB at a time:
+//   * the tile is laid right-aligned into a 16 KiB frame, lane l owns frame bytes [256 l, 256 l + 256) (the lanes in front of a
+//     short tile are empty: a zero register is neutral under what follows) and runs the plain bit-serial CRC over its piece,
+//     a dword at a time out of LDS (rows of 65 dwords: lanes read different banks) — 128 vector instructions per dword, no
+//     table, nothing shared between lanes;
+//   * a CRC register is linear in (register, data): crc(A || B) = shift(crc(A), |B|) ^ crc_0(B), and shifting by a FIXED
+//     length is one multiplication mod P by a constant x^(8 |B|) — six levels of a lane tree (|B| = 256, 512 .. 8192 bytes)
+//     and one more per tile (16384): seven constants, computed once on the host (crc_shift_constants).
+// A whole 10^6-record fetch (30 MB of sections) costs the chip ~25 us of vector time.  A mismatch is reported like a bad LZ4
+// frame: the push fails with SURGE_E_CORRUPT, nothing of it is delivered, no key it brought stays interned.
+struct CrcSpan {
+  int64_t off;      // the section's first byte in the staged bytes; {crc, register after the header} in the 8 bytes before it
+  int32_t len;
+  int32_t section;
+};
+struct CrcShift { uint32_t tree[6], tile; };
+constexpr uint32_t kCrcPoly = 0x82F63B78u;
+constexpr int kCrcTile = 16384, kCrcLdsDwords = 65 * 65;
+
+// a * b mod P, reflected representation (bit 31 = x^0): 32 fixed steps (zlib's multmodp stops early on a's last set bit —
+// and never on a == 0, which an empty lane's register is)
+__host__ __device__ inline uint32_t crc_mulmod(uint32_t a, uint32_t b) {
+  uint32_t p = 0u;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    p ^= b & (uint32_t)-(int32_t)((a >> (31 - i)) & 1u);
+    b = (b >> 1) ^ (kCrcPoly & (uint32_t)-(int32_t)(b & 1u));
+  }
+  return p;
+}
+
+// x^(8 n) mod P
+static uint32_t crc_x8n(uint64_t n) {
+  uint32_t sq = 1u << 30, p = 1u << 31;  // x^1, x^0
+  for (uint64_t bits = n * 8; bits; bits >>= 1) {
+    if (bits & 1u) p = crc_mulmod(sq, p);
+    sq = crc_mulmod(sq, sq);
+  }
+  return p;
+}
+
+static CrcShift crc_shift_constants() {
+  CrcShift k;
+  for (int s = 0; s < 6; ++s) k.tree[s] = crc_x8n(256ull << s);
+  k.tile = crc_x8n((uint64_t)kCrcTile);
+  return k;
+}
+
+__device__ __forceinline__ uint32_t crc_step32(uint32_t r) {
+#pragma unroll
+  for (int k = 0; k < 32; ++k) r = (r >> 1) ^ (kCrcPoly & (uint32_t)-(int32_t)(r & 1u));
+  return r;
+}
+
+__global__ void __launch_bounds__(64) crc_kernel(const uint8_t* __restrict__ bytes, const CrcSpan* __restrict__ spans, int32_t n_spans, CrcShift K,
+                                                 ErrorCell* err) {
+  __shared__ uint32_t A[kCrcLdsDwords];
+  const int lane = threadIdx.x;
+  const CrcSpan sp = spans[blockIdx.x];
+  const uint8_t* pre = bytes + sp.off - 8;
+  const uint32_t expect = (uint32_t)pre[0] | ((uint32_t)pre[1] << 8) | ((uint32_t)pre[2] << 16) | ((uint32_t)pre[3] << 24);
+  const uint32_t state = (uint32_t)pre[4] | ((uint32_t)pre[5] << 8) | ((uint32_t)pre[6] << 16) | ((uint32_t)pre[7] << 24);
+  uint32_t total = state;  // (a section of no bytes: the register as the host left it)
+  int64_t done = 0;
+  bool first = true;
+  while (done < sp.len) {
+    int32_t T = (int32_t)((sp.len - done) % kCrcTile);
+    if (T == 0) T = kCrcTile;
+    // frame byte p of this tile = global byte base + p, valid for p >= v0
+    const int32_t v0 = kCrcTile - T;
+    const int64_t base = sp.off + done - v0;   // (may lie in front of the staged bytes: only p >= v0 is ever read)
+    const int32_t sh = (int32_t)(base & 3);
+    const int64_t abase = base - sh;           // the aligned stream A[j] = dword at abase + 4 j, j in [0, 4096]
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j <= kCrcTile / 4; j += 64) {
+      const int64_t g = abase + 4ll * j;
+      uint32_t w = 0u;
+      if (g + 4 > base + v0 && g < base + kCrcTile) {  // overlaps the tile
+        if (g >= sp.off - 8 && g + 4 <= sp.off + sp.len + 64) w = *(const uint32_t*)(bytes + g);  // inside what was staged (the prefix in front, 64 spare bytes behind)
+        else
+          for (int b = 0; b < 4; ++b)
+            if (g + b >= sp.off && g + b < sp.off + sp.len) w |= (uint32_t)bytes[g + b] << (8 * b);
+      }
+      A[(j >> 6) * 65 + (j & 63)] = w;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // my 256 bytes: frame [256 lane, 256 lane + 256)
+    const int32_t p0 = 256 * lane, p1 = p0 + 256;
+    uint32_t r = 0u;
+    if (p1 > v0) {
+      int32_t p = p0 > v0 ? p0 : v0;
+      const bool holds_first = first && p0 <= v0;  // the section's very first byte is mine: the host's register goes in here
+      if (holds_first) r = state;
+      auto dword_at = [&](int32_t q) -> uint32_t {  // frame dword q (frame bytes [4 q, 4 q + 4))
+        const uint32_t lo = A[(q >> 6) * 65 + (q & 63)], hi = A[((q + 1) >> 6) * 65 + ((q + 1) & 63)];
+        return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh);
+      };
+      // the bytes in front of my first whole dword (a tile that starts inside one)
+      while ((p & 3) && p < p1) {
+        const uint32_t w = dword_at(p >> 2);
+        r ^= (w >> (8 * (p & 3))) & 0xffu;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r = (r >> 1) ^ (kCrcPoly & (uint32_t)-(int32_t)(r & 1u));
+        ++p;
+      }
+      for (; p + 4 <= p1; p += 4) r = crc_step32(r ^ dword_at(p >> 2));
+    }
+    // lane tree: after level s the lanes whose low s + 1 bits are set hold the register of their 2^(s+1) pieces
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      const uint32_t left = (uint32_t)__shfl_up((int)r, 1 << s, 64);
+      if (((lane >> s) & 1) && ((lane & ((1 << s) - 1)) == ((1 << s) - 1))) r = crc_mulmod(left, K.tree[s]) ^ r;
+    }
+    const uint32_t tile_reg = (uint32_t)__shfl((int)r, 63, 64);
+    total = first ? tile_reg : crc_mulmod(total, K.tile) ^ tile_reg;
+    first = false;
+    done += T;
+  }
+  if (lane == 0 && ~total != expect) atomicMin(&err->crc_bad, (unsigned int)sp.section);
 }
 
 // ---- LZ4 (the reference's producer publishes lz4: reference.conf:112) ------------------------------------------------
@@ -1325,6 +1450,8 @@ struct PushSlot {
   size_t pinned_cap = 0;
   std::vector<Section> h_secs;      // (sources of asynchronous copies: they live as long as the slot is busy)
   std::vector<Lz4Block> h_blocks;
+  std::vector<CrcSpan> h_crc;       // sections whose CRC-32C this push finishes on the device
+  Buf crc_spans;
   ErrorCell h_err;
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;      // recorded on `stream` behind stage 1
@@ -1552,7 +1679,7 @@ int32_t surge_device_decoder_destroy(surge_device_decoder* d) {
     if (s.done) (void)hipEventDestroy(s.done);
     if (s.released) (void)hipEventDestroy(s.released);
     Buf* sb[] = {&s.lz4_blocks, &s.lz4_sizes, &s.lz4_nseq, &s.lz4_seq, &s.lz4_cls, &s.d_bytes, &s.d_sections, &s.rec_a, &s.rec_b, &s.rec_c, &s.meta, &s.ev_tmp,
-                 &s.f64_list, &s.d_err};
+                 &s.f64_list, &s.d_err, &s.crc_spans};
     for (Buf* b : sb) b->release();
     if (s.pinned) (void)hipHostFree(s.pinned);
   }
@@ -1614,7 +1741,7 @@ int32_t slot_scratch(surge_device_decoder* d, PushSlot& s, int64_t n_rec) {
   DCHK(d, s.meta.reserve(R * sizeof(RecMeta), false, s.stream));
   DCHK(d, s.ev_tmp.reserve(R * 16, false, s.stream));
   DCHK(d, s.f64_list.reserve(R * 4, false, s.stream));
-  static const ErrorCell kZero{~0ull, 0u, 0u, ~0u, 0u};  // (the source of an asynchronous copy: it must outlive the call)
+  static const ErrorCell kZero{~0ull, 0u, 0u, ~0u, ~0u};  // (the source of an asynchronous copy: it must outlive the call)
   DCHK(d, hipMemcpyAsync(s.d_err.p, &kZero, sizeof(kZero), hipMemcpyHostToDevice, s.stream));
   return OK;
 }
@@ -1633,12 +1760,16 @@ int32_t slot_pinned(surge_device_decoder* d, PushSlot& s, size_t bytes) {
 // SURGE_DBG_DECODE=<lz4 mode><section mode> (two digits; timing experiments only — see Lz4Work::dbg / JsonCtx::dbg; a
 // lz4 mode needs a section mode, since the sections' bytes are then not the topic's)
 int32_t dbg_decode() {
+#ifdef SURGE_EXPERIMENTS  // this hook makes the decoder deliver records that are NOT the topic's: experiment builds of the library only
   static const int32_t v = [] {
     const char* e = std::getenv("SURGE_DBG_DECODE");
     const int32_t x = e ? std::atoi(e) : 0;
     return (x >= 10 && x % 10 == 0) ? x + 1 : x;
   }();
   return v;
+#else
+  return 0;
+#endif
 }
 
 // Stage 1 of a wire push: the parts' records sections to the device, LZ4 blocks decoded, every record chained, parsed and
@@ -1673,6 +1804,7 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
   try {
     secs.resize((size_t)total_sections);
     blocks.clear();
+    s.h_crc.clear();
     // the span of each part's arena this push needs, laid out one after the other (16-byte aligned) on the device
     int64_t at = 0;
     for (int32_t p = 0; p < n_parts; ++p) {
@@ -1680,7 +1812,9 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
       for (int64_t i = 0; i < n_sections[p]; ++i) {
         const surge_batch_section& in = sections[p][i];
         if (in.byte_off < 0 || in.byte_len < 0 || in.n_records < 0) return dfail(d, E_INVALID, "negative section field");
-        lo = in.byte_off < lo ? in.byte_off : lo;
+        const bool crc_pending = (in.codec & SURGE_SECTION_CRC_PENDING) != 0;
+        if (crc_pending && (in.byte_off < 8 || in.byte_len >= (1ll << 31))) return dfail(d, E_INVALID, "a CRC-pending section without its 8-byte prefix");
+        lo = in.byte_off - (crc_pending ? 8 : 0) < lo ? in.byte_off - (crc_pending ? 8 : 0) : lo;
         hi = in.byte_off + in.byte_len > hi ? in.byte_off + in.byte_len : hi;
       }
       if (n_sections[p] == 0) lo = hi = 0;
@@ -1691,6 +1825,7 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
       for (int64_t i = 0; i < n_sections[p]; ++i, ++at) {
         const surge_batch_section& in = sections[p][i];
         secs[(size_t)at] = Section{part_dev[(size_t)p] + (in.byte_off - lo), in.byte_len, in.base_offset, in.n_records, 0, n_rec};
+        if (in.codec & SURGE_SECTION_CRC_PENDING) s.h_crc.push_back(CrcSpan{part_dev[(size_t)p] + (in.byte_off - lo), (int32_t)in.byte_len, (int32_t)at});
         n_rec += in.n_records;
         max_recs = in.n_records > max_recs ? in.n_records : max_recs;
       }
@@ -1715,7 +1850,7 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
         // (the frame headers were written by the framing threads, on other cores: one cache miss per batch — 1.2 ms per
         // 7000-batch push — unless they are asked for ahead of time)
         if (i + 12 < n_sections[p]) __builtin_prefetch(bytes[p] + sections[p][i + 12].byte_off);
-        if (in.codec != 3 || in.n_records == 0) continue;
+        if ((in.codec & 0xff) != 3 || in.n_records == 0) continue;
         Section& sec = secs[(size_t)at];
         const uint8_t* f = bytes[p] + in.byte_off;
         const int64_t fl = in.byte_len;
@@ -1830,7 +1965,7 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
   lap("reserve");
   // the section and block tables travel through page-locked staging too: a copy from pageable memory waits for the stream
   // (1.4 ms of host time per push went there)
-  size_t need_stage = ((extra.size() + 15) & ~(size_t)15) + sec_bytes + blk_bytes + 64;
+  size_t need_stage = ((extra.size() + 15) & ~(size_t)15) + sec_bytes + blk_bytes + ((s.h_crc.size() * sizeof(CrcSpan) + 15) & ~(size_t)15) + 64;
   std::vector<char> in_place((size_t)n_parts, 0);
   for (int32_t p = 0; p < n_parts; ++p) {
     if (part_len[(size_t)p] == 0) continue;
@@ -1863,6 +1998,15 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
   }
   if (!extra.empty()) DCHK(d, hipMemcpyAsync((uint8_t*)s.d_bytes.p + n_raw, stage(extra.data(), extra.size()), extra.size(), hipMemcpyHostToDevice, st));
   DCHK(d, hipMemcpyAsync(s.d_sections.p, stage(secs.data(), sec_bytes), sec_bytes, hipMemcpyHostToDevice, st));
+  if (!s.h_crc.empty()) {
+    // the batches' CRC-32C, finished where their bytes now are (the host ran it over the 40 header bytes only)
+    static const CrcShift kShift = crc_shift_constants();
+    const size_t crc_bytes = s.h_crc.size() * sizeof(CrcSpan);
+    DCHK(d, s.crc_spans.reserve(crc_bytes, false, st));
+    DCHK(d, hipMemcpyAsync(s.crc_spans.p, stage(s.h_crc.data(), crc_bytes), crc_bytes, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(crc_kernel, dim3((unsigned)s.h_crc.size()), dim3(64), 0, st, (const uint8_t*)s.d_bytes.p, (const CrcSpan*)s.crc_spans.p, (int32_t)s.h_crc.size(), kShift,
+                       (ErrorCell*)s.d_err.p);
+  }
   lap("copies");
   const uint8_t* dby = (const uint8_t*)s.d_bytes.p;
   Section* dsec = (Section*)s.d_sections.p;
@@ -2059,7 +2203,7 @@ int32_t stage2(surge_device_decoder* d, PushSlot& s, bool wait) {
     PCHK(hipMemcpyAsync(&first_total, (unsigned long long*)d->first_scan.p + R, 8, hipMemcpyDeviceToHost, st));
     PCHK(hipMemcpyAsync(&kept, (uint32_t*)d->keep_pos.p + R, 4, hipMemcpyDeviceToHost, st));
     PCHK(hipStreamSynchronize(st));
-    if (ec.lz4_bad == ~0u && ec.first_bad != ~0ull && (uint32_t)(ec.first_bad & 0xff) == RS_COLLISION && attempt < 3) {
+    if (ec.lz4_bad == ~0u && ec.crc_bad == ~0u && ec.first_bad != ~0ull && (uint32_t)(ec.first_bad & 0xff) == RS_COLLISION && attempt < 3) {
       // Two different keys share a 64-bit hash (about 3 in a million pushes at 10^7 keys): the table gets another hash
       // function — every known key re-hashed from its bytes in the arena, the push's records from theirs — and the push
       // goes through again.  Nothing of it was committed.
@@ -2074,7 +2218,7 @@ int32_t stage2(surge_device_decoder* d, PushSlot& s, bool wait) {
         hipLaunchKernelGGL(rehash_kernel, dim3(kb), dim3(256), 0, st, (const unsigned long long*)d->key_hash.p, d->n_keys, table_of(d));
       }
       hipLaunchKernelGGL(rekey_records_kernel, dim3(rb), dim3(256), 0, st, dmeta, n_rec, dby, d->seed);
-      s.h_err = ErrorCell{~0ull, 0u, ec.n_f64_host, ~0u, 0u};
+      s.h_err = ErrorCell{~0ull, 0u, ec.n_f64_host, ~0u, ~0u};
       PCHK(hipMemcpyAsync(derr, &s.h_err, sizeof(s.h_err), hipMemcpyHostToDevice, st));
       continue;
     }
@@ -2086,6 +2230,12 @@ int32_t stage2(surge_device_decoder* d, PushSlot& s, bool wait) {
     PCHK(hipStreamSynchronize(st));
     return OK;
   };
+  if (ec.crc_bad != ~0u) {
+    const int32_t rc = rollback();
+    if (rc != OK) return rc;
+    return dfail(d, SURGE_E_CORRUPT, "record batch CRC-32C mismatch (verified on the device) in the batch at base offset " +
+                                         std::to_string(ec.crc_bad < s.h_secs.size() ? s.h_secs[ec.crc_bad].base_offset : -1));
+  }
   if (ec.lz4_bad != ~0u) {
     const int32_t rc = rollback();
     if (rc != OK) return rc;

@@ -21,6 +21,8 @@ from .schema import EVENT_DTYPE
 READ_UNCOMMITTED, READ_COMMITTED = 0, 1
 FRAMES = 0x100  # SURGE_INGEST_FRAMES: frame on the host, decode the records on the GPU (DeviceDecoder)
 DEVICE_LZ4 = 0x200  # SURGE_INGEST_DEVICE_LZ4: ... and leave LZ4 frames for the GPU as well
+DEVICE_CRC = 0x400  # SURGE_INGEST_DEVICE_CRC: ... and finish a data batch's CRC-32C on the GPU (the host checksums its 40 header bytes only)
+SECTION_CRC_PENDING = 0x100  # in a section's codec
 
 SECTION_DTYPE = np.dtype([("byte_off", "<i8"), ("byte_len", "<i8"), ("base_offset", "<i8"), ("n_records", "<i4"), ("codec", "<i4")])
 assert SECTION_DTYPE.itemsize == 32
@@ -84,14 +86,15 @@ class IngestError(RuntimeError):
 
 
 class EventsTopicIngest:
-    def __init__(self, isolation_level: int = READ_COMMITTED, frames: bool = False, device_lz4: bool = False, threads: int = 1):
+    def __init__(self, isolation_level: int = READ_COMMITTED, frames: bool = False, device_lz4: bool = False, threads: int = 1, device_crc: bool = False):
         self._lib = _native.load()
         self._h = ctypes.c_void_p()
         self.frames = frames
-        rc = self._lib.surge_ingest_create(isolation_level | (FRAMES if frames else 0) | (DEVICE_LZ4 if device_lz4 else 0), ctypes.byref(self._h))
+        rc = self._lib.surge_ingest_create(isolation_level | (FRAMES if frames else 0) | (DEVICE_LZ4 if device_lz4 else 0) | (DEVICE_CRC if device_crc else 0),
+                                           ctypes.byref(self._h))
         if rc != 0:
             raise IngestError(rc, (self._lib.surge_ingest_last_error(None) or b"").decode())
-        if (frames or device_lz4) and os.environ.get("SURGE_INGEST_PAGEABLE_ARENA") != "1":
+        if (frames or device_lz4 or device_crc) and os.environ.get("SURGE_INGEST_PAGEABLE_ARENA") != "1":
             # page-locked arena when a GPU is there: the device decoder copies out of it in place (a pageable arena works too)
             self._lib.surge_ingest_use_pinned_arena(self._h)
         if threads != 1:  # host threads verifying the batches' CRC-32C of one feed (surge_ingest_set_threads)
@@ -211,13 +214,15 @@ class FramedFetches:
     Iterating yields ``(sections, arena_address)`` per fetch, in order.  ``overlap=False`` frames inline (same results,
     one thread)."""
 
-    def __init__(self, fetches, isolation_level: int = READ_COMMITTED, device_lz4: bool = True, overlap: bool = True, threads: int = 1, hold: int = 1):
+    def __init__(self, fetches, isolation_level: int = READ_COMMITTED, device_lz4: bool = True, overlap: bool = True, threads: int = 1, hold: int = 1,
+                 device_crc: bool = True):
         import queue
         import threading
 
         if not 1 <= hold <= 5:
             raise ValueError("hold must be 1 .. 5 (the framer has six arenas)")
-        self._g = EventsTopicIngest(isolation_level, frames=True, device_lz4=device_lz4, threads=threads)
+        # device_crc needs the sections as they are on the wire: with host-side LZ4 (device_lz4=False) the host has the bytes in hand anyway
+        self._g = EventsTopicIngest(isolation_level, frames=True, device_lz4=device_lz4, threads=threads, device_crc=device_crc and device_lz4)
         self._fetches = iter(fetches)
         self._overlap = overlap
         self._hold = hold
@@ -301,7 +306,7 @@ class PartitionedFramedFetches:
     (the group rotates through six slabs)."""
 
     def __init__(self, fetches, n_partitions: int, threads: int = 8, hold: int = 3, isolation_level: int = READ_COMMITTED, device_lz4: bool = True,
-                 overlap: bool = True):
+                 overlap: bool = True, device_crc: bool = True):
         import queue
         import threading
 
@@ -309,7 +314,8 @@ class PartitionedFramedFetches:
             raise ValueError("hold must be 1 .. 5 (the group has six slabs)")
         self._lib = _native.load()
         self._h = ctypes.c_void_p()
-        rc = self._lib.surge_ingest_group_create(n_partitions, isolation_level | (DEVICE_LZ4 if device_lz4 else 0), ctypes.byref(self._h))
+        rc = self._lib.surge_ingest_group_create(n_partitions, isolation_level | (DEVICE_LZ4 if device_lz4 else 0) | (DEVICE_CRC if device_crc and device_lz4 else 0),
+                                                 ctypes.byref(self._h))
         if rc != 0:
             raise IngestError(rc, (self._lib.surge_ingest_group_last_error(None) or b"").decode())
         if os.environ.get("SURGE_INGEST_PAGEABLE_ARENA") != "1":

@@ -123,7 +123,7 @@ class GpuReplayStateStore:
         return counters
 
     def restore_from_fetches(self, fetches, capacity: int = 0, overlap: bool = True, n_partitions: int = 0, framing_threads: int = 8,
-                             consumer_threads: int = 1, bound_log: bool = False, algo: int = ALGO_AUTO) -> dict:
+                             consumer_threads: int = 1, bound_log: bool = False, algo: int = ALGO_AUTO, device_crc: bool = True) -> dict:
         """Recover from the events topic as a consumer receives it: ``fetches`` yields the record-batch bytes of one
         partition, fetch by fetch, in offset order (a list, or a generator that polls) — or, with ``n_partitions``, per
         fetch response the next bytes of each of the consumer's partitions (``PartitionedFramedFetches``: one framer per
@@ -194,8 +194,10 @@ class GpuReplayStateStore:
                 self.engine.n_agg = n_agg = n_keys  # (grown inside the call)
 
         try:
-            framer = (PartitionedFramedFetches(fetches, n_partitions, threads=framing_threads, hold=depth, overlap=overlap) if n_partitions
-                      else FramedFetches(fetches, overlap=overlap, hold=depth))
+            # device_crc: the batches' CRC-32C is finished on the GPU where their bytes go anyway (SURGE_INGEST_DEVICE_CRC): the framing
+            # threads touch a batch's header, not its bytes
+            framer = (PartitionedFramedFetches(fetches, n_partitions, threads=framing_threads, hold=depth, overlap=overlap, device_crc=device_crc) if n_partitions
+                      else FramedFetches(fetches, overlap=overlap, hold=depth, device_crc=device_crc))
             with framer as framed, (self.engine.on_own_stream() if two_threads else contextlib.nullcontext()):
                 try:
                     if two_threads:
@@ -395,7 +397,7 @@ def _sniff_value_kind(sections, arena_address: int):
     from . import _native
 
     for s in sections:
-        if int(s["codec"]) == 3:  # still an LZ4 frame (decoded on the GPU): look into it with the library's host decoder
+        if int(s["codec"]) & 0xFF == 3:  # still an LZ4 frame (decoded on the GPU): look into it with the library's host decoder
             frame = ctypes.string_at(arena_address + int(s["byte_off"]), int(s["byte_len"]))
             cap = max(1 << 16, 64 * len(frame))
             out = ctypes.create_string_buffer(cap)

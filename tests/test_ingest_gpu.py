@@ -744,3 +744,73 @@ def test_two_host_threads_drive_one_decoder_and_the_fold_takes_the_results_witho
         evs = model.encode_events(published[agg])
         off = np.array([0, evs.shape[0]], np.int64)
         assert states_b[by_key[agg]].tobytes() == oracle.fold_csr(off, evs, None, model.event_algebra())[0].tobytes(), agg
+
+
+@pytest.mark.gpu
+def test_a_batchs_crc32c_is_finished_on_the_device_and_a_damaged_byte_fails_the_push_like_the_host_check():
+    """SURGE_INGEST_DEVICE_CRC: the framer checksums the 40 header bytes a batch's CRC-32C covers and
+    passes the register on; one wave per section finishes it over the section's bytes on the device (crc_kernel: 16 KiB tiles,
+    lane pieces combined by multiplications with x^(8 n) mod P).  Sections of every shape — one record, a few hundred bytes,
+    more than one 16 KiB tile, more than two, lz4 frames and plain ones, at whatever alignment the arena gives them: the
+    decoded records are the host-checked framer's; one damaged byte — first / middle / last of a section, inside the covered
+    header fields, the CRC field itself — fails the PUSH with the host check's status (SURGE_E_CORRUPT), delivers nothing,
+    interns nothing, and the decoder takes the undamaged bytes afterwards."""
+    from surge_amd.ingest import SECTION_CRC_PENDING
+
+    rng = random.Random(17)
+    batches, off = [], 0
+    for n, comp in ((1, "none"), (3, "lz4"), (40, "none"), (700, "none"), (2500, "none"), (5000, "lz4"), (17, "none"), (1200, "lz4"), (333, "none"), (1, "lz4")):
+        rs = [(f"acct-{rng.randrange(5000):05d}:{off + j}".encode() + b"x" * rng.randrange(0, 3), counter_event(rng.choice([0, 1, 2]), off + j, rng.randrange(-50, 50)), []) for j in range(n)]
+        batches.append(kw.record_batch(off, rs, compression=comp))
+        off += n
+    wire = b"".join(batches)
+    starts = np.cumsum([0] + [len(b) for b in batches])
+
+    def decode(data, device_crc):
+        with EventsTopicIngest(frames=True, device_lz4=True, device_crc=device_crc) as g, DeviceDecoder(None) as d:
+            g.feed(data)
+            secs, arena = g.drain_sections()
+            assert bool(np.all((secs["codec"] & SECTION_CRC_PENDING) != 0)) == device_crc and secs.shape[0] == len(batches)
+            d.push(secs, arena)
+            agg, ev, offs, nk = d.result()
+            return agg.cpu().numpy(), ev.cpu().numpy(), offs.cpu().numpy(), d.keys()
+
+    host = decode(wire, False)
+    dev = decode(wire, True)
+    assert dev[3] == host[3] and all(h.tobytes() == g.tobytes() for h, g in zip(host[:3], dev[:3])) and host[0].shape[0] == off
+    # damage: (batch, position inside the batch)
+    spots = []
+    for b in (0, 2, 3, 4, 5, 7, 9):
+        L = len(batches[b])
+        spots += [(b, 61), (b, L - 1), (b, 61 + (L - 61) // 2)]      # first / last / middle byte of the records section
+    spots += [(4, 23), (4, 45), (5, 57), (3, 17), (3, 20)]          # covered header fields (lastOffsetDelta .. recordCount), the CRC field
+    for b, at in spots:
+        bad = bytearray(wire)
+        bad[starts[b] + at] ^= 0x40 if at != 23 else 0x01            # (0x01 of lastOffsetDelta: not the compression bits of the attributes)
+        bad = bytes(bad)
+        with EventsTopicIngest(frames=True, device_lz4=True) as g:
+            with pytest.raises(IngestError) as host_err:
+                g.feed(bad)
+        assert "CRC-32C mismatch" in str(host_err.value)
+        with EventsTopicIngest(frames=True, device_lz4=True, device_crc=True) as g, DeviceDecoder(None) as d:
+            g.feed(wire[: starts[1]])                                # a good push first: the table holds a key
+            d.push_from(g)
+            d.clear()
+            keys_before = d.keys()
+            with pytest.raises(IngestError) as dev_err:  # (a recordCount no batch of that size can hold is refused by the framer itself)
+                g.feed(bad[starts[1]:] if b >= 1 else bad)
+                secs, arena = g.drain_sections()
+                d.push(secs, arena)
+            if "recordCount impossible" in str(dev_err.value):
+                assert at == 57 and dev_err.value.status == host_err.value.status
+                continue
+            # (a damaged LZ4 frame header is already refused by the push's host-side walk of the frame, with the same status)
+            assert dev_err.value.status == host_err.value.status, (b, at, str(dev_err.value))
+            assert "CRC-32C mismatch (verified on the device)" in str(dev_err.value) or (batches[b][21 + 1] & 7 == 3 and "bad LZ4 frame" in str(dev_err.value)), (b, at, str(dev_err.value))
+            assert f"base offset {int(np.cumsum([0] + [x for x, _ in ((1, 0), (3, 0), (40, 0), (700, 0), (2500, 0), (5000, 0), (17, 0), (1200, 0), (333, 0), (1, 0))])[b])}" in str(dev_err.value)
+            assert d.keys() == keys_before and d.result()[0].shape[0] == 0
+            with EventsTopicIngest(frames=True, device_lz4=True, device_crc=True) as g2:  # ... and the undamaged rest goes through
+                g2.feed(wire[starts[1]:])
+                d.push_from(g2)
+                agg, ev, offs, nk = d.result()
+                assert ev.cpu().numpy().tobytes() == host[1][1:].tobytes() and d.keys() == host[3]
