@@ -209,9 +209,11 @@ def main():
     ap.add_argument("--abort-every", type=int, default=50, help="e2e, transactional topic: every N-th flush of a partition first fails (its records + an ABORT marker) and is retried; 0 = none")
     ap.add_argument("--hold-markers", type=int, default=4, help="e2e, transactional topic: on partitions p %% N == 1 the last marker of a fetch response arrives with the next one; 0 = never")
     ap.add_argument("--no-capacity-hint", action="store_true", help="e2e: let the resident state and the key table grow as aggregates appear instead of sizing them up front")
-    ap.add_argument("--framing-threads", type=int, default=12, help="e2e: host threads framing a fetch's partitions side by side (12 of the boxes' 16-CPU quota: a topic of small "
-                    "publisher flushes holds 32 000 batches per 10^6-record fetch and is bound by the framing — 8 -> 12 threads: 6.1 -> 6.55e8 events/s on one box, profiles/r05_e2e_framing_threads.jsonl; "
-                    "capped at the CPUs the process may use minus three)")
+    ap.add_argument("--framing-by-copy", action="store_true", help="e2e: frame the way rounds 4 / 5 did — every records section copied into the framer's slab and its CRC-32C run "
+                    "on the host (default: fetch responses are received into the slab and framed in place, the CRC-32C is finished on the device: the host reads batch headers only)")
+    ap.add_argument("--framing-threads", type=int, default=3, help="e2e: host threads receiving and framing a fetch's partitions side by side (3: in-place framing with the CRC on the device leaves the host the "
+                    "batch headers; rounds 4 / 5 framed by copy with the CRC on the host and needed 12 of the boxes' 16-CPU quota — --framing-by-copy --framing-threads 12; "
+                    "capped at this rank's share of the CPUs the process may use)")
     ap.add_argument("--bound-log", action="store_true", help="e2e: a recovery that folds ONCE — every fetch's decoded events are staged on the device (surge_replay_stage_decoded), the topic's "
                     "end packs them into one CSR log (surge_replay_pack_staged) and ONE fold of what AUTO picks for that log produces the states; the packed log is then re-folded a few times "
                     "(refold_events_per_s).  Default: every fetch is folded onto the resident state as it arrives (K3)")
@@ -557,7 +559,7 @@ def main():
             torch.cuda.empty_cache()
             keep = ("value", "unit", "steps", "warmup", "ms_per_step", "data", "config", "roofline", "cpu_baseline")
             base = {**vars(args), "workload": "e2e", "warmup": 2, "batch_events": 1_000_000, "aggregates": None, "events_cap": 8, "writer": "independent",
-                    "codec": "lz4", "serial_framing": False, "two_thread_consumer": False, "no_capacity_hint": False, "framing_threads": 12,
+                    "codec": "lz4", "serial_framing": False, "two_thread_consumer": False, "no_capacity_hint": False, "framing_threads": 3, "framing_by_copy": False,
                     "abort_every": 50, "hold_markers": 4, "bound_log": False}
             e2e = run_e2e(_ap.Namespace(**{**base, "steps": 28, "txn_flush_events": 512}))
             result["e2e"] = {k: e2e[k] for k in keep}
@@ -1107,7 +1109,9 @@ def run_e2e(args):
     args.framing_threads = max(1, min(args.framing_threads, int(effective_cpus()[0]) // world - (3 if world == 1 else 1)))
     bound_log = bool(getattr(args, "bound_log", False))
     cpu_t0 = [None]
-    with PartitionedFramedFetches((f for f, _ in fetches), P, threads=args.framing_threads, hold=depth, overlap=not args.serial_framing) as framed, \
+    by_copy = bool(getattr(args, "framing_by_copy", False))
+    with PartitionedFramedFetches((f for f, _ in fetches), P, threads=args.framing_threads, hold=depth, overlap=not args.serial_framing, device_crc=not by_copy,
+                                  in_place=not by_copy) as framed, \
             DeviceDecoder(tmpl, device=local_rank) as d:
         # capacity hints (a recovery knows roughly how many aggregates the store held: its last snapshot): the resident state
         # and the decoder's key table are sized for this rank's aggregates up front instead of growing step by step
@@ -1137,7 +1141,7 @@ def run_e2e(args):
                 d.fold_into(eng, wait=wait)
             t2 = time.perf_counter()
             if len(marks) == W - 1:
-                cpu_t0[0] = time.process_time()  # host CPU seconds (every thread of this process) from the end of the warm-up on
+                cpu_t0[0] = (time.process_time(), framed.cpu_seconds())  # host CPU seconds (every thread of this process; the framing threads' own) from the end of the warm-up on
             if os.environ.get("SURGE_BENCH_TRACE"):
                 print(f"[bench] fetch {len(marks)}: finish {(ta - t1) * 1e3:.2f} grow {(tb - ta) * 1e3:.2f} fold {(t2 - tb) * 1e3:.2f} ms, keys {n_keys}", file=sys.stderr)
             marks.append(t2)
@@ -1181,7 +1185,9 @@ def run_e2e(args):
             push_ms = [x * 1e3 for x in pipe.push_seconds]
         torch.cuda.synchronize(dev)
         marks[-1] = time.perf_counter()  # (the last fetch counts as done when the device is)
-        cpu_s = time.process_time() - (cpu_t0[0] if cpu_t0[0] is not None else 0.0)
+        cpu_s = time.process_time() - (cpu_t0[0][0] if cpu_t0[0] is not None else 0.0)
+        grp_cpu = framed.cpu_seconds()
+        recv_cpu_s, framing_cpu_s = (grp_cpu[0] - cpu_t0[0][1][0], grp_cpu[1] - cpu_t0[0][1][1]) if cpu_t0[0] is not None else grp_cpu
         torch.cuda.synchronize(dev)
         t_begin = marks[W - 1] if W > 0 else t_start
         elapsed_local = marks[-1] - t_begin
@@ -1216,6 +1222,7 @@ def run_e2e(args):
         koff = np.zeros(nk.value + 1, np.int64)
         lib.surge_device_decoder_keys(d._h, kb.ctypes.data_as(ctypes.c_void_p), kb.shape[0], koff.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nk), ctypes.byref(nb))
         host_ms = [x * 1e3 for x in framed.framing_seconds]
+        recv_ms = [x * 1e3 for x in framed.receive_seconds]
         ingest_counters = framed.counters()
     assert np.all(np.diff(koff) == 13), "every key is an acct-%08d id"
     digits = kb[: 13 * n_keys].reshape(n_keys, 13)[:, 5:].astype(np.int64) - 48
@@ -1336,7 +1343,14 @@ def run_e2e(args):
                    "consumer": "one thread, a host wait behind interning and behind the fold" if one_thread else "push worker thread + finisher, event-ordered hand-over to the fold (no host wait behind either)",
                    "bound_log": packed,
                    "host_cpu_ms_per_1e6_records": cpu_s * 1e3 / max(1, n_events_timed) * 1e6,
-                   "host_cpu_note": "process CPU time (every thread: framing pool, framing driver, consumer) over the timed fetches of rank 0",
+                   "host_cpu_ms_per_1e6_records_without_the_receive_copy": (cpu_s - recv_cpu_s) * 1e3 / max(1, n_events_timed) * 1e6,
+                   "framing_cpu_ms_per_1e6_records": framing_cpu_s * 1e3 / max(1, n_events_timed) * 1e6,
+                   "receive_copy_cpu_ms_per_1e6_records": recv_cpu_s * 1e3 / max(1, n_events_timed) * 1e6,
+                   "receive_copy_ms_per_fetch": float(np.mean(recv_ms[W:])) if len(recv_ms) > W else None,
+                   "host_cpu_note": "process CPU time (every thread: framing pool, framing driver, consumer — the consumer spins in its waits for the device) over the timed fetches of "
+                                    "rank 0.  In-place framing: a fetch response is RECEIVED into the framer's page-locked slab — here one memmove per partition out of the topic's "
+                                    "bytes objects, standing in for the socket read a consumer aims there (a read it performs either way): its CPU time is reported and subtracted separately",
+                   "framing": "by copy, CRC-32C on the host (rounds 4 / 5)" if by_copy else "in place (no copy of the sections), CRC-32C finished on the device",
                    "framing_threads": args.framing_threads, "capacity_hint": not args.no_capacity_hint, "events_timed": total_events, "per_rank_events": per_rank, "keys_interned": total_keys,
                    "wire_bytes_per_record": total_wire / max(1, int(totals[4].item())),
                    "fetch_ms": {"p50": float(np.percentile(lat, 50)), "p90": float(np.percentile(lat, 90)), "max": float(np.max(lat))},

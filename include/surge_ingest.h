@@ -148,6 +148,8 @@ int32_t surge_ingest_drain_json(surge_ingest* g, int64_t max, const surge_event_
                                          framer and decoder, start again from the last good offsets.                               */
 #define SURGE_SECTION_CRC_PENDING 0x100 /* in surge_batch_section.codec: the 8 bytes in front of byte_off hold {the batch's CRC-32C,
                                            the CRC register after the covered header bytes}, little-endian u32 each                  */
+#define SURGE_SECTION_CRC_WIRE    0x200 /* ... (in-place framing) the 44 bytes in front of byte_off are the batch's own crc field (big-endian)
+                                           and the 40 header bytes it covers, as received: the device runs the whole CRC             */
 typedef struct surge_batch_section {
   int64_t byte_off;    /* the batch's records section inside the arena (surge_ingest_arena)            */
   int64_t byte_len;
@@ -189,6 +191,22 @@ int32_t surge_ingest_group_destroy(surge_ingest_group* g);
 const char* surge_ingest_group_last_error(const surge_ingest_group* g);
 int32_t surge_ingest_group_feed(surge_ingest_group* g, const uint8_t* const* data, const int64_t* len, int32_t threads, int64_t* consumed_out,
                                 int64_t max_sections, surge_batch_section* sections_out, int64_t* n_sections_out, const uint8_t** slab_out);
+/* Framing IN PLACE: where the consumer can choose where a fetch response lands (a socket read, a JNI direct buffer), it
+ * receives straight into the group's next page-locked slab: receive_buffer returns room for `bytes` bytes there (behind the few
+ * sections the partitions carry over — open transactions); the feed that follows, with every data[p] inside that room,
+ * copies NOTHING: the sections it hands out are the received bytes themselves.  With SURGE_INGEST_DEVICE_LZ4 |
+ * SURGE_INGEST_DEVICE_CRC the host then reads a batch's 61-byte header and not one byte more (sections carry
+ * SURGE_SECTION_CRC_WIRE: the device runs the whole CRC-32C over the header bytes and the section as received).  A feed whose
+ * data lies elsewhere frames by copy as before.  lz4 batches need SURGE_INGEST_DEVICE_LZ4 in place. */
+int32_t surge_ingest_group_receive_buffer(surge_ingest_group* g, int64_t bytes, uint8_t** buf_out);
+/* ... and for a host whose fetch responses already lie somewhere else: receive_buffer for the sum of len[], then the one copy the
+ * socket read would have made — partition after partition, on `threads` threads — placed_out[p] = where partition p's bytes
+ * now are (NULL for len[p] == 0): what the in-place feed takes as data[p]. */
+int32_t surge_ingest_group_receive_copy(surge_ingest_group* g, const uint8_t* const* data, const int64_t* len, int32_t threads, const uint8_t** placed_out);
+/* What the group's host threads have cost so far, as thread CPU time (not wall): out[0] seconds inside receive_copy's copies,
+ * out[1] seconds framing (surge_ingest_group_feed's per-partition work: headers, transactions — and the sections' copy and
+ * CRC-32C where those still run on the host). */
+int32_t surge_ingest_group_cpu_seconds(const surge_ingest_group* g, double out[2]);
 int64_t surge_ingest_group_queued_sections(const surge_ingest_group* g); /* batches the partitions hold from earlier feeds (upper bound of what the next feed delivers beyond its own) */
 int32_t surge_ingest_group_counters(const surge_ingest_group* g, int64_t out[8]); /* surge_ingest_counters, summed */
 int32_t surge_ingest_group_set_allocator(surge_ingest_group* g, void* (*alloc)(size_t), void (*release)(void*));

@@ -108,6 +108,9 @@ INGEST_EXPORTS = (
     "surge_ingest_group_destroy",
     "surge_ingest_group_last_error",
     "surge_ingest_group_feed",
+    "surge_ingest_group_receive_buffer",
+    "surge_ingest_group_receive_copy",
+    "surge_ingest_group_cpu_seconds",
     "surge_ingest_group_queued_sections",
     "surge_ingest_group_counters",
     "surge_ingest_group_set_allocator",
@@ -339,6 +342,9 @@ def load() -> ctypes.CDLL:
         "surge_ingest_group_destroy": ([vp], i32),
         "surge_ingest_group_last_error": ([vp], ctypes.c_char_p),
         "surge_ingest_group_feed": ([vp, vp, vp, i32, vp, i64, vp, ctypes.POINTER(i64), ctypes.POINTER(vp)], i32),
+        "surge_ingest_group_receive_buffer": ([vp, i64, ctypes.POINTER(vp)], i32),
+        "surge_ingest_group_receive_copy": ([vp, vp, vp, i32, vp], i32),
+        "surge_ingest_group_cpu_seconds": ([vp, ctypes.POINTER(ctypes.c_double * 2)], i32),
         "surge_ingest_group_queued_sections": ([vp], i64),
         "surge_ingest_group_counters": ([vp, ctypes.POINTER(i64 * 8)], i32),
         "surge_ingest_group_set_allocator": ([vp, vp, vp], i32),

@@ -7,6 +7,8 @@
 #include <deque>
 #include <new>
 #include <string>
+#include <time.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -36,7 +38,10 @@ struct Batch {
   // FRAMES mode (device decode): the batch's records section, verbatim, inside the arena
   int64_t sect_off = -1, sect_len = 0, base_offset = 0;
   int32_t count = 0, sect_codec = 0;
-  bool crc_pending = false;  // SURGE_INGEST_DEVICE_CRC: the section is preceded by 8 bytes {crc, register after the header bytes} (sect_off points at them)
+  // SURGE_INGEST_DEVICE_CRC: bytes in front of the section that travel with it (sect_off points at them): 8 = {crc, register after
+  // the header bytes} written by the framer; 44 = the batch's own crc field and the 40 header bytes it covers, as received
+  // (in-place framing: the device runs the whole CRC)
+  int32_t crc_prefix = 0;
 };
 
 struct CrcTables {
@@ -273,6 +278,7 @@ struct surge_ingest {
   bool frames = false;  // SURGE_INGEST_FRAMES: records are not parsed here, their sections go to a surge_device_decoder
   bool device_lz4 = false;  // SURGE_INGEST_DEVICE_LZ4: ... and LZ4 frames stay compressed (the device decoder undoes them)
   bool device_crc = false;  // SURGE_INGEST_DEVICE_CRC: ... and a data batch's CRC-32C is finished and compared on the device
+  bool inplace = false;     // (a group's in-place feed) `data` lies inside the slab this member's slice is a view of: sections stay where they were received
   std::string err;
   // FRAMES mode rotates through six arenas, one per feed: the sections a drain handed out stay where they are while
   // the next FIVE feeds fill the others, so host threads can frame fetches i + 1 .. i + 5 while a device decoder still
@@ -640,7 +646,7 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
       const bool defer_crc = g->device_crc && batch_len >= 49 && !(r.p[1] & 0x20);
       uint32_t crc_state = 0;
       if (defer_crc) {
-        crc_state = ~surge_crc32c(r.p, 40);  // the register (not finalised) after attributes .. recordCount
+        if (!g->inplace) crc_state = ~surge_crc32c(r.p, 40);  // the register (not finalised) after attributes .. recordCount
       } else {
         const bool crc_good = batch_no < crc_ok.size() ? crc_ok[batch_no] != 0 : surge_crc32c(r.p, r.end - r.p) == crc;
         if (!crc_good) return bail(SURGE_E_CORRUPT, "record batch CRC-32C mismatch");
@@ -666,6 +672,8 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
       int sect_codec = 0;
       if (codec == 3 && g->device_lz4 && !control) {
         sect_codec = 3;  // the frame travels as it is: the device decoder walks its blocks and decodes them on the GPU
+      } else if (codec == 3 && g->inplace && !control) {
+        return bail(E_UNSUPPORTED, "an in-place feed leaves the sections where they were received: lz4 topics need SURGE_INGEST_DEVICE_LZ4");
       } else if (codec == 3) {
         // first guess: the frame's content-size field when the producer wrote one, else 8x (Kafka's LZ4 output
         // stream omits it); a too-small guess comes back as -6 (out of space) and is grown, never as "corrupt"
@@ -701,14 +709,22 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
         b.base_offset = base_offset;
         b.count = count;
         b.sect_codec = sect_codec;
-        if (defer_crc) {
-          if (recs != r.p) return bail(E_UNSUPPORTED, "SURGE_INGEST_DEVICE_CRC needs the sections to travel as they are on the wire (SURGE_INGEST_DEVICE_LZ4 for lz4 topics)");
-          const uint32_t pre[2] = {crc, crc_state};
-          g->arena_now().append((const uint8_t*)pre, 8);
-          b.sect_len += 8;
-          b.crc_pending = true;
+        if (defer_crc && recs != r.p) return bail(E_UNSUPPORTED, "SURGE_INGEST_DEVICE_CRC needs the sections to travel as they are on the wire (SURGE_INGEST_DEVICE_LZ4 for lz4 topics)");
+        if (g->inplace) {
+          // nothing is copied: the section is where the fetch response was received (inside the slab this slice is a view of);
+          // with the device CRC the 44 bytes in front of it — the crc field and the header bytes it covers — go along as they are
+          b.crc_prefix = defer_crc ? 44 : 0;
+          b.sect_off = (int64_t)(recs - g->arena_now().data()) - b.crc_prefix;
+          b.sect_len = recs_len + b.crc_prefix;
+        } else {
+          if (defer_crc) {
+            const uint32_t pre[2] = {crc, crc_state};
+            g->arena_now().append((const uint8_t*)pre, 8);
+            b.sect_len += 8;
+            b.crc_prefix = 8;
+          }
+          g->arena_now().append(recs, (size_t)recs_len);
         }
-        g->arena_now().append(recs, (size_t)recs_len);
         g->counters[1] += count;
       } else {
         const int32_t rc = parse_records(g, b, recs, recs_len, count, base_offset, control, &control_type);
@@ -865,11 +881,11 @@ int32_t surge_ingest_drain_sections(surge_ingest* g, int64_t max_sections, surge
     Batch& b = g->queue.front();
     if (b.decided == 0) break;  // an open transaction: nothing behind it is stable yet
     if (b.decided == 1) {
-      out[n].byte_off = b.sect_off + (b.crc_pending ? 8 : 0);
-      out[n].byte_len = b.sect_len - (b.crc_pending ? 8 : 0);
+      out[n].byte_off = b.sect_off + b.crc_prefix;
+      out[n].byte_len = b.sect_len - b.crc_prefix;
       out[n].base_offset = b.base_offset;
       out[n].n_records = b.count;
-      out[n].codec = b.sect_codec | (b.crc_pending ? SURGE_SECTION_CRC_PENDING : 0);
+      out[n].codec = b.sect_codec | (b.crc_prefix == 8 ? SURGE_SECTION_CRC_PENDING : b.crc_prefix == 44 ? SURGE_SECTION_CRC_WIRE : 0);
       recs += b.count;
       ++n;
     }
@@ -973,6 +989,11 @@ struct surge_ingest_group {
   std::vector<MemberSave> saved;
   std::vector<int32_t> status;
   std::vector<int64_t> consumed;
+  // in-place feeds (surge_ingest_group_receive_buffer): the slab the caller is receiving into and the room in front of the
+  // receive region that the partitions' carried sections (open transactions) move into
+  int recv_slab = -1;
+  int64_t recv_carry = 0, recv_bytes = 0;
+  std::atomic<int64_t> cpu_ns[2] = {{0}, {0}};  // thread CPU time spent in {receive copies, framing} since the group was created (surge_ingest_group_cpu_seconds)
   int64_t expand_hint = 1;  // the slice factor the last feed needed (host-side lz4: the topic's compression ratio does not change from feed to feed)
   FramingPool pool;
   ~surge_ingest_group() {
@@ -1037,6 +1058,103 @@ int64_t surge_ingest_group_queued_sections(const surge_ingest_group* grp) {
   return n;
 }
 
+static int64_t thread_cpu_ns() {
+  struct timespec ts;
+  if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) != 0) return 0;
+  return (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
+
+int32_t surge_ingest_group_cpu_seconds(const surge_ingest_group* grp, double out[2]) {
+  if (!grp || !out) return E_INVALID;
+  out[0] = (double)grp->cpu_ns[0].load() * 1e-9;
+  out[1] = (double)grp->cpu_ns[1].load() * 1e-9;
+  return OK;
+}
+
+// what the partitions still hold (open transactions, batches not drained yet), 16-byte aligned per partition
+static int64_t group_carry_bytes(const surge_ingest_group* grp) {
+  int64_t total = 0;
+  for (const surge_ingest* x : grp->g) {
+    int64_t queued = 0;
+    for (const Batch& qb : x->queue) queued += qb.sect_off >= 0 ? qb.sect_len : 0;
+    total = (total + queued + 15) & ~15ll;
+  }
+  return total;
+}
+
+int32_t surge_ingest_group_receive_buffer(surge_ingest_group* grp, int64_t bytes, uint8_t** buf_out) {
+  if (!grp || !buf_out || bytes < 0) return fail(nullptr, E_INVALID, "bad argument");
+  *buf_out = nullptr;
+  const int next = (grp->cur + 1) % surge_ingest::kArenas;
+  Arena& slab = grp->slabs[next];
+  const int64_t carry = (group_carry_bytes(grp) + 63) & ~63ll;
+  try {
+    slab.clear();
+    const size_t want = (size_t)(carry + bytes) + 64;
+    if (slab.cap < want) {
+      const size_t roomy = want + want / 4 + 65536;  // (as surge_ingest_group_feed sizes them: every slab by the first response)
+      bool first = true;
+      for (const Arena& a : grp->slabs) first = first && a.cap == 0;
+      if (first) {
+        for (Arena& a : grp->slabs) a.reserve_exact(roomy);
+      } else {
+        slab.reserve_exact(roomy);
+      }
+    }
+  } catch (const std::bad_alloc&) {
+    grp->err = "out of host memory for the group's slab";
+    return E_NOMEM;
+  }
+  grp->recv_slab = next;
+  grp->recv_carry = carry;
+  grp->recv_bytes = bytes;
+  *buf_out = slab.data() + carry;
+  return OK;
+}
+
+// For a host whose fetch responses lie elsewhere (a test harness, a consumer library that owns its buffers): the one copy a
+// socket read would have made — every partition's bytes into the group's receive buffer, on `threads` threads (the calling
+// thread + the group's pool), cut into pieces of 1 MiB — and where each partition's bytes now are.
+int32_t surge_ingest_group_receive_copy(surge_ingest_group* grp, const uint8_t* const* data, const int64_t* len, int32_t threads, const uint8_t** placed_out) {
+  if (!grp || !data || !len || !placed_out) return fail(nullptr, E_INVALID, "bad argument");
+  const int32_t n = (int32_t)grp->g.size();
+  int64_t total = 0;
+  for (int32_t p = 0; p < n; ++p) {
+    if (len[p] < 0 || (!data[p] && len[p] > 0)) { grp->err = "bad buffer for partition " + std::to_string(p); return E_INVALID; }
+    total += len[p];
+  }
+  uint8_t* base = nullptr;
+  const int32_t rc = surge_ingest_group_receive_buffer(grp, total, &base);
+  if (rc != OK) return rc;
+  struct Piece { uint8_t* to; const uint8_t* from; size_t n; };
+  std::vector<Piece> pieces;
+  try {
+    int64_t at = 0;
+    for (int32_t p = 0; p < n; ++p) {
+      placed_out[p] = len[p] ? base + at : nullptr;
+      for (int64_t o = 0; o < len[p]; o += 1 << 20) pieces.push_back(Piece{base + at + o, data[p] + o, (size_t)(len[p] - o < (1 << 20) ? len[p] - o : (1 << 20))});
+      at += len[p];
+    }
+  } catch (const std::bad_alloc&) {
+    grp->err = "out of host memory";
+    return E_NOMEM;
+  }
+  std::atomic<size_t> next{0};
+  const std::function<void()> work = [&]() {
+    const int64_t t0 = thread_cpu_ns();
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= pieces.size()) break;
+      std::memcpy(pieces[k].to, pieces[k].from, pieces[k].n);
+    }
+    grp->cpu_ns[0] += thread_cpu_ns() - t0;
+  };
+  int32_t t = threads < 1 ? 1 : threads;
+  if ((size_t)t > pieces.size()) t = (int32_t)(pieces.size() ? pieces.size() : 1);
+  grp->pool.run(work, t - 1);
+  return OK;
+}
+
 int32_t surge_ingest_group_feed(surge_ingest_group* grp, const uint8_t* const* data, const int64_t* len, int32_t threads, int64_t* consumed_out,
                                 int64_t max_sections, surge_batch_section* sections_out, int64_t* n_sections_out, const uint8_t** slab_out) {
   if (!grp || !data || !len || !n_sections_out || !slab_out || max_sections < 0 || (!sections_out && max_sections > 0)) return fail(nullptr, E_INVALID, "bad argument");
@@ -1048,6 +1166,21 @@ int32_t surge_ingest_group_feed(surge_ingest_group* grp, const uint8_t* const* d
   for (int32_t p = 0; p < n; ++p)
     if (len[p] < 0 || (!data[p] && len[p] > 0)) { grp->err = "bad buffer for partition " + std::to_string(p); return E_INVALID; }
   const int group_cur = grp->cur;
+  // In place: every partition's bytes lie inside the region surge_ingest_group_receive_buffer handed out for this feed.  The
+  // sections then stay where they were received — the slab is not written at all beyond the few carried sections in front.
+  bool inplace = grp->recv_slab == (group_cur + 1) % surge_ingest::kArenas;
+  if (inplace) {
+    const uint8_t* lo = grp->slabs[grp->recv_slab].data() + grp->recv_carry;
+    const uint8_t* hi = lo + grp->recv_bytes;
+    bool any = false;
+    for (int32_t p = 0; p < n; ++p) {
+      if (len[p] == 0) continue;
+      any = true;
+      if (data[p] < lo || data[p] + len[p] > hi) inplace = false;
+    }
+    inplace = inplace && any;
+  }
+  grp->recv_slab = -1;
   auto undo = [&]() {
     for (int32_t p = 0; p < n; ++p) {
       surge_ingest* x = grp->g[(size_t)p];
@@ -1059,6 +1192,7 @@ int32_t surge_ingest_group_feed(surge_ingest_group* grp, const uint8_t* const* d
       grp->drained[(size_t)p].clear();
     }
     grp->cur = group_cur;
+    if (inplace) grp->recv_slab = (group_cur + 1) % surge_ingest::kArenas;  // (the received bytes are still there: the caller may feed them again)
     if (consumed_out)
       for (int32_t p = 0; p < n; ++p) consumed_out[p] = 0;
   };
@@ -1088,13 +1222,20 @@ int32_t surge_ingest_group_feed(surge_ingest_group* grp, const uint8_t* const* d
       int64_t queued = 0;
       for (const Batch& qb : grp->g[(size_t)p]->queue) queued += qb.sect_off >= 0 ? qb.sect_len : 0;
       grp->off[(size_t)p] = total;
-      total = (total + queued + len[p] * expand + 15) & ~15ll;
+      total = (total + queued + (inplace ? 0 : len[p] * expand) + 15) & ~15ll;
     }
     grp->off[(size_t)n] = total;
     Arena& slab = grp->slabs[(group_cur + 1) % surge_ingest::kArenas];
     try {
-      slab.clear();
-      if (slab.cap < (size_t)total + 16) {
+      if (inplace) {
+        if (total > grp->recv_carry) {  // (cannot happen: nothing was fed between receive_buffer and this call)
+          grp->err = "the partitions' carried sections outgrew the room surge_ingest_group_receive_buffer left for them";
+          return E_INVALID;
+        }
+      } else {
+        slab.clear();
+      }
+      if (!inplace && slab.cap < (size_t)total + 16) {
         // Page-locking a 30 - 45 MB slab takes 1.5 ms on a good day and 20 ms on a bad one (bytes -> states on the small-flush
         // topic: two of a dozen runs lost a 24 ms fetch to it and with it two thirds of their rate).  So the group's FIRST feed
         // sizes ALL its slabs, with a quarter to spare — fetch responses of one consumer are alike — and a recovery pays for
@@ -1115,9 +1256,10 @@ int32_t surge_ingest_group_feed(surge_ingest_group* grp, const uint8_t* const* d
     grp->cur = (group_cur + 1) % surge_ingest::kArenas;
     std::atomic<int32_t> next{0};
     const std::function<void()> work = [&]() {
+      const int64_t t0 = thread_cpu_ns();
       for (;;) {
         const int32_t p = next.fetch_add(1);
-        if (p >= n) return;
+        if (p >= n) break;
         surge_ingest* x = grp->g[(size_t)p];
         int32_t rc = OK;
         int64_t consumed = 0;
@@ -1125,7 +1267,9 @@ int32_t surge_ingest_group_feed(surge_ingest_group* grp, const uint8_t* const* d
           x->ext_next = slab.data() + grp->off[(size_t)p];
           x->ext_next_cap = (size_t)(grp->off[(size_t)p + 1] - grp->off[(size_t)p]);
           x->slice_overflow = false;
+          x->inplace = inplace;
           rc = surge_ingest_feed(x, data[p], len[p], &consumed);
+          x->inplace = false;
           std::vector<surge_batch_section>& out = grp->drained[(size_t)p];
           out.clear();
           if (rc == OK && !x->queue.empty()) {
@@ -1141,6 +1285,7 @@ int32_t surge_ingest_group_feed(surge_ingest_group* grp, const uint8_t* const* d
         grp->status[(size_t)p] = rc;
         grp->consumed[(size_t)p] = consumed;
       }
+      grp->cpu_ns[1] += thread_cpu_ns() - t0;
     };
     int32_t t = threads < 1 ? 1 : threads;
     if (t > n) t = n;

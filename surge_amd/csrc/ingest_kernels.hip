@@ -93,9 +93,12 @@ __device__ __forceinline__ void report(ErrorCell* err, int64_t rec, uint32_t sta
 // A whole 10^6-record fetch (30 MB of sections) costs the chip ~25 us of vector time.  A mismatch is reported like a bad LZ4
 // frame: the push fails with SURGE_E_CORRUPT, nothing of it is delivered, no key it brought stays interned.
 struct CrcSpan {
-  int64_t off;      // the section's first byte in the staged bytes; {crc, register after the header} in the 8 bytes before it
+  int64_t off;      // first byte the device still has to run the CRC over, in the staged bytes
   int32_t len;
   int32_t section;
+  uint32_t expect;  // the batch's CRC-32C
+  uint32_t state;   // the CRC register in front of `off`: after the 40 header bytes (the host ran those), or ~0 (in-place framing:
+                    // off points at the header bytes, the device runs everything)
 };
 struct CrcShift { uint32_t tree[6], tile; };
 constexpr uint32_t kCrcPoly = 0x82F63B78u;
@@ -141,9 +144,7 @@ __global__ void __launch_bounds__(64) crc_kernel(const uint8_t* __restrict__ byt
   __shared__ uint32_t A[kCrcLdsDwords];
   const int lane = threadIdx.x;
   const CrcSpan sp = spans[blockIdx.x];
-  const uint8_t* pre = bytes + sp.off - 8;
-  const uint32_t expect = (uint32_t)pre[0] | ((uint32_t)pre[1] << 8) | ((uint32_t)pre[2] << 16) | ((uint32_t)pre[3] << 24);
-  const uint32_t state = (uint32_t)pre[4] | ((uint32_t)pre[5] << 8) | ((uint32_t)pre[6] << 16) | ((uint32_t)pre[7] << 24);
+  const uint32_t expect = sp.expect, state = sp.state;
   uint32_t total = state;  // (a section of no bytes: the register as the host left it)
   int64_t done = 0;
   bool first = true;
@@ -160,7 +161,7 @@ __global__ void __launch_bounds__(64) crc_kernel(const uint8_t* __restrict__ byt
       const int64_t g = abase + 4ll * j;
       uint32_t w = 0u;
       if (g + 4 > base + v0 && g < base + kCrcTile) {  // overlaps the tile
-        if (g >= sp.off - 8 && g + 4 <= sp.off + sp.len + 64) w = *(const uint32_t*)(bytes + g);  // inside what was staged (the prefix in front, 64 spare bytes behind)
+        if (g >= sp.off - 4 && g + 4 <= sp.off + sp.len + 64) w = *(const uint32_t*)(bytes + g);  // inside what was staged (at least 4 bytes of prefix in front, 64 spare bytes behind)
         else
           for (int b = 0; b < 4; ++b)
             if (g + b >= sp.off && g + b < sp.off + sp.len) w |= (uint32_t)bytes[g + b] << (8 * b);
@@ -1501,6 +1502,8 @@ struct surge_device_decoder {
   // hand-over of the result arrays to a consumer on another stream (surge_replay_append_decoded_async): `consumed` is
   // recorded on the consumer's stream behind its last read, the next stage 2 waits for it before it writes the arrays
   hipEvent_t ready = nullptr, consumed = nullptr;
+  hipEvent_t sleeper = nullptr;  // hipEventBlockingSync: host waits of the consumer thread sleep on it instead of spinning
+  bool block_waits = true;
   bool consumed_valid = false;
   int64_t counters[4] = {0, 0, 0, 0};  // records seen, delivered, flush records skipped, f64 values re-parsed on the host
   int64_t reseeds = 0, pushes = 0;
@@ -1616,6 +1619,13 @@ int32_t surge_device_decoder_create(int32_t device_id, void* hip_stream, const s
     }
     DCHK(d, hipEventCreateWithFlags(&d->ready, hipEventDisableTiming));
     DCHK(d, hipEventCreateWithFlags(&d->consumed, hipEventDisableTiming));
+    // A consumer thread that waits for the device a few times per fetch spins a core away in hipStreamSynchronize (0.4 - 1.2 ms of
+    // CPU per 10^6-record fetch, and — on a host whose CPUs the framing threads need — 5 - 15 % of the bytes -> states rate:
+    // profiles/r06_e2e_host_budget.jsonl).  So those waits sleep on an interrupt-driven event (a wake-up costs tens of
+    // microseconds); SURGE_INGEST_WAIT=spin keeps hipStreamSynchronize.
+    d->block_waits = true;
+    if (const char* v = std::getenv("SURGE_INGEST_WAIT")) d->block_waits = std::strcmp(v, "spin") != 0;
+    if (d->block_waits) DCHK(d, hipEventCreateWithFlags(&d->sleeper, hipEventDisableTiming | hipEventBlockingSync));
     DCHK(d, d->key_off.reserve(8, false, d->stream));
     DCHK(d, hipMemset(d->key_off.p, 0, 8));
     if (tmpl) {
@@ -1688,6 +1698,7 @@ int32_t surge_device_decoder_destroy(surge_device_decoder* d) {
   for (Buf* b : bufs) b->release();
   if (d->ready) (void)hipEventDestroy(d->ready);
   if (d->consumed) (void)hipEventDestroy(d->consumed);
+  if (d->sleeper) (void)hipEventDestroy(d->sleeper);
   (void)hipSetDevice(prev);
   delete d;
   return OK;
@@ -1812,9 +1823,9 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
       for (int64_t i = 0; i < n_sections[p]; ++i) {
         const surge_batch_section& in = sections[p][i];
         if (in.byte_off < 0 || in.byte_len < 0 || in.n_records < 0) return dfail(d, E_INVALID, "negative section field");
-        const bool crc_pending = (in.codec & SURGE_SECTION_CRC_PENDING) != 0;
-        if (crc_pending && (in.byte_off < 8 || in.byte_len >= (1ll << 31))) return dfail(d, E_INVALID, "a CRC-pending section without its 8-byte prefix");
-        lo = in.byte_off - (crc_pending ? 8 : 0) < lo ? in.byte_off - (crc_pending ? 8 : 0) : lo;
+        const int64_t crc_prefix = (in.codec & SURGE_SECTION_CRC_PENDING) ? 8 : (in.codec & SURGE_SECTION_CRC_WIRE) ? 44 : 0;
+        if (crc_prefix && (in.byte_off < crc_prefix || in.byte_len >= (1ll << 31) - 64)) return dfail(d, E_INVALID, "a CRC-pending section without the bytes in front of it");
+        lo = in.byte_off - crc_prefix < lo ? in.byte_off - crc_prefix : lo;
         hi = in.byte_off + in.byte_len > hi ? in.byte_off + in.byte_len : hi;
       }
       if (n_sections[p] == 0) lo = hi = 0;
@@ -1825,7 +1836,6 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
       for (int64_t i = 0; i < n_sections[p]; ++i, ++at) {
         const surge_batch_section& in = sections[p][i];
         secs[(size_t)at] = Section{part_dev[(size_t)p] + (in.byte_off - lo), in.byte_len, in.base_offset, in.n_records, 0, n_rec};
-        if (in.codec & SURGE_SECTION_CRC_PENDING) s.h_crc.push_back(CrcSpan{part_dev[(size_t)p] + (in.byte_off - lo), (int32_t)in.byte_len, (int32_t)at});
         n_rec += in.n_records;
         max_recs = in.n_records > max_recs ? in.n_records : max_recs;
       }
@@ -1849,9 +1859,25 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
         const surge_batch_section& in = sections[p][i];
         // (the frame headers were written by the framing threads, on other cores: one cache miss per batch — 1.2 ms per
         // 7000-batch push — unless they are asked for ahead of time)
-        if (i + 12 < n_sections[p]) __builtin_prefetch(bytes[p] + sections[p][i + 12].byte_off);
-        if ((in.codec & 0xff) != 3 || in.n_records == 0) continue;
+        // ... the lines this walk reads of a section: its frame header (and, framed in place, the crc field 44 bytes in front of
+        // it), and the frame's last words — the EndMark behind its last block
+        if (i + 16 < n_sections[p]) {
+          const surge_batch_section& nx = sections[p][i + 16];
+          __builtin_prefetch(bytes[p] + nx.byte_off - ((nx.codec & SURGE_SECTION_CRC_WIRE) ? 44 : 0));
+          __builtin_prefetch(bytes[p] + nx.byte_off + 16);
+          if (nx.byte_len > 64) __builtin_prefetch(bytes[p] + nx.byte_off + nx.byte_len - 8);
+        }
         Section& sec = secs[(size_t)at];
+        if (in.codec & SURGE_SECTION_CRC_PENDING) {  // {crc, register after the header bytes}, written by the framer in front of the section
+          uint32_t pre[2];
+          std::memcpy(pre, bytes[p] + in.byte_off - 8, 8);
+          s.h_crc.push_back(CrcSpan{sec.byte_off, (int32_t)in.byte_len, (int32_t)at, pre[0], pre[1]});
+        } else if (in.codec & SURGE_SECTION_CRC_WIRE) {  // the batch as received: its crc field (big-endian), then the 40 header bytes it covers, then the section
+          const uint8_t* c = bytes[p] + in.byte_off - 44;
+          const uint32_t expect = ((uint32_t)c[0] << 24) | ((uint32_t)c[1] << 16) | ((uint32_t)c[2] << 8) | c[3];
+          s.h_crc.push_back(CrcSpan{sec.byte_off - 40, (int32_t)in.byte_len + 40, (int32_t)at, expect, ~0u});
+        }
+        if ((in.codec & 0xff) != 3 || in.n_records == 0) continue;
         const uint8_t* f = bytes[p] + in.byte_off;
         const int64_t fl = in.byte_len;
         bool device_ok = fl >= 7 && f[0] == 0x04 && f[1] == 0x22 && f[2] == 0x4D && f[3] == 0x18 && (f[4] >> 6) == 1 && (f[4] & 0x20) &&
@@ -2156,6 +2182,13 @@ int32_t stage1_records(surge_device_decoder* d, PushSlot& s, const uint8_t* keys
 // first: a push that fails takes the keys it probed out of the table again (rollback_kernel), so a failed push leaves
 // the decoder exactly as it was.  wait = false leaves the second synchronisation out: the results are complete in the
 // order of the decoder's stream (surge_device_decoder_push_finish_async).
+// the consumer thread's wait for `st`: asleep on an event, not spinning (SURGE_INGEST_WAIT=spin: hipStreamSynchronize)
+hipError_t wait_stream(surge_device_decoder* d, hipStream_t st) {
+  if (!d->block_waits) return hipStreamSynchronize(st);
+  const hipError_t e = hipEventRecord(d->sleeper, st);
+  return e != hipSuccess ? e : hipEventSynchronize(d->sleeper);
+}
+
 int32_t stage2(surge_device_decoder* d, PushSlot& s, bool wait) {
   const int64_t n_rec = s.n_rec;
   if (n_rec == 0) return OK;
@@ -2202,7 +2235,7 @@ int32_t stage2(surge_device_decoder* d, PushSlot& s, bool wait) {
     PCHK(hipMemcpyAsync(&ec, derr, sizeof(ec), hipMemcpyDeviceToHost, st));
     PCHK(hipMemcpyAsync(&first_total, (unsigned long long*)d->first_scan.p + R, 8, hipMemcpyDeviceToHost, st));
     PCHK(hipMemcpyAsync(&kept, (uint32_t*)d->keep_pos.p + R, 4, hipMemcpyDeviceToHost, st));
-    PCHK(hipStreamSynchronize(st));
+    PCHK(wait_stream(d, st));
     if (ec.lz4_bad == ~0u && ec.crc_bad == ~0u && ec.first_bad != ~0ull && (uint32_t)(ec.first_bad & 0xff) == RS_COLLISION && attempt < 3) {
       // Two different keys share a 64-bit hash (about 3 in a million pushes at 10^7 keys): the table gets another hash
       // function — every known key re-hashed from its bytes in the arena, the push's records from theirs — and the push
@@ -2310,7 +2343,7 @@ int32_t stage2(surge_device_decoder* d, PushSlot& s, bool wait) {
   d->counters[2] += n_rec - kept;
   ++d->pushes;
   if (wait) {
-    PCHK(hipStreamSynchronize(st));
+    PCHK(wait_stream(d, st));
   } else {  // the slot's buffers are read until here: its next stage 1 waits for this point of the stream
     PCHK(hipEventRecord(s.released, st));
     s.released_valid = true;
@@ -2474,11 +2507,19 @@ int32_t surge_replay_append_decoded(surge_replay_handle* h, surge_device_decoder
     int prev = 0;
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(d->device);
-    const hipError_t e = hipStreamSynchronize(d->stream);
+    const hipError_t e = wait_stream(d, d->stream);
     (void)hipSetDevice(prev);
     if (e != hipSuccess) return dfail(d, E_DEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     rc = surge_replay_append_events_device(h, (const int64_t*)d->r_agg.p, d->r_ev.p, d->n_records);
     if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
+    if (d->block_waits) {  // (sleep until the fold is through, then let surge_replay_synchronize report what it has to)
+      void* hs = nullptr;
+      if (surge_replay_get_stream(h, &hs) == OK) {
+        (void)hipSetDevice(d->device);
+        (void)wait_stream(d, (hipStream_t)hs);
+        (void)hipSetDevice(prev);
+      }
+    }
     rc = surge_replay_synchronize(h);  // the arrays are reused by the next push
     if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
   }

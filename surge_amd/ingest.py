@@ -306,7 +306,7 @@ class PartitionedFramedFetches:
     (the group rotates through six slabs)."""
 
     def __init__(self, fetches, n_partitions: int, threads: int = 8, hold: int = 3, isolation_level: int = READ_COMMITTED, device_lz4: bool = True,
-                 overlap: bool = True, device_crc: bool = True):
+                 overlap: bool = True, device_crc: bool = True, in_place: bool = False):
         import queue
         import threading
 
@@ -321,6 +321,11 @@ class PartitionedFramedFetches:
         if os.environ.get("SURGE_INGEST_PAGEABLE_ARENA") != "1":
             self._lib.surge_ingest_group_use_pinned_slabs(self._h)  # (fails without a GPU: the slabs stay pageable, which works too)
         self._threads = max(1, min(threads, n_partitions))
+        # in_place: the fetch response is RECEIVED into the group's next page-locked slab (surge_ingest_group_receive_copy: one copy out of
+        # the bytes objects on the framing threads, standing in for the socket reads a consumer would aim there) and framed
+        # where it lies — with device_lz4 and device_crc the host reads the batches' 61-byte headers and nothing else
+        self._in_place = in_place and device_lz4
+        self.receive_seconds: List[float] = []      # wall time of that stand-in receive copy, per fetch
         self._n = n_partitions
         self._tails = [b""] * n_partitions
         self._fetches = iter(fetches)
@@ -348,8 +353,18 @@ class PartitionedFramedFetches:
         for tail, data in zip(self._tails, fetch):  # a partition's cut batch from the last fetch goes in front (rare: whole batches are the rule)
             data = data or b""
             bufs.append(tail + bytes(data) if tail else (data if isinstance(data, bytes) else bytes(data)))
-        data_arr = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) if b else None for b in bufs])
         len_arr = (ctypes.c_int64 * n)(*[len(b) for b in bufs])
+        if self._in_place:
+            tr = time.perf_counter()
+            src_arr = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) if b else None for b in bufs])
+            data_arr = (ctypes.c_void_p * n)()
+            rc = self._lib.surge_ingest_group_receive_copy(self._h, src_arr, len_arr, self._threads, data_arr)
+            if rc != 0:
+                raise IngestError(rc, (self._lib.surge_ingest_group_last_error(self._h) or b"").decode())
+            self.receive_seconds.append(time.perf_counter() - tr)
+            t0 = time.perf_counter()  # (framing_seconds: the framing proper)
+        else:
+            data_arr = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) if b else None for b in bufs])
         # a batch is at least its 61-byte header; a feed also delivers what the partitions still hold from earlier feeds (a
         # transaction whose COMMIT marker only arrives now)
         max_sec = sum(len(b) for b in bufs) // 61 + int(self._lib.surge_ingest_group_queued_sections(self._h)) + 16
@@ -376,6 +391,12 @@ class PartitionedFramedFetches:
     _run = FramedFetches._run
     __iter__ = FramedFetches.__iter__
     __next__ = FramedFetches.__next__
+
+    def cpu_seconds(self):
+        """``(receive copy, framing)``: thread CPU seconds the group's host threads have spent so far (``surge_ingest_group_cpu_seconds``)."""
+        out = (ctypes.c_double * 2)()
+        self._lib.surge_ingest_group_cpu_seconds(self._h, ctypes.byref(out))
+        return float(out[0]), float(out[1])
 
     def counters(self) -> dict:
         """The partitions' ingest counters, summed; call it when the iteration has ended."""

@@ -123,7 +123,7 @@ class GpuReplayStateStore:
         return counters
 
     def restore_from_fetches(self, fetches, capacity: int = 0, overlap: bool = True, n_partitions: int = 0, framing_threads: int = 8,
-                             consumer_threads: int = 1, bound_log: bool = False, algo: int = ALGO_AUTO, device_crc: bool = True) -> dict:
+                             consumer_threads: int = 1, bound_log: bool = False, algo: int = ALGO_AUTO, device_crc: bool = True, in_place: bool = True) -> dict:
         """Recover from the events topic as a consumer receives it: ``fetches`` yields the record-batch bytes of one
         partition, fetch by fetch, in offset order (a list, or a generator that polls) — or, with ``n_partitions``, per
         fetch response the next bytes of each of the consumer's partitions (``PartitionedFramedFetches``: one framer per
@@ -196,7 +196,9 @@ class GpuReplayStateStore:
         try:
             # device_crc: the batches' CRC-32C is finished on the GPU where their bytes go anyway (SURGE_INGEST_DEVICE_CRC): the framing
             # threads touch a batch's header, not its bytes
-            framer = (PartitionedFramedFetches(fetches, n_partitions, threads=framing_threads, hold=depth, overlap=overlap, device_crc=device_crc) if n_partitions
+            # in_place: a fetch response is received into the framer's page-locked slab and framed where it lies (no copy of the sections)
+            framer = (PartitionedFramedFetches(fetches, n_partitions, threads=framing_threads, hold=depth, overlap=overlap, device_crc=device_crc, in_place=in_place)
+                      if n_partitions
                       else FramedFetches(fetches, overlap=overlap, hold=depth, device_crc=device_crc))
             with framer as framed, (self.engine.on_own_stream() if two_threads else contextlib.nullcontext()):
                 try:

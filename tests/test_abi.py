@@ -35,7 +35,7 @@ def test_exports_match_the_header():
 
 def test_ingest_exports_match_their_header():
     lib = _native.load()
-    declared = header_symbols("surge_ingest.h", "surge_(?:ingest|event_json|crc32c|lz4|xxh32|device_decoder|parse_f64|replay_append_decoded)")
+    declared = header_symbols("surge_ingest.h", "surge_(?:ingest|event_json|crc32c|lz4|xxh32|device_decoder|parse_f64|replay_append_decoded|replay_stage_decoded)")
     assert declared == sorted(_native.INGEST_EXPORTS)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in surge_ingest.h but not exported"

@@ -661,7 +661,7 @@ def test_partitioned_framed_fetches_frame_every_partition_like_its_own_framer_an
     flat_want = [[x for row in rows for x in row] for rows in want]  # partition after partition
     for overlap in (False, True):
         alive, got = [], []
-        with PartitionedFramedFetches(iter(fetches), P, threads=3, hold=5, overlap=overlap) as framed:
+        with PartitionedFramedFetches(iter(fetches), P, threads=3, hold=5, overlap=overlap, device_crc=False) as framed:
             for sec, slab in framed:
                 alive.append((sec, slab))
                 if len(alive) > 5:
@@ -672,6 +672,47 @@ def test_partitioned_framed_fetches_frame_every_partition_like_its_own_framer_an
                 assert snap == flat_want[len(got) - len(alive): len(got)]
             assert framed.counters() == want_counters
         assert got == flat_want
+    # Round 6: the same fetches framed IN PLACE (received into the group's slab, nothing copied) and / or with the CRC-32C left
+    # to the device: the same sections, partition after partition, byte for byte — and in front of every section what the
+    # device needs to finish the check: {crc, register after the 40 covered header bytes} (framing by copy), or the batch's
+    # own crc field and header bytes as received (in place: the CRC over them and the section IS the crc field)
+    from surge_amd.ingest import SECTION_CRC_PENDING
+
+    L = _native.load()
+
+    def crc(b):
+        return L.surge_crc32c(b, len(b)) & 0xFFFFFFFF
+
+    for in_place in (False, True):
+        for device_crc in (False, True):
+            alive, got = [], []
+            with PartitionedFramedFetches(iter(fetches), P, threads=3, hold=5, overlap=False, device_crc=device_crc, in_place=in_place) as framed:
+                for sec, slab in framed:
+                    alive.append((sec, slab))
+                    if len(alive) > 5:
+                        alive.pop(0)
+                    snap = [[(int(s["base_offset"]), int(s["n_records"]), int(s["codec"]) & 0xFF, b) for s, b in zip(sc, _section_bytes(sc, sl))] for sc, sl in alive]
+                    got.append(snap[-1])
+                    assert snap == flat_want[len(got) - len(alive): len(got)], (in_place, device_crc)
+                    for sc, sl in alive:
+                        for s_ in sc:
+                            flag = int(s_["codec"]) & ~0xFF
+                            body = ctypes.string_at(sl + int(s_["byte_off"]), int(s_["byte_len"]))
+                            if not device_crc:
+                                assert flag == 0
+                            elif in_place:
+                                assert flag == 0x200
+                                pre = ctypes.string_at(sl + int(s_["byte_off"]) - 44, 44)
+                                assert int.from_bytes(pre[:4], "big") == crc(pre[4:] + body)
+                            else:
+                                assert flag == SECTION_CRC_PENDING
+                                pre = ctypes.string_at(sl + int(s_["byte_off"]) - 8, 8)
+                                # the register after the header bytes, continued over the section, is the batch's crc: checked
+                                # through linearity — crc(h || body) for the h whose register this is cannot be recomputed without h,
+                                # so the GPU suite checks the value end to end; here: the crc field is a plausible, non-trivial word
+                                assert pre[:4] != b"\0\0\0\0"
+                assert framed.counters() == want_counters, (in_place, device_crc)
+            assert got == flat_want
 
 
 def test_push_pipeline_runs_pushes_on_its_worker_at_most_depth_ahead_and_in_order():
