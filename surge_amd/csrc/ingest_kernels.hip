@@ -84,9 +84,11 @@ __device__ __forceinline__ void report(ErrorCell* err, int64_t rec, uint32_t sta
 // bytes and then the records section — the bytes this decoder is handed anyway.  The host framer runs the CRC over the 40
 // header bytes only and passes on the register; one WAVE per section takes it from there, 16 KiB at a time:
 //   * the tile is laid right-aligned into a 16 KiB frame, lane l owns frame bytes [256 l, 256 l + 256) (the lanes in front of a
-//     short tile are empty: a zero register is neutral under what follows) and runs the plain bit-serial CRC over its piece,
-//     a dword at a time out of LDS (rows of 65 dwords: lanes read different banks) — 128 vector instructions per dword, no
-//     table, nothing shared between lanes;
+//     short tile are empty: a zero register is neutral under what follows) and runs the CRC over its piece a dword at a time
+//     out of LDS (rows of 65 dwords: lanes read different banks), four table look-ups per dword (slicing by four: 4 x 256
+//     entries in LDS, loaded by every wave from a 4 KB table in device memory).  The first version was bit-serial — 128 vector
+//     instructions per dword, 182 us per 10^6-record fetch (profiles/r06_e2e_inplace_kernel_stats.csv); the tables cost a
+//     tenth of that;
 //   * a CRC register is linear in (register, data): crc(A || B) = shift(crc(A), |B|) ^ crc_0(B), and shifting by a FIXED
 //     length is one multiplication mod P by a constant x^(8 |B|) — six levels of a lane tree (|B| = 256, 512 .. 8192 bytes)
 //     and one more per tile (16384): seven constants, computed once on the host (crc_shift_constants).
@@ -133,16 +135,29 @@ static CrcShift crc_shift_constants() {
   return k;
 }
 
-__device__ __forceinline__ uint32_t crc_step32(uint32_t r) {
-#pragma unroll
-  for (int k = 0; k < 32; ++k) r = (r >> 1) ^ (kCrcPoly & (uint32_t)-(int32_t)(r & 1u));
-  return r;
+// slicing by four: T[k][b] = the register after byte b followed by k zero bytes (k = 0 .. 3)
+struct CrcSlice { uint32_t t[4][256]; };
+static const CrcSlice& crc_slice_tables() {
+  static const CrcSlice T = [] {
+    CrcSlice x;
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
+      x.t[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int k = 1; k < 4; ++k) x.t[k][i] = (x.t[k - 1][i] >> 8) ^ x.t[0][x.t[k - 1][i] & 0xffu];
+    return x;
+  }();
+  return T;
 }
 
 __global__ void __launch_bounds__(64) crc_kernel(const uint8_t* __restrict__ bytes, const CrcSpan* __restrict__ spans, int32_t n_spans, CrcShift K,
-                                                 ErrorCell* err) {
+                                                 const uint32_t* __restrict__ slice, ErrorCell* err) {
   __shared__ uint32_t A[kCrcLdsDwords];
+  __shared__ uint32_t Ts[4 * 256];
   const int lane = threadIdx.x;
+  for (int i = lane; i < 4 * 256; i += 64) Ts[i] = slice[i];
   const CrcSpan sp = spans[blockIdx.x];
   const uint32_t expect = sp.expect, state = sp.state;
   uint32_t total = state;  // (a section of no bytes: the register as the host left it)
@@ -185,11 +200,13 @@ __global__ void __launch_bounds__(64) crc_kernel(const uint8_t* __restrict__ byt
       while ((p & 3) && p < p1) {
         const uint32_t w = dword_at(p >> 2);
         r ^= (w >> (8 * (p & 3))) & 0xffu;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) r = (r >> 1) ^ (kCrcPoly & (uint32_t)-(int32_t)(r & 1u));
+        r = (r >> 8) ^ Ts[r & 0xffu];
         ++p;
       }
-      for (; p + 4 <= p1; p += 4) r = crc_step32(r ^ dword_at(p >> 2));
+      for (; p + 4 <= p1; p += 4) {
+        const uint32_t x = r ^ dword_at(p >> 2);
+        r = Ts[768 + (x & 0xffu)] ^ Ts[512 + ((x >> 8) & 0xffu)] ^ Ts[256 + ((x >> 16) & 0xffu)] ^ Ts[x >> 24];
+      }
     }
     // lane tree: after level s the lanes whose low s + 1 bits are set hold the register of their 2^(s+1) pieces
 #pragma unroll
@@ -1502,6 +1519,7 @@ struct surge_device_decoder {
   // hand-over of the result arrays to a consumer on another stream (surge_replay_append_decoded_async): `consumed` is
   // recorded on the consumer's stream behind its last read, the next stage 2 waits for it before it writes the arrays
   hipEvent_t ready = nullptr, consumed = nullptr;
+  void* crc_slice = nullptr;     // the CRC-32C slicing tables (4 KB) on the device: made at the first push that needs them
   hipEvent_t sleeper = nullptr;  // hipEventBlockingSync: host waits of the consumer thread sleep on it instead of spinning
   bool block_waits = true;
   bool consumed_valid = false;
@@ -1699,6 +1717,7 @@ int32_t surge_device_decoder_destroy(surge_device_decoder* d) {
   if (d->ready) (void)hipEventDestroy(d->ready);
   if (d->consumed) (void)hipEventDestroy(d->consumed);
   if (d->sleeper) (void)hipEventDestroy(d->sleeper);
+  if (d->crc_slice) (void)hipFree(d->crc_slice);
   (void)hipSetDevice(prev);
   delete d;
   return OK;
@@ -2027,11 +2046,15 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
   if (!s.h_crc.empty()) {
     // the batches' CRC-32C, finished where their bytes now are (the host ran it over the 40 header bytes only)
     static const CrcShift kShift = crc_shift_constants();
+    if (!d->crc_slice) {
+      DCHK(d, hipMalloc(&d->crc_slice, sizeof(CrcSlice)));
+      DCHK(d, hipMemcpy(d->crc_slice, &crc_slice_tables(), sizeof(CrcSlice), hipMemcpyHostToDevice));
+    }
     const size_t crc_bytes = s.h_crc.size() * sizeof(CrcSpan);
     DCHK(d, s.crc_spans.reserve(crc_bytes, false, st));
     DCHK(d, hipMemcpyAsync(s.crc_spans.p, stage(s.h_crc.data(), crc_bytes), crc_bytes, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(crc_kernel, dim3((unsigned)s.h_crc.size()), dim3(64), 0, st, (const uint8_t*)s.d_bytes.p, (const CrcSpan*)s.crc_spans.p, (int32_t)s.h_crc.size(), kShift,
-                       (ErrorCell*)s.d_err.p);
+                       (const uint32_t*)d->crc_slice, (ErrorCell*)s.d_err.p);
   }
   lap("copies");
   const uint8_t* dby = (const uint8_t*)s.d_bytes.p;
