@@ -52,18 +52,18 @@ ZIPF_SEED = 3
 C2_AGGREGATES, C2_EVENTS, C2_SEED = 1_000_000, 256, 2
 
 
-ALGO_NAMES = {"auto": 0, "fixed": 1, "flat": 2, "rows": 3, "sorted": 4, "chunked": 5, "tiled": 7}
+ALGO_NAMES = {"auto": 0, "fixed": 1, "flat": 2, "rows": 3, "sorted": 4, "chunked": 5, "tiled": 7, "short": 8}
 
 
 def kernel_name(S, algo):
     return {S.ALGO_FIXED: "fold_kernel<FIXED,16>", S.ALGO_FLAT: "fold_kernel<FLAT,16>", S.ALGO_ROWS: "fold_rows_kernel<8>",
             S.ALGO_SORTED: "fold_sorted_kernel<16>" if os.environ.get("SURGE_REPLAY_SORTED_KERNEL") == "plain" else "fold_sorted_pf_kernel<16>", S.ALGO_CHUNKED: "fold_chunked_kernel<16> + chunk_stitch_kernel",
-            S.ALGO_TILED: "fold_tiled_kernel<2> + chunk_stitch_kernel"}.get(algo, str(algo))
+            S.ALGO_TILED: "fold_tiled_kernel<2> + chunk_stitch_kernel", S.ALGO_SHORT: "fold_short_kernel"}.get(algo, str(algo))
 
 
 def algo_name(S, algo):
     return {S.ALGO_FIXED: "fixed", S.ALGO_FLAT: "flat", S.ALGO_ROWS: "rows", S.ALGO_SORTED: "sorted", S.ALGO_CHUNKED: "chunked",
-            S.ALGO_TILED: "tiled"}.get(algo, str(algo))
+            S.ALGO_TILED: "tiled", S.ALGO_SHORT: "short"}.get(algo, str(algo))
 
 
 def parse_algo(text):

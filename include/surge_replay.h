@@ -239,6 +239,13 @@ typedef struct surge_replay_schema_v2 {
                               bound log is folded more than once or is bound ahead of need: never chosen by
                               SURGE_ALGO_AUTO, ask for it (surge_replay_prepare does the copy without folding).  Any
                               CSR; v2 handles fold the same copy with whole aggregates as rows (nothing cut). */
+#define SURGE_ALGO_SHORT 8 /* K1s: short rows — one lane per aggregate straight from the CSR arrays, no LDS transport, no index:
+                              a wave's 64 consecutive rows are one contiguous stretch of the log, every lane loads its own
+                              few events (16 B each, four ahead) and walks a concrete state.  For logs of MANY SHORT
+                              aggregates — what a packed events topic looks like when most aggregates published a handful
+                              of events — where FLAT spends its time on segment heads (one state store per head) and the
+                              lane-per-row kernels' 16-event tiles are mostly padding.  SURGE_ALGO_AUTO picks it when the
+                              longest aggregate has at most 64 events and the mean is below 16.  Any CSR.               */
 
 typedef struct surge_replay_stats_t {
   int64_t n_aggregates;

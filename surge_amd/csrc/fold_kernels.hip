@@ -182,6 +182,53 @@ __global__ void __launch_bounds__(kWave) fold_sorted_kernel(const FoldParams p) 
   dispenser_leave(p.counter, lane);
 }
 
+// ---- K1s "short rows": any CSR of many short aggregates, one lane per aggregate, no LDS transport, no index ---------------
+// Rows r .. r + 63 of a wave are consecutive in the log, so what the wave reads is one contiguous stretch of it (every cache
+// line it touches is used whole, by neighbouring lanes); every lane loads its own events — four 16-byte loads in flight — and
+// walks a concrete state like the rows kernels do.  A wave takes as many steps as its longest row needs: the kernel is for logs
+// whose rows are all short (engine.hip: longest <= 64 events, mean < 16), where the tile kernels' 16-event lanes would walk
+// mostly padding and the flat kernel pays a presence pass, a scan and a state store per segment HEAD.  Empty rows are rows
+// like any other (their state is the prior one, or None): no compaction, no fill pass.
+__global__ void __launch_bounds__(256) fold_short_kernel(const FoldParams p) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_tab[kTableLdsDwords];
+  {
+    const uint32_t* src = &p.table[0][0];
+    for (int i = threadIdx.x; i < kTableEntries * kTableWords; i += 256)
+      lds_tab[(i / kTableWords == kTableEntries - 1 ? kNullEntryOff : (i / kTableWords) * kTableStride) + (i % kTableWords)] = src[i];
+  }
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool mine = r < p.n_seg;
+  const int64_t s0 = mine ? p.seg_off[r] : 0, s1 = mine ? p.seg_off[r + 1] : 0;
+  Acc a = (mine && p.init) ? load_state(p.init, r) : acc_none();
+  uint32_t frozenM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 1, 1), presentM = (uint32_t)__builtin_amdgcn_sbfe((int32_t)a.fl, 0, 1), corr = 0u;
+  begin_concrete(a);
+  const int64_t last = p.n_events > 0 ? p.n_events - 1 : 0;
+  for (int64_t j = s0; __builtin_amdgcn_ballot_w64(j < s1) != 0ull; j += 4) {  // (wave-uniform trip count: the longest row of the wave)
+    uint4 ev[4];
+    uint32_t tyc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t at = j + k < s1 ? j + k : (j + k <= last ? j + k : last);  // (a load past my row still hits the log: its event is replaced by the null event)
+      typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+      const v4u w = __builtin_nontemporal_load((const v4u*)&p.events[at]);
+      ev[k] = make_uint4(w.x, w.y, w.z, w.w);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tyc[k] = j + k < s1 ? type_off(ev[k].x) : kNullEntryOffBytes;
+    // (rows of one or two events are the rule here: a step that no lane of the wave has an event for is not walked)
+    if (__builtin_amdgcn_ballot_w64(j + 2 < s1) != 0ull) {
+      walk_events_concrete<4>(a, presentM, frozenM, corr, ev, tyc, lds_tab, p);
+    } else if (__builtin_amdgcn_ballot_w64(j + 1 < s1) != 0ull) {
+      walk_events_concrete<2>(a, presentM, frozenM, corr, ev, tyc, lds_tab, p);
+    } else {
+      walk_events_concrete<1>(a, presentM, frozenM, corr, ev, tyc, lds_tab, p);
+    }
+  }
+  finish_concrete(a, presentM, frozenM, corr, p);
+  if (mine) store_state(p.out, r, a);
+}
+
 // ---- plan: task k owns segments [lower_bound(off, off[0] + k*T), lower_bound(off, off[0] + (k+1)*T)) ----
 __global__ void plan_kernel(const int64_t* __restrict__ off, int64_t n_seg, int64_t task_events,
                             int64_t n_tasks, int64_t* __restrict__ plan) {
@@ -344,6 +391,12 @@ hipError_t launch_fold_rows(const FoldParams& p, const V1Kernels* spec, int64_t 
     if (conc) hipLaunchKernelGGL((fold_rows_kernel<16, true>), dim3((unsigned)n_tasks), dim3(kWave), 0, stream, p);
     else hipLaunchKernelGGL((fold_rows_kernel<16, false>), dim3((unsigned)n_tasks), dim3(kWave), 0, stream, p);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_fold_short(const FoldParams& p, hipStream_t stream) {
+  if (p.n_seg <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fold_short_kernel, dim3((unsigned)((p.n_seg + 255) / 256)), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 

@@ -41,6 +41,7 @@ hipError_t launch_fold_flat(const FoldParams& p, const V1Kernels* spec, int64_t 
 // lanes: the V1_LANES kernels compiled for the handle's op table, or nullptr = the ahead-of-time kernels (op table in LDS)
 hipError_t launch_fold_rows(const FoldParams& p, const V1Kernels* lanes, int64_t n_tasks, int lane_events, hipStream_t stream);
 hipError_t launch_fold_sorted(const FoldParams& p, int64_t n_waves, int lane_events, hipStream_t stream);
+hipError_t launch_fold_short(const FoldParams& p, hipStream_t stream);  // K1s: one lane per aggregate of a log of many short rows (p.seg_off over ALL aggregates, empty ones included)
 // the same fold, pipelined across groups (fold_chunked.hip: the chunked kernel's walk over whole aggregates); 8 or 16 events per lane
 hipError_t launch_fold_sorted_pf(const FoldParams& p, const V1Kernels* lanes, int64_t n_waves, int lane_events, hipStream_t stream);
 // ---- index_kernels.hip: the per-log indexes (length order, chunk table), built with rocPRIM sorts / scans -----------

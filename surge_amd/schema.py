@@ -59,6 +59,7 @@ ALGO_ROWS = 3
 ALGO_SORTED = 4
 ALGO_CHUNKED = 5
 ALGO_TILED = 7
+ALGO_SHORT = 8
 
 INT32_MAX = 2**31 - 1
 INT32_MIN = -(2**31)

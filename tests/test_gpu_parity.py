@@ -336,7 +336,7 @@ def test_random_log_shapes_through_every_kernel(seed):
         if rng.random() < 0.5:
             prior = oracle.fold_csr(*synth.csr_log(rng.integers(0, 4, size=n), int(rng.integers(1, 1 << 30)), synth.STRESS_MIX))
         exp = oracle.fold_csr(so, ev, prior)
-        algos = [S.ALGO_AUTO, S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED, S.ALGO_TILED] + ([S.ALGO_FIXED, S.ALGO_ROWS] if kind == 4 else [])
+        algos = [S.ALGO_AUTO, S.ALGO_FLAT, S.ALGO_SORTED, S.ALGO_CHUNKED, S.ALGO_TILED, S.ALGO_SHORT] + ([S.ALGO_FIXED, S.ALGO_ROWS] if kind == 4 else [])
         for algo in algos:
             got, _ = gpu_fold(so, ev, prior, algo=algo)
             assert got.tobytes() == exp.tobytes(), (seed, kind, n, algo)
@@ -1104,3 +1104,31 @@ def test_the_counting_sort_of_the_index_orders_rows_exactly_like_the_radix_sort(
     ref = nz[np.argsort(-lens[nz], kind="stable")]
     got = orders[("counting", "4096")][0]
     assert np.array_equal(nz[got] if lens.min() == 0 else got, ref), shape
+
+
+@pytest.mark.gpu
+def test_short_rows_kernel_on_logs_of_many_short_aggregates_and_auto_picks_it():
+    """SURGE_ALGO_SHORT (round 6): one lane per aggregate straight from the CSR arrays — the shape of a packed events topic whose
+    aggregates published a handful of events each (the e2e topic: 10 M aggregates, 1.4 events each).  Rows of 0 .. 64 events
+    with empties in runs and at both ends, a prior snapshot, throwing / deleting events; AUTO picks it for such a log (and not
+    for a uniform one or one with a long aggregate); states = the oracle's, byte for byte."""
+    rng = np.random.default_rng(9)
+    n = 150_000
+    lens = np.where(rng.random(n) < 0.3, 0, rng.integers(1, 9, size=n))
+    lens[:300] = 0
+    lens[-77:] = 0
+    lens[1000] = 64
+    so, ev = synth.csr_log(lens.astype(np.int64), 13, synth.STRESS_MIX)
+    prior = oracle.fold_csr(*synth.csr_log(rng.integers(0, 3, size=n), 14, synth.STRESS_MIX))
+    for init in (None, prior):
+        exp = oracle.fold_csr(so, ev, init)
+        got, st = gpu_fold(so, ev, init, algo=S.ALGO_SHORT)
+        assert got.tobytes() == exp.tobytes() and st.last_algo == S.ALGO_SHORT
+        got, st = gpu_fold(so, ev, init, algo=S.ALGO_AUTO)
+        assert got.tobytes() == exp.tobytes() and st.last_algo == S.ALGO_SHORT
+    lens[5] = 65  # one aggregate longer than the kernel is meant for: AUTO goes back to the flat fold
+    so, ev = synth.csr_log(lens.astype(np.int64), 13, synth.STRESS_MIX)
+    got, st = gpu_fold(so, ev, None, algo=S.ALGO_AUTO)
+    assert st.last_algo == S.ALGO_FLAT and got.tobytes() == oracle.fold_csr(so, ev).tobytes()
+    got, st = gpu_fold(so, ev, None, algo=S.ALGO_SHORT)  # asked for, it still folds any CSR
+    assert got.tobytes() == oracle.fold_csr(so, ev).tobytes()
