@@ -1996,9 +1996,16 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
   };
   if (!d->slots_sized) {
     d->slots_sized = true;
-    for (PushSlot& t : d->slots)
-      if (&t != &s && !t.busy) (void)size_slot(t);  // (best effort: a slot that could not be sized now reports it when its turn comes)
-    (void)hipGetLastError();
+    // (only while nothing else is in flight — the decoder's first push as a rule: no other slot is then being read by a push or by
+    // the thread that finishes pushes; a slot whose last push was finished without a wait is left alone too)
+    bool idle;
+    {
+      std::lock_guard<std::mutex> lk(d->mu);
+      idle = d->n_pending == 0;
+    }
+    if (idle)
+      for (PushSlot& t : d->slots)
+        if (&t != &s && !t.busy && !t.released_valid && size_slot(t) != OK) (void)hipGetLastError();  // (best effort: a slot that could not be sized now reports it when its turn comes)
   }
   {
     int32_t rc = size_slot(s);
@@ -2023,9 +2030,16 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
     const bool first_staging = s.pinned_cap == 0;
     const int32_t rc = slot_pinned(d, s, need_stage);
     if (rc != OK) return rc;
-    if (first_staging)  // (page-locking memory takes milliseconds: every slot's staging while the pipeline is still empty)
-      for (PushSlot& t : d->slots)
-        if (&t != &s && !t.busy && t.pinned_cap == 0) (void)slot_pinned(d, t, need_stage);
+    if (first_staging) {  // (page-locking memory takes milliseconds: every slot's staging while the pipeline is still empty)
+      bool idle;
+      {
+        std::lock_guard<std::mutex> lk(d->mu);
+        idle = d->n_pending == 0;
+      }
+      if (idle)
+        for (PushSlot& t : d->slots)
+          if (&t != &s && !t.busy && !t.released_valid && t.pinned_cap == 0) (void)slot_pinned(d, t, need_stage);
+    }
   }
   size_t staged = 0;
   auto stage = [&](const void* src, size_t len) -> const uint8_t* {

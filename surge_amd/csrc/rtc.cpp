@@ -6,6 +6,7 @@
 // hiprtc -> a gfx950 code object -> hipModuleLoadData (fold_slots.hip).  libhiprtc is dlopen'ed on first use — hosts
 // without it keep the interpreter (surge_replay_kernel_info says which one a handle runs).
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -127,6 +128,16 @@ uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
   return h;
 }
 
+// The directory must be this user's own: a directory (not a link to one), owned by getuid(), writable by nobody else.
+// Anything else — a directory someone else created first, a symbolic link, a group-writable path — and there is NO cache:
+// a forged <key>.co would be loaded as GPU code without hiprtc ever running.  No fallback under /tmp either: a
+// process without HOME / XDG_CACHE_HOME / SURGE_REPLAY_CACHE_DIR compiles every time.
+bool own_private_dir(const std::string& d) {
+  struct stat st;
+  if (lstat(d.c_str(), &st) != 0) return false;
+  return S_ISDIR(st.st_mode) && st.st_uid == getuid() && (st.st_mode & 022) == 0;
+}
+
 std::string cache_dir() {
   if (const char* v = std::getenv("SURGE_REPLAY_CACHE"))
     if (std::atoi(v) == 0) return "";
@@ -137,12 +148,9 @@ std::string cache_dir() {
     const std::string c = std::string(hme) + "/.cache";
     (void)mkdir(c.c_str(), 0700);
     d = c + "/surge_amd";
-  } else d = "/tmp/surge_amd-" + std::to_string((long)getuid());
-  if (mkdir(d.c_str(), 0700) != 0) {
-    struct stat st;
-    if (stat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return "";
-  }
-  return d;
+  } else return "";
+  (void)mkdir(d.c_str(), 0700);
+  return own_private_dir(d) ? d : "";
 }
 
 std::string cache_key(const std::string& source, const char* const* headers, int n_headers, const char* const* opts, int n_opts) {
@@ -155,18 +163,44 @@ std::string cache_key(const std::string& source, const char* const* headers, int
   mix(source.data(), source.size());
   for (int i = 0; i < n_headers; ++i) mix(headers[i], std::strlen(headers[i]));
   for (int i = 0; i < n_opts; ++i) mix(opts[i], std::strlen(opts[i]));
-  // the compiler: the HIP runtime's version (hiprtc ships with it) — a ROCm upgrade compiles afresh
+  // the compiler: the HIP runtime's version (hiprtc ships with it) and, when it is loaded, hiprtc's own version and path — a
+  // ROCm upgrade compiles afresh.  (Looked up in the libraries this process has loaded, whatever scope they were loaded with.)
   int ver = 0;
-  if (void* f = dlsym(RTLD_DEFAULT, "hipRuntimeGetVersion")) (void)((int (*)(int*))f)(&ver);
+  void* f = dlsym(RTLD_DEFAULT, "hipRuntimeGetVersion");
+  if (!f)
+    for (const char* n : {"libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"})
+      if (void* lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) {
+        f = dlsym(lib, "hipRuntimeGetVersion");
+        if (f) break;
+      }
+  if (f) (void)((int (*)(int*))f)(&ver);
   mix(&ver, sizeof ver);
+  if (g_rtc.lib) {
+    int major = 0, minor = 0;
+    if (void* v = dlsym(g_rtc.lib, "hiprtcVersion")) (void)((int (*)(int*, int*))v)(&major, &minor);
+    mix(&major, sizeof major);
+    mix(&minor, sizeof minor);
+    mix(g_rtc.path.data(), g_rtc.path.size());
+  }
+  if (ver == 0) return std::string();  // the compiler cannot be told apart from another one: nothing is cached
   char hex[40];
   std::snprintf(hex, sizeof hex, "%016llx%016llx", (unsigned long long)a, (unsigned long long)b);
   return hex;
 }
 
 bool cache_load(const std::string& path, std::vector<char>* code) {
-  FILE* f = std::fopen(path.c_str(), "rb");
-  if (!f) return false;
+  const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+  if (fd < 0) return false;
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 022) != 0) {
+    close(fd);
+    return false;
+  }
+  FILE* f = fdopen(fd, "rb");
+  if (!f) {
+    close(fd);
+    return false;
+  }
   char head[24];
   bool ok = std::fread(head, 1, 24, f) == 24 && std::memcmp(head, "SRGCO1\0\0", 8) == 0;
   uint64_t len = 0, sum = 0;
@@ -186,8 +220,14 @@ bool cache_load(const std::string& path, std::vector<char>* code) {
 
 void cache_store(const std::string& path, const std::vector<char>& code) {
   const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-  FILE* f = std::fopen(tmp.c_str(), "wb");
-  if (!f) return;
+  (void)unlink(tmp.c_str());
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+  if (fd < 0) return;
+  FILE* f = fdopen(fd, "wb");
+  if (!f) {
+    close(fd);
+    return;
+  }
   const uint64_t len = code.size(), sum = fnv1a(code.data(), code.size(), 1469598103934665603ull);
   bool ok = std::fwrite("SRGCO1\0\0", 1, 8, f) == 8 && std::fwrite(&len, 8, 1, f) == 1 && std::fwrite(&sum, 8, 1, f) == 1 && std::fwrite(code.data(), 1, code.size(), f) == code.size();
   ok = std::fclose(f) == 0 && ok;
@@ -209,8 +249,9 @@ bool rtc_compile(const std::string& source, const char* arch, std::vector<char>*
   // -ffp-contract=off: an f64 ADD must round exactly like the JVM's (no fused multiply-add anywhere near it)
   const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
   const std::string dir = cache_dir();
+  (void)load_rtc_locked();  // (before the key: the compiler's identity is part of it; a host without libhiprtc still hits entries made without it)
   const std::string key = cache_key(source, headers, n_headers, opts, 4);
-  const std::string cached = dir.empty() ? "" : dir + "/" + key + ".co";
+  const std::string cached = (dir.empty() || key.empty()) ? "" : dir + "/" + key + ".co";
   if (const char* dump = std::getenv("SURGE_REPLAY_RTC_DUMP")) {  // the program text, for reading its ISA offline (hipcc -S -I surge_amd/csrc)
     if (FILE* f = std::fopen((std::string(dump) + "/" + key + ".hip").c_str(), "w")) {
       std::fwrite(source.data(), 1, source.size(), f);

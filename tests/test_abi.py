@@ -128,6 +128,28 @@ def test_compiled_code_objects_are_kept_on_disk_and_a_damaged_file_is_compiled_a
     monkeypatch.setenv("SURGE_REPLAY_CACHE", "0")
     files[0].unlink()
     assert compile_once()[0] == first and not list(tmp_path.glob("*.co"))
+    monkeypatch.delenv("SURGE_REPLAY_CACHE")
+    # the cache only lives in a directory that is this user's own and nobody else's to write — a directory others can
+    # write to, or a symbolic link to one, is not used at all (a planted <key>.co would be loaded as GPU code unseen by hiprtc);
+    # neither is a cached FILE that is a link or writable by others
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    shared.chmod(0o777)
+    monkeypatch.setenv("SURGE_REPLAY_CACHE_DIR", str(shared))
+    assert compile_once()[0] == first and not list(shared.glob("*.co"))
+    link = tmp_path / "link"
+    private = tmp_path / "private"
+    private.mkdir(mode=0o700)
+    link.symlink_to(private)
+    monkeypatch.setenv("SURGE_REPLAY_CACHE_DIR", str(link))
+    assert compile_once()[0] == first and not list(private.glob("*.co"))
+    monkeypatch.setenv("SURGE_REPLAY_CACHE_DIR", str(private))
+    assert compile_once()[0] == first
+    (stored,) = list(private.glob("*.co"))
+    assert stored.stat().st_mode & 0o077 == 0
+    planted = bytearray(stored.read_bytes())
+    stored.chmod(0o666)  # somebody else could have written it: not trusted, compiled again (and replaced by a private file)
+    assert compile_once()[0] == first and list(private.glob("*.co"))[0].stat().st_mode & 0o022 == 0
 
 
 def test_default_schema_matches_python_mirror():
