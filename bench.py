@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--framing-threads", type=int, default=3, help="e2e: host threads receiving and framing a fetch's partitions side by side (3: in-place framing with the CRC on the device leaves the host the "
                     "batch headers; rounds 4 / 5 framed by copy with the CRC on the host and needed 12 of the boxes' 16-CPU quota — --framing-by-copy --framing-threads 12; "
                     "capped at this rank's share of the CPUs the process may use)")
+    ap.add_argument("--host-only", action="store_true", help="e2e: the HOST side alone — every rank receives and frames its fetch responses (its share of the framing threads, "
+                    "page-locked slabs) and hands nothing to the device: the rate the host sustains, its CPU time and its page-locked bytes per rank.  With --gpus 8 on a one-GPU box "
+                    "(SURGE_BENCH_REHEARSAL=1): what bounds an 8-rank node on the host side, which no one-GPU run of the whole path can show")
     ap.add_argument("--bound-log", action="store_true", help="e2e: a recovery that folds ONCE — every fetch's decoded events are staged on the device (surge_replay_stage_decoded), the topic's "
                     "end packs them into one CSR log (surge_replay_pack_staged) and ONE fold of what AUTO picks for that log produces the states; the packed log is then re-folded a few times "
                     "(refold_events_per_s).  Default: every fetch is folded onto the resident state as it arrives (K3)")
@@ -561,7 +564,7 @@ def main():
             base = {**vars(args), "workload": "e2e", "warmup": 2, "batch_events": 1_000_000, "aggregates": None, "events_cap": 8, "writer": "independent",
                     "codec": "lz4", "serial_framing": False, "two_thread_consumer": False, "no_capacity_hint": False, "framing_threads": 3, "framing_by_copy": False,
                     "abort_every": 50, "hold_markers": 4, "bound_log": False}
-            e2e = run_e2e(_ap.Namespace(**{**base, "steps": 28, "txn_flush_events": 512}))
+            e2e = run_e2e(_ap.Namespace(**{**base, "steps": 60, "txn_flush_events": 512}))
             result["e2e"] = {k: e2e[k] for k in keep}
             layouts = {"flush_512": {"value": e2e["value"], "control_batches": e2e["config"]["control_batches"], "parity": e2e["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_source_events"]}}
             for name, kf in (("flush_64", 64), ("full_16KiB_no_transactions", 0)):
@@ -573,9 +576,17 @@ def main():
             # ... and the same topic the way a recovery that folds ONCE runs it: fetches staged on the device, one pack, one fold of the kernel AUTO picks
             # for the packed log (1.2e7 records: the lane-per-row kernels need a log of that size), re-folds of the packed log beside it
             torch.cuda.empty_cache()
-            o = run_e2e(_ap.Namespace(**{**base, "steps": 10, "txn_flush_events": 512, "bound_log": True}))
-            result["e2e"]["bound_log"] = {"value_bytes_to_staged_events_per_s": o["value"], **(o["config"]["bound_log"] or {}),
+            # — on a topic whose aggregates are LONG (250 000 aggregates of the same Zipf(1..4096) counts, every event of each: 1.1e8 records, 114 fetches), so that
+            # what AUTO picks for the packed log is a lane-per-row kernel (CHUNKED), the family of the headline number
+            o = run_e2e(_ap.Namespace(**{**base, "steps": 400, "txn_flush_events": 512, "bound_log": True, "aggregates": 250_000, "events_cap": 4096}))
+            result["e2e"]["bound_log"] = {"topic": "250 000 aggregates, Zipf(1..4096) events each, all published", "fetches_timed": o["steps"],
+                                          "value_bytes_to_staged_events_per_s": o["value"], **(o["config"]["bound_log"] or {}),
                                           "parity": o["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_source_events"]}
+            # the same default topic framed the way rounds 4 / 5 framed it (sections copied into the slab, CRC-32C on 12 host threads): what in-place framing + the device CRC replace
+            torch.cuda.empty_cache()
+            o = run_e2e(_ap.Namespace(**{**base, "steps": 10, "txn_flush_events": 512, "framing_by_copy": True, "framing_threads": 12}))
+            result["e2e"]["framing_by_copy_12_threads"] = {"value": o["value"], **{k: o["config"][k] for k in ("host_cpu_ms_per_1e6_records", "framing_cpu_ms_per_1e6_records", "framing_threads")},
+                                                           "parity": o["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_source_events"]}
         except Exception as exc:  # pragma: no cover
             result["e2e"] = {"skipped": repr(exc)}
     if dist is not None:
@@ -1098,6 +1109,8 @@ def run_e2e(args):
     if K < 1:
         raise SystemExit(f"--workload e2e: the topic holds {len(fetches)} fetch(es): nothing to time behind {W} warm-up fetch(es)")
 
+    if getattr(args, "host_only", False):
+        return run_e2e_host_only(args, torch, np, fetches, W, world, rank, dist, ctl, wire_bytes, n_pub, gen_s, topic_counts, PartitionedFramedFetches, P)
     # ---- the run --------------------------------------------------------------------------------------------------------
     marks, dev_ms, keys_at, push_ms = [], [], [], []
     if dist is not None:
@@ -1368,6 +1381,55 @@ def run_e2e(args):
                          "sample": f"{sample_records} records of the same fetches through the library's host decoder (surge_ingest_feed + surge_ingest_drain_json), decode only — no fold",
                          "oracle_fold_events_per_s": int(off[-1]) / oracle_s if oracle_s > 0 else None,
                          "gpu_states_match_cpu_fold_of_the_source_events": None if args.parity == "none" else bool(parity_all)},
+    }
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def run_e2e_host_only(args, torch, np, fetches, W, world, rank, dist, ctl, wire_bytes, n_pub, gen_s, topic_counts, PartitionedFramedFetches, P):
+    """The host side of bytes -> states alone (--host-only): receive + frame every fetch response, device stage stubbed out."""
+    eff = effective_cpus()
+    threads = max(1, min(args.framing_threads, int(eff[0]) // world - (3 if world == 1 else 1)))
+    by_copy = bool(getattr(args, "framing_by_copy", False))
+    if dist is not None:
+        dist.barrier()
+    n_sections = 0
+    with PartitionedFramedFetches((f for f, _ in fetches), P, threads=threads, hold=4, overlap=False, device_crc=not by_copy, in_place=not by_copy) as framed:
+        t0 = c0 = g0 = None
+        for i, (sec, slab) in enumerate(framed):
+            n_sections += int(sec.shape[0])
+            if i == W - 1 or (W == 0 and i == 0):
+                t0, c0, g0 = time.perf_counter(), time.process_time(), framed.cpu_seconds()
+        t1, c1, g1 = time.perf_counter(), time.process_time(), framed.cpu_seconds()
+        slab_bytes, pinned = framed.slab_bytes()
+        counters = framed.counters()
+    n_timed = sum(n for _, n in fetches[W:])
+    mine = torch.tensor([t1 - t0, c1 - c0, g1[0] - g0[0], g1[1] - g0[1], float(n_timed), float(slab_bytes), float(wire_bytes)], dtype=torch.float64, device=ctl)
+    rows = [mine]
+    if dist is not None:
+        rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return None
+    R = np.array([r.cpu().numpy() for r in rows])
+    total_records = float(R[:, 4].sum())
+    out = {
+        "metric": "records/sec framed by the host (device stage stubbed out)", "value": total_records / float(R[:, 0].max()), "unit": "records/s", "n_gpus": world,
+        "steps": len(fetches) - W, "warmup": W, "higher_is_better": True, "data": "synthetic (the e2e topic of this rank's partitions)",
+        "config": {"workload": "E2E host side only: receive + frame (in place, CRC-32C left to the device)" if not by_copy else "E2E host side only: framing by copy, CRC-32C on the host",
+                   "ranks": world, "cpus_usable": eff[0], "cpu_quota": eff[2], "framing_threads_per_rank": threads, "partitions_per_rank": P // world if world > 1 else P,
+                   "per_rank": [{"records": int(r[4]), "wall_s": float(r[0]), "process_cpu_ms_per_1e6_records": float(r[1] * 1e3 / max(1.0, r[4]) * 1e6),
+                                 "receive_copy_cpu_ms_per_1e6_records": float(r[2] * 1e3 / max(1.0, r[4]) * 1e6), "framing_cpu_ms_per_1e6_records": float(r[3] * 1e3 / max(1.0, r[4]) * 1e6),
+                                 "slab_bytes": int(r[5]), "records_per_s": float(r[4] / r[0])} for r in R],
+                   "page_locked_slabs": bool(pinned), "slab_bytes_all_ranks": int(R[:, 5].sum()), "wire_bytes_per_record": float(R[:, 6].sum() / max(1, n_pub * world)) if world == 1 else None,
+                   "sections": n_sections, "ingest": counters, "generate_s": gen_s, "topic": topic_counts,
+                   "note": "every rank frames its own partitions' fetch responses on its share of the CPUs this process group may use; nothing is pushed to a device, so the figure is the "
+                           "host-side ceiling of N ranks on one node — the device side of N > 1 has never been measured (no multi-GPU node was available)"},
     }
     if dist is not None:
         dist.barrier()

@@ -207,6 +207,9 @@ int32_t surge_ingest_group_receive_copy(surge_ingest_group* g, const uint8_t* co
  * out[1] seconds framing (surge_ingest_group_feed's per-partition work: headers, transactions — and the sections' copy and
  * CRC-32C where those still run on the host). */
 int32_t surge_ingest_group_cpu_seconds(const surge_ingest_group* g, double out[2]);
+/* The group's six slabs: bytes allocated so far, and whether they come from an allocator the host set
+ * (surge_ingest_group_use_pinned_slabs: page-locked memory — the footprint a host has to budget per consumer). */
+int32_t surge_ingest_group_slab_bytes(const surge_ingest_group* g, int64_t* bytes_out, int32_t* custom_allocator_out);
 int64_t surge_ingest_group_queued_sections(const surge_ingest_group* g); /* batches the partitions hold from earlier feeds (upper bound of what the next feed delivers beyond its own) */
 int32_t surge_ingest_group_counters(const surge_ingest_group* g, int64_t out[8]); /* surge_ingest_counters, summed */
 int32_t surge_ingest_group_set_allocator(surge_ingest_group* g, void* (*alloc)(size_t), void (*release)(void*));

@@ -111,6 +111,7 @@ INGEST_EXPORTS = (
     "surge_ingest_group_receive_buffer",
     "surge_ingest_group_receive_copy",
     "surge_ingest_group_cpu_seconds",
+    "surge_ingest_group_slab_bytes",
     "surge_ingest_group_queued_sections",
     "surge_ingest_group_counters",
     "surge_ingest_group_set_allocator",
@@ -345,6 +346,7 @@ def load() -> ctypes.CDLL:
         "surge_ingest_group_receive_buffer": ([vp, i64, ctypes.POINTER(vp)], i32),
         "surge_ingest_group_receive_copy": ([vp, vp, vp, i32, vp], i32),
         "surge_ingest_group_cpu_seconds": ([vp, ctypes.POINTER(ctypes.c_double * 2)], i32),
+        "surge_ingest_group_slab_bytes": ([vp, ctypes.POINTER(i64), ctypes.POINTER(i32)], i32),
         "surge_ingest_group_queued_sections": ([vp], i64),
         "surge_ingest_group_counters": ([vp, ctypes.POINTER(i64 * 8)], i32),
         "surge_ingest_group_set_allocator": ([vp, vp, vp], i32),

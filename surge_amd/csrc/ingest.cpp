@@ -1064,6 +1064,19 @@ static int64_t thread_cpu_ns() {
   return (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
 }
 
+int32_t surge_ingest_group_slab_bytes(const surge_ingest_group* grp, int64_t* bytes_out, int32_t* custom_allocator_out) {
+  if (!grp || !bytes_out) return E_INVALID;
+  int64_t total = 0;
+  bool custom = false;
+  for (const Arena& a : grp->slabs) {
+    total += (int64_t)a.cap;
+    custom = custom || a.alloc != nullptr;
+  }
+  *bytes_out = total;
+  if (custom_allocator_out) *custom_allocator_out = custom ? 1 : 0;
+  return OK;
+}
+
 int32_t surge_ingest_group_cpu_seconds(const surge_ingest_group* grp, double out[2]) {
   if (!grp || !out) return E_INVALID;
   out[0] = (double)grp->cpu_ns[0].load() * 1e-9;

@@ -392,6 +392,12 @@ class PartitionedFramedFetches:
     __iter__ = FramedFetches.__iter__
     __next__ = FramedFetches.__next__
 
+    def slab_bytes(self):
+        """``(bytes, page_locked)``: what the group's six slabs take (``surge_ingest_group_slab_bytes``)."""
+        b, c = ctypes.c_int64(), ctypes.c_int32()
+        self._lib.surge_ingest_group_slab_bytes(self._h, ctypes.byref(b), ctypes.byref(c))
+        return int(b.value), bool(c.value)
+
     def cpu_seconds(self):
         """``(receive copy, framing)``: thread CPU seconds the group's host threads have spent so far (``surge_ingest_group_cpu_seconds``)."""
         out = (ctypes.c_double * 2)()
