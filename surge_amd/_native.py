@@ -24,7 +24,9 @@ def _read_sources() -> tuple:
 
 
 SOURCES = _read_sources()
-HEADERS = (os.path.join(CSRC, "replay_internal.h"), os.path.join(CSRC, "fold_layout.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "fold_chunk_device.h"), os.path.join(CSRC, "fold_flat_device.h"), os.path.join(CSRC, "fold_slots_device.h"), os.path.join(CSRC, "f64_text.h"), os.path.join(CSRC, "f64_parse.h"), os.path.join(INCLUDE, "surge_replay.h"), os.path.join(INCLUDE, "surge_ingest.h"), os.path.join(INCLUDE, "surge_snapshot.h"))
+# every header a translation unit may include or rtc.cpp embeds (.incbin): a change to any of them rebuilds every object
+HEADERS = tuple(sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))) + tuple(
+    os.path.join(INCLUDE, f) for f in ("surge_replay.h", "surge_ingest.h", "surge_snapshot.h"))
 
 #: every symbol ``include/surge_replay.h`` declares (checked by tests/test_abi.py)
 EXPORTS = (

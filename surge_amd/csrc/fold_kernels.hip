@@ -541,11 +541,14 @@ void v1_kernels_acquire(const uint32_t (*table)[kTableWords], int device, int ki
   }
   if (kind == V1_LANES) {
     // Opt-in (SURGE_REPLAY_RTC_LANES=1).  Measured in round 6 on the 10 M-aggregate log, one box, A/B/A
-    // (profiles/r06_lane_spec_ab_*.jsonl): with 8-event lanes the compiled kernels tie the ahead-of-time ones to 0.1 % —
-    // for the built-in schema (54 -> 53 VALU per event) AND for the Counter fixture's own schema (20 VALU per event): the
-    // walk's instruction count is not what bounds SORTED / CHUNKED; with 16-event lanes they are 13 - 29 % slower at equal
-    // HBM traffic (the waves wait 2.7 x longer for their tiles; not understood).  ROWS gains 0.6 - 2 %.  So the default stays
-    // the ahead-of-time kernels; the compiled ones are kept, fuzzed against the oracle, for schemas and shapes where they pay.
+    // (profiles/r06_lane_spec_*.jsonl): SORTED takes 12.2 ms whatever its walk costs — compiled for the built-in schema (53 VALU
+    // per event), for the Counter fixture's own schema (20), or with the arithmetic REMOVED (an experiment build that only moves
+    // the events): 12.19 / 12.22 / 12.20 ms, at 8- and 16-event lanes, from six resident waves per CU up.  The kernel runs at
+    // the pace of its transport — 64 row pieces per load instruction, gathered from anywhere in the log — not of its
+    // instruction stream; compiling the walk buys nothing there (CHUNKED on one GPU's C4 shard: -1 %; ROWS on C2: +1.5 %).
+    // So the default stays the ahead-of-time kernels; the compiled ones are kept, fuzzed against the oracle, for hosts whose
+    // schemas or shapes differ.  (Their first version was 13 - 29 % SLOWER: hiprtc's compiler puts an s_waitcnt vmcnt(0) in front
+    // of every LDS read that follows an LDS-DMA load, which serialised the sixteen loads of a tile — fold_lane_device.h, issue().)
     const char* v = std::getenv("SURGE_REPLAY_RTC_LANES");
     if (!v || std::atoi(v) == 0) {
       *why = "off (SURGE_REPLAY_RTC_LANES=1 compiles them)";

@@ -24,7 +24,12 @@ __device__ __forceinline__ void chunk_walk(const FoldParams& p, const ChunkTable
   char* lds_ev = smem;
   int64_t* lds_rs = (int64_t*)(smem + G::kTileBytes);                  // 64 chunk starts ...
   uint32_t* lds_len = (uint32_t*)(smem + G::kTileBytes + kWave * 8);   // ... and 64 chunk lengths
+#ifdef SURGE_EXP_STATIC_TABLE  // (experiment builds: the op table as an LDS object of its own — the compiler then drops the vmcnt(0) it puts in front of the walk's table reads)
+  __shared__ __attribute__((aligned(16))) uint32_t lds_tab_static[kTableLdsDwords];
+  uint32_t* lds_tab = lds_tab_static;
+#else
   uint32_t* lds_tab = (uint32_t*)(smem + G::kTileBytes + G::kAuxSorted);
+#endif
   const int lane = threadIdx.x;
   load_table<LE>(p, lds_tab, lane);
   const uint32_t ev_row = G::ev_row(lane);
@@ -88,10 +93,22 @@ __device__ __forceinline__ void chunk_walk(const FoldParams& p, const ChunkTable
   auto issue = [&](int c, uint32_t minlen) {
     if ((uint32_t)(c + 1) * LE <= minlen) {
       const uint64_t coff = (uint64_t)(uint32_t)c * (uint32_t)(LE * 16);
+      // Every row start out of the LDS table FIRST, then the loads back to back.  Interleaved (read a start, issue its load, read
+      // the next start ...) is what this was until round 6 — and what hiprtc's compiler, unlike hipcc's, answers with an
+      // s_waitcnt vmcnt(0) in front of every one of those LDS reads (an LDS-DMA load in flight "may alias" them): each load of
+      // the tile then waits for the one before it, a 16 KiB tile takes 16 memory latencies (4.4 us on an idle chip against 1.4:
+      // profiles/r06_lane_spec_ab_c3_per_wave.jsonl) and the kernels compiled at run time lost 25 % to the ones compiled ahead.
+      constexpr int kBurst = G::kLoads <= 16 ? G::kLoads : 16;
 #pragma unroll
-      for (int q = 0; q < G::kLoads; ++q) {
-        const uint64_t a = ebase[q % G::kClasses] + coff + ((uint64_t)lds_rs[G::kRowsPerLoad * q + lane / LE] << 4);
-        __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(lds_ev + q * 1024), 16, 0, kLoadAux);
+      for (int q0 = 0; q0 < G::kLoads; q0 += kBurst) {
+        uint64_t addr[kBurst];
+#pragma unroll
+        for (int q = 0; q < kBurst; ++q) addr[q] = ebase[(q0 + q) % G::kClasses] + coff + ((uint64_t)lds_rs[G::kRowsPerLoad * (q0 + q) + lane / LE] << 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < kBurst; ++q) __builtin_amdgcn_global_load_lds((gptr_t)addr[q], (lptr_t)(lds_ev + (q0 + q) * 1024), 16, 0, kLoadAux);
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {  // some chunk ends inside this tile: never read past a chunk's own events
       int lane_o = lane;
