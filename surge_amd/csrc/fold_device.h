@@ -529,7 +529,11 @@ __device__ __forceinline__ void walk_events_concrete(Acc& a, uint32_t& presentM,
       const uint4* te = table_entry(lds_tab, tyc[j + 1]);
       nq0 = te[0]; nq1 = te[1]; nq2 = te[2]; nq3 = *(const uint2*)(te + 3);
     }
+#ifdef SURGE_EXP_SKIP_APPLY_AOT  // (experiment builds: the transport and the table reads without the arithmetic)
+    a.count ^= (int32_t)(tq0.x ^ tq1.x ^ tq2.x ^ tq3.x ^ ev[j].y ^ ev[j].z ^ ev[j].w);
+#else
     apply_event_concrete(a, presentM, frozenM, corr, tq0, tq1, tq2, tq3, ev[j].y, ev[j].z, ev[j].w, p);
+#endif
     tq0 = nq0; tq1 = nq1; tq2 = nq2; tq3 = nq3;
     __builtin_amdgcn_sched_barrier(0);
   }
