@@ -88,7 +88,9 @@ def csrc_sha16(kernel=""):
     the rows kernel's counter profile stale."""
     files = ["fold_layout.h", "fold_device.h"]
     if "sorted_pf" in kernel or "chunked" in kernel:
-        files += ["fold_chunk_device.h", "fold_chunked.hip"]
+        files += ["fold_chunk_device.h", "fold_lane_device.h", "fold_chunked.hip"]
+    elif "rows" in kernel:
+        files += ["fold_chunk_device.h", "fold_lane_device.h", "fold_kernels.hip"]
     elif "tiled" in kernel and "slots" not in kernel:
         files += ["fold_chunk_device.h", "fold_tiled.hip"]
     elif "slots" in kernel:

@@ -366,6 +366,26 @@ JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_appendDecoded(JNIEnv* 
   return rc;
 }
 
+/* A recovery that folds ONCE (surge_replay.h, "the device packer"): stageDecoded per poll instead of appendDecoded — the decoded
+ * events are kept on the device in topic order —, then packStaged(nAgg = the decoder's key count) and ONE fold.
+ * out (nullable, 16 bytes): {events staged by this call, keys known} */
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_stageDecoded(JNIEnv* env, jclass c, jlong h, jlong d, jobject out) {
+  int bad = 0;
+  int64_t* o = (int64_t*)buf(env, out, 16, 1, &bad, "out: direct buffer of 16 bytes expected");
+  int64_t n_events = 0, n_keys = 0;
+  int32_t rc;
+  (void)c;
+  if (bad) return SURGE_E_INVALID;
+  rc = check_dec(env, surge_replay_stage_decoded(H(h), D(d), &n_events, &n_keys));
+  if (o) { o[0] = n_events; o[1] = n_keys; }
+  return rc;
+}
+
+JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_packStaged(JNIEnv* env, jclass c, jlong h, jlong nAgg) {
+  (void)c;
+  return check(env, surge_replay_pack_staged(H(h), (int64_t)nAgg));
+}
+
 /* The key table: utf8Out / keyOffOut nullable (size query); counts (16 bytes) receives {keys, utf8 bytes} */
 JNIEXPORT jint JNICALL Java_surge_replay_gpu_NativeReplay_decoderKeys(JNIEnv* env, jclass c, jlong d, jobject utf8Out, jobject keyOffOut,
                                                                         jobject counts) {

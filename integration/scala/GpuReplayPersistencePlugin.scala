@@ -187,7 +187,10 @@ object GpuReplayRecovery {
  *  `eventTemplate`: include/surge_ingest.h surge_event_json_template) and the group-by + fold all run on the GPU; the JVM
  *  crosses JNI twice per poll.  Replaces the HashMap / ArrayList loop of `recover` above for topics of any size. */
 object GpuReplayBulkRecovery {
-  final class Session(model: ReplayableModel[_, _], device: Int, eventTemplate: ByteBuffer) extends AutoCloseable {
+  /** foldOnce = true: a recovery that folds the topic ONCE — every poll's decoded events are staged on the device
+   *  (stageDecoded) instead of folded, finish() packs them into one bound CSR log (packStaged) and runs a single fold of the
+   *  kernel the library picks for that log (the lane-per-row kernels for a log large enough); the log stays bound. */
+  final class Session(model: ReplayableModel[_, _], device: Int, eventTemplate: ByteBuffer, foldOnce: Boolean = false) extends AutoCloseable {
     NativeReplay.ensureLoaded()
     private val handle = NativeReplay.create(model.schema, device)
     private val decoder = NativeReplay.decoderCreate(eventTemplate, device)
@@ -215,7 +218,7 @@ object GpuReplayBulkRecovery {
         keyOff.putLong(keys.position().toLong); valOff.putLong(values.position().toLong); offsets.putLong(o)
       }
       NativeReplay.decoderPushRecords(decoder, keys, keyOff, values, valOff, offsets, n.toLong)
-      NativeReplay.appendDecoded(handle, decoder, null)
+      if (foldOnce) NativeReplay.stageDecoded(handle, decoder, null) else NativeReplay.appendDecoded(handle, decoder, null)
     }
 
     /** End of the topic: publish the host mirror that serves the 32 concurrent readers and hand over the store. */
@@ -223,6 +226,10 @@ object GpuReplayBulkRecovery {
       val counts = ByteBuffer.allocateDirect(16).order(ByteOrder.LITTLE_ENDIAN)
       NativeReplay.decoderKeys(decoder, null, null, counts)
       val nKeys = counts.getLong(0)
+      if (foldOnce) { // everything staged -> one bound log -> one fold
+        NativeReplay.packStaged(handle, nKeys)
+        NativeReplay.fold(handle, 0)
+      }
       val utf8 = ByteBuffer.allocateDirect(math.max(1L, counts.getLong(8)).toInt)
       val keyOff = ByteBuffer.allocateDirect(((nKeys + 1) * 8).toInt).order(ByteOrder.LITTLE_ENDIAN)
       NativeReplay.decoderKeys(decoder, utf8, keyOff, counts)

@@ -50,6 +50,10 @@ object NativeReplay {
                                  offsets: ByteBuffer, n: Long): Int
   /** grow + device group-by + fold of everything pushed since the last call; out (nullable, 16 bytes): events folded, keys known. */
   @native def appendDecoded(handle: Long, decoder: Long, out: ByteBuffer): Int
+  /** A recovery that folds once: keep this poll's decoded events on the device (topic order) instead of folding them ... */
+  @native def stageDecoded(handle: Long, decoder: Long, out: ByteBuffer): Int
+  /** ... and, at the topic's end, pack everything staged into one bound CSR log over nAgg aggregates: one fold(handle, algo) follows. */
+  @native def packStaged(handle: Long, nAgg: Long): Int
   /** counts (16 bytes): keys, UTF-8 bytes; utf8Out / keyOffOut nullable for a size query. */
   @native def decoderKeys(decoder: Long, utf8Out: ByteBuffer, keyOffOut: ByteBuffer, counts: ByteBuffer): Int
 }

@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 
 def short_name(k):
-    for n in ("fold_rows_kernel", "fold_sorted_pf_kernel", "fold_sorted_kernel", "fold_chunked_kernel", "fold_tiled_kernel", "relayout_kernel", "fold_slots_tiled_kernel", "fold_slots_kernel", "surge_slots_tiled2", "surge_slots_tiled1", "surge_slots_csr16", "surge_slots_csr8",
+    for n in ("fold_rows_kernel", "fold_short_kernel", "fold_sorted_pf_kernel", "fold_sorted_kernel", "fold_chunked_kernel", "fold_tiled_kernel", "relayout_kernel", "fold_slots_tiled_kernel", "fold_slots_kernel", "surge_slots_tiled2", "surge_slots_tiled1", "surge_slots_csr16", "surge_slots_csr8",
               "chunk_stitch_kernel", "stream_probe", "plan_kernel"):
         if n in k:
             return n

@@ -37,6 +37,8 @@ jlong Java_surge_replay_gpu_NativeReplay_decoderCreate(JNIEnv*, jclass, jobject,
 void Java_surge_replay_gpu_NativeReplay_decoderDestroy(JNIEnv*, jclass, jlong);
 jint Java_surge_replay_gpu_NativeReplay_decoderPushRecords(JNIEnv*, jclass, jlong, jobject, jobject, jobject, jobject, jobject, jlong);
 jint Java_surge_replay_gpu_NativeReplay_appendDecoded(JNIEnv*, jclass, jlong, jlong, jobject);
+jint Java_surge_replay_gpu_NativeReplay_stageDecoded(JNIEnv*, jclass, jlong, jlong, jobject);
+jint Java_surge_replay_gpu_NativeReplay_packStaged(JNIEnv*, jclass, jlong, jlong);
 jint Java_surge_replay_gpu_NativeReplay_decoderKeys(JNIEnv*, jclass, jlong, jobject, jobject, jobject);
 
 typedef struct { void* address; jlong capacity; } fake_direct_buffer;
@@ -284,6 +286,21 @@ int main(void) {
       check(Java_surge_replay_gpu_NativeReplay_decoderKeys(env, NULL, dec, &b_u, &b_kf, &b_cn) == 0 && counts[0] == 2 && counts[1] == 10 &&
                 memcmp(utf8, "agg-1agg-2", 10) == 0 && koff[1] == 5 && koff[2] == 10,
             "decoderKeys: aggregate ids in first-delivered order");
+      {
+        /* the same poll through the recovery that folds ONCE: stageDecoded (nothing folded yet) -> packStaged -> one fold */
+        jlong h3 = Java_surge_replay_gpu_NativeReplay_create(env, NULL, NULL, 0), dec3 = Java_surge_replay_gpu_NativeReplay_decoderCreate(env, NULL, &b_t, 0);
+        out2[0] = out2[1] = 0;
+        n_thrown = 0;
+        check(h3 != 0 && dec3 != 0 && Java_surge_replay_gpu_NativeReplay_decoderPushRecords(env, NULL, dec3, &b_k, &b_ko, &b_v, &b_vo, &b_of, 4) == 0 &&
+                  Java_surge_replay_gpu_NativeReplay_stageDecoded(env, NULL, h3, dec3, &b_o2) == 0 && out2[0] == 4 && out2[1] == 2 &&
+                  Java_surge_replay_gpu_NativeReplay_packStaged(env, NULL, h3, 2) == 0 && Java_surge_replay_gpu_NativeReplay_fold(env, NULL, h3, 0) == 0 && n_thrown == 0,
+              "stageDecoded / packStaged / fold: the poll staged on the device, packed into one bound log, folded once");
+        check(Java_surge_replay_gpu_NativeReplay_get(env, NULL, h3, 0, &b_st) == 1 && got.count == -3 && got.version == 3 &&
+                  Java_surge_replay_gpu_NativeReplay_get(env, NULL, h3, 1, &b_st) == 1 && got.count == 7 && got.version == 1,
+              "states of the packed log: agg-1 = (1 + 1 - 5, 3), agg-2 = (7, 1)");
+        Java_surge_replay_gpu_NativeReplay_decoderDestroy(env, NULL, dec3);
+        Java_surge_replay_gpu_NativeReplay_destroy(env, NULL, h3);
+      }
       n_thrown = 0;
       val_off[2] = val_off[1] - 3; /* offsets that decrease: refused before the C ABI sees them */
       check(Java_surge_replay_gpu_NativeReplay_decoderPushRecords(env, NULL, dec, &b_k, &b_ko, &b_v, &b_vo, &b_of, 4) == SURGE_E_INVALID && n_thrown == 1,
