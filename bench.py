@@ -82,6 +82,23 @@ def free_port():
         return sk.getsockname()[1]
 
 
+def thread_cpu_seconds():
+    """{tid: (name, CPU seconds)} of every thread of this process — Python threads by their names, native ones (the framing pool
+    names its own; the HIP runtime's are left with the process's) by /proc/<pid>/task/<tid>/comm — read from each thread's CPU-time
+    clock (clock id (~tid << 3) | 6: CPUCLOCK_SCHED, per thread), which has the scheduler's resolution, not a tick's."""
+    import threading
+    names = {t.native_id: t.name for t in threading.enumerate()}
+    out = {}
+    for tid in os.listdir("/proc/self/task"):
+        tid = int(tid)
+        try:
+            comm = open(f"/proc/self/task/{tid}/comm").read().strip()
+            out[tid] = (names.get(tid, comm), time.clock_gettime(((~tid) << 3) | 6))
+        except (OSError, ValueError):
+            pass  # (the thread ended between the listing and the read)
+    return out
+
+
 def csrc_sha16(kernel=""):
     """Identity of the sources ``kernel`` is built from (profiles/traffic_manifest.json records it per entry): the two
     headers every fold shares plus the translation unit(s) of that kernel — a change to the chunked kernel does not make
@@ -201,6 +218,11 @@ def main():
     ap.add_argument("--two-thread-consumer", action="store_true", help="e2e: a worker thread enqueues the pushes, this one finishes them with an event-ordered hand-over to the fold and no host wait (default: one thread does both and waits for the device after each half — the device is the bound, the extra thread measured 7 %% slower)")
     ap.add_argument("--serial-framing", action="store_true", help="e2e: frame each fetch, then push it, then fold it, one after the other (default: framing one fetch ahead on its own threads, four pushes in flight)")
     ap.add_argument("--events-cap", type=int, default=8, help="e2e: every aggregate publishes the first min(count, cap) of its events (8: 6.4e7 records over the 10 M aggregates)")
+    ap.add_argument("--e2e-topic", default="counter", choices=["counter", "mixed"],
+                    help="e2e: counter = the Counter fixture's events on the C3 / C4 population (keys <id>:<seq>, Int arguments); mixed = the surge-docs BankAccount model's events "
+                         "(BankAccountSurgeModel.scala:26-32: UUID record keys without ':', no sequence numbers, Double balances as play-json text), every record with two "
+                         "headers (a W3C traceparent and a content type: SurgeModel.scala:46-52 passes a message's headers and tracing context on), and every 128th account "
+                         "publishing 64..256 events instead of <= --events-cap — 4 M accounts by default")
     ap.add_argument("--writer", default="independent", choices=["independent", "product"],
                     help="e2e: who writes the topic — the independent test-side producer (tests/native/wire_writer.c: shares no code with the library that "
                          "reads it; default) or the product's own RecordBatchWriter (plain 16 KiB batches only)")
@@ -565,7 +587,7 @@ def main():
             keep = ("value", "unit", "steps", "warmup", "ms_per_step", "data", "config", "roofline", "cpu_baseline")
             base = {**vars(args), "workload": "e2e", "warmup": 2, "batch_events": 1_000_000, "aggregates": None, "events_cap": 8, "writer": "independent",
                     "codec": "lz4", "serial_framing": False, "two_thread_consumer": False, "no_capacity_hint": False, "framing_threads": 3, "framing_by_copy": False,
-                    "abort_every": 50, "hold_markers": 4, "bound_log": False}
+                    "abort_every": 50, "hold_markers": 4, "bound_log": False, "e2e_topic": "counter"}
             e2e = run_e2e(_ap.Namespace(**{**base, "steps": 60, "txn_flush_events": 512}))
             result["e2e"] = {k: e2e[k] for k in keep}
             layouts = {"flush_512": {"value": e2e["value"], "control_batches": e2e["config"]["control_batches"], "parity": e2e["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_source_events"]}}
@@ -589,6 +611,18 @@ def main():
             o = run_e2e(_ap.Namespace(**{**base, "steps": 10, "txn_flush_events": 512, "framing_by_copy": True, "framing_threads": 12}))
             result["e2e"]["framing_by_copy_12_threads"] = {"value": o["value"], **{k: o["config"][k] for k in ("host_cpu_ms_per_1e6_records", "framing_cpu_ms_per_1e6_records", "framing_threads")},
                                                            "parity": o["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_source_events"]}
+            # the wider topic (--e2e-topic mixed): BankAccount events — UUID keys without ':', Double balances as text — with two headers per record and a slice of
+            # accounts publishing 64..256 events; 4 M accounts, the whole topic
+            try:
+                torch.cuda.empty_cache()
+                o = run_e2e(_ap.Namespace(**{**base, "steps": 100, "txn_flush_events": 512, "e2e_topic": "mixed"}))
+                result["e2e"]["mixed_topic"] = {"value": o["value"], "workload": o["config"]["workload"], "fetches_timed": o["steps"], "events_timed": o["config"]["events_timed"],
+                                                **{k: o["config"][k] for k in ("record_header_bytes", "max_events_of_one_aggregate", "wire_bytes_per_record", "host_cpu_ms_per_1e6_records",
+                                                                               "host_cpu_ms_per_1e6_records_without_the_receive_copy", "keys_interned")},
+                                                "doubles_parsed_on_host": o["config"]["decoder"]["doubles_parsed_on_host"],
+                                                "parity": o["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_source_events"]}
+            except Exception as exc:  # pragma: no cover
+                result["e2e"]["mixed_topic"] = {"skipped": repr(exc)}
         except Exception as exc:  # pragma: no cover
             result["e2e"] = {"skipped": repr(exc)}
     if dist is not None:
@@ -985,6 +1019,140 @@ def e2e_events(np, synth, agg, j):
     return (synth._h(E2E_SEED, idx, 21) % 3).astype(np.int32), (synth._h(E2E_SEED, idx, 22) % 1000).astype(np.int32)
 
 
+class CounterTopic:
+    """The e2e topic's default model: Counter fixture events (TestBoundedContext.scala:42-49,122-124) on the C3 / C4 population."""
+    name = "counter"
+    key_bytes = 13
+    headers = ()
+
+    def __init__(self, np, synth, S):
+        from fixture_models import CT_DEC, CT_INC, CT_NOOP, CounterBusinessLogic
+
+        self.np, self.synth, self.S = np, synth, S
+        bl = CounterBusinessLogic()
+        self.model, self.fmt = bl.command_model(), bl.event_write_formatting()
+        self.types = np.array([CT_INC, CT_DEC, CT_NOOP], np.int32)
+        self.data = "Counter fixture events as play-json text"
+        self.population = "the C3 / C4 population: {A} aggregates (acct-%08d, Zipf(1..4096) counts, seed {seed}), the first <= {cap} events of each"
+
+    def partitions(self, A, P, eng, dev, torch):
+        from surge_amd.dist import partitions_of_ids
+
+        ids_all = torch.arange(A, dtype=torch.int64, device=dev)
+        return partitions_of_ids(ids_all, P, eng).cpu().numpy().astype(self.np.int32)
+
+    def counts(self, ids, cap):
+        return self.np.minimum(self.synth.zipf_lengths(ids, ZIPF_SEED), cap).astype(self.np.int64)
+
+    def records(self, topic_gen, a, j):
+        ty, arg = e2e_events(self.np, self.synth, a, j)
+        return topic_gen.counter_records(a, ty, arg, j)
+
+    def check_sample(self, a, j, i, key, value):
+        from fixture_models import CountDecremented, CountIncremented, NoOpEvent
+
+        ty, arg = e2e_events(self.np, self.synth, a[i:i + 1], j[i:i + 1])
+        agg = f"acct-{a[i]:08d}"
+        e = [CountIncremented(agg, int(arg[0]), int(j[i])), CountDecremented(agg, int(arg[0]), int(j[i])), NoOpEvent(agg, int(j[i]))][ty[0]]
+        m = self.fmt.write_event(e)
+        assert key == m.key.encode() and value == m.value
+
+    def ids_of_keys(self, kb, koff, n_keys):
+        np = self.np
+        assert np.all(np.diff(koff) == 13), "every key is an acct-%08d id"
+        digits = kb[: 13 * n_keys].reshape(n_keys, 13)[:, 5:].astype(np.int64) - 48
+        return (digits * (10 ** np.arange(7, -1, -1, dtype=np.int64))).sum(axis=1)
+
+    def source_events(self, ev_agg, ev_j):
+        ty, arg = e2e_events(self.np, self.synth, ev_agg, ev_j)
+        src = self.np.zeros(ev_agg.shape[0], dtype=self.S.EVENT_DTYPE)
+        src["type"] = self.types[ty]
+        src["seq"] = ev_j
+        src["raw"] = arg.astype(self.np.uint32).astype(self.np.uint64)
+        return src
+
+
+class MixedTopic:
+    """--e2e-topic mixed: what the Counter topic leaves out — the surge-docs BankAccount model
+    (BankAccountSurgeModel.scala:26-32, BankAccountCommandModel.scala:81-86): record keys are the account's UUID alone (36
+    bytes, no ':' and no sequence number), the balances are Doubles as play-json text (parsed to the bit on the device),
+    every record carries two headers the decoder has to step over, and every 128th account publishes 64..256 events where
+    the others publish <= --events-cap — a fetch of a late round holds the same few thousand accounts dozens of times."""
+    name = "mixed"
+    key_bytes = 36
+    headers = (("traceparent", b"00-0af7651916cd43dd8448eb211c80319c-b7ad6b7169203331-01"), ("content-type", b"application/json"))
+    LONG_EVERY, LONG_MIN, LONG_SPAN = 128, 64, 193
+
+    def __init__(self, np, synth, S):
+        from fixture_models import BA_CREATED, BA_UPDATED, BankAccountCommandModel, BankAccountEventFormat
+
+        self.np, self.synth, self.S = np, synth, S
+        self.model, self.fmt = BankAccountCommandModel(), BankAccountEventFormat()
+        self.types = (BA_CREATED, BA_UPDATED)
+        self.data = "surge-docs BankAccount events (UUID keys, Double balances) as play-json text, two record headers each"
+        self.population = ("{A} accounts (UUID ids), Zipf(1..4096) counts (seed {seed}) cut to <= {cap} events each except every 128th account, which publishes 64..256; "
+                           "every record with a traceparent and a content-type header")
+
+    def cents(self, a, j):
+        return 1 + (self.synth._h(E2E_SEED, a.astype(self.np.int64) * 8192 + j, 22) % 999_999_998).astype(self.np.int64)
+
+    def partitions(self, A, P, eng, dev, torch):
+        import ctypes
+
+        import topic_gen
+        from surge_amd import _native
+
+        np = self.np
+        out = np.zeros(A, np.int32)
+        step = 1 << 20
+        for lo in range(0, A, step):  # partitionForKey of the UUID strings (KafkaPartitioner.scala:8), through the C ABI's host entry point
+            ids = np.arange(lo, min(A, lo + step), dtype=np.int64)
+            k, ko, _, _ = topic_gen.bank_records(ids, np.full(ids.shape[0], 2, np.int32), np.ones(ids.shape[0], np.int64))
+            utf16 = k.astype(np.uint16)
+            part = np.zeros(ids.shape[0], np.int32)
+            rc = _native.load().surge_replay_partition_hash(utf16.ctypes.data_as(ctypes.c_void_p), np.ascontiguousarray(ko).ctypes.data_as(ctypes.c_void_p), ids.shape[0], P,
+                                                            part.ctypes.data_as(ctypes.c_void_p))
+            assert rc == 0
+            out[lo:lo + ids.shape[0]] = part
+        return out
+
+    def counts(self, ids, cap):
+        np = self.np
+        c = np.minimum(self.synth.zipf_lengths(ids, ZIPF_SEED), cap).astype(np.int64)
+        long_rows = self.synth._h(E2E_SEED, ids, 24) % self.LONG_EVERY == 0
+        return np.where(long_rows, self.LONG_MIN + (self.synth._h(E2E_SEED, ids, 25) % self.LONG_SPAN).astype(np.int64), c)
+
+    def records(self, topic_gen, a, j):
+        return topic_gen.bank_records(a, j, self.cents(a, j))
+
+    def check_sample(self, a, j, i, key, value):
+        import uuid
+
+        from fixture_models import BankAccountCreated, BankAccountUpdated
+
+        u = uuid.UUID(key.decode())
+        assert str(u) == key.decode() and int(key[-12:], 16) == int(a[i])
+        amount = int(self.cents(a[i:i + 1], j[i:i + 1])[0]) / 100
+        e = BankAccountCreated(u, f"Owner {int(a[i]) % 1000}", f"{int(a[i]) % 10000:04d}", amount) if j[i] == 1 else BankAccountUpdated(u, amount)
+        m = self.fmt.write_event(e)
+        assert key == m.key.encode() and value == m.value, (value, m.value)
+
+    def ids_of_keys(self, kb, koff, n_keys):
+        np = self.np
+        assert np.all(np.diff(koff) == 36), "every key is a UUID"
+        hexd = kb[: 36 * n_keys].reshape(n_keys, 36)[:, 24:].astype(np.int64)
+        val = np.where(hexd >= 97, hexd - 87, hexd - 48)
+        return (val << (4 * np.arange(11, -1, -1, dtype=np.int64))).sum(axis=1)
+
+    def source_events(self, ev_agg, ev_j):
+        np = self.np
+        src = np.zeros(ev_agg.shape[0], dtype=self.S.EVENT_DTYPE)
+        src["type"] = np.where(ev_j == 1, self.types[0], self.types[1]).astype(np.int32)
+        src["seq"] = 0  # (these events carry no sequence number: BankAccountCommandModel.encode_event)
+        src["raw"] = (self.cents(ev_agg, ev_j) / 100.0).view(np.uint64)
+        return src
+
+
 def run_e2e(args):
     """From the bytes Kafka hands over to recovered states, on the population BASELINE.json's target is quoted on
     (SURVEY §8f N1 in front of R2; the recovery SurgeStateStoreConsumer.scala:57-76 performs record by record).
@@ -1017,37 +1185,36 @@ def run_e2e(args):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import topic_gen
-    from fixture_models import CT_DEC, CT_INC, CT_NOOP, CounterBusinessLogic, CountDecremented, CountIncremented, NoOpEvent
     from oracle import oracle
     from surge_amd import schema as S
     from surge_amd import synth
-    from surge_amd.dist import partitions_of_ids, shard_of_partition
+    from surge_amd.dist import shard_of_partition
     from surge_amd.ingest import DeviceDecoder, EventsTopicIngest, PartitionedFramedFetches, PushPipeline
     from surge_amd.replay import ReplayEngine
     from surge_amd.snapshot import RecordBatchWriter
 
     world, rank, local_rank, dev, ctl, dist, rehearsal = init_ranks(args, torch)
-    A = args.aggregates or N_AGGREGATES
+    mixed = args.e2e_topic == "mixed"
+    A = args.aggregates or (4_000_000 if mixed else N_AGGREGATES)
     cap = args.events_cap
     P = N_PARTITIONS
     n_fetch = args.batch_events if args.batch_events != 100_000 else 1_000_000
     W = min(args.warmup, 2)
     depth = 1 if args.serial_framing else int(os.environ.get("SURGE_BENCH_DEPTH", "4"))
     one_thread = args.serial_framing or not args.two_thread_consumer
-    bl = CounterBusinessLogic()
-    model, fmt = bl.command_model(), bl.event_write_formatting()
+    topic = (MixedTopic if mixed else CounterTopic)(np, synth, S)
+    model = topic.model
     tmpl = model.event_json_template()
     t_gen = time.perf_counter()
 
     eng = ReplayEngine(model.event_algebra(), device=local_rank)
     # ---- this rank's aggregates: its partitions' -------------------------------------------------------------------------
-    ids_all = torch.arange(A, dtype=torch.int64, device=dev)
-    part_all = partitions_of_ids(ids_all, P, eng).to(torch.int64)
+    part_all = topic.partitions(A, P, eng, dev, torch)
     mine = shard_of_partition(part_all, world) == rank
-    my_ids = ids_all[mine].cpu().numpy()
-    my_part = part_all[mine].cpu().numpy().astype(np.int32)
-    del ids_all, part_all, mine
-    counts = np.minimum(synth.zipf_lengths(my_ids, ZIPF_SEED), cap).astype(np.int64)
+    my_ids = np.flatnonzero(mine).astype(np.int64)
+    my_part = part_all[mine].astype(np.int32)
+    del part_all, mine
+    counts = topic.counts(my_ids, cap)
     order = np.argsort(synth._h(E2E_SEED, my_ids, 23), kind="stable")  # the order aggregates take turns in, every round
     my_ids, my_part, counts = my_ids[order], my_part[order], counts[order]
     n_total = int(counts.sum())
@@ -1060,6 +1227,9 @@ def run_e2e(args):
     sample_checked = False
     independent = args.writer == "independent"
     K_flush = args.txn_flush_events if independent else 0
+    if topic.headers and not independent:
+        raise SystemExit("--e2e-topic mixed writes record headers: only the independent writer (tests/native/wire_writer.c) does")
+    header_bytes = topic_gen.set_record_headers(topic.headers) if independent else 0
     with (topic_gen.WireTopic(P, K_flush, 16384, args.codec, args.abort_every if K_flush else 0, args.hold_markers if K_flush else 0) if independent
           else RecordBatchWriter(P, 0, 16384, args.codec)) as writer:
         pend_a, pend_j, pend_p, pend_n = [], [], [], 0
@@ -1071,14 +1241,10 @@ def run_e2e(args):
                 take = min(n_fetch, a.shape[0])
                 pend_a, pend_j, pend_p, pend_n = [a[take:]], [j[take:]], [p[take:]], a.shape[0] - take
                 a, j, p = a[:take], j[:take], p[:take]
-                ty, arg = e2e_events(np, synth, a, j)
-                k, ko, v, vo = topic_gen.counter_records(a, ty, arg, j)
+                k, ko, v, vo = topic.records(topic_gen, a, j)
                 if not sample_checked:  # the generator's text IS what the fixture's event writer writes
                     for i in range(0, take, max(1, take // 200)):
-                        agg = f"acct-{a[i]:08d}"
-                        e = [CountIncremented(agg, int(arg[i]), int(j[i])), CountDecremented(agg, int(arg[i]), int(j[i])), NoOpEvent(agg, int(j[i]))][ty[i]]
-                        m = fmt.write_event(e)
-                        assert bytes(k[ko[i]:ko[i + 1]]) == m.key.encode() and bytes(v[vo[i]:vo[i + 1]]) == m.value
+                        topic.check_sample(a, j, i, bytes(k[ko[i]:ko[i + 1]]), bytes(v[vo[i]:vo[i + 1]]))
                     sample_checked = True
                 # (the topic's last response holds no marker back: what an earlier response held back arrives with it)
                 last = final and pend_n == 0 or n_pub >= n_total and pend_n == 0
@@ -1086,7 +1252,7 @@ def run_e2e(args):
                 wire_bytes += sum(len(x) for x in parts if x)
                 fetches.append((parts, take))
 
-        for j in range(1, cap + 1):
+        for j in range(1, int(counts.max()) + 1 if counts.shape[0] else 1):
             if n_pub >= n_total:
                 break
             sel = np.flatnonzero(counts >= j)
@@ -1106,6 +1272,8 @@ def run_e2e(args):
                 wire_bytes += sum(len(x) for x in parts if x)
                 fetches.append((parts, 0))
         topic_counts = writer.counts if independent else None
+    if header_bytes:
+        topic_gen.set_record_headers(())  # (a process-wide setting of the test writer)
     gen_s = time.perf_counter() - t_gen
     K = len(fetches) - W
     if K < 1:
@@ -1135,7 +1303,7 @@ def run_e2e(args):
         eng.load_csr(np.zeros(hint + 1, np.int64), np.zeros(0, dtype=S.EVENT_DTYPE))
         eng.fold()
         if hint:
-            d.reserve(hint, 13 * hint)
+            d.reserve(hint, topic.key_bytes * hint)
         n_agg = hint
 
         def finish_one(wait):
@@ -1156,7 +1324,7 @@ def run_e2e(args):
                 d.fold_into(eng, wait=wait)
             t2 = time.perf_counter()
             if len(marks) == W - 1:
-                cpu_t0[0] = (time.process_time(), framed.cpu_seconds())  # host CPU seconds (every thread of this process; the framing threads' own) from the end of the warm-up on
+                cpu_t0[0] = (time.process_time(), framed.cpu_seconds(), thread_cpu_seconds())  # host CPU seconds (every thread of this process; the framing threads' own) from the end of the warm-up on
             if os.environ.get("SURGE_BENCH_TRACE"):
                 print(f"[bench] fetch {len(marks)}: finish {(ta - t1) * 1e3:.2f} grow {(tb - ta) * 1e3:.2f} fold {(t2 - tb) * 1e3:.2f} ms, keys {n_keys}", file=sys.stderr)
             marks.append(t2)
@@ -1202,6 +1370,13 @@ def run_e2e(args):
         marks[-1] = time.perf_counter()  # (the last fetch counts as done when the device is)
         cpu_s = time.process_time() - (cpu_t0[0][0] if cpu_t0[0] is not None else 0.0)
         grp_cpu = framed.cpu_seconds()
+        thr1, thr0 = thread_cpu_seconds(), (cpu_t0[0][2] if cpu_t0[0] is not None else {})
+        by_thread = {}
+        for tid, (name, sec) in thr1.items():
+            name = "hip runtime / other native threads" if name in ("python", "python3", "pt_main_thread") else name
+            by_thread[name] = by_thread.get(name, 0.0) + sec - thr0.get(tid, (name, 0.0))[1]
+        if cpu_t0[0] is not None and cpu_s - sum(by_thread.values()) > 0:
+            by_thread["threads that ended before the timed region did (the framing driver)"] = cpu_s - sum(by_thread.values())
         recv_cpu_s, framing_cpu_s = (grp_cpu[0] - cpu_t0[0][1][0], grp_cpu[1] - cpu_t0[0][1][1]) if cpu_t0[0] is not None else grp_cpu
         torch.cuda.synchronize(dev)
         t_begin = marks[W - 1] if W > 0 else t_start
@@ -1239,9 +1414,7 @@ def run_e2e(args):
         host_ms = [x * 1e3 for x in framed.framing_seconds]
         recv_ms = [x * 1e3 for x in framed.receive_seconds]
         ingest_counters = framed.counters()
-    assert np.all(np.diff(koff) == 13), "every key is an acct-%08d id"
-    digits = kb[: 13 * n_keys].reshape(n_keys, 13)[:, 5:].astype(np.int64) - 48
-    key_ids = (digits * (10 ** np.arange(7, -1, -1, dtype=np.int64))).sum(axis=1)
+    key_ids = topic.ids_of_keys(kb, koff, n_keys)
     # ---- parity: the oracle folds the SOURCE events of every aggregate, in the device's key order ------------------------
     t_par = time.perf_counter()
     sorter = np.argsort(my_ids)
@@ -1252,11 +1425,7 @@ def run_e2e(args):
     np.cumsum(cnt_k, out=off[1:])
     ev_agg = np.repeat(key_ids, cnt_k)
     ev_j = (np.arange(off[-1], dtype=np.int64) - np.repeat(off[:-1], cnt_k) + 1).astype(np.int32)
-    ty, arg = e2e_events(np, synth, ev_agg, ev_j)
-    src = np.zeros(off[-1], dtype=S.EVENT_DTYPE)
-    src["type"] = np.array([CT_INC, CT_DEC, CT_NOOP], np.int32)[ty]
-    src["seq"] = ev_j
-    src["raw"] = arg.astype(np.uint32).astype(np.uint64)
+    src = topic.source_events(ev_agg, ev_j)
     t_or = time.perf_counter()
     if args.parity == "none":  # (A/B runs of one kernel against another: the states are not checked, and the line says so)
         exp, oracle_s, parity = None, 0.0, True
@@ -1341,17 +1510,18 @@ def run_e2e(args):
     out = {
         "metric": "events/sec replayed", "value": total_events / elapsed_s, "unit": "events/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed_s / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bytes -> int32 events -> int32/int64 adds", "data": "synthetic (Counter fixture events as play-json text in Kafka record batches v2, written by "
+        "dtype": "bytes -> f64 events -> f64 moves" if mixed else "bytes -> int32 events -> int32/int64 adds", "data": f"synthetic ({topic.data} in Kafka record batches v2, written by "
                                                                    + ("the independent test-side producer tests/native/wire_writer.c — no code shared with the library that reads them)" if independent
                                                                       else "the product's record-batch writer)"),
-        "config": {"workload": f"E2E: events-topic bytes -> states on the C3 / C4 population: {A} aggregates (acct-%08d, Zipf(1..4096) counts, seed {ZIPF_SEED}), the first "
-                               f"<= {cap} events of each, published in rounds (a fetch touches as many different aggregates as it has records), {P} partitions by "
+        "config": {"workload": f"E2E: events-topic bytes -> states on " + topic.population.format(A=A, seed=ZIPF_SEED, cap=cap) + ", "
+                               f"published in rounds (a fetch touches as many different aggregates as it has records), {P} partitions by "
                                f"partitionForKey, {args.codec} batches, " + (f"one transaction per publisher flush of {K_flush} records per partition (data batches closed by the flush or at 16 KiB, "
                                f"then a COMMIT control batch; every {args.abort_every}th flush aborted and retried; on partitions p % {args.hold_markers} == 1 a response's last marker "
                                f"arrives a fetch late)" if K_flush else "not transactional, every batch filled to 16 KiB") + f"; fetches of {n_fetch} records per rank; host framing (headers, CRC-32C, "
                                f"transactions) per partition on {args.framing_threads} threads one fetch ahead; one device push per fetch, {depth} in flight: LZ4 / records / "
                                f"JSON decode / key interning / group-by / fold on the GPU" + (" [REHEARSAL: every rank on cuda:0, throughput meaningless]" if rehearsal else ""),
                    "parallelism": f"partitions p % {world} == rank; no data-path collective; final snapshot all-gathered through the C ABI" if world > 1 else "one GPU",
+                   "topic_model": topic.name, "record_header_bytes": header_bytes, "max_events_of_one_aggregate": int(counts.max()) if counts.shape[0] else 0,
                    "writer": args.writer, "txn_flush_events": K_flush, "topic": topic_counts,
                    "control_batches": None if topic_counts is None else topic_counts["control_batches"],
                    "aggregates": A, "events_cap": cap, "partitions": P, "fetch_records": n_fetch, "fetches": len(fetches), "pushes_in_flight": depth,
@@ -1361,6 +1531,7 @@ def run_e2e(args):
                    "host_cpu_ms_per_1e6_records_without_the_receive_copy": (cpu_s - recv_cpu_s) * 1e3 / max(1, n_events_timed) * 1e6,
                    "framing_cpu_ms_per_1e6_records": framing_cpu_s * 1e3 / max(1, n_events_timed) * 1e6,
                    "receive_copy_cpu_ms_per_1e6_records": recv_cpu_s * 1e3 / max(1, n_events_timed) * 1e6,
+                   "host_cpu_ms_per_1e6_records_by_thread": {k: round(v * 1e3 / max(1, n_events_timed) * 1e6, 3) for k, v in sorted(by_thread.items(), key=lambda kv: -kv[1]) if v > 0},
                    "receive_copy_ms_per_fetch": float(np.mean(recv_ms[W:])) if len(recv_ms) > W else None,
                    "host_cpu_note": "process CPU time (every thread: framing pool, framing driver, consumer — the consumer spins in its waits for the device) over the timed fetches of "
                                     "rank 0.  In-place framing: a fetch response is RECEIVED into the framer's page-locked slab — here one memmove per partition out of the topic's "

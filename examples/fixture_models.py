@@ -451,6 +451,28 @@ class BankAccountFormat(SurgeAggregateFormatting[BankAccount]):
             return None
 
 
+class BankAccountEventFormat:
+    """``BankAccountSurgeModel.eventWriteFormatting`` (``.../docs/command/BankAccountSurgeModel.scala:30-32``):
+    ``SerializedMessage(evt.accountNumber.toString, Json.toJson(evt)(Json.format[BankAccountEvent]))`` — the record key is
+    the account's UUID alone (no ``:<seq>``: these events carry no sequence number), the value the case class's fields in
+    declaration order followed by play-json's sealed-family discriminator ``_type`` (the fully qualified class name), the
+    balances written as play-json writes a ``Double``."""
+
+    def write_event(self, evt) -> SerializedMessage:
+        from surge_amd.encode import play_json_double
+
+        q = lambda v: json.dumps(v, ensure_ascii=False)  # noqa: E731
+        if isinstance(evt, BankAccountCreated):
+            text = (f'{{"accountNumber":{q(str(evt.accountNumber))},"accountOwner":{q(evt.accountOwner)},"securityCode":{q(evt.securityCode)},'
+                    f'"balance":{play_json_double(evt.balance)},"_type":"docs.command.BankAccountCreated"}}')
+        elif isinstance(evt, BankAccountUpdated):
+            text = (f'{{"accountNumber":{q(str(evt.accountNumber))},"newBalance":{play_json_double(evt.newBalance)},'
+                    f'"_type":"docs.command.BankAccountUpdated"}}')
+        else:
+            raise TypeError(f"not a BankAccount event: {evt!r}")
+        return SerializedMessage(str(evt.accountNumber), text.encode("utf-8"))
+
+
 # ======================================================================================================
 # Multilanguage Scala SDK sample (SURVEY R8): the second copy of the fold, behind the gRPC bridge.
 #   CQRSModel.applyEvents = e.foldLeft(s)(eventHandler)

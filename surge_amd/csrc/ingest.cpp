@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -923,6 +924,9 @@ struct FramingPool {
   bool stop = false;
 
   void worker(int idx) {
+    char name[16];
+    snprintf(name, sizeof name, "surge-frame-%d", idx);  // (shows in /proc/<pid>/task/*/comm: bench.py's per-thread CPU table)
+    pthread_setname_np(pthread_self(), name);
     uint64_t seen = 0;
     std::unique_lock<std::mutex> lk(mu);
     for (;;) {

@@ -82,18 +82,21 @@ __device__ __forceinline__ void report(ErrorCell* err, int64_t rec, uint32_t sta
 // ---- CRC-32C of a batch, finished on the device (SURGE_INGEST_DEVICE_CRC) ----------------------------------------------------
 // A record batch's CRC-32C (Castagnoli, reflected; kafka-clients: Crc32C over attributes .. end of the batch) covers 40 header
 // bytes and then the records section — the bytes this decoder is handed anyway.  The host framer runs the CRC over the 40
-// header bytes only and passes on the register; one WAVE per section takes it from there, 16 KiB at a time:
-//   * the tile is laid right-aligned into a 16 KiB frame, lane l owns frame bytes [256 l, 256 l + 256) (the lanes in front of a
+// header bytes only and passes on the register (in-place framing: not even those); one WAVE per section takes it from there,
+// 4 KiB at a time (a compressed batch of the reference's publisher is 2 - 5 KB: one or two tiles):
+//   * the tile is laid right-aligned into a 4 KiB frame, lane l owns frame bytes [64 l, 64 l + 64) (the lanes in front of a
 //     short tile are empty: a zero register is neutral under what follows) and runs the CRC over its piece a dword at a time
-//     out of LDS (rows of 65 dwords: lanes read different banks), four table look-ups per dword (slicing by four: 4 x 256
-//     entries in LDS, loaded by every wave from a 4 KB table in device memory).  The first version was bit-serial — 128 vector
-//     instructions per dword, 182 us per 10^6-record fetch (profiles/r06_e2e_inplace_kernel_stats.csv); the tables cost a
-//     tenth of that;
+//     out of LDS (pieces of 16 dwords, 17 apart: lanes read different banks), four table look-ups per dword (slicing by four:
+//     4 x 256 entries in LDS, loaded once per workgroup of four waves);
 //   * a CRC register is linear in (register, data): crc(A || B) = shift(crc(A), |B|) ^ crc_0(B), and shifting by a FIXED
-//     length is one multiplication mod P by a constant x^(8 |B|) — six levels of a lane tree (|B| = 256, 512 .. 8192 bytes)
-//     and one more per tile (16384): seven constants, computed once on the host (crc_shift_constants).
-// A whole 10^6-record fetch (30 MB of sections) costs the chip ~25 us of vector time.  A mismatch is reported like a bad LZ4
-// frame: the push fails with SURGE_E_CORRUPT, nothing of it is delivered, no key it brought stays interned.
+//     length is one multiplication mod P by a constant x^(8 |B|): lane l multiplies its register by x^(8 * 64 (63 - l)) — ONE
+//     multiplication per lane, all lanes at once — and the tile's register is the XOR over the wave; one more multiplication
+//     (by x^(8 * 4096), wave-uniform) chains a tile to the ones before it.  65 constants, computed once on the host.
+// History: bit-serial CRC, 16 KiB tiles, 182 us per 10^6-record fetch (profiles/r06_e2e_inplace_kernel_stats.csv); slicing by
+// four with 256-byte pieces and a six-level lane tree of multiplications, 122 us alone / 244 us on the wider topic's 66 MB
+// (r06_e2e_*_depth1_kernel_stats.csv): 64 dependent look-up rounds and seven serial 32-step multiplications per tile, most
+// lanes of a 4 KB section idle.  A mismatch is reported like a bad LZ4 frame: the push fails with SURGE_E_CORRUPT, nothing of
+// it is delivered, no key it brought stays interned.
 struct CrcSpan {
   int64_t off;      // first byte the device still has to run the CRC over, in the staged bytes
   int32_t len;
@@ -102,9 +105,9 @@ struct CrcSpan {
   uint32_t state;   // the CRC register in front of `off`: after the 40 header bytes (the host ran those), or ~0 (in-place framing:
                     // off points at the header bytes, the device runs everything)
 };
-struct CrcShift { uint32_t tree[6], tile; };
 constexpr uint32_t kCrcPoly = 0x82F63B78u;
-constexpr int kCrcTile = 16384, kCrcLdsDwords = 65 * 65;
+constexpr int kCrcTile = 4096, kCrcPiece = 64, kCrcWaves = 4;
+constexpr int kCrcLdsDwords = 65 * 17;  // 64 pieces + the dword a misaligned tile spills into, every piece padded by one dword
 
 // a * b mod P, reflected representation (bit 31 = x^0): 32 fixed steps (zlib's multmodp stops early on a's last set bit —
 // and never on a == 0, which an empty lane's register is)
@@ -128,37 +131,42 @@ static uint32_t crc_x8n(uint64_t n) {
   return p;
 }
 
-static CrcShift crc_shift_constants() {
-  CrcShift k;
-  for (int s = 0; s < 6; ++s) k.tree[s] = crc_x8n(256ull << s);
-  k.tile = crc_x8n((uint64_t)kCrcTile);
-  return k;
-}
-
-// slicing by four: T[k][b] = the register after byte b followed by k zero bytes (k = 0 .. 3)
-struct CrcSlice { uint32_t t[4][256]; };
-static const CrcSlice& crc_slice_tables() {
-  static const CrcSlice T = [] {
-    CrcSlice x;
+// What the kernel reads from device memory: the slicing-by-four tables (T[k][b] = the register after byte b followed by k
+// zero bytes), lane l's shift x^(8 * 64 (63 - l)), the tile's shift x^(8 * 4096).
+struct CrcTables {
+  uint32_t slice[4][256];
+  uint32_t lane_shift[64];
+  uint32_t tile_shift, pad[3];
+};
+static const CrcTables& crc_tables() {
+  static const CrcTables T = [] {
+    CrcTables x{};
     for (uint32_t i = 0; i < 256; ++i) {
       uint32_t c = i;
       for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
-      x.t[0][i] = c;
+      x.slice[0][i] = c;
     }
     for (uint32_t i = 0; i < 256; ++i)
-      for (int k = 1; k < 4; ++k) x.t[k][i] = (x.t[k - 1][i] >> 8) ^ x.t[0][x.t[k - 1][i] & 0xffu];
+      for (int k = 1; k < 4; ++k) x.slice[k][i] = (x.slice[k - 1][i] >> 8) ^ x.slice[0][x.slice[k - 1][i] & 0xffu];
+    for (int l = 0; l < 64; ++l) x.lane_shift[l] = crc_x8n((uint64_t)kCrcPiece * (uint64_t)(63 - l));
+    x.tile_shift = crc_x8n((uint64_t)kCrcTile);
     return x;
   }();
   return T;
 }
 
-__global__ void __launch_bounds__(64) crc_kernel(const uint8_t* __restrict__ bytes, const CrcSpan* __restrict__ spans, int32_t n_spans, CrcShift K,
-                                                 const uint32_t* __restrict__ slice, ErrorCell* err) {
-  __shared__ uint32_t A[kCrcLdsDwords];
+__global__ void __launch_bounds__(64 * kCrcWaves) crc_kernel(const uint8_t* __restrict__ bytes, const CrcSpan* __restrict__ spans, int32_t n_spans,
+                                                             const CrcTables* __restrict__ tables, ErrorCell* err) {
+  __shared__ uint32_t frames[kCrcWaves][kCrcLdsDwords];
   __shared__ uint32_t Ts[4 * 256];
-  const int lane = threadIdx.x;
-  for (int i = lane; i < 4 * 256; i += 64) Ts[i] = slice[i];
-  const CrcSpan sp = spans[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4 * 256; i += 64 * kCrcWaves) Ts[i] = (&tables->slice[0][0])[i];
+  __syncthreads();
+  const int32_t span = (int32_t)blockIdx.x * kCrcWaves + wave;
+  if (span >= n_spans) return;  // (behind the workgroup's only barrier)
+  uint32_t* A = frames[wave];
+  const uint32_t lane_k = tables->lane_shift[lane], tile_k = tables->tile_shift;
+  const CrcSpan sp = spans[span];
   const uint32_t expect = sp.expect, state = sp.state;
   uint32_t total = state;  // (a section of no bytes: the register as the host left it)
   int64_t done = 0;
@@ -170,9 +178,12 @@ __global__ void __launch_bounds__(64) crc_kernel(const uint8_t* __restrict__ byt
     const int32_t v0 = kCrcTile - T;
     const int64_t base = sp.off + done - v0;   // (may lie in front of the staged bytes: only p >= v0 is ever read)
     const int32_t sh = (int32_t)(base & 3);
-    const int64_t abase = base - sh;           // the aligned stream A[j] = dword at abase + 4 j, j in [0, 4096]
+    const int64_t abase = base - sh;           // the aligned stream A[j] = dword at abase + 4 j, j in [0, 1024]
     __builtin_amdgcn_wave_barrier();
-    for (int j = lane; j <= kCrcTile / 4; j += 64) {
+#pragma unroll
+    for (int k = 0; k <= kCrcTile / 256; ++k) {
+      const int j = lane + 64 * k;
+      if (j > kCrcTile / 4) continue;  // (the 1025th dword: lane 0 only)
       const int64_t g = abase + 4ll * j;
       uint32_t w = 0u;
       if (g + 4 > base + v0 && g < base + kCrcTile) {  // overlaps the tile
@@ -181,19 +192,19 @@ __global__ void __launch_bounds__(64) crc_kernel(const uint8_t* __restrict__ byt
           for (int b = 0; b < 4; ++b)
             if (g + b >= sp.off && g + b < sp.off + sp.len) w |= (uint32_t)bytes[g + b] << (8 * b);
       }
-      A[(j >> 6) * 65 + (j & 63)] = w;
+      A[(j >> 4) * 17 + (j & 15)] = w;
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
-    // my 256 bytes: frame [256 lane, 256 lane + 256)
-    const int32_t p0 = 256 * lane, p1 = p0 + 256;
+    // my 64 bytes: frame [64 lane, 64 lane + 64)
+    const int32_t p0 = kCrcPiece * lane, p1 = p0 + kCrcPiece;
     uint32_t r = 0u;
     if (p1 > v0) {
       int32_t p = p0 > v0 ? p0 : v0;
       const bool holds_first = first && p0 <= v0;  // the section's very first byte is mine: the host's register goes in here
       if (holds_first) r = state;
       auto dword_at = [&](int32_t q) -> uint32_t {  // frame dword q (frame bytes [4 q, 4 q + 4))
-        const uint32_t lo = A[(q >> 6) * 65 + (q & 63)], hi = A[((q + 1) >> 6) * 65 + ((q + 1) & 63)];
+        const uint32_t lo = A[(q >> 4) * 17 + (q & 15)], hi = A[((q + 1) >> 4) * 17 + ((q + 1) & 15)];
         return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh);
       };
       // the bytes in front of my first whole dword (a tile that starts inside one)
@@ -208,14 +219,11 @@ __global__ void __launch_bounds__(64) crc_kernel(const uint8_t* __restrict__ byt
         r = Ts[768 + (x & 0xffu)] ^ Ts[512 + ((x >> 8) & 0xffu)] ^ Ts[256 + ((x >> 16) & 0xffu)] ^ Ts[x >> 24];
       }
     }
-    // lane tree: after level s the lanes whose low s + 1 bits are set hold the register of their 2^(s+1) pieces
+    // every lane shifts its register over the pieces behind it; the tile's register is the XOR of them all
+    r = crc_mulmod(r, lane_k);
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-      const uint32_t left = (uint32_t)__shfl_up((int)r, 1 << s, 64);
-      if (((lane >> s) & 1) && ((lane & ((1 << s) - 1)) == ((1 << s) - 1))) r = crc_mulmod(left, K.tree[s]) ^ r;
-    }
-    const uint32_t tile_reg = (uint32_t)__shfl((int)r, 63, 64);
-    total = first ? tile_reg : crc_mulmod(total, K.tile) ^ tile_reg;
+    for (int s = 32; s >= 1; s >>= 1) r ^= (uint32_t)__shfl_xor((int)r, s, 64);
+    total = first ? r : crc_mulmod(total, tile_k) ^ r;
     first = false;
     done += T;
   }
@@ -1308,6 +1316,25 @@ __global__ void table_clear_kernel(TableSlot* __restrict__ s, uint64_t n) {
   if (i < n) ((uint4*)s)[i] = make_uint4(0u, 0u, 0xffffffffu, 0xffffffffu);
 }
 
+// n bytes at a == n bytes at b?  Sixteen bytes a round, every load of a round in flight at once (the first version compared
+// byte by byte and stopped at the first difference: two dependent single-byte loads per byte — 110 us per 10^6 records on
+// 13-byte ids, 550 us on 36-byte UUIDs, profiles/r06_e2e_*_depth1_kernel_stats.csv).  Reads at most 7 bytes past either end
+// (the staged bytes and the key arena both end 16 bytes after their last byte).
+__device__ __forceinline__ bool keys_equal(const uint8_t* a, const uint8_t* b, int n) {
+  uint32_t diff = 0u;
+  for (int i = 0; i < n; i += 16) {
+    uint32_t x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int left = n - i - 4 * k;
+      x[k] = left > 0 ? load4(a + i + 4 * k) ^ load4(b + i + 4 * k) : 0u;
+      if (left < 4 && left > 0) x[k] &= (1u << (8 * left)) - 1u;
+    }
+    diff |= x[0] | x[1] | x[2] | x[3];
+  }
+  return diff == 0u;
+}
+
 // insert-or-find by hash; a slot this push inserts remembers its first record
 __global__ void probe_kernel(RecMeta* __restrict__ meta, int64_t n_rec, Table t) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1343,8 +1370,7 @@ __global__ void flag_kernel(const RecMeta* __restrict__ meta, int64_t n_rec, con
       bool same;
       if (id != 0xffffffffu) {
         const int64_t a0 = key_off[id], a1 = key_off[id + 1];
-        same = a1 - a0 == m.key_len;
-        for (int b = 0; same && b < m.key_len; ++b) same = arena[a0 + b] == kp[b];
+        same = a1 - a0 == m.key_len && keys_equal(arena + a0, kp, m.key_len);
       } else {
         const uint32_t fr = t.s[m.slot].first_rec;
         if ((int64_t)fr == i) {
@@ -1353,8 +1379,7 @@ __global__ void flag_kernel(const RecMeta* __restrict__ meta, int64_t n_rec, con
         } else {
           const RecMeta o = meta[fr];
           const uint8_t* op = bytes + o.key_off;
-          same = o.key_len == m.key_len;
-          for (int b = 0; same && b < m.key_len; ++b) same = op[b] == kp[b];
+          same = o.key_len == m.key_len && keys_equal(op, kp, m.key_len);
         }
       }
       if (same) k = 1u; else report(err, i, RS_COLLISION);
@@ -2059,16 +2084,15 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
   DCHK(d, hipMemcpyAsync(s.d_sections.p, stage(secs.data(), sec_bytes), sec_bytes, hipMemcpyHostToDevice, st));
   if (!s.h_crc.empty()) {
     // the batches' CRC-32C, finished where their bytes now are (the host ran it over the 40 header bytes only)
-    static const CrcShift kShift = crc_shift_constants();
     if (!d->crc_slice) {
-      DCHK(d, hipMalloc(&d->crc_slice, sizeof(CrcSlice)));
-      DCHK(d, hipMemcpy(d->crc_slice, &crc_slice_tables(), sizeof(CrcSlice), hipMemcpyHostToDevice));
+      DCHK(d, hipMalloc(&d->crc_slice, sizeof(CrcTables)));
+      DCHK(d, hipMemcpy(d->crc_slice, &crc_tables(), sizeof(CrcTables), hipMemcpyHostToDevice));
     }
     const size_t crc_bytes = s.h_crc.size() * sizeof(CrcSpan);
     DCHK(d, s.crc_spans.reserve(crc_bytes, false, st));
     DCHK(d, hipMemcpyAsync(s.crc_spans.p, stage(s.h_crc.data(), crc_bytes), crc_bytes, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(crc_kernel, dim3((unsigned)s.h_crc.size()), dim3(64), 0, st, (const uint8_t*)s.d_bytes.p, (const CrcSpan*)s.crc_spans.p, (int32_t)s.h_crc.size(), kShift,
-                       (const uint32_t*)d->crc_slice, (ErrorCell*)s.d_err.p);
+    hipLaunchKernelGGL(crc_kernel, dim3((unsigned)((s.h_crc.size() + kCrcWaves - 1) / kCrcWaves)), dim3(64 * kCrcWaves), 0, st, (const uint8_t*)s.d_bytes.p,
+                       (const CrcSpan*)s.crc_spans.p, (int32_t)s.h_crc.size(), (const CrcTables*)d->crc_slice, (ErrorCell*)s.d_err.p);
   }
   lap("copies");
   const uint8_t* dby = (const uint8_t*)s.d_bytes.p;

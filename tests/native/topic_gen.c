@@ -72,3 +72,84 @@ int64_t surge_test_counter_records(int64_t n, const int64_t* agg, const int32_t*
   }
   return n;
 }
+
+/* ---- BankAccount (surge-docs sample) -----------------------------------------------------------------------------------
+ * What `BankAccountEventFormat.write_event` (examples/fixture_models.py, restating BankAccountSurgeModel.scala:30-32)
+ * writes: the record key is the account's UUID alone (no ':' and no sequence number), the balances are JSON numbers as
+ * play-json writes a Double.
+ *   account number of aggregate a:  hhhhhhhh-hhhh-4hhh-[89ab]hhh-<a as 12 hex digits>   (h: a hash of a; version 4, variant 1)
+ *   j = 1:  {"accountNumber":"<uuid>","accountOwner":"Owner <a % 1000>","securityCode":"<a % 10000, 4 digits>","balance":<amount>,"_type":"docs.command.BankAccountCreated"}
+ *   j > 1:  {"accountNumber":"<uuid>","newBalance":<amount>,"_type":"docs.command.BankAccountUpdated"}
+ * amount = cents / 100 (0 < cents < 10^9: Double.toString stays in plain notation), written with its shortest digits:
+ * 1000, 1234.5, 12.34.  keys need 36 bytes per record, vals 192. */
+static uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+static uint8_t* put_hex(uint8_t* p, uint64_t v, int digits) {
+  for (int k = digits - 1; k >= 0; --k) { p[k] = (uint8_t)"0123456789abcdef"[v & 15]; v >>= 4; }
+  return p + digits;
+}
+static uint8_t* put_uuid(uint8_t* p, int64_t agg) {
+  const uint64_t h = mix64((uint64_t)agg), g = mix64(h);
+  p = put_hex(p, h >> 32, 8); *p++ = '-';
+  p = put_hex(p, (h >> 16) & 0xffff, 4); *p++ = '-';
+  p = put_hex(p, 0x4000 | (h & 0x0fff), 4); *p++ = '-';
+  p = put_hex(p, 0x8000 | (g & 0x3fff), 4); *p++ = '-';
+  return put_hex(p, (uint64_t)agg, 12);
+}
+static int amount_len(int64_t cents) {
+  const int fr = (int)(cents % 100);
+  return digits_u((uint64_t)(cents / 100)) + (fr == 0 ? 0 : fr % 10 == 0 ? 2 : 3);
+}
+static uint8_t* put_amount(uint8_t* p, int64_t cents) {
+  const int fr = (int)(cents % 100);
+  p = put_u(p, (uint64_t)(cents / 100));
+  if (fr == 0) return p;
+  *p++ = '.';
+  *p++ = (uint8_t)('0' + fr / 10);
+  if (fr % 10) *p++ = (uint8_t)('0' + fr % 10);
+  return p;
+}
+int64_t surge_test_bank_records(int64_t n, const int64_t* agg, const int32_t* seq, const int64_t* cents, uint8_t* keys, int64_t* key_off, uint8_t* vals,
+                                int64_t* val_off) {
+  key_off[0] = 0;
+  val_off[0] = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    key_off[i + 1] = key_off[i] + 36;
+    /* {"accountNumber":" = 18; uuid 36; ", = 2 */
+    int64_t vl = 18 + 36 + 2;
+    if (seq[i] == 1) /* "accountOwner":"Owner  = 22; n; ","securityCode":" = 18; 4; ","balance": = 12; amount; ,"_type":" = 10; name 31; "} = 2 */
+      vl += 22 + digits_u((uint64_t)(agg[i] % 1000)) + 18 + 4 + 12 + amount_len(cents[i]) + 10 + 31 + 2;
+    else /* "newBalance": = 13; amount; ,"_type":" = 10; name 31; "} = 2 */
+      vl += 13 + amount_len(cents[i]) + 10 + 31 + 2;
+    val_off[i + 1] = val_off[i] + vl;
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    uint8_t* k = keys + key_off[i];
+    uint8_t* v = vals + val_off[i];
+    k = put_uuid(k, agg[i]);
+    v = put(v, "{\"accountNumber\":\"");
+    v = put_uuid(v, agg[i]);
+    v = put(v, "\",");
+    if (seq[i] == 1) {
+      v = put(v, "\"accountOwner\":\"Owner ");
+      v = put_u(v, (uint64_t)(agg[i] % 1000));
+      v = put(v, "\",\"securityCode\":\"");
+      for (int d = 3, c = (int)(agg[i] % 10000); d >= 0; --d) { v[d] = (uint8_t)('0' + c % 10); c /= 10; }
+      v += 4;
+      v = put(v, "\",\"balance\":");
+      v = put_amount(v, cents[i]);
+      v = put(v, ",\"_type\":\"docs.command.BankAccountCreated\"}");
+    } else {
+      v = put(v, "\"newBalance\":");
+      v = put_amount(v, cents[i]);
+      v = put(v, ",\"_type\":\"docs.command.BankAccountUpdated\"}");
+    }
+    if (k != keys + key_off[i + 1] || v != vals + val_off[i + 1]) __builtin_trap(); /* the length pass and the text disagree */
+  }
+  return n;
+}

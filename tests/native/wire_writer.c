@@ -183,9 +183,22 @@ static int64_t put_batch(uint8_t* out, int64_t base_offset, int32_t n_records, c
   return p - out;
 }
 
-/* One record: length, attributes 0, timestampDelta, offsetDelta, key, value, 0 headers.  klen / vlen < 0 = null. */
-static uint8_t* put_record(uint8_t* p, int64_t ts_delta, int32_t offset_delta, const uint8_t* key, int64_t klen, const uint8_t* val, int64_t vlen) {
-  const int64_t body = 1 + varlong_len(ts_delta) + varlong_len(offset_delta) + varlong_len(klen) + (klen > 0 ? klen : 0) + varlong_len(vlen) + (vlen > 0 ? vlen : 0) + 1;
+/* The headers section every record written from now on carries (the encoded section as it stands in a record: varint
+ * count, then per header varint key length, key, varint value length, value); len = 0: no headers (one byte, the count 0).
+ * Kafka clients attach headers per record — the reference's publisher passes SerializedMessage.headers and its tracing
+ * context on (SurgeModel.scala:46-52, HeadersHelper.scala:17) — and a reader has to step over them.  At most 255 bytes. */
+static uint8_t g_headers[256];
+static int64_t g_headers_len = 0;
+int32_t surge_test_wire_set_record_headers(const uint8_t* section, int64_t len) {
+  if (len < 0 || len > 255) return -1;
+  if (len > 0) memcpy(g_headers, section, (size_t)len);
+  g_headers_len = len;
+  return 0;
+}
+
+/* One record: length, attributes 0, timestampDelta, offsetDelta, key, value, headers (none unless set above).  klen / vlen < 0 = null. */
+static uint8_t* put_record_h(uint8_t* p, int64_t ts_delta, int32_t offset_delta, const uint8_t* key, int64_t klen, const uint8_t* val, int64_t vlen, int64_t headers_len) {
+  const int64_t body = 1 + varlong_len(ts_delta) + varlong_len(offset_delta) + varlong_len(klen) + (klen > 0 ? klen : 0) + varlong_len(vlen) + (vlen > 0 ? vlen : 0) + (headers_len ? headers_len : 1);
   p = varlong(p, body);
   *p++ = 0;
   p = varlong(p, ts_delta);
@@ -194,8 +207,13 @@ static uint8_t* put_record(uint8_t* p, int64_t ts_delta, int32_t offset_delta, c
   if (klen > 0) { memcpy(p, key, (size_t)klen); p += klen; }
   p = varlong(p, vlen);
   if (vlen > 0) { memcpy(p, val, (size_t)vlen); p += vlen; }
-  *p++ = 0; /* headers: 0 (zig-zag of 0) */
+  if (headers_len) { memcpy(p, g_headers, (size_t)headers_len); p += headers_len; }
+  else *p++ = 0; /* headers: 0 (zig-zag of 0) */
   return p;
+}
+
+static uint8_t* put_record(uint8_t* p, int64_t ts_delta, int32_t offset_delta, const uint8_t* key, int64_t klen, const uint8_t* val, int64_t vlen) {
+  return put_record_h(p, ts_delta, offset_delta, key, klen, val, vlen, g_headers_len); /* a data record */
 }
 
 /* The records idx[0 .. n) (NULL: 0 .. n) as ONE batch at `out`; a record's timestampDelta is ts_delta[i] (NULL: 0).
@@ -206,7 +224,7 @@ int64_t surge_test_wire_batch(uint8_t* out, int64_t base_offset, int64_t n, cons
   int64_t bound = 0;
   for (int64_t i = 0; i < n; ++i) {
     const int64_t r = idx ? idx[i] : i;
-    bound += 40 + (key_off[r + 1] - key_off[r]) + (val_off[r + 1] - val_off[r]);
+    bound += 40 + g_headers_len + (key_off[r + 1] - key_off[r]) + (val_off[r + 1] - val_off[r]);
   }
   uint8_t* recs = (uint8_t*)malloc((size_t)bound + 16);
   uint8_t* scratch = (uint8_t*)malloc((size_t)(bound + bound / 255 + 64 + 8 * (bound / 65536 + 1)));
@@ -230,7 +248,7 @@ int64_t surge_test_wire_control(uint8_t* out, int64_t offset, int64_t producer_i
   uint8_t key[4], val[6], recs[32];
   be16(be16(key, 0), kind);      /* version 0, type */
   be32(be16(val, 0), 0);         /* version 0, coordinatorEpoch 0 */
-  uint8_t* p = put_record(recs, 0, 0, key, 4, val, 6);
+  uint8_t* p = put_record_h(recs, 0, 0, key, 4, val, 6, 0); /* (a marker carries no headers) */
   return put_batch(out, offset, 1, recs, p - recs, WIRE_TRANSACTIONAL | WIRE_CONTROL, producer_id, producer_epoch, -1, ts, ts, NULL);
 }
 
@@ -322,7 +340,7 @@ static int32_t partition_fetch(wire_partition* w, int32_t p, const int64_t* idx,
         while (done + cnt < fn) {
           const int64_t r = idx[f0 + done + cnt];
           const int64_t kl = key_off[r + 1] - key_off[r], vl = val_off[r + 1] - val_off[r];
-          if (cnt > 0 && max_batch_bytes > 0 && (rp - w->recs) + kl + vl + 12 > max_batch_bytes) break;
+          if (cnt > 0 && max_batch_bytes > 0 && (rp - w->recs) + kl + vl + 12 + g_headers_len > max_batch_bytes) break;
           const int64_t when = txn ? ((done + cnt) * 50) / fn : 0; /* ms into the flush interval */
           if (first_delta < 0) first_delta = when;
           if (when - first_delta > max_delta) max_delta = when - first_delta;
@@ -389,7 +407,7 @@ int32_t surge_test_wire_topic_fetch(wire_topic* t, int64_t n, const int32_t* par
   int64_t max_rec = 64;
   for (int64_t i = 0; i < n; ++i) {
     ++start[partition[i] + 1];
-    const int64_t rl = 40 + (key_off[i + 1] - key_off[i]) + (val_off[i + 1] - val_off[i]);
+    const int64_t rl = 40 + g_headers_len + (key_off[i + 1] - key_off[i]) + (val_off[i + 1] - val_off[i]);
     if (rl > max_rec) max_rec = rl;
   }
   for (int32_t p = 0; p < P; ++p) start[p + 1] += start[p];

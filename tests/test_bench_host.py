@@ -88,3 +88,71 @@ def test_algo_names_and_plain_multi_gpu_invocation_starts_its_own_ranks():
     assert res.returncode != 0
     # both ranks were started by torch.distributed.run (its failure report lists them); the first to reach the check stops the job
     assert res.stderr.count("bench.py needs a GPU") >= 1 and "local_rank: 1" in res.stderr and "local_rank: 0" in res.stderr, res.stderr[-3000:]
+
+
+def test_mixed_topic_bank_account_events_with_headers_decode_to_the_generators_source_events():
+    """bench.py --e2e-topic mixed on the host: the generator's BankAccount records (UUID keys without ':', Double balances as
+    play-json text — a sample compared with the fixture's event writer byte for byte), written by the independent writer with
+    two headers per record into transactional lz4 batches, framed and decoded by the library's HOST decoder: per account the
+    decoded events are the generator's source events in order, and the oracle's fold of either is the same state."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import topic_gen
+    from oracle import oracle
+    from surge_amd import schema as S
+    from surge_amd import synth
+    from surge_amd.ingest import EventsTopicIngest
+
+    topic = bench.MixedTopic(np, synth, S)
+    A, P = 3000, 8
+    part = topic.partitions(A, P, None, None, None)
+    assert part.min() >= 0 and part.max() < P and np.unique(part).shape[0] == P
+    ids = np.arange(A, dtype=np.int64)
+    counts = topic.counts(ids, 8)
+    long_rows = counts >= topic.LONG_MIN
+    assert 5 <= int(long_rows.sum()) <= 60 and counts[long_rows].max() <= 256 and counts[~long_rows].max() <= 8
+    a = np.repeat(ids, counts)
+    j = (np.arange(a.shape[0]) - np.repeat(np.cumsum(counts) - counts, counts) + 1).astype(np.int32)
+    order = np.argsort(j, kind="stable")  # rounds: the j-th event of every account that has one
+    a, j = a[order], j[order]
+    tmpl = topic.model.event_json_template()
+    hdr = topic_gen.set_record_headers(topic.headers)
+    try:
+        assert hdr > 80
+        handles = [EventsTopicIngest() for _ in range(P)]
+        got = {}
+        with topic_gen.WireTopic(P, 64, 16384, "lz4", 5, 4) as w:
+            for lo in range(0, a.shape[0], 5000):
+                aa, jj = a[lo:lo + 5000], j[lo:lo + 5000]
+                k, ko, v, vo = topic.records(topic_gen, aa, jj)
+                for i in range(0, aa.shape[0], 97):
+                    topic.check_sample(aa, jj, i, bytes(k[ko[i]:ko[i + 1]]), bytes(v[vo[i]:vo[i + 1]]))
+                last = lo + 5000 >= a.shape[0]
+                for q, data in enumerate(w.fetch(part[aa], k, ko, v, vo, last=last)):
+                    if data:
+                        assert b"traceparent" not in data[:61]  # (lz4: the header text is inside the compressed records)
+                        handles[q].feed(data)
+                        agg, ev, _ = handles[q].drain_json(tmpl)
+                        keys = handles[q].key_table().keys
+                        for x, e in zip(agg, ev):
+                            got.setdefault(keys[int(x)], []).append((int(e["type"]), int(e["seq"]), int(e["raw"])))
+            assert w.counts["records_aborted"] > 0 and w.counts["control_batches"] > 0
+        for h in handles:
+            h.close()
+    finally:
+        topic_gen.set_record_headers(())
+    assert len(got) == A
+    kb = np.frombuffer("".join(got).encode(), np.uint8)
+    key_ids = topic.ids_of_keys(kb, np.arange(A + 1, dtype=np.int64) * 36, A)
+    assert np.array_equal(np.sort(key_ids), ids)
+    off = np.zeros(A + 1, np.int64)
+    np.cumsum(counts[key_ids], out=off[1:])
+    src = topic.source_events(np.repeat(key_ids, counts[key_ids]), (np.arange(off[-1]) - np.repeat(off[:-1], counts[key_ids]) + 1).astype(np.int32))
+    dec = np.zeros(off[-1], dtype=S.EVENT_DTYPE)
+    flat = [e for key in got for e in got[key]]
+    dec["type"], dec["seq"], dec["raw"] = [x[0] for x in flat], [x[1] for x in flat], np.array([x[2] for x in flat], np.uint64)
+    assert dec.tobytes() == src.tobytes()
+    exp = oracle.fold_csr(off, src, None, topic.model.event_algebra())
+    assert float(exp["balance"][0]) == float(np.array([src["raw"][off[1] - 1]], np.uint64).view(np.float64)[0])  # the last balance written

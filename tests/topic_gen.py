@@ -43,6 +43,8 @@ def _load():
         _lib = ctypes.CDLL(build())
         _lib.surge_test_counter_records.restype = ctypes.c_int64
         _lib.surge_test_counter_records.argtypes = [ctypes.c_int64] + [ctypes.c_void_p] * 8
+        _lib.surge_test_bank_records.restype = ctypes.c_int64
+        _lib.surge_test_bank_records.argtypes = [ctypes.c_int64] + [ctypes.c_void_p] * 7
     return _lib
 
 
@@ -62,6 +64,48 @@ def counter_records(agg, ev_type, arg, seq):
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     lib.surge_test_counter_records(n, p(agg), p(ev_type), p(arg), p(seq), p(keys), p(ko), p(vals), p(vo))
     return keys[: ko[n]], ko, vals[: vo[n]], vo
+
+
+def bank_records(agg, seq, cents):
+    """``(keys_utf8, key_off, values, val_off)`` for BankAccount events (tests/native/topic_gen.c): ``seq`` 1 = the account's
+    ``BankAccountCreated`` with balance ``cents / 100``, above = a ``BankAccountUpdated`` with that new balance; the key is
+    the account's UUID alone.  Views of reused buffers, like ``counter_records``."""
+    lib = _load()
+    agg, cents = np.ascontiguousarray(agg, dtype=np.int64), np.ascontiguousarray(cents, dtype=np.int64)
+    seq = np.ascontiguousarray(seq, dtype=np.int32)
+    n = agg.shape[0]
+    if _bank_buffers.get("n", -1) < n:
+        _bank_buffers.update(n=n, keys=np.empty(36 * n + 8, np.uint8), vals=np.empty(192 * n + 8, np.uint8), ko=np.empty(n + 1, np.int64), vo=np.empty(n + 1, np.int64))
+    keys, vals, ko, vo = _bank_buffers["keys"], _bank_buffers["vals"], _bank_buffers["ko"][: n + 1], _bank_buffers["vo"][: n + 1]
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    lib.surge_test_bank_records(n, p(agg), p(seq), p(cents), p(keys), p(ko), p(vals), p(vo))
+    return keys[: ko[n]], ko, vals[: vo[n]], vo
+
+
+_bank_buffers = {}
+
+
+def set_record_headers(headers=()):
+    """Every record the independent writer writes from now on carries these ``(key: str, value: bytes)`` headers (none:
+    the default).  Process-wide (a static of tests/native/wire_writer.c)."""
+    def varint(v):
+        z = (v << 1) ^ (v >> 63)
+        out = bytearray()
+        while z >= 0x80:
+            out.append((z & 0x7F) | 0x80)
+            z >>= 7
+        out.append(z)
+        return bytes(out)
+
+    section = b""
+    if headers:
+        section = varint(len(headers))
+        for k, v in headers:
+            kb = k.encode("utf-8")
+            section += varint(len(kb)) + kb + varint(len(v)) + v
+    if wire_lib().surge_test_wire_set_record_headers(section, len(section)) != 0:
+        raise ValueError("headers section longer than 255 bytes")
+    return len(section)
 
 
 def frame_partitions(writer, partition, keys, key_off, values, val_off, timestamp_ms: int = 0):
@@ -93,6 +137,7 @@ def wire_lib():
         L.surge_test_wire_topic_partition.restype, L.surge_test_wire_topic_partition.argtypes = vp, [vp, i32, ctypes.POINTER(i64)]
         L.surge_test_wire_topic_end_offset.restype, L.surge_test_wire_topic_end_offset.argtypes = i64, [vp, i32]
         L.surge_test_wire_topic_fetch.restype, L.surge_test_wire_topic_fetch.argtypes = i32, [vp, i64, vp, vp, vp, vp, vp, i64, i64, i32, i64, i32, vp]
+        L.surge_test_wire_set_record_headers.restype, L.surge_test_wire_set_record_headers.argtypes = i32, [ctypes.c_char_p, i64]
         _wlib = L
     return _wlib
 
