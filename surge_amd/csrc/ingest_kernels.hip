@@ -1065,6 +1065,10 @@ struct JsonCtx {  // what the value decoder needs besides the value
   const EvjDevice* tmpl;  // nullptr: 16-byte fixed events
   const surge::F64ParseTable* ptab;
   int32_t dbg = 0;  // SURGE_DBG_DECODE (timing experiments only, results are NOT the topic's): 1 = sections are staged, nothing else; 2 = staged and chained, no record decoded
+#ifdef SURGE_EXPERIMENTS
+  unsigned long long* ticks = nullptr;  // per workgroup: wall clock (10 ns) at start, after staging, after the chain, at the end
+#endif
+  int32_t wave_chain = 1;  // a staged batch's records are found by its first wave, every lane in its own chunk (chain_records_parallel); 0: walked by one lane (SURGE_INGEST_CHAIN=lane)
 };
 
 // a record value -> event16 + status
@@ -1189,6 +1193,145 @@ __device__ bool chain_records(P base, int32_t len, int32_t* pos, int32_t cnt, in
   return true;
 }
 
+// The same walk by the batch's first WAVE, every lane on its own 1/64th of the section (the walk above is
+// the one sequential step of a batch — half of section_kernel's time alone, profiles/r06_section_chain_ab.txt).  A record's
+// start cannot be computed without the records before it, but it can be RECOGNISED and the recognition verified:
+//   * find: lane k looks in its chunk [k C, (k + 1) C) for the first position that reads as a record start — a length
+//     varint of one to three bytes, the attributes byte 0 behind it (kafka-clients writes 0; zero bytes are found four at a
+//     time), the record ending inside the section, and the same again at the position where it ends (lane 0: position 0);
+//   * walk: from there the lane follows the lengths to the first start at or behind its chunk's end, counting its records;
+//   * link: the find is a guess, the walk is exact GIVEN a true start — so if every lane's find is the position the nearest
+//     lane in front of it walked to (lane 0's is 0, which is a start by definition), every lane stood on the true chain, by
+//     induction; the last walk has to end at the section's end and the counts have to add up to the batch's record count.
+//   * write: an exclusive prefix sum of the counts gives each lane its records' indices; it walks its chunk once more and
+//     writes their bounds.
+// Anything else — a find that does not link (binary values full of zero bytes can fake a start), a four-byte varint, a length
+// that leaves the section, a count that differs — makes the function return false with nothing used: the one-lane walk then
+// does what it always did, and reports what it always reported.  Called by the 64 lanes of a workgroup's first wave.
+__device__ bool chain_records_parallel(lds_ptr_t base, int32_t len, int32_t cnt, int32_t* rec_body, int32_t* rec_end, int32_t* link) {
+  const int lane = (int)(threadIdx.x & 63u);
+  int32_t C = (((len + 63) >> 6) + 3) & ~3;  // a chunk: a multiple of four bytes ...
+  C += (C & 4) ? 0 : 4;                      // ... and an odd number of dwords: lane l's w-th word then lies in bank (l C / 4 + w) % 64, a different one
+                                             // for every lane (a 16 KiB section's 256-byte chunks put all 64 lanes on ONE bank: 64-way conflicts, measured 2 x slower)
+  if (C > 284) return false;                       // (the find keeps a chunk's zero bytes in 288 bits: sections up to 17.75 KiB, a 16 KiB batch with room to spare)
+  const int32_t lo = lane * C, hi = lo + C < len ? lo + C : len;
+  // one step of the walk at p (< len): false = not a record start this walk follows
+  auto step = [&](int32_t p, int32_t& body, int32_t& end) -> bool {
+    const uint32_t w = load4(base + p);
+    uint32_t v;
+    int32_t n;
+    if (!(w & 0x80u)) { v = w & 0x7fu; n = 1; }
+    else if (!(w & 0x8000u)) { v = (w & 0x7fu) | ((w >> 1) & 0x3f80u); n = 2; }
+    else if (!(w & 0x800000u)) { v = (w & 0x7fu) | ((w >> 1) & 0x3f80u) | ((w >> 2) & 0x1fc000u); n = 3; }
+    else return false;
+    if (v & 1u) return false;  // (zig-zag: a negative length)
+    body = p + n;
+    end = body + (int32_t)(v >> 1);
+    return end <= len;  // (n bytes of varint fit as well: end >= body)
+  };
+  // find, part one (the same instructions in every lane: a wave pays for the union of its lanes' paths): the zero bytes of
+  // positions [lo, lo + 288) — a record that starts in my chunk has its attributes byte there — as nine 32-bit masks
+  uint32_t zm[9];
+#pragma unroll
+  for (int g = 0; g < 9; ++g) {
+    uint32_t m = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int32_t q = lo + 32 * g + 4 * k;
+      const uint32_t w = q < len ? load4(base + q) : 0xffffffffu;
+      const uint32_t z = ~(((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w | 0x7f7f7f7fu);  // 0x80 exactly where a byte is zero
+      m |= (((z >> 7) * 0x10204080u) >> 28) << (4 * k);                             // ... as four bits
+    }
+    const int32_t left = len - lo - 32 * g;  // positions of this mask inside the section
+    zm[g] = left >= 32 ? m : left <= 0 ? 0u : m & ((1u << left) - 1u);
+  }
+  // find, part two: my zero bytes in ascending order, for each the starts one to three bytes in front of it, longest varint
+  // first (= ascending position); a start has to read as a record — varint, attributes 0, at least the six one-byte fields,
+  // inside the section — and so has the position where it ends.  At most 32 candidates: binary values are left to the one-lane walk
+  int32_t s = -1;
+  if (lane == 0) {
+    s = len > 0 ? 0 : -1;
+  } else {
+    int g = 0, tests = 0;
+    uint32_t cur = zm[0];
+    while (s < 0 && tests < 32) {
+      while (cur == 0u && g < 8) {
+        ++g;
+        cur = g == 1 ? zm[1] : g == 2 ? zm[2] : g == 3 ? zm[3] : g == 4 ? zm[4] : g == 5 ? zm[5] : g == 6 ? zm[6] : g == 7 ? zm[7] : zm[8];
+      }
+      if (cur == 0u) break;
+      const int32_t at = lo + 32 * g + __builtin_ctz(cur);
+      cur &= cur - 1u;
+      if (at <= lo) continue;
+      const uint32_t f = load4(base + at - 3);  // (at >= 5: lane >= 1, C >= 4)
+      const uint32_t b3 = f & 0xffu, b2 = (f >> 8) & 0xffu, b1 = (f >> 16) & 0xffu;
+      if (b1 & 0x80u) continue;
+      for (int n = (b2 & 0x80u) ? ((b3 & 0x80u) ? 3 : 2) : 1; n >= 1 && s < 0; --n) {
+        const int32_t p = at - n;
+        if (p < lo || p >= hi) continue;
+        ++tests;
+        const uint32_t v = n == 1 ? b1 : n == 2 ? ((b2 & 0x7fu) | (b1 << 7)) : ((b3 & 0x7fu) | ((b2 & 0x7fu) << 7) | (b1 << 14));
+        const int32_t l = (int32_t)(v >> 1), end = at + l;
+        if ((v & 1u) || l < 6 || end > len) continue;
+        if (end < len) {  // the record behind it
+          const uint32_t w2 = load4(base + end);
+          const int n2 = !(w2 & 0x80u) ? 1 : !(w2 & 0x8000u) ? 2 : !(w2 & 0x800000u) ? 3 : 0;
+          if (n2 == 0) continue;
+          const uint32_t v2 = n2 == 1 ? (w2 & 0x7fu) : n2 == 2 ? ((w2 & 0x7fu) | ((w2 >> 1) & 0x3f80u)) : ((w2 & 0x7fu) | ((w2 >> 1) & 0x3f80u) | ((w2 >> 2) & 0x1fc000u));
+          const uint32_t attr2 = n2 == 3 ? (w2 >> 24) : (w2 >> (8 * n2)) & 0xffu;
+          if ((v2 & 1u) || (v2 >> 1) < 6u || attr2 != 0u || end + n2 + (int32_t)(v2 >> 1) > len) continue;
+        }
+        s = p;
+      }
+    }
+  }
+  // walk my chunk: count
+  int32_t c = 0, e = s;
+  bool ok = true;
+  if (s >= 0) {
+    int32_t p = s;
+    while (p < lo + C && p < len) {
+      int32_t body, end;
+      if (!step(p, body, end)) { ok = false; break; }
+      ++c;
+      p = end;
+    }
+    e = p;
+  }
+  link[lane] = e;
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  const unsigned long long have = __ballot(s >= 0);
+  if (s >= 0 && lane > 0) {
+    const unsigned long long front = have & ((1ull << lane) - 1ull);
+    ok = ok && front != 0ull && link[63 - __builtin_clzll(front)] == s;
+  }
+  const int last = 63 - __builtin_clzll(have | 1ull);
+  if (lane == last) ok = ok && e == len;
+  // the counts: inclusive scan over the lanes
+  int32_t incl = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int32_t up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  const int32_t total = __shfl(incl, 63, 64);
+  if (__ballot(!ok) != 0ull || total != cnt || (have & 1ull) == 0ull) return false;
+  // write
+  if (s >= 0) {
+    int32_t idx = incl - c, p = s;
+    while (p < lo + C && p < len) {
+      int32_t body, end;
+      (void)step(p, body, end);
+      rec_body[idx] = body;
+      rec_end[idx] = end;
+      ++idx;
+      p = end;
+    }
+  }
+  return true;
+}
+
 // A workgroup takes its section when lo_excl < byte_len and (byte_len <= cap or take_rest); byte_len <= cap is staged.
 template <int kSecThreads>
 __global__ void __launch_bounds__(kSecThreads) __attribute__((amdgpu_waves_per_eu(kSecThreads == 256 ? 5 : 6)))  // (four waves at 80 VGPRs spill)
@@ -1196,21 +1339,29 @@ section_kernel(const uint8_t* __restrict__ bytes, const Section* __restrict__ se
                uint64_t seed, JsonCtx jc, RecMeta* __restrict__ meta, uint4* __restrict__ ev_tmp, uint32_t* __restrict__ f64_host_list, ErrorCell* err) {
   extern __shared__ __attribute__((aligned(16))) uint8_t sec_smem[];
   __shared__ int32_t s_pos, s_bad;
+  __shared__ int32_t s_link[64];
   const Section sec = sections[blockIdx.x];
   if (sec.n_records <= 0) return;
   const int64_t len = sec.byte_len;
   if (!(len > lo_excl && (len <= cap || take_rest))) return;
   const bool staged = len <= cap && len < (1ll << 31);
+#ifdef SURGE_EXPERIMENTS
+#define SURGE_TICK(k) do { if (jc.ticks && threadIdx.x == 0) jc.ticks[4ull * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define SURGE_TICK(k) do { } while (0)
+#endif
+  SURGE_TICK(0);
   int32_t* const rec_body = (int32_t*)(sec_smem + ((cap + 47) & ~15ll));
   int32_t* const rec_end = rec_body + kSecRecs;
   const int64_t a0 = sec.byte_off & ~15ll;
   const int32_t skew = (int32_t)(sec.byte_off - a0);
+  const int n16 = staged ? (int)((skew + len + 15) >> 4) : 0;
   if (staged) {  // (the staged bytes buffer ends 16 bytes after its last byte)
-    const int n16 = (int)((skew + len + 15) >> 4);
     for (int c = threadIdx.x; c < n16; c += kSecThreads) ((uint4*)sec_smem)[c] = *(const uint4*)(bytes + a0 + 16ll * c);
   }
   if (threadIdx.x == 0) { s_pos = 0; s_bad = -1; }
   __syncthreads();
+  SURGE_TICK(1);
   if (jc.dbg) {  // timing experiments: every record of the batch is "skipped"
     RecMeta m;
     m.key_off = m.val_off = m.offset = 0; m.hash = 0; m.key_len = m.val_len = 0; m.slot = 0; m.status = RS_SKIP;
@@ -1226,22 +1377,32 @@ section_kernel(const uint8_t* __restrict__ bytes, const Section* __restrict__ se
   const uint8_t* gbase = bytes + sec.byte_off;
   for (int32_t r0 = 0; r0 < sec.n_records; r0 += kSecRecs) {
     const int32_t cnt = sec.n_records - r0 < kSecRecs ? sec.n_records - r0 : kSecRecs;
+    int32_t chained = 0;
+    if (staged && jc.wave_chain && sec.n_records <= kSecRecs && threadIdx.x < 64u) {  // (the first wave, all of it; a batch of one round)
+      if (chain_records_parallel(lbase, (int32_t)len, cnt, rec_body, rec_end, s_link)) chained = cnt;
+      else if (threadIdx.x == 0) atomicAdd(&err->reserved, 1u);
+    }
     if (threadIdx.x == 0) {
       if (s_bad < 0) {
-        int32_t pos = s_pos, bad = 0;
-        const bool ok = staged ? chain_records(lbase, (int32_t)len, &pos, cnt, rec_body, rec_end, &bad) : chain_records(gbase, (int32_t)len, &pos, cnt, rec_body, rec_end, &bad);
-        s_pos = pos;
-        if (!ok) {
-          // everything from here to the end of the batch is unreadable: the rest is marked, the first is reported
-          s_bad = r0 + bad;
-          for (int32_t k = bad; k < cnt; ++k) rec_body[k] = -1;
-          report(err, sec.rec_first + r0 + bad, RS_MALFORMED);
+        if (chained < cnt) {  // not chained by the wave, or left by it at a record it does not read: the one-lane walk from there
+          int32_t pos = s_pos, bad = 0;
+          const bool ok = staged ? chain_records(lbase, (int32_t)len, &pos, cnt - chained, rec_body + chained, rec_end + chained, &bad)
+                                 : chain_records(gbase, (int32_t)len, &pos, cnt - chained, rec_body + chained, rec_end + chained, &bad);
+          s_pos = pos;
+          if (!ok) {
+            // everything from here to the end of the batch is unreadable: the rest is marked, the first is reported
+            bad += chained;
+            s_bad = r0 + bad;
+            for (int32_t k = bad; k < cnt; ++k) rec_body[k] = -1;
+            report(err, sec.rec_first + r0 + bad, RS_MALFORMED);
+          }
         }
       } else {
         for (int32_t k = 0; k < cnt; ++k) rec_body[k] = -1;
       }
     }
     __syncthreads();
+    SURGE_TICK(2);
     for (int32_t i0 = 0; i0 < (jc.dbg ? 0 : cnt); i0 += kSecThreads) {
       const int32_t i = i0 + (int32_t)threadIdx.x;
       const bool valid = i < cnt;
@@ -1252,6 +1413,7 @@ section_kernel(const uint8_t* __restrict__ bytes, const Section* __restrict__ se
         decode_record(gbase, sec.byte_off, sec.base_offset, valid, body, end, sec.rec_first + r0 + i, seed, jc, meta, ev_tmp, f64_host_list, err);
     }
     __syncthreads();
+    SURGE_TICK(3);
   }
 }
 
@@ -1549,6 +1711,7 @@ struct surge_device_decoder {
   bool block_waits = true;
   bool consumed_valid = false;
   int64_t counters[4] = {0, 0, 0, 0};  // records seen, delivered, flush records skipped, f64 values re-parsed on the host
+  int64_t chain_fallbacks = 0;         // batches whose records the one-lane walk chained after the parallel recognition declined (SURGE_EXPERIMENTS builds print it)
   int64_t reseeds = 0, pushes = 0;
   bool slots_sized = false;  // the first wire push has sized every slot's buffers like its own
 };
@@ -1720,6 +1883,10 @@ int32_t surge_device_decoder_create(int32_t device_id, void* hip_stream, const s
 
 int32_t surge_device_decoder_destroy(surge_device_decoder* d) {
   if (!d) return OK;
+#ifdef SURGE_EXPERIMENTS
+  std::fprintf(stderr, "[surge experiments] decoder: %lld pushes, %lld batches chained by the one-lane walk after the parallel recognition declined\n", (long long)d->pushes,
+               (long long)d->chain_fallbacks);
+#endif
   int prev = 0;
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(d->device);
@@ -2163,13 +2330,28 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
   {
     JsonCtx jc{d->json ? (const EvjDevice*)d->d_tmpl.p : nullptr, (const surge::F64ParseTable*)d->d_ptab.p};
     jc.dbg = dbg_decode() % 10;
+    static const bool lane_chain = [] { const char* v = std::getenv("SURGE_INGEST_CHAIN"); return v && v[0] == 'l'; }();  // A/B: "lane" = the one-lane walk of rounds 4 / 5
+    jc.wave_chain = lane_chain ? 0 : 1;
     static const int force_threads = [] { const char* v = std::getenv("SURGE_INGEST_SEC_THREADS"); return v ? std::atoi(v) : 0; }();  // experiments: 64 / 128 / 192 / 256
     static const bool two_classes = [] { const char* v = std::getenv("SURGE_INGEST_SEC_CLASSES"); return v && v[0] == '2'; }();      // experiments: round 4's two launches
     const int threads = force_threads ? force_threads : (max_recs <= 64 ? 64 : max_recs <= 128 ? 128 : max_recs <= 192 ? 192 : 256);
     const int64_t caps3[3] = {8320, 16640, 65536};
     const int64_t* caps = two_classes ? caps3 + 1 : caps3;
     const int n_caps = two_classes ? 2 : 3;
+#ifdef SURGE_EXPERIMENTS
+    static unsigned long long* tick_buf = nullptr;
+    static const bool want_ticks = std::getenv("SURGE_SECTION_TICKS") != nullptr;
+    if (want_ticks && !tick_buf) (void)hipMalloc(&tick_buf, 4ull * 8 * 65536);
+#endif
     for (int c = 0; c < n_caps; ++c) {
+#ifdef SURGE_EXPERIMENTS
+      if (want_ticks && total_sections <= 65536 && c == 1) {
+        (void)hipMemsetAsync(tick_buf, 0, 4ull * 8 * 65536, st);
+        jc.ticks = tick_buf;
+      } else {
+        jc.ticks = nullptr;
+      }
+#endif
       const size_t lds = (size_t)((caps[c] + 47) & ~15ll) + 2 * (size_t)kSecRecs * 4;
       const int64_t lo_excl = c == 0 ? -1 : caps[c - 1];
       const int32_t rest = c == n_caps - 1 ? 1 : 0;
@@ -2181,6 +2363,26 @@ int32_t stage1_wire(surge_device_decoder* d, PushSlot& s, int32_t n_parts, const
       else if (threads <= 192) SURGE_SECTION_LAUNCH(192);
       else SURGE_SECTION_LAUNCH(256);
 #undef SURGE_SECTION_LAUNCH
+#ifdef SURGE_EXPERIMENTS
+      if (jc.ticks) {  // (blocks: experiment runs only)
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> t(4ull * (size_t)total_sections);
+        (void)hipMemcpy(t.data(), tick_buf, t.size() * 8, hipMemcpyDeviceToHost);
+        double sum[3] = {0, 0, 0};
+        unsigned long long first = ~0ull, last = 0;
+        size_t n = 0;
+        for (size_t b = 0; b < (size_t)total_sections; ++b) {
+          const unsigned long long* q = &t[4 * b];
+          if (!q[0] || !q[3]) continue;
+          ++n;
+          for (int k = 0; k < 3; ++k) sum[k] += (double)(q[k + 1] - q[k]);
+          first = q[0] < first ? q[0] : first;
+          last = q[3] > last ? q[3] : last;
+        }
+        if (n) std::fprintf(stderr, "[surge experiments] section launch (class 2): %zu workgroups with work, mean us: staging %.2f, chain %.2f, decode %.2f; first start to last end %.1f us\n", n,
+                            sum[0] / n / 100.0, sum[1] / n / 100.0, sum[2] / n / 100.0, (double)(last - first) / 100.0);
+      }
+#endif
     }
     DCHK(d, hipGetLastError());
   }
@@ -2399,6 +2601,7 @@ int32_t stage2(surge_device_decoder* d, PushSlot& s, bool wait) {
     }
     d->counters[3] += ec.n_f64_host;
   }
+  d->chain_fallbacks += ec.reserved;
   d->n_records += kept;
   d->counters[1] += kept;
   d->counters[2] += n_rec - kept;

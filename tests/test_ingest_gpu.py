@@ -814,3 +814,62 @@ def test_a_batchs_crc32c_is_finished_on_the_device_and_a_damaged_byte_fails_the_
                 d.push_from(g2)
                 agg, ev, offs, nk = d.result()
                 assert ev.cpu().numpy().tobytes() == host[1][1:].tobytes() and d.keys() == host[3]
+
+
+@pytest.mark.gpu
+def test_parallel_record_chain_is_never_fooled_by_bytes_that_look_like_record_starts():
+    """section_kernel finds a batch's records with 64 lanes at once (chain_records_parallel: every lane recognises a record
+    start in its own 1/64th of the section, walks from it, and the walks have to link up) and falls back to the one-lane walk
+    when they do not.  Topics built to fool the recognition — keys and headers that contain whole fake records (length varint,
+    attributes 0, a plausible body) and runs of zero bytes, records of every length from a dozen bytes to a few KiB so that
+    starts fall anywhere in a lane's chunk and long records span many chunks, compressed and not — decode exactly like the
+    host decoder, record for record; so do thousands of uniform play-json records (the recognition's positive case)."""
+    rng = random.Random(23)
+
+    def fake_record(n):
+        body = bytes([0, 0, rng.randrange(0, 127) * 2]) + bytes(rng.randrange(256) if rng.random() < 0.7 else 0 for _ in range(n))
+        z = len(body) << 1
+        return (bytes([z]) if z < 0x80 else bytes([(z & 0x7F) | 0x80, z >> 7])) + body
+
+    def hostile(n):
+        kind = rng.randrange(3)
+        if kind == 0:
+            return b"".join(fake_record(rng.randrange(6, 60)) for _ in range(max(1, n // 40)))
+        if kind == 1:
+            return bytes(n)
+        return bytes(rng.randrange(256) for _ in range(n))
+
+    batches, off = [], 0
+    for b in range(200):
+        n = rng.randrange(1, 150)
+        style = rng.choice(["tiny", "fake-keys", "fake-headers", "long", "mixed"])
+        rs = []
+        for j in range(n):
+            st = style if style != "mixed" else rng.choice(["tiny", "fake-keys", "fake-headers", "long"])
+            agg = f"a{rng.randrange(500)}"
+            key, hdrs = f"{agg}:{j}".encode(), []
+            if st == "fake-keys":
+                key = f"{agg}:".encode() + hostile(rng.randrange(8, 80))
+            elif st == "fake-headers":
+                hdrs = [(b"h", hostile(rng.randrange(8, 120)))]
+            elif st == "long":
+                hdrs = [(b"blob", hostile(rng.randrange(200, 3000)))]
+            rs.append((key, counter_event(rng.choice([0, 1, 2]), off + j, rng.randrange(-5, 5)), hdrs))
+        batches.append(kw.record_batch(off, rs, compression=rng.choice(["none", "lz4"])))
+        off += n
+    wire = b"".join(batches)
+    host, host_keys, dev, dev_keys, counters = both_decoders(wire, device_lz4=True)
+    assert dev_keys == host_keys and counters["records_delivered"] == host[0].shape[0] == off
+    for h, g in zip(host, dev):
+        assert h.shape == g.shape and h.tobytes() == g.tobytes()
+    bl = CounterBusinessLogic()
+    model, fmt = bl.command_model(), bl.event_write_formatting()
+    recs = []
+    for i in range(30000):
+        m = fmt.write_event(CountIncremented(f"agg-{rng.randrange(3000)}", rng.randrange(1000), i + 1))
+        recs.append((m.key.encode(), m.value, [(b"trace", hostile(40))] if i % 97 == 0 else []))
+    wire = b"".join(kw.record_batch(s, recs[s:s + 140], compression="lz4" if (s // 140) % 3 else "none") for s in range(0, len(recs), 140))
+    host, host_keys, dev, dev_keys, _ = both_decoders(wire, model.event_json_template(), device_lz4=True)
+    assert dev_keys == host_keys
+    for h, g in zip(host, dev):
+        assert h.shape == g.shape and h.tobytes() == g.tobytes()
