@@ -290,7 +290,7 @@ def test_jni_shim_compiles_and_turns_a_missing_gpu_into_an_ioexception(tmp_path)
 def test_jni_shim_replays_the_reference_known_answers_through_direct_buffers(tmp_path):
     res = _build_jni_harness(tmp_path)
     assert res.returncode == 0, res.stdout + res.stderr
-    assert "ALL PASS" in res.stdout and res.stdout.count("PASS  ") == 24 and "FAIL" not in res.stdout
+    assert "ALL PASS" in res.stdout and res.stdout.count("PASS  ") == 26 and "FAIL" not in res.stdout
 
 
 def test_the_fake_jnienv_harness_drives_every_jni_export():
