@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <immintrin.h>
 #include <pthread.h>
 #include <thread>
 #include <vector>
@@ -622,6 +623,10 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
     }
   }
   size_t batch_no = 0;
+  // open transactions' batches in the queue (few at a feed's start; a marker looks for its producer's among them from the
+  // back and stops at the oldest open one — the first version walked the whole queue per marker: every batch of the feed)
+  int64_t n_open = 0;
+  for (const Batch& qb : g->queue) n_open += qb.decided == 0;
   // A failure in batch k leaves batches 0..k-1 of this buffer decoded and queued: report them as consumed so a
   // caller that retries (or skips the bad batch) never feeds them twice.
   auto bail = [&](int32_t code, const char* msg) {
@@ -636,6 +641,8 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
       if (batch_len < 49) return bail(SURGE_E_CORRUPT, "batchLength below the v2 header size");
       if (len - pos - 12 < batch_len) break;  // partial batch: wait for more bytes
       const uint8_t* body = data + pos + 12;
+      __builtin_prefetch(body + batch_len);       // the next batch's header: a fresh cache line every few KB of a buffer that was just received
+      __builtin_prefetch(body + batch_len + 64);
       Reader r{body, body + batch_len};
       (void)r.i32();  // partitionLeaderEpoch
       const uint8_t magic = r.u8();
@@ -738,15 +745,23 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
       if (control) {
         g->counters[4] += 1;
         if (control_type == 0 || control_type == 1) {  // ABORT / COMMIT ends this producer's open transaction
-          for (Batch& qb : g->queue)
-            if (qb.decided == 0 && qb.producer_id == producer_id) {
-              qb.decided = control_type == 1 ? 1 : 2;
-              if (control_type == 0) g->counters[3] += qb.sect_off >= 0 ? (int64_t)qb.count : (int64_t)qb.recs.size();
+          int64_t still_to_see = n_open;
+          for (auto qb = g->queue.rbegin(); qb != g->queue.rend() && still_to_see > 0; ++qb) {
+            if (qb->decided != 0) continue;
+            --still_to_see;
+            if (qb->producer_id == producer_id) {
+              qb->decided = control_type == 1 ? 1 : 2;
+              --n_open;
+              if (control_type == 0) g->counters[3] += qb->sect_off >= 0 ? (int64_t)qb->count : (int64_t)qb->recs.size();
             }
+          }
         }
       } else {
         b.decided = (transactional && g->isolation == SURGE_INGEST_READ_COMMITTED) ? 0 : 1;
-        if (!b.recs.empty() || b.count > 0) g->queue.push_back(std::move(b));
+        if (!b.recs.empty() || b.count > 0) {
+          n_open += b.decided == 0;
+          g->queue.push_back(std::move(b));
+        }
       }
       pos += 12 + batch_len;
     }
@@ -759,9 +774,7 @@ int32_t surge_ingest_feed(surge_ingest* g, const uint8_t* data, int64_t len, int
     return fail(g, E_NOMEM, "out of host memory while decoding");
   }
   if (consumed_out) *consumed_out = pos;
-  int64_t open = 0;
-  for (const Batch& qb : g->queue) open += qb.decided == 0;
-  g->counters[7] = open;
+  g->counters[7] = n_open;
   return OK;
 }
 
@@ -1132,6 +1145,34 @@ int32_t surge_ingest_group_receive_buffer(surge_ingest_group* grp, int64_t bytes
 // For a host whose fetch responses lie elsewhere (a test harness, a consumer library that owns its buffers): the one copy a
 // socket read would have made — every partition's bytes into the group's receive buffer, on `threads` threads (the calling
 // thread + the group's pool), cut into pieces of 1 MiB — and where each partition's bytes now are.
+namespace {
+// A fetch response's bytes into the slab with non-temporal stores.  What is written is read again by the framer — one header line
+// per few KB, prefetched a batch ahead — and by the copy engine; a cached copy reads every destination line first (read for
+// ownership: a third more memory traffic) and evicts what the other threads work on.  Falls back to memcpy without AVX2.
+__attribute__((target("avx2"))) void stream_copy_avx2(uint8_t* to, const uint8_t* from, size_t n) {
+  size_t head = (size_t)(-(intptr_t)to) & 31u;
+  if (head > n) head = n;
+  std::memcpy(to, from, head);
+  to += head; from += head; n -= head;
+  size_t i = 0;
+  for (; i + 128 <= n; i += 128) {
+    const __m256i a = _mm256_loadu_si256((const __m256i*)(from + i)), b = _mm256_loadu_si256((const __m256i*)(from + i + 32));
+    const __m256i c = _mm256_loadu_si256((const __m256i*)(from + i + 64)), d = _mm256_loadu_si256((const __m256i*)(from + i + 96));
+    _mm256_stream_si256((__m256i*)(to + i), a);
+    _mm256_stream_si256((__m256i*)(to + i + 32), b);
+    _mm256_stream_si256((__m256i*)(to + i + 64), c);
+    _mm256_stream_si256((__m256i*)(to + i + 96), d);
+  }
+  _mm_sfence();
+  std::memcpy(to + i, from + i, n - i);
+}
+void stream_copy(uint8_t* to, const uint8_t* from, size_t n) {
+  static const bool avx2 = __builtin_cpu_supports("avx2") && std::getenv("SURGE_INGEST_RECEIVE_COPY") == nullptr;  // (any value: plain memcpy, for A/B)
+  if (avx2 && n >= 4096) stream_copy_avx2(to, from, n);
+  else std::memcpy(to, from, n);
+}
+}  // namespace
+
 int32_t surge_ingest_group_receive_copy(surge_ingest_group* grp, const uint8_t* const* data, const int64_t* len, int32_t threads, const uint8_t** placed_out) {
   if (!grp || !data || !len || !placed_out) return fail(nullptr, E_INVALID, "bad argument");
   const int32_t n = (int32_t)grp->g.size();
@@ -1162,7 +1203,7 @@ int32_t surge_ingest_group_receive_copy(surge_ingest_group* grp, const uint8_t* 
     for (;;) {
       const size_t k = next.fetch_add(1);
       if (k >= pieces.size()) break;
-      std::memcpy(pieces[k].to, pieces[k].from, pieces[k].n);
+      stream_copy(pieces[k].to, pieces[k].from, pieces[k].n);
     }
     grp->cpu_ns[0] += thread_cpu_ns() - t0;
   };

@@ -539,7 +539,7 @@ def test_get_point_reads_and_errors():
             eng.load_csr(bad, ev)
         assert ei.value.status == -1 and "monotone" in str(ei.value)
         with pytest.raises(ReplayError):
-            eng.fold(S.ALGO_FIXED + 7)
+            eng.fold(99)  # not an algorithm
     so, ev = synth.fixed_log(10, 20, 4)
     with ReplayEngine() as eng:
         eng.load_csr(so, ev)
