@@ -17,5 +17,5 @@ c=e.get('config',{})
 print('host cpu', c.get('host_cpu_ms_per_1e6_records'), c.get('host_cpu_ms_per_1e6_records_without_the_receive_copy'), c.get('host_cpu_ms_per_1e6_records_by_thread'))
 print('cpu_baseline', {k:(round(v,4) if isinstance(v,float) else v) for k,v in d['cpu_baseline'].items() if not isinstance(v,(dict,list,str))})
 PY
-timeout 1500 python -m pytest tests -x -q -m gpu --timeout 300 2>&1 | tail -4 | tee gpurun_out/r06_gpu_suite.txt
+bash scripts/experiments/run_r6_suite.sh
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
