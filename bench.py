@@ -235,7 +235,7 @@ def main():
     ap.add_argument("--no-capacity-hint", action="store_true", help="e2e: let the resident state and the key table grow as aggregates appear instead of sizing them up front")
     ap.add_argument("--framing-by-copy", action="store_true", help="e2e: frame the way rounds 4 / 5 did — every records section copied into the framer's slab and its CRC-32C run "
                     "on the host (default: fetch responses are received into the slab and framed in place, the CRC-32C is finished on the device: the host reads batch headers only)")
-    ap.add_argument("--framing-threads", type=int, default=3, help="e2e: host threads receiving and framing a fetch's partitions side by side (3: in-place framing with the CRC on the device leaves the host the "
+    ap.add_argument("--framing-threads", type=int, default=2, help="e2e: host threads receiving and framing a fetch's partitions side by side (2: in-place framing with the CRC on the device leaves the host the "
                     "batch headers; rounds 4 / 5 framed by copy with the CRC on the host and needed 12 of the boxes' 16-CPU quota — --framing-by-copy --framing-threads 12; "
                     "capped at this rank's share of the CPUs the process may use)")
     ap.add_argument("--host-only", action="store_true", help="e2e: the HOST side alone — every rank receives and frames its fetch responses (its share of the framing threads, "
@@ -586,7 +586,7 @@ def main():
             torch.cuda.empty_cache()
             keep = ("value", "unit", "steps", "warmup", "ms_per_step", "data", "config", "roofline", "cpu_baseline")
             base = {**vars(args), "workload": "e2e", "warmup": 2, "batch_events": 1_000_000, "aggregates": None, "events_cap": 8, "writer": "independent",
-                    "codec": "lz4", "serial_framing": False, "two_thread_consumer": False, "no_capacity_hint": False, "framing_threads": 3, "framing_by_copy": False,
+                    "codec": "lz4", "serial_framing": False, "two_thread_consumer": False, "no_capacity_hint": False, "framing_threads": 2, "framing_by_copy": False,
                     "abort_every": 50, "hold_markers": 4, "bound_log": False, "e2e_topic": "counter"}
             # (the primary leg runs the first <= 14 events of every aggregate: 1.05e8 records, 103 timed fetches — a region long enough that one stalled fetch does not
             # decide the figure; the comparison legs below keep the 6.5e7-record topic)
@@ -613,8 +613,7 @@ def main():
             o = run_e2e(_ap.Namespace(**{**base, "steps": 10, "txn_flush_events": 512, "framing_by_copy": True, "framing_threads": 12}))
             result["e2e"]["framing_by_copy_12_threads"] = {"value": o["value"], **{k: o["config"][k] for k in ("host_cpu_ms_per_1e6_records", "framing_cpu_ms_per_1e6_records", "framing_threads")},
                                                            "parity": o["cpu_baseline"]["gpu_states_match_cpu_fold_of_the_source_events"]}
-            # ... and in place with eight threads: with the records found by a whole wave and the CRC in 4 KiB tiles the device stage outruns three framing threads
-            # (the primary figure stays at three: what a rank of an 8-GPU node on a 16-CPU quota can afford)
+            # ... and in place with eight threads (the primary figure stays at two: what a rank of an 8-GPU node on a 16-CPU quota can afford)
             torch.cuda.empty_cache()
             o = run_e2e(_ap.Namespace(**{**base, "steps": 10, "txn_flush_events": 512, "framing_threads": 8}))
             result["e2e"]["in_place_8_threads"] = {"value": o["value"], **{k: o["config"][k] for k in ("host_cpu_ms_per_1e6_records", "framing_cpu_ms_per_1e6_records", "framing_threads")},
@@ -1300,6 +1299,7 @@ def run_e2e(args):
     args.framing_threads = max(1, min(args.framing_threads, int(effective_cpus()[0]) // world - (3 if world == 1 else 1)))
     bound_log = bool(getattr(args, "bound_log", False))
     cpu_t0 = [None]
+    consumer_cpu, push_cpu = [], []  # the consumer thread's CPU seconds per fetch: (finish, fold) and push_async
     by_copy = bool(getattr(args, "framing_by_copy", False))
     with PartitionedFramedFetches((f for f, _ in fetches), P, threads=args.framing_threads, hold=depth, overlap=not args.serial_framing, device_crc=not by_copy,
                                   in_place=not by_copy) as framed, \
@@ -1317,8 +1317,10 @@ def run_e2e(args):
         def finish_one(wait):
             nonlocal n_agg
             t1 = time.perf_counter()
+            c1 = time.thread_time()
             d.finish(wait=wait)
             ta = time.perf_counter()
+            ca = time.thread_time()
             n_keys = d.n_keys
             if n_keys > n_agg:
                 eng.grow(max(n_keys, min(2 * n_agg, my_ids.shape[0])))  # (grow in big steps: a grow copies the resident state)
@@ -1331,6 +1333,7 @@ def run_e2e(args):
             else:
                 d.fold_into(eng, wait=wait)
             t2 = time.perf_counter()
+            consumer_cpu.append((ca - c1, time.thread_time() - ca))
             if len(marks) == W - 1:
                 cpu_t0[0] = (time.process_time(), framed.cpu_seconds(), thread_cpu_seconds())  # host CPU seconds (every thread of this process; the framing threads' own) from the end of the warm-up on
             if os.environ.get("SURGE_BENCH_TRACE"):
@@ -1353,9 +1356,10 @@ def run_e2e(args):
                 parts = next(fetch_iter, None)
                 if parts is None:
                     break
-                tp = time.perf_counter()
+                tp, cp = time.perf_counter(), time.thread_time()
                 d.push_async(parts)
                 push_ms.append((time.perf_counter() - tp) * 1e3)
+                push_cpu.append(time.thread_time() - cp)
                 pending += 1
             while pending:
                 finish_one(True)
@@ -1540,6 +1544,10 @@ def run_e2e(args):
                    "framing_cpu_ms_per_1e6_records": framing_cpu_s * 1e3 / max(1, n_events_timed) * 1e6,
                    "receive_copy_cpu_ms_per_1e6_records": recv_cpu_s * 1e3 / max(1, n_events_timed) * 1e6,
                    "host_cpu_ms_per_1e6_records_by_thread": {k: round(v * 1e3 / max(1, n_events_timed) * 1e6, 3) for k, v in sorted(by_thread.items(), key=lambda kv: -kv[1]) if v > 0},
+                   "consumer_cpu_ms_per_fetch": {"push_async": float(np.mean(push_cpu[W:])) * 1e3 if len(push_cpu) > W else None,
+                                                 "finish (interning; one wait in the middle, one behind)": float(np.mean([c[0] for c in consumer_cpu[W:]])) * 1e3,
+                                                 "fold (group-by + FLAT, one wait behind)": float(np.mean([c[1] for c in consumer_cpu[W:]])) * 1e3,
+                                                 "waits": os.environ.get("SURGE_INGEST_WAIT", "poll")},
                    "receive_copy_ms_per_fetch": float(np.mean(recv_ms[W:])) if len(recv_ms) > W else None,
                    "host_cpu_note": "process CPU time (every thread: framing pool, framing driver, consumer — the consumer spins in its waits for the device) over the timed fetches of "
                                     "rank 0.  In-place framing: a fetch response is RECEIVED into the framer's page-locked slab — here one memmove per partition out of the topic's "

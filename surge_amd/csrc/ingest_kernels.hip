@@ -22,6 +22,9 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
+#include <sys/prctl.h>
+#include <time.h>
+
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -1709,6 +1712,7 @@ struct surge_device_decoder {
   void* crc_slice = nullptr;     // the CRC-32C slicing tables (4 KB) on the device: made at the first push that needs them
   hipEvent_t sleeper = nullptr;  // hipEventBlockingSync: host waits of the consumer thread sleep on it instead of spinning
   bool block_waits = true;
+  int64_t poll_ns = 0;  // > 0 (SURGE_INGEST_WAIT=poll): the waits query the event between naps of this length instead
   bool consumed_valid = false;
   int64_t counters[4] = {0, 0, 0, 0};  // records seen, delivered, flush records skipped, f64 values re-parsed on the host
   int64_t chain_fallbacks = 0;         // batches whose records the one-lane walk chained after the parallel recognition declined (SURGE_EXPERIMENTS builds print it)
@@ -1827,10 +1831,19 @@ int32_t surge_device_decoder_create(int32_t device_id, void* hip_stream, const s
     DCHK(d, hipEventCreateWithFlags(&d->consumed, hipEventDisableTiming));
     // A consumer thread that waits for the device a few times per fetch spins a core away in hipStreamSynchronize (0.4 - 1.2 ms of
     // CPU per 10^6-record fetch, and — on a host whose CPUs the framing threads need — 5 - 15 % of the bytes -> states rate:
-    // profiles/r06_e2e_host_budget.jsonl).  So those waits sleep on an interrupt-driven event (a wake-up costs tens of
-    // microseconds); SURGE_INGEST_WAIT=spin keeps hipStreamSynchronize.
+    // profiles/r06_e2e_host_budget.jsonl).  The runtime's blocking wait (hipEventBlockingSync) still spins for its first few
+    // hundred microseconds — most of a wait here — before it sleeps on the interrupt.  So the waits NAP: the event is queried
+    // between nanosleeps of SURGE_INGEST_POLL_US (10) microseconds — the consumer thread's CPU 1.28 -> 0.81 ms per fetch at the
+    // same rate (profiles/r06_e2e_wait_modes.txt).  SURGE_INGEST_WAIT=block sleeps on the blocking event, =spin keeps
+    // hipStreamSynchronize.
     d->block_waits = true;
-    if (const char* v = std::getenv("SURGE_INGEST_WAIT")) d->block_waits = std::strcmp(v, "spin") != 0;
+    d->poll_ns = 10000;
+    if (const char* v = std::getenv("SURGE_INGEST_WAIT")) {
+      d->block_waits = std::strcmp(v, "spin") != 0;
+      if (std::strcmp(v, "poll") != 0) d->poll_ns = 0;
+    }
+    if (d->poll_ns > 0)
+      if (const char* u = std::getenv("SURGE_INGEST_POLL_US")) d->poll_ns = std::atoll(u) > 0 ? std::atoll(u) * 1000 : d->poll_ns;
     if (d->block_waits) DCHK(d, hipEventCreateWithFlags(&d->sleeper, hipEventDisableTiming | hipEventBlockingSync));
     DCHK(d, d->key_off.reserve(8, false, d->stream));
     DCHK(d, hipMemset(d->key_off.p, 0, 8));
@@ -2448,8 +2461,16 @@ int32_t stage1_records(surge_device_decoder* d, PushSlot& s, const uint8_t* keys
 // the consumer thread's wait for `st`: asleep on an event, not spinning (SURGE_INGEST_WAIT=spin: hipStreamSynchronize)
 hipError_t wait_stream(surge_device_decoder* d, hipStream_t st) {
   if (!d->block_waits) return hipStreamSynchronize(st);
-  const hipError_t e = hipEventRecord(d->sleeper, st);
-  return e != hipSuccess ? e : hipEventSynchronize(d->sleeper);
+  hipError_t e = hipEventRecord(d->sleeper, st);
+  if (e != hipSuccess || d->poll_ns <= 0) return e != hipSuccess ? e : hipEventSynchronize(d->sleeper);
+  // naps of poll_ns between queries; the thread's timer slack (50 us by default: it would triple a 25 us nap) is 1 us meanwhile
+  const int slack = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+  if (slack > 1000) (void)prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0);
+  const timespec nap{0, (long)d->poll_ns};
+  while ((e = hipEventQuery(d->sleeper)) == hipErrorNotReady) (void)nanosleep(&nap, nullptr);
+  (void)hipGetLastError();  // (hipErrorNotReady is remembered as the thread's last error: not one)
+  if (slack > 1000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)slack, 0, 0, 0);
+  return e;
 }
 
 int32_t stage2(surge_device_decoder* d, PushSlot& s, bool wait) {
