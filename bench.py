@@ -215,6 +215,8 @@ def main():
     ap.add_argument("--device-batches", action="store_true", help="c5: batches already in HBM (no staging / H2D)")
     ap.add_argument("--codec", default="lz4", choices=["lz4", "none"], help="e2e: compression of the record batches (the reference's producer: lz4)")
     ap.add_argument("--host-framing", action="store_true", help="c5: frame the state-topic record batches with the host writer instead of the device framer")
+    ap.add_argument("--consumer-waits", choices=("both", "finish", "none"), default="finish", help="e2e, one consumer thread: where it waits for the device — behind interning and behind the fold (both), "
+                    "behind interning only (finish: the fold is handed over by an event and runs while the next push is enqueued), or only in the middle of interning (none)")
     ap.add_argument("--two-thread-consumer", action="store_true", help="e2e: a worker thread enqueues the pushes, this one finishes them with an event-ordered hand-over to the fold and no host wait (default: one thread does both and waits for the device after each half — the device is the bound, the extra thread measured 7 %% slower)")
     ap.add_argument("--serial-framing", action="store_true", help="e2e: frame each fetch, then push it, then fold it, one after the other (default: framing one fetch ahead on its own threads, four pushes in flight)")
     ap.add_argument("--events-cap", type=int, default=8, help="e2e: every aggregate publishes the first min(count, cap) of its events (8: 6.4e7 records over the 10 M aggregates)")
@@ -586,7 +588,7 @@ def main():
             torch.cuda.empty_cache()
             keep = ("value", "unit", "steps", "warmup", "ms_per_step", "data", "config", "roofline", "cpu_baseline")
             base = {**vars(args), "workload": "e2e", "warmup": 2, "batch_events": 1_000_000, "aggregates": None, "events_cap": 8, "writer": "independent",
-                    "codec": "lz4", "serial_framing": False, "two_thread_consumer": False, "no_capacity_hint": False, "framing_threads": 2, "framing_by_copy": False,
+                    "codec": "lz4", "serial_framing": False, "two_thread_consumer": False, "no_capacity_hint": False, "framing_threads": 2, "framing_by_copy": False, "consumer_waits": "finish",
                     "abort_every": 50, "hold_markers": 4, "bound_log": False, "e2e_topic": "counter"}
             # (the primary leg runs the first <= 14 events of every aggregate: 1.05e8 records, 103 timed fetches — a region long enough that one stalled fetch does not
             # decide the figure; the comparison legs below keep the 6.5e7-record topic)
@@ -1318,7 +1320,7 @@ def run_e2e(args):
             nonlocal n_agg
             t1 = time.perf_counter()
             c1 = time.thread_time()
-            d.finish(wait=wait)
+            d.finish(wait=(wait is True or wait == "finish"))
             ta = time.perf_counter()
             ca = time.thread_time()
             n_keys = d.n_keys
@@ -1328,10 +1330,10 @@ def run_e2e(args):
             tb = time.perf_counter()
             if bound_log:
                 d.stage_into(eng)  # no fold: the topic's end packs what was staged (below)
-                if wait:
+                if wait is True:
                     eng.synchronize()
             else:
-                d.fold_into(eng, wait=wait)
+                d.fold_into(eng, wait=(wait is True))
             t2 = time.perf_counter()
             consumer_cpu.append((ca - c1, time.thread_time() - ca))
             if len(marks) == W - 1:
@@ -1345,25 +1347,30 @@ def run_e2e(args):
         if one_thread:
             # one host thread enqueues stage 1 of fetch i + depth, then finishes fetch i and folds it, waiting for the device
             # after each half (the device is the bound: profiles/r04_e2e_consumer_threads.txt)
+            import contextlib
+
+            waits = getattr(args, "consumer_waits", "both")
             pending = 0
             fetch_iter = iter(framed)
-            while True:
-                # the oldest push is finished BEFORE the next fetch is asked for: asking tells the framer that the oldest fetch's
-                # slab may be framed into again, and a push reads its bytes until it is finished
-                if pending == depth:
-                    finish_one(True)
+            with contextlib.nullcontext():  # (the engine stays on its stream: two push streams + the decoder's + this one = the runtime's four hardware queues)
+                while True:
+                    # the oldest push is finished BEFORE the next fetch is asked for: asking tells the framer that the oldest fetch's
+                    # slab may be framed into again, and a push reads its bytes until it is finished
+                    if pending == depth:
+                        finish_one(True if waits == "both" else waits)
+                        pending -= 1
+                    parts = next(fetch_iter, None)
+                    if parts is None:
+                        break
+                    tp, cp = time.perf_counter(), time.thread_time()
+                    d.push_async(parts)
+                    push_ms.append((time.perf_counter() - tp) * 1e3)
+                    push_cpu.append(time.thread_time() - cp)
+                    pending += 1
+                while pending:
+                    finish_one(True if waits == "both" else waits)
                     pending -= 1
-                parts = next(fetch_iter, None)
-                if parts is None:
-                    break
-                tp, cp = time.perf_counter(), time.thread_time()
-                d.push_async(parts)
-                push_ms.append((time.perf_counter() - tp) * 1e3)
-                push_cpu.append(time.thread_time() - cp)
-                pending += 1
-            while pending:
-                finish_one(True)
-                pending -= 1
+                eng.synchronize()
         else:
             # three host threads: the framer's driver, the pipeline's worker (stage 1 of up to `depth` fetches ahead: section
             # tables, staging, launches) and this one (stage 2 + fold of the oldest push, no host wait behind either: the
@@ -1537,7 +1544,9 @@ def run_e2e(args):
                    "writer": args.writer, "txn_flush_events": K_flush, "topic": topic_counts,
                    "control_batches": None if topic_counts is None else topic_counts["control_batches"],
                    "aggregates": A, "events_cap": cap, "partitions": P, "fetch_records": n_fetch, "fetches": len(fetches), "pushes_in_flight": depth,
-                   "consumer": "one thread, a host wait behind interning and behind the fold" if one_thread else "push worker thread + finisher, event-ordered hand-over to the fold (no host wait behind either)",
+                   "consumer": ("one thread, a host wait behind interning and behind the fold" if getattr(args, "consumer_waits", "both") == "both" else
+                                "one thread, a host wait behind interning; the fold handed over by an event" if getattr(args, "consumer_waits", "both") == "finish" else
+                                "one thread, no host wait behind interning or the fold (event-ordered hand-over)") if one_thread else "push worker thread + finisher, event-ordered hand-over to the fold (no host wait behind either)",
                    "bound_log": packed,
                    "host_cpu_ms_per_1e6_records": cpu_s * 1e3 / max(1, n_events_timed) * 1e6,
                    "host_cpu_ms_per_1e6_records_without_the_receive_copy": (cpu_s - recv_cpu_s) * 1e3 / max(1, n_events_timed) * 1e6,

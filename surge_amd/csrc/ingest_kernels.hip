@@ -1814,8 +1814,12 @@ int32_t surge_device_decoder_create(int32_t device_id, void* hip_stream, const s
   auto init = [&]() -> int32_t {
     DCHK(d, hipSetDevice(device_id));
     {
-      int n = 3;
-      if (const char* v = std::getenv("SURGE_INGEST_PUSH_STREAMS")) n = std::atoi(v);  // experiments: 5 = a stream per slot (round 4)
+      // Two stage-1 streams: with the decoder's own stream and the engine's that makes four — the hardware queues the runtime
+      // maps streams onto (GPU_MAX_HW_QUEUES).  A fifth stream shares a queue with another one, and a queue runs in order:
+      // with three push streams every third push's interning sat behind a later push's whole stage 1 (2 ms instead of 0.4:
+      // profiles/r06_e2e_consumer_waits_trace.txt).
+      int n = 2;
+      if (const char* v = std::getenv("SURGE_INGEST_PUSH_STREAMS")) n = std::atoi(v);  // experiments: 5 = a stream per slot (round 4), 3 = rounds 5 / 6
       n = n < 1 ? 1 : (n > kSlots ? kSlots : n);
       for (int i = 0; i < n; ++i) {
         DCHK(d, hipStreamCreateWithFlags(&d->push_streams[i], hipStreamNonBlocking));

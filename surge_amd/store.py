@@ -133,10 +133,11 @@ class GpuReplayStateStore:
         whose events are grouped and folded onto the resident state (the K3 path), so neither side waits for the other;
         the resident state and the device key table grow as new aggregates appear.  What
         ``SurgeStateStoreConsumer.scala:33-46,57-76`` does record by record through Kafka Streams' restore.
-        ``consumer_threads=2`` moves the host work of enqueueing a push (section tables, staging, launches: about a
-        millisecond per 10^6-record fetch) to a worker thread and hands the results to the fold without a host wait
-        (``PushPipeline``, ``surge_replay_append_decoded_async``); measured on the 10^7-aggregate topic it is not faster —
-        the device is the bound there, not this thread — so one thread is the default.
+        One consumer thread enqueues a push, waits for the interning of the oldest one and hands its events to the fold by an
+        event (``surge_replay_append_decoded_async``): no host wait behind the fold.  ``consumer_threads=2`` moves the host
+        work of enqueueing a push (section tables, staging, launches: 0.3 ms per 10^6-record fetch) to a worker thread
+        (``PushPipeline``) and drops the wait behind the interning too; measured on the 10^7-aggregate topic it is not
+        faster, so one thread is the default.
         ``bound_log=True``: a recovery that folds ONCE — every fetch's decoded events are staged on the device instead of
         folded (``surge_replay_stage_decoded``), the topic's end packs them into one CSR log (``surge_replay_pack_staged``:
         stable device sort by aggregate, topic order kept inside an aggregate) and ONE fold with ``algo`` (AUTO: the
@@ -186,10 +187,12 @@ class GpuReplayStateStore:
                 n_agg = capacity
                 self.engine.load_csr(np.zeros(n_agg + 1, dtype=np.int64), np.zeros(0, dtype=EVENT_DTYPE))
                 self.engine.fold()  # every aggregate None
-            # two threads: no host wait behind the interning or the fold — the decoder's stream and the engine's are ordered by
-            # events, so the next fetch's interning runs beside this one's group-by and fold
+            # No host wait behind the fold: the decoder's stream and the engine's are ordered by events, so the next push is
+            # enqueued — and, with two threads (no wait behind the interning either), the next fetch interned — beside this
+            # one's group-by and fold (one thread: 7.7 -> 8.7e8 events/s, profiles/r06_e2e_consumer_waits_queues2.txt).  What a
+            # fold has to report (a bad index, a poisoned state) it reports at the synchronisation that ends the restore.
             d.finish(wait=not two_threads)
-            _, n_keys = d.fold_into(self.engine, wait=not two_threads)  # grows the resident state for new ids, group-by + fold (K3), clears
+            _, n_keys = d.fold_into(self.engine, wait=False)  # grows the resident state for new ids, group-by + fold (K3), clears
             if n_keys > n_agg:
                 self.engine.n_agg = n_agg = n_keys  # (grown inside the call)
 
