@@ -1347,12 +1347,10 @@ def run_e2e(args):
         if one_thread:
             # one host thread enqueues stage 1 of fetch i + depth, then finishes fetch i and folds it, waiting for the device
             # after each half (the device is the bound: profiles/r04_e2e_consumer_threads.txt)
-            import contextlib
-
             waits = getattr(args, "consumer_waits", "both")
             pending = 0
             fetch_iter = iter(framed)
-            with contextlib.nullcontext():  # (the engine stays on its stream: two push streams + the decoder's + this one = the runtime's four hardware queues)
+            if True:  # (the engine stays on its stream: two push streams + the decoder's + this one = the runtime's four hardware queues)
                 while True:
                     # the oldest push is finished BEFORE the next fetch is asked for: asking tells the framer that the oldest fetch's
                     # slab may be framed into again, and a push reads its bytes until it is finished

@@ -1,0 +1,18 @@
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+run() { # label, args..., env via leading VAR=
+label=$1; shift
+env "$@" > gpurun_out/x.json 2> gpurun_out/x.err || tail -3 gpurun_out/x.err
+python - "$label" <<'PY'
+import json,sys
+d=json.loads(open('gpurun_out/x.json').read().strip().splitlines()[-1]); c=d['config']
+print(sys.argv[1], 'value %.3e'%d['value'], 'cpu', round(c['host_cpu_ms_per_1e6_records'],2), 'by thread', c['host_cpu_ms_per_1e6_records_by_thread'], 'fetch_ms', {k:round(v,2) for k,v in c['fetch_ms'].items()}, 'finish+fold wall', round(c['finish_and_fold_ms_per_fetch'],2), 'push wall', round(c['push_async_host_ms_per_fetch'],2))
+PY
+}
+B="timeout 600 python bench.py --workload e2e --steps 60 --warmup 2 --framing-threads 2 --parity none"
+for rep in 1 2; do
+run "one thread (default)      " X=1 $B
+run "two threads, own stream   " X=1 $B --two-thread-consumer
+run "two threads, null stream  " SURGE_BENCH_OWN_STREAM=0 $B --two-thread-consumer
+run "two threads, null, 3 frm  " SURGE_BENCH_OWN_STREAM=0 $B --two-thread-consumer --framing-threads 3
+done 2>&1 | tee gpurun_out/r06_e2e_two_thread.txt
