@@ -1693,6 +1693,8 @@ struct surge_device_decoder {
   // (profiles/r05_e2e_k512_per_fetch_trace.txt: finish 1.1 - 1.5 ms instead of 0.4 on fetches 8, 13, 18, 23, 28).
   hipStream_t push_streams[kSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int n_push_streams = 0;
+  int n_push_active = 0;       // of them in rotation (<= n_push_streams): one fewer once a consumer folds on a stream of its own (hardware queues, below)
+  bool push_streams_pinned = false;  // SURGE_INGEST_PUSH_STREAMS said how many: never adjusted
   uint64_t push_seq = 0;
   int head = 0;
   std::atomic<int> n_pending{0};  // slots [head, head + n_pending) hold pushes whose stage 1 is enqueued (changes under `mu`)
@@ -1814,16 +1816,31 @@ int32_t surge_device_decoder_create(int32_t device_id, void* hip_stream, const s
   auto init = [&]() -> int32_t {
     DCHK(d, hipSetDevice(device_id));
     {
-      // Two stage-1 streams: with the decoder's own stream and the engine's that makes four — the hardware queues the runtime
+      // Stage 1 rotates over THREE streams — with the decoder's own stream that makes four, the hardware queues the runtime
       // maps streams onto (GPU_MAX_HW_QUEUES).  A fifth stream shares a queue with another one, and a queue runs in order:
-      // with three push streams every third push's interning sat behind a later push's whole stage 1 (2 ms instead of 0.4:
-      // profiles/r06_e2e_consumer_waits_trace.txt).
-      int n = 2;
-      if (const char* v = std::getenv("SURGE_INGEST_PUSH_STREAMS")) n = std::atoi(v);  // experiments: 5 = a stream per slot (round 4), 3 = rounds 5 / 6
+      // with the fold on a stream of its own every third push's interning sat behind a later push's whole stage 1 (2 ms
+      // instead of 0.4: profiles/r06_e2e_consumer_waits_trace.txt).  So the hand-over calls (surge_replay_append_decoded_async,
+      // surge_replay_stage_decoded) take one stream out of the rotation when the handle folds on another stream than the
+      // decoder's.  Measured, fold on the decoder's stream: 3 streams 9.1 - 9.2e8, 2 streams 8.6 - 8.7e8 events/s
+      // (profiles/r06_e2e_push_streams.txt); fold on its own stream: 3 streams 6.9 - 7.3e8, 2 streams 8.3 - 8.7e8.
+      int n = 3;
+      if (const char* v = std::getenv("SURGE_INGEST_PUSH_STREAMS")) {  // experiments: 5 = a stream per slot (round 4)
+        n = std::atoi(v);
+        d->push_streams_pinned = true;
+      }
       n = n < 1 ? 1 : (n > kSlots ? kSlots : n);
       for (int i = 0; i < n; ++i) {
-        DCHK(d, hipStreamCreateWithFlags(&d->push_streams[i], hipStreamNonBlocking));
-        d->n_push_streams = i + 1;
+        // ... and at LOW priority: the runtime keeps a pool of hardware queues per priority, so the stage-1 streams cannot land on
+        // the queue of the decoder's own stream or of the fold's whatever other streams the process has created (in bench.py's
+        // default line, behind the legs that ran before it, one of three normal-priority push streams did: 7.4 instead of 9.1e8);
+        // and stage 1 is the bulk work — interning and fold, the dependent chain, should win a tie (SURGE_INGEST_PUSH_PRIORITY=normal)
+        int least = 0, greatest = 0;
+        static const bool normal_prio = [] { const char* v = std::getenv("SURGE_INGEST_PUSH_PRIORITY"); return v && std::strcmp(v, "normal") == 0; }();
+        if (!normal_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+          DCHK(d, hipStreamCreateWithPriority(&d->push_streams[i], hipStreamNonBlocking, least));
+        else
+          DCHK(d, hipStreamCreateWithFlags(&d->push_streams[i], hipStreamNonBlocking));
+        d->n_push_streams = d->n_push_active = i + 1;
       }
     }
     for (PushSlot& s : d->slots) {
@@ -1960,7 +1977,7 @@ PushSlot* claim_slot(surge_device_decoder* d, int32_t* rc) {
   {
     std::lock_guard<std::mutex> lk(d->mu);
     if (d->n_pending < kSlots) s = &d->slots[(d->head + d->n_pending) % kSlots];  // (a finish on the other thread moves head and n_pending together: the same slot)
-    if (s) s->stream = d->push_streams[d->push_seq++ % (uint64_t)d->n_push_streams];
+    if (s) s->stream = d->push_streams[d->push_seq++ % (uint64_t)d->n_push_active];
   }
   if (!s) *rc = dfail(d, SURGE_E_STATE, "every push slot holds an unfinished push: call surge_device_decoder_push_finish first");
   return s;
@@ -2462,6 +2479,13 @@ int32_t stage1_records(surge_device_decoder* d, PushSlot& s, const uint8_t* keys
 // first: a push that fails takes the keys it probed out of the table again (rollback_kernel), so a failed push leaves
 // the decoder exactly as it was.  wait = false leaves the second synchronisation out: the results are complete in the
 // order of the decoder's stream (surge_device_decoder_push_finish_async).
+// a consumer that folds on another stream than the decoder's adds a stream: stage 1 then rotates over one fewer (surge_device_decoder_create)
+void fold_stream_seen(surge_device_decoder* d, hipStream_t fold_stream) {
+  if (d->push_streams_pinned || fold_stream == d->stream) return;
+  std::lock_guard<std::mutex> lk(d->mu);
+  if (d->n_push_active == d->n_push_streams && d->n_push_active > 2) d->n_push_active = d->n_push_streams - 1;
+}
+
 // the consumer thread's wait for `st`: asleep on an event, not spinning (SURGE_INGEST_WAIT=spin: hipStreamSynchronize)
 hipError_t wait_stream(surge_device_decoder* d, hipStream_t st) {
   if (!d->block_waits) return hipStreamSynchronize(st);
@@ -2837,6 +2861,7 @@ int32_t surge_replay_append_decoded_async(surge_replay_handle* h, surge_device_d
     rc = surge_replay_get_stream(h, &hs);
     if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
     DeviceScope scope(d->device);
+    fold_stream_seen(d, (hipStream_t)hs);
     DCHK(d, hipEventRecord(d->ready, d->stream));
     DCHK(d, hipStreamWaitEvent((hipStream_t)hs, d->ready, 0));
     rc = surge_replay_append_events_device(h, (const int64_t*)d->r_agg.p, d->r_ev.p, d->n_records);
@@ -2862,6 +2887,7 @@ int32_t surge_replay_stage_decoded(surge_replay_handle* h, surge_device_decoder*
     int32_t rc = surge_replay_get_stream(h, &hs);
     if (rc != OK) return dfail(d, rc, surge_replay_last_error(h));
     DeviceScope scope(d->device);
+    fold_stream_seen(d, (hipStream_t)hs);
     DCHK(d, hipEventRecord(d->ready, d->stream));
     DCHK(d, hipStreamWaitEvent((hipStream_t)hs, d->ready, 0));
     rc = surge_replay_stage_events_device(h, (const int64_t*)d->r_agg.p, d->r_ev.p, d->n_records);
