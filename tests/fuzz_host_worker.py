@@ -57,6 +57,12 @@ lib.surge_event_json_decode.argtypes = [vp, ctypes.c_char_p, i64, vp]
 lib.surge_parse_f64_json.argtypes = [ctypes.c_char_p, i64, ctypes.POINTER(ctypes.c_uint64)]
 lib.surge_format_f64_json.argtypes = [ctypes.c_uint64, ctypes.c_char_p, ctypes.c_int32]
 lib.surge_ingest_drain_sections.argtypes = [vp, i64, vp, ctypes.POINTER(i64)]
+lib.surge_ingest_group_create.argtypes = [i32, i32, ctypes.POINTER(vp)]
+lib.surge_ingest_group_destroy.argtypes = [vp]
+lib.surge_ingest_group_queued_sections.argtypes = [vp]
+lib.surge_ingest_group_queued_sections.restype = i64
+lib.surge_ingest_group_receive_copy.argtypes = [vp, vp, vp, i32, vp]
+lib.surge_ingest_group_feed.argtypes = [vp, vp, vp, i32, vp, i64, vp, ctypes.POINTER(i64), ctypes.POINTER(vp)]
 
 
 def valid_wire():
@@ -222,4 +228,44 @@ while time.time() < t_end:
                 addr = ctypes.addressof(lib.surge_ingest_arena(hf).contents) + byte_off
                 held.append((addr, ctypes.string_at(addr, byte_len)))  # readable end to end (ASan checks)
     lib.surge_ingest_destroy(hf)
+    # The partition group (surge_ingest_group_feed): a framing thread walks the batch LENGTHS of eight partitions side by
+    # side before it frames them (round 6) — lengths read out of whatever the responses hold.  9 .. 17 partitions of valid,
+    # mutated, truncated and empty responses, each in a buffer of exactly its size (a read past its end is an ASan report),
+    # framed by copy and in place (received into the group's slab first); every section a successful feed hands out lies
+    # inside the slab.
+    P = rng.randrange(9, 18)
+    dev_lz4 = rng.random() < 0.7
+    flags = rng.randrange(2) | (0x200 if dev_lz4 else 0) | (0x400 if dev_lz4 and rng.random() < 0.6 else 0)  # isolation | SURGE_INGEST_DEVICE_LZ4 | _DEVICE_CRC
+    grp = vp()
+    assert lib.surge_ingest_group_create(P, flags, ctypes.byref(grp)) == 0
+    for fetch in range(rng.randrange(1, 4)):
+        bufs = []
+        for q in range(P):
+            w = valid_wire()
+            r = rng.random()
+            w = b"" if r < 0.1 else w[: rng.randrange(0, 80)] if r < 0.25 else fix_crc(mutate(w)) if r < 0.5 else mutate(w) if r < 0.6 else w
+            bufs.append(ctypes.create_string_buffer(w, len(w)) if w else None)
+        lens = (i64 * P)(*[len(b) if b is not None else 0 for b in bufs])
+        src = (vp * P)(*[ctypes.addressof(b) if b is not None else None for b in bufs])
+        data = src
+        if dev_lz4 and rng.random() < 0.7:  # in place
+            placed = (vp * P)()
+            if lib.surge_ingest_group_receive_copy(grp, src, lens, rng.randrange(1, 4), placed) != 0:
+                break
+            data = placed
+        cap = sum(lens) // 61 + int(lib.surge_ingest_group_queued_sections(grp)) + 16
+        secs = (i64 * (4 * cap))()
+        n_sec, slab = i64(), vp()
+        consumed = (i64 * P)()
+        rc = lib.surge_ingest_group_feed(grp, data, lens, rng.randrange(1, 4), consumed, cap, secs, ctypes.byref(n_sec), ctypes.byref(slab))
+        if rc != 0:
+            continue  # undone: the group is what it was
+        for q in range(P):
+            assert 0 <= consumed[q] <= lens[q]
+        for k in range(n_sec.value):
+            byte_off, byte_len = secs[4 * k], secs[4 * k + 1]
+            assert byte_off >= 0 and byte_len >= 0
+            if byte_len:
+                _ = ctypes.string_at((slab.value or 0) + byte_off, byte_len)  # readable end to end (ASan checks)
+    lib.surge_ingest_group_destroy(grp)
 print(f"OK {rounds} rounds")

@@ -796,3 +796,79 @@ def test_kafka_clients_pin_of_the_wire_format():
             g.feed(bytes.fromhex(wire_hex))
             got = [(k, v) for _, _, k, v in g.drain_records() if not (k == b"" and v == b"")]
         assert got == want, name
+
+
+def test_the_framers_side_by_side_header_walk_takes_any_bytes_and_changes_nothing():
+    """Round 6: a framing thread takes the partitions eight at a time and walks their batch lengths side by side first
+    (prefetching every next header) before it frames them one by one.  The walk reads lengths out of whatever a fetch
+    response holds: 19 partitions (two full rounds of eight and three), responses cut in the middle of a header, in the
+    middle of a length word and after a handful of bytes, an empty one, and — last — a length word no batch can have in
+    one partition.  What every partition delivers is what its own framer delivers; the bad length fails the feed with
+    its framer's error and nothing of that fetch is delivered (all-or-nothing), whichever way the bytes are framed."""
+    from surge_amd.ingest import IngestError, PartitionedFramedFetches
+
+    ev = lambda seq: counter_event(S.EVT_INC, seq, seq)
+    rnd = random.Random(19)
+    P, F = 19, 4
+    logs = []
+    for p in range(P):
+        off, chunks = 0, []
+        for f in range(F):
+            parts = []
+            for b in range(rnd.randrange(1, 6)):
+                n = rnd.randrange(1, 40)
+                parts.append(kw.record_batch(off, [(b"p%dk%d:%d" % (p, rnd.randrange(9), i), ev(off + i + 1)) for i in range(n)], compression=rnd.choice(["none", "lz4"])))
+                off += n
+            chunks.append(b"".join(parts))
+        logs.append(chunks)
+    # responses that end inside a batch: after 3 bytes, inside the length word (10 bytes), inside the header (30), one byte short
+    for p, keep in ((1, 3), (4, 10), (9, 30), (12, None), (17, 61)):
+        whole = logs[p][1]
+        cut = len(whole) - 1 if keep is None else len(whole) - len(kw.record_batch(0, [(b"x:1", ev(1))])) // 2 if keep == 61 else keep
+        logs[p][1], logs[p][2] = whole[:cut], whole[cut:] + logs[p][2]
+    logs[6][2] = b""  # a partition with nothing in a fetch
+    fetches = [[logs[p][f] or None for p in range(P)] for f in range(F)]
+
+    def own_framers(rows):
+        out, singles = [], [EventsTopicIngest(frames=True, device_lz4=True) for _ in range(P)]
+        try:
+            for row in rows:
+                got = []
+                for p in range(P):
+                    if row[p]:
+                        singles[p].feed(row[p])
+                    sec, arena = singles[p].drain_sections()
+                    got += [(int(s["base_offset"]), int(s["n_records"]), int(s["codec"]) & 0xFF, b) for s, b in zip(sec, _section_bytes(sec, arena))]
+                out.append(got)
+        finally:
+            for g in singles:
+                g.close()
+        return out
+
+    want = own_framers(fetches)
+    assert sum(len(w) for w in want) > 100
+    for in_place in (False, True):
+        for threads in (1, 3):
+            got = []
+            with PartitionedFramedFetches(iter(fetches), P, threads=threads, hold=2, overlap=False, device_crc=in_place, in_place=in_place) as framed:
+                for sec, slab in framed:
+                    got.append([(int(s["base_offset"]), int(s["n_records"]), int(s["codec"]) & 0xFF, b) for s, b in zip(sec, _section_bytes(sec, slab))])
+            assert got == want, (in_place, threads)
+    # a batchLength below the 49 bytes a v2 batch has behind the length word, in partition 11 of a fifth fetch
+    bad = bytearray(kw.record_batch(10_000, [(b"z:1", ev(1))]))
+    bad[8:12] = (17).to_bytes(4, "big")
+    last = [kw.record_batch(20_000 + p, [(b"q%d:1" % p, ev(2))]) for p in range(P)]
+    last[11] = bytes(bad)
+    single = EventsTopicIngest(frames=True, device_lz4=True)
+    try:
+        with pytest.raises(IngestError) as own:
+            single.feed(bytes(bad))
+    finally:
+        single.close()
+    for in_place in (False, True):
+        got = []
+        with pytest.raises(IngestError) as grp:
+            with PartitionedFramedFetches(iter(fetches + [last]), P, threads=3, hold=2, overlap=False, device_crc=in_place, in_place=in_place) as framed:
+                for sec, slab in framed:
+                    got.append([(int(s["base_offset"]), int(s["n_records"]), int(s["codec"]) & 0xFF, b) for s, b in zip(sec, _section_bytes(sec, slab))])
+        assert got == want and grp.value.status == own.value.status == -7, (in_place, str(grp.value))
