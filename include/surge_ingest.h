@@ -242,8 +242,13 @@ int32_t surge_device_decoder_push(surge_device_decoder* d, const uint8_t* bytes,
  * push, appends its records to the result and returns what surge_device_decoder_push would have returned.  Up to five
  * pushes may be unfinished at a time (SURGE_E_STATE beyond that, and from push / push_records while any is), so the
  * copy engine, the latency-bound LZ4 kernels and the compute-bound decode of consecutive fetches overlap on the chip:
- *     push_async(fetch 0); push_async(fetch 1);
- *     loop i: push_async(fetch i + 2); push_finish() -> fold the result of fetch i; clear
+ *     push_async(fetch 0) ... push_async(fetch 3);
+ *     loop i: push_finish() -> surge_replay_append_decoded_async (fold of fetch i, no host wait); push_async(fetch i + 4)
+ * (what surge_amd/store.py and bench.py --workload e2e do; 8.9 - 9.2e8 events/s on a 10^7-aggregate topic).
+ * Stage 1 rotates over three LOW-priority streams: the runtime maps streams onto four hardware queues per priority, a queue
+ * runs in order, and a stage-1 stream that shares the queue of the decoder's own stream puts a push's interning behind a
+ * later push's whole stage 1 — low-priority streams come out of another pool of queues than the decoder's stream and the
+ * fold's (SURGE_INGEST_PUSH_PRIORITY, SURGE_INGEST_PUSH_STREAMS: INTEGRATION.md).
  * `bytes` and `sections` must stay valid until the matching push_finish.  push_parts_async takes the sections of
  * several arenas — e.g. one per partition of a fetch response, framed on as many host threads — as ONE push: part p's
  * sections index bytes[p]; records are delivered part after part.  A push_async that fails occupies no slot. */
@@ -279,7 +284,9 @@ int32_t surge_replay_append_decoded(struct surge_replay_handle* h, surge_device_
 /* The same without a host wait: the handle's stream waits (event) for the decoder's, group-by + fold are enqueued, the
  * decoder is cleared; the next push_finish* waits (event, on the device) for the group-by's last read of the result
  * arrays before it writes them again.  With the handle on a stream of its own (surge_replay_set_stream, non-blocking),
- * interning of fetch i + 1 overlaps the fold of fetch i.  Errors of the fold surface at the next
+ * interning of fetch i + 1 overlaps the fold of fetch i — and the decoder then rotates its stage 1 over two streams instead
+ * of three (the handle's stream is one more for the four hardware queues); on the decoder's stream (the default of both) the
+ * host thread simply does not wait for the fold, which measured the same or better.  Errors of the fold surface at the next
  * surge_replay_synchronize. */
 int32_t surge_replay_append_decoded_async(struct surge_replay_handle* h, surge_device_decoder* d, int64_t* n_events_out, int64_t* n_keys_out);
 /* For a recovery that ends with ONE fold of the whole topic (surge_replay_pack_staged in surge_replay.h): instead of

@@ -585,8 +585,10 @@ class DeviceDecoder:
     def fold_into(self, engine, wait: bool = True):
         """Everything decoded since the last clear, folded onto ``engine``'s resident state (grown first for ids seen for the
         first time), and cleared: ``surge_replay_append_decoded``; with ``wait=False`` its ``_async`` form — no host wait,
-        the two streams are ordered by events, so with the engine on a stream of its own the interning of the next fetch
-        overlaps this fold.  Returns ``(n_events, n_keys)``."""
+        the two streams are ordered by events, so the host goes on to enqueue the next push while this fold runs (and with
+        the engine on a stream of its own the interning of the next fetch overlaps it on the device too: the decoder then
+        rotates stage 1 over two streams instead of three — hardware queues, ``include/surge_ingest.h``).  What the fold
+        has to report it reports at the engine's next ``synchronize``.  Returns ``(n_events, n_keys)``."""
         n_ev, n_keys = ctypes.c_int64(), ctypes.c_int64()
         fn = self._lib.surge_replay_append_decoded if wait else self._lib.surge_replay_append_decoded_async
         self._check(fn(engine._h, self._h, ctypes.byref(n_ev), ctypes.byref(n_keys)))
