@@ -2473,12 +2473,6 @@ int32_t stage1_records(surge_device_decoder* d, PushSlot& s, const uint8_t* keys
   return OK;
 }
 
-// Stage 2: everything behind the per-record metadata and decoded values — interning, compaction, append — on the
-// decoder's stream.  Two synchronisations: one in the middle (what the push discovered: errors, new keys, their bytes,
-// delivered records — everything the allocations behind it need), one at the end.  Nothing is committed before the
-// first: a push that fails takes the keys it probed out of the table again (rollback_kernel), so a failed push leaves
-// the decoder exactly as it was.  wait = false leaves the second synchronisation out: the results are complete in the
-// order of the decoder's stream (surge_device_decoder_push_finish_async).
 // a consumer that folds on another stream than the decoder's adds a stream: stage 1 then rotates over one fewer (surge_device_decoder_create)
 void fold_stream_seen(surge_device_decoder* d, hipStream_t fold_stream) {
   if (d->push_streams_pinned || fold_stream == d->stream) return;
@@ -2486,7 +2480,8 @@ void fold_stream_seen(surge_device_decoder* d, hipStream_t fold_stream) {
   if (d->n_push_active == d->n_push_streams && d->n_push_active > 2) d->n_push_active = d->n_push_streams - 1;
 }
 
-// the consumer thread's wait for `st`: asleep on an event, not spinning (SURGE_INGEST_WAIT=spin: hipStreamSynchronize)
+// the consumer thread's wait for `st`: naps between event queries (surge_device_decoder_create; SURGE_INGEST_WAIT=block: asleep on
+// the blocking event, =spin: hipStreamSynchronize)
 hipError_t wait_stream(surge_device_decoder* d, hipStream_t st) {
   if (!d->block_waits) return hipStreamSynchronize(st);
   hipError_t e = hipEventRecord(d->sleeper, st);
@@ -2501,6 +2496,12 @@ hipError_t wait_stream(surge_device_decoder* d, hipStream_t st) {
   return e;
 }
 
+// Stage 2: everything behind the per-record metadata and decoded values — interning, compaction, append — on the
+// decoder's stream.  Two synchronisations: one in the middle (what the push discovered: errors, new keys, their bytes,
+// delivered records — everything the allocations behind it need), one at the end.  Nothing is committed before the
+// first: a push that fails takes the keys it probed out of the table again (rollback_kernel), so a failed push leaves
+// the decoder exactly as it was.  wait = false leaves the second synchronisation out: the results are complete in the
+// order of the decoder's stream (surge_device_decoder_push_finish_async).
 int32_t stage2(surge_device_decoder* d, PushSlot& s, bool wait) {
   const int64_t n_rec = s.n_rec;
   if (n_rec == 0) return OK;
