@@ -1822,7 +1822,8 @@ int32_t surge_device_decoder_create(int32_t device_id, void* hip_stream, const s
       // instead of 0.4: profiles/r06_e2e_consumer_waits_trace.txt).  So the hand-over calls (surge_replay_append_decoded_async,
       // surge_replay_stage_decoded) take one stream out of the rotation when the handle folds on another stream than the
       // decoder's.  Measured, fold on the decoder's stream: 3 streams 9.1 - 9.2e8, 2 streams 8.6 - 8.7e8 events/s
-      // (profiles/r06_e2e_push_streams.txt); fold on its own stream: 3 streams 6.9 - 7.3e8, 2 streams 8.3 - 8.7e8.
+      // (profiles/r06_e2e_push_streams.txt); fold on its own stream: 3 streams 6.9 - 7.3e8, 2 streams 8.3 - 8.7e8.  A fourth
+      // (low-priority) push stream: 6.8 - 7.0e8 with the 2.5 ms stalls back (profiles/r06_e2e_push_priority.txt).
       int n = 3;
       if (const char* v = std::getenv("SURGE_INGEST_PUSH_STREAMS")) {  // experiments: 5 = a stream per slot (round 4)
         n = std::atoi(v);
