@@ -1345,30 +1345,31 @@ def run_e2e(args):
             keys_at.append(n_keys)
 
         if one_thread:
-            # one host thread enqueues stage 1 of fetch i + depth, then finishes fetch i and folds it, waiting for the device
-            # after each half (the device is the bound: profiles/r04_e2e_consumer_threads.txt)
+            # one host thread enqueues stage 1 of fetch i + depth, then finishes fetch i and folds it
             waits = getattr(args, "consumer_waits", "both")
             pending = 0
             fetch_iter = iter(framed)
-            if True:  # (the engine stays on its stream: two push streams + the decoder's + this one = the runtime's four hardware queues)
-                while True:
-                    # the oldest push is finished BEFORE the next fetch is asked for: asking tells the framer that the oldest fetch's
-                    # slab may be framed into again, and a push reads its bytes until it is finished
-                    if pending == depth:
-                        finish_one(True if waits == "both" else waits)
-                        pending -= 1
-                    parts = next(fetch_iter, None)
-                    if parts is None:
-                        break
-                    tp, cp = time.perf_counter(), time.thread_time()
-                    d.push_async(parts)
-                    push_ms.append((time.perf_counter() - tp) * 1e3)
-                    push_cpu.append(time.thread_time() - cp)
-                    pending += 1
-                while pending:
+            # (the engine stays on the decoder's stream: with the three low-priority push streams that is the arrangement of DESIGN section 7;
+            # --consumer-waits: both = a host wait behind interning and behind the fold, finish = behind interning only — the fold is handed
+            # over by an event —, none = only the wait in the middle of interning)
+            while True:
+                # the oldest push is finished BEFORE the next fetch is asked for: asking tells the framer that the oldest fetch's
+                # slab may be framed into again, and a push reads its bytes until it is finished
+                if pending == depth:
                     finish_one(True if waits == "both" else waits)
                     pending -= 1
-                eng.synchronize()
+                parts = next(fetch_iter, None)
+                if parts is None:
+                    break
+                tp, cp = time.perf_counter(), time.thread_time()
+                d.push_async(parts)
+                push_ms.append((time.perf_counter() - tp) * 1e3)
+                push_cpu.append(time.thread_time() - cp)
+                pending += 1
+            while pending:
+                finish_one(True if waits == "both" else waits)
+                pending -= 1
+            eng.synchronize()
         else:
             # three host threads: the framer's driver, the pipeline's worker (stage 1 of up to `depth` fetches ahead: section
             # tables, staging, launches) and this one (stage 2 + fold of the oldest push, no host wait behind either: the
