@@ -217,7 +217,7 @@ def main():
     ap.add_argument("--host-framing", action="store_true", help="c5: frame the state-topic record batches with the host writer instead of the device framer")
     ap.add_argument("--consumer-waits", choices=("both", "finish", "none"), default="finish", help="e2e, one consumer thread: where it waits for the device — behind interning and behind the fold (both), "
                     "behind interning only (finish: the fold is handed over by an event and runs while the next push is enqueued), or only in the middle of interning (none)")
-    ap.add_argument("--two-thread-consumer", action="store_true", help="e2e: a worker thread enqueues the pushes, this one finishes them with an event-ordered hand-over to the fold and no host wait (default: one thread does both and waits for the device after each half — the device is the bound, the extra thread measured 7 %% slower)")
+    ap.add_argument("--two-thread-consumer", action="store_true", help="e2e: a worker thread enqueues the pushes, this one finishes them with an event-ordered hand-over to the fold and no host wait (default: one thread does both, with the host waits --consumer-waits names — the device is the bound, the extra thread measured no faster at 1 ms more CPU per fetch)")
     ap.add_argument("--serial-framing", action="store_true", help="e2e: frame each fetch, then push it, then fold it, one after the other (default: framing one fetch ahead on its own threads, four pushes in flight)")
     ap.add_argument("--events-cap", type=int, default=8, help="e2e: every aggregate publishes the first min(count, cap) of its events (8: 6.4e7 records over the 10 M aggregates)")
     ap.add_argument("--e2e-topic", default="counter", choices=["counter", "mixed"],
